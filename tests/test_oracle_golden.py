@@ -1,0 +1,181 @@
+"""Pins oracle/pylamp_oracle.py to fixtures produced by the reference itself (CPU only)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import golden, relerr, maxrel
+
+STOKES_CASES = ["a", "b", "c", "d", "e"]
+
+
+def _csr(g, n):
+    return sp.csr_matrix((g["data"], g["indices"], g["indptr"]), shape=(n, n))
+
+
+@pytest.mark.parametrize("tag", STOKES_CASES)
+def test_stokes_csr_matches_reference(oracle, tag):
+    g = golden("stokes_op_" + tag)
+    nx = [int(v) for v in g["nx"]]
+    A, rhs = oracle.stokes_csr(nx, [g["gz"], g["gx"]], g["etas"], g["etan"], g["rho"], list(g["bc"]))
+    R = _csr(g, A.shape[0])
+    D = (A - R).tocoo()
+    scale = np.abs(R).max()
+    assert (np.abs(D.data).max() if D.nnz else 0.0) <= 1e-14 * scale
+    # structure: same number of stored non-zeros row by row (every row defined once)
+    A.eliminate_zeros(); R.eliminate_zeros()
+    assert np.array_equal(np.diff(A.indptr), np.diff(R.indptr))
+    assert np.allclose(rhs, g["rhs"], rtol=1e-15, atol=0)
+
+
+@pytest.mark.parametrize("tag", STOKES_CASES)
+def test_stokes_matrix_free_apply(oracle, tag):
+    g = golden("stokes_op_" + tag)
+    nx = [int(v) for v in g["nx"]]
+    for x, y in zip(g["xs"], g["ys"]):
+        ya = oracle.stokes_apply(nx, [g["gz"], g["gx"]], g["etas"], g["etan"], list(g["bc"]), x)
+        # compare per row relative to the row's magnitude scale |A||x|
+        assert relerr(ya, y) < 1e-13
+    assert np.allclose(oracle.stokes_rhs(nx, g["rho"]), g["rhs"], rtol=1e-15, atol=0)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_stokes_surfstab(oracle, tag):
+    g = golden("stokes_surfstab_" + tag)
+    nx = [int(v) for v in g["nx"]]
+    kw = dict(surfstab=True, tstep=float(g["tstep"]), theta=float(g["theta"]))
+    A, rhs = oracle.stokes_csr(nx, [g["gz"], g["gx"]], g["etas"], g["etan"], g["rho"], list(g["bc"]), **kw)
+    R = _csr(g, A.shape[0])
+    D = (A - R).tocoo()
+    assert (np.abs(D.data).max() if D.nnz else 0.0) <= 1e-14 * np.abs(R).max()
+    for x, y in zip(g["xs"], g["ys"]):
+        ya = oracle.stokes_apply(nx, [g["gz"], g["gx"]], g["etas"], g["etan"], list(g["bc"]), x,
+                                 rho=g["rho"], **kw)
+        assert relerr(ya, y) < 1e-13
+
+
+def test_stokes_row_classes_partition(oracle):
+    # the reference's `lc` idea: every row belongs to exactly one class and the CSR has
+    # no empty row
+    for nx in ([9, 7], [41, 41], [12, 33]):
+        c = oracle.stokes_row_class(nx)
+        assert c.shape == (3, nx[0], nx[1])
+        g = [np.linspace(0, 1, nx[0]), np.linspace(0, 2, nx[1])]
+        e = np.ones(nx)
+        A, _ = oracle.stokes_csr(nx, g, e, e, e, [1, 1, 1, 1])
+        assert np.all(np.diff(A.indptr) > 0)
+        # row census: identity rows have 1 entry, tangential 2, interior 11
+        nnz = np.diff(A.indptr).reshape(nx[0], nx[1], 3)
+        assert np.all(nnz[:, :, 0][c[0] == 1] == 11) and np.all(nnz[:, :, 0][c[0] == 0] == 1)
+        assert np.all(nnz[:, :, 2][c[2] == 1] == 4)
+
+
+@pytest.mark.parametrize("name", ["stokes_solve_block41", "stokes_solve_tdep33x49"])
+def test_stokes_solve(oracle, name):
+    g = golden(name)
+    nx = [int(v) for v in g["nx"]]
+    x = oracle.stokes_solve(nx, [g["gz"], g["gx"]], g["etas"], g["etan"], g["rho"], list(g["bc"]))
+    (vz, vx), p = oracle.x2vp(x, nx)
+    (rz, rx), rp = oracle.x2vp(g["x"], nx)
+    assert relerr(vz, rz) < 1e-9 and relerr(vx, rx) < 1e-9 and relerr(p, rp) < 1e-8
+
+
+@pytest.mark.parametrize("tag", [t + str(i) for t in "abc" for i in range(4)])
+def test_heat(oracle, tag):
+    g = golden("heat_" + tag)
+    nx = [int(v) for v in g["nx"]]
+    grid = [g["gz"], g["gx"]]; gmp = [g["gmz"], g["gmx"]]
+    k = [g["kz"], g["kx"]]
+    bc = list(g["bc"]); bcv = list(g["bcvalue"]); ts = float(g["tstep"])
+    A, rhs = oracle.heat_csr(nx, grid, gmp, g["T"], k, g["Cp"], g["rho"], g["H"], bc, bcv, ts)
+    R = _csr(g, A.shape[0])
+    D = (A - R).tocoo()
+    assert (np.abs(D.data).max() if D.nnz else 0.0) <= 1e-14 * np.abs(R).max()
+    assert np.allclose(rhs, g["rhs"], rtol=1e-15, atol=0)
+    assert np.allclose(oracle.heat_rhs(nx, g["T"], g["Cp"], g["rho"], g["H"], bc, bcv, ts), g["rhs"],
+                       rtol=1e-15, atol=0)
+    for x, y in zip(g["xs"], g["ys"]):
+        ya = oracle.heat_apply(nx, grid, gmp, k, g["Cp"], g["rho"], bc, ts, x)
+        assert relerr(ya, y) < 1e-13
+    sol = oracle.heat_solve(nx, grid, gmp, g["T"], k, g["Cp"], g["rho"], g["H"], bc, bcv, ts)
+    assert relerr(sol, g["sol"]) < 1e-11
+
+
+def _targets(oracle, nx, L):
+    grid = [np.linspace(0, L[i], nx[i]) for i in range(2)]
+    gmp = oracle.gridmp_of(grid)
+    return {"nodes": grid, "centres": gmp, "zmid": [gmp[0], grid[1]], "xmid": [grid[0], gmp[1]]}
+
+
+@pytest.mark.parametrize("case", ["dense", "sparse", "outside"])
+def test_trac2grid(oracle, case):
+    g = golden("trac2grid")
+    nx = [int(v) for v in g["nx"]]
+    tg = _targets(oracle, nx, g["L"])
+    schemes = [int(s) for s in g["schemes"]]
+    for tname, grid in tg.items():
+        out = oracle.trac2grid(g[case + "_tr_x"], g[case + "_tr_f"], grid, nx, schemes)
+        ref = g["%s_%s" % (case, tname)]
+        for k in range(len(schemes)):
+            assert maxrel(out[k], ref[k]) < 1e-12, (tname, schemes[k])
+    if case == "sparse":
+        assert np.isnan(g["sparse_nodes"]).any()      # empty nodes are NaN in the reference
+
+
+def test_trac2grid_zero_under_geom(oracle):
+    g = golden("trac2grid")
+    nx = [int(v) for v in g["nx"]]
+    grid = _targets(oracle, nx, g["L"])["nodes"]
+    out = oracle.trac2grid(g["zero_tr_x"], g["zero_tr_f"], grid, nx, [6, 2])
+    for k in range(2):
+        assert maxrel(out[k], g["zero_nodes"][k]) < 1e-12
+    assert (g["zero_nodes"] == 1.0).any()
+
+
+def test_grid2trac(oracle):
+    g = golden("grid2trac")
+    nx = [int(v) for v in g["nx"]]
+    grid = [np.linspace(0, g["L"][i], nx[i]) for i in range(2)]
+    F = [g["F"][0], g["F"][1]]
+    for mname, meth in (("linear", 16), ("nearest", 8), ("veldiv", 32)):
+        o = oracle.grid2trac(g["inside"], grid, F, nx, method=meth)
+        assert maxrel(o, g["inside_" + mname]) < 1e-13
+        for dname, dv in (("nan", np.nan), ("zero", 0.0)):
+            o = oracle.grid2trac(g["mixed"], grid, F, nx, defval=dv, method=meth)
+            assert maxrel(o, g["mixed_%s_%s" % (mname, dname)]) < 1e-13
+    with pytest.raises(Exception):
+        oracle.grid2trac(g["mixed"], grid, F, nx, stop_on_error=True)
+
+
+def test_rk4(oracle):
+    g = golden("rk4")
+    nx = [int(v) for v in g["nx"]]
+    v, x = oracle.rk4(g["tr"], [g["gz"], g["gx"]], [g["Vz"], g["Vx"]], nx, float(g["tstep"]))
+    assert maxrel(x, g["x1"]) < 1e-14 and maxrel(v, g["v1"]) < 1e-9
+    v, x = oracle.rk4(g["tr"], [g["gz"], g["gx"]], [g["Vz2"], g["Vx2"]], nx, 4 * float(g["tstep"]))
+    assert maxrel(x, g["x2"]) < 1e-14 and maxrel(v, g["v2"]) < 1e-9
+
+
+@pytest.mark.parametrize("name,heat,model", [("traj_block41", False, 2), ("traj_mantle33x41", True, 1)])
+def test_trajectory(oracle, name, heat, model):
+    """K steps of the stock driver (pylamp2.py loop) vs the oracle's step()."""
+    g = golden(name)
+    gz, gx = g["gz"], g["gx"]
+    nx = [gz.size, gx.size]
+    L = [gz[-1], gx[-1]]
+    st = dict(nx=nx, L=L, grid=[gz, gx], tr_x=g["init_tr_x"].copy(), tr_f=g["init_tr_f"].copy())
+    cfg = oracle.StepConfig(do_heatdiff=heat, tdep_rho=heat, tdep_eta=heat,
+                            tstep_modifier=0.67)
+    ttot = 0.0
+    for it in range(1, int(g["nsteps"]) + 1):
+        out = oracle.step(st, cfg, it)
+        ttot += out["tstep"]
+        p = "s%d_" % it
+        assert relerr(out["velz"], g[p + "velz"]) < 1e-7
+        assert relerr(out["velx"], g[p + "velx"]) < 1e-7
+        assert relerr(out["rho"], g[p + "rho"]) < 1e-12
+        assert abs(ttot - float(g[p + "time"])) < 1e-9 * ttot
+        assert relerr(st["tr_x"], g[p + "tr_x"]) < 1e-10
+        assert relerr(out["tr_v"], g[p + "tr_v"]) < 1e-6
+        if heat:
+            assert relerr(out["temp"], g[p + "temp"]) < 1e-10
+            assert relerr(st["tr_f"][:, oracle.TR_TMP], g[p + "tr_T"]) < 1e-10
