@@ -1,0 +1,155 @@
+/* pylamp_hip.h — C ABI of libpylamp_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for PyLamp's per-time-step hot path.  The reference has no FFI layer:
+ * its boundary is the Python module API of pylamp_stokes.py / pylamp_diff.py /
+ * pylamp_trac.py called from the loop body of pylamp2.py.  the modules under pylamp_amd/ keep those
+ * names and signatures and forwards to the entry points declared here through ctypes
+ * (see INTEGRATION.md for the binding a PyLamp maintainer would add).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all floating point data is IEEE double;
+ *   - host arrays are C-contiguous, shape (nz, nx) indexed [i=z][j=x]
+ *     (reference: pylamp_const.py:9-13, pylamp2.py:37,100-113);
+ *   - Stokes vectors use the reference DOF order: (vz, vx, P) interleaved per node,
+ *     nodes row-major, length 3*nz*nx (pylamp_stokes.py:22-35 gidx, 86-101 x2vp);
+ *   - every function returns 0 on success, non-zero on error; pl_last_error() gives the
+ *     message (the Python side raises Exception(msg), the reference's error convention);
+ *   - one context per GPU / rank; calls on one context are not thread-safe;
+ *   - the library never keeps a host pointer after a call returns;
+ *   - there is no CPU fallback: without a usable HIP device pl_create fails.
+ */
+#ifndef PYLAMP_HIP_H
+#define PYLAMP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pl_ctx pl_ctx;
+
+/* Boundary-condition codes (pylamp_stokes.py:17-20, pylamp_diff.py:12-13). */
+enum { PL_BC_NOSLIP = 0, PL_BC_FREESLIP = 1, PL_BC_CYCLIC = 2, PL_BC_FLOWTHRU = 4 };
+enum { PL_BC_FIXTEMP = 0, PL_BC_FIXFLOW = 1 };
+/* Averaging schemes / interpolation methods (pylamp_trac.py:11-22). */
+enum { PL_AVG_ARITHMETIC = 1, PL_AVG_GEOMETRIC = 2, PL_AVG_WEIGHTED = 4 };
+enum { PL_INTERP_NEAREST = 8, PL_INTERP_LINEAR = 16, PL_INTERP_VELDIV = 32 };
+
+typedef struct pl_solve_stats {
+    int    iterations;      /* outer Krylov iterations used                       */
+    int    converged;       /* 1 if the TRUE residual met rtol                    */
+    double rel_residual;    /* ||b - A x|| / ||b||, recomputed, not the recurrence */
+    double solve_ms;        /* device time of the solve (HIP events)              */
+    int    operator_applies;
+    int    precond_applies;
+} pl_solve_stats;
+
+/* ---- context --------------------------------------------------------------------- */
+/* Global grid of nz x nx nodes with node coordinates zc[nz], xc[nx] (non-uniform
+ * allowed for Stokes/heat; MIC requires a regular grid like the reference,
+ * pylamp_trac.py:34,162).  The context owns all device memory and one HIP stream. */
+int  pl_create(pl_ctx** out, int device, int nz, int nx, const double* zc, const double* xc);
+void pl_destroy(pl_ctx* ctx);
+const char* pl_last_error(const pl_ctx* ctx);   /* ctx may be NULL: error of a failed pl_create */
+int  pl_sync(pl_ctx* ctx);                      /* hipStreamSynchronize on the context stream */
+int  pl_device_info(pl_ctx* ctx, char* name, size_t name_len, int* cu_count, size_t* hbm_bytes);
+
+/* HIP-event timing on the context's stream (bench.py measures kernels with these). */
+int  pl_timer_start(pl_ctx* ctx);
+int  pl_timer_stop_ms(pl_ctx* ctx, double* ms);
+
+/* ---- Stokes: replaces makeStokesMatrix (pylamp_stokes.py:104-563) + the spsolve call
+ *      site pylamp2.py:360 ------------------------------------------------------------ */
+/* Upload viscosity/density and fix the operator.  bc = [z0, x0, zL, xL]
+ * (index DIM*wall+dir as in pylamp_stokes.py:163,202,242,289).  Computes Kcont/Kbond
+ * exactly as pylamp_stokes.py:116-122.  surfstab != 0 adds the stabilisation terms of
+ * pylamp_stokes.py:422-426,483-487 with the given tstep and theta. */
+int  pl_stokes_set_coeffs(pl_ctx* ctx, const double* etas, const double* etan, const double* rho,
+                          const int bc[4], int surfstab, double tstep, double theta);
+int  pl_stokes_get_scaling(pl_ctx* ctx, double* kcont, double* kbond);
+/* y = A x, matrix-free (what A@x would give for the lil_matrix the reference builds). */
+int  pl_stokes_apply(pl_ctx* ctx, const double* x, double* y);
+/* rhs vector of makeStokesMatrix (pylamp_stokes.py:429,490). */
+int  pl_stokes_rhs(pl_ctx* ctx, double* rhs);
+/* x = A^-1 rhs by preconditioned BiCGStab (replaces spsolve, pylamp2.py:360,394).
+ * rhs == NULL uses the operator's own rhs.  x is output only (initial guess 0) unless
+ * use_x0 != 0. */
+int  pl_stokes_solve(pl_ctx* ctx, const double* rhs, double* x, int use_x0, double rtol,
+                     int maxit, pl_solve_stats* stats);
+/* Times `reps` back-to-back applies of the device-resident operator on device-resident
+ * vectors with HIP events (no host transfers); returns average ms per apply. */
+int  pl_stokes_apply_bench(pl_ctx* ctx, int reps, double* avg_ms);
+
+/* ---- Heat: replaces makeDiffusionMatrix (pylamp_diff.py:85-183) + spsolve
+ *      (pylamp2.py:419) --------------------------------------------------------------- */
+int  pl_heat_set_coeffs(pl_ctx* ctx, const double* zmp, const double* xmp, const double* T,
+                        const double* kz, const double* kx, const double* cp, const double* rho,
+                        const double* H, const int bc[4], const double bcvalue[4], double tstep);
+int  pl_heat_apply(pl_ctx* ctx, const double* x, double* y);
+int  pl_heat_rhs(pl_ctx* ctx, double* rhs);
+int  pl_heat_solve(pl_ctx* ctx, const double* rhs, double* x, double rtol, int maxit,
+                   pl_solve_stats* stats);
+int  pl_heat_apply_bench(pl_ctx* ctx, int reps, double* avg_ms);
+
+/* ---- Marker-in-cell: replaces pylamp_trac.trac2grid / grid2trac / RK ----------------- */
+/* Tracer -> grid (pylamp_trac.py:161-318, method ELEM).  tr_x is (n,2) [z,x]; tr_f is
+ * (n,nf) with leading dimension ld_f; target node set given by its first coordinate and
+ * spacing per axis (any of the 4 staggerings; regular grid); out[k] are nf host arrays
+ * (nz,nx) written in place.  Nodes outside [0,nz)x[0,nx) are discarded, which is what
+ * the reference's grid extension + crop (pylamp_trac.py:207-220,313-316) amounts to. */
+int  pl_trac2grid(pl_ctx* ctx, int64_t n, const double* tr_x, const double* tr_f, int64_t ld_f,
+                  int nf, const int* avgscheme, double z0, double hz, double x0, double hx,
+                  double* const* out);
+/* Grid -> tracer (pylamp_trac.py:30-158).  fields: nf host arrays (gnz,gnx) on the regular
+ * grid gz[gnz], gx[gnx]; out is (n,nf) with leading dimension ld_out (may be a strided
+ * view like pylamp2.py:445).  *n_outside returns how many tracers used defval; with
+ * stop_on_error != 0 and any outside the call fails (pylamp_trac.py:53-54). */
+int  pl_grid2trac(pl_ctx* ctx, int64_t n, const double* tr_x, int nf, const double* const* fields,
+                  int gnz, int gnx, const double* gz, const double* gx, int method, double defval,
+                  int stop_on_error, double* out, int64_t ld_out, int64_t* n_outside);
+/* RK(order=4) (pylamp_trac.py:347-388): vels are (gnz,gnx) on gz,gx (the padded
+ * cell-centre grid, pylamp2.py:491-545).  v_out, x_out are (n,2). */
+int  pl_rk4(pl_ctx* ctx, int64_t n, const double* tr_x, int gnz, int gnx, const double* gz,
+            const double* gx, const double* vz, const double* vx, double tstep, double* v_out,
+            double* x_out);
+
+/* ---- Device-resident time step (the build's counterpart of pylamp2.py:273-581) ------- */
+typedef struct pl_step_config {
+    int    do_heatdiff, do_subgrid_heatdiff, tdep_rho, tdep_eta;
+    double etamin, etamax, tref;
+    double tstep_adv_max, tstep_adv_min, tstep_dif_max, tstep_dif_min, tstep_modifier;
+    int    bcstokes[4];
+    int    bcheat[4];
+    double bcheatvals[4];
+    double stokes_rtol, heat_rtol;
+    int    stokes_maxit, heat_maxit;
+    double length[2];               /* domain size L[z], L[x] (pylamp2.py:38) */
+} pl_step_config;
+
+typedef struct pl_step_report {
+    double tstep;                   /* chosen time step (pylamp2.py:374-385) */
+    int    limiter;                 /* 'H' or 'S' */
+    double tstep_heat, tstep_stokes;
+    pl_solve_stats stokes, heat;
+    double ms_props, ms_scatter, ms_stokes, ms_heat, ms_gather, ms_advect, ms_sort, ms_total;
+    int64_t ntrac;
+} pl_step_report;
+
+/* Upload tracer state: tr_x (n,2), tr_f (n,13) AoS rows as in pylamp_const.py:29-42. */
+int  pl_tracers_upload(pl_ctx* ctx, int64_t n, const double* tr_x, const double* tr_f);
+int  pl_tracers_download(pl_ctx* ctx, int64_t n, double* tr_x, double* tr_f);
+int  pl_tracers_count(pl_ctx* ctx, int64_t* n);
+/* One full time step on the device-resident state. */
+int  pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_report* rep);
+/* Copy a named grid field of the last step to host, shape (nz,nx): "velz","velx","pres",
+ * "rho","etas","etan","temp","f_T","kz","kx","cp","H". */
+int  pl_get_field(pl_ctx* ctx, const char* name, double* out);
+/* Velocity of the last advection, (n,2) like trac_vel (pylamp2.py:547-555). */
+int  pl_get_tracer_velocity(pl_ctx* ctx, int64_t n, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYLAMP_HIP_H */

@@ -1,0 +1,64 @@
+"""One device context per (grid) — owner of all HIP memory behind the module API."""
+import ctypes as C
+import os
+import weakref
+
+import numpy as np
+
+from . import _lib
+
+
+class Context:
+    def __init__(self, nx, grid, device=None):
+        lib = _lib.load()
+        self.lib = lib
+        self.nz, self.nx = int(nx[0]), int(nx[1])
+        self.gz = _lib.f64(grid[0]).copy()
+        self.gx = _lib.f64(grid[1]).copy()
+        if self.gz.size != self.nz or self.gx.size != self.nx:
+            raise Exception("grid arrays do not match nx")
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0")) if os.environ.get("PYLAMP_DEVICE") is None \
+                else int(os.environ["PYLAMP_DEVICE"])
+        h = C.c_void_p()
+        rc = lib.pl_create(C.byref(h), int(device), self.nz, self.nx, _lib.dptr(self.gz), _lib.dptr(self.gx))
+        if rc != 0:
+            msg = lib.pl_last_error(None)
+            raise Exception(msg.decode() if msg else "pl_create failed")
+        self.h = h
+        self._fin = weakref.finalize(self, lib.pl_destroy, h)
+
+    def check(self, rc):
+        _lib.check(self.h, rc)
+
+    def close(self):
+        self._fin()
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cu = C.c_int(); mem = C.c_size_t()
+        self.check(self.lib.pl_device_info(self.h, name, 256, C.byref(cu), C.byref(mem)))
+        return name.value.decode(), cu.value, mem.value
+
+
+_cache = {}
+
+
+def get_context(nx, grid):
+    """Context for this grid; cached so consecutive module calls share device state."""
+    gz = _lib.f64(grid[0]); gx = _lib.f64(grid[1])
+    key = (int(nx[0]), int(nx[1]), gz.tobytes(), gx.tobytes())
+    ctx = _cache.get(key)
+    if ctx is None:
+        if len(_cache) >= 4:                 # keep device memory bounded
+            _, old = _cache.popitem()
+            old.close()
+        ctx = Context(nx, [gz, gx])
+        _cache[key] = ctx
+    return ctx
+
+
+def clear_contexts():
+    while _cache:
+        _, c = _cache.popitem()
+        c.close()

@@ -1,0 +1,210 @@
+// Context, memory, geometry tables and host<->device layout conversion.
+#include "pl_internal.h"
+#include <cmath>
+
+thread_local std::string pl_tls_error;
+
+int pl_fail(pl_ctx* ctx, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    pl_tls_error = msg;
+    return 1;
+}
+
+extern "C" const char* pl_last_error(const pl_ctx* ctx) {
+    if (ctx) return ctx->err.c_str();
+    return pl_tls_error.c_str();
+}
+
+int pl_buf(pl_ctx* ctx, const char* name, size_t bytes, double** out, bool zero) {
+    auto it = ctx->bufs.find(name);
+    if (it != ctx->bufs.end() && ctx->buf_bytes[name] >= bytes) {
+        *out = it->second;
+        return 0;
+    }
+    if (it != ctx->bufs.end()) {
+        PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PL_HIP(ctx, hipFree(it->second));
+        ctx->bufs.erase(it);
+    }
+    double* p = nullptr;
+    PL_HIP(ctx, hipMalloc((void**)&p, bytes));
+    if (zero) PL_HIP(ctx, hipMemsetAsync(p, 0, bytes, ctx->stream));
+    ctx->bufs[name] = p;
+    ctx->buf_bytes[name] = bytes;
+    *out = p;
+    return 0;
+}
+
+int pl_stage(pl_ctx* ctx, size_t bytes) {
+    if (ctx->stage_bytes >= bytes) return 0;
+    if (ctx->stage) {
+        PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PL_HIP(ctx, hipFree(ctx->stage));
+        ctx->stage = nullptr; ctx->stage_bytes = 0;
+    }
+    PL_HIP(ctx, hipMalloc((void**)&ctx->stage, bytes));
+    ctx->stage_bytes = bytes;
+    return 0;
+}
+
+// ---- geometry -----------------------------------------------------------------------
+int pl_geom_build(pl_ctx* ctx, PlGeomHost& gh, int nz, int nx, const double* zc, const double* xc) {
+    gh.zc.assign(zc, zc + nz);
+    gh.xc.assign(xc, xc + nx);
+    PlGeom& g = gh.d;
+    g.nz = nz; g.nx = nx; g.lnz = nz; g.lnx = nx; g.gi0 = 0; g.gj0 = 0;
+    g.pitch = ((PL_PADL + nx + 1 + 15) / 16) * 16;
+    g.plane = (long long)(nz + 2) * g.pitch;
+    // tables indexed by global index + 1, length n+3 each
+    size_t lz = nz + 3, lx = nx + 3;
+    std::vector<double> t(3 * lz + 3 * lx, 0.0);
+    double* tz = t.data(); double* trdz = tz + lz; double* trDz = trdz + lz;
+    double* tx = trDz + lz; double* trdx = tx + lx; double* trDx = trdx + lx;
+    for (int i = 0; i < nz; i++) tz[i + 1] = zc[i];
+    for (int j = 0; j < nx; j++) tx[j + 1] = xc[j];
+    for (int i = 0; i + 1 < nz; i++) trdz[i + 1] = 1.0 / (zc[i + 1] - zc[i]);
+    for (int i = 1; i + 1 < nz; i++) trDz[i + 1] = 1.0 / (zc[i + 1] - zc[i - 1]);
+    for (int j = 0; j + 1 < nx; j++) trdx[j + 1] = 1.0 / (xc[j + 1] - xc[j]);
+    for (int j = 1; j + 1 < nx; j++) trDx[j + 1] = 1.0 / (xc[j + 1] - xc[j - 1]);
+    if (gh.tables) { (void)hipFree(gh.tables); gh.tables = nullptr; }
+    PL_HIP(ctx, hipMalloc((void**)&gh.tables, t.size() * sizeof(double)));
+    PL_HIP(ctx, hipMemcpy(gh.tables, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    g.zc = gh.tables; g.rdz = gh.tables + lz; g.rDz = gh.tables + 2 * lz;
+    g.xc = gh.tables + 3 * lz; g.rdx = g.xc + lx; g.rDx = g.xc + 2 * lx;
+    // uniformity (informational; kernels always use the tables)
+    gh.uniform = true;
+    double hz = (zc[nz - 1] - zc[0]) / (nz - 1), hx = (xc[nx - 1] - xc[0]) / (nx - 1);
+    for (int i = 0; i + 1 < nz; i++) if (std::fabs((zc[i + 1] - zc[i]) - hz) > 1e-9 * hz) gh.uniform = false;
+    for (int j = 0; j + 1 < nx; j++) if (std::fabs((xc[j + 1] - xc[j]) - hx) > 1e-9 * hx) gh.uniform = false;
+    return 0;
+}
+
+void pl_geom_free(PlGeomHost& gh) {
+    if (gh.tables) (void)hipFree(gh.tables);
+    gh.tables = nullptr;
+}
+
+// ---- context ---------------------------------------------------------------------------
+extern "C" int pl_create(pl_ctx** out, int device, int nz, int nx, const double* zc, const double* xc) {
+    if (!out) return pl_fail(nullptr, "pl_create: out is NULL");
+    *out = nullptr;
+    if (nz < 5 || nx < 5) return pl_fail(nullptr, "pl_create: grid must be at least 5x5 nodes");
+    if (!zc || !xc) return pl_fail(nullptr, "pl_create: coordinate arrays are NULL");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return pl_fail(nullptr, "pl_create: no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return pl_fail(nullptr, "pl_create: bad device index");
+    pl_ctx* ctx = new pl_ctx();
+    ctx->device = device; ctx->nz = nz; ctx->nx = nx;
+    if (hipSetDevice(device) != hipSuccess) { delete ctx; return pl_fail(nullptr, "pl_create: hipSetDevice failed"); }
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        delete ctx; return pl_fail(nullptr, "pl_create: stream/event creation failed");
+    }
+    if (pl_geom_build(ctx, ctx->geom, nz, nx, zc, xc)) {
+        std::string m = ctx->err; pl_destroy(ctx); return pl_fail(nullptr, m);
+    }
+    *out = ctx;
+    return 0;
+}
+
+extern "C" void pl_destroy(pl_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    pl_step_free(ctx);
+    pl_mic_free(ctx);
+    pl_solver_free(ctx);
+    for (auto& kv : ctx->bufs) (void)hipFree(kv.second);
+    if (ctx->stage) (void)hipFree(ctx->stage);
+    pl_geom_free(ctx->geom);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int pl_sync(pl_ctx* ctx) {
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int pl_device_info(pl_ctx* ctx, char* name, size_t name_len, int* cu_count, size_t* hbm_bytes) {
+    hipDeviceProp_t p;
+    PL_HIP(ctx, hipGetDeviceProperties(&p, ctx->device));
+    if (name && name_len) { std::snprintf(name, name_len, "%s (%s)", p.name, p.gcnArchName); }
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = p.totalGlobalMem;
+    return 0;
+}
+
+extern "C" int pl_timer_start(pl_ctx* ctx) {
+    PL_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    return 0;
+}
+
+extern "C" int pl_timer_stop_ms(pl_ctx* ctx, double* ms) {
+    PL_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    PL_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    float f = 0;
+    PL_HIP(ctx, hipEventElapsedTime(&f, ctx->ev0, ctx->ev1));
+    if (ms) *ms = f;
+    return 0;
+}
+
+// ---- plane / vector transfers ---------------------------------------------------------------
+int pl_plane_upload(pl_ctx* ctx, const PlGeom& g, const double* host, double* dplane) {
+    PL_HIP(ctx, hipMemcpy2DAsync(dplane + pl_idx(g, 0, 0), (size_t)g.pitch * sizeof(double), host,
+                                 (size_t)g.lnx * sizeof(double), (size_t)g.lnx * sizeof(double), g.lnz,
+                                 hipMemcpyHostToDevice, ctx->stream));
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));   // host buffer may be reused by the caller
+    return 0;
+}
+
+int pl_plane_download(pl_ctx* ctx, const PlGeom& g, const double* dplane, double* host) {
+    PL_HIP(ctx, hipMemcpy2DAsync(host, (size_t)g.lnx * sizeof(double), dplane + pl_idx(g, 0, 0),
+                                 (size_t)g.pitch * sizeof(double), (size_t)g.lnx * sizeof(double), g.lnz,
+                                 hipMemcpyDeviceToHost, ctx->stream));
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// interleaved (node-major, 3 per node) <-> 3 planes
+__global__ __launch_bounds__(256) void k_deinterleave3(PlGeom g, const double* __restrict__ src,
+                                                       double* __restrict__ dst) {
+    int lj = blockIdx.x * 64 + threadIdx.x, li = blockIdx.y * 4 + threadIdx.y;
+    if (lj >= g.lnx || li >= g.lnz) return;
+    long long n = ((long long)li * g.lnx + lj) * 3, c = pl_idx(g, li, lj);
+    dst[c] = src[n]; dst[c + g.plane] = src[n + 1]; dst[c + 2 * g.plane] = src[n + 2];
+}
+
+__global__ __launch_bounds__(256) void k_interleave3(PlGeom g, const double* __restrict__ src,
+                                                     double* __restrict__ dst) {
+    int lj = blockIdx.x * 64 + threadIdx.x, li = blockIdx.y * 4 + threadIdx.y;
+    if (lj >= g.lnx || li >= g.lnz) return;
+    long long n = ((long long)li * g.lnx + lj) * 3, c = pl_idx(g, li, lj);
+    dst[n] = src[c]; dst[n + 1] = src[c + g.plane]; dst[n + 2] = src[c + 2 * g.plane];
+}
+
+static dim3 grid2d(const PlGeom& g) { return dim3((g.lnx + 63) / 64, (g.lnz + 3) / 4); }
+
+int pl_vec3_upload(pl_ctx* ctx, const PlGeom& g, const double* host, double* dvec) {
+    size_t bytes = (size_t)3 * g.lnz * g.lnx * sizeof(double);
+    PL_TRY(pl_stage(ctx, bytes));
+    PL_HIP(ctx, hipMemcpyAsync(ctx->stage, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_deinterleave3, grid2d(g), dim3(64, 4), 0, ctx->stream, g, ctx->stage, dvec);
+    PL_HIP(ctx, hipGetLastError());
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int pl_vec3_download(pl_ctx* ctx, const PlGeom& g, const double* dvec, double* host) {
+    size_t bytes = (size_t)3 * g.lnz * g.lnx * sizeof(double);
+    PL_TRY(pl_stage(ctx, bytes));
+    hipLaunchKernelGGL(k_interleave3, grid2d(g), dim3(64, 4), 0, ctx->stream, g, dvec, ctx->stage);
+    PL_HIP(ctx, hipGetLastError());
+    PL_HIP(ctx, hipMemcpyAsync(host, ctx->stage, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}

@@ -1,0 +1,119 @@
+// Internal declarations shared by the HIP translation units of libpylamp_hip.so.
+// gfx950 only; wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <map>
+#include "../../include/pylamp_hip.h"
+
+#define PL_PADL 16           // doubles of left padding: interior column 0 is 128-B aligned
+#define PL_WAVE 64
+
+// ---- device-side view of one grid block (fine grid or a multigrid level) -------------
+// Local block of lnz x lnx nodes whose node (0,0) is global node (gi0,gj0); every 2-D
+// plane carries a one-node ring (halo for neighbour ranks, unused at global walls).
+struct PlGeom {
+    int nz, nx;              // global node counts
+    int lnz, lnx;            // local block
+    int gi0, gj0;            // global index of local node (0,0)
+    int pitch;               // doubles per row
+    long long plane;         // doubles per plane = (lnz+2)*pitch
+    // 1-D tables indexed by GLOBAL node index + 1, length n+3, zero padded:
+    const double* zc; const double* xc;
+    const double* rdz; const double* rdx;   // rdz[i] = 1/(z[i+1]-z[i])
+    const double* rDz; const double* rDx;   // rDz[i] = 1/(z[i+1]-z[i-1])
+};
+
+__host__ __device__ inline long long pl_idx(const PlGeom& g, int li, int lj) {
+    return (long long)(li + 1) * g.pitch + (lj + PL_PADL);
+}
+
+struct PlStokesOp {
+    PlGeom g;
+    const double* etas; const double* etan; const double* rho;
+    double Kc, Kb;
+    int bc_z0, bc_zL;        // z-wall BC for the tangential rows (x-walls are FREESLIP)
+    int surfstab; double ss; // ss = theta * tstep
+    int anchor_i, anchor_j;  // pressure anchor cell (3,2) (pylamp_stokes.py:536-551)
+    double gz, gx;           // gravity components G[IZ], G[IX] (pylamp_const.py:21)
+};
+
+struct PlHeatOp {
+    PlGeom g;
+    const double* kz; const double* kx; const double* rhocp_inv_dt; // dt/(rho*Cp)
+    const double* rdzb; const double* rdxb;  // 1/(zm[i]-zm[i-1]) tables (global idx + 1)
+    int bc[4];
+    double dt;
+};
+
+// ---- host-side context ----------------------------------------------------------------
+struct PlGeomHost {
+    PlGeom d;                               // device view
+    std::vector<double> zc, xc;             // host copies of the node coordinates
+    double* tables = nullptr;               // one device allocation holding the 6 tables
+    bool uniform = true;
+};
+
+struct pl_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    int nz = 0, nx = 0;
+    PlGeomHost geom;
+    // generic staging
+    double* stage = nullptr; size_t stage_bytes = 0;     // device staging buffer
+    // named device planes / vectors, allocated on demand
+    std::map<std::string, double*> bufs;
+    std::map<std::string, size_t> buf_bytes;
+    // Stokes
+    PlStokesOp sop{}; bool sop_ready = false;
+    // Heat
+    PlHeatOp hop{}; bool hop_ready = false; double heat_bcvalue[4] = {0, 0, 0, 0};
+    std::vector<double> zmp, xmp;
+    // opaque extension slots owned by other translation units
+    void* krylov = nullptr;   // pl_solver.hip
+    void* mic = nullptr;      // pl_mic.hip
+    void* step = nullptr;     // pl_step.hip
+};
+
+// ---- error helpers ----------------------------------------------------------------------
+extern thread_local std::string pl_tls_error;
+int pl_fail(pl_ctx* ctx, const std::string& msg);
+#define PL_HIP(ctx, call)                                                                   \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return pl_fail(ctx, std::string(#call) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+#define PL_TRY(expr)                                                                        \
+    do {                                                                                    \
+        int rc_ = (expr);                                                                   \
+        if (rc_) return rc_;                                                                \
+    } while (0)
+
+// ---- shared helpers (pl_ctx.hip) --------------------------------------------------------
+int pl_buf(pl_ctx* ctx, const char* name, size_t bytes, double** out, bool zero = true);
+int pl_stage(pl_ctx* ctx, size_t bytes);
+int pl_geom_build(pl_ctx* ctx, PlGeomHost& gh, int nz, int nx, const double* zc, const double* xc);
+void pl_geom_free(PlGeomHost& gh);
+// host (nz,nx) C-order  <->  device plane with ring/pitch
+int pl_plane_upload(pl_ctx* ctx, const PlGeom& g, const double* host, double* dplane);
+int pl_plane_download(pl_ctx* ctx, const PlGeom& g, const double* dplane, double* host);
+// reference-interleaved host vector (3N) <-> 3 device planes
+int pl_vec3_upload(pl_ctx* ctx, const PlGeom& g, const double* host, double* dvec);
+int pl_vec3_download(pl_ctx* ctx, const PlGeom& g, const double* dvec, double* host);
+
+// ---- kernels launched from several units -------------------------------------------------
+void pl_launch_stokes_apply(pl_ctx* ctx, const PlStokesOp& op, const double* x, double* y);
+void pl_launch_stokes_rhs(pl_ctx* ctx, const PlStokesOp& op, double* rhs);
+void pl_launch_heat_apply(pl_ctx* ctx, const PlHeatOp& op, const double* x, double* y);
+
+// krylov / MIC / step teardown hooks
+void pl_solver_free(pl_ctx* ctx);
+void pl_mic_free(pl_ctx* ctx);
+void pl_step_free(pl_ctx* ctx);

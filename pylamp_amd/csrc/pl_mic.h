@@ -1,0 +1,57 @@
+// Argument blocks of the marker-in-cell kernels (passed by value to the kernels).
+#pragma once
+#include "pl_internal.h"
+
+#define PL_MAX_SCATTER_FIELDS 8
+#define PL_MAX_GATHER_FIELDS 8
+
+struct PlScatterArgs {
+    long long n;
+    const double* tz; const double* tx;
+    int nf;
+    const double* f[PL_MAX_SCATTER_FIELDS];
+    int scheme[PL_MAX_SCATTER_FIELDS];
+    // regular target node set: node k at z0 + k*hz (k < nz), x0 + k*hx (k < nx)
+    double z0, hz, x0, hx;
+    int nz, nx;
+    // dense (nz*nx) accumulators
+    double* wsum; double* cnt;
+    double* acc[PL_MAX_SCATTER_FIELDS];
+};
+
+struct PlGatherGrid {
+    int nz, nx;                 // node counts of the field being interpolated
+    const double* gz; const double* gx;
+    double zmin, xmin, Lz, Lx;
+};
+
+struct PlGatherArgs {
+    long long n;
+    const double* tz; const double* tx;
+    PlGatherGrid g;
+    int nf;
+    const double* fields[PL_MAX_GATHER_FIELDS];   // dense (nz,nx)
+    double* out[PL_MAX_GATHER_FIELDS];
+    int method;
+    double defval;
+    int accumulate;                                // LINEAR only: out += value
+    unsigned long long* n_outside;
+};
+
+struct PlRk4Args {
+    long long n;
+    const double* tz; const double* tx;
+    PlGatherGrid g;
+    const double* Vz; const double* Vx;
+    double dt;
+    double* tz_out; double* tx_out; double* vz_out; double* vx_out;
+    int fence; double eps, Lz, Lx;                 // optional fence of pylamp2.py:563-570
+};
+
+int pl_scatter_device(pl_ctx* ctx, PlScatterArgs& a, double* const* out, long long out_pitch, long long out_off);
+void pl_launch_gather(pl_ctx* ctx, const PlGatherArgs& a);
+void pl_launch_rk4(pl_ctx* ctx, const PlRk4Args& a);
+void pl_launch_aos_to_soa(pl_ctx* ctx, long long n, const double* src, long long ld, int ncol, double* dst,
+                          long long dstride);
+void pl_launch_soa_to_aos(pl_ctx* ctx, long long n, const double* src, long long sstride, int ncol, double* dst,
+                          long long ld);

@@ -1,0 +1,361 @@
+// Marker-in-cell kernels: tracer->grid scatter, grid->tracer gather, RK4 advection.
+// Replaces pylamp_trac.trac2grid / grid2trac / RK (pylamp_trac.py:30-388).
+// Tracers are held SoA on the device (tz[n], tx[n], f_k[n]); the AoS host layout of the
+// reference (tr_x (n,2), tr_f (n,13)) is converted at the C-ABI boundary.
+#include "pl_internal.h"
+#include "pl_mic.h"
+#include <cmath>
+
+// ---------------------------------------------------------------------------------------
+// AoS <-> SoA
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_aos_to_soa(long long n, const double* __restrict__ src, long long ld,
+                                                    int ncol, double* __restrict__ dst, long long dstride) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    for (int k = 0; k < ncol; k++) dst[k * dstride + t] = src[t * ld + k];
+}
+
+__global__ __launch_bounds__(256) void k_soa_to_aos(long long n, const double* __restrict__ src, long long sstride,
+                                                    int ncol, double* __restrict__ dst, long long ld) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    for (int k = 0; k < ncol; k++) dst[t * ld + k] = src[k * sstride + t];
+}
+
+void pl_launch_aos_to_soa(pl_ctx* ctx, long long n, const double* src, long long ld, int ncol, double* dst,
+                          long long dstride) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_aos_to_soa, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, src, ld, ncol,
+                       dst, dstride);
+}
+
+void pl_launch_soa_to_aos(pl_ctx* ctx, long long n, const double* src, long long sstride, int ncol, double* dst,
+                          long long ld) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_soa_to_aos, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, src, sstride,
+                       ncol, dst, ld);
+}
+
+// ---------------------------------------------------------------------------------------
+// Scatter (trac2grid).  Clipped bilinear scatter, SURVEY.md B.3.
+// ---------------------------------------------------------------------------------------
+__device__ inline void mic_atomic_add(double* p, double v) {
+    // hardware FP64 atomic add (global_atomic_add_f64); no CAS loop
+    unsafeAtomicAdd(p, v);
+}
+
+// Unsorted tracers: one thread per tracer, global FP64 atomics.
+__global__ __launch_bounds__(256) void k_scatter_atomic(PlScatterArgs a) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.n) return;
+    const double z = a.tz[t], x = a.tx[t];
+    const double sz = (z - a.z0) / a.hz, sx = (x - a.x0) / a.hx;
+    const double fz = floor(sz), fx = floor(sx);
+    const int ie = (int)fz, je = (int)fx;
+    const double ca = (z - (a.z0 + fz * a.hz)) / a.hz;    // a in pylamp_trac.py:247
+    const double cb = (x - (a.x0 + fx * a.hx)) / a.hx;
+    double w[4] = {(1 - cb) * (1 - ca), (1 - cb) * ca, cb * (1 - ca), cb * ca};
+    double val[PL_MAX_SCATTER_FIELDS];
+    for (int k = 0; k < a.nf; k++) {
+        double v = a.f[k][t];
+        val[k] = (a.scheme[k] & PL_AVG_GEOMETRIC) && !(a.scheme[k] & PL_AVG_ARITHMETIC) ? log(v) : v;
+    }
+#pragma unroll
+    for (int cnr = 0; cnr < 4; cnr++) {
+        const int ni = ie + (cnr & 1), nj = je + (cnr >> 1);
+        if (ni < 0 || ni >= a.nz || nj < 0 || nj >= a.nx) continue;
+        const long long o = (long long)ni * a.nx + nj;
+        if (a.wsum) mic_atomic_add(a.wsum + o, w[cnr]);
+        if (a.cnt) mic_atomic_add(a.cnt + o, 1.0);
+        for (int k = 0; k < a.nf; k++)
+            mic_atomic_add(a.acc[k] + o, (a.scheme[k] & PL_AVG_WEIGHTED) ? val[k] * w[cnr] : val[k]);
+    }
+}
+
+// out = g^-1(acc / den), written into a ring/pitch plane or a dense (nz,nx) array
+__global__ __launch_bounds__(256) void k_scatter_finalize(int nz, int nx, const double* __restrict__ acc,
+                                                          const double* __restrict__ den, int scheme,
+                                                          double* __restrict__ out, long long out_pitch,
+                                                          long long out_off) {
+    const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
+    if (j >= nx || i >= nz) return;
+    const long long o = (long long)i * nx + j;
+    double s = acc[o];
+    const double d = den[o];
+    double r;
+    if (scheme & PL_AVG_ARITHMETIC) r = s / d;
+    else {
+        if (isinf(s)) s = 0.0;                    // pylamp_trac.py:301
+        r = exp(s / d);
+    }
+    out[out_off + (long long)i * out_pitch + j] = r;
+}
+
+int pl_scatter_device(pl_ctx* ctx, PlScatterArgs& a, double* const* out, long long out_pitch, long long out_off) {
+    // accumulators: wsum, cnt, acc[nf] dense (nz*nx)
+    if (a.nf < 1 || a.nf > PL_MAX_SCATTER_FIELDS) return pl_fail(ctx, "trac2grid: bad number of fields");
+    bool has_w = false, has_c = false;
+    for (int k = 0; k < a.nf; k++) {
+        int s = a.scheme[k];
+        if (!(s & (PL_AVG_ARITHMETIC | PL_AVG_GEOMETRIC))) return pl_fail(ctx, "!!! ERROR INVALID AVERAGING SCHEME");
+        if (s & PL_AVG_WEIGHTED) has_w = true; else has_c = true;
+    }
+    size_t N = (size_t)a.nz * a.nx;
+    double* accbuf;
+    PL_TRY(pl_buf(ctx, "scatter_acc", (size_t)(a.nf + 2) * N * sizeof(double), &accbuf, false));
+    PL_HIP(ctx, hipMemsetAsync(accbuf, 0, (size_t)(a.nf + 2) * N * sizeof(double), ctx->stream));
+    a.wsum = has_w ? accbuf : nullptr;
+    a.cnt = has_c ? accbuf + N : nullptr;
+    for (int k = 0; k < a.nf; k++) a.acc[k] = accbuf + (size_t)(2 + k) * N;
+    if (a.n > 0) {
+        hipLaunchKernelGGL(k_scatter_atomic, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, ctx->stream, a);
+        PL_HIP(ctx, hipGetLastError());
+    }
+    dim3 g2((a.nx + 63) / 64, (a.nz + 3) / 4);
+    for (int k = 0; k < a.nf; k++) {
+        const double* den = (a.scheme[k] & PL_AVG_WEIGHTED) ? accbuf : accbuf + N;
+        hipLaunchKernelGGL(k_scatter_finalize, g2, dim3(64, 4), 0, ctx->stream, a.nz, a.nx, a.acc[k], den,
+                           a.scheme[k], out[k], out_pitch, out_off);
+    }
+    PL_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// Gather (grid2trac) and RK4
+// ---------------------------------------------------------------------------------------
+struct CellLoc { int ie, je; bool bad; double a, b; };
+
+// Cell lookup + normalised in-cell coordinates exactly as pylamp_trac.py:42-52,63-75,89-90.
+// A cell index equal to n-1 passes the reference's range test but then indexes one past
+// its coordinate array (IndexError); here it is treated as outside.
+__device__ inline CellLoc mic_locate(const PlGatherGrid& g, double z, double x) {
+    CellLoc c;
+    const double fi = floor((g.nz - 1) * (z - g.zmin) / g.Lz);
+    const double fj = floor((g.nx - 1) * (x - g.xmin) / g.Lx);
+    c.bad = !(fi >= 0.0 && fi <= (double)(g.nz - 2) && fj >= 0.0 && fj <= (double)(g.nx - 2));
+    c.ie = c.bad ? 0 : (int)fi;
+    c.je = c.bad ? 0 : (int)fj;
+    const double dz0 = z - g.gz[c.ie], dz1 = g.gz[c.ie + 1] - z;
+    const double dx0 = x - g.gx[c.je], dx1 = g.gx[c.je + 1] - x;
+    c.a = dz0 / (dz0 + dz1);
+    c.b = dx0 / (dx0 + dx1);
+    return c;
+}
+
+__device__ inline double mic_bilinear(const double* __restrict__ F, int nx, const CellLoc& c) {
+    const long long o = (long long)c.ie * nx + c.je;
+    return (1 - c.b) * (1 - c.a) * F[o] + c.b * (1 - c.a) * F[o + 1] + (1 - c.b) * c.a * F[o + nx] +
+           c.b * c.a * F[o + nx + 1];
+}
+
+// divergence-conserving velocity interpolation (pylamp_trac.py:98-154)
+__device__ inline void mic_veldiv(const PlGatherGrid& g, const double* __restrict__ Vz,
+                                  const double* __restrict__ Vx, double z, double x, double defval, double& uz,
+                                  double& ux, bool& bad) {
+    const CellLoc c = mic_locate(g, z, x);
+    const long long o = (long long)c.ie * g.nx + c.je;
+    const double hz = g.gz[c.ie + 1] - g.gz[c.ie], hx = g.gx[c.je + 1] - g.gx[c.je];
+    const double z00 = Vz[o], z01 = Vz[o + 1], z10 = Vz[o + g.nx], z11 = Vz[o + g.nx + 1];
+    const double x00 = Vx[o], x01 = Vx[o + 1], x10 = Vx[o + g.nx], x11 = Vx[o + g.nx + 1];
+    const double w00 = (1 - c.b) * (1 - c.a), w01 = c.b * (1 - c.a), w10 = (1 - c.b) * c.a, w11 = c.b * c.a;
+    const double C10 = (0.5 * hx / hz) * (z00 - z10 + z11 - z01);
+    const double C20 = (0.5 * hz / hx) * (x00 - x01 + x11 - x10);
+    ux = w00 * x00 + w01 * x01 + w10 * x10 + w11 * x11 + c.b * (1 - c.b) * C10;
+    uz = w00 * z00 + w01 * z01 + w10 * z10 + w11 * z11 + c.a * (1 - c.a) * C20;
+    // Reference quirk (pylamp_trac.py:83,156): only the LAST field (vx) receives defval for an
+    // out-of-grid tracer; vz keeps the value extrapolated from cell (0,0).
+    if (c.bad) ux = defval;
+    bad = c.bad;
+}
+
+__global__ __launch_bounds__(256) void k_gather(PlGatherArgs a) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.n) return;
+    const double z = a.tz[t], x = a.tx[t];
+    if (a.method & PL_INTERP_NEAREST) {
+        const CellLoc c = mic_locate(a.g, z, x);
+        const double dz0 = z - a.g.gz[c.ie], dz1 = a.g.gz[c.ie + 1] - z;
+        const double dx0 = x - a.g.gx[c.je], dx1 = a.g.gx[c.je + 1] - x;
+        const double d[4] = {dz0 * dz0 + dx0 * dx0, dz0 * dz0 + dx1 * dx1, dz1 * dz1 + dx0 * dx0, dz1 * dz1 + dx1 * dx1};
+        int m = 0;
+        for (int k = 1; k < 4; k++) if (d[k] < d[m]) m = k;     // first minimum, like np.argmin
+        const long long o = (long long)(c.ie + (m >> 1)) * a.g.nx + (c.je + (m & 1));
+        for (int k = 0; k < a.nf; k++) a.out[k][t] = c.bad ? a.defval : a.fields[k][o];
+        if (c.bad) atomicAdd(a.n_outside, 1ull);
+    } else if (a.method & PL_INTERP_LINEAR) {
+        const CellLoc c = mic_locate(a.g, z, x);
+        for (int k = 0; k < a.nf; k++) {
+            const double v = mic_bilinear(a.fields[k], a.g.nx, c);
+            a.out[k][t] = c.bad ? a.defval : (a.accumulate ? a.out[k][t] + v : v);
+        }
+        if (c.bad) atomicAdd(a.n_outside, 1ull);
+    } else {
+        double uz, ux; bool bad;
+        mic_veldiv(a.g, a.fields[0], a.fields[1], z, x, a.defval, uz, ux, bad);
+        a.out[0][t] = uz; a.out[1][t] = ux;
+        if (bad) atomicAdd(a.n_outside, 1ull);
+    }
+}
+
+// RK4 with the reference's weights (1,1,1,1)/6 (pylamp_trac.py:385) and v = (x_new - x)/dt.
+// 48 B/tracer: read (z,x), write (z',x') and (vz,vx); the velocity grid is read through L2.
+__global__ __launch_bounds__(256) void k_rk4(PlRk4Args a) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.n) return;
+    const double z = a.tz[t], x = a.tx[t], dt = a.dt;
+    double k1z, k1x, k2z, k2x, k3z, k3x, k4z, k4x; bool bad;
+    mic_veldiv(a.g, a.Vz, a.Vx, z, x, 0.0, k1z, k1x, bad);
+    mic_veldiv(a.g, a.Vz, a.Vx, z + 0.5 * dt * k1z, x + 0.5 * dt * k1x, 0.0, k2z, k2x, bad);
+    mic_veldiv(a.g, a.Vz, a.Vx, z + 0.5 * dt * k2z, x + 0.5 * dt * k2x, 0.0, k3z, k3x, bad);
+    mic_veldiv(a.g, a.Vz, a.Vx, z + dt * k3z, x + dt * k3x, 0.0, k4z, k4x, bad);
+    const double zn = z + (1.0 / 6.0) * dt * (k1z + k2z + k3z + k4z);
+    const double xn = x + (1.0 / 6.0) * dt * (k1x + k2x + k3x + k4x);
+    a.vz_out[t] = (zn - z) / dt; a.vx_out[t] = (xn - x) / dt;
+    double zf = zn, xf = xn;
+    if (a.fence) {                                     // pylamp2.py:563-570
+        if (zf <= 0.0) zf = a.eps; if (zf >= a.Lz) zf = a.Lz - a.eps;
+        if (xf <= 0.0) xf = a.eps; if (xf >= a.Lx) xf = a.Lx - a.eps;
+    }
+    a.tz_out[t] = zf; a.tx_out[t] = xf;
+}
+
+void pl_launch_gather(pl_ctx* ctx, const PlGatherArgs& a) {
+    if (a.n <= 0) return;
+    hipLaunchKernelGGL(k_gather, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, ctx->stream, a);
+}
+
+void pl_launch_rk4(pl_ctx* ctx, const PlRk4Args& a) {
+    if (a.n <= 0) return;
+    hipLaunchKernelGGL(k_rk4, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, ctx->stream, a);
+}
+
+// ---------------------------------------------------------------------------------------
+// C-ABI with host pointers
+// ---------------------------------------------------------------------------------------
+static int upload_grid(pl_ctx* ctx, const char* name, int gnz, int gnx, const double* gz, const double* gx,
+                       PlGatherGrid& g) {
+    double* d;
+    PL_TRY(pl_buf(ctx, name, (size_t)(gnz + gnx) * sizeof(double), &d, false));
+    PL_HIP(ctx, hipMemcpyAsync(d, gz, gnz * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PL_HIP(ctx, hipMemcpyAsync(d + gnz, gx, gnx * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    g.nz = gnz; g.nx = gnx; g.gz = d; g.gx = d + gnz;
+    g.zmin = gz[0]; g.xmin = gx[0]; g.Lz = gz[gnz - 1] - gz[0]; g.Lx = gx[gnx - 1] - gx[0];
+    return 0;
+}
+
+extern "C" int pl_trac2grid(pl_ctx* ctx, int64_t n, const double* tr_x, const double* tr_f, int64_t ld_f, int nf,
+                            const int* avgscheme, double z0, double hz, double x0, double hx, double* const* out) {
+    if (n < 0 || !tr_x || !tr_f || !avgscheme || !out) return pl_fail(ctx, "pl_trac2grid: bad argument");
+    if (nf < 1 || nf > PL_MAX_SCATTER_FIELDS) return pl_fail(ctx, "pl_trac2grid: 1..8 fields per call");
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    const int nz = ctx->nz, nx = ctx->nx;
+    size_t N = (size_t)nz * nx;
+    double *d_aos, *d_soa, *d_out;
+    size_t nn = (size_t)(n > 0 ? n : 1);
+    PL_TRY(pl_buf(ctx, "mic_aos", nn * (size_t)(2 + ld_f) * sizeof(double), &d_aos, false));
+    PL_TRY(pl_buf(ctx, "mic_soa", nn * (size_t)(2 + nf) * sizeof(double), &d_soa, false));
+    PL_TRY(pl_buf(ctx, "mic_out", (size_t)nf * N * sizeof(double), &d_out, false));
+    if (n > 0) {
+        PL_HIP(ctx, hipMemcpyAsync(d_aos, tr_x, (size_t)n * 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        PL_HIP(ctx, hipMemcpyAsync(d_aos + 2 * n, tr_f, (size_t)n * ld_f * sizeof(double), hipMemcpyHostToDevice,
+                                   ctx->stream));
+        pl_launch_aos_to_soa(ctx, n, d_aos, 2, 2, d_soa, n);
+        pl_launch_aos_to_soa(ctx, n, d_aos + 2 * n, ld_f, nf, d_soa + 2 * n, n);
+    }
+    PlScatterArgs a{};
+    a.n = n; a.tz = d_soa; a.tx = d_soa + n; a.nf = nf;
+    for (int k = 0; k < nf; k++) { a.f[k] = d_soa + (size_t)(2 + k) * n; a.scheme[k] = avgscheme[k]; }
+    a.z0 = z0; a.hz = hz; a.x0 = x0; a.hx = hx; a.nz = nz; a.nx = nx;
+    double* outs[PL_MAX_SCATTER_FIELDS];
+    for (int k = 0; k < nf; k++) outs[k] = d_out + (size_t)k * N;
+    PL_TRY(pl_scatter_device(ctx, a, outs, nx, 0));
+    for (int k = 0; k < nf; k++)
+        PL_HIP(ctx, hipMemcpyAsync(out[k], outs[k], N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int pl_grid2trac(pl_ctx* ctx, int64_t n, const double* tr_x, int nf, const double* const* fields, int gnz,
+                            int gnx, const double* gz, const double* gx, int method, double defval,
+                            int stop_on_error, double* out, int64_t ld_out, int64_t* n_outside) {
+    if (n < 0 || !tr_x || !fields || !gz || !gx || !out) return pl_fail(ctx, "pl_grid2trac: bad argument");
+    if (nf < 1 || nf > PL_MAX_GATHER_FIELDS) return pl_fail(ctx, "pl_grid2trac: 1..8 fields per call");
+    if (!(method & (PL_INTERP_LINEAR | PL_INTERP_NEAREST | PL_INTERP_VELDIV)))
+        return pl_fail(ctx, "pl_grid2trac: unknown interpolation method");
+    if (!(method & (PL_INTERP_LINEAR | PL_INTERP_NEAREST)) && nf != 2)
+        return pl_fail(ctx, "grid2trac(): method INTERP_METHOD_VELDIV only works in 2D and expects field to be (vz,vx)");
+    if (gnz < 2 || gnx < 2) return pl_fail(ctx, "pl_grid2trac: grid too small");
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    size_t GN = (size_t)gnz * gnx, nn = (size_t)(n > 0 ? n : 1);
+    double *d_aos, *d_soa, *d_f, *d_o;
+    PL_TRY(pl_buf(ctx, "mic_aos", nn * (size_t)(2 + nf) * sizeof(double), &d_aos, false));
+    PL_TRY(pl_buf(ctx, "mic_soa", nn * (size_t)(2 + nf) * sizeof(double), &d_soa, false));
+    PL_TRY(pl_buf(ctx, "mic_gfields", (size_t)nf * GN * sizeof(double), &d_f, false));
+    PL_TRY(pl_buf(ctx, "mic_counter", 64, &d_o, false));
+    PL_HIP(ctx, hipMemsetAsync(d_o, 0, 64, ctx->stream));
+    PlGatherArgs a{};
+    PL_TRY(upload_grid(ctx, "mic_ggrid", gnz, gnx, gz, gx, a.g));
+    for (int k = 0; k < nf; k++) {
+        PL_HIP(ctx, hipMemcpyAsync(d_f + k * GN, fields[k], GN * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        a.fields[k] = d_f + k * GN;
+        a.out[k] = d_soa + (size_t)(2 + k) * nn;
+    }
+    if (n > 0) {
+        PL_HIP(ctx, hipMemcpyAsync(d_aos, tr_x, (size_t)n * 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        pl_launch_aos_to_soa(ctx, n, d_aos, 2, 2, d_soa, nn);
+    }
+    a.n = n; a.tz = d_soa; a.tx = d_soa + nn; a.nf = nf; a.method = method; a.defval = defval; a.accumulate = 0;
+    a.n_outside = (unsigned long long*)d_o;
+    pl_launch_gather(ctx, a);
+    PL_HIP(ctx, hipGetLastError());
+    unsigned long long nout = 0;
+    PL_HIP(ctx, hipMemcpyAsync(&nout, d_o, sizeof(nout), hipMemcpyDeviceToHost, ctx->stream));
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_outside) *n_outside = (int64_t)nout;
+    if (stop_on_error && nout > 0) return pl_fail(ctx, "stopOnError in grid2trac");
+    if (n > 0) {
+        pl_launch_soa_to_aos(ctx, n, d_soa + 2 * nn, nn, nf, d_aos, nf);
+        PL_HIP(ctx, hipMemcpy2DAsync(out, (size_t)ld_out * sizeof(double), d_aos, (size_t)nf * sizeof(double),
+                                     (size_t)nf * sizeof(double), (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return 0;
+}
+
+extern "C" int pl_rk4(pl_ctx* ctx, int64_t n, const double* tr_x, int gnz, int gnx, const double* gz,
+                      const double* gx, const double* vz, const double* vx, double tstep, double* v_out,
+                      double* x_out) {
+    if (n < 0 || !tr_x || !gz || !gx || !vz || !vx || !v_out || !x_out) return pl_fail(ctx, "pl_rk4: bad argument");
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    size_t GN = (size_t)gnz * gnx, nn = (size_t)(n > 0 ? n : 1);
+    double *d_aos, *d_soa, *d_f;
+    PL_TRY(pl_buf(ctx, "mic_aos", nn * 4 * sizeof(double), &d_aos, false));
+    PL_TRY(pl_buf(ctx, "mic_soa", nn * 6 * sizeof(double), &d_soa, false));
+    PL_TRY(pl_buf(ctx, "mic_gfields", 2 * GN * sizeof(double), &d_f, false));
+    PlRk4Args a{};
+    PL_TRY(upload_grid(ctx, "mic_ggrid", gnz, gnx, gz, gx, a.g));
+    PL_HIP(ctx, hipMemcpyAsync(d_f, vz, GN * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PL_HIP(ctx, hipMemcpyAsync(d_f + GN, vx, GN * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (n > 0) {
+        PL_HIP(ctx, hipMemcpyAsync(d_aos, tr_x, (size_t)n * 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        pl_launch_aos_to_soa(ctx, n, d_aos, 2, 2, d_soa, nn);
+    }
+    a.n = n; a.tz = d_soa; a.tx = d_soa + nn; a.Vz = d_f; a.Vx = d_f + GN; a.dt = tstep;
+    a.tz_out = d_soa + 2 * nn; a.tx_out = d_soa + 3 * nn; a.vz_out = d_soa + 4 * nn; a.vx_out = d_soa + 5 * nn;
+    a.fence = 0;
+    pl_launch_rk4(ctx, a);
+    PL_HIP(ctx, hipGetLastError());
+    if (n > 0) {
+        pl_launch_soa_to_aos(ctx, n, d_soa + 2 * nn, nn, 2, d_aos, 2);
+        pl_launch_soa_to_aos(ctx, n, d_soa + 4 * nn, nn, 2, d_aos + 2 * nn, 2);
+        PL_HIP(ctx, hipMemcpyAsync(x_out, d_aos, (size_t)n * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        PL_HIP(ctx, hipMemcpyAsync(v_out, d_aos + 2 * nn, (size_t)n * 2 * sizeof(double), hipMemcpyDeviceToHost,
+                                   ctx->stream));
+    }
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+void pl_mic_free(pl_ctx* ctx) { (void)ctx; }

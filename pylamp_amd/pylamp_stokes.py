@@ -1,0 +1,142 @@
+"""Drop-in for the reference's pylamp_stokes.py, backed by HIP kernels.
+
+Same names and signatures as pylamp_stokes.py:17-20 (BC constants), 22-35 (gidx),
+86-101 (x2vp), 104-563 (makeStokesMatrix).  makeStokesMatrix returns (A, rhs) where A is a
+matrix-free StokesOperator living on the GPU instead of a lil_matrix; `solve(A, rhs)`
+replaces the driver's spsolve(csc_matrix(A), rhs) (pylamp2.py:360,394).  The DOF order of
+x / rhs is the reference's, so x2vp is unchanged.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .pylamp_const import *  # noqa: F401,F403
+from .pylamp_const import DIM, IZ, IX
+from . import _lib
+from ._context import get_context
+
+BC_TYPE_NOSLIP = 0
+BC_TYPE_FREESLIP = 1
+BC_TYPE_CYCLIC = 2
+BC_TYPE_FLOWTHRU = 4
+
+# default stopping rule of solve(): true-residual ||b-Ax||/||b||
+DEFAULT_RTOL = 1e-10
+DEFAULT_MAXIT = 400
+
+
+def gidx(idxs, nx, dim):
+    """Global matrix index of node(s) idxs=[i, j]; add IZ/IX/IP for the equation
+    (pylamp_stokes.py:22-35)."""
+    if len(idxs) != dim:
+        raise Exception("num of idxs != dimensions")
+    if dim == 2:
+        ret = idxs[IZ] * nx[IX] * (dim + 1) + idxs[IX] * (dim + 1)
+    else:
+        print("!!! NOT IMPLEMENTED")
+        raise Exception("gidx: only 2D is implemented")
+    return ret
+
+
+def x2vp(x, nx):
+    """Split a solution vector into ([vz, vx], P), ghosts retained, pressure left in
+    Kcont-scaled units (pylamp_stokes.py:86-101)."""
+    dof = int(np.prod(nx)) * (DIM + 1)
+    x = np.asarray(x)
+    newvel = [[]] * DIM
+    for d in range(DIM):
+        newvel[d] = x[d:dof:DIM + 1].reshape(nx)
+    newpres = x[DIM:dof:DIM + 1].reshape(nx)
+    return (newvel, newpres)
+
+
+class StokesOperator:
+    """Matrix-free A of the Stokes system, resident on the GPU.
+
+    Offers what the reference's callers use of the sparse matrix: .shape, A @ x / .dot /
+    .matvec, and .tocsc() (materialised by 27 coloured probe applies; for tests).
+    """
+
+    def __init__(self, ctx, nx):
+        self._ctx = ctx
+        self.nx = [int(nx[0]), int(nx[1])]
+        n = 3 * self.nx[0] * self.nx[1]
+        self.shape = (n, n)
+        self.dtype = np.dtype(np.float64)
+        self.last_stats = None
+        kc = C.c_double(); kb = C.c_double()
+        ctx.check(ctx.lib.pl_stokes_get_scaling(ctx.h, C.byref(kc), C.byref(kb)))
+        self.Kcont, self.Kbond = kc.value, kb.value
+
+    def matvec(self, x):
+        x = _lib.f64(x).reshape(-1)
+        if x.size != self.shape[0]:
+            raise Exception("dimension mismatch")
+        y = np.empty_like(x)
+        self._ctx.check(self._ctx.lib.pl_stokes_apply(self._ctx.h, _lib.dptr(x), _lib.dptr(y)))
+        return y
+
+    dot = matvec
+
+    def __matmul__(self, x):
+        return self.matvec(x)
+
+    def rhs(self):
+        r = np.empty(self.shape[0])
+        self._ctx.check(self._ctx.lib.pl_stokes_rhs(self._ctx.h, _lib.dptr(r)))
+        return r
+
+    def tocsc(self):
+        """Explicit scipy CSC equal to the reference's matrix (probing: every row reaches
+        only nodes within +-1 in i and j, so 3x3x3 colours separate all its entries)."""
+        import scipy.sparse as sp
+        nz, nxx = self.nx
+        ii, jj = np.meshgrid(np.arange(nz), np.arange(nxx), indexing='ij')
+        rows, cols, vals = [], [], []
+        node = (ii * nxx + jj)
+        for ci in range(3):
+            for cj in range(3):
+                mask = ((ii % 3) == ci) & ((jj % 3) == cj)
+                for q in range(3):
+                    e = np.zeros((nz, nxx, 3))
+                    e[mask, q] = 1.0
+                    y = self.matvec(e.reshape(-1)).reshape(nz, nxx, 3)
+                    ri, rj, rq = np.nonzero(y)
+                    # the probed column seen by row (ri,rj): the node of colour (ci,cj) within +-1
+                    pi = ri + ((ci - ri % 3 + 1) % 3 - 1)
+                    pj = rj + ((cj - rj % 3 + 1) % 3 - 1)
+                    ok = (pi >= 0) & (pi < nz) & (pj >= 0) & (pj < nxx)
+                    rows.append((node[ri, rj] * 3 + rq)[ok])
+                    cols.append((pi * nxx + pj)[ok] * 3 + q)
+                    vals.append(y[ri, rj, rq][ok])
+        A = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=self.shape)
+        return A.tocsc()
+
+
+def makeStokesMatrix(nx, grid, f_etas, f_etan, f_rho, bc, surfstab=False, tstep=None, surfstab_theta=0.5):
+    """Set up the matrix-free Stokes operator and its rhs (pylamp_stokes.py:104-563)."""
+    ctx = get_context(nx, grid)
+    if surfstab and tstep is None:
+        raise Exception("surface stabilization needs predetermined tstep")
+    bc_arr = (C.c_int * 4)(*[int(b) for b in bc])
+    es, en, rho = _lib.f64(f_etas), _lib.f64(f_etan), _lib.f64(f_rho)
+    for a in (es, en, rho):
+        if a.shape != (int(nx[0]), int(nx[1])):
+            raise Exception("field shape does not match nx")
+    ctx.check(ctx.lib.pl_stokes_set_coeffs(ctx.h, _lib.dptr(es), _lib.dptr(en), _lib.dptr(rho), bc_arr,
+                                           1 if surfstab else 0, float(tstep) if tstep is not None else 0.0,
+                                           float(surfstab_theta)))
+    A = StokesOperator(ctx, nx)
+    return (A, A.rhs())
+
+
+def solve(A, rhs, x0=None, rtol=DEFAULT_RTOL, maxit=DEFAULT_MAXIT):
+    """x = A^-1 rhs on the GPU; stands in for spsolve(csc_matrix(A), rhs) (pylamp2.py:360)."""
+    ctx = A._ctx
+    rhs = _lib.f64(rhs).reshape(-1)
+    x = np.zeros_like(rhs) if x0 is None else _lib.f64(x0).reshape(-1).copy()
+    st = _lib.SolveStats()
+    ctx.check(ctx.lib.pl_stokes_solve(ctx.h, _lib.dptr(rhs), _lib.dptr(x), 0 if x0 is None else 1, float(rtol),
+                                      int(maxit), C.byref(st)))
+    A.last_stats = st.as_dict()
+    return x

@@ -1,0 +1,228 @@
+"""GPU parity: the HIP path, called through the C ABI via the drop-in modules, against the
+golden fixtures (made by the reference) and against the oracle on seeded inputs."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import golden, relerr, maxrel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from pylamp_amd import pylamp_stokes, pylamp_diff, pylamp_trac
+    return pylamp_stokes, pylamp_diff, pylamp_trac
+
+
+def _csr(g, n):
+    return sp.csr_matrix((g["data"], g["indices"], g["indptr"]), shape=(n, n))
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e"])
+def test_stokes_apply_and_rhs_vs_reference(mods, tag):
+    S = mods[0]
+    g = golden("stokes_op_" + tag)
+    nx = [int(v) for v in g["nx"]]
+    A, rhs = S.makeStokesMatrix(nx, [g["gz"], g["gx"]], g["etas"], g["etan"], g["rho"], list(g["bc"]))
+    assert A.shape == (3 * nx[0] * nx[1],) * 2
+    assert np.allclose(rhs, g["rhs"], rtol=1e-14, atol=0)
+    for x, y in zip(g["xs"], g["ys"]):
+        ya = A @ x
+        assert relerr(ya, y) < 1e-13
+        # row-wise: error relative to |A||x| of the same row
+        R = _csr(g, A.shape[0])
+        scale = abs(R) @ abs(x)
+        assert np.max(np.abs(ya - y) / np.maximum(scale, 1e-300)) < 1e-13
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_stokes_surfstab(mods, tag):
+    S = mods[0]
+    g = golden("stokes_surfstab_" + tag)
+    nx = [int(v) for v in g["nx"]]
+    A, rhs = S.makeStokesMatrix(nx, [g["gz"], g["gx"]], g["etas"], g["etan"], g["rho"], list(g["bc"]),
+                                surfstab=True, tstep=float(g["tstep"]), surfstab_theta=float(g["theta"]))
+    assert np.allclose(rhs, g["rhs"], rtol=1e-14, atol=0)
+    for x, y in zip(g["xs"], g["ys"]):
+        assert relerr(A @ x, y) < 1e-13
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_stokes_tocsc_equals_reference_matrix(mods, tag):
+    S = mods[0]
+    g = golden("stokes_op_" + tag)
+    nx = [int(v) for v in g["nx"]]
+    A, _ = S.makeStokesMatrix(nx, [g["gz"], g["gx"]], g["etas"], g["etan"], g["rho"], list(g["bc"]))
+    M = A.tocsc().tocsr()
+    R = _csr(g, A.shape[0])
+    D = (M - R).tocoo()
+    assert (np.abs(D.data).max() if D.nnz else 0.0) <= 1e-13 * np.abs(R).max()
+    M.eliminate_zeros(); R.eliminate_zeros()
+    assert np.array_equal(np.diff(M.indptr), np.diff(R.indptr))     # every row defined once, same pattern
+
+
+def test_stokes_bad_bc_raises(mods):
+    S = mods[0]
+    nx = [9, 7]
+    g = [np.linspace(0, 1, 9), np.linspace(0, 1, 7)]
+    e = np.ones(nx)
+    with pytest.raises(Exception):
+        S.makeStokesMatrix(nx, g, e, e, e, [1, 2, 1, 1])
+    with pytest.raises(Exception):
+        S.makeStokesMatrix(nx, g, e, e, e, [1, 1, 1, 1], surfstab=True)      # needs tstep
+
+
+def test_stokes_apply_vs_oracle_513(mods, oracle):
+    S = mods[0]
+    rng = np.random.default_rng(7)
+    nx = [513, 257]
+    grid = [np.linspace(0, 660e3, nx[0]), np.linspace(0, 330e3, nx[1])]
+    etas = 1e19 * 10 ** rng.uniform(0, 3, nx); etan = 1e19 * 10 ** rng.uniform(0, 3, nx)
+    etan[:, -1] = np.nan                       # empty ghost column: python-min quirk (pylamp_stokes.py:116-118)
+    rho = 3300 + rng.uniform(-50, 50, nx)
+    bc = [0, 1, 1, 1]
+    A, rhs = S.makeStokesMatrix(nx, grid, etas, etan, rho, bc)
+    Kc, Kb = oracle.stokes_scaling(grid, etas, etan)
+    assert A.Kcont == pytest.approx(Kc, rel=1e-15) and A.Kbond == pytest.approx(Kb, rel=1e-15)
+    x = rng.standard_normal(A.shape[0])
+    yo = oracle.stokes_apply(nx, grid, etas, etan, bc, x)      # the ghost column is never read
+    assert not np.isnan(yo).any()
+    assert relerr(A @ x, yo) < 1e-13
+    assert np.allclose(rhs, oracle.stokes_rhs(nx, rho), rtol=1e-14, atol=0)
+
+
+def test_stokes_apply_linearity_2049(mods):
+    """Full-size property test: A(ax+by) = aAx + bAy at the BASELINE size."""
+    S = mods[0]
+    rng = np.random.default_rng(8)
+    nx = [2049, 2049]
+    grid = [np.linspace(0, 660e3, nx[0]), np.linspace(0, 660e3, nx[1])]
+    etas = 1e19 * 10 ** rng.uniform(0, 3, nx); etan = 1e19 * 10 ** rng.uniform(0, 3, nx)
+    rho = 3300 + rng.uniform(-50, 50, nx)
+    A, rhs = S.makeStokesMatrix(nx, grid, etas, etan, rho, [1, 1, 1, 1])
+    x = rng.standard_normal(A.shape[0]); y = rng.standard_normal(A.shape[0])
+    lhs = A @ (2.0 * x - 0.5 * y)
+    r = 2.0 * (A @ x) - 0.5 * (A @ y)
+    assert relerr(lhs, r) < 1e-12
+    # identity rows: ghosts and walls return Kcont * x
+    X = x.reshape(nx[0], nx[1], 3); Y = (A @ x).reshape(nx[0], nx[1], 3)
+    assert np.allclose(Y[:, -1, 0], A.Kcont * X[:, -1, 0], rtol=1e-14)
+    assert np.allclose(Y[-1, :, 1], A.Kcont * X[-1, :, 1], rtol=1e-14)
+    assert Y[3, 2, 2] == pytest.approx(A.Kcont * X[3, 2, 2], rel=1e-14)
+
+
+@pytest.mark.parametrize("tag", [t + str(i) for t in "abc" for i in range(4)])
+def test_heat_apply_and_rhs(mods, tag):
+    D = mods[1]
+    g = golden("heat_" + tag)
+    nx = [int(v) for v in g["nx"]]
+    A, rhs = D.makeDiffusionMatrix(nx, [g["gz"], g["gx"]], [g["gmz"], g["gmx"]], g["T"], [g["kz"], g["kx"]],
+                                   g["Cp"], g["rho"], g["H"], list(g["bc"]), list(g["bcvalue"]), float(g["tstep"]))
+    assert np.allclose(rhs, g["rhs"], rtol=1e-13, atol=0)
+    for x, y in zip(g["xs"], g["ys"]):
+        assert relerr(A @ x, y) < 1e-13
+    if nx[0] * nx[1] < 200:
+        M = A.tocsc().tocsr(); R = _csr(g, A.shape[0])
+        Dm = (M - R).tocoo()
+        assert (np.abs(Dm.data).max() if Dm.nnz else 0.0) <= 1e-13 * np.abs(R).max()
+
+
+def _targets(oracle, nx, L):
+    grid = [np.linspace(0, L[i], nx[i]) for i in range(2)]
+    gmp = oracle.gridmp_of(grid)
+    mesh = np.meshgrid(*grid, indexing='ij')
+    return {"nodes": grid, "centres": gmp, "zmid": [gmp[0], grid[1]], "xmid": [grid[0], gmp[1]]}, mesh
+
+
+@pytest.mark.parametrize("case", ["dense", "sparse", "outside"])
+def test_trac2grid_vs_reference(mods, oracle, case):
+    T = mods[2]
+    g = golden("trac2grid")
+    nx = [int(v) for v in g["nx"]]
+    tg, mesh = _targets(oracle, nx, g["L"])
+    schemes = [int(s) for s in g["schemes"]]
+    for tname, grid in tg.items():
+        gf = [np.zeros(nx) for _ in schemes]
+        T.trac2grid(g[case + "_tr_x"], g[case + "_tr_f"], mesh, grid, gf, nx, avgscheme=list(schemes))
+        ref = g["%s_%s" % (case, tname)]
+        for k in range(len(schemes)):
+            # atomics change the summation order: tolerance 1e-12, NaN masks identical
+            assert maxrel(gf[k], ref[k]) < 1e-12, (tname, schemes[k])
+
+
+def test_trac2grid_zero_under_geom_and_empty(mods, oracle):
+    T = mods[2]
+    g = golden("trac2grid")
+    nx = [int(v) for v in g["nx"]]
+    tg, mesh = _targets(oracle, nx, g["L"])
+    gf = [np.zeros(nx), np.zeros(nx)]
+    T.trac2grid(g["zero_tr_x"], g["zero_tr_f"], mesh, tg["nodes"], gf, nx, avgscheme=[6, 2])
+    for k in range(2):
+        assert maxrel(gf[k], g["zero_nodes"][k]) < 1e-12
+    # no tracers at all: every node is 0/0 = NaN
+    gf = [np.zeros(nx)]
+    T.trac2grid(np.zeros((0, 2)), np.zeros((0, 1)), mesh, tg["nodes"], gf, nx)
+    assert np.isnan(gf[0]).all()
+
+
+def test_grid2trac_vs_reference(mods):
+    T = mods[2]
+    g = golden("grid2trac")
+    nx = [int(v) for v in g["nx"]]
+    grid = [np.linspace(0, g["L"][i], nx[i]) for i in range(2)]
+    F = [g["F"][0], g["F"][1]]
+    for mname, meth in (("linear", 16), ("nearest", 8), ("veldiv", 32)):
+        o = np.zeros((g["inside"].shape[0], 2))
+        T.grid2trac(g["inside"], o, grid, F, nx, method=meth)
+        assert maxrel(o, g["inside_" + mname]) < 1e-13
+        for dname, dv in (("nan", np.nan), ("zero", 0.0)):
+            o = np.zeros((g["mixed"].shape[0], 2))
+            T.grid2trac(g["mixed"], o, grid, F, nx, defval=dv, method=meth)
+            assert maxrel(o, g["mixed_%s_%s" % (mname, dname)]) < 1e-13
+    with pytest.raises(Exception):
+        T.grid2trac(g["mixed"], np.zeros((g["mixed"].shape[0], 2)), grid, F, nx, stopOnError=True)
+    # strided destination like pylamp2.py:445
+    big = np.zeros((2 * g["inside"].shape[0], 1))
+    T.grid2trac(g["inside"], big[0::2], grid, [F[0]], nx)
+    assert maxrel(big[0::2, 0], g["inside_linear"][:, 0]) < 1e-13 and np.all(big[1::2] == 0)
+
+
+def test_rk4_vs_reference(mods):
+    T = mods[2]
+    g = golden("rk4")
+    nx = [int(v) for v in g["nx"]]
+    v, x = T.RK(g["tr"], [g["gz"], g["gx"]], [g["Vz"], g["Vx"]], nx, float(g["tstep"]))
+    assert maxrel(x, g["x1"]) < 1e-14 and maxrel(v, g["v1"]) < 1e-9
+    v, x = T.RK(g["tr"], [g["gz"], g["gx"]], [g["Vz2"], g["Vx2"]], nx, 4 * float(g["tstep"]))
+    assert maxrel(x, g["x2"]) < 1e-14 and maxrel(v, g["v2"]) < 1e-9
+    with pytest.raises(Exception):
+        T.RK(g["tr"], [g["gz"], g["gx"]], [g["Vz"], g["Vx"]], nx, 1.0, order=3)
+
+
+def test_mic_large_vs_oracle(mods, oracle):
+    """1M tracers on 257x129: scatter/gather/RK4 vs the oracle on the same seeded input."""
+    T = mods[2]
+    rng = np.random.default_rng(99)
+    nx = [257, 129]; L = [660e3, 330e3]
+    tg, mesh = _targets(oracle, nx, L)
+    n = 1_000_000
+    tr_x = rng.random((n, 2)) * np.array(L)
+    f = np.stack([rng.uniform(3000, 3400, n), 10 ** rng.uniform(18, 22, n)], axis=1)
+    for tname in ("nodes", "centres"):
+        gf = [np.zeros(nx), np.zeros(nx)]
+        T.trac2grid(tr_x, f, mesh, tg[tname], gf, nx, avgscheme=[5, 6])
+        ref = oracle.trac2grid(tr_x, f, tg[tname], nx, [5, 6])
+        assert maxrel(gf[0], ref[0]) < 1e-12 and maxrel(gf[1], ref[1]) < 1e-11
+    F = rng.standard_normal(nx)
+    o = np.zeros((n, 1))
+    T.grid2trac(tr_x, o, tg["nodes"], [F], nx, stopOnError=True)
+    assert maxrel(o, oracle.grid2trac(tr_x, tg["nodes"], [F], nx)) < 1e-13
+    # encode -> decode property: scattering a field that is linear in (z,x) and gathering it
+    # back reproduces it away from the walls (bilinear weights are exact for linear data)
+    lin = (2.0 + tr_x[:, 0] / L[0] + 3 * tr_x[:, 1] / L[1])[:, None]
+    gl = [np.zeros(nx)]
+    T.trac2grid(tr_x, lin, mesh, tg["nodes"], gl, nx)
+    Z, X = mesh
+    exact = 2.0 + Z / L[0] + 3 * X / L[1]
+    assert np.max(np.abs(gl[0] - exact)[2:-2, 2:-2]) < 2e-2
