@@ -82,6 +82,12 @@ int  pl_stokes_solve(pl_ctx* ctx, const double* rhs, double* x, int use_x0, doub
  * vectors with HIP events (no host transfers); returns average ms per apply. */
 int  pl_stokes_apply_bench(pl_ctx* ctx, int reps, double* avg_ms);
 
+/* Diagnostics for component tests of the solver: z = M^-1 r for an UNSCALED residual r in
+ * the reference DOF order (builds the multigrid hierarchy for the current coefficients), and
+ * the hierarchy's level count / per-level Chebyshev lambda_max. */
+int  pl_stokes_precond_apply(pl_ctx* ctx, const double* r, double* z);
+int  pl_stokes_mg_info(pl_ctx* ctx, int* nlevels, double* lmax, int max_levels);
+
 /* ---- Heat: replaces makeDiffusionMatrix (pylamp_diff.py:85-183) + spsolve
  *      (pylamp2.py:419) --------------------------------------------------------------- */
 int  pl_heat_set_coeffs(pl_ctx* ctx, const double* zmp, const double* xmp, const double* T,

@@ -1,260 +1,211 @@
 """Algorithm prototype of the GPU Stokes solver (TEST/DESIGN INFRASTRUCTURE, not product).
 
-Right-preconditioned BiCGStab (seeded random shadow residual) on the reference's Stokes
-matrix with the block upper-triangular preconditioner
+Right-preconditioned BiCGStab (seeded random shadow residual) on the row-scaled reference
+Stokes matrix with the block upper-triangular preconditioner
         M = [[A_vv, A_vp], [0, S^]],   S^ = diag(Kc^2/eta_n) on continuity rows,
-where A_vv^-1 is approximated by geometric multigrid V-cycles on the staggered velocity
-block (rediscretised coarse operators, Chebyshev-Jacobi smoothing, wall/slave rows closed
-exactly).  Written with whole-array slicing so that every function maps 1:1 onto a HIP
-kernel in pylamp_amd/csrc/pl_solver.hip.  Used by tests to cross-check the HIP solver's
-iteration counts; never imported by the product.
+where A_vv^-1 is one geometric-multigrid V-cycle on the staggered velocity block:
+rediscretised coarse operators (arithmetic viscosity coarsening), Chebyshev-Jacobi smoothing,
+constraint rows closed exactly; the finest level keeps the reference's slaved boundary rows,
+coarse levels use natural mirror rows.  Arrays carry a one-node ring like the device planes,
+so every function maps 1:1 onto a kernel of pylamp_amd/csrc/pl_solver.hip.  Tests use it to
+check the HIP preconditioner component-wise; the product never imports it.
 """
 import numpy as np
 import scipy.sparse as sp
-import scipy.sparse.linalg as spla
 
 from . import pylamp_oracle as O
 
 
-class Level:
-    def __init__(self, nz, nx, hz, hx, etas, etan, bc):
-        self.nz, self.nx, self.hz, self.hx = nz, nx, hz, hx
-        self.etas, self.etan, self.bc = etas, etan, bc
-        self.lmax = None
+class Lv: pass
 
+def tables(n, h):
+    # index k+1 ; rd[k]=1/(x[k+1]-x[k]) for 0<=k<n-1 ; rD[k]=1/(x[k+1]-x[k-1]) for 1<=k<=n-2 ; else 0
+    rd=np.zeros(n+3); rD=np.zeros(n+3)
+    rd[1:n]=1.0/h
+    rD[2:n]=1.0/(2*h)
+    return rd,rD
 
-# ---- velocity block: interior rows only ------------------------------------------------
-def vv_coefs(L):
-    """Coefficient arrays of the interior momentum rows on a uniform grid."""
-    nz, nx, hz, hx = L.nz, L.nx, L.hz, L.hx
-    es, en = L.etas, L.etan
-    c = {}
-    # z-momentum rows i in [1,nz-2], j in [1,nx-3]
-    I = slice(1, nz - 1); J = slice(1, nx - 2)
-    c['zN'] = 2 * en[I, J] / hz**2
-    c['zS'] = 2 * en[0:nz - 2, J] / hz**2
-    c['zE'] = es[I, 2:nx - 1] / hx**2
-    c['zW'] = es[I, J] / hx**2
-    c['zxE'] = es[I, 2:nx - 1] / (hz * hx)
-    c['zxW'] = es[I, J] / (hz * hx)
-    # x-momentum rows i in [1,nz-3], j in [1,nx-2]
-    I = slice(1, nz - 2); J = slice(1, nx - 1)
-    c['xE'] = 2 * en[I, J] / hx**2
-    c['xW'] = 2 * en[I, 0:nx - 2] / hx**2
-    c['xN'] = es[2:nz - 1, J] / hz**2
-    c['xS'] = es[I, J] / hz**2
-    c['xzN'] = es[2:nz - 1, J] / (hz * hx)
-    c['xzS'] = es[I, J] / (hz * hx)
-    return c
+def pad(a):
+    return np.pad(a,1)
 
+def setup(nz,nx,hz,hx,etas,etan,bc,quirk):
+    L=Lv(); L.nz,L.nx,L.hz,L.hx,L.bc,L.quirk=nz,nx,hz,hx,bc,quirk
+    L.es=pad(etas); L.en=pad(etan)
+    L.rdz,L.rDz=tables(nz,hz); L.rdx,L.rDx=tables(nx,hx)
+    mz=np.zeros((nz,nx)); mx=np.zeros((nz,nx))
+    if quirk:
+        mz[1:nz-1,1:nx-2]=1; mx[1:nz-2,1:nx-1]=1
+    else:
+        mz[1:nz-1,0:nx-1]=1
+        mx[0:nz-1,1:nx-1]=1
+        if bc[0]!=O.BC_FREESLIP: mx[0,:]=0
+        if bc[2]!=O.BC_FREESLIP: mx[nz-2,:]=0
+    L.mz=pad(mz); L.mx=pad(mx)
+    # coefficient arrays for all rows (garbage where masked)
+    i=np.arange(nz); j=np.arange(nx)
+    rdz_i=L.rdz[i+1][:,None]; rdz_m=L.rdz[i][:,None]; rDz_i=L.rDz[i+1][:,None]; rDz_p=L.rDz[i+2][:,None]
+    rdx_j=L.rdx[j+1][None,:]; rdx_m=L.rdx[j][None,:]; rDx_j=L.rDx[j+1][None,:]; rDx_p=L.rDx[j+2][None,:]
+    C=slice(1,nz+1),slice(1,nx+1)
+    def sh(a,di,dj): return a[1+di:nz+1+di,1+dj:nx+1+dj]
+    es,en=L.es,L.en
+    L.zN=4*sh(en,0,0)*rdz_i*rDz_i; L.zS=4*sh(en,-1,0)*rdz_m*rDz_i
+    L.zE=2*sh(es,0,1)*rDx_p*rdx_j; L.zW=2*sh(es,0,0)*rDx_j*rdx_j
+    L.zxE=2*sh(es,0,1)*rDz_i*rdx_j; L.zxW=2*sh(es,0,0)*rDz_i*rdx_j
+    L.xE=4*sh(en,0,0)*rdx_j*rDx_j; L.xW=4*sh(en,0,-1)*rdx_m*rDx_j
+    L.xN=2*sh(es,1,0)*rDz_p*rdz_i; L.xS=2*sh(es,0,0)*rDz_i*rdz_i
+    L.xzN=2*sh(es,1,0)*rDx_j*rdz_i; L.xzS=2*sh(es,0,0)*rDx_j*rdz_i
+    dz=-(L.zN+L.zS+L.zE+L.zW); dx=-(L.xE+L.xW+L.xN+L.xS)
+    L.dz=np.pad(np.where(mz>0,dz,1.0),1,constant_values=1.0); L.dx=np.pad(np.where(mx>0,dx,1.0),1,constant_values=1.0)
+    L.sh=sh
+    return L
 
-def vv_apply(L, vz, vx):
-    nz, nx = L.nz, L.nx
-    c = L.c
-    yz = np.zeros_like(vz); yx = np.zeros_like(vx)
-    I = slice(1, nz - 1); J = slice(1, nx - 2); Ip = slice(2, nz); Im = slice(0, nz - 2)
-    Jp = slice(2, nx - 1); Jm = slice(0, nx - 3)
-    yz[I, J] = (c['zN'] * (vz[Ip, J] - vz[I, J]) - c['zS'] * (vz[I, J] - vz[Im, J])
-                + c['zE'] * (vz[I, Jp] - vz[I, J]) - c['zW'] * (vz[I, J] - vz[I, Jm])
-                + c['zxE'] * (vx[I, Jp] - vx[Im, Jp]) - c['zxW'] * (vx[I, J] - vx[Im, J]))
-    I = slice(1, nz - 2); J = slice(1, nx - 1); Ip = slice(2, nz - 1); Im = slice(0, nz - 3)
-    Jp = slice(2, nx); Jm = slice(0, nx - 2)
-    yx[I, J] = (c['xE'] * (vx[I, Jp] - vx[I, J]) - c['xW'] * (vx[I, J] - vx[I, Jm])
-                + c['xN'] * (vx[Ip, J] - vx[I, J]) - c['xS'] * (vx[I, J] - vx[Im, J])
-                + c['xzN'] * (vz[Ip, J] - vz[Ip, Jm]) - c['xzS'] * (vz[I, J] - vz[I, Jm]))
-    return yz, yx
+def apply(L,vz,vx):
+    sh=L.sh; nz,nx=L.nz,L.nx
+    yz=(L.zN*(sh(vz,1,0)-sh(vz,0,0))-L.zS*(sh(vz,0,0)-sh(vz,-1,0))+L.zE*(sh(vz,0,1)-sh(vz,0,0))-L.zW*(sh(vz,0,0)-sh(vz,0,-1))
+        +L.zxE*(sh(vx,0,1)-sh(vx,-1,1))-L.zxW*(sh(vx,0,0)-sh(vx,-1,0)))
+    yx=(L.xE*(sh(vx,0,1)-sh(vx,0,0))-L.xW*(sh(vx,0,0)-sh(vx,0,-1))+L.xN*(sh(vx,1,0)-sh(vx,0,0))-L.xS*(sh(vx,0,0)-sh(vx,-1,0))
+        +L.xzN*(sh(vz,1,0)-sh(vz,1,-1))-L.xzS*(sh(vz,0,0)-sh(vz,0,-1)))
+    return pad(yz)*L.mz, pad(yx)*L.mx
 
+def close(L,vz,vx,gz=None,gx=None):
+    """arrays padded (index+1). Enforce constraint rows; g = rhs/Kc on those rows (fine level only)."""
+    nz,nx=L.nz,L.nx
+    G=lambda g,s: 0.0 if g is None else g[s]
+    R=slice(1,nz+1); Cc=slice(1,nx+1)
+    if L.quirk:
+        vz[R,nx]=G(gz,(R,nx)); vz[1,1:nx]=G(gz,(1,slice(1,nx))); vz[nz,1:nx]=G(gz,(nz,slice(1,nx)))
+        I=slice(2,nz)
+        vz[I,1]=vz[I,2]+G(gz,(I,1)); vz[I,nx-1]=vz[I,nx-2]+G(gz,(I,nx-1))
+        vx[nz,Cc]=G(gx,(nz,Cc)); vx[1:nz,1]=G(gx,(slice(1,nz),1)); vx[1:nz,nx]=G(gx,(slice(1,nz),nx))
+        J=slice(2,nx)
+        if L.bc[0]==O.BC_FREESLIP: vx[1,J]=vx[2,J]+G(gx,(1,J))
+        else: vx[1,J]=(vx[2,J]/(2*L.hz)-G(gx,(1,J)))/(1.5/L.hz)
+        if L.bc[2]==O.BC_FREESLIP: vx[nz-1,J]=vx[nz-2,J]+G(gx,(nz-1,J))
+        else: vx[nz-1,J]=(vx[nz-2,J]/(2*L.hz)+G(gx,(nz-1,J)))/(1.5/L.hz)
+    else:
+        vz[1,:]=0; vz[nz,:]=0            # no flow through z walls
+        vz[:,nx]=vz[:,nx-1]; vz[:,0]=vz[:,1]      # mirror ghosts (x walls, free slip)
+        vx[:,1]=0; vx[:,nx]=0
+        J=slice(2,nx)
+        if L.bc[0]==O.BC_FREESLIP: vx[0,:]=vx[1,:]
+        else: vx[1,J]=vx[2,J]/3.0
+        if L.bc[2]==O.BC_FREESLIP: vx[nz,:]=vx[nz-1,:]
+        else: vx[nz-1,J]=vx[nz-2,J]/3.0; vx[nz,:]=0
 
-def vv_diag(L):
-    c = L.c
-    dz = np.ones((L.nz, L.nx)); dx = np.ones((L.nz, L.nx))
-    dz[1:L.nz - 1, 1:L.nx - 2] = -(c['zN'] + c['zS'] + c['zE'] + c['zW'])
-    dx[1:L.nz - 2, 1:L.nx - 1] = -(c['xE'] + c['xW'] + c['xN'] + c['xS'])
-    return dz, dx
-
-
-def bc_close(L, vz, vx, gz=None, gx=None):
-    """Solve the wall / slave / ghost rows exactly for the given right-hand side g (already
-    divided by Kc); g=None means homogeneous (coarse-grid corrections)."""
-    nz, nx = L.nz, L.nx
-    z = lambda a, s: 0.0 if a is None else a[s]
-    vz[:, nx - 1] = z(gz, (slice(None), nx - 1))
-    vz[0, :nx - 1] = z(gz, (0, slice(0, nx - 1)))
-    vz[nz - 1, :nx - 1] = z(gz, (nz - 1, slice(0, nx - 1)))
-    vz[1:nz - 1, 0] = vz[1:nz - 1, 1] + z(gz, (slice(1, nz - 1), 0))
-    vz[1:nz - 1, nx - 2] = vz[1:nz - 1, nx - 3] + z(gz, (slice(1, nz - 1), nx - 2))
-    vx[nz - 1, :] = z(gx, (nz - 1, slice(None)))
-    vx[:nz - 1, 0] = z(gx, (slice(0, nz - 1), 0))
-    vx[:nz - 1, nx - 1] = z(gx, (slice(0, nz - 1), nx - 1))
-    J = slice(1, nx - 1)
-    if L.bc[0] == O.BC_FREESLIP:
-        vx[0, J] = vx[1, J] + z(gx, (0, J))
-    else:   # NOSLIP linear extrapolation row: (-1/(2h) - 1/h) vx0 + vx1/(2h) = g
-        vx[0, J] = (vx[1, J] / (2 * L.hz) - z(gx, (0, J))) / (1.5 / L.hz)
-    if L.bc[2] == O.BC_FREESLIP:
-        vx[nz - 2, J] = vx[nz - 3, J] + z(gx, (nz - 2, J))
-    else:   # (1/(2h) + 1/h) vx[m-1] - vx[m-2]/(2h) = g
-        vx[nz - 2, J] = (vx[nz - 3, J] / (2 * L.hz) + z(gx, (nz - 2, J))) / (1.5 / L.hz)
-
-
-def estimate_lmax(L, iters=12, seed=0):
-    rng = np.random.default_rng(seed)
-    vz = rng.standard_normal((L.nz, L.nx)); vx = rng.standard_normal((L.nz, L.nx))
-    lam = 2.0
+def lmax_est(L,iters=15):
+    rng=np.random.default_rng(0)
+    vz=rng.standard_normal(L.mz.shape); vx=rng.standard_normal(L.mz.shape)
+    lam=2.0
     for _ in range(iters):
-        bc_close(L, vz, vx)
-        yz, yx = vv_apply(L, vz, vx)
-        yz /= L.dz; yx /= L.dx
-        yz[L.mz == 0] = 0; yx[L.mx == 0] = 0
-        lam = np.sqrt((np.sum(yz**2) + np.sum(yx**2)) / (np.sum((vz * L.mz)**2) + np.sum((vx * L.mx)**2)))
-        vz, vx = yz / lam, yx / lam
+        vz*=L.mz; vx*=L.mx
+        n0=np.sqrt(np.sum(vz**2)+np.sum(vx**2))
+        close(L,vz,vx)
+        yz,yx=apply(L,vz,vx); yz/=L.dz; yx/=L.dx
+        lam=np.sqrt(np.sum(yz**2)+np.sum(yx**2))/n0
+        vz,vx=yz/lam,yx/lam
     return lam
 
+def smooth(L,vz,vx,fz,fx,n,gz=None,gx=None,ratio=6.0):
+    lmax=L.lmax; lmin=lmax/ratio
+    theta=0.5*(lmax+lmin); delta=0.5*(lmax-lmin); sigma=theta/delta; rho_old=1/sigma
+    close(L,vz,vx,gz,gx)
+    yz,yx=apply(L,vz,vx)
+    rz=(fz-yz)/L.dz*L.mz; rx=(fx-yx)/L.dx*L.mx
+    dz=rz/theta; dx=rx/theta
+    for k in range(n):
+        vz+=dz; vx+=dx
+        close(L,vz,vx,gz,gx)
+        if k==n-1: break
+        yz,yx=apply(L,vz,vx)
+        rz=(fz-yz)/L.dz*L.mz; rx=(fx-yx)/L.dx*L.mx
+        rho=1/(2*sigma-rho_old)
+        dz=rho*rho_old*dz+2*rho/delta*rz; dx=rho*rho_old*dx+2*rho/delta*rx
+        rho_old=rho
 
-def setup_level(L):
-    L.c = vv_coefs(L)
-    L.dz, L.dx = vv_diag(L)
-    L.mz = np.zeros((L.nz, L.nx)); L.mz[1:L.nz - 1, 1:L.nx - 2] = 1
-    L.mx = np.zeros((L.nz, L.nx)); L.mx[1:L.nz - 2, 1:L.nx - 1] = 1
-    L.lmax = 1.1 * estimate_lmax(L)
+def restrict(L,Lc,rz,rx):
+    """padded in/out. vz: vertex in z (1/4,1/2,1/4), cell-centred in x (1/8,3/8,3/8,1/8)."""
+    nzc,nxc=Lc.nz,Lc.nx
+    cz=np.zeros((nzc+2,nxc+2)); cx=np.zeros((nzc+2,nxc+2))
+    # unpadded fine index fi -> padded fi+1.  Need fine indices -1..n (pad has them: index 0 and n+1) and n+1 -> extend
+    rzp=np.pad(rz,((0,0),(0,2))); rxp=np.pad(rx,((0,2),(0,0)))
+    I=np.arange(nzc); J=np.arange(nxc)
+    # vz coarse (I,J): fine rows 2I-1,2I,2I+1 ; fine cols 2J-1,2J,2J+1,2J+2
+    def gz_(di,dj): 
+        ii=np.clip(2*I+di+1,0,rzp.shape[0]-1); jj=2*J+dj+1
+        return rzp[np.ix_(ii,jj)]
+    t=0
+    for di,wi in ((-1,.25),(0,.5),(1,.25)):
+        for dj,wj in ((-1,.125),(0,.375),(1,.375),(2,.125)):
+            t=t+wi*wj*gz_(di,dj)
+    cz[1:nzc+1,1:nxc+1]=t
+    def gx_(di,dj):
+        ii=2*I+di+1; jj=np.clip(2*J+dj+1,0,rxp.shape[1]-1)
+        return rxp[np.ix_(ii,jj)]
+    t=0
+    for di,wi in ((-1,.125),(0,.375),(1,.375),(2,.125)):
+        for dj,wj in ((-1,.25),(0,.5),(1,.25)):
+            t=t+wi*wj*gx_(di,dj)
+    cx[1:nzc+1,1:nxc+1]=t
+    return cz*Lc.mz, cx*Lc.mx
 
+def prolong(L,Lc,ez,ex):
+    """coarse padded (closed: ghosts/mirrors valid) -> fine padded correction"""
+    nz,nx=L.nz,L.nx; nzc,nxc=Lc.nz,Lc.nx
+    fz=np.zeros((nz+2,nx+2)); fx=np.zeros((nz+2,nx+2))
+    # vz: z vertex-linear, x cell-linear (3/4,1/4).  fine (i,j): 
+    i=np.arange(nz); j=np.arange(nx)
+    I0=i//2; I1=(i+1)//2                      # z: even -> I0=I1, odd -> average
+    Jn=j//2; Jo=np.where(j%2==0,Jn-1,Jn+1)    # x: nearest coarse centre and the other one
+    Jo=np.clip(Jo,-1,nxc)                      # ring indices allowed (-1 -> padded 0, nxc -> padded nxc+1)
+    Jn=np.clip(Jn,0,nxc)
+    a=0.5*(ez[np.ix_(I0+1,Jn+1)]+ez[np.ix_(I1+1,Jn+1)]); b=0.5*(ez[np.ix_(I0+1,Jo+1)]+ez[np.ix_(I1+1,Jo+1)])
+    fz[1:nz+1,1:nx+1]=0.75*a+0.25*b
+    J0=j//2; J1=(j+1)//2
+    In=i//2; Io=np.where(i%2==0,In-1,In+1); Io=np.clip(Io,-1,nzc); In=np.clip(In,0,nzc)
+    a=0.5*(ex[np.ix_(In+1,J0+1)]+ex[np.ix_(In+1,J1+1)]); b=0.5*(ex[np.ix_(Io+1,J0+1)]+ex[np.ix_(Io+1,J1+1)])
+    fx[1:nz+1,1:nx+1]=0.75*a+0.25*b
+    return fz*L.mz, fx*L.mx
 
-def smooth(L, vz, vx, fz, fx, nsweep, gz=None, gx=None, ratio=6.0):
-    """Chebyshev-accelerated Jacobi on the interior rows, eigenvalue window [lmax/ratio, lmax]."""
-    lmax = L.lmax; lmin = lmax / ratio
-    theta = 0.5 * (lmax + lmin); delta = 0.5 * (lmax - lmin)
-    sigma = theta / delta
-    rho_old = 1.0 / sigma
-    bc_close(L, vz, vx, gz, gx)
-    yz, yx = vv_apply(L, vz, vx)
-    rz = (fz - yz) / L.dz * L.mz; rx = (fx - yx) / L.dx * L.mx
-    dz = rz / theta; dx = rx / theta
-    for k in range(nsweep):
-        vz += dz; vx += dx
-        bc_close(L, vz, vx, gz, gx)
-        if k == nsweep - 1:
-            break
-        yz, yx = vv_apply(L, vz, vx)
-        rz = (fz - yz) / L.dz * L.mz; rx = (fx - yx) / L.dx * L.mx
-        rho = 1.0 / (2 * sigma - rho_old)
-        dz = rho * rho_old * dz + 2 * rho / delta * rz
-        dx = rho * rho_old * dx + 2 * rho / delta * rx
-        rho_old = rho
+def coarsen_visc(es,en,mode):
+    f,g={"geom":(np.log,np.exp),"arith":(lambda a:a,lambda a:a),"harm":(lambda a:1/a,lambda a:1/a)}[mode]
+    nz,nx=es.shape
+    p=np.pad(f(es),1,mode='edge')
+    w=(p[:-2,:-2]+p[:-2,2:]+p[2:,:-2]+p[2:,2:])/16+(p[:-2,1:-1]+p[2:,1:-1]+p[1:-1,:-2]+p[1:-1,2:])/8+p[1:-1,1:-1]/4
+    esc=g(w[0::2,0::2])
+    nzc,nxc=esc.shape
+    a=f(en[:nz-1,:nx-1])
+    enc=np.ones((nzc,nxc))
+    enc[:nzc-1,:nxc-1]=g(0.25*(a[0::2,0::2]+a[1::2,0::2]+a[0::2,1::2]+a[1::2,1::2]))
+    enc[nzc-1,:]=enc[nzc-2,:]; enc[:,nxc-1]=enc[:,nxc-2]
+    return esc,enc
 
-
-# ---- transfers ---------------------------------------------------------------------------
-def restrict_z(L, Lc, rz):
-    """vz residual (vertex in z, cell-centred in x) -> coarse.  Full weighting in z
-    [1/4,1/2,1/4], [1/8,3/8,3/8,1/8] in x (transpose of linear interpolation)."""
-    nzc, nxc = Lc.nz, Lc.nx
-    out = np.zeros((nzc, nxc))
-    r = rz
-    # x first: coarse J (0..nxc-2) from fine 2J-1,2J,2J+1,2J+2
-    t = np.zeros((L.nz, nxc))
-    pad = np.zeros((L.nz, L.nx + 3)); pad[:, 1:L.nx + 1] = r          # pad[:, j+1] = r[:, j]
-    J = np.arange(nxc - 1)
-    t[:, :nxc - 1] = 0.125 * pad[:, 2 * J] + 0.375 * pad[:, 2 * J + 1] + 0.375 * pad[:, 2 * J + 2] + 0.125 * pad[:, 2 * J + 3]
-    I = np.arange(1, nzc - 1)
-    out[1:nzc - 1, :] = 0.25 * t[2 * I - 1, :] + 0.5 * t[2 * I, :] + 0.25 * t[2 * I + 1, :]
-    return out * Lc.mz
-
-
-def restrict_x(L, Lc, rx):
-    nzc, nxc = Lc.nz, Lc.nx
-    out = np.zeros((nzc, nxc))
-    pad = np.zeros((L.nz + 3, L.nx)); pad[1:L.nz + 1, :] = rx
-    I = np.arange(nzc - 1)
-    t = np.zeros((nzc, L.nx))
-    t[:nzc - 1, :] = 0.125 * pad[2 * I, :] + 0.375 * pad[2 * I + 1, :] + 0.375 * pad[2 * I + 2, :] + 0.125 * pad[2 * I + 3, :]
-    J = np.arange(1, nxc - 1)
-    out[:, 1:nxc - 1] = 0.25 * t[:, 2 * J - 1] + 0.5 * t[:, 2 * J] + 0.25 * t[:, 2 * J + 1]
-    return out * Lc.mx
-
-
-def prolong_z(L, Lc, ez):
-    """coarse vz correction -> fine (linear in z at vertices, linear in x between centres)."""
-    nz, nx = L.nz, L.nx
-    nzc, nxc = Lc.nz, Lc.nx
-    # z direction: fine 2I = coarse I, fine 2I+1 = mean
-    t = np.zeros((nz, nxc))
-    t[0::2, :] = ez
-    t[1::2, :] = 0.5 * (ez[:-1, :] + ez[1:, :])
-    out = np.zeros((nz, nx))
-    # x direction, cell-centred: fine 2J = 3/4 c[J] + 1/4 c[J-1]; fine 2J+1 = 3/4 c[J] + 1/4 c[J+1]
-    pad = np.zeros((nz, nxc + 1)); pad[:, 1:] = t                       # pad[:, J+1] = t[:, J]; pad[:,0] = c[-1]
-    pad[:, 0] = t[:, 0]                                                 # mirror at the wall
-    J = np.arange(nxc - 1)
-    out[:, 2 * J] = 0.75 * pad[:, J + 1] + 0.25 * pad[:, J]
-    tn = np.concatenate([t[:, 1:nxc - 1], t[:, nxc - 2:nxc - 1]], axis=1)  # c[J+1], mirrored at the end
-    out[:, 2 * J + 1] = 0.75 * t[:, :nxc - 1] + 0.25 * tn
-    return out
-
-
-def prolong_x(L, Lc, ex):
-    nz, nx = L.nz, L.nx
-    nzc, nxc = Lc.nz, Lc.nx
-    t = np.zeros((nzc, nx))
-    t[:, 0::2] = ex
-    t[:, 1::2] = 0.5 * (ex[:, :-1] + ex[:, 1:])
-    out = np.zeros((nz, nx))
-    pad = np.zeros((nzc + 1, nx)); pad[1:, :] = t; pad[0, :] = t[0, :]
-    I = np.arange(nzc - 1)
-    out[2 * I, :] = 0.75 * pad[I + 1, :] + 0.25 * pad[I, :]
-    tn = np.concatenate([t[1:nzc - 1, :], t[nzc - 2:nzc - 1, :]], axis=0)
-    out[2 * I + 1, :] = 0.75 * t[:nzc - 1, :] + 0.25 * tn
-    return out
-
-
-def coarsen_visc(L, mode="geom"):
-    """etas at coarse nodes, etan at coarse centres."""
-    f = np.log if mode == "geom" else (lambda a: a)
-    g = np.exp if mode == "geom" else (lambda a: a)
-    nz, nx = L.nz, L.nx
-    nzc, nxc = (nz - 1) // 2 + 1, (nx - 1) // 2 + 1
-    es = f(L.etas); en = f(L.etan)
-    # coarse node (I,J) = fine node (2I,2J): weighted average of the 3x3 neighbourhood
-    p = np.pad(es, 1, mode='edge')
-    w = (p[:-2, :-2] + p[:-2, 2:] + p[2:, :-2] + p[2:, 2:]) / 16 + (p[:-2, 1:-1] + p[2:, 1:-1] + p[1:-1, :-2] + p[1:-1, 2:]) / 8 + p[1:-1, 1:-1] / 4
-    esc = g(w[0::2, 0::2])
-    # coarse centre (I,J) covers fine centres (2I..2I+1, 2J..2J+1)
-    enc = np.ones((nzc, nxc)) * np.exp(np.mean(np.log(L.etan[:nz - 1, :nx - 1])))
-    a = en[:nz - 1, :nx - 1]
-    enc[:nzc - 1, :nxc - 1] = g(0.25 * (a[0::2, 0::2] + a[1::2, 0::2] + a[0::2, 1::2] + a[1::2, 1::2]))
-    return nzc, nxc, esc, enc
-
-
-def build_hierarchy(nx, grid, etas, etan, bc, min_cells=4):
-    nz, nxx = nx
-    hz = (grid[0][-1] - grid[0][0]) / (nz - 1); hx = (grid[1][-1] - grid[1][0]) / (nxx - 1)
-    etan = np.array(etan, copy=True)
-    bad = ~np.isfinite(etan)
-    etan[bad] = np.exp(np.mean(np.log(etan[~bad])))
-    levels = [Level(nz, nxx, hz, hx, np.asarray(etas), etan, bc)]
+def hierarchy(nx,grid,etas,etan,bc,mode="geom",natural=True,min_cells=4):
+    nz,nxx=nx
+    hz=(grid[0][-1]-grid[0][0])/(nz-1); hx=(grid[1][-1]-grid[1][0])/(nxx-1)
+    etan=np.array(etan,copy=True); bad=~np.isfinite(etan); etan[bad]=np.exp(np.mean(np.log(etan[~bad])))
+    es,en=np.asarray(etas),etan
+    Ls=[setup(nz,nxx,hz,hx,es,en,bc,True)]
     while True:
-        L = levels[-1]
-        if (L.nz - 1) % 2 or (L.nx - 1) % 2 or (L.nz - 1) // 2 < min_cells or (L.nx - 1) // 2 < min_cells:
-            break
-        nzc, nxc, esc, enc = coarsen_visc(L)
-        levels.append(Level(nzc, nxc, 2 * L.hz, 2 * L.hx, esc, enc, bc))
-    for L in levels:
-        setup_level(L)
-    return levels
+        L=Ls[-1]
+        if (L.nz-1)%2 or (L.nx-1)%2 or (L.nz-1)//2<min_cells or (L.nx-1)//2<min_cells: break
+        es,en=coarsen_visc(es,en,mode)
+        Ls.append(setup((L.nz-1)//2+1,(L.nx-1)//2+1,2*L.hz,2*L.hx,es,en,bc,not natural))
+    for L in Ls: L.lmax=1.1*lmax_est(L)
+    return Ls
 
-
-def vcycle(levels, l, fz, fx, gz=None, gx=None, nu=(3, 3), coarse_sweeps=40):
-    L = levels[l]
-    vz = np.zeros((L.nz, L.nx)); vx = np.zeros((L.nz, L.nx))
-    if l == len(levels) - 1:
-        smooth(L, vz, vx, fz, fx, coarse_sweeps, gz, gx, ratio=max(30.0, 0.4 * (L.nz * L.nx)))
-        return vz, vx
-    smooth(L, vz, vx, fz, fx, nu[0], gz, gx)
-    yz, yx = vv_apply(L, vz, vx)
-    rz = (fz - yz) * L.mz; rx = (fx - yx) * L.mx
-    Lc = levels[l + 1]
-    ez, ex = vcycle(levels, l + 1, restrict_z(L, Lc, rz), restrict_x(L, Lc, rx), None, None, nu, coarse_sweeps)
-    vz += prolong_z(L, Lc, ez); vx += prolong_x(L, Lc, ex)
-    smooth(L, vz, vx, fz, fx, nu[1], gz, gx)
-    return vz, vx
+def vcycle(Ls,l,fz,fx,gz=None,gx=None,nu=(3,3),csweeps=40,damp=1.0):
+    L=Ls[l]
+    vz=np.zeros_like(fz); vx=np.zeros_like(fx)
+    if l==len(Ls)-1:
+        smooth(L,vz,vx,fz,fx,csweeps,gz,gx,ratio=max(30.0,0.4*L.nz*L.nx)); return vz,vx
+    smooth(L,vz,vx,fz,fx,nu[0],gz,gx)
+    yz,yx=apply(L,vz,vx)
+    cz,cx=restrict(L,Ls[l+1],(fz-yz)*L.mz,(fx-yx)*L.mx)
+    ez,ex=vcycle(Ls,l+1,cz,cx,None,None,nu,csweeps,damp)
+    pz,px=prolong(L,Ls[l+1],ez,ex)
+    vz+=damp*pz; vx+=damp*px
+    smooth(L,vz,vx,fz,fx,nu[1],gz,gx)
+    return vz,vx
 
 
 # ---- outer solver ----------------------------------------------------------------------------
@@ -268,84 +219,80 @@ def join(vz, vx, p):
 
 
 class Precond:
-    def __init__(self, nx, grid, etas, etan, rho, bc, inner="mg", ncyc=1, nu=(3, 3)):
+    """z = M^-1 r for UNSCALED r in the reference DOF order."""
+
+    def __init__(self, nx, grid, etas, etan, rho, bc, nu=(2, 2), mode="arith", lmax=None):
         self.nx = nx
         self.A, self.b = O.stokes_csr(nx, grid, etas, etan, rho, bc)
         self.Kc, self.Kb = O.stokes_scaling(grid, etas, etan)
         N = nx[0] * nx[1]
         iv = np.sort(np.concatenate([np.arange(N) * 3, np.arange(N) * 3 + 1])); ip = np.arange(N) * 3 + 2
-        self.iv, self.ip = iv, ip
         self.Avp = self.A[iv][:, ip].tocsr()
-        self.inner = inner; self.ncyc = ncyc; self.nu = nu
+        self.nu = nu
         self.cls = O.stokes_row_class(nx)
         en = np.array(etan, copy=True); en[~np.isfinite(en)] = 1.0
         self.Sinv = np.where(self.cls[2] == 1, en / self.Kc**2, 1.0 / self.Kc)
+        self.Ls = hierarchy(nx, grid, etas, etan, bc, mode=mode, natural=True)
+        if lmax is not None:
+            for L, lm in zip(self.Ls, lmax):
+                L.lmax = lm
         self.napply = 0
-        if inner == "exact":
-            self.lu = spla.splu(self.A[iv][:, iv].tocsc())
-        else:
-            self.levels = build_hierarchy(nx, grid, etas, etan, bc)
 
     def apply(self, r):
         self.napply += 1
         nx = self.nx
         rz, rx, rp = split(r, nx)
         zp = self.Sinv * rp
-        # corner rows: Kb (P_nb - P_c) = r  ->  P_c = P_nb - r/Kb
         for i0 in (0, nx[0] - 2):
             zp[i0, 0] = zp[i0, 1] - rp[i0, 0] / self.Kb
             zp[i0, nx[1] - 2] = zp[i0, nx[1] - 3] - rp[i0, nx[1] - 2] / self.Kb
         rv = np.stack([rz, rx], axis=2).reshape(-1) - self.Avp @ zp.reshape(-1)
-        if self.inner == "exact":
-            zv = self.lu.solve(rv)
-            Z = zv.reshape(nx[0], nx[1], 2)
-            return join(Z[:, :, 0], Z[:, :, 1], zp)
         R = rv.reshape(nx[0], nx[1], 2)
-        fz, fx = R[:, :, 0].copy(), R[:, :, 1].copy()
-        L0 = self.levels[0]
-        gz = fz / self.Kc; gx = fx / self.Kc          # wall-row right-hand sides
-        if L0.bc[0] != O.BC_FREESLIP:
-            pass
-        vz = np.zeros(nx); vx = np.zeros(nx)
-        for c in range(self.ncyc):
-            if c == 0:
-                vz, vx = vcycle(self.levels, 0, fz * L0.mz, fx * L0.mx, gz, gx, self.nu)
-            else:
-                yz, yx = vv_apply(L0, vz, vx)
-                ez, ex = vcycle(self.levels, 0, (fz - yz) * L0.mz, (fx - yx) * L0.mx, None, None, self.nu)
-                vz += ez; vx += ex
-        return join(vz, vx, zp)
+        L0 = self.Ls[0]
+        fz = np.pad(R[:, :, 0], 1); fx = np.pad(R[:, :, 1], 1)
+        gz = fz / self.Kc; gx = fx / self.Kc
+        vz, vx = vcycle(self.Ls, 0, fz * L0.mz, fx * L0.mx, gz, gx, self.nu)
+        return join(vz[1:-1, 1:-1], vx[1:-1, 1:-1], zp)
 
 
-def bicgstab(A, b, M, rtol=1e-10, maxit=200, seed=1234, verbose=False):
+class Scaled:
+    """Row-scaled system (D_r A, D_r b) with the preconditioner M^-1 D_r^-1."""
+
+    def __init__(self, M, nx, grid):
+        self.M = M
+        d = np.abs(M.A.diagonal())
+        cls = O.stokes_row_class(nx)
+        hz = (grid[0][-1] - grid[0][0]) / (nx[0] - 1); hx = (grid[1][-1] - grid[1][0]) / (nx[1] - 1)
+        dd = d.reshape(nx[0], nx[1], 3).copy()
+        dd[:, :, 2][cls[2] == 1] = M.Kc * (1 / hz + 1 / hx)
+        self.s = 1.0 / dd.reshape(-1)
+        self.A = sp.diags(self.s) @ M.A
+        self.b = self.s * M.b
+
+    def apply(self, r):
+        return self.M.apply(r / self.s)
+
+
+def bicgstab(A, b, M, rtol=1e-10, maxit=200, seed=1234):
     n = b.size
-    x = np.zeros(n)
-    r = b.copy()
-    rng = np.random.default_rng(seed)
-    rt = rng.standard_normal(n)
+    x = np.zeros(n); r = b.copy()
+    rt = np.random.default_rng(seed).standard_normal(n)
     rho = alpha = omega = 1.0
     v = np.zeros(n); p = np.zeros(n)
     bn = np.linalg.norm(b)
-    hist = []
+    it = 0
     for it in range(1, maxit + 1):
         rho_new = rt @ r
         beta = (rho_new / rho) * (alpha / omega)
         p = r + beta * (p - omega * v)
-        y = M.apply(p)
-        v = A @ y
+        y = M.apply(p); v = A @ y
         alpha = rho_new / (rt @ v)
         s = r - alpha * v
-        z = M.apply(s)
-        t = A @ z
+        z = M.apply(s); t = A @ z
         omega = (t @ s) / (t @ t)
         x = x + alpha * y + omega * z
         r = s - omega * t
         rho = rho_new
-        res = np.linalg.norm(r) / bn
-        hist.append(res)
-        if verbose:
-            print(it, res)
-        if res < rtol:
+        if np.linalg.norm(r) / bn < rtol:
             break
-    true = np.linalg.norm(b - A @ x) / bn
-    return x, it, true, hist
+    return x, it, np.linalg.norm(b - A @ x) / bn

@@ -1,16 +1,846 @@
-// Krylov solvers (placeholder until the preconditioned solvers land in this file).
+// Krylov solvers replacing the reference's scipy.sparse.linalg.spsolve call sites
+// (pylamp2.py:360,394 Stokes; pylamp2.py:419 heat).
+//
+// Stokes:  right-preconditioned BiCGStab with a seeded random shadow residual on the
+// ROW-SCALED system (D_r A) x = D_r b  (scaling makes ||r|| track the velocity error over
+// 6 decades of viscosity; it does not change x).  Preconditioner: block upper triangular
+//        M = [[A_vv, A_vp], [0, S^]],  S^ = diag(Kc^2/eta_n) on continuity rows,
+// with A_vv^-1 ~ one geometric-multigrid V-cycle on the staggered velocity block:
+// rediscretised coarse operators (arithmetic viscosity coarsening), Chebyshev-Jacobi
+// smoothing, constraint rows (walls, slaved tangential rows, ghosts) closed inside every
+// kernel.  The finest level uses the reference's rows (slaved outermost in-domain
+// velocities, pylamp_stokes.py:170-175,209-214,249-255,296-301); coarse levels use natural
+// mirror rows so the effective wall does not move by h_l per level.
+// Heat: BiCGStab on the Jacobi-scaled operator.
+//
+// Algorithm prototype with the same structure: oracle/proto_stokes_solver.py (tests only).
 #include "pl_internal.h"
+#include <cmath>
+#include <functional>
+#include <limits>
+
+#define TB(tab, k) (tab)[(k) + 1]
+
+void pl_launch_heat_rhs(pl_ctx* ctx, const PlHeatOp& op, const double* Told, const double* H, double* rhs);
+
+// =========================================================================================
+// Velocity block
+// =========================================================================================
+struct PlVvOp {
+    PlGeom g;
+    const double* etas; const double* etan;
+    int slave_x;            // vz rows j=0 / j=nx-2 slaved to their inner neighbour (reference rows)
+    int slave_z0, slave_zL; // vx rows i=0 / i=nz-2 slaved (reference rows, or NOSLIP on any level)
+    double s0, sL;          // slave factor: v_slave = s * v_master
+};
+
+enum { VV_ZERO = 0, VV_INT = 1, VV_SLAVE = 2 };
+
+__device__ inline int vv_cls_z(const PlVvOp& op, int i, int j, int& moff, double& s) {
+    const int nz = op.g.nz, nx = op.g.nx;
+    moff = 0; s = 1.0;
+    if (j >= nx - 1 || i <= 0 || i >= nz - 1) return VV_ZERO;
+    if (op.slave_x) {
+        if (j == 0) { moff = 1; s = 1.0; return VV_SLAVE; }
+        if (j == nx - 2) { moff = -1; s = 1.0; return VV_SLAVE; }
+    }
+    return VV_INT;
+}
+
+__device__ inline int vv_cls_x(const PlVvOp& op, int i, int j, int& moff, double& s) {
+    const int nz = op.g.nz, nx = op.g.nx;
+    moff = 0; s = 1.0;
+    if (i >= nz - 1 || j <= 0 || j >= nx - 1) return VV_ZERO;
+    if (i == 0 && op.slave_z0) { moff = op.g.pitch; s = op.s0; return VV_SLAVE; }
+    if (i == nz - 2 && op.slave_zL) { moff = -op.g.pitch; s = op.sL; return VV_SLAVE; }
+    return VV_INT;
+}
+
+// (A_vv v)_z and -diag at global node (i,j), plane offset c.  Zero-padded tables make the
+// mirror terms of the natural rows vanish (rDx[0] = rDx[nx-1] = 0, same in z).
+__device__ inline void vv_row_z(const PlVvOp& op, const double* __restrict__ vz, const double* __restrict__ vx,
+                                long long c, int i, int j, double& Av, double& dg) {
+    const PlGeom& g = op.g;
+    const int p = g.pitch;
+    const double rdz_i = TB(g.rdz, i), rdz_m = TB(g.rdz, i - 1), rDz_i = TB(g.rDz, i);
+    const double rdx_j = TB(g.rdx, j), rDx_j = TB(g.rDx, j), rDx_p = TB(g.rDx, j + 1);
+    const double esC = op.etas[c], esE = op.etas[c + 1];
+    const double cN = 4.0 * op.etan[c] * rdz_i * rDz_i, cS = 4.0 * op.etan[c - p] * rdz_m * rDz_i;
+    const double cE = 2.0 * esE * rDx_p * rdx_j, cW = 2.0 * esC * rDx_j * rdx_j;
+    const double xE = 2.0 * esE * rDz_i * rdx_j, xW = 2.0 * esC * rDz_i * rdx_j;
+    const double v0 = vz[c];
+    Av = cN * (vz[c + p] - v0) - cS * (v0 - vz[c - p]) + cE * (vz[c + 1] - v0) - cW * (v0 - vz[c - 1]) +
+         xE * (vx[c + 1] - vx[c - p + 1]) - xW * (vx[c] - vx[c - p]);
+    dg = cN + cS + cE + cW;
+}
+
+__device__ inline void vv_row_x(const PlVvOp& op, const double* __restrict__ vz, const double* __restrict__ vx,
+                                long long c, int i, int j, double& Av, double& dg) {
+    const PlGeom& g = op.g;
+    const int p = g.pitch;
+    const double rdx_j = TB(g.rdx, j), rdx_m = TB(g.rdx, j - 1), rDx_j = TB(g.rDx, j);
+    const double rdz_i = TB(g.rdz, i), rDz_i = TB(g.rDz, i), rDz_p = TB(g.rDz, i + 1);
+    const double esC = op.etas[c], esN = op.etas[c + p];
+    const double cE = 4.0 * op.etan[c] * rdx_j * rDx_j, cW = 4.0 * op.etan[c - 1] * rdx_m * rDx_j;
+    const double cN = 2.0 * esN * rDz_p * rdz_i, cS = 2.0 * esC * rDz_i * rdz_i;
+    const double zN = 2.0 * esN * rDx_j * rdz_i, zS = 2.0 * esC * rDx_j * rdz_i;
+    const double v0 = vx[c];
+    Av = cE * (vx[c + 1] - v0) - cW * (v0 - vx[c - 1]) + cN * (vx[c + p] - v0) - cS * (v0 - vx[c - p]) +
+         zN * (vz[c + p] - vz[c + p - 1]) - zS * (vz[c] - vz[c - 1]);
+    dg = cE + cW + cN + cS;
+}
+
+#define PL_NODE_PROLOGUE(g)                                                         \
+    const int lj = blockIdx.x * 64 + threadIdx.x, li = blockIdx.y * 4 + threadIdx.y; \
+    if (lj >= (g).lnx || li >= (g).lnz) return;                                      \
+    const int i = (g).gi0 + li, j = (g).gj0 + lj;                                    \
+    const long long c = pl_idx((g), li, lj);
+
+// One Chebyshev-Jacobi sweep in three-term form:
+//     v_next = v_cur + c1 (v_cur - v_prev) + c2 D^-1 (f - A v_cur)
+// with the constraint rows closed in the same pass (a slave thread evaluates its master's
+// update; all inputs are read-only so there is no ordering hazard).  80 B/node/sweep.
+__global__ __launch_bounds__(256) void k_vv_cheb(PlVvOp op, const double* __restrict__ vcur,
+                                                 const double* __restrict__ vprev, const double* __restrict__ f,
+                                                 double* __restrict__ vnext, double c1, double c2) {
+    PL_NODE_PROLOGUE(op.g)
+    const long long P = op.g.plane;
+    const double* vz = vcur; const double* vx = vcur + P;
+    int moff = 0; double s = 1.0;
+    int cls = vv_cls_z(op, i, j, moff, s);
+    double out = 0.0;
+    if (cls != VV_ZERO) {
+        const long long cm = c + moff;
+        double Av, dg;
+        vv_row_z(op, vz, vx, cm, i, j + moff, Av, dg);             // moff is +-1 for vz
+        const double v0 = vz[cm];
+        const double mom = (c1 != 0.0) ? c1 * (v0 - vprev[cm]) : 0.0;
+        out = s * (v0 + mom + c2 * (Av - f[cm]) / dg);              // D = -dg
+    }
+    vnext[c] = out;
+    cls = vv_cls_x(op, i, j, moff, s);
+    out = 0.0;
+    if (cls != VV_ZERO) {
+        const long long cm = c + moff;
+        const int im = i + (moff > 0 ? 1 : (moff < 0 ? -1 : 0));
+        double Av, dg;
+        vv_row_x(op, vz, vx, cm, im, j, Av, dg);
+        const double v0 = vx[cm];
+        const double mom = (c1 != 0.0) ? c1 * (v0 - vprev[cm + P]) : 0.0;
+        out = s * (v0 + mom + c2 * (Av - f[cm + P]) / dg);
+    }
+    vnext[c + P] = out;
+}
+
+// r = f - A v on interior rows, 0 elsewhere
+// (f and r may alias: every thread reads only its own f entries before writing r)
+__global__ __launch_bounds__(256) void k_vv_residual(PlVvOp op, const double* __restrict__ v, const double* f,
+                                                     double* r) {
+    PL_NODE_PROLOGUE(op.g)
+    const long long P = op.g.plane;
+    int moff; double s, Av, dg;
+    double rz = 0.0, rx = 0.0;
+    if (vv_cls_z(op, i, j, moff, s) == VV_INT) { vv_row_z(op, v, v + P, c, i, j, Av, dg); rz = f[c] - Av; }
+    if (vv_cls_x(op, i, j, moff, s) == VV_INT) { vv_row_x(op, v, v + P, c, i, j, Av, dg); rx = f[c + P] - Av; }
+    r[c] = rz; r[c + P] = rx;
+}
+
+// y = D^-1 A v with closure (power iteration for lambda_max)
+__global__ __launch_bounds__(256) void k_vv_dinv_apply(PlVvOp op, const double* __restrict__ v,
+                                                       double* __restrict__ y) {
+    PL_NODE_PROLOGUE(op.g)
+    const long long P = op.g.plane;
+    int moff = 0; double s = 1.0, Av, dg;
+    int cls = vv_cls_z(op, i, j, moff, s);
+    double o = 0.0;
+    if (cls != VV_ZERO) { vv_row_z(op, v, v + P, c + moff, i, j + moff, Av, dg); o = s * Av / dg; }
+    y[c] = o;
+    cls = vv_cls_x(op, i, j, moff, s);
+    o = 0.0;
+    if (cls != VV_ZERO) {
+        const int im = i + (moff > 0 ? 1 : (moff < 0 ? -1 : 0));
+        vv_row_x(op, v, v + P, c + moff, im, j, Av, dg); o = s * Av / dg;
+    }
+    y[c + P] = o;
+}
+
+// Full-weighting restriction of the velocity residual (uniform-grid weights):
+// vz is vertex-centred in z [1/4,1/2,1/4] and cell-centred in x [1/8,3/8,3/8,1/8]; vx mirrored.
+__global__ __launch_bounds__(256) void k_vv_restrict(PlGeom gf, PlVvOp opc, const double* __restrict__ rf,
+                                                     double* __restrict__ fc) {
+    PL_NODE_PROLOGUE(opc.g)
+    int moff; double s;
+    const int pf = gf.pitch;
+    double oz = 0.0, ox = 0.0;
+    if (vv_cls_z(opc, i, j, moff, s) == VV_INT) {
+        const long long b = pl_idx(gf, 2 * i, 2 * j);
+        const double wz[3] = {0.25, 0.5, 0.25}, wx[4] = {0.125, 0.375, 0.375, 0.125};
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) oz += wz[a] * wx[q] * rf[b + (long long)(a - 1) * pf + (q - 1)];
+    }
+    if (vv_cls_x(opc, i, j, moff, s) == VV_INT) {
+        const long long b = pl_idx(gf, 2 * i, 2 * j) + gf.plane;
+        const double wz[4] = {0.125, 0.375, 0.375, 0.125}, wx[3] = {0.25, 0.5, 0.25};
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int q = 0; q < 3; q++) ox += wz[a] * wx[q] * rf[b + (long long)(a - 1) * pf + (q - 1)];
+    }
+    fc[c] = oz; fc[c + opc.g.plane] = ox;
+}
+
+// (P e)(i,j) for vz / vx on the fine grid from the coarse correction e (bilinear; mirror clamp)
+__device__ inline double prolong_z_at(const PlGeom& gc, const double* __restrict__ ez, int i, int j) {
+    const int I0 = i >> 1, I1 = (i + 1) >> 1;
+    int Jn = j >> 1, Jo = (j & 1) ? Jn + 1 : Jn - 1;
+    const int jmax = gc.nx - 2;
+    Jn = min(max(Jn, 0), jmax); Jo = min(max(Jo, 0), jmax);
+    const double a = 0.5 * (ez[pl_idx(gc, I0, Jn)] + ez[pl_idx(gc, I1, Jn)]);
+    const double b = 0.5 * (ez[pl_idx(gc, I0, Jo)] + ez[pl_idx(gc, I1, Jo)]);
+    return 0.75 * a + 0.25 * b;
+}
+
+__device__ inline double prolong_x_at(const PlGeom& gc, const double* __restrict__ ex, int i, int j) {
+    const int J0 = j >> 1, J1 = (j + 1) >> 1;
+    int In = i >> 1, Io = (i & 1) ? In + 1 : In - 1;
+    const int imax = gc.nz - 2;
+    In = min(max(In, 0), imax); Io = min(max(Io, 0), imax);
+    const double a = 0.5 * (ex[pl_idx(gc, In, J0)] + ex[pl_idx(gc, In, J1)]);
+    const double b = 0.5 * (ex[pl_idx(gc, Io, J0)] + ex[pl_idx(gc, Io, J1)]);
+    return 0.75 * a + 0.25 * b;
+}
+
+__global__ __launch_bounds__(256) void k_vv_prolong_add(PlVvOp opf, PlGeom gc, const double* __restrict__ ec,
+                                                        const double* __restrict__ vin, double* __restrict__ vout) {
+    PL_NODE_PROLOGUE(opf.g)
+    const long long P = opf.g.plane;
+    int moff = 0; double s = 1.0;
+    int cls = vv_cls_z(opf, i, j, moff, s);
+    double o = 0.0;
+    if (cls != VV_ZERO) o = s * (vin[c + moff] + prolong_z_at(gc, ec, i, j + moff));
+    vout[c] = o;
+    cls = vv_cls_x(opf, i, j, moff, s);
+    o = 0.0;
+    if (cls != VV_ZERO) {
+        const int im = i + (moff > 0 ? 1 : (moff < 0 ? -1 : 0));
+        o = s * (vin[c + moff + P] + prolong_x_at(gc, ec + gc.plane, im, j));
+    }
+    vout[c + P] = o;
+}
+
+// arithmetic viscosity coarsening: nodes by a [1 2 1]x[1 2 1]/16 stencil (edge-clamped),
+// cell centres by the mean of the 4 covered fine cells
+__global__ __launch_bounds__(256) void k_coarsen_visc(PlGeom gf, const double* __restrict__ esf,
+                                                      const double* __restrict__ enf, PlGeom gc,
+                                                      double* __restrict__ esc, double* __restrict__ enc) {
+    PL_NODE_PROLOGUE(gc)
+    double acc = 0.0;
+#pragma unroll
+    for (int a = -1; a <= 1; a++)
+#pragma unroll
+        for (int q = -1; q <= 1; q++) {
+            const int fi = min(max(2 * i + a, 0), gf.nz - 1), fj = min(max(2 * j + q, 0), gf.nx - 1);
+            acc += (a == 0 ? 2.0 : 1.0) * (q == 0 ? 2.0 : 1.0) * esf[pl_idx(gf, fi, fj)];
+        }
+    esc[c] = acc * (1.0 / 16.0);
+    const int ci = min(i, gc.nz - 2), cj = min(j, gc.nx - 2);      // ghost row/col copies its neighbour
+    const long long b = pl_idx(gf, 2 * ci, 2 * cj);
+    enc[c] = 0.25 * (enf[b] + enf[b + 1] + enf[b + gf.pitch] + enf[b + gf.pitch + 1]);
+}
+
+// =========================================================================================
+// Vector kernels (nplanes planes; dots over interior nodes only)
+// =========================================================================================
+__device__ inline double block_reduce_sum(double v) {
+    __shared__ double sh[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    if ((tid & 63) == 0) sh[tid >> 6] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (tid == 0) r = sh[0] + sh[1] + sh[2] + sh[3];
+    return r;
+}
+
+// out[0] += a.b   out[1] += c.d   (either pair may be NULL)
+__global__ __launch_bounds__(256) void k_dot2(PlGeom g, int nplanes, const double* __restrict__ a,
+                                              const double* __restrict__ b, const double* __restrict__ cc,
+                                              const double* __restrict__ dd, double* __restrict__ out) {
+    const int lj = blockIdx.x * 64 + threadIdx.x, li = blockIdx.y * 4 + threadIdx.y;
+    double s0 = 0.0, s1 = 0.0;
+    if (lj < g.lnx && li < g.lnz) {
+        const long long c = pl_idx(g, li, lj);
+        for (int q = 0; q < nplanes; q++) {
+            const long long o = c + q * g.plane;
+            if (a) s0 += a[o] * b[o];
+            if (cc) s1 += cc[o] * dd[o];
+        }
+    }
+    s0 = block_reduce_sum(s0);
+    __syncthreads();
+    s1 = block_reduce_sum(s1);
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        if (a) unsafeAtomicAdd(out, s0);
+        if (cc) unsafeAtomicAdd(out + 1, s1);
+    }
+}
+
+// p = r + beta (p - omega v)
+__global__ void k_p_update(long long n, double* __restrict__ p, const double* __restrict__ r,
+                           const double* __restrict__ v, double beta, double omega) {
+    long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; k < n; k += (long long)gridDim.x * blockDim.x) p[k] = r[k] + beta * (p[k] - omega * v[k]);
+}
+// y = a + alpha b
+__global__ void k_axpy_out(long long n, double* __restrict__ y, const double* __restrict__ a,
+                           const double* __restrict__ b, double alpha) {
+    long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; k < n; k += (long long)gridDim.x * blockDim.x) y[k] = a[k] + alpha * b[k];
+}
+// x += alpha y + omega z ; r = s - omega t
+__global__ void k_xr_update(long long n, double* __restrict__ x, const double* __restrict__ y,
+                            const double* __restrict__ z, double* __restrict__ r, const double* __restrict__ s,
+                            const double* __restrict__ t, double alpha, double omega) {
+    long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; k < n; k += (long long)gridDim.x * blockDim.x) {
+        x[k] += alpha * y[k] + omega * z[k];
+        r[k] = s[k] - omega * t[k];
+    }
+}
+__global__ void k_scale(long long n, double* __restrict__ x, double a) {
+    long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; k < n; k += (long long)gridDim.x * blockDim.x) x[k] *= a;
+}
+// seeded pseudo-random values in [-1,1) on interior nodes (shadow residual, power iteration)
+__global__ __launch_bounds__(256) void k_random_interior(PlGeom g, int nplanes, double* __restrict__ v, unsigned seed) {
+    PL_NODE_PROLOGUE(g)
+    for (int q = 0; q < nplanes; q++) {
+        unsigned h = (unsigned)(((unsigned)i * 73856093u) ^ ((unsigned)j * 19349663u) ^ ((unsigned)(q + 1) * 83492791u)) ^ seed;
+        h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+        v[c + q * g.plane] = (double)h * (2.0 / 4294967296.0) - 1.0;
+    }
+}
+
+static dim3 grid2d(const PlGeom& g) { return dim3((g.lnx + 63) / 64, (g.lnz + 3) / 4); }
+static dim3 grid1d(long long n) { long long b = (n + 255) / 256; return dim3((unsigned)(b > 4096 ? 4096 : b)); }
+
+// =========================================================================================
+// Stokes row scaling and preconditioner glue kernels
+// =========================================================================================
+// Row scale factors D_r of the full Stokes system at node (i,j) (positive).
+__device__ inline void stokes_row_scales(const PlStokesOp& op, int i, int j, long long c, double& sz, double& sx,
+                                         double& sp) {
+    const PlGeom& g = op.g;
+    const int nz = g.nz, nx = g.nx, p = g.pitch;
+    const double iKc = 1.0 / op.Kc;
+    sz = iKc; sx = iKc; sp = iKc;
+    if (i >= 1 && i <= nz - 2 && j >= 1 && j <= nx - 3) {
+        const double rdz_i = TB(g.rdz, i), rdz_m = TB(g.rdz, i - 1), rDz_i = TB(g.rDz, i);
+        const double rdx_j = TB(g.rdx, j), rDx_j = TB(g.rDx, j), rDx_p = TB(g.rDx, j + 1);
+        sz = 1.0 / (4.0 * op.etan[c] * rdz_i * rDz_i + 4.0 * op.etan[c - p] * rdz_m * rDz_i +
+                    2.0 * op.etas[c + 1] * rDx_p * rdx_j + 2.0 * op.etas[c] * rDx_j * rdx_j);
+    }
+    if (i >= 1 && i <= nz - 3 && j >= 1 && j <= nx - 2) {
+        const double rdx_j = TB(g.rdx, j), rdx_m = TB(g.rdx, j - 1), rDx_j = TB(g.rDx, j);
+        const double rdz_i = TB(g.rdz, i), rDz_i = TB(g.rDz, i), rDz_p = TB(g.rDz, i + 1);
+        sx = 1.0 / (4.0 * op.etan[c] * rdx_j * rDx_j + 4.0 * op.etan[c - 1] * rdx_m * rDx_j +
+                    2.0 * op.etas[c + p] * rDz_p * rdz_i + 2.0 * op.etas[c] * rDz_i * rdz_i);
+    }
+    if (i <= nz - 2 && j <= nx - 2 && !(i == op.anchor_i && j == op.anchor_j)) {
+        if ((i == 0 || i == nz - 2) && (j == 0 || j == nx - 2)) sp = 1.0 / op.Kb;
+        else sp = 1.0 / (op.Kc * (TB(g.rdx, j) + TB(g.rdz, i)));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_stokes_scale_rows(PlStokesOp op, double* __restrict__ v) {
+    PL_NODE_PROLOGUE(op.g)
+    double sz, sx, sp;
+    stokes_row_scales(op, i, j, c, sz, sx, sp);
+    v[c] *= sz; v[c + op.g.plane] *= sx; v[c + 2 * op.g.plane] *= sp;
+}
+
+// S^ solve of one pressure node from the SCALED residual rs (continuity rows only)
+__device__ inline double prec_p_cont(const PlStokesOp& op, const double* __restrict__ rs_p, int i, int j, long long c) {
+    const double unscale = op.Kc * (TB(op.g.rdx, j) + TB(op.g.rdz, i));
+    return rs_p[c] * unscale * op.etan[c] / (op.Kc * op.Kc);
+}
+
+// z_p = S^-1 r_p  (ghost/anchor rows: r/Kc; corners: P_c = P_nb - r/Kb)
+__global__ __launch_bounds__(256) void k_prec_p(PlStokesOp op, const double* __restrict__ rs, double* __restrict__ z) {
+    PL_NODE_PROLOGUE(op.g)
+    const int nz = op.g.nz, nx = op.g.nx;
+    const double* rs_p = rs + 2 * op.g.plane;
+    double zp;
+    if (i == nz - 1 || j == nx - 1 || (i == op.anchor_i && j == op.anchor_j)) {
+        zp = rs_p[c];                                   // scaled by 1/Kc, row is Kc*P -> P = r/Kc = rs
+    } else if ((i == 0 || i == nz - 2) && j == 0) {
+        zp = prec_p_cont(op, rs_p, i, 1, c + 1) - rs_p[c];       // rs = r/Kb
+    } else if ((i == 0 || i == nz - 2) && j == nx - 2) {
+        zp = prec_p_cont(op, rs_p, i, nx - 3, c - 1) - rs_p[c];
+    } else {
+        zp = prec_p_cont(op, rs_p, i, j, c);
+    }
+    z[c + 2 * op.g.plane] = zp;
+}
+
+// velocity right-hand side of the block solve: f = r_v - A_vp z_p on interior rows, and the
+// lift z0 of the inhomogeneous constraint rows (walls: r/Kc, slaves: r/(Kc a0)).
+__global__ __launch_bounds__(256) void k_prec_rv(PlStokesOp op, PlVvOp vop, const double* __restrict__ rs,
+                                                 const double* __restrict__ z, double* __restrict__ f,
+                                                 double* __restrict__ z0) {
+    PL_NODE_PROLOGUE(op.g)
+    const long long P = op.g.plane;
+    const int p = op.g.pitch;
+    const double* zp = z + 2 * P;
+    double sz, sx, sp;
+    stokes_row_scales(op, i, j, c, sz, sx, sp);
+    int moff; double s;
+    double fz = 0.0, fx = 0.0, lz = 0.0, lx = 0.0;
+    int cls = vv_cls_z(vop, i, j, moff, s);
+    if (cls == VV_INT) fz = rs[c] / sz + 2.0 * op.Kc * TB(op.g.rDz, i) * (zp[c] - zp[c - p]);
+    else lz = rs[c];                                        // rs = r/Kc
+    cls = vv_cls_x(vop, i, j, moff, s);
+    if (cls == VV_INT) fx = rs[c + P] / sx + 2.0 * op.Kc * TB(op.g.rDx, j) * (zp[c] - zp[c - 1]);
+    else {
+        lx = rs[c + P];
+        if (cls == VV_SLAVE && i == 0 && op.bc_z0 != PL_BC_FREESLIP) lx /= (-TB(op.g.rDz, 1) - TB(op.g.rdz, 0));
+        if (cls == VV_SLAVE && i == op.g.nz - 2 && op.bc_zL != PL_BC_FREESLIP)
+            lx /= (TB(op.g.rDz, op.g.nz - 2) + TB(op.g.rdz, op.g.nz - 2));
+    }
+    f[c] = fz; f[c + P] = fx; z0[c] = lz; z0[c + P] = lx;
+}
+
+// z_v = e + z0
+__global__ __launch_bounds__(256) void k_prec_finish(PlGeom g, const double* __restrict__ e,
+                                                     const double* __restrict__ z0, double* __restrict__ z) {
+    PL_NODE_PROLOGUE(g)
+    (void)i; (void)j;
+    z[c] = e[c] + z0[c]; z[c + g.plane] = e[c + g.plane] + z0[c + g.plane];
+}
+
+// =========================================================================================
+// Host side
+// =========================================================================================
+struct MgLevel {
+    PlGeomHost gh;
+    PlVvOp op{};
+    double* etas = nullptr; double* etan = nullptr; bool own_visc = false;
+    double* v[3] = {nullptr, nullptr, nullptr};      // rotating Chebyshev buffers (2 planes each)
+    double *f = nullptr, *r = nullptr;
+    double lmax = 3.0;
+};
+
+struct PlSolver {
+    std::vector<MgLevel*> levels;
+    int bc_key[4] = {-1, -1, -1, -1};
+    // BiCGStab work vectors (3 planes each)
+    double *r = nullptr, *rt = nullptr, *p = nullptr, *v = nullptr, *s = nullptr, *t = nullptr, *y = nullptr,
+           *z = nullptr, *b = nullptr, *x = nullptr, *z0 = nullptr;
+    double* scal = nullptr;     // device scalars
+    int nu_pre = 2, nu_post = 2, coarse_sweeps = 40;
+    // heat work vectors (1 plane each)
+    double* h[9] = {nullptr};
+    int napply = 0, nprec = 0;
+};
+
+static PlSolver* solver_of(pl_ctx* ctx) {
+    if (!ctx->krylov) ctx->krylov = new PlSolver();
+    return (PlSolver*)ctx->krylov;
+}
+
+static void free_levels(PlSolver* S) {
+    for (MgLevel* L : S->levels) {
+        if (L->own_visc) { (void)hipFree(L->etas); (void)hipFree(L->etan); }
+        for (double* q : {L->v[0], L->v[1], L->v[2], L->f, L->r}) if (q) (void)hipFree(q);
+        pl_geom_free(L->gh);
+        delete L;
+    }
+    S->levels.clear();
+}
+
+void pl_solver_free(pl_ctx* ctx) {
+    PlSolver* S = (PlSolver*)ctx->krylov;
+    if (!S) return;
+    free_levels(S);
+    for (double* q : {S->r, S->rt, S->p, S->v, S->s, S->t, S->y, S->z, S->b, S->x, S->z0, S->scal})
+        if (q) (void)hipFree(q);
+    for (double* q : S->h) if (q) (void)hipFree(q);
+    delete S;
+    ctx->krylov = nullptr;
+}
+
+static int dmalloc0(pl_ctx* ctx, double** p, size_t bytes) {
+    PL_HIP(ctx, hipMalloc((void**)p, bytes));
+    PL_HIP(ctx, hipMemsetAsync(*p, 0, bytes, ctx->stream));
+    return 0;
+}
+
+static int dots(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const double* a, const double* b, const double* c,
+                const double* d, double* out2) {
+    PL_HIP(ctx, hipMemsetAsync(S->scal, 0, 2 * sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(k_dot2, grid2d(g), dim3(64, 4), 0, ctx->stream, g, np, a, b, c, d, S->scal);
+    PL_HIP(ctx, hipMemcpyAsync(out2, S->scal, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// ---- hierarchy ------------------------------------------------------------------------------
+static void level_flags(MgLevel* L, const PlStokesOp& sop, bool finest) {
+    PlVvOp& o = L->op;
+    o.g = L->gh.d; o.etas = L->etas; o.etan = L->etan;
+    o.slave_x = finest ? 1 : 0;
+    const bool ns0 = sop.bc_z0 != PL_BC_FREESLIP, nsL = sop.bc_zL != PL_BC_FREESLIP;
+    o.slave_z0 = (finest || ns0) ? 1 : 0;
+    o.slave_zL = (finest || nsL) ? 1 : 0;
+    const std::vector<double>& z = L->gh.zc;
+    const int nz = (int)z.size();
+    // NOSLIP extrapolation rows (pylamp_stokes.py:165-166,204-205): a0 v_s + a1 v_m = 0
+    o.s0 = ns0 ? (1.0 / (z[2] - z[0])) / (1.0 / (z[2] - z[0]) + 1.0 / (z[1] - z[0])) : 1.0;
+    o.sL = nsL ? (1.0 / (z[nz - 1] - z[nz - 3])) / (1.0 / (z[nz - 1] - z[nz - 3]) + 1.0 / (z[nz - 1] - z[nz - 2])) : 1.0;
+}
+
+static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
+    const PlStokesOp& sop = ctx->sop;
+    bool rebuild = S->levels.empty();
+    int key[4] = {sop.bc_z0, 0, sop.bc_zL, 0};
+    if (!rebuild && (S->bc_key[0] != key[0] || S->bc_key[2] != key[2])) rebuild = true;
+    if (rebuild) {
+        free_levels(S);
+        int nz = ctx->nz, nx = ctx->nx;
+        std::vector<double> zc = ctx->geom.zc, xc = ctx->geom.xc;
+        for (int l = 0;; l++) {
+            MgLevel* L = new MgLevel();
+            if (pl_geom_build(ctx, L->gh, nz, nx, zc.data(), xc.data())) { delete L; return 1; }
+            size_t vb = (size_t)2 * L->gh.d.plane * sizeof(double), pb = (size_t)L->gh.d.plane * sizeof(double);
+            if (l > 0) {
+                L->own_visc = true;
+                PL_TRY(dmalloc0(ctx, &L->etas, pb)); PL_TRY(dmalloc0(ctx, &L->etan, pb));
+            }
+            for (int q = 0; q < 3; q++) PL_TRY(dmalloc0(ctx, &L->v[q], vb));
+            PL_TRY(dmalloc0(ctx, &L->f, vb)); PL_TRY(dmalloc0(ctx, &L->r, vb));
+            S->levels.push_back(L);
+            if ((nz - 1) % 2 || (nx - 1) % 2 || (nz - 1) / 2 < 4 || (nx - 1) / 2 < 4) break;
+            std::vector<double> z2, x2;
+            for (int i = 0; i < nz; i += 2) z2.push_back(zc[i]);
+            for (int j = 0; j < nx; j += 2) x2.push_back(xc[j]);
+            zc.swap(z2); xc.swap(x2); nz = (nz - 1) / 2 + 1; nx = (nx - 1) / 2 + 1;
+        }
+        S->bc_key[0] = key[0]; S->bc_key[2] = key[2];
+    }
+    // (re)attach viscosities, coarsen, estimate lambda_max
+    S->levels[0]->etas = (double*)sop.etas; S->levels[0]->etan = (double*)sop.etan;
+    for (size_t l = 0; l < S->levels.size(); l++) {
+        MgLevel* L = S->levels[l];
+        if (l > 0) {
+            MgLevel* F = S->levels[l - 1];
+            hipLaunchKernelGGL(k_coarsen_visc, grid2d(L->gh.d), dim3(64, 4), 0, ctx->stream, F->gh.d, F->etas, F->etan,
+                               L->gh.d, L->etas, L->etan);
+        }
+        level_flags(L, sop, l == 0);
+    }
+    PL_HIP(ctx, hipGetLastError());
+    for (MgLevel* L : S->levels) {
+        const PlGeom& g = L->gh.d;
+        long long n2 = 2 * g.plane;
+        hipLaunchKernelGGL(k_random_interior, grid2d(g), dim3(64, 4), 0, ctx->stream, g, 2, L->v[0], 777u);
+        double lam = 2.5, nn[2];
+        for (int it = 0; it < 12; it++) {
+            hipLaunchKernelGGL(k_vv_dinv_apply, grid2d(g), dim3(64, 4), 0, ctx->stream, L->op, L->v[0], L->v[1]);
+            PL_TRY(dots(ctx, S, g, 2, L->v[1], L->v[1], L->v[0], L->v[0], nn));
+            if (!(nn[1] > 0.0) || !(nn[0] > 0.0)) break;
+            lam = std::sqrt(nn[0] / nn[1]);
+            hipLaunchKernelGGL(k_axpy_out, grid1d(n2), dim3(256), 0, ctx->stream, n2, L->v[0], L->v[1], L->v[1],
+                               1.0 / std::sqrt(nn[0]) - 1.0);     // v0 = v1 / ||v1||
+        }
+        L->lmax = 1.1 * lam;
+    }
+    return 0;
+}
+
+// ---- smoothing and V-cycle ----------------------------------------------------------------
+// nsweep Chebyshev-Jacobi sweeps on level L; buf[0] is the current iterate on entry and on exit
+static void smooth(pl_ctx* ctx, MgLevel* L, double* buf[3], const double* f, int nsweep, double ratio) {
+    const double lmax = L->lmax, lmin = lmax / ratio;
+    const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
+    double rho_old = 1.0 / sigma;
+    for (int k = 0; k < nsweep; k++) {
+        double c1, c2;
+        if (k == 0) { c1 = 0.0; c2 = 1.0 / theta; }
+        else { const double rho = 1.0 / (2.0 * sigma - rho_old); c1 = rho * rho_old; c2 = 2.0 * rho / delta; rho_old = rho; }
+        hipLaunchKernelGGL(k_vv_cheb, grid2d(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, buf[0], buf[1], f, buf[2],
+                           c1, c2);
+        double* nxt = buf[2]; buf[2] = buf[1]; buf[1] = buf[0]; buf[0] = nxt;     // (cur, prev, free)
+    }
+}
+
+// solves A_vv e = f(level l) approximately; result in *out (one of the level's v buffers)
+static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const double* f, double** out) {
+    MgLevel* L = S->levels[l];
+    const PlGeom& g = L->gh.d;
+    double* buf[3] = {L->v[0], L->v[1], L->v[2]};
+    (void)hipMemsetAsync(buf[0], 0, (size_t)2 * g.plane * sizeof(double), ctx->stream);
+    if (l + 1 == S->levels.size()) {
+        double ratio = 0.4 * g.nz * g.nx; if (ratio < 30.0) ratio = 30.0;
+        smooth(ctx, L, buf, f, S->coarse_sweeps, ratio);
+        *out = buf[0];
+        return;
+    }
+    smooth(ctx, L, buf, f, S->nu_pre, 6.0);
+    hipLaunchKernelGGL(k_vv_residual, grid2d(g), dim3(64, 4), 0, ctx->stream, L->op, buf[0], f, L->r);
+    MgLevel* C = S->levels[l + 1];
+    hipLaunchKernelGGL(k_vv_restrict, grid2d(C->gh.d), dim3(64, 4), 0, ctx->stream, g, C->op, L->r, C->f);
+    double* ec = nullptr;
+    vcycle(ctx, S, l + 1, C->f, &ec);
+    hipLaunchKernelGGL(k_vv_prolong_add, grid2d(g), dim3(64, 4), 0, ctx->stream, L->op, C->gh.d, ec, buf[0], buf[2]);
+    std::swap(buf[0], buf[2]);
+    smooth(ctx, L, buf, f, S->nu_post, 6.0);
+    *out = buf[0];
+}
+
+// z = M^-1 rs   (rs: scaled residual, 3 planes)
+static int stokes_precond(pl_ctx* ctx, PlSolver* S, const double* rs, double* z) {
+    const PlStokesOp& op = ctx->sop;
+    MgLevel* L0 = S->levels[0];
+    const PlGeom& g = op.g;
+    hipLaunchKernelGGL(k_prec_p, grid2d(g), dim3(64, 4), 0, ctx->stream, op, rs, z);
+    hipLaunchKernelGGL(k_prec_rv, grid2d(g), dim3(64, 4), 0, ctx->stream, op, L0->op, rs, z, L0->f, S->z0);
+    // f' = f - A_vv z0, in place (each thread touches only its own f entries)
+    hipLaunchKernelGGL(k_vv_residual, grid2d(g), dim3(64, 4), 0, ctx->stream, L0->op, S->z0, L0->f, L0->f);
+    double* e = nullptr;
+    vcycle(ctx, S, 0, L0->f, &e);
+    hipLaunchKernelGGL(k_prec_finish, grid2d(g), dim3(64, 4), 0, ctx->stream, g, e, S->z0, z);
+    PL_HIP(ctx, hipGetLastError());
+    S->nprec++;
+    return 0;
+}
+
+// =========================================================================================
+// Generic right-preconditioned BiCGStab (host-driven scalars)
+// =========================================================================================
+typedef std::function<int(const double*, double*)> VecOp;
+
+struct BicgVecs { double *r, *rt, *p, *v, *s, *t, *y, *z; };
+
+static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const VecOp& A, const VecOp* M,
+                    const double* b, double* x, bool use_x0, double rtol, int maxit, BicgVecs w,
+                    pl_solve_stats* st) {
+    const long long n = (long long)np * g.plane;
+    const size_t bytes = (size_t)n * sizeof(double);
+    double d2[2];
+    PL_TRY(dots(ctx, S, g, np, b, b, nullptr, nullptr, d2));
+    const double bnorm = std::sqrt(d2[0]);
+    st->iterations = 0; st->converged = 0; st->rel_residual = 0.0;
+    if (!(bnorm > 0.0)) {                       // b = 0 -> x = 0
+        PL_HIP(ctx, hipMemsetAsync(x, 0, bytes, ctx->stream));
+        st->converged = 1;
+        return 0;
+    }
+    if (use_x0) {
+        PL_TRY(A(x, w.v));
+        hipLaunchKernelGGL(k_axpy_out, grid1d(n), dim3(256), 0, ctx->stream, n, w.r, b, w.v, -1.0);
+    } else {
+        PL_HIP(ctx, hipMemsetAsync(x, 0, bytes, ctx->stream));
+        PL_HIP(ctx, hipMemcpyAsync(w.r, b, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    PL_HIP(ctx, hipMemsetAsync(w.rt, 0, bytes, ctx->stream));
+    hipLaunchKernelGGL(k_random_interior, grid2d(g), dim3(64, 4), 0, ctx->stream, g, np, w.rt, 1234u);
+    PL_HIP(ctx, hipMemsetAsync(w.p, 0, bytes, ctx->stream));
+    PL_HIP(ctx, hipMemsetAsync(w.v, 0, bytes, ctx->stream));
+    double rho = 1.0, alpha = 1.0, omega = 1.0;
+    PL_TRY(dots(ctx, S, g, np, w.rt, w.r, w.r, w.r, d2));
+    double rho_new = d2[0], rnorm = std::sqrt(d2[1]);
+    int it = 0;
+    while (it < maxit && rnorm > rtol * bnorm) {
+        it++;
+        if (!(std::fabs(rho_new) > 0.0) || !std::isfinite(rho_new)) break;
+        const double beta = (rho_new / rho) * (alpha / omega);
+        hipLaunchKernelGGL(k_p_update, grid1d(n), dim3(256), 0, ctx->stream, n, w.p, w.r, w.v, beta, omega);
+        const double* yv = w.p;
+        if (M) { PL_TRY((*M)(w.p, w.y)); yv = w.y; }
+        PL_TRY(A(yv, w.v));
+        PL_TRY(dots(ctx, S, g, np, w.rt, w.v, nullptr, nullptr, d2));
+        if (!(std::fabs(d2[0]) > 0.0) || !std::isfinite(d2[0])) break;
+        alpha = rho_new / d2[0];
+        hipLaunchKernelGGL(k_axpy_out, grid1d(n), dim3(256), 0, ctx->stream, n, w.s, w.r, w.v, -alpha);
+        const double* zv = w.s;
+        if (M) { PL_TRY((*M)(w.s, w.z)); zv = w.z; }
+        PL_TRY(A(zv, w.t));
+        PL_TRY(dots(ctx, S, g, np, w.t, w.s, w.t, w.t, d2));
+        if (!(d2[1] > 0.0) || !std::isfinite(d2[1])) {        // s is already (numerically) zero
+            hipLaunchKernelGGL(k_xr_update, grid1d(n), dim3(256), 0, ctx->stream, n, x, yv, zv, w.r, w.s, w.t, alpha, 0.0);
+            rnorm = 0.0;
+            break;
+        }
+        omega = d2[0] / d2[1];
+        hipLaunchKernelGGL(k_xr_update, grid1d(n), dim3(256), 0, ctx->stream, n, x, yv, zv, w.r, w.s, w.t, alpha, omega);
+        rho = rho_new;
+        PL_TRY(dots(ctx, S, g, np, w.rt, w.r, w.r, w.r, d2));
+        rho_new = d2[0]; rnorm = std::sqrt(d2[1]);
+        if (!std::isfinite(rnorm) || !(std::fabs(omega) > 0.0)) break;
+    }
+    // true residual
+    PL_TRY(A(x, w.t));
+    hipLaunchKernelGGL(k_axpy_out, grid1d(n), dim3(256), 0, ctx->stream, n, w.s, b, w.t, -1.0);
+    PL_TRY(dots(ctx, S, g, np, w.s, w.s, nullptr, nullptr, d2));
+    st->iterations = it;
+    st->rel_residual = std::sqrt(d2[0]) / bnorm;
+    st->converged = (st->rel_residual <= 10.0 * rtol) ? 1 : 0;
+    return 0;
+}
+
+// =========================================================================================
+// Stokes solve (device-resident core + C ABI)
+// =========================================================================================
+static int stokes_alloc(pl_ctx* ctx, PlSolver* S) {
+    if (S->r) return 0;
+    size_t vb = (size_t)3 * ctx->geom.d.plane * sizeof(double);
+    for (double** q : {&S->r, &S->rt, &S->p, &S->v, &S->s, &S->t, &S->y, &S->z, &S->b, &S->x, &S->z0})
+        PL_TRY(dmalloc0(ctx, q, vb));
+    if (!S->scal) PL_TRY(dmalloc0(ctx, &S->scal, 64));
+    return 0;
+}
+
+// Solve A x = b for device vectors (3 planes, UNSCALED b).  x is S->x on return.
+int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double rtol, int maxit,
+                           pl_solve_stats* st) {
+    PlSolver* S = solver_of(ctx);
+    PL_TRY(stokes_alloc(ctx, S));
+    PL_TRY(pl_timer_start(ctx));
+    PL_TRY(build_hierarchy(ctx, S));
+    const PlGeom& g = ctx->geom.d;
+    PlStokesOp sop = ctx->sop;
+    S->napply = 0; S->nprec = 0;
+    VecOp A = [&](const double* in, double* out) -> int {
+        pl_launch_stokes_apply(ctx, sop, in, out);
+        hipLaunchKernelGGL(k_stokes_scale_rows, grid2d(g), dim3(64, 4), 0, ctx->stream, sop, out);
+        S->napply++;
+        return 0;
+    };
+    VecOp M = [&](const double* in, double* out) -> int { return stokes_precond(ctx, S, in, out); };
+    if (b_dev != S->b)
+        PL_HIP(ctx, hipMemcpyAsync(S->b, b_dev, (size_t)3 * g.plane * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_stokes_scale_rows, grid2d(g), dim3(64, 4), 0, ctx->stream, sop, S->b);
+    BicgVecs w{S->r, S->rt, S->p, S->v, S->s, S->t, S->y, S->z};
+    PL_TRY(bicgstab(ctx, S, g, 3, A, &M, S->b, S->x, use_x0, rtol, maxit, w, st));
+    double ms = 0;
+    PL_TRY(pl_timer_stop_ms(ctx, &ms));
+    st->solve_ms = ms; st->operator_applies = S->napply; st->precond_applies = S->nprec;
+    return 0;
+}
+
+double* pl_stokes_solution_device(pl_ctx* ctx) { return solver_of(ctx)->x; }
+double* pl_stokes_rhs_buffer_device(pl_ctx* ctx) {
+    PlSolver* S = solver_of(ctx);
+    if (stokes_alloc(ctx, S)) return nullptr;
+    return S->b;
+}
 
 extern "C" int pl_stokes_solve(pl_ctx* ctx, const double* rhs, double* x, int use_x0, double rtol, int maxit,
                                pl_solve_stats* stats) {
-    (void)rhs; (void)x; (void)use_x0; (void)rtol; (void)maxit; (void)stats;
-    return pl_fail(ctx, "pl_stokes_solve: not implemented yet");
+    if (!ctx->sop_ready) return pl_fail(ctx, "stokes operator not set");
+    if (!x) return pl_fail(ctx, "pl_stokes_solve: x is NULL");
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    PlSolver* S = solver_of(ctx);
+    PL_TRY(stokes_alloc(ctx, S));
+    const PlGeom& g = ctx->geom.d;
+    if (rhs) PL_TRY(pl_vec3_upload(ctx, g, rhs, S->b));
+    else pl_launch_stokes_rhs(ctx, ctx->sop, S->b);
+    if (use_x0) PL_TRY(pl_vec3_upload(ctx, g, x, S->x));
+    pl_solve_stats st{};
+    if (rtol <= 0) rtol = 1e-10;
+    if (maxit <= 0) maxit = 400;
+    PL_TRY(pl_stokes_solve_device(ctx, S->b, use_x0 != 0, rtol, maxit, &st));
+    PL_TRY(pl_vec3_download(ctx, g, S->x, x));
+    if (stats) *stats = st;
+    return 0;
+}
+
+extern "C" int pl_stokes_precond_apply(pl_ctx* ctx, const double* r, double* z) {
+    if (!ctx->sop_ready) return pl_fail(ctx, "stokes operator not set");
+    if (!r || !z) return pl_fail(ctx, "pl_stokes_precond_apply: NULL argument");
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    PlSolver* S = solver_of(ctx);
+    PL_TRY(stokes_alloc(ctx, S));
+    PL_TRY(build_hierarchy(ctx, S));
+    const PlGeom& g = ctx->geom.d;
+    PL_TRY(pl_vec3_upload(ctx, g, r, S->s));
+    hipLaunchKernelGGL(k_stokes_scale_rows, grid2d(g), dim3(64, 4), 0, ctx->stream, ctx->sop, S->s);
+    PL_TRY(stokes_precond(ctx, S, S->s, S->z));
+    PL_TRY(pl_vec3_download(ctx, g, S->z, z));
+    return 0;
+}
+
+extern "C" int pl_stokes_mg_info(pl_ctx* ctx, int* nlevels, double* lmax, int max_levels) {
+    PlSolver* S = solver_of(ctx);
+    if (nlevels) *nlevels = (int)S->levels.size();
+    for (int l = 0; lmax && l < max_levels && l < (int)S->levels.size(); l++) lmax[l] = S->levels[l]->lmax;
+    return 0;
+}
+
+// =========================================================================================
+// Heat solve: BiCGStab on the Jacobi-scaled operator D^-1 A
+// =========================================================================================
+__global__ __launch_bounds__(256) void k_heat_dinv(PlHeatOp op, double* __restrict__ v) {
+    PL_NODE_PROLOGUE(op.g)
+    const int nz = op.g.nz, nx = op.g.nx, p = op.g.pitch;
+    double dg;
+    if (i == 0) dg = (op.bc[0] == PL_BC_FIXTEMP) ? 1.0 : -op.kz[c] * TB(op.g.rdz, 0);
+    else if (i == nz - 1) dg = (op.bc[2] == PL_BC_FIXTEMP) ? 1.0 : op.kz[c - p] * TB(op.g.rdz, nz - 2);
+    else if (j == 0) dg = (op.bc[1] == PL_BC_FIXTEMP) ? 1.0 : -op.kx[c] * TB(op.g.rdx, 0);
+    else if (j == nx - 1) dg = (op.bc[3] == PL_BC_FIXTEMP) ? 1.0 : op.kx[c - 1] * TB(op.g.rdx, nx - 2);
+    else
+        dg = -op.rhocp_inv_dt[c] * ((op.kx[c] * TB(op.g.rdx, j) + op.kx[c - 1] * TB(op.g.rdx, j - 1)) * TB(op.rdxb, j) +
+                                    (op.kz[c] * TB(op.g.rdz, i) + op.kz[c - p] * TB(op.g.rdz, i - 1)) * TB(op.rdzb, i)) - 1.0;
+    v[c] /= dg;
+}
+
+int pl_heat_solve_device(pl_ctx* ctx, const double* b_dev, double rtol, int maxit, pl_solve_stats* st,
+                         double** x_out) {
+    PlSolver* S = solver_of(ctx);
+    const PlGeom& g = ctx->geom.d;
+    size_t pb = (size_t)g.plane * sizeof(double);
+    for (int k = 0; k < 9; k++) if (!S->h[k]) PL_TRY(dmalloc0(ctx, &S->h[k], pb));
+    if (!S->scal) PL_TRY(dmalloc0(ctx, &S->scal, 64));
+    PL_TRY(pl_timer_start(ctx));
+    PlHeatOp hop = ctx->hop;
+    S->napply = 0;
+    VecOp A = [&](const double* in, double* out) -> int {
+        pl_launch_heat_apply(ctx, hop, in, out);
+        hipLaunchKernelGGL(k_heat_dinv, grid2d(g), dim3(64, 4), 0, ctx->stream, hop, out);
+        S->napply++;
+        return 0;
+    };
+    double* b = S->h[8];
+    PL_HIP(ctx, hipMemcpyAsync(b, b_dev, pb, hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_heat_dinv, grid2d(g), dim3(64, 4), 0, ctx->stream, hop, b);
+    BicgVecs w{S->h[0], S->h[1], S->h[2], S->h[3], S->h[4], S->h[5], nullptr, nullptr};
+    PL_TRY(bicgstab(ctx, S, g, 1, A, nullptr, b, S->h[7], false, rtol, maxit, w, st));
+    double ms = 0;
+    PL_TRY(pl_timer_stop_ms(ctx, &ms));
+    st->solve_ms = ms; st->operator_applies = S->napply; st->precond_applies = 0;
+    *x_out = S->h[7];
+    return 0;
 }
 
 extern "C" int pl_heat_solve(pl_ctx* ctx, const double* rhs, double* x, double rtol, int maxit,
                              pl_solve_stats* stats) {
-    (void)rhs; (void)x; (void)rtol; (void)maxit; (void)stats;
-    return pl_fail(ctx, "pl_heat_solve: not implemented yet");
+    if (!ctx->hop_ready) return pl_fail(ctx, "heat operator not set");
+    if (!x) return pl_fail(ctx, "pl_heat_solve: x is NULL");
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    const PlGeom& g = ctx->geom.d;
+    double* db;
+    PL_TRY(pl_buf(ctx, "api_hx", (size_t)g.plane * sizeof(double), &db));
+    if (rhs) PL_TRY(pl_plane_upload(ctx, g, rhs, db));
+    else pl_launch_heat_rhs(ctx, ctx->hop, ctx->bufs["f_T"], ctx->bufs["H"], db);
+    pl_solve_stats st{};
+    if (rtol <= 0) rtol = 1e-12;
+    if (maxit <= 0) maxit = 2000;
+    double* xs = nullptr;
+    PL_TRY(pl_heat_solve_device(ctx, db, rtol, maxit, &st, &xs));
+    PL_TRY(pl_plane_download(ctx, g, xs, x));
+    if (stats) *stats = st;
+    return 0;
 }
-
-void pl_solver_free(pl_ctx* ctx) { (void)ctx; }

@@ -86,6 +86,18 @@ class StokesOperator:
         self._ctx.check(self._ctx.lib.pl_stokes_rhs(self._ctx.h, _lib.dptr(r)))
         return r
 
+    def precond(self, r):
+        """z = M^-1 r of the solver's preconditioner (diagnostic; r unscaled)."""
+        r = _lib.f64(r).reshape(-1)
+        z = np.empty_like(r)
+        self._ctx.check(self._ctx.lib.pl_stokes_precond_apply(self._ctx.h, _lib.dptr(r), _lib.dptr(z)))
+        return z
+
+    def mg_info(self):
+        n = C.c_int(); lm = (C.c_double * 32)()
+        self._ctx.check(self._ctx.lib.pl_stokes_mg_info(self._ctx.h, C.byref(n), lm, 32))
+        return n.value, [lm[k] for k in range(n.value)]
+
     def tocsc(self):
         """Explicit scipy CSC equal to the reference's matrix (probing: every row reaches
         only nodes within +-1 in i and j, so 3x3x3 colours separate all its entries)."""

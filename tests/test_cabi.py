@@ -35,11 +35,15 @@ def test_struct_layouts_match_header():
 
 
 def test_product_never_imports_oracle():
+    pat_py = re.compile(r"^\s*(from|import)\s+\.*oracle|[\"']oracle[/\"']|oracle/_ref", re.M)
+    pat_c = re.compile(r"#include\s*[<\"][^\n]*oracle|dlopen\([^\n]*oracle", re.M)
     for dirpath, _, files in os.walk(os.path.join(ROOT, "pylamp_amd")):
         for f in files:
-            if f.endswith((".py", ".hip", ".h")):
-                src = open(os.path.join(dirpath, f)).read()
-                assert "oracle" not in src.replace("no oracle", ""), f
+            src = open(os.path.join(dirpath, f), errors="ignore").read() if f.endswith((".py", ".hip", ".h")) else ""
+            if f.endswith(".py"):
+                assert not pat_py.search(src), f
+            elif src:
+                assert not pat_c.search(src), f
 
 
 def test_no_cpu_fallback():
