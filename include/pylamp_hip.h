@@ -40,7 +40,9 @@ enum { PL_INTERP_NEAREST = 8, PL_INTERP_LINEAR = 16, PL_INTERP_VELDIV = 32 };
 typedef struct pl_solve_stats {
     int    iterations;      /* outer Krylov iterations used                       */
     int    converged;       /* 1 if the TRUE residual met rtol                    */
-    double rel_residual;    /* ||b - A x|| / ||b||, recomputed, not the recurrence */
+    double rel_residual;    /* TRUE residual ||D(b - A x)|| / ref, recomputed (not the recurrence);
+                             * D = row scaling; ref = ||D b|| (heat) or the dynamic load
+                             * ||D(b - A x_hydrostatic)|| (Stokes) */
     double solve_ms;        /* device time of the solve (HIP events)              */
     int    operator_applies;
     int    precond_applies;

@@ -113,6 +113,22 @@ void pl_launch_stokes_apply(pl_ctx* ctx, const PlStokesOp& op, const double* x, 
 void pl_launch_stokes_rhs(pl_ctx* ctx, const PlStokesOp& op, double* rhs);
 void pl_launch_heat_apply(pl_ctx* ctx, const PlHeatOp& op, const double* x, double* y);
 
+// ---- device-resident entry points shared between units -----------------------------------
+void pl_launch_heat_rhs(pl_ctx* ctx, const PlHeatOp& op, const double* Told, const double* H, double* rhs);
+void pl_launch_heat_coef(pl_ctx* ctx, const PlGeom& g, const double* rho, const double* cp, double dt, double* c);
+int  pl_heat_tables(pl_ctx* ctx, const double* zmp, const double* xmp);
+int  pl_heat_check_bc(pl_ctx* ctx, const int bc[4]);
+int  pl_stokes_check_bc(pl_ctx* ctx, const int bc[4]);
+void pl_stokes_scaling_host(const PlGeomHost& gh, double minetas, double minetan, double* Kc, double* Kb);
+void pl_stokes_fill_op(pl_ctx* ctx, double* etas, double* etan, double* rho, const int bc[4], int surfstab,
+                       double tstep, double theta, double Kc, double Kb);
+int  pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double rtol, int maxit,
+                            pl_solve_stats* st);
+double* pl_stokes_solution_device(pl_ctx* ctx);
+double* pl_stokes_rhs_buffer_device(pl_ctx* ctx);
+int  pl_heat_solve_device(pl_ctx* ctx, const double* b_dev, double rtol, int maxit, pl_solve_stats* st,
+                          double** x_out);
+
 // krylov / MIC / step teardown hooks
 void pl_solver_free(pl_ctx* ctx);
 void pl_mic_free(pl_ctx* ctx);

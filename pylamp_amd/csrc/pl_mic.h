@@ -23,6 +23,7 @@ struct PlGatherGrid {
     int nz, nx;                 // node counts of the field being interpolated
     const double* gz; const double* gx;
     double zmin, xmin, Lz, Lx;
+    long long pitch, off;       // field element (i,j) is F[off + i*pitch + j] (dense: pitch = nx, off = 0)
 };
 
 struct PlGatherArgs {

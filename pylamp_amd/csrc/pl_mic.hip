@@ -144,10 +144,10 @@ __device__ inline CellLoc mic_locate(const PlGatherGrid& g, double z, double x) 
     return c;
 }
 
-__device__ inline double mic_bilinear(const double* __restrict__ F, int nx, const CellLoc& c) {
-    const long long o = (long long)c.ie * nx + c.je;
-    return (1 - c.b) * (1 - c.a) * F[o] + c.b * (1 - c.a) * F[o + 1] + (1 - c.b) * c.a * F[o + nx] +
-           c.b * c.a * F[o + nx + 1];
+__device__ inline double mic_bilinear(const double* __restrict__ F, const PlGatherGrid& g, const CellLoc& c) {
+    const long long o = g.off + (long long)c.ie * g.pitch + c.je;
+    return (1 - c.b) * (1 - c.a) * F[o] + c.b * (1 - c.a) * F[o + 1] + (1 - c.b) * c.a * F[o + g.pitch] +
+           c.b * c.a * F[o + g.pitch + 1];
 }
 
 // divergence-conserving velocity interpolation (pylamp_trac.py:98-154)
@@ -155,10 +155,10 @@ __device__ inline void mic_veldiv(const PlGatherGrid& g, const double* __restric
                                   const double* __restrict__ Vx, double z, double x, double defval, double& uz,
                                   double& ux, bool& bad) {
     const CellLoc c = mic_locate(g, z, x);
-    const long long o = (long long)c.ie * g.nx + c.je;
+    const long long o = g.off + (long long)c.ie * g.pitch + c.je;
     const double hz = g.gz[c.ie + 1] - g.gz[c.ie], hx = g.gx[c.je + 1] - g.gx[c.je];
-    const double z00 = Vz[o], z01 = Vz[o + 1], z10 = Vz[o + g.nx], z11 = Vz[o + g.nx + 1];
-    const double x00 = Vx[o], x01 = Vx[o + 1], x10 = Vx[o + g.nx], x11 = Vx[o + g.nx + 1];
+    const double z00 = Vz[o], z01 = Vz[o + 1], z10 = Vz[o + g.pitch], z11 = Vz[o + g.pitch + 1];
+    const double x00 = Vx[o], x01 = Vx[o + 1], x10 = Vx[o + g.pitch], x11 = Vx[o + g.pitch + 1];
     const double w00 = (1 - c.b) * (1 - c.a), w01 = c.b * (1 - c.a), w10 = (1 - c.b) * c.a, w11 = c.b * c.a;
     const double C10 = (0.5 * hx / hz) * (z00 - z10 + z11 - z01);
     const double C20 = (0.5 * hz / hx) * (x00 - x01 + x11 - x10);
@@ -181,13 +181,13 @@ __global__ __launch_bounds__(256) void k_gather(PlGatherArgs a) {
         const double d[4] = {dz0 * dz0 + dx0 * dx0, dz0 * dz0 + dx1 * dx1, dz1 * dz1 + dx0 * dx0, dz1 * dz1 + dx1 * dx1};
         int m = 0;
         for (int k = 1; k < 4; k++) if (d[k] < d[m]) m = k;     // first minimum, like np.argmin
-        const long long o = (long long)(c.ie + (m >> 1)) * a.g.nx + (c.je + (m & 1));
+        const long long o = a.g.off + (long long)(c.ie + (m >> 1)) * a.g.pitch + (c.je + (m & 1));
         for (int k = 0; k < a.nf; k++) a.out[k][t] = c.bad ? a.defval : a.fields[k][o];
         if (c.bad) atomicAdd(a.n_outside, 1ull);
     } else if (a.method & PL_INTERP_LINEAR) {
         const CellLoc c = mic_locate(a.g, z, x);
         for (int k = 0; k < a.nf; k++) {
-            const double v = mic_bilinear(a.fields[k], a.g.nx, c);
+            const double v = mic_bilinear(a.fields[k], a.g, c);
             a.out[k][t] = c.bad ? a.defval : (a.accumulate ? a.out[k][t] + v : v);
         }
         if (c.bad) atomicAdd(a.n_outside, 1ull);
@@ -242,6 +242,7 @@ static int upload_grid(pl_ctx* ctx, const char* name, int gnz, int gnx, const do
     PL_HIP(ctx, hipMemcpyAsync(d + gnz, gx, gnx * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     g.nz = gnz; g.nx = gnx; g.gz = d; g.gx = d + gnz;
     g.zmin = gz[0]; g.xmin = gx[0]; g.Lz = gz[gnz - 1] - gz[0]; g.Lx = gx[gnx - 1] - gx[0];
+    g.pitch = gnx; g.off = 0;
     return 0;
 }
 

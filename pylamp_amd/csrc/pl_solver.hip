@@ -421,6 +421,36 @@ __global__ __launch_bounds__(256) void k_prec_finish(PlGeom g, const double* __r
     z[c] = e[c] + z0[c]; z[c + g.plane] = e[c + g.plane] + z0[c + g.plane];
 }
 
+// Hydrostatic pressure guess: with v = 0 the interior z-momentum rows reduce to
+//   -2 Kc rDz_i (P[i,j] - P[i-1,j]) = -1/2 (rho[i,j] + rho[i,j+1]) g
+// which is integrated down every column (one thread per column), then shifted so that the
+// anchor cell is 0.  b - A x_h is the DYNAMIC load the solver's tolerance is measured against.
+__global__ void k_hydrostatic_columns(PlStokesOp op, double* __restrict__ x) {
+    const PlGeom& g = op.g;
+    const int lj = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lj >= g.lnx) return;
+    double* P = x + 2 * g.plane;
+    const double* r = op.rho;
+    double acc = 0.0;
+    P[pl_idx(g, 0, lj)] = 0.0;
+    for (int i = 1; i <= g.nz - 2; i++) {
+        const long long c = pl_idx(g, i, lj);
+        const int jn = (lj + 1 < g.nx) ? 1 : 0;
+        acc += 0.5 * (r[c] + r[c + jn]) * op.gz / (2.0 * op.Kc * TB(g.rDz, i));
+        P[c] = acc;
+    }
+    P[pl_idx(g, g.nz - 1, lj)] = 0.0;
+}
+
+__global__ __launch_bounds__(256) void k_hydrostatic_apply_shift(PlStokesOp op, double* __restrict__ x, const double* __restrict__ pa_ptr) {
+    PL_NODE_PROLOGUE(op.g)
+    const PlGeom& g = op.g;
+    double* P = x + 2 * g.plane;
+    const double pa = *pa_ptr;
+    x[c] = 0.0; x[c + g.plane] = 0.0;
+    P[c] = (i >= g.nz - 1 || j >= g.nx - 1) ? 0.0 : P[c] - pa;
+}
+
 // =========================================================================================
 // Host side
 // =========================================================================================
@@ -624,14 +654,16 @@ typedef std::function<int(const double*, double*)> VecOp;
 
 struct BicgVecs { double *r, *rt, *p, *v, *s, *t, *y, *z; };
 
+// ref_norm > 0 replaces ||b|| as the reference of the stopping test and of rel_residual.
 static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const VecOp& A, const VecOp* M,
                     const double* b, double* x, bool use_x0, double rtol, int maxit, BicgVecs w,
-                    pl_solve_stats* st) {
+                    pl_solve_stats* st, double ref_norm = 0.0) {
     const long long n = (long long)np * g.plane;
     const size_t bytes = (size_t)n * sizeof(double);
     double d2[2];
     PL_TRY(dots(ctx, S, g, np, b, b, nullptr, nullptr, d2));
-    const double bnorm = std::sqrt(d2[0]);
+    double bnorm = std::sqrt(d2[0]);
+    if (ref_norm > 0.0 && bnorm > 0.0) bnorm = ref_norm;
     st->iterations = 0; st->converged = 0; st->rel_residual = 0.0;
     if (!(bnorm > 0.0)) {                       // b = 0 -> x = 0
         PL_HIP(ctx, hipMemsetAsync(x, 0, bytes, ctx->stream));
@@ -724,7 +756,25 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
         PL_HIP(ctx, hipMemcpyAsync(S->b, b_dev, (size_t)3 * g.plane * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     hipLaunchKernelGGL(k_stokes_scale_rows, grid2d(g), dim3(64, 4), 0, ctx->stream, sop, S->b);
     BicgVecs w{S->r, S->rt, S->p, S->v, S->s, S->t, S->y, S->z};
-    PL_TRY(bicgstab(ctx, S, g, 3, A, &M, S->b, S->x, use_x0, rtol, maxit, w, st));
+    // hydrostatic pressure x_h (in S->y) and the dynamic-load reference norm ||D_r (b - A x_h)||
+    double d2[2], ref = 0.0;
+    {
+        const long long n3 = 3 * g.plane;
+        hipLaunchKernelGGL(k_hydrostatic_columns, dim3((g.lnx + 63) / 64), dim3(64), 0, ctx->stream, sop, S->y);
+        PL_HIP(ctx, hipMemcpyAsync(S->scal + 4, S->y + 2 * g.plane + pl_idx(g, sop.anchor_i, sop.anchor_j), sizeof(double),
+                                   hipMemcpyDeviceToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_hydrostatic_apply_shift, grid2d(g), dim3(64, 4), 0, ctx->stream, sop, S->y, S->scal + 4);
+        PL_TRY(A(S->y, S->t));
+        hipLaunchKernelGGL(k_axpy_out, grid1d(n3), dim3(256), 0, ctx->stream, n3, S->s, S->b, S->t, -1.0);
+        PL_TRY(dots(ctx, S, g, 3, S->s, S->s, S->b, S->b, d2));
+        ref = std::sqrt(d2[0]);
+        if (!(ref > 1e-14 * std::sqrt(d2[1]))) ref = 0.0;          // no dynamic load at all: fall back to ||b||
+        if (!use_x0) {                                               // cold start from the hydrostatic state
+            PL_HIP(ctx, hipMemcpyAsync(S->x, S->y, (size_t)n3 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+            use_x0 = true;
+        }
+    }
+    PL_TRY(bicgstab(ctx, S, g, 3, A, &M, S->b, S->x, use_x0, rtol, maxit, w, st, ref));
     double ms = 0;
     PL_TRY(pl_timer_stop_ms(ctx, &ms));
     st->solve_ms = ms; st->operator_applies = S->napply; st->precond_applies = S->nprec;

