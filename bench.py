@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Benchmark of the PyLamp hot path on MI355X: full time step (MIC scatter, Stokes solve, heat
+solve, temperature to tracers, RK4 advection) at BASELINE config 3 — 2049x2049 nodes
+(2048x2048 cells), 16 markers per node (67.2 M tracers), T-dependent mantle model with heat.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0).  `value` = cell-updates/s = cells * steps / time, whole job.
+Extra objects: `roofline` (matrix-free Stokes stencil, algorithmic 64 B/node/apply, timed with
+HIP events on the library's own stream) and `cpu_baseline` (the NumPy/SciPy oracle = numerically
+the reference path, on a bounded sample, rank 0 at N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def build_sim(n, tracdens, seed, device):
+    from pylamp_amd import driver
+    nx = [n, n]; L = [660e3, 660e3]
+    rng = np.random.default_rng(seed)
+    tr_x, tr_f = driver.mantle_tracers(nx, L, tracdens, rng)
+    sim = driver.Simulation(nx, L, tr_x, tr_f, driver.Options(), device=device)
+    del tr_x, tr_f
+    return sim
+
+
+def kernel_roofline(sim, reps):
+    """Average duration of the Stokes stencil apply on the resident operator (HIP events)."""
+    ctx = sim.ctx
+    ms = C.c_double()
+    best = None
+    for _ in range(3):
+        ctx.check(ctx.lib.pl_stokes_apply_bench(ctx.h, reps, C.byref(ms)))
+        best = ms.value if best is None else min(best, ms.value)
+    avg_ms = ms.value                       # report the LAST average (not the best) as the measured value
+    n = sim.nx[0] * sim.nx[1]
+    alg_bytes = 64.0 * n                    # x 24 + etas 8 + etan 8 + y 24 B per node
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tf):
+        try:
+            traffic = json.load(open(tf)).get("k_stokes_apply", {}).get(str(sim.nx[0]))
+        except Exception:
+            traffic = None
+    return {"kernel": "k_stokes_apply", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 5),
+            "best_launch_ms": round(best, 5), "launches_timed": reps}
+
+
+def cpu_baseline(n=257, tracdens=16, steps=1):
+    """The oracle (NumPy assembly + scipy spsolve + NumPy MIC) on a bounded sample."""
+    from oracle import pylamp_oracle as O
+    from pylamp_amd import driver
+    nx = [n, n]; L = [660e3, 660e3]
+    rng = np.random.default_rng(20260103)
+    tr_x, tr_f = driver.mantle_tracers(nx, L, tracdens, rng)
+    st = dict(nx=nx, L=L, grid=[np.linspace(0, L[0], n), np.linspace(0, L[1], n)], tr_x=tr_x, tr_f=tr_f)
+    cfg = O.StepConfig()
+    t0 = time.perf_counter()
+    for it in range(1, steps + 1):
+        O.step(st, cfg, it)
+    dt = time.perf_counter() - t0
+    cells = (n - 1) * (n - 1)
+    return {"value": round(cells * steps / dt, 1), "unit": "cell-updates/s", "cores": 1, "kind": "port",
+            "sample": "full step (scatter, scipy spsolve Stokes, heat, gather, RK4), mantle model, %dx%d nodes, "
+                      "%d markers/node, %d step(s), %.1f s; the direct solve is infeasible at 2049^2" %
+                      (n, n, tracdens, steps, dt),
+            "steps_per_s": round(steps / dt, 5)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=2049, help="nodes per side (default: BASELINE config 3)")
+    ap.add_argument("--tracdens", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--apply-reps", type=int, default=50)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    sim = build_sim(args.n, args.tracdens, 20260103 + rank, local_rank)
+    ctx = sim.ctx
+    reports = []
+    for _ in range(args.warmup):
+        reports.append(sim.step())
+    ctx.check(ctx.lib.pl_sync(ctx.h))
+    barrier()
+    t0 = time.perf_counter()
+    timed = []
+    for _ in range(args.steps):
+        timed.append(sim.step())
+    ctx.check(ctx.lib.pl_sync(ctx.h))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    cells = (args.n - 1) * (args.n - 1)
+    ms_per_step = 1e3 * elapsed / args.steps
+    # N > 1: every rank advances its own full-size replica (grid domain decomposition over RCCL is
+    # not in this round); the aggregate is therefore replica throughput, labelled as such.
+    value = cells * args.steps * world / elapsed
+    if rank == 0:
+        roof = kernel_roofline(sim, args.apply_reps)
+        stage_keys = ["ms_sort", "ms_props", "ms_scatter", "ms_stokes", "ms_heat", "ms_gather", "ms_advect", "ms_total"]
+        stages = {k: round(float(np.mean([r[k] for r in timed])), 3) for k in stage_keys}
+        out = {
+            "metric": "stokes_heat_mic_cell_updates_per_s", "value": round(value, 1), "unit": "cell-updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "2D %dx%d nodes (%dx%d cells), %d markers/node (%d tracers), T-dependent mantle "
+                                   "model, heat + subgrid diffusion on, all free-slip, full time step" %
+                                   (args.n, args.n, args.n - 1, args.n - 1, args.tracdens, sim.ntrac),
+                       "parallelism": "1 GPU" if world == 1 else "%d independent replicas (no domain decomposition yet)" % world,
+                       "stokes_rtol": sim.opt.stokes_rtol, "heat_rtol": sim.opt.heat_rtol},
+            "time_steps_per_s": round(args.steps * world / elapsed, 4),
+            "stage_ms": stages,
+            "stokes_iterations": [r["stokes"]["iterations"] for r in timed],
+            "stokes_rel_residual": [float("%.3g" % r["stokes"]["rel_residual"]) for r in timed],
+            "stokes_converged": [r["stokes"]["converged"] for r in timed],
+            "heat_iterations": [r["heat"]["iterations"] for r in timed],
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -17,7 +17,14 @@ struct PlScatterArgs {
     // dense (nz*nx) accumulators
     double* wsum; double* cnt;
     double* acc[PL_MAX_SCATTER_FIELDS];
+    // cell-sorted tracers (optional): tracers of sort cell (ci,cj) are [cell_start[ci*ncx+cj],
+    // cell_start[ci*ncx+cj+1]); the sort grid has ncz x ncx cells.  NULL -> unsorted path.
+    const int* cell_start; int ncz, ncx;
 };
+
+// tile of sort cells handled by one workgroup of the LDS-binned scatter
+#define PL_TILE_R 8
+#define PL_TILE_C 32
 
 struct PlGatherGrid {
     int nz, nx;                 // node counts of the field being interpolated

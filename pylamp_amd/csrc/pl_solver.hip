@@ -253,38 +253,33 @@ __global__ __launch_bounds__(256) void k_coarsen_visc(PlGeom gf, const double* _
 // =========================================================================================
 // Vector kernels (nplanes planes; dots over interior nodes only)
 // =========================================================================================
-__device__ inline double block_reduce_sum(double v) {
-    __shared__ double sh[4];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    const int tid = threadIdx.y * 64 + threadIdx.x;
-    if ((tid & 63) == 0) sh[tid >> 6] = v;
-    __syncthreads();
-    double r = 0.0;
-    if (tid == 0) r = sh[0] + sh[1] + sh[2] + sh[3];
-    return r;
-}
-
-// out[0] += a.b   out[1] += c.d   (either pair may be NULL)
+// Block partials of two dot products over the interior nodes of nplanes planes:
+// part[2*b] = sum a.b, part[2*b+1] = sum c.d (either pair may be NULL).  Grid-stride over rows,
+// no atomics; the host adds the (<= DOT_BLOCKS) partials in a fixed order, so the result is
+// deterministic.
+#define DOT_BLOCKS 1024
 __global__ __launch_bounds__(256) void k_dot2(PlGeom g, int nplanes, const double* __restrict__ a,
                                               const double* __restrict__ b, const double* __restrict__ cc,
-                                              const double* __restrict__ dd, double* __restrict__ out) {
-    const int lj = blockIdx.x * 64 + threadIdx.x, li = blockIdx.y * 4 + threadIdx.y;
+                                              const double* __restrict__ dd, double* __restrict__ part) {
     double s0 = 0.0, s1 = 0.0;
-    if (lj < g.lnx && li < g.lnz) {
-        const long long c = pl_idx(g, li, lj);
-        for (int q = 0; q < nplanes; q++) {
-            const long long o = c + q * g.plane;
+    const long long rows = (long long)g.lnz * nplanes;
+    for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
+        const int q = (int)(r / g.lnz), li = (int)(r % g.lnz);
+        const long long base = pl_idx(g, li, 0) + q * g.plane;
+        for (int lj = threadIdx.x; lj < g.lnx; lj += 256) {
+            const long long o = base + lj;
             if (a) s0 += a[o] * b[o];
             if (cc) s1 += cc[o] * dd[o];
         }
     }
-    s0 = block_reduce_sum(s0);
+    __shared__ double sh[2][4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_down(s0, o, 64); s1 += __shfl_down(s1, o, 64); }
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s0; sh[1][threadIdx.x >> 6] = s1; }
     __syncthreads();
-    s1 = block_reduce_sum(s1);
-    if (threadIdx.x == 0 && threadIdx.y == 0) {
-        if (a) unsafeAtomicAdd(out, s0);
-        if (cc) unsafeAtomicAdd(out + 1, s1);
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+        part[2 * blockIdx.x + 1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
     }
 }
 
@@ -469,7 +464,8 @@ struct PlSolver {
     // BiCGStab work vectors (3 planes each)
     double *r = nullptr, *rt = nullptr, *p = nullptr, *v = nullptr, *s = nullptr, *t = nullptr, *y = nullptr,
            *z = nullptr, *b = nullptr, *x = nullptr, *z0 = nullptr;
-    double* scal = nullptr;     // device scalars
+    double* scal = nullptr;     // device scalars [0..8) + dot partials [8..8+2*DOT_BLOCKS)
+    double* hpart = nullptr;    // pinned host copy of the dot partials
     int nu_pre = 2, nu_post = 2, coarse_sweeps = 40;
     // heat work vectors (1 plane each)
     double* h[9] = {nullptr};
@@ -498,6 +494,7 @@ void pl_solver_free(pl_ctx* ctx) {
     for (double* q : {S->r, S->rt, S->p, S->v, S->s, S->t, S->y, S->z, S->b, S->x, S->z0, S->scal})
         if (q) (void)hipFree(q);
     for (double* q : S->h) if (q) (void)hipFree(q);
+    if (S->hpart) (void)hipHostFree(S->hpart);
     delete S;
     ctx->krylov = nullptr;
 }
@@ -510,10 +507,14 @@ static int dmalloc0(pl_ctx* ctx, double** p, size_t bytes) {
 
 static int dots(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const double* a, const double* b, const double* c,
                 const double* d, double* out2) {
-    PL_HIP(ctx, hipMemsetAsync(S->scal, 0, 2 * sizeof(double), ctx->stream));
-    hipLaunchKernelGGL(k_dot2, grid2d(g), dim3(64, 4), 0, ctx->stream, g, np, a, b, c, d, S->scal);
-    PL_HIP(ctx, hipMemcpyAsync(out2, S->scal, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    long long rows = (long long)g.lnz * np;
+    const int nb = (int)(rows < DOT_BLOCKS ? rows : DOT_BLOCKS);
+    hipLaunchKernelGGL(k_dot2, dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 8);
+    PL_HIP(ctx, hipMemcpyAsync(S->hpart, S->scal + 8, (size_t)2 * nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = 0; k < nb; k++) { s0 += S->hpart[2 * k]; s1 += S->hpart[2 * k + 1]; }
+    out2[0] = s0; out2[1] = s1;
     return 0;
 }
 
@@ -731,7 +732,10 @@ static int stokes_alloc(pl_ctx* ctx, PlSolver* S) {
     size_t vb = (size_t)3 * ctx->geom.d.plane * sizeof(double);
     for (double** q : {&S->r, &S->rt, &S->p, &S->v, &S->s, &S->t, &S->y, &S->z, &S->b, &S->x, &S->z0})
         PL_TRY(dmalloc0(ctx, q, vb));
-    if (!S->scal) PL_TRY(dmalloc0(ctx, &S->scal, 64));
+    if (!S->scal) {
+        PL_TRY(dmalloc0(ctx, &S->scal, (8 + 2 * DOT_BLOCKS) * sizeof(double)));
+        PL_HIP(ctx, hipHostMalloc((void**)&S->hpart, 2 * DOT_BLOCKS * sizeof(double)));
+    }
     return 0;
 }
 
@@ -853,7 +857,10 @@ int pl_heat_solve_device(pl_ctx* ctx, const double* b_dev, double rtol, int maxi
     const PlGeom& g = ctx->geom.d;
     size_t pb = (size_t)g.plane * sizeof(double);
     for (int k = 0; k < 9; k++) if (!S->h[k]) PL_TRY(dmalloc0(ctx, &S->h[k], pb));
-    if (!S->scal) PL_TRY(dmalloc0(ctx, &S->scal, 64));
+    if (!S->scal) {
+        PL_TRY(dmalloc0(ctx, &S->scal, (8 + 2 * DOT_BLOCKS) * sizeof(double)));
+        PL_HIP(ctx, hipHostMalloc((void**)&S->hpart, 2 * DOT_BLOCKS * sizeof(double)));
+    }
     PL_TRY(pl_timer_start(ctx));
     PlHeatOp hop = ctx->hop;
     S->napply = 0;

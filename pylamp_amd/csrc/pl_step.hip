@@ -26,6 +26,12 @@ struct PlStepState {
     std::vector<double> hpartial;
     double* gcoords = nullptr;                       // device copies of node / padded-centre coordinates
     bool have_newtemp = false, have_solution = false;
+    // cell sort
+    double* f2[NFTRAC] = {nullptr};                  // permutation targets (swapped with f)
+    int* cell = nullptr; int* dest = nullptr;        // per tracer: sort cell, destination slot
+    int* orig = nullptr; int* orig2 = nullptr;       // caller's index of the tracer now stored at slot t
+    int* cell_count = nullptr; int* cell_start = nullptr; int* block_sums = nullptr;
+    int ncz = 0, ncx = 0;
     std::vector<double> gmz, gmx;                    // midpoint grids (pylamp2.py:92-95)
 };
 
@@ -40,6 +46,8 @@ void pl_step_free(pl_ctx* ctx) {
     for (double* q : {s->tz, s->tx, s->tz2, s->tx2, s->vtz, s->vtx, s->tmp[0], s->tmp[1], s->tmp[2], s->partial, s->gcoords})
         if (q) (void)hipFree(q);
     for (double* q : s->f) if (q) (void)hipFree(q);
+    for (double* q : s->f2) if (q) (void)hipFree(q);
+    for (int* q : {s->cell, s->dest, s->orig, s->orig2, s->cell_count, s->cell_start, s->block_sums}) if (q) (void)hipFree(q);
     delete s;
     ctx->step = nullptr;
 }
@@ -68,6 +76,89 @@ __global__ __launch_bounds__(256) void k_col_to_aos(long long m, const double* _
                                                     double* __restrict__ dst) {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < m) dst[t * ld + k] = src[t];
+}
+
+// ---- counting sort of the tracers by node-grid cell --------------------------------------------
+__global__ __launch_bounds__(256) void k_cell_count(long long n, const double* __restrict__ tz, const double* __restrict__ tx,
+                                                    double z0, double hz, double x0, double hx, int ncz, int ncx,
+                                                    int* __restrict__ cell, int* __restrict__ count) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    int ci = (int)floor((tz[t] - z0) / hz), cj = (int)floor((tx[t] - x0) / hx);
+    ci = min(max(ci, 0), ncz - 1); cj = min(max(cj, 0), ncx - 1);
+    const int c = ci * ncx + cj;
+    cell[t] = c;
+    atomicAdd(&count[c], 1);
+}
+// exclusive scan of m ints in three passes (1024 elements per block)
+__global__ __launch_bounds__(256) void k_scan_block(int m, const int* __restrict__ in, int* __restrict__ out,
+                                                    int* __restrict__ bsum) {
+    __shared__ int sh[256];
+    const int base = blockIdx.x * 1024 + threadIdx.x * 4;
+    int v[4], s = 0;
+    for (int k = 0; k < 4; k++) { v[k] = (base + k < m) ? in[base + k] : 0; s += v[k]; }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        int add = (threadIdx.x >= o) ? sh[threadIdx.x - o] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += add;
+        __syncthreads();
+    }
+    int run = sh[threadIdx.x] - s;                 // exclusive prefix of this thread inside the block
+    for (int k = 0; k < 4; k++) { if (base + k < m) out[base + k] = run; run += v[k]; }
+    if (threadIdx.x == 255) bsum[blockIdx.x] = sh[255];
+}
+__global__ void k_scan_sums(int nb, int* __restrict__ bsum) {       // single thread block, serial over <= 64k sums
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < nb; b0 += 256) {
+        __shared__ int sh[256];
+        const int k = b0 + threadIdx.x;
+        const int v = (k < nb) ? bsum[k] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            int add = (threadIdx.x >= o) ? sh[threadIdx.x - o] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (k < nb) bsum[k] = carry + sh[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry += sh[255];
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void k_scan_add(int m, int* __restrict__ out, const int* __restrict__ bsum, int total_slot) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k < m) out[k] += bsum[k / 1024];
+    (void)total_slot;
+}
+__global__ __launch_bounds__(256) void k_cell_place(long long n, const int* __restrict__ cell, const int* __restrict__ start,
+                                                    int* __restrict__ fill, int* __restrict__ dest) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int c = cell[t];
+    dest[t] = start[c] + atomicAdd(&fill[c], 1);
+}
+__global__ __launch_bounds__(256) void k_iota(long long n, int* __restrict__ v) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) v[t] = (int)t;
+}
+__global__ __launch_bounds__(256) void k_permute_int(long long n, const int* __restrict__ dest, const int* __restrict__ in,
+                                                     int* __restrict__ out) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[dest[t]] = in[t];
+}
+// out_k[dest[t]] = in_k[t] for up to 5 arrays per launch
+struct PermArgs { const double* in[5]; double* out[5]; int na; };
+__global__ __launch_bounds__(256) void k_permute(long long n, const int* __restrict__ dest, PermArgs a) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int d = dest[t];
+    for (int k = 0; k < a.na; k++) a.out[k][d] = a.in[k][t];
 }
 
 // pylamp2.py:291-303
@@ -223,10 +314,16 @@ static int ensure_tracers(pl_ctx* ctx, PlStepState* S, long long n) {
         return 0;
     };
     for (double** q : {&S->tz, &S->tx, &S->tz2, &S->tx2, &S->vtz, &S->vtx, &S->tmp[0], &S->tmp[1], &S->tmp[2]}) PL_TRY(re(q));
-    for (int k = 0; k < NFTRAC; k++) PL_TRY(re(&S->f[k]));
+    for (int k = 0; k < NFTRAC; k++) { PL_TRY(re(&S->f[k])); PL_TRY(re(&S->f2[k])); }
+    for (int** q : {&S->cell, &S->dest, &S->orig, &S->orig2}) {
+        if (*q) (void)hipFree(*q);
+        PL_HIP(ctx, hipMalloc((void**)q, (size_t)cap * sizeof(int)));
+    }
     S->cap = cap;
     return 0;
 }
+
+static void unpermute(pl_ctx* ctx, PlStepState* S, int na, const double* const* in, double* const* out);
 
 extern "C" int pl_tracers_upload(pl_ctx* ctx, int64_t n, const double* tr_x, const double* tr_f) {
     if (n < 0 || !tr_x || !tr_f) return pl_fail(ctx, "pl_tracers_upload: bad argument");
@@ -247,6 +344,8 @@ extern "C" int pl_tracers_upload(pl_ctx* ctx, int64_t n, const double* tr_x, con
         PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     PL_HIP(ctx, hipGetLastError());
+    if (n > 0) hipLaunchKernelGGL(k_iota, grid1d(n), dim3(256), 0, ctx->stream, (long long)n, S->orig);
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     S->n = n; S->have_newtemp = false; S->have_solution = false;
     return 0;
 }
@@ -257,16 +356,23 @@ extern "C" int pl_tracers_download(pl_ctx* ctx, int64_t n, double* tr_x, double*
     PL_HIP(ctx, hipSetDevice(ctx->device));
     const long long chunk = 1 << 22;
     PL_TRY(pl_stage(ctx, (size_t)chunk * NFTRAC * sizeof(double)));
+    {   // caller's order
+        const double* in[15]; double* out[15];
+        in[0] = S->tz; out[0] = S->tz2; in[1] = S->tx; out[1] = S->tx2;
+        for (int k = 0; k < NFTRAC; k++) { in[2 + k] = S->f[k]; out[2 + k] = S->f2[k]; }
+        unpermute(ctx, S, 15, in, out);
+    }
+    double* const uz = S->tz2; double* const ux = S->tx2; double* const* uf = S->f2;
     for (long long t0 = 0; t0 < n; t0 += chunk) {
         long long m = std::min<long long>(chunk, n - t0);
         if (tr_x) {
-            hipLaunchKernelGGL(k_aos2_from_soa, grid1d(m), dim3(256), 0, ctx->stream, m, S->tz + t0, S->tx + t0, ctx->stage);
+            hipLaunchKernelGGL(k_aos2_from_soa, grid1d(m), dim3(256), 0, ctx->stream, m, uz + t0, ux + t0, ctx->stage);
             PL_HIP(ctx, hipMemcpyAsync(tr_x + 2 * t0, ctx->stage, (size_t)m * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
             PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }
         if (tr_f) {
             for (int k = 0; k < NFTRAC; k++)
-                hipLaunchKernelGGL(k_col_to_aos, grid1d(m), dim3(256), 0, ctx->stream, m, S->f[k] + t0, NFTRAC, k, ctx->stage);
+                hipLaunchKernelGGL(k_col_to_aos, grid1d(m), dim3(256), 0, ctx->stream, m, uf[k] + t0, NFTRAC, k, ctx->stage);
             PL_HIP(ctx, hipMemcpyAsync(tr_f + NFTRAC * t0, ctx->stage, (size_t)m * NFTRAC * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
             PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }
@@ -286,13 +392,63 @@ extern "C" int pl_get_tracer_velocity(pl_ctx* ctx, int64_t n, double* out) {
     PL_HIP(ctx, hipSetDevice(ctx->device));
     const long long chunk = 1 << 22;
     PL_TRY(pl_stage(ctx, (size_t)chunk * 2 * sizeof(double)));
+    {
+        const double* in[2] = {S->vtz, S->vtx}; double* out[2] = {S->tmp[0], S->tmp[1]};
+        unpermute(ctx, S, 2, in, out);
+    }
     for (long long t0 = 0; t0 < n; t0 += chunk) {
         long long m = std::min<long long>(chunk, n - t0);
-        hipLaunchKernelGGL(k_aos2_from_soa, grid1d(m), dim3(256), 0, ctx->stream, m, S->vtz + t0, S->vtx + t0, ctx->stage);
+        hipLaunchKernelGGL(k_aos2_from_soa, grid1d(m), dim3(256), 0, ctx->stream, m, S->tmp[0] + t0, S->tmp[1] + t0, ctx->stage);
         PL_HIP(ctx, hipMemcpyAsync(out + 2 * t0, ctx->stage, (size_t)m * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     return 0;
+}
+
+// Counting sort of all tracer arrays by node-grid cell; leaves cell_start (ncells+1 ints) valid.
+static int sort_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, double x0, double hx) {
+    const int ncz = ctx->nz - 1, ncx = ctx->nx - 1, nc = ncz * ncx;
+    const long long n = S->n;
+    if (n >= (1LL << 31)) return pl_fail(ctx, "sort_tracers: more than 2^31 tracers per GPU");
+    if (!S->cell_count) {
+        const int nb = (nc + 1 + 1023) / 1024;
+        PL_HIP(ctx, hipMalloc((void**)&S->cell_count, (size_t)(nc + 1) * sizeof(int)));
+        PL_HIP(ctx, hipMalloc((void**)&S->cell_start, (size_t)(nc + 1) * sizeof(int)));
+        PL_HIP(ctx, hipMalloc((void**)&S->block_sums, (size_t)(nb + 1) * sizeof(int)));
+        S->ncz = ncz; S->ncx = ncx;
+    }
+    PL_HIP(ctx, hipMemsetAsync(S->cell_count, 0, (size_t)(nc + 1) * sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_cell_count, grid1d(n), dim3(256), 0, ctx->stream, n, S->tz, S->tx, z0, hz, x0, hx, ncz, ncx, S->cell,
+                       S->cell_count);
+    const int m = nc + 1, nb = (m + 1023) / 1024;
+    hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(256), 0, ctx->stream, m, S->cell_count, S->cell_start, S->block_sums);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, ctx->stream, nb, S->block_sums);
+    hipLaunchKernelGGL(k_scan_add, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, m, S->cell_start, S->block_sums, 0);
+    PL_HIP(ctx, hipMemsetAsync(S->cell_count, 0, (size_t)(nc + 1) * sizeof(int), ctx->stream));   // reused as fill counters
+    hipLaunchKernelGGL(k_cell_place, grid1d(n), dim3(256), 0, ctx->stream, n, S->cell, S->cell_start, S->cell_count, S->dest);
+    // permute positions and the 13 fields
+    const double* src[15]; double* dst[15];
+    src[0] = S->tz; dst[0] = S->tz2; src[1] = S->tx; dst[1] = S->tx2;
+    for (int k = 0; k < NFTRAC; k++) { src[2 + k] = S->f[k]; dst[2 + k] = S->f2[k]; }
+    for (int k0 = 0; k0 < 15; k0 += 5) {
+        PermArgs pa{}; pa.na = 5;
+        for (int k = 0; k < 5; k++) { pa.in[k] = src[k0 + k]; pa.out[k] = dst[k0 + k]; }
+        hipLaunchKernelGGL(k_permute, grid1d(n), dim3(256), 0, ctx->stream, n, S->dest, pa);
+    }
+    hipLaunchKernelGGL(k_permute_int, grid1d(n), dim3(256), 0, ctx->stream, n, S->dest, S->orig, S->orig2);
+    PL_HIP(ctx, hipGetLastError());
+    std::swap(S->tz, S->tz2); std::swap(S->tx, S->tx2); std::swap(S->orig, S->orig2);
+    for (int k = 0; k < NFTRAC; k++) std::swap(S->f[k], S->f2[k]);
+    return 0;
+}
+
+// un-permute resident arrays into the spare buffers so that downloads come out in the caller's order
+static void unpermute(pl_ctx* ctx, PlStepState* S, int na, const double* const* in, double* const* out) {
+    for (int k0 = 0; k0 < na; k0 += 5) {
+        PermArgs pa{}; pa.na = std::min(5, na - k0);
+        for (int k = 0; k < pa.na; k++) { pa.in[k] = in[k0 + k]; pa.out[k] = out[k0 + k]; }
+        hipLaunchKernelGGL(k_permute, grid1d(S->n), dim3(256), 0, ctx->stream, S->n, S->orig, pa);
+    }
 }
 
 static double now_ms() {
@@ -307,6 +463,7 @@ static int scatter_to_planes(pl_ctx* ctx, PlStepState* S, int nf, const int* fid
     a.n = S->n; a.tz = S->tz; a.tx = S->tx; a.nf = nf;
     for (int k = 0; k < nf; k++) { a.f[k] = fidx[k] >= 0 ? S->f[fidx[k]] : S->tmp[-fidx[k] - 1]; a.scheme[k] = schemes[k]; }
     a.z0 = z0; a.hz = hz; a.x0 = x0; a.hx = hx; a.nz = g.nz; a.nx = g.nx;
+    a.cell_start = S->cell_start; a.ncz = S->ncz; a.ncx = S->ncx;     // tracers are cell-sorted (sort_tracers)
     return pl_scatter_device(ctx, a, planes, g.pitch, pl_idx(g, 0, 0));
 }
 
@@ -338,6 +495,12 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
     PL_TRY(pl_buf(ctx, "mat", pb, &p_mat)); PL_TRY(pl_buf(ctx, "kz", pb, &p_kz)); PL_TRY(pl_buf(ctx, "kx", pb, &p_kx));
     PL_TRY(pl_buf(ctx, "temp", pb, &p_newT)); PL_TRY(pl_buf(ctx, "heat_c", pb, &p_c)); PL_TRY(pl_buf(ctx, "sgc", pb, &p_sgc));
     PL_TRY(pl_buf(ctx, "dT", pb, &p_dT));
+
+    // ---- 0. cell sort (keeps scatter windows and gathers local) -----------------------------
+    t0 = now_ms();
+    PL_TRY(sort_tracers(ctx, S, z0, hz, x0, hx));
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    rep->ms_sort = now_ms() - t0;
 
     // ---- 1. tracer properties --------------------------------------------------------------
     t0 = now_ms();
