@@ -85,7 +85,8 @@ int  pl_stokes_solve(pl_ctx* ctx, const double* rhs, double* x, int use_x0, doub
 int  pl_stokes_apply_bench(pl_ctx* ctx, int reps, double* avg_ms);
 
 /* Diagnostics for component tests of the solver: z = M^-1 r for an UNSCALED residual r in
- * the reference DOF order (builds the multigrid hierarchy for the current coefficients), and
+ * the reference DOF order (builds the multigrid hierarchy for the current coefficients; the
+ * wall/slave/ghost velocity rows of r are ignored - they are identically zero in the solver), and
  * the hierarchy's level count / per-level Chebyshev lambda_max. */
 int  pl_stokes_precond_apply(pl_ctx* ctx, const double* r, double* z);
 int  pl_stokes_mg_info(pl_ctx* ctx, int* nlevels, double* lmax, int max_levels);

@@ -193,7 +193,7 @@ def hierarchy(nx,grid,etas,etan,bc,mode="geom",natural=True,min_cells=4):
     for L in Ls: L.lmax=1.1*lmax_est(L)
     return Ls
 
-def vcycle(Ls,l,fz,fx,gz=None,gx=None,nu=(3,3),csweeps=40,damp=1.0):
+def vcycle(Ls,l,fz,fx,gz=None,gx=None,nu=(3,3),csweeps=12,damp=1.0):
     L=Ls[l]
     vz=np.zeros_like(fz); vx=np.zeros_like(fx)
     if l==len(Ls)-1:

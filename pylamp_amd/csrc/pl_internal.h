@@ -40,6 +40,7 @@ struct PlStokesOp {
     int surfstab; double ss; // ss = theta * tstep
     int anchor_i, anchor_j;  // pressure anchor cell (3,2) (pylamp_stokes.py:536-551)
     double gz, gx;           // gravity components G[IZ], G[IX] (pylamp_const.py:21)
+    int scaled;              // 1: y = D_r A x (Jacobi-like row scaling used by the Krylov solver)
 };
 
 struct PlHeatOp {

@@ -100,10 +100,9 @@ __device__ inline void vv_row_x(const PlVvOp& op, const double* __restrict__ vz,
 //     v_next = v_cur + c1 (v_cur - v_prev) + c2 D^-1 (f - A v_cur)
 // with the constraint rows closed in the same pass (a slave thread evaluates its master's
 // update; all inputs are read-only so there is no ordering hazard).  80 B/node/sweep.
-__global__ __launch_bounds__(256) void k_vv_cheb(PlVvOp op, const double* __restrict__ vcur,
-                                                 const double* __restrict__ vprev, const double* __restrict__ f,
-                                                 double* __restrict__ vnext, double c1, double c2) {
-    PL_NODE_PROLOGUE(op.g)
+__device__ inline void cheb_node(const PlVvOp& op, const double* __restrict__ vcur, const double* __restrict__ vprev,
+                                 const double* __restrict__ f, double* __restrict__ vnext, double c1, double c2, int i,
+                                 int j, long long c) {
     const long long P = op.g.plane;
     const double* vz = vcur; const double* vx = vcur + P;
     int moff = 0; double s = 1.0;
@@ -132,17 +131,29 @@ __global__ __launch_bounds__(256) void k_vv_cheb(PlVvOp op, const double* __rest
     vnext[c + P] = out;
 }
 
+__global__ __launch_bounds__(256) void k_vv_cheb(PlVvOp op, const double* __restrict__ vcur,
+                                                 const double* __restrict__ vprev, const double* __restrict__ f,
+                                                 double* __restrict__ vnext, double c1, double c2) {
+    PL_NODE_PROLOGUE(op.g)
+    cheb_node(op, vcur, vprev, f, vnext, c1, c2, i, j, c);
+}
+
 // r = f - A v on interior rows, 0 elsewhere
 // (f and r may alias: every thread reads only its own f entries before writing r)
-__global__ __launch_bounds__(256) void k_vv_residual(PlVvOp op, const double* __restrict__ v, const double* f,
-                                                     double* r) {
-    PL_NODE_PROLOGUE(op.g)
+__device__ inline void residual_node(const PlVvOp& op, const double* __restrict__ v, const double* f, double* r, int i,
+                                     int j, long long c) {
     const long long P = op.g.plane;
     int moff; double s, Av, dg;
     double rz = 0.0, rx = 0.0;
     if (vv_cls_z(op, i, j, moff, s) == VV_INT) { vv_row_z(op, v, v + P, c, i, j, Av, dg); rz = f[c] - Av; }
     if (vv_cls_x(op, i, j, moff, s) == VV_INT) { vv_row_x(op, v, v + P, c, i, j, Av, dg); rx = f[c + P] - Av; }
     r[c] = rz; r[c + P] = rx;
+}
+
+__global__ __launch_bounds__(256) void k_vv_residual(PlVvOp op, const double* __restrict__ v, const double* f,
+                                                     double* r) {
+    PL_NODE_PROLOGUE(op.g)
+    residual_node(op, v, f, r, i, j, c);
 }
 
 // y = D^-1 A v with closure (power iteration for lambda_max)
@@ -166,9 +177,8 @@ __global__ __launch_bounds__(256) void k_vv_dinv_apply(PlVvOp op, const double* 
 
 // Full-weighting restriction of the velocity residual (uniform-grid weights):
 // vz is vertex-centred in z [1/4,1/2,1/4] and cell-centred in x [1/8,3/8,3/8,1/8]; vx mirrored.
-__global__ __launch_bounds__(256) void k_vv_restrict(PlGeom gf, PlVvOp opc, const double* __restrict__ rf,
-                                                     double* __restrict__ fc) {
-    PL_NODE_PROLOGUE(opc.g)
+__device__ inline void restrict_node(const PlGeom& gf, const PlVvOp& opc, const double* __restrict__ rf,
+                                     double* __restrict__ fc, int i, int j, long long c) {
     int moff; double s;
     const int pf = gf.pitch;
     double oz = 0.0, ox = 0.0;
@@ -189,6 +199,12 @@ __global__ __launch_bounds__(256) void k_vv_restrict(PlGeom gf, PlVvOp opc, cons
             for (int q = 0; q < 3; q++) ox += wz[a] * wx[q] * rf[b + (long long)(a - 1) * pf + (q - 1)];
     }
     fc[c] = oz; fc[c + opc.g.plane] = ox;
+}
+
+__global__ __launch_bounds__(256) void k_vv_restrict(PlGeom gf, PlVvOp opc, const double* __restrict__ rf,
+                                                     double* __restrict__ fc) {
+    PL_NODE_PROLOGUE(opc.g)
+    restrict_node(gf, opc, rf, fc, i, j, c);
 }
 
 // (P e)(i,j) for vz / vx on the fine grid from the coarse correction e (bilinear; mirror clamp)
@@ -212,9 +228,8 @@ __device__ inline double prolong_x_at(const PlGeom& gc, const double* __restrict
     return 0.75 * a + 0.25 * b;
 }
 
-__global__ __launch_bounds__(256) void k_vv_prolong_add(PlVvOp opf, PlGeom gc, const double* __restrict__ ec,
-                                                        const double* __restrict__ vin, double* __restrict__ vout) {
-    PL_NODE_PROLOGUE(opf.g)
+__device__ inline void prolong_node(const PlVvOp& opf, const PlGeom& gc, const double* __restrict__ ec,
+                                    const double* __restrict__ vin, double* __restrict__ vout, int i, int j, long long c) {
     const long long P = opf.g.plane;
     int moff = 0; double s = 1.0;
     int cls = vv_cls_z(opf, i, j, moff, s);
@@ -228,6 +243,85 @@ __global__ __launch_bounds__(256) void k_vv_prolong_add(PlVvOp opf, PlGeom gc, c
         o = s * (vin[c + moff + P] + prolong_x_at(gc, ec + gc.plane, im, j));
     }
     vout[c + P] = o;
+}
+
+__global__ __launch_bounds__(256) void k_vv_prolong_add(PlVvOp opf, PlGeom gc, const double* __restrict__ ec,
+                                                        const double* __restrict__ vin, double* __restrict__ vout) {
+    PL_NODE_PROLOGUE(opf.g)
+    prolong_node(opf, gc, ec, vin, vout, i, j, c);
+}
+
+// ---- fused coarse tail: the whole V-cycle for the levels below PL_TAIL_MAX_NODES nodes runs in
+// ONE workgroup (1024 threads), stages separated by __syncthreads().  These levels are pure launch
+// latency as separate kernels (a few microseconds of work each, ~75 launches per cycle).
+#define PL_TAIL_MAX_LEVELS 8
+#define PL_TAIL_MAX_NODES (65 * 65)
+struct TailLevel { PlVvOp op; double* v[3]; double* f; double* r; double lmax; };
+struct TailArgs { int nlev; int nu_pre, nu_post, coarse_sweeps; TailLevel L[PL_TAIL_MAX_LEVELS]; };
+
+#define TAIL_FOR_NODES(g)                                                              \
+    for (int idx_ = threadIdx.x; idx_ < (g).lnz * (g).lnx; idx_ += blockDim.x)
+
+__device__ inline void tail_smooth(const TailLevel& L, double* buf[3], int nsweep, double ratio) {
+    const double lmax = L.lmax, lmin = lmax / ratio;
+    const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
+    double rho_old = 1.0 / sigma;
+    const PlGeom& g = L.op.g;
+    for (int k = 0; k < nsweep; k++) {
+        double c1, c2;
+        if (k == 0) { c1 = 0.0; c2 = 1.0 / theta; }
+        else { const double rho = 1.0 / (2.0 * sigma - rho_old); c1 = rho * rho_old; c2 = 2.0 * rho / delta; rho_old = rho; }
+        TAIL_FOR_NODES(g) {
+            const int li = idx_ / g.lnx, lj = idx_ % g.lnx;
+            cheb_node(L.op, buf[0], buf[1], L.f, buf[2], c1, c2, g.gi0 + li, g.gj0 + lj, pl_idx(g, li, lj));
+        }
+        __syncthreads();
+        double* nxt = buf[2]; buf[2] = buf[1]; buf[1] = buf[0]; buf[0] = nxt;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_mg_tail(TailArgs a) {
+    double* cur[PL_TAIL_MAX_LEVELS][3];
+    // ---- down sweep
+    for (int l = 0; l < a.nlev; l++) {
+        const TailLevel& L = a.L[l];
+        const PlGeom& g = L.op.g;
+        double* buf[3] = {L.v[0], L.v[1], L.v[2]};
+        TAIL_FOR_NODES(g) { const long long c = pl_idx(g, idx_ / g.lnx, idx_ % g.lnx); buf[0][c] = 0.0; buf[0][c + g.plane] = 0.0; }
+        __syncthreads();
+        if (l == a.nlev - 1) {
+            double ratio = 0.4 * g.nz * g.nx; if (ratio < 30.0) ratio = 30.0;
+            tail_smooth(L, buf, a.coarse_sweeps, ratio);
+        } else {
+            tail_smooth(L, buf, a.nu_pre, 6.0);
+            TAIL_FOR_NODES(g) { const int li = idx_ / g.lnx, lj = idx_ % g.lnx; residual_node(L.op, buf[0], L.f, L.r, g.gi0 + li, g.gj0 + lj, pl_idx(g, li, lj)); }
+            __syncthreads();
+            const TailLevel& C = a.L[l + 1];
+            const PlGeom& gc = C.op.g;
+            TAIL_FOR_NODES(gc) { const int li = idx_ / gc.lnx, lj = idx_ % gc.lnx; restrict_node(g, C.op, L.r, C.f, gc.gi0 + li, gc.gj0 + lj, pl_idx(gc, li, lj)); }
+            __syncthreads();
+        }
+        cur[l][0] = buf[0]; cur[l][1] = buf[1]; cur[l][2] = buf[2];
+    }
+    // ---- up sweep
+    for (int l = a.nlev - 2; l >= 0; l--) {
+        const TailLevel& L = a.L[l];
+        const PlGeom& g = L.op.g;
+        const PlGeom& gc = a.L[l + 1].op.g;
+        double* buf[3] = {cur[l][0], cur[l][1], cur[l][2]};
+        const double* ec = cur[l + 1][0];
+        TAIL_FOR_NODES(g) { const int li = idx_ / g.lnx, lj = idx_ % g.lnx; prolong_node(L.op, gc, ec, buf[0], buf[2], g.gi0 + li, g.gj0 + lj, pl_idx(g, li, lj)); }
+        __syncthreads();
+        { double* t = buf[0]; buf[0] = buf[2]; buf[2] = t; }
+        tail_smooth(L, buf, a.nu_post, 6.0);
+        cur[l][0] = buf[0]; cur[l][1] = buf[1]; cur[l][2] = buf[2];
+    }
+    // result of the first tail level must be in L[0].v[0]
+    if (cur[0][0] != a.L[0].v[0]) {
+        const PlGeom& g = a.L[0].op.g;
+        const double* src = cur[0][0]; double* dst = a.L[0].v[0];
+        TAIL_FOR_NODES(g) { const long long c = pl_idx(g, idx_ / g.lnx, idx_ % g.lnx); dst[c] = src[c]; dst[c + g.plane] = src[c + g.plane]; }
+    }
 }
 
 // arithmetic viscosity coarsening: nodes by a [1 2 1]x[1 2 1]/16 stencil (edge-clamped),
@@ -363,57 +457,64 @@ __device__ inline double prec_p_cont(const PlStokesOp& op, const double* __restr
     return rs_p[c] * unscale * op.etan[c] / (op.Kc * op.Kc);
 }
 
-// z_p = S^-1 r_p  (ghost/anchor rows: r/Kc; corners: P_c = P_nb - r/Kb)
-__global__ __launch_bounds__(256) void k_prec_p(PlStokesOp op, const double* __restrict__ rs, double* __restrict__ z) {
-    PL_NODE_PROLOGUE(op.g)
+// z_p = S^-1 r_p at one pressure node, from the SCALED residual (ghost/anchor rows: r/Kc = rs;
+// corners: P_c = P_nb - r/Kb; continuity rows: r eta_n / Kc^2)
+__device__ inline double prec_p_value(const PlStokesOp& op, const double* __restrict__ rs_p, int i, int j, long long c) {
     const int nz = op.g.nz, nx = op.g.nx;
-    const double* rs_p = rs + 2 * op.g.plane;
-    double zp;
-    if (i == nz - 1 || j == nx - 1 || (i == op.anchor_i && j == op.anchor_j)) {
-        zp = rs_p[c];                                   // scaled by 1/Kc, row is Kc*P -> P = r/Kc = rs
-    } else if ((i == 0 || i == nz - 2) && j == 0) {
-        zp = prec_p_cont(op, rs_p, i, 1, c + 1) - rs_p[c];       // rs = r/Kb
-    } else if ((i == 0 || i == nz - 2) && j == nx - 2) {
-        zp = prec_p_cont(op, rs_p, i, nx - 3, c - 1) - rs_p[c];
-    } else {
-        zp = prec_p_cont(op, rs_p, i, j, c);
-    }
-    z[c + 2 * op.g.plane] = zp;
+    if (i >= nz - 1 || j >= nx - 1 || (i == op.anchor_i && j == op.anchor_j)) return rs_p[c];
+    if ((i == 0 || i == nz - 2) && j == 0) return prec_p_cont(op, rs_p, i, 1, c + 1) - rs_p[c];
+    if ((i == 0 || i == nz - 2) && j == nx - 2) return prec_p_cont(op, rs_p, i, nx - 3, c - 1) - rs_p[c];
+    return prec_p_cont(op, rs_p, i, j, c);
 }
 
-// velocity right-hand side of the block solve: f = r_v - A_vp z_p on interior rows, and the
-// lift z0 of the inhomogeneous constraint rows (walls: r/Kc, slaves: r/(Kc a0)).
-__global__ __launch_bounds__(256) void k_prec_rv(PlStokesOp op, PlVvOp vop, const double* __restrict__ rs,
-                                                 const double* __restrict__ z, double* __restrict__ f,
-                                                 double* __restrict__ z0) {
+// First stage of z = M^-1 rs:  z_p = S^-1 r_p  and the velocity right-hand side
+// f = r_v - A_vp z_p on the interior momentum rows (0 on constraint rows).
+// Constraint-row residuals are NOT lifted: inside the Krylov iteration they are identically zero,
+// because x0 is closed with k_close_constraints and every preconditioned direction satisfies the
+// homogeneous wall/slave rows, so (A y)_constraint = 0 for all iterates.
+__global__ __launch_bounds__(256) void k_prec_stage1(PlStokesOp op, PlVvOp vop, const double* __restrict__ rs,
+                                                     double* __restrict__ z, double* __restrict__ f) {
     PL_NODE_PROLOGUE(op.g)
     const long long P = op.g.plane;
     const int p = op.g.pitch;
-    const double* zp = z + 2 * P;
+    const double* rs_p = rs + 2 * P;
     double sz, sx, sp;
     stokes_row_scales(op, i, j, c, sz, sx, sp);
+    const double zp_c = prec_p_value(op, rs_p, i, j, c);
     int moff; double s;
-    double fz = 0.0, fx = 0.0, lz = 0.0, lx = 0.0;
-    int cls = vv_cls_z(vop, i, j, moff, s);
-    if (cls == VV_INT) fz = rs[c] / sz + 2.0 * op.Kc * TB(op.g.rDz, i) * (zp[c] - zp[c - p]);
-    else lz = rs[c];                                        // rs = r/Kc
-    cls = vv_cls_x(vop, i, j, moff, s);
-    if (cls == VV_INT) fx = rs[c + P] / sx + 2.0 * op.Kc * TB(op.g.rDx, j) * (zp[c] - zp[c - 1]);
-    else {
-        lx = rs[c + P];
-        if (cls == VV_SLAVE && i == 0 && op.bc_z0 != PL_BC_FREESLIP) lx /= (-TB(op.g.rDz, 1) - TB(op.g.rdz, 0));
-        if (cls == VV_SLAVE && i == op.g.nz - 2 && op.bc_zL != PL_BC_FREESLIP)
-            lx /= (TB(op.g.rDz, op.g.nz - 2) + TB(op.g.rdz, op.g.nz - 2));
-    }
-    f[c] = fz; f[c + P] = fx; z0[c] = lz; z0[c + P] = lx;
+    double fz = 0.0, fx = 0.0;
+    if (vv_cls_z(vop, i, j, moff, s) == VV_INT)
+        fz = rs[c] / sz + 2.0 * op.Kc * TB(op.g.rDz, i) * (zp_c - prec_p_value(op, rs_p, i - 1, j, c - p));
+    if (vv_cls_x(vop, i, j, moff, s) == VV_INT)
+        fx = rs[c + P] / sx + 2.0 * op.Kc * TB(op.g.rDx, j) * (zp_c - prec_p_value(op, rs_p, i, j - 1, c - 1));
+    f[c] = fz; f[c + P] = fx; z[c + 2 * P] = zp_c;
 }
 
-// z_v = e + z0
-__global__ __launch_bounds__(256) void k_prec_finish(PlGeom g, const double* __restrict__ e,
-                                                     const double* __restrict__ z0, double* __restrict__ z) {
+// Make x satisfy the constraint rows of A x = b exactly (b given SCALED, bs = b / Kc on these rows):
+// walls and ghosts x = bs; slaved rows x_s = s x_m + bs / a0.
+__global__ __launch_bounds__(256) void k_close_constraints(PlStokesOp op, PlVvOp vop, const double* __restrict__ bs,
+                                                           double* __restrict__ x) {
+    PL_NODE_PROLOGUE(op.g)
+    const long long P = op.g.plane;
+    int moff; double s;
+    int cls = vv_cls_z(vop, i, j, moff, s);
+    if (cls == VV_ZERO) x[c] = bs[c];
+    else if (cls == VV_SLAVE) x[c] = s * x[c + moff] + bs[c];
+    cls = vv_cls_x(vop, i, j, moff, s);
+    if (cls == VV_ZERO) x[c + P] = bs[c + P];
+    else if (cls == VV_SLAVE) {
+        double g0 = bs[c + P];
+        if (i == 0 && op.bc_z0 != PL_BC_FREESLIP) g0 /= (-TB(op.g.rDz, 1) - TB(op.g.rdz, 0));
+        if (i == op.g.nz - 2 && op.bc_zL != PL_BC_FREESLIP) g0 /= (TB(op.g.rDz, op.g.nz - 2) + TB(op.g.rdz, op.g.nz - 2));
+        x[c + P] = s * x[c + moff + P] + g0;
+    }
+}
+
+// copy 2 velocity planes
+__global__ __launch_bounds__(256) void k_copy_vel(PlGeom g, const double* __restrict__ e, double* __restrict__ z) {
     PL_NODE_PROLOGUE(g)
     (void)i; (void)j;
-    z[c] = e[c] + z0[c]; z[c + g.plane] = e[c + g.plane] + z0[c + g.plane];
+    z[c] = e[c]; z[c + g.plane] = e[c + g.plane];
 }
 
 // Hydrostatic pressure guess: with v = 0 the interior z-momentum rows reduce to
@@ -463,17 +564,25 @@ struct PlSolver {
     int bc_key[4] = {-1, -1, -1, -1};
     // BiCGStab work vectors (3 planes each)
     double *r = nullptr, *rt = nullptr, *p = nullptr, *v = nullptr, *s = nullptr, *t = nullptr, *y = nullptr,
-           *z = nullptr, *b = nullptr, *x = nullptr, *z0 = nullptr;
+           *z = nullptr, *b = nullptr, *x = nullptr;
     double* scal = nullptr;     // device scalars [0..8) + dot partials [8..8+2*DOT_BLOCKS)
     double* hpart = nullptr;    // pinned host copy of the dot partials
-    int nu_pre = 2, nu_post = 2, coarse_sweeps = 40;
+    int nu_pre = 2, nu_post = 2, coarse_sweeps = 12;
+    bool use_tail = true;
     // heat work vectors (1 plane each)
     double* h[9] = {nullptr};
     int napply = 0, nprec = 0;
 };
 
 static PlSolver* solver_of(pl_ctx* ctx) {
-    if (!ctx->krylov) ctx->krylov = new PlSolver();
+    if (!ctx->krylov) {
+        PlSolver* S = new PlSolver();
+        // tuning knobs (defaults chosen on MI355X at 2049^2): PYLAMP_MG_NU="pre,post", PYLAMP_MG_COARSE=sweeps
+        if (const char* e = getenv("PYLAMP_MG_NU")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b >= 0 && a + b > 0) { S->nu_pre = a; S->nu_post = b; } }
+        if (const char* e = getenv("PYLAMP_MG_COARSE")) { int a = atoi(e); if (a > 0) S->coarse_sweeps = a; }
+        if (const char* e = getenv("PYLAMP_MG_TAIL")) S->use_tail = atoi(e) != 0;
+        ctx->krylov = S;
+    }
     return (PlSolver*)ctx->krylov;
 }
 
@@ -491,7 +600,7 @@ void pl_solver_free(pl_ctx* ctx) {
     PlSolver* S = (PlSolver*)ctx->krylov;
     if (!S) return;
     free_levels(S);
-    for (double* q : {S->r, S->rt, S->p, S->v, S->s, S->t, S->y, S->z, S->b, S->x, S->z0, S->scal})
+    for (double* q : {S->r, S->rt, S->p, S->v, S->s, S->t, S->y, S->z, S->b, S->x, S->scal})
         if (q) (void)hipFree(q);
     for (double* q : S->h) if (q) (void)hipFree(q);
     if (S->hpart) (void)hipHostFree(S->hpart);
@@ -593,7 +702,8 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
 
 // ---- smoothing and V-cycle ----------------------------------------------------------------
 // nsweep Chebyshev-Jacobi sweeps on level L; buf[0] is the current iterate on entry and on exit
-static void smooth(pl_ctx* ctx, MgLevel* L, double* buf[3], const double* f, int nsweep, double ratio) {
+static void smooth(pl_ctx* ctx, MgLevel* L, double* buf[3], const double* f, int nsweep, double ratio,
+                   double* final_out = nullptr) {
     const double lmax = L->lmax, lmin = lmax / ratio;
     const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
     double rho_old = 1.0 / sigma;
@@ -601,16 +711,31 @@ static void smooth(pl_ctx* ctx, MgLevel* L, double* buf[3], const double* f, int
         double c1, c2;
         if (k == 0) { c1 = 0.0; c2 = 1.0 / theta; }
         else { const double rho = 1.0 / (2.0 * sigma - rho_old); c1 = rho * rho_old; c2 = 2.0 * rho / delta; rho_old = rho; }
-        hipLaunchKernelGGL(k_vv_cheb, grid2d(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, buf[0], buf[1], f, buf[2],
-                           c1, c2);
-        double* nxt = buf[2]; buf[2] = buf[1]; buf[1] = buf[0]; buf[0] = nxt;     // (cur, prev, free)
+        double* dst = (final_out && k == nsweep - 1) ? final_out : buf[2];
+        hipLaunchKernelGGL(k_vv_cheb, grid2d(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, buf[0], buf[1], f, dst, c1, c2);
+        if (dst != buf[2]) { buf[1] = buf[0]; buf[0] = dst; }
+        else { double* nxt = buf[2]; buf[2] = buf[1]; buf[1] = buf[0]; buf[0] = nxt; }    // (cur, prev, free)
     }
 }
 
 // solves A_vv e = f(level l) approximately; result in *out (one of the level's v buffers)
-static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const double* f, double** out) {
+// final_out (level 0 only): the last post-smoothing sweep writes its result there (zero-copy into z)
+static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const double* f, double** out, double* final_out = nullptr) {
     MgLevel* L = S->levels[l];
     const PlGeom& g = L->gh.d;
+    if (S->use_tail && l > 0 && (long long)g.nz * g.nx <= PL_TAIL_MAX_NODES &&
+        S->levels.size() - l <= PL_TAIL_MAX_LEVELS && f == L->f) {
+        TailArgs ta{};
+        ta.nlev = (int)(S->levels.size() - l); ta.nu_pre = S->nu_pre; ta.nu_post = S->nu_post; ta.coarse_sweeps = S->coarse_sweeps;
+        for (int q = 0; q < ta.nlev; q++) {
+            MgLevel* T = S->levels[l + q];
+            ta.L[q].op = T->op; ta.L[q].f = T->f; ta.L[q].r = T->r; ta.L[q].lmax = T->lmax;
+            for (int b = 0; b < 3; b++) ta.L[q].v[b] = T->v[b];
+        }
+        hipLaunchKernelGGL(k_mg_tail, dim3(1), dim3(1024), 0, ctx->stream, ta);
+        *out = L->v[0];
+        return;
+    }
     double* buf[3] = {L->v[0], L->v[1], L->v[2]};
     (void)hipMemsetAsync(buf[0], 0, (size_t)2 * g.plane * sizeof(double), ctx->stream);
     if (l + 1 == S->levels.size()) {
@@ -627,7 +752,7 @@ static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const double* f, double**
     vcycle(ctx, S, l + 1, C->f, &ec);
     hipLaunchKernelGGL(k_vv_prolong_add, grid2d(g), dim3(64, 4), 0, ctx->stream, L->op, C->gh.d, ec, buf[0], buf[2]);
     std::swap(buf[0], buf[2]);
-    smooth(ctx, L, buf, f, S->nu_post, 6.0);
+    smooth(ctx, L, buf, f, S->nu_post, 6.0, final_out);
     *out = buf[0];
 }
 
@@ -636,13 +761,11 @@ static int stokes_precond(pl_ctx* ctx, PlSolver* S, const double* rs, double* z)
     const PlStokesOp& op = ctx->sop;
     MgLevel* L0 = S->levels[0];
     const PlGeom& g = op.g;
-    hipLaunchKernelGGL(k_prec_p, grid2d(g), dim3(64, 4), 0, ctx->stream, op, rs, z);
-    hipLaunchKernelGGL(k_prec_rv, grid2d(g), dim3(64, 4), 0, ctx->stream, op, L0->op, rs, z, L0->f, S->z0);
-    // f' = f - A_vv z0, in place (each thread touches only its own f entries)
-    hipLaunchKernelGGL(k_vv_residual, grid2d(g), dim3(64, 4), 0, ctx->stream, L0->op, S->z0, L0->f, L0->f);
+    hipLaunchKernelGGL(k_prec_stage1, grid2d(g), dim3(64, 4), 0, ctx->stream, op, L0->op, rs, z, L0->f);
     double* e = nullptr;
-    vcycle(ctx, S, 0, L0->f, &e);
-    hipLaunchKernelGGL(k_prec_finish, grid2d(g), dim3(64, 4), 0, ctx->stream, g, e, S->z0, z);
+    const bool direct = S->levels.size() > 1 && S->nu_post > 0;     // last sweep writes into z
+    vcycle(ctx, S, 0, L0->f, &e, direct ? z : nullptr);
+    if (e != z) hipLaunchKernelGGL(k_copy_vel, grid2d(g), dim3(64, 4), 0, ctx->stream, g, e, z);
     PL_HIP(ctx, hipGetLastError());
     S->nprec++;
     return 0;
@@ -730,7 +853,7 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
 static int stokes_alloc(pl_ctx* ctx, PlSolver* S) {
     if (S->r) return 0;
     size_t vb = (size_t)3 * ctx->geom.d.plane * sizeof(double);
-    for (double** q : {&S->r, &S->rt, &S->p, &S->v, &S->s, &S->t, &S->y, &S->z, &S->b, &S->x, &S->z0})
+    for (double** q : {&S->r, &S->rt, &S->p, &S->v, &S->s, &S->t, &S->y, &S->z, &S->b, &S->x})
         PL_TRY(dmalloc0(ctx, q, vb));
     if (!S->scal) {
         PL_TRY(dmalloc0(ctx, &S->scal, (8 + 2 * DOT_BLOCKS) * sizeof(double)));
@@ -748,10 +871,10 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
     PL_TRY(build_hierarchy(ctx, S));
     const PlGeom& g = ctx->geom.d;
     PlStokesOp sop = ctx->sop;
+    PlStokesOp sop_scaled = sop; sop_scaled.scaled = 1;
     S->napply = 0; S->nprec = 0;
     VecOp A = [&](const double* in, double* out) -> int {
-        pl_launch_stokes_apply(ctx, sop, in, out);
-        hipLaunchKernelGGL(k_stokes_scale_rows, grid2d(g), dim3(64, 4), 0, ctx->stream, sop, out);
+        pl_launch_stokes_apply(ctx, sop_scaled, in, out);      // y = D_r A x in one pass
         S->napply++;
         return 0;
     };
@@ -778,6 +901,7 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
             use_x0 = true;
         }
     }
+    hipLaunchKernelGGL(k_close_constraints, grid2d(g), dim3(64, 4), 0, ctx->stream, sop, S->levels[0]->op, S->b, S->x);
     PL_TRY(bicgstab(ctx, S, g, 3, A, &M, S->b, S->x, use_x0, rtol, maxit, w, st, ref));
     double ms = 0;
     PL_TRY(pl_timer_stop_ms(ctx, &ms));

@@ -35,6 +35,11 @@ __global__ __launch_bounds__(256) void k_stokes_apply(PlStokesOp op, const doubl
     const double Kc = op.Kc;
     const double vz_c = vz[c], vx_c = vx[c], p_c = P[c];
 
+    // row scale factors D_r (used only when op.scaled): 1/(sum of the 4 own-component
+    // coefficients) on interior momentum rows, 1/Kc on constraint rows, 1/(Kc (1/dx+1/dz)) on
+    // continuity rows, 1/Kb on corner rows.  No extra memory traffic.
+    double sz = 1.0 / Kc, sx = 1.0 / Kc, sp = 1.0 / Kc;
+
     // ---------------- vz row (z-momentum) ----------------
     double yz;
     if (j == nx - 1 || i == 0 || i == nz - 1) {
@@ -56,6 +61,7 @@ __global__ __launch_bounds__(256) void k_stokes_apply(PlStokesOp op, const doubl
         yz = cN * (vz[c + p] - vz_c) - cS * (vz_c - vz[c - p]) + cE * (vz[c + 1] - vz_c) -
              cW * (vz_c - vz[c - 1]) + xE * (vx[c + 1] - vx[c - p + 1]) - xW * (vx_c - vx[c - p]) -
              2.0 * Kc * rDz_i * (p_c - P[c - p]);
+        sz = 1.0 / (cN + cS + cE + cW);
         if (op.surfstab) {
             const double* __restrict__ r = op.rho;
             yz += op.ss * op.gz * 0.5 *
@@ -87,6 +93,7 @@ __global__ __launch_bounds__(256) void k_stokes_apply(PlStokesOp op, const doubl
         yx = cE * (vx[c + 1] - vx_c) - cW * (vx_c - vx[c - 1]) + cN * (vx[c + p] - vx_c) -
              cS * (vx_c - vx[c - p]) + zN * (vz[c + p] - vz[c + p - 1]) - zS * (vz_c - vz[c - 1]) -
              2.0 * Kc * rDx_j * (p_c - P[c - 1]);
+        sx = 1.0 / (cE + cW + cN + cS);
         if (op.surfstab && op.gx != 0.0) {
             const double* __restrict__ r = op.rho;
             yx += op.ss * op.gx * 0.5 *
@@ -101,11 +108,15 @@ __global__ __launch_bounds__(256) void k_stokes_apply(PlStokesOp op, const doubl
         yp = Kc * p_c;                                    // ghosts, pressure anchor
     } else if ((i == 0 || i == nz - 2) && j == 0) {
         yp = op.Kb * (P[c + 1] - p_c);                    // corner symmetry (pylamp_stokes.py:358-369)
+        sp = 1.0 / op.Kb;
     } else if ((i == 0 || i == nz - 2) && j == nx - 2) {
         yp = op.Kb * (P[c - 1] - p_c);
+        sp = 1.0 / op.Kb;
     } else {
         yp = Kc * ((vx[c + 1] - vx_c) * TB(g.rdx, j) + (vz[c + p] - vz_c) * TB(g.rdz, i));
+        sp = 1.0 / (Kc * (TB(g.rdx, j) + TB(g.rdz, i)));
     }
+    if (op.scaled) { yz *= sz; yx *= sx; yp *= sp; }
 
     y[c] = yz;
     y[c + g.plane] = yx;
@@ -175,6 +186,7 @@ void pl_stokes_fill_op(pl_ctx* ctx, double* etas, double* etan, double* rho, con
     op.surfstab = surfstab ? 1 : 0; op.ss = theta * tstep;
     op.anchor_i = 3; op.anchor_j = 2;
     op.gz = 9.81; op.gx = 0.0;                     // pylamp_const.py:21
+    op.scaled = 0;
     ctx->sop_ready = true;
 }
 

@@ -96,6 +96,13 @@ def test_preconditioner_matches_prototype(name):
     A, rhs = S.makeStokesMatrix(nx, grid, g["etas"], g["etan"], g["rho"], bc)
     rng = np.random.default_rng(0)
     r = rng.standard_normal(A.shape[0]) * np.abs(rhs).max()
+    # wall / slave / ghost velocity rows carry no residual inside the solver: the device
+    # preconditioner ignores them, so compare on a residual that is zero there
+    from oracle import pylamp_oracle as O
+    cls = O.stokes_row_class(nx)
+    R = r.reshape(nx[0], nx[1], 3)
+    R[:, :, 0][cls[0] != 1] = 0.0
+    R[:, :, 1][cls[1] != 1] = 0.0
     z = A.precond(r)
     nl, lm = A.mg_info()
     M = PS.Precond(nx, grid, g["etas"], g["etan"], g["rho"], bc, nu=(2, 2), lmax=lm)
