@@ -58,6 +58,40 @@ const char* pl_last_error(const pl_ctx* ctx);   /* ctx may be NULL: error of a f
 int  pl_sync(pl_ctx* ctx);                      /* hipStreamSynchronize on the context stream */
 int  pl_device_info(pl_ctx* ctx, char* name, size_t name_len, int* cu_count, size_t* hbm_bytes);
 
+/* ---- multi-GPU: one context per rank, 1-D slab decomposition of the node ROWS (z) -------------
+ * The reference only strides tracers over MPI ranks and replicates every grid array
+ * (pylamp2.py:30-32,445-455,550-555); here the grid itself is decomposed.  Rank r owns node rows
+ * [r*C, (r+1)*C) with C = (nz-1)/nranks (the last rank also owns row nz-1); (nz-1) must be
+ * divisible by nranks*2^k for the k distributed multigrid levels.  Communication is delegated to
+ * the host program (torch.distributed over RCCL in pylamp_amd/parallel.py) through this table;
+ * every callback returns 0 on success and must have completed when it returns.
+ * Device pointers are plain HIP allocations of this context's device. */
+typedef struct pl_comm_ops {
+    /* Neighbour exchange of nseg segments of `count` doubles, segment k at base + k*stride:
+     * send send_lo[] to rank-1 and receive recv_lo[] from it; send send_hi[] to rank+1 and receive
+     * recv_hi[] from it.  A missing neighbour (rank 0 / last rank) is skipped. add != 0: the
+     * received data is ADDED to recv (reverse halo of scatter accumulators). */
+    int (*exchange)(void* user, const double* send_lo, double* recv_lo, const double* send_hi, double* recv_hi,
+                    int64_t count, int nseg, int64_t stride, int add);
+    /* In-place all-reduce of n doubles in HOST memory; op: 0 sum, 1 min, 2 max. */
+    int (*allreduce_host)(void* user, double* buf, int64_t n, int op);
+    /* All-gather of nseg segments: rank r contributes count doubles at recv + r*count (+ k*stride). */
+    int (*allgather)(void* user, double* recv, int64_t count, int nseg, int64_t stride);
+    /* Variable-size neighbour exchange of tracer columns: send n_lo (n_hi) doubles of each of ncol
+     * columns starting at send_lo[k] (send_hi[k]); received columns are appended at recv[k];
+     * *got returns the number of doubles received per column (from both neighbours together). */
+    int (*exchange_var)(void* user, double* const* send_lo, int64_t n_lo, double* const* send_hi, int64_t n_hi,
+                        double* const* recv, int64_t recv_capacity, int ncol, int64_t* got);
+    void* user;
+} pl_comm_ops;
+int  pl_set_comm(pl_ctx* ctx, int rank, int nranks, const pl_comm_ops* ops);   /* right after pl_create */
+int  pl_local_rows(pl_ctx* ctx, int* first_row, int* n_rows);
+/* raw copies between host and this context's device memory (used by the gloo fallback of the
+ * communication layer, which stages through host buffers) */
+int  pl_memcpy_d2h(pl_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int  pl_memcpy_h2d(pl_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int  pl_dev_add(pl_ctx* ctx, double* dst_dev, const double* src_dev, int64_t n);   /* dst += src */
+
 /* HIP-event timing on the context's stream (bench.py measures kernels with these). */
 int  pl_timer_start(pl_ctx* ctx);
 int  pl_timer_stop_ms(pl_ctx* ctx, double* ms);

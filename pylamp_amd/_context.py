@@ -27,9 +27,28 @@ class Context:
             raise Exception(msg.decode() if msg else "pl_create failed")
         self.h = h
         self._fin = weakref.finalize(self, lib.pl_destroy, h)
+        self.comm = None
+        self.rank, self.nranks = 0, 1
+        # under torch.distributed (torchrun) every rank owns a row slab of the grid
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and not os.environ.get("PYLAMP_NO_DIST"):
+                from .parallel import Comm
+                Comm(self)
+                self.rank, self.nranks = self.comm.rank, self.comm.size
+        except ImportError:
+            pass
 
     def check(self, rc):
+        if rc != 0 and self.comm is not None and self.comm.errors:
+            raise Exception("communication layer: " + "; ".join(self.comm.errors[-3:]))
         _lib.check(self.h, rc)
+
+    def local_rows(self):
+        import ctypes as C_
+        a = C_.c_int(); b = C_.c_int()
+        self.check(self.lib.pl_local_rows(self.h, C_.byref(a), C_.byref(b)))
+        return a.value, b.value
 
     def close(self):
         self._fin()

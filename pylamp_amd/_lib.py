@@ -48,6 +48,11 @@ SIGNATURES = {
     "pl_last_error": (C.c_char_p, [C.c_void_p]),
     "pl_sync": (C.c_int, [C.c_void_p]),
     "pl_device_info": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, c_int_p, C.POINTER(C.c_size_t)]),
+    "pl_set_comm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "pl_local_rows": (C.c_int, [C.c_void_p, c_int_p, c_int_p]),
+    "pl_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "pl_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "pl_dev_add": (C.c_int, [C.c_void_p, c_double_p, c_double_p, C.c_int64]),
     "pl_timer_start": (C.c_int, [C.c_void_p]),
     "pl_timer_stop_ms": (C.c_int, [C.c_void_p, c_double_p]),
     "pl_stokes_set_coeffs": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_int_p, C.c_int,

@@ -79,6 +79,76 @@ int pl_geom_build(pl_ctx* ctx, PlGeomHost& gh, int nz, int nx, const double* zc,
     return 0;
 }
 
+void pl_geom_set_rows(PlGeomHost& gh, int gi0, int lnz) {
+    gh.d.gi0 = gi0; gh.d.lnz = lnz;
+    gh.d.plane = (long long)(lnz + 2) * gh.d.pitch;
+}
+
+int pl_halo_rows(pl_ctx* ctx, const PlGeom& g, double* planes, int nplanes, long long plane_stride, bool add) {
+    if (ctx->nranks <= 1) return 0;
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const long long p = g.pitch;
+    int rc;
+    if (!add)   // forward: my first/last owned rows -> neighbours' ring rows
+        rc = ctx->comm.exchange(ctx->comm.user, planes + p, planes, planes + (long long)g.lnz * p,
+                                planes + (long long)(g.lnz + 1) * p, p, nplanes, plane_stride, 0);
+    else        // reverse: my ring rows are added to the neighbours' owned boundary rows
+        rc = ctx->comm.exchange(ctx->comm.user, planes, planes + p, planes + (long long)(g.lnz + 1) * p,
+                                planes + (long long)g.lnz * p, p, nplanes, plane_stride, 1);
+    if (rc) return pl_fail(ctx, "communication callback 'exchange' failed");
+    return 0;
+}
+
+int pl_allreduce_host(pl_ctx* ctx, double* buf, long long n, int op) {
+    if (ctx->nranks <= 1) return 0;
+    if (ctx->comm.allreduce_host(ctx->comm.user, buf, n, op)) return pl_fail(ctx, "communication callback 'allreduce_host' failed");
+    return 0;
+}
+
+extern "C" int pl_set_comm(pl_ctx* ctx, int rank, int nranks, const pl_comm_ops* ops) {
+    if (!ops || nranks < 1 || rank < 0 || rank >= nranks) return pl_fail(ctx, "pl_set_comm: bad argument");
+    if (!ctx->bufs.empty() || ctx->krylov || ctx->step) return pl_fail(ctx, "pl_set_comm must be called right after pl_create");
+    if (nranks == 1) { ctx->rank = 0; ctx->nranks = 1; return 0; }
+    if (!ops->exchange || !ops->allreduce_host || !ops->allgather || !ops->exchange_var)
+        return pl_fail(ctx, "pl_set_comm: incomplete callback table");
+    const int cells = ctx->nz - 1;
+    if (cells % nranks) return pl_fail(ctx, "pl_set_comm: (nz-1) must be divisible by the number of ranks");
+    const int C = cells / nranks;
+    if (C < 8 || (C % 2)) return pl_fail(ctx, "pl_set_comm: need an even number (>= 8) of node rows per rank");
+    ctx->rank = rank; ctx->nranks = nranks; ctx->comm = *ops;
+    pl_geom_set_rows(ctx->geom, rank * C, (rank == nranks - 1) ? C + 1 : C);
+    return 0;
+}
+
+extern "C" int pl_local_rows(pl_ctx* ctx, int* first_row, int* n_rows) {
+    if (first_row) *first_row = ctx->geom.d.gi0;
+    if (n_rows) *n_rows = ctx->geom.d.lnz;
+    return 0;
+}
+
+extern "C" int pl_memcpy_d2h(pl_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes) {
+    PL_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+extern "C" int pl_memcpy_h2d(pl_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
+    PL_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+__global__ void k_dev_add(long long n, double* __restrict__ d, const double* __restrict__ s) {
+    long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; k < n; k += (long long)gridDim.x * blockDim.x) d[k] += s[k];
+}
+extern "C" int pl_dev_add(pl_ctx* ctx, double* dst_dev, const double* src_dev, int64_t n) {
+    if (n <= 0) return 0;
+    long long nb = (n + 255) / 256; if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(k_dev_add, dim3((unsigned)nb), dim3(256), 0, ctx->stream, (long long)n, dst_dev, src_dev);
+    PL_HIP(ctx, hipGetLastError());
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 void pl_geom_free(PlGeomHost& gh) {
     if (gh.tables) (void)hipFree(gh.tables);
     gh.tables = nullptr;
@@ -154,20 +224,25 @@ extern "C" int pl_timer_stop_ms(pl_ctx* ctx, double* ms) {
 }
 
 // ---- plane / vector transfers ---------------------------------------------------------------
+// host is the GLOBAL (nz,nx) array on every rank; the local rows plus the neighbouring ring rows
+// (when they exist) are taken from it, so coefficient planes need no halo exchange.
 int pl_plane_upload(pl_ctx* ctx, const PlGeom& g, const double* host, double* dplane) {
-    PL_HIP(ctx, hipMemcpy2DAsync(dplane + pl_idx(g, 0, 0), (size_t)g.pitch * sizeof(double), host,
-                                 (size_t)g.lnx * sizeof(double), (size_t)g.lnx * sizeof(double), g.lnz,
-                                 hipMemcpyHostToDevice, ctx->stream));
+    const int r0 = (g.gi0 > 0) ? -1 : 0, r1 = (g.gi0 + g.lnz < g.nz) ? g.lnz + 1 : g.lnz;
+    PL_HIP(ctx, hipMemcpy2DAsync(dplane + pl_idx(g, r0, 0), (size_t)g.pitch * sizeof(double),
+                                 host + (size_t)(g.gi0 + r0) * g.lnx, (size_t)g.lnx * sizeof(double),
+                                 (size_t)g.lnx * sizeof(double), r1 - r0, hipMemcpyHostToDevice, ctx->stream));
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));   // host buffer may be reused by the caller
     return 0;
 }
 
+// every rank receives the complete GLOBAL (nz,nx) array (own rows + zero elsewhere, summed over ranks)
 int pl_plane_download(pl_ctx* ctx, const PlGeom& g, const double* dplane, double* host) {
-    PL_HIP(ctx, hipMemcpy2DAsync(host, (size_t)g.lnx * sizeof(double), dplane + pl_idx(g, 0, 0),
+    if (ctx->nranks > 1) memset(host, 0, (size_t)g.nz * g.lnx * sizeof(double));
+    PL_HIP(ctx, hipMemcpy2DAsync(host + (size_t)g.gi0 * g.lnx, (size_t)g.lnx * sizeof(double), dplane + pl_idx(g, 0, 0),
                                  (size_t)g.pitch * sizeof(double), (size_t)g.lnx * sizeof(double), g.lnz,
                                  hipMemcpyDeviceToHost, ctx->stream));
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return 0;
+    return pl_allreduce_host(ctx, host, (long long)g.nz * g.lnx, 0);
 }
 
 // interleaved (node-major, 3 per node) <-> 3 planes
@@ -192,7 +267,7 @@ static dim3 grid2d(const PlGeom& g) { return dim3((g.lnx + 63) / 64, (g.lnz + 3)
 int pl_vec3_upload(pl_ctx* ctx, const PlGeom& g, const double* host, double* dvec) {
     size_t bytes = (size_t)3 * g.lnz * g.lnx * sizeof(double);
     PL_TRY(pl_stage(ctx, bytes));
-    PL_HIP(ctx, hipMemcpyAsync(ctx->stage, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    PL_HIP(ctx, hipMemcpyAsync(ctx->stage, host + (size_t)3 * g.gi0 * g.lnx, bytes, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_deinterleave3, grid2d(g), dim3(64, 4), 0, ctx->stream, g, ctx->stage, dvec);
     PL_HIP(ctx, hipGetLastError());
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -204,7 +279,8 @@ int pl_vec3_download(pl_ctx* ctx, const PlGeom& g, const double* dvec, double* h
     PL_TRY(pl_stage(ctx, bytes));
     hipLaunchKernelGGL(k_interleave3, grid2d(g), dim3(64, 4), 0, ctx->stream, g, dvec, ctx->stage);
     PL_HIP(ctx, hipGetLastError());
-    PL_HIP(ctx, hipMemcpyAsync(host, ctx->stage, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->nranks > 1) memset(host, 0, (size_t)3 * g.nz * g.lnx * sizeof(double));
+    PL_HIP(ctx, hipMemcpyAsync(host + (size_t)3 * g.gi0 * g.lnx, ctx->stage, bytes, hipMemcpyDeviceToHost, ctx->stream));
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return 0;
+    return pl_allreduce_host(ctx, host, (long long)3 * g.nz * g.lnx, 0);
 }

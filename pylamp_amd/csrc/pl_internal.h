@@ -76,6 +76,9 @@ struct pl_ctx {
     // Heat
     PlHeatOp hop{}; bool hop_ready = false; double heat_bcvalue[4] = {0, 0, 0, 0};
     std::vector<double> zmp, xmp;
+    // multi-GPU (row slabs): rank r owns node rows [row0, row0 + geom.d.lnz)
+    int rank = 0, nranks = 1;
+    pl_comm_ops comm{};
     // opaque extension slots owned by other translation units
     void* krylov = nullptr;   // pl_solver.hip
     void* mic = nullptr;      // pl_mic.hip
@@ -101,6 +104,11 @@ int pl_fail(pl_ctx* ctx, const std::string& msg);
 int pl_buf(pl_ctx* ctx, const char* name, size_t bytes, double** out, bool zero = true);
 int pl_stage(pl_ctx* ctx, size_t bytes);
 int pl_geom_build(pl_ctx* ctx, PlGeomHost& gh, int nz, int nx, const double* zc, const double* xc);
+// restrict the geometry to the row slab [gi0, gi0+lnz)
+void pl_geom_set_rows(PlGeomHost& gh, int gi0, int lnz);
+// halo exchange of the ring rows of nplanes planes (no-op on one rank); add: reverse (accumulating) halo
+int pl_halo_rows(pl_ctx* ctx, const PlGeom& g, double* planes, int nplanes, long long plane_stride, bool add = false);
+int pl_allreduce_host(pl_ctx* ctx, double* buf, long long n, int op);
 void pl_geom_free(PlGeomHost& gh);
 // host (nz,nx) C-order  <->  device plane with ring/pitch
 int pl_plane_upload(pl_ctx* ctx, const PlGeom& g, const double* host, double* dplane);

@@ -183,7 +183,7 @@ __device__ inline void restrict_node(const PlGeom& gf, const PlVvOp& opc, const 
     const int pf = gf.pitch;
     double oz = 0.0, ox = 0.0;
     if (vv_cls_z(opc, i, j, moff, s) == VV_INT) {
-        const long long b = pl_idx(gf, 2 * i, 2 * j);
+        const long long b = pl_idx(gf, 2 * i - gf.gi0, 2 * j - gf.gj0);
         const double wz[3] = {0.25, 0.5, 0.25}, wx[4] = {0.125, 0.375, 0.375, 0.125};
 #pragma unroll
         for (int a = 0; a < 3; a++)
@@ -191,7 +191,7 @@ __device__ inline void restrict_node(const PlGeom& gf, const PlVvOp& opc, const 
             for (int q = 0; q < 4; q++) oz += wz[a] * wx[q] * rf[b + (long long)(a - 1) * pf + (q - 1)];
     }
     if (vv_cls_x(opc, i, j, moff, s) == VV_INT) {
-        const long long b = pl_idx(gf, 2 * i, 2 * j) + gf.plane;
+        const long long b = pl_idx(gf, 2 * i - gf.gi0, 2 * j - gf.gj0) + gf.plane;
         const double wz[4] = {0.125, 0.375, 0.375, 0.125}, wx[3] = {0.25, 0.5, 0.25};
 #pragma unroll
         for (int a = 0; a < 4; a++)
@@ -213,8 +213,9 @@ __device__ inline double prolong_z_at(const PlGeom& gc, const double* __restrict
     int Jn = j >> 1, Jo = (j & 1) ? Jn + 1 : Jn - 1;
     const int jmax = gc.nx - 2;
     Jn = min(max(Jn, 0), jmax); Jo = min(max(Jo, 0), jmax);
-    const double a = 0.5 * (ez[pl_idx(gc, I0, Jn)] + ez[pl_idx(gc, I1, Jn)]);
-    const double b = 0.5 * (ez[pl_idx(gc, I0, Jo)] + ez[pl_idx(gc, I1, Jo)]);
+    const int o0 = gc.gi0, o1 = gc.gj0;            // coarse indices are global; the block may be a slab
+    const double a = 0.5 * (ez[pl_idx(gc, I0 - o0, Jn - o1)] + ez[pl_idx(gc, I1 - o0, Jn - o1)]);
+    const double b = 0.5 * (ez[pl_idx(gc, I0 - o0, Jo - o1)] + ez[pl_idx(gc, I1 - o0, Jo - o1)]);
     return 0.75 * a + 0.25 * b;
 }
 
@@ -223,8 +224,9 @@ __device__ inline double prolong_x_at(const PlGeom& gc, const double* __restrict
     int In = i >> 1, Io = (i & 1) ? In + 1 : In - 1;
     const int imax = gc.nz - 2;
     In = min(max(In, 0), imax); Io = min(max(Io, 0), imax);
-    const double a = 0.5 * (ex[pl_idx(gc, In, J0)] + ex[pl_idx(gc, In, J1)]);
-    const double b = 0.5 * (ex[pl_idx(gc, Io, J0)] + ex[pl_idx(gc, Io, J1)]);
+    const int o0 = gc.gi0, o1 = gc.gj0;
+    const double a = 0.5 * (ex[pl_idx(gc, In - o0, J0 - o1)] + ex[pl_idx(gc, In - o0, J1 - o1)]);
+    const double b = 0.5 * (ex[pl_idx(gc, Io - o0, J0 - o1)] + ex[pl_idx(gc, Io - o0, J1 - o1)]);
     return 0.75 * a + 0.25 * b;
 }
 
@@ -336,11 +338,11 @@ __global__ __launch_bounds__(256) void k_coarsen_visc(PlGeom gf, const double* _
 #pragma unroll
         for (int q = -1; q <= 1; q++) {
             const int fi = min(max(2 * i + a, 0), gf.nz - 1), fj = min(max(2 * j + q, 0), gf.nx - 1);
-            acc += (a == 0 ? 2.0 : 1.0) * (q == 0 ? 2.0 : 1.0) * esf[pl_idx(gf, fi, fj)];
+            acc += (a == 0 ? 2.0 : 1.0) * (q == 0 ? 2.0 : 1.0) * esf[pl_idx(gf, fi - gf.gi0, fj - gf.gj0)];
         }
     esc[c] = acc * (1.0 / 16.0);
     const int ci = min(i, gc.nz - 2), cj = min(j, gc.nx - 2);      // ghost row/col copies its neighbour
-    const long long b = pl_idx(gf, 2 * ci, 2 * cj);
+    const long long b = pl_idx(gf, 2 * ci - gf.gi0, 2 * cj - gf.gj0);
     enc[c] = 0.25 * (enf[b] + enf[b + 1] + enf[b + gf.pitch] + enf[b + gf.pitch + 1]);
 }
 
@@ -521,30 +523,33 @@ __global__ __launch_bounds__(256) void k_copy_vel(PlGeom g, const double* __rest
 //   -2 Kc rDz_i (P[i,j] - P[i-1,j]) = -1/2 (rho[i,j] + rho[i,j+1]) g
 // which is integrated down every column (one thread per column), then shifted so that the
 // anchor cell is 0.  b - A x_h is the DYNAMIC load the solver's tolerance is measured against.
-__global__ void k_hydrostatic_columns(PlStokesOp op, double* __restrict__ x) {
+__global__ void k_hydrostatic_columns(PlStokesOp op, double* __restrict__ x, double* __restrict__ coltot) {
     const PlGeom& g = op.g;
     const int lj = blockIdx.x * blockDim.x + threadIdx.x;
     if (lj >= g.lnx) return;
     double* P = x + 2 * g.plane;
     const double* r = op.rho;
     double acc = 0.0;
-    P[pl_idx(g, 0, lj)] = 0.0;
-    for (int i = 1; i <= g.nz - 2; i++) {
-        const long long c = pl_idx(g, i, lj);
-        const int jn = (lj + 1 < g.nx) ? 1 : 0;
-        acc += 0.5 * (r[c] + r[c + jn]) * op.gz / (2.0 * op.Kc * TB(g.rDz, i));
-        P[c] = acc;
+    for (int li = 0; li < g.lnz; li++) {
+        const int i = g.gi0 + li;
+        const long long c = pl_idx(g, li, lj);
+        if (i >= 1 && i <= g.nz - 2) {
+            const int jn = (lj + 1 < g.nx) ? 1 : 0;
+            acc += 0.5 * (r[c] + r[c + jn]) * op.gz / (2.0 * op.Kc * TB(g.rDz, i));
+        }
+        P[c] = acc;                       // relative to the top of this slab; ghost row fixed below
     }
-    P[pl_idx(g, g.nz - 1, lj)] = 0.0;
+    coltot[lj] = acc;
 }
 
-__global__ __launch_bounds__(256) void k_hydrostatic_apply_shift(PlStokesOp op, double* __restrict__ x, const double* __restrict__ pa_ptr) {
+// P += prefix[j] (sum of the slabs above) - pa (anchor value); ghosts 0; velocities 0
+__global__ __launch_bounds__(256) void k_hydrostatic_apply_shift(PlStokesOp op, double* __restrict__ x,
+                                                                 const double* __restrict__ prefix, double pa) {
     PL_NODE_PROLOGUE(op.g)
     const PlGeom& g = op.g;
     double* P = x + 2 * g.plane;
-    const double pa = *pa_ptr;
     x[c] = 0.0; x[c + g.plane] = 0.0;
-    P[c] = (i >= g.nz - 1 || j >= g.nx - 1) ? 0.0 : P[c] - pa;
+    P[c] = (i >= g.nz - 1 || j >= g.nx - 1) ? 0.0 : P[c] + prefix[j] - pa;
 }
 
 // =========================================================================================
@@ -552,6 +557,9 @@ __global__ __launch_bounds__(256) void k_hydrostatic_apply_shift(PlStokesOp op, 
 // =========================================================================================
 struct MgLevel {
     PlGeomHost gh;
+    bool dist = false;          // rows decomposed over the ranks (halo exchanges needed)
+    PlGeom win{};               // first tail level only: this rank's row window of the GLOBAL arrays
+    int win_rows0 = 0;
     PlVvOp op{};
     double* etas = nullptr; double* etan = nullptr; bool own_visc = false;
     double* v[3] = {nullptr, nullptr, nullptr};      // rotating Chebyshev buffers (2 planes each)
@@ -562,6 +570,7 @@ struct MgLevel {
 struct PlSolver {
     std::vector<MgLevel*> levels;
     int bc_key[4] = {-1, -1, -1, -1};
+    int tail_start = -1;        // first replicated level (multi-rank: levels below are distributed)
     // BiCGStab work vectors (3 planes each)
     double *r = nullptr, *rt = nullptr, *p = nullptr, *v = nullptr, *s = nullptr, *t = nullptr, *y = nullptr,
            *z = nullptr, *b = nullptr, *x = nullptr;
@@ -624,6 +633,7 @@ static int dots(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const double*
     double s0 = 0.0, s1 = 0.0;
     for (int k = 0; k < nb; k++) { s0 += S->hpart[2 * k]; s1 += S->hpart[2 * k + 1]; }
     out2[0] = s0; out2[1] = s1;
+    if (ctx->nranks > 1 && g.lnz != g.nz) PL_TRY(pl_allreduce_host(ctx, out2, 2, 0));
     return 0;
 }
 
@@ -642,8 +652,19 @@ static void level_flags(MgLevel* L, const PlStokesOp& sop, bool finest) {
     o.sL = nsL ? (1.0 / (z[nz - 1] - z[nz - 3])) / (1.0 / (z[nz - 1] - z[nz - 3]) + 1.0 / (z[nz - 1] - z[nz - 2])) : 1.0;
 }
 
+// copy the last global node row of a replicated plane from the last rank to everybody
+static int share_last_row(pl_ctx* ctx, const PlGeom& gg, double* plane) {
+    std::vector<double> row((size_t)gg.pitch, 0.0);
+    double* p = plane + (long long)(gg.nz) * gg.pitch;          // row index nz-1 -> plane row nz
+    if (ctx->rank == ctx->nranks - 1) PL_HIP(ctx, hipMemcpy(row.data(), p, row.size() * sizeof(double), hipMemcpyDeviceToHost));
+    PL_TRY(pl_allreduce_host(ctx, row.data(), (long long)row.size(), 0));
+    PL_HIP(ctx, hipMemcpy(p, row.data(), row.size() * sizeof(double), hipMemcpyHostToDevice));
+    return 0;
+}
+
 static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
     const PlStokesOp& sop = ctx->sop;
+    const int R = ctx->nranks;
     bool rebuild = S->levels.empty();
     int key[4] = {sop.bc_z0, 0, sop.bc_zL, 0};
     if (!rebuild && (S->bc_key[0] != key[0] || S->bc_key[2] != key[2])) rebuild = true;
@@ -651,9 +672,23 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
         free_levels(S);
         int nz = ctx->nz, nx = ctx->nx;
         std::vector<double> zc = ctx->geom.zc, xc = ctx->geom.xc;
+        S->tail_start = -1;
         for (int l = 0;; l++) {
             MgLevel* L = new MgLevel();
             if (pl_geom_build(ctx, L->gh, nz, nx, zc.data(), xc.data())) { delete L; return 1; }
+            if (S->tail_start < 0 && l > 0 && (long long)nz * nx <= PL_TAIL_MAX_NODES) S->tail_start = l;
+            if (R > 1 && S->tail_start < 0) {                     // distributed level
+                const int C = (nz - 1) / R;
+                if ((nz - 1) % R || C < 2 || (C % 2)) { delete L; return pl_fail(ctx, "multigrid: (nz-1) must be divisible by ranks*2^levels down to the replicated coarse grid"); }
+                L->dist = true;
+                pl_geom_set_rows(L->gh, ctx->rank * C, (ctx->rank == R - 1) ? C + 1 : C);
+            }
+            if (R > 1 && l == S->tail_start) {                    // window of the replicated arrays
+                const int C = (nz - 1) / R;
+                if ((nz - 1) % R || C < 1) { delete L; return pl_fail(ctx, "multigrid: coarse grid smaller than the number of ranks"); }
+                L->win = L->gh.d; L->win.gi0 = ctx->rank * C; L->win.lnz = (ctx->rank == R - 1) ? C + 1 : C;
+                L->win_rows0 = ctx->rank * C;
+            }
             size_t vb = (size_t)2 * L->gh.d.plane * sizeof(double), pb = (size_t)L->gh.d.plane * sizeof(double);
             if (l > 0) {
                 L->own_visc = true;
@@ -668,6 +703,10 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
             for (int j = 0; j < nx; j += 2) x2.push_back(xc[j]);
             zc.swap(z2); xc.swap(x2); nz = (nz - 1) / 2 + 1; nx = (nx - 1) / 2 + 1;
         }
+        if (R > 1) {
+            if (S->tail_start < 0 || !S->use_tail || (int)S->levels.size() - S->tail_start > PL_TAIL_MAX_LEVELS)
+                return pl_fail(ctx, "multigrid: the multi-rank solver needs a replicated coarse tail (grid too small or too deep)");
+        }
         S->bc_key[0] = key[0]; S->bc_key[2] = key[2];
     }
     // (re)attach viscosities, coarsen, estimate lambda_max
@@ -676,10 +715,32 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
         MgLevel* L = S->levels[l];
         if (l > 0) {
             MgLevel* F = S->levels[l - 1];
-            hipLaunchKernelGGL(k_coarsen_visc, grid2d(L->gh.d), dim3(64, 4), 0, ctx->stream, F->gh.d, F->etas, F->etan,
-                               L->gh.d, L->etas, L->etan);
+            if (F->dist) {       // fine viscosity rings must be valid for the [1 2 1] stencil
+                PL_TRY(pl_halo_rows(ctx, F->gh.d, F->etas, 1, F->gh.d.plane));
+                PL_TRY(pl_halo_rows(ctx, F->gh.d, F->etan, 1, F->gh.d.plane));
+            }
+            if (R > 1 && (int)l == S->tail_start) {
+                // my rows of the replicated arrays, then all-gather (+ the last node row)
+                const long long sh = (long long)L->win_rows0 * L->gh.d.pitch;
+                hipLaunchKernelGGL(k_coarsen_visc, grid2d(L->win), dim3(64, 4), 0, ctx->stream, F->gh.d, F->etas, F->etan,
+                                   L->win, L->etas + sh, L->etan + sh);
+                PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                const long long cnt = (long long)((L->gh.d.nz - 1) / R) * L->gh.d.pitch;
+                if (ctx->comm.allgather(ctx->comm.user, L->etas + L->gh.d.pitch, cnt, 1, 0) ||
+                    ctx->comm.allgather(ctx->comm.user, L->etan + L->gh.d.pitch, cnt, 1, 0))
+                    return pl_fail(ctx, "communication callback 'allgather' failed");
+                PL_TRY(share_last_row(ctx, L->gh.d, L->etas));
+                PL_TRY(share_last_row(ctx, L->gh.d, L->etan));
+            } else {
+                hipLaunchKernelGGL(k_coarsen_visc, grid2d(L->gh.d), dim3(64, 4), 0, ctx->stream, F->gh.d, F->etas, F->etan,
+                                   L->gh.d, L->etas, L->etan);
+            }
         }
         level_flags(L, sop, l == 0);
+        if (R > 1 && (int)l == S->tail_start) {           // window view shares flags and pointers (shifted)
+            const PlGeom w = L->win;
+            (void)w;
+        }
     }
     PL_HIP(ctx, hipGetLastError());
     for (MgLevel* L : S->levels) {
@@ -688,6 +749,7 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
         hipLaunchKernelGGL(k_random_interior, grid2d(g), dim3(64, 4), 0, ctx->stream, g, 2, L->v[0], 777u);
         double lam = 2.5, nn[2];
         for (int it = 0; it < 12; it++) {
+            if (L->dist) PL_TRY(pl_halo_rows(ctx, g, L->v[0], 2, g.plane));
             hipLaunchKernelGGL(k_vv_dinv_apply, grid2d(g), dim3(64, 4), 0, ctx->stream, L->op, L->v[0], L->v[1]);
             PL_TRY(dots(ctx, S, g, 2, L->v[1], L->v[1], L->v[0], L->v[0], nn));
             if (!(nn[1] > 0.0) || !(nn[0] > 0.0)) break;
@@ -703,7 +765,7 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
 // ---- smoothing and V-cycle ----------------------------------------------------------------
 // nsweep Chebyshev-Jacobi sweeps on level L; buf[0] is the current iterate on entry and on exit
 static void smooth(pl_ctx* ctx, MgLevel* L, double* buf[3], const double* f, int nsweep, double ratio,
-                   double* final_out = nullptr) {
+                   double* final_out = nullptr, bool zero_guess = false) {
     const double lmax = L->lmax, lmin = lmax / ratio;
     const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
     double rho_old = 1.0 / sigma;
@@ -711,6 +773,7 @@ static void smooth(pl_ctx* ctx, MgLevel* L, double* buf[3], const double* f, int
         double c1, c2;
         if (k == 0) { c1 = 0.0; c2 = 1.0 / theta; }
         else { const double rho = 1.0 / (2.0 * sigma - rho_old); c1 = rho * rho_old; c2 = 2.0 * rho / delta; rho_old = rho; }
+        if (L->dist && !(k == 0 && zero_guess)) (void)pl_halo_rows(ctx, L->gh.d, buf[0], 2, L->gh.d.plane);
         double* dst = (final_out && k == nsweep - 1) ? final_out : buf[2];
         hipLaunchKernelGGL(k_vv_cheb, grid2d(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, buf[0], buf[1], f, dst, c1, c2);
         if (dst != buf[2]) { buf[1] = buf[0]; buf[0] = dst; }
@@ -740,16 +803,29 @@ static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const double* f, double**
     (void)hipMemsetAsync(buf[0], 0, (size_t)2 * g.plane * sizeof(double), ctx->stream);
     if (l + 1 == S->levels.size()) {
         double ratio = 0.4 * g.nz * g.nx; if (ratio < 30.0) ratio = 30.0;
-        smooth(ctx, L, buf, f, S->coarse_sweeps, ratio);
+        smooth(ctx, L, buf, f, S->coarse_sweeps, ratio, nullptr, true);
         *out = buf[0];
         return;
     }
-    smooth(ctx, L, buf, f, S->nu_pre, 6.0);
+    smooth(ctx, L, buf, f, S->nu_pre, 6.0, nullptr, true);
+    if (L->dist) (void)pl_halo_rows(ctx, g, buf[0], 2, g.plane);
     hipLaunchKernelGGL(k_vv_residual, grid2d(g), dim3(64, 4), 0, ctx->stream, L->op, buf[0], f, L->r);
+    if (L->dist) (void)pl_halo_rows(ctx, g, L->r, 2, g.plane);
     MgLevel* C = S->levels[l + 1];
-    hipLaunchKernelGGL(k_vv_restrict, grid2d(C->gh.d), dim3(64, 4), 0, ctx->stream, g, C->op, L->r, C->f);
+    if (L->dist && !C->dist) {
+        // restrict my rows into the replicated coarse rhs, then all-gather it
+        PlVvOp wop = C->op; wop.g = C->win;
+        const long long sh = (long long)C->win_rows0 * C->gh.d.pitch;
+        hipLaunchKernelGGL(k_vv_restrict, grid2d(C->win), dim3(64, 4), 0, ctx->stream, g, wop, L->r, C->f + sh);
+        (void)hipStreamSynchronize(ctx->stream);
+        const long long cnt = (long long)((C->gh.d.nz - 1) / ctx->nranks) * C->gh.d.pitch;
+        (void)ctx->comm.allgather(ctx->comm.user, C->f + C->gh.d.pitch, cnt, 2, C->gh.d.plane);
+    } else {
+        hipLaunchKernelGGL(k_vv_restrict, grid2d(C->gh.d), dim3(64, 4), 0, ctx->stream, g, C->op, L->r, C->f);
+    }
     double* ec = nullptr;
     vcycle(ctx, S, l + 1, C->f, &ec);
+    if (C->dist) (void)pl_halo_rows(ctx, C->gh.d, ec, 2, C->gh.d.plane);
     hipLaunchKernelGGL(k_vv_prolong_add, grid2d(g), dim3(64, 4), 0, ctx->stream, L->op, C->gh.d, ec, buf[0], buf[2]);
     std::swap(buf[0], buf[2]);
     smooth(ctx, L, buf, f, S->nu_post, 6.0, final_out);
@@ -761,6 +837,7 @@ static int stokes_precond(pl_ctx* ctx, PlSolver* S, const double* rs, double* z)
     const PlStokesOp& op = ctx->sop;
     MgLevel* L0 = S->levels[0];
     const PlGeom& g = op.g;
+    if (L0->dist) PL_TRY(pl_halo_rows(ctx, g, (double*)rs + 2 * g.plane, 1, g.plane));      // rs_p row above
     hipLaunchKernelGGL(k_prec_stage1, grid2d(g), dim3(64, 4), 0, ctx->stream, op, L0->op, rs, z, L0->f);
     double* e = nullptr;
     const bool direct = S->levels.size() > 1 && S->nu_post > 0;     // last sweep writes into z
@@ -874,6 +951,7 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
     PlStokesOp sop_scaled = sop; sop_scaled.scaled = 1;
     S->napply = 0; S->nprec = 0;
     VecOp A = [&](const double* in, double* out) -> int {
+        PL_TRY(pl_halo_rows(ctx, g, (double*)in, 3, g.plane));
         pl_launch_stokes_apply(ctx, sop_scaled, in, out);      // y = D_r A x in one pass
         S->napply++;
         return 0;
@@ -887,10 +965,31 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
     double d2[2], ref = 0.0;
     {
         const long long n3 = 3 * g.plane;
-        hipLaunchKernelGGL(k_hydrostatic_columns, dim3((g.lnx + 63) / 64), dim3(64), 0, ctx->stream, sop, S->y);
-        PL_HIP(ctx, hipMemcpyAsync(S->scal + 4, S->y + 2 * g.plane + pl_idx(g, sop.anchor_i, sop.anchor_j), sizeof(double),
-                                   hipMemcpyDeviceToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_hydrostatic_apply_shift, grid2d(g), dim3(64, 4), 0, ctx->stream, sop, S->y, S->scal + 4);
+        double *coltot, *prefix;
+        PL_TRY(pl_buf(ctx, "hydro_coltot", (size_t)g.lnx * sizeof(double), &coltot));
+        PL_TRY(pl_buf(ctx, "hydro_prefix", (size_t)g.lnx * sizeof(double), &prefix));
+        hipLaunchKernelGGL(k_hydrostatic_columns, dim3((g.lnx + 63) / 64), dim3(64), 0, ctx->stream, sop, S->y, coltot);
+        // prefix over the slabs above + anchor value, through the host
+        const int R = ctx->nranks;
+        std::vector<double> hb((size_t)R * g.lnx + 1, 0.0);
+        PL_HIP(ctx, hipMemcpyAsync(hb.data() + (size_t)ctx->rank * g.lnx, coltot, (size_t)g.lnx * sizeof(double),
+                                   hipMemcpyDeviceToHost, ctx->stream));
+        const bool own_anchor = sop.anchor_i >= g.gi0 && sop.anchor_i < g.gi0 + g.lnz;
+        if (own_anchor)
+            PL_HIP(ctx, hipMemcpyAsync(&hb[(size_t)R * g.lnx], S->y + 2 * g.plane + pl_idx(g, sop.anchor_i - g.gi0, sop.anchor_j),
+                                       sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PL_TRY(pl_allreduce_host(ctx, hb.data(), (long long)hb.size(), 0));
+        std::vector<double> pre((size_t)g.lnx, 0.0);
+        for (int q = 0; q < ctx->rank; q++) for (int jj = 0; jj < g.lnx; jj++) pre[jj] += hb[(size_t)q * g.lnx + jj];
+        double pa = hb[(size_t)R * g.lnx];
+        if (R > 1) {      // the anchor value was taken before the prefix of its own slab was added
+            int owner = 0; while ((owner + 1) * ((g.nz - 1) / R) <= sop.anchor_i && owner + 1 < R) owner++;
+            for (int q = 0; q < owner; q++) pa += hb[(size_t)q * g.lnx + sop.anchor_j];
+        }
+        PL_HIP(ctx, hipMemcpyAsync(prefix, pre.data(), (size_t)g.lnx * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_hydrostatic_apply_shift, grid2d(g), dim3(64, 4), 0, ctx->stream, sop, S->y, prefix, pa);
+        PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
         PL_TRY(A(S->y, S->t));
         hipLaunchKernelGGL(k_axpy_out, grid1d(n3), dim3(256), 0, ctx->stream, n3, S->s, S->b, S->t, -1.0);
         PL_TRY(dots(ctx, S, g, 3, S->s, S->s, S->b, S->b, d2));
@@ -989,6 +1088,7 @@ int pl_heat_solve_device(pl_ctx* ctx, const double* b_dev, double rtol, int maxi
     PlHeatOp hop = ctx->hop;
     S->napply = 0;
     VecOp A = [&](const double* in, double* out) -> int {
+        PL_TRY(pl_halo_rows(ctx, g, (double*)in, 1, g.plane));
         pl_launch_heat_apply(ctx, hop, in, out);
         hipLaunchKernelGGL(k_heat_dinv, grid2d(g), dim3(64, 4), 0, ctx->stream, hop, out);
         S->napply++;

@@ -225,6 +225,7 @@ extern "C" int pl_stokes_apply(pl_ctx* ctx, const double* x, double* y) {
     double *dx, *dy;
     PL_TRY(pl_buf(ctx, "api_x", vb, &dx)); PL_TRY(pl_buf(ctx, "api_y", vb, &dy));
     PL_TRY(pl_vec3_upload(ctx, g, x, dx));
+    PL_TRY(pl_halo_rows(ctx, g, dx, 3, g.plane));
     pl_launch_stokes_apply(ctx, ctx->sop, dx, dy);
     PL_HIP(ctx, hipGetLastError());
     PL_TRY(pl_vec3_download(ctx, g, dy, y));
