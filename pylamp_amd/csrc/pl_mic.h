@@ -14,12 +14,15 @@ struct PlScatterArgs {
     // regular target node set: node k at z0 + k*hz (k < nz), x0 + k*hx (k < nx)
     double z0, hz, x0, hx;
     int nz, nx;
-    // dense (nz*nx) accumulators
+    // dense accumulators of nrows x nx doubles; accumulator row 0 is GLOBAL node row `row0`
+    // (single rank / host API: row0 = 0, nrows = nz; slab: row0 = gi0-1, nrows = lnz+2)
+    int row0, nrows;
     double* wsum; double* cnt;
     double* acc[PL_MAX_SCATTER_FIELDS];
     // cell-sorted tracers (optional): tracers of sort cell (ci,cj) are [cell_start[ci*ncx+cj],
     // cell_start[ci*ncx+cj+1]); the sort grid has ncz x ncx cells.  NULL -> unsorted path.
     const int* cell_start; int ncz, ncx;
+    int crow0;                  // global cell row of sort row 0
 };
 
 // tile of sort cells handled by one workgroup of the LDS-binned scatter
@@ -56,7 +59,11 @@ struct PlRk4Args {
     int fence; double eps, Lz, Lx;                 // optional fence of pylamp2.py:563-570
 };
 
-int pl_scatter_device(pl_ctx* ctx, PlScatterArgs& a, double* const* out, long long out_pitch, long long out_off);
+// slab != NULL: accumulators carry one ring row on each side; they are summed across ranks
+// (reverse halo), only the owned rows are finalised into the ring planes `out`, whose ring rows are
+// then filled by a forward halo exchange.
+int pl_scatter_device(pl_ctx* ctx, PlScatterArgs& a, double* const* out, long long out_pitch, long long out_off,
+                      const PlGeom* slab = nullptr);
 void pl_launch_gather(pl_ctx* ctx, const PlGatherArgs& a);
 void pl_launch_rk4(pl_ctx* ctx, const PlRk4Args& a);
 void pl_launch_aos_to_soa(pl_ctx* ctx, long long n, const double* src, long long ld, int ncol, double* dst,

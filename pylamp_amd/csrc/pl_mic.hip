@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256) void k_scatter_atomic(PlScatterArgs a) {
     for (int cnr = 0; cnr < 4; cnr++) {
         const int ni = ie + (cnr & 1), nj = je + (cnr >> 1);
         if (ni < 0 || ni >= a.nz || nj < 0 || nj >= a.nx) continue;
-        const long long o = (long long)ni * a.nx + nj;
+        if (ni < a.row0 || ni >= a.row0 + a.nrows) continue;
+        const long long o = (long long)(ni - a.row0) * a.nx + nj;
         if (a.wsum) mic_atomic_add(a.wsum + o, w[cnr]);
         if (a.cnt) mic_atomic_add(a.cnt + o, 1.0);
         for (int k = 0; k < a.nf; k++)
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(256) void k_scatter_binned(PlScatterArgs a, int til
     const int tid = threadIdx.x;
     const int ti = blockIdx.x / tiles_x, tj = blockIdx.x % tiles_x;
     const int ci0 = ti * PL_TILE_R, cj0 = tj * PL_TILE_C;
+    const int ni0 = a.crow0 + ci0 - 1;                          // global node row of window row 0
     for (int k = tid; k < nacc * WH; k += 256) lds[k] = 0.0;
     __syncthreads();
     const int cj1 = min(cj0 + PL_TILE_C, a.ncx);
@@ -109,7 +111,8 @@ __global__ __launch_bounds__(256) void k_scatter_binned(PlScatterArgs a, int til
             for (int cnr = 0; cnr < 4; cnr++) {
                 const int ni = ie + (cnr & 1), nj = je + (cnr >> 1);
                 if (ni < 0 || ni >= a.nz || nj < 0 || nj >= a.nx) continue;
-                const int li = ni - (ci0 - 1), lj = nj - (cj0 - 1);
+                if (ni < a.row0 || ni >= a.row0 + a.nrows) continue;
+                const int li = ni - ni0, lj = nj - (cj0 - 1);
                 if (li >= 0 && li < H && lj >= 0 && lj < W) {
                     const int o = li * W + lj;
                     if (a.wsum) unsafeAtomicAdd(&lds[o], w[cnr]);
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(256) void k_scatter_binned(PlScatterArgs a, int til
                     for (int k = 0; k < a.nf; k++)
                         unsafeAtomicAdd(&lds[(2 + k) * WH + o], (a.scheme[k] & PL_AVG_WEIGHTED) ? val[k] * w[cnr] : val[k]);
                 } else {
-                    const long long o = (long long)ni * a.nx + nj;
+                    const long long o = (long long)(ni - a.row0) * a.nx + nj;
                     if (a.wsum) mic_atomic_add(a.wsum + o, w[cnr]);
                     if (a.cnt) mic_atomic_add(a.cnt + o, 1.0);
                     for (int k = 0; k < a.nf; k++)
@@ -128,9 +131,10 @@ __global__ __launch_bounds__(256) void k_scatter_binned(PlScatterArgs a, int til
     }
     __syncthreads();
     for (int o = tid; o < WH; o += 256) {
-        const int ni = ci0 - 1 + o / W, nj = cj0 - 1 + o % W;
+        const int ni = ni0 + o / W, nj = cj0 - 1 + o % W;
         if (ni < 0 || ni >= a.nz || nj < 0 || nj >= a.nx) continue;
-        const long long go = (long long)ni * a.nx + nj;
+        if (ni < a.row0 || ni >= a.row0 + a.nrows) continue;
+        const long long go = (long long)(ni - a.row0) * a.nx + nj;
         if (a.wsum) { const double v = lds[o]; if (v != 0.0) mic_atomic_add(a.wsum + go, v); }
         if (a.cnt) { const double v = lds[WH + o]; if (v != 0.0) mic_atomic_add(a.cnt + go, v); }
         for (int k = 0; k < a.nf; k++) { const double v = lds[(2 + k) * WH + o]; if (v != 0.0) mic_atomic_add(a.acc[k] + go, v); }
@@ -156,8 +160,8 @@ __global__ __launch_bounds__(256) void k_scatter_finalize(int nz, int nx, const 
     out[out_off + (long long)i * out_pitch + j] = r;
 }
 
-int pl_scatter_device(pl_ctx* ctx, PlScatterArgs& a, double* const* out, long long out_pitch, long long out_off) {
-    // accumulators: wsum, cnt, acc[nf] dense (nz*nx)
+int pl_scatter_device(pl_ctx* ctx, PlScatterArgs& a, double* const* out, long long out_pitch, long long out_off,
+                      const PlGeom* slab) {
     if (a.nf < 1 || a.nf > PL_MAX_SCATTER_FIELDS) return pl_fail(ctx, "trac2grid: bad number of fields");
     bool has_w = false, has_c = false;
     for (int k = 0; k < a.nf; k++) {
@@ -165,7 +169,9 @@ int pl_scatter_device(pl_ctx* ctx, PlScatterArgs& a, double* const* out, long lo
         if (!(s & (PL_AVG_ARITHMETIC | PL_AVG_GEOMETRIC))) return pl_fail(ctx, "!!! ERROR INVALID AVERAGING SCHEME");
         if (s & PL_AVG_WEIGHTED) has_w = true; else has_c = true;
     }
-    size_t N = (size_t)a.nz * a.nx;
+    if (slab) { a.row0 = slab->gi0 - 1; a.nrows = slab->lnz + 2; }
+    else { a.row0 = 0; a.nrows = a.nz; }
+    size_t N = (size_t)a.nrows * a.nx;
     double* accbuf;
     PL_TRY(pl_buf(ctx, "scatter_acc", (size_t)(a.nf + 2) * N * sizeof(double), &accbuf, false));
     PL_HIP(ctx, hipMemsetAsync(accbuf, 0, (size_t)(a.nf + 2) * N * sizeof(double), ctx->stream));
@@ -181,13 +187,27 @@ int pl_scatter_device(pl_ctx* ctx, PlScatterArgs& a, double* const* out, long lo
         hipLaunchKernelGGL(k_scatter_atomic, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, ctx->stream, a);
         PL_HIP(ctx, hipGetLastError());
     }
-    dim3 g2((a.nx + 63) / 64, (a.nz + 3) / 4);
+    int frows = a.nrows; const double* fbase = accbuf;
+    if (slab) {
+        if (ctx->nranks > 1) {
+            // reverse halo: my ring rows are added to the neighbours' first / last owned rows
+            PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            const long long nx = a.nx;
+            if (ctx->comm.exchange(ctx->comm.user, accbuf, accbuf + nx, accbuf + (long long)(slab->lnz + 1) * nx,
+                                   accbuf + (long long)slab->lnz * nx, nx, a.nf + 2, (long long)N, 1))
+                return pl_fail(ctx, "communication callback 'exchange' failed");
+        }
+        frows = slab->lnz; fbase = accbuf + a.nx;           // owned rows only
+    }
+    dim3 g2((a.nx + 63) / 64, (frows + 3) / 4);
     for (int k = 0; k < a.nf; k++) {
-        const double* den = (a.scheme[k] & PL_AVG_WEIGHTED) ? accbuf : accbuf + N;
-        hipLaunchKernelGGL(k_scatter_finalize, g2, dim3(64, 4), 0, ctx->stream, a.nz, a.nx, a.acc[k], den,
+        const double* den = (a.scheme[k] & PL_AVG_WEIGHTED) ? fbase : fbase + N;
+        hipLaunchKernelGGL(k_scatter_finalize, g2, dim3(64, 4), 0, ctx->stream, frows, a.nx, fbase + (size_t)(2 + k) * N, den,
                            a.scheme[k], out[k], out_pitch, out_off);
     }
     PL_HIP(ctx, hipGetLastError());
+    if (slab && ctx->nranks > 1)
+        for (int k = 0; k < a.nf; k++) PL_TRY(pl_halo_rows(ctx, *slab, out[k], 1, slab->plane));
     return 0;
 }
 
@@ -340,6 +360,7 @@ extern "C" int pl_trac2grid(pl_ctx* ctx, int64_t n, const double* tr_x, const do
     a.z0 = z0; a.hz = hz; a.x0 = x0; a.hx = hx; a.nz = nz; a.nx = nx;
     double* outs[PL_MAX_SCATTER_FIELDS];
     for (int k = 0; k < nf; k++) outs[k] = d_out + (size_t)k * N;
+    if (ctx->nranks > 1) return pl_fail(ctx, "pl_trac2grid: host-array MIC calls are single-rank; use the resident step");
     PL_TRY(pl_scatter_device(ctx, a, outs, nx, 0));
     for (int k = 0; k < nf; k++)
         PL_HIP(ctx, hipMemcpyAsync(out[k], outs[k], N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

@@ -31,7 +31,9 @@ struct PlStepState {
     int* cell = nullptr; int* dest = nullptr;        // per tracer: sort cell, destination slot
     int* orig = nullptr; int* orig2 = nullptr;       // caller's index of the tracer now stored at slot t
     int* cell_count = nullptr; int* cell_start = nullptr; int* block_sums = nullptr;
-    int ncz = 0, ncx = 0;
+    int ncz = 0, ncx = 0;                            // sort grid (rows incl. the leaver rows of a slab)
+    int crow0 = 0;                                   // global cell row of sort row 0
+    int lo_ext = 0, hi_ext = 0;                      // 1: sort row 0 / last row collect tracers leaving to rank-1 / rank+1
     std::vector<double> gmz, gmx;                    // midpoint grids (pylamp2.py:92-95)
 };
 
@@ -80,11 +82,12 @@ __global__ __launch_bounds__(256) void k_col_to_aos(long long m, const double* _
 
 // ---- counting sort of the tracers by node-grid cell --------------------------------------------
 __global__ __launch_bounds__(256) void k_cell_count(long long n, const double* __restrict__ tz, const double* __restrict__ tx,
-                                                    double z0, double hz, double x0, double hx, int ncz, int ncx,
-                                                    int* __restrict__ cell, int* __restrict__ count) {
+                                                    double z0, double hz, double x0, double hx, int ncz, int ncx, int crow0,
+                                                    int gcz, int* __restrict__ cell, int* __restrict__ count) {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     int ci = (int)floor((tz[t] - z0) / hz), cj = (int)floor((tx[t] - x0) / hx);
+    ci = min(max(ci, 0), gcz - 1) - crow0;              // global cell row (clamped to the domain) -> sort row
     ci = min(max(ci, 0), ncz - 1); cj = min(max(cj, 0), ncx - 1);
     const int c = ci * ncx + cj;
     cell[t] = c;
@@ -299,6 +302,12 @@ static int reduce_minmax(pl_ctx* ctx, PlStepState* S, const PlGeom& g, const dou
         m0 = std::fmin(m0, S->hpartial[3 * k]); m1 = std::fmax(m1, S->hpartial[3 * k + 1]);
         if (S->hpartial[3 * k + 2] > 0) nf = true;
     }
+    if (ctx->nranks > 1) {
+        double v[1] = {m0};
+        PL_TRY(pl_allreduce_host(ctx, v, 1, 1)); m0 = v[0];
+        v[0] = m1; PL_TRY(pl_allreduce_host(ctx, v, 1, 2)); m1 = v[0];
+        v[0] = nf ? 1.0 : 0.0; PL_TRY(pl_allreduce_host(ctx, v, 1, 2)); nf = v[0] > 0.0;
+    }
     *mn = m0; *mx = m1; *has_nan = nf;
     return 0;
 }
@@ -406,11 +415,18 @@ extern "C" int pl_get_tracer_velocity(pl_ctx* ctx, int64_t n, double* out) {
 }
 
 // Counting sort of all tracer arrays by node-grid cell; leaves cell_start (ncells+1 ints) valid.
+// On a slab the sort grid has one extra row on each interior side that collects the tracers which
+// left the slab (they end up as contiguous ranges at the two ends of every array).
 static int sort_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, double x0, double hx) {
-    const int ncz = ctx->nz - 1, ncx = ctx->nx - 1, nc = ncz * ncx;
+    const PlGeom& g = ctx->geom.d;
+    const int C = (ctx->nranks > 1) ? (g.nz - 1) / ctx->nranks : g.nz - 1;
+    S->lo_ext = (ctx->rank > 0) ? 1 : 0; S->hi_ext = (ctx->rank < ctx->nranks - 1) ? 1 : 0;
+    const int ncz = C + S->lo_ext + S->hi_ext, ncx = ctx->nx - 1, nc = ncz * ncx;
+    S->crow0 = g.gi0 - S->lo_ext;
     const long long n = S->n;
     if (n >= (1LL << 31)) return pl_fail(ctx, "sort_tracers: more than 2^31 tracers per GPU");
-    if (!S->cell_count) {
+    if (!S->cell_count || S->ncz != ncz) {
+        for (int** q : {&S->cell_count, &S->cell_start, &S->block_sums}) { if (*q) (void)hipFree(*q); *q = nullptr; }
         const int nb = (nc + 1 + 1023) / 1024;
         PL_HIP(ctx, hipMalloc((void**)&S->cell_count, (size_t)(nc + 1) * sizeof(int)));
         PL_HIP(ctx, hipMalloc((void**)&S->cell_start, (size_t)(nc + 1) * sizeof(int)));
@@ -418,28 +434,63 @@ static int sort_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, doubl
         S->ncz = ncz; S->ncx = ncx;
     }
     PL_HIP(ctx, hipMemsetAsync(S->cell_count, 0, (size_t)(nc + 1) * sizeof(int), ctx->stream));
-    hipLaunchKernelGGL(k_cell_count, grid1d(n), dim3(256), 0, ctx->stream, n, S->tz, S->tx, z0, hz, x0, hx, ncz, ncx, S->cell,
-                       S->cell_count);
+    if (n > 0)
+        hipLaunchKernelGGL(k_cell_count, grid1d(n), dim3(256), 0, ctx->stream, n, S->tz, S->tx, z0, hz, x0, hx, ncz, ncx,
+                           S->crow0, g.nz - 1, S->cell, S->cell_count);
     const int m = nc + 1, nb = (m + 1023) / 1024;
     hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(256), 0, ctx->stream, m, S->cell_count, S->cell_start, S->block_sums);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, ctx->stream, nb, S->block_sums);
     hipLaunchKernelGGL(k_scan_add, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, m, S->cell_start, S->block_sums, 0);
     PL_HIP(ctx, hipMemsetAsync(S->cell_count, 0, (size_t)(nc + 1) * sizeof(int), ctx->stream));   // reused as fill counters
-    hipLaunchKernelGGL(k_cell_place, grid1d(n), dim3(256), 0, ctx->stream, n, S->cell, S->cell_start, S->cell_count, S->dest);
-    // permute positions and the 13 fields
-    const double* src[15]; double* dst[15];
-    src[0] = S->tz; dst[0] = S->tz2; src[1] = S->tx; dst[1] = S->tx2;
-    for (int k = 0; k < NFTRAC; k++) { src[2 + k] = S->f[k]; dst[2 + k] = S->f2[k]; }
-    for (int k0 = 0; k0 < 15; k0 += 5) {
-        PermArgs pa{}; pa.na = 5;
-        for (int k = 0; k < 5; k++) { pa.in[k] = src[k0 + k]; pa.out[k] = dst[k0 + k]; }
-        hipLaunchKernelGGL(k_permute, grid1d(n), dim3(256), 0, ctx->stream, n, S->dest, pa);
+    if (n > 0) {
+        hipLaunchKernelGGL(k_cell_place, grid1d(n), dim3(256), 0, ctx->stream, n, S->cell, S->cell_start, S->cell_count, S->dest);
+        // permute positions and the 13 fields
+        const double* src[15]; double* dst[15];
+        src[0] = S->tz; dst[0] = S->tz2; src[1] = S->tx; dst[1] = S->tx2;
+        for (int k = 0; k < NFTRAC; k++) { src[2 + k] = S->f[k]; dst[2 + k] = S->f2[k]; }
+        for (int k0 = 0; k0 < 15; k0 += 5) {
+            PermArgs pa{}; pa.na = 5;
+            for (int k = 0; k < 5; k++) { pa.in[k] = src[k0 + k]; pa.out[k] = dst[k0 + k]; }
+            hipLaunchKernelGGL(k_permute, grid1d(n), dim3(256), 0, ctx->stream, n, S->dest, pa);
+        }
+        hipLaunchKernelGGL(k_permute_int, grid1d(n), dim3(256), 0, ctx->stream, n, S->dest, S->orig, S->orig2);
+        std::swap(S->tz, S->tz2); std::swap(S->tx, S->tx2); std::swap(S->orig, S->orig2);
+        for (int k = 0; k < NFTRAC; k++) std::swap(S->f[k], S->f2[k]);
     }
-    hipLaunchKernelGGL(k_permute_int, grid1d(n), dim3(256), 0, ctx->stream, n, S->dest, S->orig, S->orig2);
     PL_HIP(ctx, hipGetLastError());
-    std::swap(S->tz, S->tz2); std::swap(S->tx, S->tx2); std::swap(S->orig, S->orig2);
-    for (int k = 0; k < NFTRAC; k++) std::swap(S->f[k], S->f2[k]);
     return 0;
+}
+
+// Slab only: send the tracers in the two leaver rows to the neighbour ranks, append what arrives,
+// then sort again.  (Tracers move less than a cell per step, so rank +-1 is always the destination;
+// one that jumps further is simply forwarded again at the next step.)
+static int migrate_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, double x0, double hx) {
+    if (ctx->nranks <= 1) return 0;
+    const int ncx = S->ncx;
+    int h[2] = {0, 0};
+    PL_HIP(ctx, hipMemcpyAsync(&h[0], S->cell_start + (size_t)S->lo_ext * ncx, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    PL_HIP(ctx, hipMemcpyAsync(&h[1], S->cell_start + (size_t)(S->ncz - S->hi_ext) * ncx, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const long long n = S->n;
+    const long long n_lo = S->lo_ext ? h[0] : 0, hi_begin = S->hi_ext ? h[1] : n, n_hi = n - hi_begin, stay = hi_begin - n_lo;
+    double* cols[15]; double* spare[15];
+    cols[0] = S->tz; cols[1] = S->tx; spare[0] = S->tz2; spare[1] = S->tx2;
+    for (int k = 0; k < NFTRAC; k++) { cols[2 + k] = S->f[k]; spare[2 + k] = S->f2[k]; }
+    double *slo[15], *shi[15], *rcv[15];
+    for (int k = 0; k < 15; k++) {
+        // stayers first into the spare buffers, arrivals appended behind them
+        PL_HIP(ctx, hipMemcpyAsync(spare[k], cols[k] + n_lo, (size_t)stay * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        slo[k] = cols[k]; shi[k] = cols[k] + hi_begin; rcv[k] = spare[k] + stay;
+    }
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int64_t got = 0;
+    if (ctx->comm.exchange_var(ctx->comm.user, slo, n_lo, shi, n_hi, rcv, S->cap - stay, 15, &got))
+        return pl_fail(ctx, "communication callback 'exchange_var' failed (tracer migration)");
+    std::swap(S->tz, S->tz2); std::swap(S->tx, S->tx2);
+    for (int k = 0; k < NFTRAC; k++) std::swap(S->f[k], S->f2[k]);
+    S->n = stay + got;
+    if (S->n > 0) hipLaunchKernelGGL(k_iota, grid1d(S->n), dim3(256), 0, ctx->stream, S->n, S->orig);
+    return sort_tracers(ctx, S, z0, hz, x0, hx);
 }
 
 // un-permute resident arrays into the spare buffers so that downloads come out in the caller's order
@@ -463,24 +514,22 @@ static int scatter_to_planes(pl_ctx* ctx, PlStepState* S, int nf, const int* fid
     a.n = S->n; a.tz = S->tz; a.tx = S->tx; a.nf = nf;
     for (int k = 0; k < nf; k++) { a.f[k] = fidx[k] >= 0 ? S->f[fidx[k]] : S->tmp[-fidx[k] - 1]; a.scheme[k] = schemes[k]; }
     a.z0 = z0; a.hz = hz; a.x0 = x0; a.hx = hx; a.nz = g.nz; a.nx = g.nx;
-    a.cell_start = S->cell_start; a.ncz = S->ncz; a.ncx = S->ncx;     // tracers are cell-sorted (sort_tracers)
-    return pl_scatter_device(ctx, a, planes, g.pitch, pl_idx(g, 0, 0));
+    a.cell_start = S->cell_start; a.ncz = S->ncz; a.ncx = S->ncx; a.crow0 = S->crow0;     // cell-sorted (sort_tracers)
+    return pl_scatter_device(ctx, a, planes, g.pitch, pl_idx(g, 0, 0), &g);
 }
 
 extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_report* rep) {
     if (!cfg || !rep) return pl_fail(ctx, "pl_step: NULL argument");
     PL_HIP(ctx, hipSetDevice(ctx->device));
     PlStepState* S = state_of(ctx);
-    if (S->n <= 0) return pl_fail(ctx, "pl_step: no tracers resident (call pl_tracers_upload)");
+    if (S->n <= 0 && ctx->nranks == 1) return pl_fail(ctx, "pl_step: no tracers resident (call pl_tracers_upload)");
     if (!ctx->geom.uniform) return pl_fail(ctx, "pl_step: marker-in-cell needs a regular grid (pylamp_trac.py:34,162)");
     PL_TRY(pl_stokes_check_bc(ctx, cfg->bcstokes));
     if (cfg->do_heatdiff) PL_TRY(pl_heat_check_bc(ctx, cfg->bcheat));
     const PlGeom& g = ctx->geom.d;
     const int nz = g.nz, nx = g.nx;
-    const long long n = S->n;
     const size_t pb = (size_t)g.plane * sizeof(double);
     memset(rep, 0, sizeof(*rep));
-    rep->ntrac = n;
     const double Lz = cfg->length[0], Lx = cfg->length[1];
     const double dz = Lz / (nz - 1), dx = Lx / (nx - 1);           // pylamp2.py:87
     const double z0 = ctx->geom.zc[0], x0 = ctx->geom.xc[0];
@@ -499,8 +548,11 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
     // ---- 0. cell sort (keeps scatter windows and gathers local) -----------------------------
     t0 = now_ms();
     PL_TRY(sort_tracers(ctx, S, z0, hz, x0, hx));
+    PL_TRY(migrate_tracers(ctx, S, z0, hz, x0, hx));
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     rep->ms_sort = now_ms() - t0;
+    const long long n = S->n;
+    rep->ntrac = n;
 
     // ---- 1. tracer properties --------------------------------------------------------------
     t0 = now_ms();
@@ -606,6 +658,7 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
                                     cfg->heat_maxit > 0 ? cfg->heat_maxit : 2000, &rep->heat, &xs));
         PL_HIP(ctx, hipMemcpyAsync(p_newT, xs, pb, hipMemcpyDeviceToDevice, ctx->stream));
         PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PL_TRY(pl_halo_rows(ctx, g, p_newT, 1, g.plane));
         rep->ms_heat = now_ms() - t0;
 
         // temperature to tracers
@@ -628,12 +681,13 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
         ga.g.nz = nz; ga.g.nx = nx; ga.g.gz = S->gcoords; ga.g.gx = S->gcoords + nz;
         ga.g.zmin = ctx->geom.zc[0]; ga.g.xmin = ctx->geom.xc[0];
         ga.g.Lz = ctx->geom.zc[nz - 1] - ctx->geom.zc[0]; ga.g.Lx = ctx->geom.xc[nx - 1] - ctx->geom.xc[0];
-        ga.g.pitch = g.pitch; ga.g.off = pl_idx(g, 0, 0);
+        ga.g.pitch = g.pitch; ga.g.off = pl_idx(g, -g.gi0, 0);      // field row index is GLOBAL
         if (it == 1 || !S->have_newtemp) {
             ga.fields[0] = p_newT; ga.out[0] = S->f[TR_TMP];
             pl_launch_gather(ctx, ga);
         } else {
             hipLaunchKernelGGL(k_plane_sub, grid2d(g), dim3(64, 4), 0, ctx->stream, g, p_newT, p_T, p_dT);
+            PL_TRY(pl_halo_rows(ctx, g, p_dT, 1, g.plane));
             ga.fields[0] = p_dT; ga.out[0] = S->tmp[0];
             pl_launch_gather(ctx, ga);
             const double inv2 = (2.0 / dx) * (2.0 / dx) + (2.0 / dz) * (2.0 / dz);
@@ -651,6 +705,7 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
         unsigned long long nout = 0;
         PL_HIP(ctx, hipMemcpyAsync(&nout, cnt, sizeof(nout), hipMemcpyDeviceToHost, ctx->stream));
         PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        { double v[1] = {(double)nout}; PL_TRY(pl_allreduce_host(ctx, v, 1, 0)); nout = (unsigned long long)v[0]; }
         if (nout > 0) return pl_fail(ctx, "stopOnError in grid2trac");        // pylamp2.py:445,453 stopOnError=True
         S->have_newtemp = true;
         rep->ms_gather = now_ms() - t0;
@@ -678,9 +733,34 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
     double* V;
     const size_t VN = (size_t)(nz + 1) * (nx + 1);
     PL_TRY(pl_buf(ctx, "advect_vel", 2 * VN * sizeof(double), &V, false));
+    PlGeom gfull = g;                       // the advection velocity grid is replicated on every rank
+    const double* a_vz = p_vz; const double* a_vx = p_vx;
+    if (ctx->nranks > 1) {
+        gfull.gi0 = 0; gfull.lnz = nz; gfull.plane = (long long)(nz + 2) * g.pitch;
+        double* full;
+        PL_TRY(pl_buf(ctx, "vel_full", (size_t)2 * gfull.plane * sizeof(double), &full));
+        const long long C = (nz - 1) / ctx->nranks, cnt = C * g.pitch;
+        for (int q = 0; q < 2; q++)
+            PL_HIP(ctx, hipMemcpyAsync(full + q * gfull.plane + (long long)(1 + g.gi0) * g.pitch, (q ? p_vx : p_vz) + g.pitch,
+                                       (size_t)g.lnz * g.pitch * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->comm.allgather(ctx->comm.user, full + g.pitch, cnt, 2, gfull.plane))
+            return pl_fail(ctx, "communication callback 'allgather' failed");
+        // the last node row (a wall / ghost row) lives on the last rank only
+        std::vector<double> row((size_t)2 * g.pitch, 0.0);
+        if (ctx->rank == ctx->nranks - 1)
+            for (int q = 0; q < 2; q++)
+                PL_HIP(ctx, hipMemcpy(row.data() + (size_t)q * g.pitch, full + q * gfull.plane + (long long)nz * g.pitch,
+                                      (size_t)g.pitch * sizeof(double), hipMemcpyDeviceToHost));
+        PL_TRY(pl_allreduce_host(ctx, row.data(), (long long)row.size(), 0));
+        for (int q = 0; q < 2; q++)
+            PL_HIP(ctx, hipMemcpy(full + q * gfull.plane + (long long)nz * g.pitch, row.data() + (size_t)q * g.pitch,
+                                  (size_t)g.pitch * sizeof(double), hipMemcpyHostToDevice));
+        a_vz = full; a_vx = full + gfull.plane;
+    }
     {
         dim3 gr((nx + 1 + 63) / 64, (nz + 1 + 3) / 4);
-        hipLaunchKernelGGL(k_advection_velocity, gr, dim3(64, 4), 0, ctx->stream, g, p_vz, p_vx,
+        hipLaunchKernelGGL(k_advection_velocity, gr, dim3(64, 4), 0, ctx->stream, gfull, a_vz, a_vx,
                            (cfg->bcstokes[0] & PL_BC_FREESLIP) ? 1 : 0, (cfg->bcstokes[1] & PL_BC_FREESLIP) ? 1 : 0,
                            (cfg->bcstokes[2] & PL_BC_FREESLIP) ? 1 : 0, (cfg->bcstokes[3] & PL_BC_FREESLIP) ? 1 : 0, V, V + VN);
     }

@@ -54,13 +54,19 @@ def falling_block_tracers(nx, L, tracdens, rng):
     return tr_x, tr_f
 
 
-def mantle_tracers(nx, L, tracdens, rng, perturb=20.0):
+def mantle_tracers(nx, L, tracdens, rng, perturb=20.0, zrange=None, id0=0):
     """Model-1-like T-dependent mantle (values of pylamp2.py:146-154) with a conductive
-    initial temperature plus a sinusoidal perturbation."""
+    initial temperature plus a sinusoidal perturbation.
+    zrange=(lo, hi) draws only this slab's share of the tracers (multi-GPU benchmark set-up)."""
     n = int(np.prod(nx)) * tracdens
-    tr_x = rng.random((n, DIM)) * np.array(L)
+    if zrange is None:
+        tr_x = rng.random((n, DIM)) * np.array(L)
+    else:
+        lo, hi = max(zrange[0], 0.0), min(zrange[1], L[IZ])
+        n = int(round(n * (hi - lo) / L[IZ]))
+        tr_x = rng.random((n, DIM)) * np.array([hi - lo, L[IX]]) + np.array([lo, 0.0])
     tr_f = np.zeros((n, NFTRAC))
-    tr_f[:, TR__ID] = np.arange(n)
+    tr_f[:, TR__ID] = np.arange(n) + id0
     tr_f[:, TR_RH0] = 3300; tr_f[:, TR_ALP] = 3.5e-5; tr_f[:, TR_MAT] = 2; tr_f[:, TR_ET0] = 1e20
     tr_f[:, TR_HCD] = 4.0; tr_f[:, TR_HCP] = 1250; tr_f[:, TR_ACE] = 120e3; tr_f[:, TR_IHT] = 0.02e-6 / 3300
     z, x = tr_x[:, IZ], tr_x[:, IX]
@@ -69,7 +75,7 @@ def mantle_tracers(nx, L, tracdens, rng, perturb=20.0):
 
 
 class Simulation:
-    def __init__(self, nx, L, tr_x, tr_f, options=None, device=None):
+    def __init__(self, nx, L, tr_x=None, tr_f=None, options=None, device=None):
         self.nx = [int(nx[0]), int(nx[1])]
         self.L = [float(L[0]), float(L[1])]
         self.grid = [np.linspace(0, self.L[i], self.nx[i]) for i in range(DIM)]       # pylamp2.py:90
@@ -78,22 +84,61 @@ class Simulation:
         self.it = 0
         self.totaltime = 0.0
         self.last = None
-        self.upload(tr_x, tr_f)
+        self.ntrac = 0
+        if tr_x is not None:
+            self.upload(tr_x, tr_f)
 
     # -- tracer state -------------------------------------------------------------------------
+    def slab(self):
+        """z-interval [lo, hi) of the node rows this rank owns (whole domain on one rank)."""
+        if self.ctx.nranks == 1:
+            return -np.inf, np.inf
+        first, _ = self.ctx.local_rows()
+        c = (self.nx[0] - 1) // self.ctx.nranks
+        lo = -np.inf if self.ctx.rank == 0 else self.grid[IZ][first]
+        hi = np.inf if self.ctx.rank == self.ctx.nranks - 1 else self.grid[IZ][first + c]
+        return lo, hi
+
     def upload(self, tr_x, tr_f):
+        """Upload tracers; under torch.distributed every rank passes the full (or any superset of
+        its) tracer set and keeps the ones inside its row slab."""
         tr_x = _lib.f64(tr_x); tr_f = _lib.f64(tr_f)
         if tr_x.shape[1] != DIM or tr_f.shape != (tr_x.shape[0], NFTRAC):
             raise Exception("tracer arrays must be (n,2) and (n,13)")
+        lo, hi = self.slab()
+        if self.ctx.nranks > 1:
+            keep = (tr_x[:, IZ] >= lo) & (tr_x[:, IZ] < hi)
+            tr_x = np.ascontiguousarray(tr_x[keep]); tr_f = np.ascontiguousarray(tr_f[keep])
         self.ntrac = tr_x.shape[0]
         self.ctx.check(self.ctx.lib.pl_tracers_upload(self.ctx.h, self.ntrac, _lib.dptr(tr_x), _lib.dptr(tr_f)))
 
+    def _refresh_count(self):
+        n = C.c_int64()
+        self.ctx.check(self.ctx.lib.pl_tracers_count(self.ctx.h, C.byref(n)))
+        self.ntrac = n.value
+
     def tracers(self):
+        """Tracers resident on THIS rank (all of them on one rank, in upload order)."""
+        self._refresh_count()
         tr_x = np.empty((self.ntrac, DIM)); tr_f = np.empty((self.ntrac, NFTRAC))
         self.ctx.check(self.ctx.lib.pl_tracers_download(self.ctx.h, self.ntrac, _lib.dptr(tr_x), _lib.dptr(tr_f)))
         return tr_x, tr_f
 
+    def gather_tracers(self):
+        """All tracers of all ranks on every rank, ordered by TR__ID (tests / snapshots)."""
+        tr_x, tr_f = self.tracers()
+        v = self.tracer_velocity()
+        if self.ctx.nranks > 1:
+            import torch.distributed as dist
+            parts = [None] * self.ctx.nranks
+            dist.all_gather_object(parts, (tr_x, tr_f, v))
+            tr_x = np.concatenate([p[0] for p in parts]); tr_f = np.concatenate([p[1] for p in parts])
+            v = np.concatenate([p[2] for p in parts])
+        o = np.argsort(tr_f[:, TR__ID], kind="stable")
+        return tr_x[o], tr_f[o], v[o]
+
     def tracer_velocity(self):
+        self._refresh_count()
         v = np.empty((self.ntrac, DIM))
         self.ctx.check(self.ctx.lib.pl_get_tracer_velocity(self.ctx.h, self.ntrac, _lib.dptr(v)))
         return v
@@ -128,6 +173,7 @@ class Simulation:
         rep = _lib.StepReport()
         self.ctx.check(self.ctx.lib.pl_step(self.ctx.h, C.byref(cfg), self.it, C.byref(rep)))
         self.totaltime += rep.tstep
+        self.ntrac = rep.ntrac
         out = {k: getattr(rep, k) for k, _ in rep._fields_ if k not in ("stokes", "heat", "limiter")}
         out["limiter"] = chr(rep.limiter)
         out["stokes"] = rep.stokes.as_dict(); out["heat"] = rep.heat.as_dict()

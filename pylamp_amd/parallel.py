@@ -58,9 +58,11 @@ class Comm:
         self.rank = dist.get_rank(group)
         self.size = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
-        self.device_mode = self.backend == "nccl"
-        # host scalars always travel through gloo
+        import os
+        self.device_mode = self.backend == "nccl" and not os.environ.get("PYLAMP_COMM_STAGING")
+        # host scalars (and the staging fallback) always travel through gloo
         self.host_group = group if self.backend == "gloo" else dist.new_group(backend="gloo")
+        self.stage_group = self.host_group
         self.errors = []
         self._ops = CommOps(_EXCHANGE(self._exchange), _ALLREDUCE(self._allreduce_host), _ALLGATHER(self._allgather),
                             _EXCHANGE_VAR(self._exchange_var), None)
@@ -88,12 +90,35 @@ class Comm:
             self.errors.append(repr(e))
             return 1
 
+    def _agree_device_mode(self):
+        """All ranks must use the same transport: if the zero-copy device path is unusable on any
+        rank, everybody stages through the host (collective decision, once)."""
+        if getattr(self, "_agreed", False):
+            return
+        ok = 1
+        if self.device_mode:
+            try:
+                probe = self.torch.zeros(4, dtype=self.torch.float64, device="cuda")
+                v = self._dev(probe.data_ptr(), 4)
+                v += 1.0
+                self.torch.cuda.synchronize()
+                ok = int(bool((probe == 1.0).all().item()))
+            except Exception as e:
+                self.errors.append("device path disabled: " + repr(e))
+                ok = 0
+        t = self.torch.tensor([ok], dtype=self.torch.int64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.host_group)
+        if int(t.item()) == 0:
+            self.device_mode = False
+        self._agreed = True
+
     # ---- neighbour exchange ------------------------------------------------------------------------
     def _exchange(self, user, send_lo, recv_lo, send_hi, recv_hi, count, nseg, stride, add):
         return self._guard(self._exchange_impl, send_lo, recv_lo, send_hi, recv_hi, count, nseg, stride, add)
 
     def _exchange_impl(self, send_lo, recv_lo, send_hi, recv_hi, count, nseg, stride, add):
         dist, torch = self.dist, self.torch
+        self._agree_device_mode()
         lo, hi = self.rank - 1, self.rank + 1
         has_lo, has_hi = lo >= 0, hi < self.size
         B = 8
@@ -128,10 +153,10 @@ class Comm:
         reqs, rl, rh = [], None, None
         if has_lo:
             sl = torch.from_numpy(pack(send_lo)); rl = torch.empty(nseg * count, dtype=torch.float64)
-            reqs += [dist.isend(sl, lo, self.group), dist.irecv(rl, lo, self.group)]
+            reqs += [dist.isend(sl, lo, self.stage_group), dist.irecv(rl, lo, self.stage_group)]
         if has_hi:
             sh = torch.from_numpy(pack(send_hi)); rh = torch.empty(nseg * count, dtype=torch.float64)
-            reqs += [dist.isend(sh, hi, self.group), dist.irecv(rh, hi, self.group)]
+            reqs += [dist.isend(sh, hi, self.stage_group), dist.irecv(rh, hi, self.stage_group)]
         for r in reqs:
             r.wait()
         for base, buf in ((recv_lo, rl), (recv_hi, rh)):
@@ -160,6 +185,7 @@ class Comm:
 
     def _allgather_impl(self, recv, count, nseg, stride):
         dist, torch = self.dist, self.torch
+        self._agree_device_mode()
         B = 8
         for k in range(nseg):
             base = recv + k * stride * B
@@ -170,7 +196,7 @@ class Comm:
             else:
                 mine = torch.from_numpy(self._d2h(base + self.rank * count * B, count))
                 out = [torch.empty(count, dtype=torch.float64) for _ in range(self.size)]
-                dist.all_gather(out, mine, group=self.group)
+                dist.all_gather(out, mine, group=self.stage_group)
                 self._h2d(base, np.concatenate([o.numpy() for o in out]))
         if self.device_mode:
             torch.cuda.synchronize()
@@ -181,6 +207,7 @@ class Comm:
 
     def _exchange_var_impl(self, send_lo, n_lo, send_hi, n_hi, recv, cap, ncol, got):
         dist, torch = self.dist, self.torch
+        self._agree_device_mode()
         lo, hi = self.rank - 1, self.rank + 1
         has_lo, has_hi = lo >= 0, hi < self.size
         # 1. counts (host, gloo)
@@ -219,14 +246,14 @@ class Comm:
         reqs, rl, rh = [], None, None
         if has_lo and n_lo:
             reqs.append(dist.isend(torch.from_numpy(np.concatenate([self._d2h(send_lo[k], n_lo) for k in range(ncol)])),
-                                   lo, self.group))
+                                   lo, self.stage_group))
         if has_hi and n_hi:
             reqs.append(dist.isend(torch.from_numpy(np.concatenate([self._d2h(send_hi[k], n_hi) for k in range(ncol)])),
-                                   hi, self.group))
+                                   hi, self.stage_group))
         if m_lo:
-            rl = torch.empty(ncol * m_lo, dtype=torch.float64); reqs.append(dist.irecv(rl, lo, self.group))
+            rl = torch.empty(ncol * m_lo, dtype=torch.float64); reqs.append(dist.irecv(rl, lo, self.stage_group))
         if m_hi:
-            rh = torch.empty(ncol * m_hi, dtype=torch.float64); reqs.append(dist.irecv(rh, hi, self.group))
+            rh = torch.empty(ncol * m_hi, dtype=torch.float64); reqs.append(dist.irecv(rh, hi, self.stage_group))
         for r in reqs:
             r.wait()
         for k in range(ncol):
