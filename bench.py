@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=2049, help="nodes per side (default: BASELINE config 3)")
+    ap.add_argument("--grid", dest="n", type=int, default=2049, help="nodes per side (default 2049: BASELINE config 3)")
     ap.add_argument("--tracdens", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--apply-reps", type=int, default=50)
@@ -104,16 +104,23 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("PYLAMP_DIST_BACKEND", "nccl")     # "gloo": several ranks sharing one GPU (tests)
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
+    red_dev = "cuda" if (dist is not None and dist.get_backend() == "nccl") else "cpu"
 
     def barrier():
         if dist is not None:
             import torch
             dist.barrier()
-            torch.cuda.synchronize()
+            if red_dev == "cuda":
+                torch.cuda.synchronize()
 
-    sim = build_sim(args.n, args.tracdens, 20260103, local_rank, rank, world)
+    device = int(os.environ["PYLAMP_DEVICE"]) if os.environ.get("PYLAMP_DEVICE") else local_rank
+    sim = build_sim(args.n, args.tracdens, 20260103, device, rank, world)
     ctx = sim.ctx
     reports = []
     for _ in range(args.warmup):
@@ -129,7 +136,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -141,7 +148,7 @@ def main():
     ntrac_global = sim.ntrac
     if dist is not None:
         import torch
-        t = torch.tensor([float(sim.ntrac)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([float(sim.ntrac)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t)
         ntrac_global = int(t.item())
     if rank == 0:

@@ -197,7 +197,8 @@ def vcycle(Ls,l,fz,fx,gz=None,gx=None,nu=(3,3),csweeps=12,damp=1.0):
     L=Ls[l]
     vz=np.zeros_like(fz); vx=np.zeros_like(fx)
     if l==len(Ls)-1:
-        smooth(L,vz,vx,fz,fx,csweeps,gz,gx,ratio=max(30.0,0.4*L.nz*L.nx)); return vz,vx
+        ratio=max(30.0,0.4*L.nz*L.nx)
+        smooth(L,vz,vx,fz,fx,min(150,max(csweeps,int(np.sqrt(ratio)))),gz,gx,ratio=ratio); return vz,vx
     smooth(L,vz,vx,fz,fx,nu[0],gz,gx)
     yz,yx=apply(L,vz,vx)
     cz,cx=restrict(L,Ls[l+1],(fz-yz)*L.mz,(fx-yx)*L.mx)

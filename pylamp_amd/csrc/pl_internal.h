@@ -85,6 +85,21 @@ struct pl_ctx {
     void* step = nullptr;     // pl_step.hip
 };
 
+// ---- node-kernel launch shape -------------------------------------------------------------------
+// Blocks are 64 x 4 threads; a workgroup marches over `iters` groups of 4 rows (iters = 8 on large
+// planes, 1 on small ones).  Vertically adjacent 64x4 blocks are dealt to DIFFERENT XCDs (no shared
+// L2), so with iters = 1 every block re-fetches its halo rows from HBM: measured 1.6x read
+// amplification on k_stokes_apply (profiles/r01_pmc_v1_summary.csv); 32-row blocks cut it to 2/32.
+inline int pl_row_iters(const PlGeom& g) { (void)g; return 1; }   // 8 (32-row blocks) measured SLOWER: apply 83 -> 95 us; the re-reads hit the Infinity Cache
+inline dim3 pl_grid_rows(const PlGeom& g) {
+    const int it = pl_row_iters(g);
+    return dim3((g.lnx + 63) / 64, (g.lnz + 4 * it - 1) / (4 * it));
+}
+#define PL_ROW_LOOP(g, iters)                                                           \
+    const int lj = blockIdx.x * 64 + threadIdx.x;                                       \
+    if (lj >= (g).lnx) return;                                                          \
+    for (int it_ = 0, li = blockIdx.y * 4 * (iters) + threadIdx.y; it_ < (iters) && li < (g).lnz; it_++, li += 4)
+
 // ---- error helpers ----------------------------------------------------------------------
 extern thread_local std::string pl_tls_error;
 int pl_fail(pl_ctx* ctx, const std::string& msg);

@@ -59,7 +59,7 @@ __device__ inline int vv_cls_x(const PlVvOp& op, int i, int j, int& moff, double
 // (A_vv v)_z and -diag at global node (i,j), plane offset c.  Zero-padded tables make the
 // mirror terms of the natural rows vanish (rDx[0] = rDx[nx-1] = 0, same in z).
 __device__ inline void vv_row_z(const PlVvOp& op, const double* __restrict__ vz, const double* __restrict__ vx,
-                                long long c, int i, int j, double& Av, double& dg) {
+                                int c, int i, int j, double& Av, double& dg) {
     const PlGeom& g = op.g;
     const int p = g.pitch;
     const double rdz_i = TB(g.rdz, i), rdz_m = TB(g.rdz, i - 1), rDz_i = TB(g.rDz, i);
@@ -75,7 +75,7 @@ __device__ inline void vv_row_z(const PlVvOp& op, const double* __restrict__ vz,
 }
 
 __device__ inline void vv_row_x(const PlVvOp& op, const double* __restrict__ vz, const double* __restrict__ vx,
-                                long long c, int i, int j, double& Av, double& dg) {
+                                int c, int i, int j, double& Av, double& dg) {
     const PlGeom& g = op.g;
     const int p = g.pitch;
     const double rdx_j = TB(g.rdx, j), rdx_m = TB(g.rdx, j - 1), rDx_j = TB(g.rDx, j);
@@ -100,60 +100,71 @@ __device__ inline void vv_row_x(const PlVvOp& op, const double* __restrict__ vz,
 //     v_next = v_cur + c1 (v_cur - v_prev) + c2 D^-1 (f - A v_cur)
 // with the constraint rows closed in the same pass (a slave thread evaluates its master's
 // update; all inputs are read-only so there is no ordering hazard).  80 B/node/sweep.
+// (32-bit element offsets from wave-uniform plane bases keep the address arithmetic in SGPR-base +
+// VGPR-offset form: fewer VGPRs, more waves per SIMD)
 __device__ inline void cheb_node(const PlVvOp& op, const double* __restrict__ vcur, const double* __restrict__ vprev,
                                  const double* __restrict__ f, double* __restrict__ vnext, double c1, double c2, int i,
-                                 int j, long long c) {
+                                 int j, long long c64) {
     const long long P = op.g.plane;
-    const double* vz = vcur; const double* vx = vcur + P;
+    const int c = (int)c64;
+    const double* __restrict__ vz = vcur; const double* __restrict__ vx = vcur + P;
+    const double* __restrict__ pz = vprev; const double* __restrict__ px = vprev + P;
+    const double* __restrict__ fz = f; const double* __restrict__ fx = f + P;
+    double* __restrict__ nz_ = vnext; double* __restrict__ nx_ = vnext + P;
     int moff = 0; double s = 1.0;
     int cls = vv_cls_z(op, i, j, moff, s);
     double out = 0.0;
     if (cls != VV_ZERO) {
-        const long long cm = c + moff;
+        const int cm = c + moff;
         double Av, dg;
         vv_row_z(op, vz, vx, cm, i, j + moff, Av, dg);             // moff is +-1 for vz
         const double v0 = vz[cm];
-        const double mom = (c1 != 0.0) ? c1 * (v0 - vprev[cm]) : 0.0;
-        out = s * (v0 + mom + c2 * (Av - f[cm]) / dg);              // D = -dg
+        const double mom = (c1 != 0.0) ? c1 * (v0 - pz[cm]) : 0.0;
+        out = s * (v0 + mom + c2 * (Av - fz[cm]) / dg);             // D = -dg
     }
-    vnext[c] = out;
+    nz_[c] = out;
     cls = vv_cls_x(op, i, j, moff, s);
     out = 0.0;
     if (cls != VV_ZERO) {
-        const long long cm = c + moff;
+        const int cm = c + moff;
         const int im = i + (moff > 0 ? 1 : (moff < 0 ? -1 : 0));
         double Av, dg;
         vv_row_x(op, vz, vx, cm, im, j, Av, dg);
         const double v0 = vx[cm];
-        const double mom = (c1 != 0.0) ? c1 * (v0 - vprev[cm + P]) : 0.0;
-        out = s * (v0 + mom + c2 * (Av - f[cm + P]) / dg);
+        const double mom = (c1 != 0.0) ? c1 * (v0 - px[cm]) : 0.0;
+        out = s * (v0 + mom + c2 * (Av - fx[cm]) / dg);
     }
-    vnext[c + P] = out;
+    nx_[c] = out;
 }
 
-__global__ __launch_bounds__(256) void k_vv_cheb(PlVvOp op, const double* __restrict__ vcur,
+#ifndef PL_CHEB_WAVES
+#define PL_CHEB_WAVES 4
+#endif
+__global__ __launch_bounds__(256, PL_CHEB_WAVES) void k_vv_cheb(PlVvOp op, const double* __restrict__ vcur,
                                                  const double* __restrict__ vprev, const double* __restrict__ f,
-                                                 double* __restrict__ vnext, double c1, double c2) {
-    PL_NODE_PROLOGUE(op.g)
-    cheb_node(op, vcur, vprev, f, vnext, c1, c2, i, j, c);
+                                                 double* __restrict__ vnext, double c1, double c2, int iters) {
+    PL_ROW_LOOP(op.g, iters)
+        cheb_node(op, vcur, vprev, f, vnext, c1, c2, op.g.gi0 + li, op.g.gj0 + lj, pl_idx(op.g, li, lj));
 }
 
 // r = f - A v on interior rows, 0 elsewhere
 // (f and r may alias: every thread reads only its own f entries before writing r)
 __device__ inline void residual_node(const PlVvOp& op, const double* __restrict__ v, const double* f, double* r, int i,
-                                     int j, long long c) {
+                                     int j, long long c64) {
     const long long P = op.g.plane;
+    const int c = (int)c64;
+    const double* fx = f + P; double* rx_ = r + P;
     int moff; double s, Av, dg;
     double rz = 0.0, rx = 0.0;
     if (vv_cls_z(op, i, j, moff, s) == VV_INT) { vv_row_z(op, v, v + P, c, i, j, Av, dg); rz = f[c] - Av; }
-    if (vv_cls_x(op, i, j, moff, s) == VV_INT) { vv_row_x(op, v, v + P, c, i, j, Av, dg); rx = f[c + P] - Av; }
-    r[c] = rz; r[c + P] = rx;
+    if (vv_cls_x(op, i, j, moff, s) == VV_INT) { vv_row_x(op, v, v + P, c, i, j, Av, dg); rx = fx[c] - Av; }
+    r[c] = rz; rx_[c] = rx;
 }
 
 __global__ __launch_bounds__(256) void k_vv_residual(PlVvOp op, const double* __restrict__ v, const double* f,
-                                                     double* r) {
-    PL_NODE_PROLOGUE(op.g)
-    residual_node(op, v, f, r, i, j, c);
+                                                     double* r, int iters) {
+    PL_ROW_LOOP(op.g, iters)
+        residual_node(op, v, f, r, op.g.gi0 + li, op.g.gj0 + lj, pl_idx(op.g, li, lj));
 }
 
 // y = D^-1 A v with closure (power iteration for lambda_max)
@@ -164,13 +175,13 @@ __global__ __launch_bounds__(256) void k_vv_dinv_apply(PlVvOp op, const double* 
     int moff = 0; double s = 1.0, Av, dg;
     int cls = vv_cls_z(op, i, j, moff, s);
     double o = 0.0;
-    if (cls != VV_ZERO) { vv_row_z(op, v, v + P, c + moff, i, j + moff, Av, dg); o = s * Av / dg; }
+    if (cls != VV_ZERO) { vv_row_z(op, v, v + P, (int)(c + moff), i, j + moff, Av, dg); o = s * Av / dg; }
     y[c] = o;
     cls = vv_cls_x(op, i, j, moff, s);
     o = 0.0;
     if (cls != VV_ZERO) {
         const int im = i + (moff > 0 ? 1 : (moff < 0 ? -1 : 0));
-        vv_row_x(op, v, v + P, c + moff, im, j, Av, dg); o = s * Av / dg;
+        vv_row_x(op, v, v + P, (int)(c + moff), im, j, Av, dg); o = s * Av / dg;
     }
     y[c + P] = o;
 }
@@ -475,8 +486,10 @@ __device__ inline double prec_p_value(const PlStokesOp& op, const double* __rest
 // because x0 is closed with k_close_constraints and every preconditioned direction satisfies the
 // homogeneous wall/slave rows, so (A y)_constraint = 0 for all iterates.
 __global__ __launch_bounds__(256) void k_prec_stage1(PlStokesOp op, PlVvOp vop, const double* __restrict__ rs,
-                                                     double* __restrict__ z, double* __restrict__ f) {
-    PL_NODE_PROLOGUE(op.g)
+                                                     double* __restrict__ z, double* __restrict__ f, int iters) {
+    PL_ROW_LOOP(op.g, iters) {
+    const int i = op.g.gi0 + li, j = op.g.gj0 + lj;
+    const long long c = pl_idx(op.g, li, lj);
     const long long P = op.g.plane;
     const int p = op.g.pitch;
     const double* rs_p = rs + 2 * P;
@@ -490,6 +503,7 @@ __global__ __launch_bounds__(256) void k_prec_stage1(PlStokesOp op, PlVvOp vop, 
     if (vv_cls_x(vop, i, j, moff, s) == VV_INT)
         fx = rs[c + P] / sx + 2.0 * op.Kc * TB(op.g.rDx, j) * (zp_c - prec_p_value(op, rs_p, i, j - 1, c - 1));
     f[c] = fz; f[c + P] = fx; z[c + 2 * P] = zp_c;
+    }
 }
 
 // Make x satisfy the constraint rows of A x = b exactly (b given SCALED, bs = b / Kc on these rows):
@@ -775,10 +789,22 @@ static void smooth(pl_ctx* ctx, MgLevel* L, double* buf[3], const double* f, int
         else { const double rho = 1.0 / (2.0 * sigma - rho_old); c1 = rho * rho_old; c2 = 2.0 * rho / delta; rho_old = rho; }
         if (L->dist && !(k == 0 && zero_guess)) (void)pl_halo_rows(ctx, L->gh.d, buf[0], 2, L->gh.d.plane);
         double* dst = (final_out && k == nsweep - 1) ? final_out : buf[2];
-        hipLaunchKernelGGL(k_vv_cheb, grid2d(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, buf[0], buf[1], f, dst, c1, c2);
+        hipLaunchKernelGGL(k_vv_cheb, pl_grid_rows(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, buf[0], buf[1], f, dst, c1, c2,
+                           pl_row_iters(L->gh.d));
         if (dst != buf[2]) { buf[1] = buf[0]; buf[0] = dst; }
         else { double* nxt = buf[2]; buf[2] = buf[1]; buf[1] = buf[0]; buf[0] = nxt; }    // (cur, prev, free)
     }
+}
+
+// Chebyshev sweeps on the coarsest level: enough for the eigenvalue window [lmax/ratio, lmax] of a
+// grid that could not be coarsened further (ratio ~ 0.4 nz nx; a 5x5 grid needs the default 12, a
+// non-coarsenable 100x60 grid ~50)
+static int coarsest_sweeps(const PlSolver* S, const PlGeom& g) {
+    double ratio = 0.4 * g.nz * g.nx; if (ratio < 30.0) ratio = 30.0;
+    int n = (int)std::sqrt(ratio);
+    if (n < S->coarse_sweeps) n = S->coarse_sweeps;
+    if (n > 150) n = 150;
+    return n;
 }
 
 // solves A_vv e = f(level l) approximately; result in *out (one of the level's v buffers)
@@ -789,7 +815,8 @@ static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const double* f, double**
     if (S->use_tail && l > 0 && (long long)g.nz * g.nx <= PL_TAIL_MAX_NODES &&
         S->levels.size() - l <= PL_TAIL_MAX_LEVELS && f == L->f) {
         TailArgs ta{};
-        ta.nlev = (int)(S->levels.size() - l); ta.nu_pre = S->nu_pre; ta.nu_post = S->nu_post; ta.coarse_sweeps = S->coarse_sweeps;
+        ta.nlev = (int)(S->levels.size() - l); ta.nu_pre = S->nu_pre; ta.nu_post = S->nu_post;
+        ta.coarse_sweeps = coarsest_sweeps(S, S->levels.back()->gh.d);
         for (int q = 0; q < ta.nlev; q++) {
             MgLevel* T = S->levels[l + q];
             ta.L[q].op = T->op; ta.L[q].f = T->f; ta.L[q].r = T->r; ta.L[q].lmax = T->lmax;
@@ -803,13 +830,13 @@ static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const double* f, double**
     (void)hipMemsetAsync(buf[0], 0, (size_t)2 * g.plane * sizeof(double), ctx->stream);
     if (l + 1 == S->levels.size()) {
         double ratio = 0.4 * g.nz * g.nx; if (ratio < 30.0) ratio = 30.0;
-        smooth(ctx, L, buf, f, S->coarse_sweeps, ratio, nullptr, true);
+        smooth(ctx, L, buf, f, coarsest_sweeps(S, g), ratio, nullptr, true);
         *out = buf[0];
         return;
     }
     smooth(ctx, L, buf, f, S->nu_pre, 6.0, nullptr, true);
     if (L->dist) (void)pl_halo_rows(ctx, g, buf[0], 2, g.plane);
-    hipLaunchKernelGGL(k_vv_residual, grid2d(g), dim3(64, 4), 0, ctx->stream, L->op, buf[0], f, L->r);
+    hipLaunchKernelGGL(k_vv_residual, pl_grid_rows(g), dim3(64, 4), 0, ctx->stream, L->op, buf[0], f, L->r, pl_row_iters(g));
     if (L->dist) (void)pl_halo_rows(ctx, g, L->r, 2, g.plane);
     MgLevel* C = S->levels[l + 1];
     if (L->dist && !C->dist) {
@@ -838,7 +865,7 @@ static int stokes_precond(pl_ctx* ctx, PlSolver* S, const double* rs, double* z)
     MgLevel* L0 = S->levels[0];
     const PlGeom& g = op.g;
     if (L0->dist) PL_TRY(pl_halo_rows(ctx, g, (double*)rs + 2 * g.plane, 1, g.plane));      // rs_p row above
-    hipLaunchKernelGGL(k_prec_stage1, grid2d(g), dim3(64, 4), 0, ctx->stream, op, L0->op, rs, z, L0->f);
+    hipLaunchKernelGGL(k_prec_stage1, pl_grid_rows(g), dim3(64, 4), 0, ctx->stream, op, L0->op, rs, z, L0->f, pl_row_iters(g));
     double* e = nullptr;
     const bool direct = S->levels.size() > 1 && S->nu_post > 0;     // last sweep writes into z
     vcycle(ctx, S, 0, L0->f, &e, direct ? z : nullptr);

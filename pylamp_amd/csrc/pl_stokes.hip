@@ -9,6 +9,7 @@
 // = 64 B.
 #include "pl_internal.h"
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 
 #define TB(tab, k) (tab)[(k) + 1]
@@ -17,16 +18,15 @@
 // row, so every z-table value is wave-uniform (scalar loads) and all plane accesses are
 // 512-B contiguous per wave-instruction; the +-1 column / +-pitch row neighbours are
 // re-reads of lines the same or the adjacent wave just touched (L1/L2 hits).
-__global__ __launch_bounds__(256) void k_stokes_apply(PlStokesOp op, const double* __restrict__ x,
-                                                      double* __restrict__ y) {
+__device__ inline void stokes_apply_node(const PlStokesOp& op, const double* __restrict__ x, double* __restrict__ y,
+                                         int li, int lj) {
     const PlGeom& g = op.g;
-    const int lj = blockIdx.x * 64 + threadIdx.x;
-    const int li = blockIdx.y * 4 + threadIdx.y;
-    if (lj >= g.lnx || li >= g.lnz) return;
     const int i = g.gi0 + li, j = g.gj0 + lj;
     const int nz = g.nz, nx = g.nx;
     const int p = g.pitch;
-    const long long c = pl_idx(g, li, lj);
+    // 32-bit element offsets from wave-uniform base pointers: lets the compiler use the
+    // SGPR-base + VGPR-offset addressing mode instead of a 64-bit address per neighbour
+    const int c = (li + 1) * p + (lj + PL_PADL);
     const double* __restrict__ vz = x;
     const double* __restrict__ vx = x + g.plane;
     const double* __restrict__ P = x + 2 * g.plane;
@@ -38,7 +38,8 @@ __global__ __launch_bounds__(256) void k_stokes_apply(PlStokesOp op, const doubl
     // row scale factors D_r (used only when op.scaled): 1/(sum of the 4 own-component
     // coefficients) on interior momentum rows, 1/Kc on constraint rows, 1/(Kc (1/dx+1/dz)) on
     // continuity rows, 1/Kb on corner rows.  No extra memory traffic.
-    double sz = 1.0 / Kc, sx = 1.0 / Kc, sp = 1.0 / Kc;
+    const double iKc = 1.0 / Kc;
+    double sz = iKc, sx = iKc, sp = iKc;
 
     // ---------------- vz row (z-momentum) ----------------
     double yz;
@@ -69,6 +70,9 @@ __global__ __launch_bounds__(256) void k_stokes_apply(PlStokesOp op, const doubl
                    (r[c + p] + r[c + p + 1] - r[c - p] - r[c - p + 1]) * rDz_i * vz_c);
         }
     }
+    y[c] = op.scaled ? yz * sz : yz;            // each row is stored as soon as it is complete;
+    __builtin_amdgcn_sched_barrier(0);          // the fence keeps the next row's loads from being hoisted
+                                                // above it (110 -> fewer VGPRs, more waves per SIMD)
 
     // ---------------- vx row (x-momentum) ----------------
     double yx;
@@ -101,6 +105,8 @@ __global__ __launch_bounds__(256) void k_stokes_apply(PlStokesOp op, const doubl
                    (r[c + p] + r[c + p + 1] - r[c - p] - r[c - p + 1]) * rDz_i * vz_c);
         }
     }
+    y[c + g.plane] = op.scaled ? yx * sx : yx;
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---------------- P row (continuity) ----------------
     double yp;
@@ -116,11 +122,29 @@ __global__ __launch_bounds__(256) void k_stokes_apply(PlStokesOp op, const doubl
         yp = Kc * ((vx[c + 1] - vx_c) * TB(g.rdx, j) + (vz[c + p] - vz_c) * TB(g.rdz, i));
         sp = 1.0 / (Kc * (TB(g.rdx, j) + TB(g.rdz, i)));
     }
-    if (op.scaled) { yz *= sz; yx *= sx; yp *= sp; }
+    y[c + 2 * g.plane] = op.scaled ? yp * sp : yp;
+}
 
-    y[c] = yz;
-    y[c + g.plane] = yx;
-    y[c + 2 * g.plane] = yp;
+#ifndef PL_APPLY_WAVES
+#define PL_APPLY_WAVES 4
+#endif
+__global__ __launch_bounds__(256, PL_APPLY_WAVES) void k_stokes_apply(PlStokesOp op, const double* __restrict__ x,
+                                                                      double* __restrict__ y, int iters) {
+    PL_ROW_LOOP(op.g, iters) stokes_apply_node(op, x, y, li, lj);
+}
+
+// XCD-aware variant (1-D grid).  The dispatcher deals consecutive workgroup ids round-robin over
+// the 8 XCDs (MI355X_MICROARCH.md, observed; used for speed only): id % 8 selects the XCD.  Block
+// column bx is served by XCD bx % 8, and inside an XCD the blocks walk row-major, so vertically
+// adjacent blocks - which share a halo row of all five input planes - share that XCD's L2.
+__global__ __launch_bounds__(256, PL_APPLY_WAVES) void k_stokes_apply_xcd(PlStokesOp op, const double* __restrict__ x,
+                                                                          double* __restrict__ y, int gx8) {
+    const int id = blockIdx.x;
+    const int xcd = id & 7, k = id >> 3;
+    const int by = k / gx8, bx = xcd + 8 * (k % gx8);
+    const int lj = bx * 64 + threadIdx.x, li = by * 4 + threadIdx.y;
+    if (lj >= op.g.lnx || li >= op.g.lnz) return;
+    stokes_apply_node(op, x, y, li, lj);
 }
 
 __global__ __launch_bounds__(256) void k_stokes_rhs(PlStokesOp op, double* __restrict__ rhs) {
@@ -139,7 +163,13 @@ __global__ __launch_bounds__(256) void k_stokes_rhs(PlStokesOp op, double* __res
 static dim3 grid2d(const PlGeom& g) { return dim3((g.lnx + 63) / 64, (g.lnz + 3) / 4); }
 
 void pl_launch_stokes_apply(pl_ctx* ctx, const PlStokesOp& op, const double* x, double* y) {
-    hipLaunchKernelGGL(k_stokes_apply, grid2d(op.g), dim3(64, 4), 0, ctx->stream, op, x, y);
+    static const int use_xcd = getenv("PYLAMP_APPLY_XCD") ? atoi(getenv("PYLAMP_APPLY_XCD")) : 1;
+    if (use_xcd && (long long)op.g.lnz * op.g.lnx >= 8000000LL) {   // measured: +5% at 4097^2, neutral at 2049^2
+        const int gx = (op.g.lnx + 63) / 64, gy = (op.g.lnz + 3) / 4, gx8 = (gx + 7) / 8;
+        hipLaunchKernelGGL(k_stokes_apply_xcd, dim3(8 * gx8 * gy), dim3(64, 4), 0, ctx->stream, op, x, y, gx8);
+        return;
+    }
+    hipLaunchKernelGGL(k_stokes_apply, pl_grid_rows(op.g), dim3(64, 4), 0, ctx->stream, op, x, y, pl_row_iters(op.g));
 }
 
 void pl_launch_stokes_rhs(pl_ctx* ctx, const PlStokesOp& op, double* rhs) {

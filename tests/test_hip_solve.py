@@ -113,3 +113,26 @@ def test_preconditioner_matches_prototype(name):
     Z = z.reshape(nx[0], nx[1], 3); ZP = zp.reshape(nx[0], nx[1], 3)
     for q in range(3):
         assert np.max(np.abs(Z[:, :, q] - ZP[:, :, q])) < 1e-11 * np.max(np.abs(ZP[:, :, q])), q
+
+
+@pytest.mark.parametrize("nx,uniform,bc", [([12, 10], False, [0, 1, 0, 1]), ([21, 37], False, [1, 1, 0, 1]),
+                                           ([100, 60], True, [1, 1, 1, 1]), ([129, 129], False, [0, 1, 1, 1])])
+def test_stokes_solve_nonuniform_and_noncoarsenable(oracle, nx, uniform, bc):
+    """Rectilinear (non-uniform) grids, NOSLIP walls, and grids that cannot be coarsened
+    (odd cell counts -> single-level preconditioner)."""
+    from pylamp_amd import pylamp_stokes as S
+    rng = np.random.default_rng(4)
+    L = [660e3, 500e3]
+
+    def nonuni(n, Ld):
+        w = rng.uniform(0.7, 1.3, n - 1); g = np.concatenate([[0.0], np.cumsum(w)]); return g * (Ld / g[-1])
+    grid = [np.linspace(0, L[d], nx[d]) if uniform else nonuni(nx[d], L[d]) for d in range(2)]
+    Z, X = np.meshgrid(*grid, indexing='ij')
+    Zc, Xc = np.meshgrid(*oracle.gridmp_of(grid), indexing='ij')
+    f = lambda z, x: 1e20 * 10 ** (1.5 * np.sin(2 * np.pi * x / L[1]) * np.cos(np.pi * z / L[0]))
+    es, en = f(Z, X), f(Zc, Xc)
+    rho = 3300 + 40 * np.sin(2 * np.pi * X / L[1]) * np.sin(np.pi * Z / L[0])
+    A, rhs = S.makeStokesMatrix(nx, grid, es, en, rho, bc)
+    x = S.solve(A, rhs)
+    ev, ep = _vel_err(S, x, oracle.stokes_solve(nx, grid, es, en, rho, bc), nx)
+    assert A.last_stats["converged"] == 1 and ev < VEL_TOL, (ev, A.last_stats)
