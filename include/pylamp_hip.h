@@ -169,6 +169,13 @@ typedef struct pl_step_config {
     double stokes_rtol, heat_rtol;
     int    stokes_maxit, heat_maxit;
     double length[2];               /* domain size L[z], L[x] (pylamp2.py:38) */
+    /* Tracer census + injection at the end of the step (pylamp2.py:588-633): cells holding fewer
+     * than tracdens_min tracers are refilled to tracdens with tracers at (seeded) random positions
+     * whose 12 fields are the plain mean of the tracers already in the cell.  tracdens_min <= 0
+     * disables it.  New IDs continue after the current maximum (unique; the reference re-uses the
+     * maximum once per cell, pylamp2.py:621-622). */
+    int    tracdens, tracdens_min;
+    uint64_t inject_seed;
 } pl_step_config;
 
 typedef struct pl_step_report {
@@ -177,7 +184,8 @@ typedef struct pl_step_report {
     double tstep_heat, tstep_stokes;
     pl_solve_stats stokes, heat;
     double ms_props, ms_scatter, ms_stokes, ms_heat, ms_gather, ms_advect, ms_sort, ms_total;
-    int64_t ntrac;
+    int64_t ntrac;                  /* tracers on this rank after the step (incl. injected) */
+    int64_t ninjected;              /* tracers injected on this rank at the end of this step */
 } pl_step_report;
 
 /* Upload tracer state: tr_x (n,2), tr_f (n,13) AoS rows as in pylamp_const.py:29-42. */

@@ -30,7 +30,8 @@ class StepConfig(C.Structure):
                 ("tstep_dif_min", C.c_double), ("tstep_modifier", C.c_double), ("bcstokes", C.c_int * 4),
                 ("bcheat", C.c_int * 4), ("bcheatvals", C.c_double * 4), ("stokes_rtol", C.c_double),
                 ("heat_rtol", C.c_double), ("stokes_maxit", C.c_int), ("heat_maxit", C.c_int),
-                ("length", C.c_double * 2)]
+                ("length", C.c_double * 2), ("tracdens", C.c_int), ("tracdens_min", C.c_int),
+                ("inject_seed", C.c_uint64)]
 
 
 class StepReport(C.Structure):
@@ -38,7 +39,7 @@ class StepReport(C.Structure):
                 ("tstep_stokes", C.c_double), ("stokes", SolveStats), ("heat", SolveStats),
                 ("ms_props", C.c_double), ("ms_scatter", C.c_double), ("ms_stokes", C.c_double),
                 ("ms_heat", C.c_double), ("ms_gather", C.c_double), ("ms_advect", C.c_double),
-                ("ms_sort", C.c_double), ("ms_total", C.c_double), ("ntrac", C.c_int64)]
+                ("ms_sort", C.c_double), ("ms_total", C.c_double), ("ntrac", C.c_int64), ("ninjected", C.c_int64)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/pylamp_hip.h

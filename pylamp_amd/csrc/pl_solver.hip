@@ -592,6 +592,10 @@ struct PlSolver {
     double* hpart = nullptr;    // pinned host copy of the dot partials
     int nu_pre = 2, nu_post = 2, coarse_sweeps = 12;
     bool use_tail = true;
+    // halo policy inside the V-cycle on distributed levels: 2 = exchange before every sweep / residual /
+    // transfer (identical numerics to one rank); 1 = once per level and direction; 0 = none (slab-local
+    // smoothing with frozen zero halos; only the replicated coarse tail couples the slabs)
+    int mg_halo = 2;
     // heat work vectors (1 plane each)
     double* h[9] = {nullptr};
     int napply = 0, nprec = 0;
@@ -604,6 +608,7 @@ static PlSolver* solver_of(pl_ctx* ctx) {
         if (const char* e = getenv("PYLAMP_MG_NU")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b >= 0 && a + b > 0) { S->nu_pre = a; S->nu_post = b; } }
         if (const char* e = getenv("PYLAMP_MG_COARSE")) { int a = atoi(e); if (a > 0) S->coarse_sweeps = a; }
         if (const char* e = getenv("PYLAMP_MG_TAIL")) S->use_tail = atoi(e) != 0;
+        if (const char* e = getenv("PYLAMP_MG_HALO")) S->mg_halo = atoi(e);
         ctx->krylov = S;
     }
     return (PlSolver*)ctx->krylov;
@@ -779,7 +784,7 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
 // ---- smoothing and V-cycle ----------------------------------------------------------------
 // nsweep Chebyshev-Jacobi sweeps on level L; buf[0] is the current iterate on entry and on exit
 static void smooth(pl_ctx* ctx, MgLevel* L, double* buf[3], const double* f, int nsweep, double ratio,
-                   double* final_out = nullptr, bool zero_guess = false) {
+                   double* final_out = nullptr, bool zero_guess = false, int halo = 2) {
     const double lmax = L->lmax, lmin = lmax / ratio;
     const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
     double rho_old = 1.0 / sigma;
@@ -787,7 +792,8 @@ static void smooth(pl_ctx* ctx, MgLevel* L, double* buf[3], const double* f, int
         double c1, c2;
         if (k == 0) { c1 = 0.0; c2 = 1.0 / theta; }
         else { const double rho = 1.0 / (2.0 * sigma - rho_old); c1 = rho * rho_old; c2 = 2.0 * rho / delta; rho_old = rho; }
-        if (L->dist && !(k == 0 && zero_guess)) (void)pl_halo_rows(ctx, L->gh.d, buf[0], 2, L->gh.d.plane);
+        if (L->dist && !(k == 0 && zero_guess) && (halo == 2 || (halo == 1 && k == 0)))
+            (void)pl_halo_rows(ctx, L->gh.d, buf[0], 2, L->gh.d.plane);
         double* dst = (final_out && k == nsweep - 1) ? final_out : buf[2];
         hipLaunchKernelGGL(k_vv_cheb, pl_grid_rows(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, buf[0], buf[1], f, dst, c1, c2,
                            pl_row_iters(L->gh.d));
@@ -830,14 +836,15 @@ static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const double* f, double**
     (void)hipMemsetAsync(buf[0], 0, (size_t)2 * g.plane * sizeof(double), ctx->stream);
     if (l + 1 == S->levels.size()) {
         double ratio = 0.4 * g.nz * g.nx; if (ratio < 30.0) ratio = 30.0;
-        smooth(ctx, L, buf, f, coarsest_sweeps(S, g), ratio, nullptr, true);
+        smooth(ctx, L, buf, f, coarsest_sweeps(S, g), ratio, nullptr, true, S->mg_halo);
         *out = buf[0];
         return;
     }
-    smooth(ctx, L, buf, f, S->nu_pre, 6.0, nullptr, true);
-    if (L->dist) (void)pl_halo_rows(ctx, g, buf[0], 2, g.plane);
+    const int hp = S->mg_halo;
+    smooth(ctx, L, buf, f, S->nu_pre, 6.0, nullptr, true, hp);
+    if (L->dist && hp >= 1) (void)pl_halo_rows(ctx, g, buf[0], 2, g.plane);
     hipLaunchKernelGGL(k_vv_residual, pl_grid_rows(g), dim3(64, 4), 0, ctx->stream, L->op, buf[0], f, L->r, pl_row_iters(g));
-    if (L->dist) (void)pl_halo_rows(ctx, g, L->r, 2, g.plane);
+    if (L->dist && hp >= 1) (void)pl_halo_rows(ctx, g, L->r, 2, g.plane);
     MgLevel* C = S->levels[l + 1];
     if (L->dist && !C->dist) {
         // restrict my rows into the replicated coarse rhs, then all-gather it
@@ -852,10 +859,10 @@ static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const double* f, double**
     }
     double* ec = nullptr;
     vcycle(ctx, S, l + 1, C->f, &ec);
-    if (C->dist) (void)pl_halo_rows(ctx, C->gh.d, ec, 2, C->gh.d.plane);
+    if (C->dist && hp >= 1) (void)pl_halo_rows(ctx, C->gh.d, ec, 2, C->gh.d.plane);
     hipLaunchKernelGGL(k_vv_prolong_add, grid2d(g), dim3(64, 4), 0, ctx->stream, L->op, C->gh.d, ec, buf[0], buf[2]);
     std::swap(buf[0], buf[2]);
-    smooth(ctx, L, buf, f, S->nu_post, 6.0, final_out);
+    smooth(ctx, L, buf, f, S->nu_post, 6.0, final_out, false, hp);
     *out = buf[0];
 }
 

@@ -33,7 +33,10 @@ struct PlStepState {
     int* cell_count = nullptr; int* cell_start = nullptr; int* block_sums = nullptr;
     int ncz = 0, ncx = 0;                            // sort grid (rows incl. the leaver rows of a slab)
     int crow0 = 0;                                   // global cell row of sort row 0
-    int lo_ext = 0, hi_ext = 0;                      // 1: sort row 0 / last row collect tracers leaving to rank-1 / rank+1
+    int lo_ext = 0, hi_ext = 0;
+    bool sorted = false;                             // tracers are cell-sorted and cell_start is valid
+    int* need = nullptr; int* need_off = nullptr;    // injection: per-cell deficit and its exclusive scan
+    double next_id = 0.0;                            // next free TR__ID                      // 1: sort row 0 / last row collect tracers leaving to rank-1 / rank+1
     std::vector<double> gmz, gmx;                    // midpoint grids (pylamp2.py:92-95)
 };
 
@@ -49,7 +52,7 @@ void pl_step_free(pl_ctx* ctx) {
         if (q) (void)hipFree(q);
     for (double* q : s->f) if (q) (void)hipFree(q);
     for (double* q : s->f2) if (q) (void)hipFree(q);
-    for (int* q : {s->cell, s->dest, s->orig, s->orig2, s->cell_count, s->cell_start, s->block_sums}) if (q) (void)hipFree(q);
+    for (int* q : {s->cell, s->dest, s->orig, s->orig2, s->cell_count, s->cell_start, s->block_sums, s->need, s->need_off}) if (q) (void)hipFree(q);
     delete s;
     ctx->step = nullptr;
 }
@@ -146,9 +149,9 @@ __global__ __launch_bounds__(256) void k_cell_place(long long n, const int* __re
     const int c = cell[t];
     dest[t] = start[c] + atomicAdd(&fill[c], 1);
 }
-__global__ __launch_bounds__(256) void k_iota(long long n, int* __restrict__ v) {
+__global__ __launch_bounds__(256) void k_iota(long long n, int* __restrict__ v, int first = 0) {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) v[t] = (int)t;
+    if (t < n) v[t] = (int)t + first;
 }
 __global__ __launch_bounds__(256) void k_permute_int(long long n, const int* __restrict__ dest, const int* __restrict__ in,
                                                      int* __restrict__ out) {
@@ -162,6 +165,54 @@ __global__ __launch_bounds__(256) void k_permute(long long n, const int* __restr
     if (t >= n) return;
     const int d = dest[t];
     for (int k = 0; k < a.na; k++) a.out[k][d] = a.in[k][t];
+}
+
+// ---- census + injection (pylamp2.py:588-633) ---------------------------------------------------
+__global__ __launch_bounds__(256) void k_deficit(int nc, int ncx, int row_lo, int row_hi, const int* __restrict__ start,
+                                                 int dens, int dmin, int* __restrict__ need) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c > nc) return;
+    int v = 0;
+    if (c < nc) {
+        const int row = c / ncx;
+        const int cnt = start[c + 1] - start[c];
+        if (row >= row_lo && row < row_hi && cnt < dmin) v = dens - cnt;
+    }
+    need[c] = v;                                   // need[nc] = 0 so that the scan yields the total
+}
+__device__ inline double inj_uniform(unsigned long long seed, unsigned a, unsigned b, unsigned c) {
+    unsigned long long h = seed ^ (0x9E3779B97F4A7C15ull * (a + 1)) ^ (0xC2B2AE3D27D4EB4Full * (b + 1)) ^ (0x165667B19E3779F9ull * (c + 1));
+    h ^= h >> 33; h *= 0xff51afd7ed558ccdull; h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ull; h ^= h >> 33;
+    return (double)(h >> 11) * (1.0 / 9007199254740992.0);          // [0,1)
+}
+struct InjectArgs {
+    int nc, ncx, crow0; long long n;
+    const int* start; const int* need; const int* off;
+    double* tz; double* tx; double* f[NFTRAC]; double* vtz; double* vtx;
+    double z0, hz, x0, hx; unsigned long long seed; unsigned step; double id0;
+};
+// one thread per deficient cell: field means of the resident tracers, then the new tracers
+__global__ __launch_bounds__(64) void k_inject(InjectArgs a) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= a.nc) return;
+    const int m = a.need[c];
+    if (m <= 0) return;
+    const int t0 = a.start[c], t1 = a.start[c + 1];
+    const int ci = c / a.ncx + a.crow0, cj = c % a.ncx;            // global cell
+    double mean[NFTRAC];
+    for (int k = 0; k < NFTRAC; k++) {
+        double sum = 0.0;
+        for (int t = t0; t < t1; t++) sum += a.f[k][t];
+        mean[k] = sum / (double)(t1 - t0);                          // 0/0 = NaN for an empty cell, like the reference
+    }
+    for (int q = 0; q < m; q++) {
+        const long long d = a.n + a.off[c] + q;
+        a.tz[d] = a.z0 + (ci + inj_uniform(a.seed, (unsigned)c, (unsigned)q, 2 * a.step)) * a.hz;
+        a.tx[d] = a.x0 + (cj + inj_uniform(a.seed, (unsigned)c, (unsigned)q, 2 * a.step + 1)) * a.hx;
+        for (int k = 0; k < NFTRAC; k++) a.f[k][d] = mean[k];
+        a.f[TR__ID][d] = a.id0 + a.off[c] + q;
+        a.vtz[d] = 0.0; a.vtx[d] = 0.0;                             // injected tracers have not been advected yet
+    }
 }
 
 // pylamp2.py:291-303
@@ -312,6 +363,35 @@ static int reduce_minmax(pl_ctx* ctx, PlStepState* S, const PlGeom& g, const dou
     return 0;
 }
 
+// grow every tracer array to hold n tracers, keeping the first `keep` entries
+static int grow_tracers(pl_ctx* ctx, PlStepState* S, long long n, long long keep) {
+    if (n <= S->cap) return 0;
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const long long cap = n + n / 8 + 1024;
+    auto regrow = [&](double** p, bool copy) -> int {
+        double* q = nullptr;
+        PL_HIP(ctx, hipMalloc((void**)&q, (size_t)cap * sizeof(double)));
+        if (copy && *p && keep > 0) PL_HIP(ctx, hipMemcpy(q, *p, (size_t)keep * sizeof(double), hipMemcpyDeviceToDevice));
+        if (*p) (void)hipFree(*p);
+        *p = q;
+        return 0;
+    };
+    PL_TRY(regrow(&S->tz, true)); PL_TRY(regrow(&S->tx, true));
+    for (int k = 0; k < NFTRAC; k++) { PL_TRY(regrow(&S->f[k], true)); PL_TRY(regrow(&S->f2[k], false)); }
+    PL_TRY(regrow(&S->vtz, true)); PL_TRY(regrow(&S->vtx, true));
+    for (double** q : {&S->tz2, &S->tx2, &S->tmp[0], &S->tmp[1], &S->tmp[2]}) PL_TRY(regrow(q, false));
+    for (int** q : {&S->cell, &S->dest, &S->orig2}) {
+        if (*q) (void)hipFree(*q);
+        PL_HIP(ctx, hipMalloc((void**)q, (size_t)cap * sizeof(int)));
+    }
+    { int* q = nullptr; PL_HIP(ctx, hipMalloc((void**)&q, (size_t)cap * sizeof(int)));
+      if (S->orig && keep > 0) PL_HIP(ctx, hipMemcpy(q, S->orig, (size_t)keep * sizeof(int), hipMemcpyDeviceToDevice));
+      if (S->orig) (void)hipFree(S->orig);
+      S->orig = q; }
+    S->cap = cap;
+    return 0;
+}
+
 static int ensure_tracers(pl_ctx* ctx, PlStepState* S, long long n) {
     if (n <= S->cap) return 0;
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -333,6 +413,8 @@ static int ensure_tracers(pl_ctx* ctx, PlStepState* S, long long n) {
 }
 
 static void unpermute(pl_ctx* ctx, PlStepState* S, int na, const double* const* in, double* const* out);
+static int sort_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, double x0, double hx);
+static int migrate_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, double x0, double hx);
 
 extern "C" int pl_tracers_upload(pl_ctx* ctx, int64_t n, const double* tr_x, const double* tr_f) {
     if (n < 0 || !tr_x || !tr_f) return pl_fail(ctx, "pl_tracers_upload: bad argument");
@@ -353,9 +435,21 @@ extern "C" int pl_tracers_upload(pl_ctx* ctx, int64_t n, const double* tr_x, con
         PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     PL_HIP(ctx, hipGetLastError());
-    if (n > 0) hipLaunchKernelGGL(k_iota, grid1d(n), dim3(256), 0, ctx->stream, (long long)n, S->orig);
+    if (n > 0) hipLaunchKernelGGL(k_iota, grid1d(n), dim3(256), 0, ctx->stream, (long long)n, S->orig, 0);
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     S->n = n; S->have_newtemp = false; S->have_solution = false;
+    double idmax[1] = {-1.0};
+    for (int64_t t = 0; t < n; t++) if (tr_f[NFTRAC * t + TR__ID] > idmax[0]) idmax[0] = tr_f[NFTRAC * t + TR__ID];
+    PL_TRY(pl_allreduce_host(ctx, idmax, 1, 2));
+    S->next_id = idmax[0] + 1.0;
+    // cell-sort (and, on a slab, hand over anything that does not belong here)
+    const int nz = ctx->nz, nx = ctx->nx;
+    const double z0 = ctx->geom.zc[0], x0 = ctx->geom.xc[0];
+    const double hz = (ctx->geom.zc[nz - 1] - z0) / (nz - 1), hx = (ctx->geom.xc[nx - 1] - x0) / (nx - 1);
+    PL_TRY(sort_tracers(ctx, S, z0, hz, x0, hx));
+    PL_TRY(migrate_tracers(ctx, S, z0, hz, x0, hx));
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    S->sorted = true;
     return 0;
 }
 
@@ -402,12 +496,12 @@ extern "C" int pl_get_tracer_velocity(pl_ctx* ctx, int64_t n, double* out) {
     const long long chunk = 1 << 22;
     PL_TRY(pl_stage(ctx, (size_t)chunk * 2 * sizeof(double)));
     {
-        const double* in[2] = {S->vtz, S->vtx}; double* out[2] = {S->tmp[0], S->tmp[1]};
+        const double* in[2] = {S->vtz, S->vtx}; double* out[2] = {S->tz2, S->tx2};
         unpermute(ctx, S, 2, in, out);
     }
     for (long long t0 = 0; t0 < n; t0 += chunk) {
         long long m = std::min<long long>(chunk, n - t0);
-        hipLaunchKernelGGL(k_aos2_from_soa, grid1d(m), dim3(256), 0, ctx->stream, m, S->tmp[0] + t0, S->tmp[1] + t0, ctx->stage);
+        hipLaunchKernelGGL(k_aos2_from_soa, grid1d(m), dim3(256), 0, ctx->stream, m, S->tz2 + t0, S->tx2 + t0, ctx->stage);
         PL_HIP(ctx, hipMemcpyAsync(out + 2 * t0, ctx->stage, (size_t)m * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
@@ -445,16 +539,19 @@ static int sort_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, doubl
     if (n > 0) {
         hipLaunchKernelGGL(k_cell_place, grid1d(n), dim3(256), 0, ctx->stream, n, S->cell, S->cell_start, S->cell_count, S->dest);
         // permute positions and the 13 fields
-        const double* src[15]; double* dst[15];
+        // positions, the 13 fields and the velocities of the last advection travel together
+        const double* src[17]; double* dst[17];
         src[0] = S->tz; dst[0] = S->tz2; src[1] = S->tx; dst[1] = S->tx2;
         for (int k = 0; k < NFTRAC; k++) { src[2 + k] = S->f[k]; dst[2 + k] = S->f2[k]; }
-        for (int k0 = 0; k0 < 15; k0 += 5) {
-            PermArgs pa{}; pa.na = 5;
-            for (int k = 0; k < 5; k++) { pa.in[k] = src[k0 + k]; pa.out[k] = dst[k0 + k]; }
+        src[15] = S->vtz; dst[15] = S->tmp[0]; src[16] = S->vtx; dst[16] = S->tmp[1];
+        for (int k0 = 0; k0 < 17; k0 += 5) {
+            PermArgs pa{}; pa.na = std::min(5, 17 - k0);
+            for (int k = 0; k < pa.na; k++) { pa.in[k] = src[k0 + k]; pa.out[k] = dst[k0 + k]; }
             hipLaunchKernelGGL(k_permute, grid1d(n), dim3(256), 0, ctx->stream, n, S->dest, pa);
         }
         hipLaunchKernelGGL(k_permute_int, grid1d(n), dim3(256), 0, ctx->stream, n, S->dest, S->orig, S->orig2);
         std::swap(S->tz, S->tz2); std::swap(S->tx, S->tx2); std::swap(S->orig, S->orig2);
+        std::swap(S->vtz, S->tmp[0]); std::swap(S->vtx, S->tmp[1]);
         for (int k = 0; k < NFTRAC; k++) std::swap(S->f[k], S->f2[k]);
     }
     PL_HIP(ctx, hipGetLastError());
@@ -473,20 +570,23 @@ static int migrate_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, do
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const long long n = S->n;
     const long long n_lo = S->lo_ext ? h[0] : 0, hi_begin = S->hi_ext ? h[1] : n, n_hi = n - hi_begin, stay = hi_begin - n_lo;
-    double* cols[15]; double* spare[15];
+    const int NC = 17;
+    double* cols[NC]; double* spare[NC];
     cols[0] = S->tz; cols[1] = S->tx; spare[0] = S->tz2; spare[1] = S->tx2;
     for (int k = 0; k < NFTRAC; k++) { cols[2 + k] = S->f[k]; spare[2 + k] = S->f2[k]; }
-    double *slo[15], *shi[15], *rcv[15];
-    for (int k = 0; k < 15; k++) {
+    cols[15] = S->vtz; spare[15] = S->tmp[0]; cols[16] = S->vtx; spare[16] = S->tmp[1];
+    double *slo[NC], *shi[NC], *rcv[NC];
+    for (int k = 0; k < NC; k++) {
         // stayers first into the spare buffers, arrivals appended behind them
         PL_HIP(ctx, hipMemcpyAsync(spare[k], cols[k] + n_lo, (size_t)stay * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
         slo[k] = cols[k]; shi[k] = cols[k] + hi_begin; rcv[k] = spare[k] + stay;
     }
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     int64_t got = 0;
-    if (ctx->comm.exchange_var(ctx->comm.user, slo, n_lo, shi, n_hi, rcv, S->cap - stay, 15, &got))
+    if (ctx->comm.exchange_var(ctx->comm.user, slo, n_lo, shi, n_hi, rcv, S->cap - stay, NC, &got))
         return pl_fail(ctx, "communication callback 'exchange_var' failed (tracer migration)");
     std::swap(S->tz, S->tz2); std::swap(S->tx, S->tx2);
+    std::swap(S->vtz, S->tmp[0]); std::swap(S->vtx, S->tmp[1]);
     for (int k = 0; k < NFTRAC; k++) std::swap(S->f[k], S->f2[k]);
     S->n = stay + got;
     if (S->n > 0) hipLaunchKernelGGL(k_iota, grid1d(S->n), dim3(256), 0, ctx->stream, S->n, S->orig);
@@ -500,6 +600,47 @@ static void unpermute(pl_ctx* ctx, PlStepState* S, int na, const double* const* 
         for (int k = 0; k < pa.na; k++) { pa.in[k] = in[k0 + k]; pa.out[k] = out[k0 + k]; }
         hipLaunchKernelGGL(k_permute, grid1d(S->n), dim3(256), 0, ctx->stream, S->n, S->orig, pa);
     }
+}
+
+// census of the sorted tracers and refill of depleted cells (end of step; pylamp2.py:588-633)
+static int inject_tracers(pl_ctx* ctx, PlStepState* S, const pl_step_config* cfg, int it, double z0, double hz, double x0,
+                          double hx, int64_t* ninj) {
+    *ninj = 0;
+    const int nc = S->ncz * S->ncx;
+    if (!S->need) {
+        PL_HIP(ctx, hipMalloc((void**)&S->need, (size_t)(nc + 1) * sizeof(int)));
+        PL_HIP(ctx, hipMalloc((void**)&S->need_off, (size_t)(nc + 1) * sizeof(int)));
+    }
+    const int m1 = nc + 1, nb = (m1 + 1023) / 1024;
+    hipLaunchKernelGGL(k_deficit, dim3((m1 + 255) / 256), dim3(256), 0, ctx->stream, nc, S->ncx, S->lo_ext, S->ncz - S->hi_ext,
+                       S->cell_start, cfg->tracdens, cfg->tracdens_min, S->need);
+    hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(256), 0, ctx->stream, m1, S->need, S->need_off, S->block_sums);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, ctx->stream, nb, S->block_sums);
+    hipLaunchKernelGGL(k_scan_add, dim3((m1 + 255) / 256), dim3(256), 0, ctx->stream, m1, S->need_off, S->block_sums, 0);
+    int m = 0;
+    PL_HIP(ctx, hipMemcpyAsync(&m, S->need_off + nc, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // globally unique new IDs: rank r takes the block after the ranks before it
+    std::vector<double> cnt((size_t)ctx->nranks, 0.0);
+    cnt[ctx->rank] = m;
+    PL_TRY(pl_allreduce_host(ctx, cnt.data(), (long long)cnt.size(), 0));
+    double before = 0.0, total = 0.0;
+    for (int q = 0; q < ctx->nranks; q++) { if (q < ctx->rank) before += cnt[q]; total += cnt[q]; }
+    const double id0 = S->next_id + before;
+    S->next_id += total;
+    if (m == 0) return 0;
+    PL_TRY(grow_tracers(ctx, S, S->n + m, S->n));
+    InjectArgs a{};
+    a.nc = nc; a.ncx = S->ncx; a.crow0 = S->crow0; a.n = S->n; a.start = S->cell_start; a.need = S->need; a.off = S->need_off;
+    a.tz = S->tz; a.tx = S->tx; for (int k = 0; k < NFTRAC; k++) a.f[k] = S->f[k];
+    a.vtz = S->vtz; a.vtx = S->vtx;
+    a.z0 = z0; a.hz = hz; a.x0 = x0; a.hx = hx; a.seed = cfg->inject_seed; a.step = (unsigned)it; a.id0 = id0;
+    hipLaunchKernelGGL(k_inject, dim3((nc + 63) / 64), dim3(64), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_iota, grid1d(m), dim3(256), 0, ctx->stream, (long long)m, S->orig + S->n, (int)S->n);
+    PL_HIP(ctx, hipGetLastError());
+    S->n += m;
+    *ninj = m;
+    return sort_tracers(ctx, S, z0, hz, x0, hx);
 }
 
 static double now_ms() {
@@ -545,14 +686,9 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
     PL_TRY(pl_buf(ctx, "temp", pb, &p_newT)); PL_TRY(pl_buf(ctx, "heat_c", pb, &p_c)); PL_TRY(pl_buf(ctx, "sgc", pb, &p_sgc));
     PL_TRY(pl_buf(ctx, "dT", pb, &p_dT));
 
-    // ---- 0. cell sort (keeps scatter windows and gathers local) -----------------------------
-    t0 = now_ms();
-    PL_TRY(sort_tracers(ctx, S, z0, hz, x0, hx));
-    PL_TRY(migrate_tracers(ctx, S, z0, hz, x0, hx));
-    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    rep->ms_sort = now_ms() - t0;
+    // tracers arrive cell-sorted (pl_tracers_upload / end of the previous step)
+    if (!S->sorted) return pl_fail(ctx, "pl_step: tracers are not sorted (internal error)");
     const long long n = S->n;
-    rep->ntrac = n;
 
     // ---- 1. tracer properties --------------------------------------------------------------
     t0 = now_ms();
@@ -780,6 +916,17 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
     std::swap(S->tz, S->tz2); std::swap(S->tx, S->tx2);
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     rep->ms_advect = now_ms() - t0;
+
+    // ---- 7. cell sort of the advected tracers, slab migration, census + injection --------------------
+    t0 = now_ms();
+    S->sorted = false;
+    PL_TRY(sort_tracers(ctx, S, z0, hz, x0, hx));
+    PL_TRY(migrate_tracers(ctx, S, z0, hz, x0, hx));
+    if (cfg->tracdens_min > 0 && cfg->tracdens > 0) PL_TRY(inject_tracers(ctx, S, cfg, it, z0, hz, x0, hx, &rep->ninjected));
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    S->sorted = true;
+    rep->ms_sort = now_ms() - t0;
+    rep->ntrac = S->n;
     rep->ms_total = now_ms() - t_all;
     return 0;
 }

@@ -36,6 +36,7 @@ class Options:
         self.bcheatvals = [273.0, 0.0, 1623.0, 0.0]
         self.stokes_rtol, self.stokes_maxit = 1e-10, 400
         self.heat_rtol, self.heat_maxit = 1e-12, 2000
+        self.tracdens, self.tracdens_min, self.inject_seed = 0, 0, 12345     # pylamp2.py:39-40; 0 = no injection
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise Exception("unknown option " + k)
@@ -163,6 +164,7 @@ class Simulation:
         c.stokes_rtol, c.heat_rtol = o.stokes_rtol, o.heat_rtol
         c.stokes_maxit, c.heat_maxit = int(o.stokes_maxit), int(o.heat_maxit)
         c.length[0], c.length[1] = self.L
+        c.tracdens, c.tracdens_min, c.inject_seed = int(o.tracdens), int(o.tracdens_min), int(o.inject_seed)
         return c
 
     def step(self):

@@ -66,3 +66,53 @@ def test_step_vs_oracle_midsize(oracle):
         X, F = sim.tracers()
         assert relerr(X, st["tr_x"]) < 1e-7 and relerr(F[:, 3], st["tr_f"][:, 3]) < 1e-6
     sim.close()
+
+
+def test_census_and_injection():
+    """Cells that fall below tracdens_min are refilled to tracdens with tracers carrying the cell
+    mean of every field (pylamp2.py:588-633); IDs stay unique; nothing else is touched."""
+    from pylamp_amd import driver
+    nx = [41, 41]; L = [660e3, 660e3]
+    rng = np.random.default_rng(21)
+    tr_x, tr_f = driver.falling_block_tracers(nx, L, 8, rng)
+    h = L[0] / 40
+    # deplete a patch of cells: keep at most one tracer per cell there
+    ci = np.floor(tr_x[:, 0] / h).astype(int); cj = np.floor(tr_x[:, 1] / h).astype(int)
+    patch = (ci >= 5) & (ci < 12) & (cj >= 20) & (cj < 30)
+    key = ci * 40 + cj
+    first = np.zeros(tr_x.shape[0], bool)
+    _, idx = np.unique(key[patch], return_index=True)
+    first[np.nonzero(patch)[0][idx]] = True
+    keep = ~patch | first
+    tr_x, tr_f = tr_x[keep], tr_f[keep]
+    n0 = tr_x.shape[0]
+    opt = driver.Options(do_heatdiff=False, tdep_rho=False, tdep_eta=False, tracdens=8, tracdens_min=3)
+    sim = driver.Simulation(nx, L, tr_x, tr_f, opt)
+    rep = sim.step()
+    assert rep["ninjected"] > 0 and rep["ntrac"] == n0 + rep["ninjected"]
+    X, F = sim.tracers()
+    assert X.shape[0] == rep["ntrac"]
+    old, new = slice(0, n0), slice(n0, None)               # injected tracers are appended
+    assert np.array_equal(F[old, 12], tr_f[:, 12])          # resident tracers keep order and identity
+    ids = F[:, 12]
+    assert np.unique(ids).size == ids.size and ids[new].min() > tr_f[:, 12].max()
+    ci = np.clip(np.floor(X[:, 0] / h).astype(int), 0, 39); cj = np.clip(np.floor(X[:, 1] / h).astype(int), 0, 39)
+    cnt_all = np.bincount(ci * 40 + cj, minlength=1600)
+    cnt_old = np.bincount(ci[old] * 40 + cj[old], minlength=1600)
+    deficient = cnt_old < 3
+    assert deficient.any()
+    assert np.all(cnt_all[deficient] == 8) and np.array_equal(cnt_all[~deficient], cnt_old[~deficient])
+    # fields of the new tracers = plain mean of the resident tracers of their cell
+    knew = ci[new] * 40 + cj[new]
+    for col in (6, 10, 8):                                   # RH0, ET0, MAT
+        s = np.bincount(ci[old] * 40 + cj[old], weights=F[old, col], minlength=1600)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            mean = s / cnt_old
+        got = F[new, col]
+        exp = mean[knew]
+        ok = ~np.isnan(exp)
+        assert np.allclose(got[ok], exp[ok], rtol=1e-13) and np.isnan(got[~ok]).all()
+    # a second step runs on the refilled set
+    rep2 = sim.step()
+    assert rep2["stokes"]["converged"] == 1
+    sim.close()
