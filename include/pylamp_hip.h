@@ -176,16 +176,22 @@ typedef struct pl_step_config {
      * maximum once per cell, pylamp2.py:621-622). */
     int    tracdens, tracdens_min;
     uint64_t inject_seed;
+    /* Free-surface stabilisation (pylamp2.py:71-73,352-355,368-372,387-405): with
+     * surfstab_tstep < 0 the Stokes system is re-assembled with the chosen time step and re-solved
+     * until the step no longer shrinks (limiter 's' = the reference's "Ss"). */
+    int    surface_stabilization;
+    double surfstab_theta, surfstab_tstep;
 } pl_step_config;
 
 typedef struct pl_step_report {
     double tstep;                   /* chosen time step (pylamp2.py:374-385) */
-    int    limiter;                 /* 'H' or 'S' */
+    int    limiter;                 /* 'H', 'S' or 's' (= "Ss") */
     double tstep_heat, tstep_stokes;
     pl_solve_stats stokes, heat;
     double ms_props, ms_scatter, ms_stokes, ms_heat, ms_gather, ms_advect, ms_sort, ms_total;
     int64_t ntrac;                  /* tracers on this rank after the step (incl. injected) */
     int64_t ninjected;              /* tracers injected on this rank at the end of this step */
+    int     stokes_resolves;        /* extra Stokes solves of the surface-stabilisation loop */
 } pl_step_report;
 
 /* Upload tracer state: tr_x (n,2), tr_f (n,13) AoS rows as in pylamp_const.py:29-42. */

@@ -357,11 +357,26 @@ def gen_trajectories():
         bcset], 3, 12)
 
 
+def gen_trajectory_surfstab():
+    bcset = ("    bcheat = [[]] * 4\n",
+             "    bcheat = [[]] * 4\n    bcstokes = [1, 1, 1, 1]\n")
+    # model 3 (rising block under a sticky-air layer), dynamic surfstab time step (pylamp2.py:387-405)
+    run_driver("surfstab41", [
+        ("nx    =   [200+1,40+1]", "nx    =   [41,41]"),
+        ("L     =   [1, 0.2] ", "L     =   [660e3, 660e3] "),
+        ("tracdens = 45 ", "tracdens = 6 "),
+        ("tracdens_min = 25 ", "tracdens_min = 0 "),
+        ("choose_model = 5", "choose_model = 3"),
+        ("surface_stabilization = False", "surface_stabilization = True"),
+        bcset], 3, 13)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["op", "solve", "heat", "t2g", "g2t", "traj"]
+    which = sys.argv[1:] or ["op", "solve", "heat", "t2g", "g2t", "traj", "surfstab"]
     if "op" in which: gen_stokes_operator()
     if "solve" in which: gen_stokes_solve()
     if "heat" in which: gen_heat()
     if "t2g" in which: gen_trac2grid()
     if "g2t" in which: gen_grid2trac_rk()
     if "traj" in which: gen_trajectories()
+    if "surfstab" in which: gen_trajectory_surfstab()

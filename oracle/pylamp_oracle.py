@@ -678,6 +678,7 @@ class StepConfig:
         self.bcstokes = [1, 1, 1, 1]
         self.bcheat = [BC_FIXTEMP, BC_FIXFLOW, BC_FIXTEMP, BC_FIXFLOW]
         self.bcheatvals = [273.0, 0.0, 1623.0, 0.0]
+        self.surface_stabilization = False; self.surfstab_theta = 0.5; self.surfstab_tstep = -1
         self.__dict__.update(kw)
 
 
@@ -711,15 +712,35 @@ def step(state, cfg, it):
         f_rho, f_etas = trac2grid(tr_x, tr_f[:, [TR_RHO, TR_ETA]], grid, nx, [AVG_ARITHW, AVG_GEOMW])
         f_etan, = trac2grid(tr_x, tr_f[:, [TR_ETA]], gridmp, nx, [AVG_GEOM])
 
-    xsol = stokes_solve(nx, grid, f_etas, f_etan, f_rho, cfg.bcstokes)
+    ss = cfg.surface_stabilization
+    if (not ss) or cfg.surfstab_tstep < 0:                       # pylamp2.py:352-355
+        xsol = stokes_solve(nx, grid, f_etas, f_etan, f_rho, cfg.bcstokes)
+    else:
+        xsol = stokes_solve(nx, grid, f_etas, f_etan, f_rho, cfg.bcstokes, surfstab=True,
+                            tstep=cfg.surfstab_tstep, theta=cfg.surfstab_theta)
     newvel, newpres = x2vp(xsol, nx)
     tstep_stokes = cfg.tstep_modifier * np.min(dx) / np.max(newvel)
     tstep_stokes = max(min(tstep_stokes, cfg.tstep_adv_max), cfg.tstep_adv_min)
+    if cfg.surfstab_tstep > 0:                                   # pylamp2.py:368-372
+        tstep_stokes = cfg.surfstab_tstep
     if cfg.do_heatdiff:
         limiter = "H" if tstep_temp < tstep_stokes else "S"
         tstep = min(tstep_temp, tstep_stokes)
     else:
         tstep, limiter = tstep_stokes, "S"
+    nresolve = 0
+    if ss and cfg.surfstab_tstep < 0:                            # pylamp2.py:387-405
+        while True:
+            xsol = stokes_solve(nx, grid, f_etas, f_etan, f_rho, cfg.bcstokes, surfstab=True, tstep=tstep,
+                                theta=cfg.surfstab_theta)
+            newvel, newpres = x2vp(xsol, nx)
+            nresolve += 1
+            check = cfg.tstep_modifier * np.min(dx) / np.max(newvel)
+            if check < tstep:
+                tstep = check; limiter = "Ss"
+            else:
+                break
+    out['nresolve'] = nresolve
     out.update(velz=newvel[IZ], velx=newvel[IX], pres=newpres, rho=f_rho, etas=f_etas,
                etan=f_etan, tstep=tstep, limiter=limiter)
 

@@ -31,7 +31,8 @@ class StepConfig(C.Structure):
                 ("bcheat", C.c_int * 4), ("bcheatvals", C.c_double * 4), ("stokes_rtol", C.c_double),
                 ("heat_rtol", C.c_double), ("stokes_maxit", C.c_int), ("heat_maxit", C.c_int),
                 ("length", C.c_double * 2), ("tracdens", C.c_int), ("tracdens_min", C.c_int),
-                ("inject_seed", C.c_uint64)]
+                ("inject_seed", C.c_uint64), ("surface_stabilization", C.c_int), ("surfstab_theta", C.c_double),
+                ("surfstab_tstep", C.c_double)]
 
 
 class StepReport(C.Structure):
@@ -39,7 +40,8 @@ class StepReport(C.Structure):
                 ("tstep_stokes", C.c_double), ("stokes", SolveStats), ("heat", SolveStats),
                 ("ms_props", C.c_double), ("ms_scatter", C.c_double), ("ms_stokes", C.c_double),
                 ("ms_heat", C.c_double), ("ms_gather", C.c_double), ("ms_advect", C.c_double),
-                ("ms_sort", C.c_double), ("ms_total", C.c_double), ("ntrac", C.c_int64), ("ninjected", C.c_int64)]
+                ("ms_sort", C.c_double), ("ms_total", C.c_double), ("ntrac", C.c_int64), ("ninjected", C.c_int64),
+                ("stokes_resolves", C.c_int)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/pylamp_hip.h

@@ -745,7 +745,9 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
     if (nen) men = std::numeric_limits<double>::quiet_NaN();
     double Kc, Kb;
     pl_stokes_scaling_host(ctx->geom, mes, men, &Kc, &Kb);
-    pl_stokes_fill_op(ctx, p_etas, p_etan, p_rho, cfg->bcstokes, 0, 0.0, 0.5, Kc, Kb);
+    const bool ss = cfg->surface_stabilization != 0;
+    if (!ss || cfg->surfstab_tstep < 0) pl_stokes_fill_op(ctx, p_etas, p_etan, p_rho, cfg->bcstokes, 0, 0.0, 0.5, Kc, Kb);
+    else pl_stokes_fill_op(ctx, p_etas, p_etan, p_rho, cfg->bcstokes, 1, cfg->surfstab_tstep, cfg->surfstab_theta, Kc, Kb);
     double* b = pl_stokes_rhs_buffer_device(ctx);
     if (!b) return 1;
     pl_launch_stokes_rhs(ctx, ctx->sop, b);
@@ -761,12 +763,32 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
     double tstep_stokes = cfg->tstep_modifier * std::fmin(dz, dx) / vmax;
     tstep_stokes = (cfg->tstep_adv_max < tstep_stokes) ? cfg->tstep_adv_max : tstep_stokes;
     tstep_stokes = (cfg->tstep_adv_min > tstep_stokes) ? cfg->tstep_adv_min : tstep_stokes;
-    rep->ms_stokes = now_ms() - t0;
+    if (cfg->surfstab_tstep > 0) tstep_stokes = cfg->surfstab_tstep;          // pylamp2.py:368-372
     double tstep; int limiter;
     if (cfg->do_heatdiff) {
         limiter = (tstep_temp < tstep_stokes) ? 'H' : 'S';
         tstep = (tstep_stokes < tstep_temp) ? tstep_stokes : tstep_temp;
     } else { tstep = tstep_stokes; limiter = 'S'; }
+    if (ss && cfg->surfstab_tstep < 0) {
+        // re-assemble with the chosen step and re-solve until the step stops shrinking (pylamp2.py:387-405)
+        for (int guard = 0; guard < 50; guard++) {
+            pl_stokes_fill_op(ctx, p_etas, p_etan, p_rho, cfg->bcstokes, 1, tstep, cfg->surfstab_theta, Kc, Kb);
+            pl_launch_stokes_rhs(ctx, ctx->sop, b);
+            pl_solve_stats st2{};
+            PL_TRY(pl_stokes_solve_device(ctx, b, true, cfg->stokes_rtol > 0 ? cfg->stokes_rtol : 1e-10,
+                                          cfg->stokes_maxit > 0 ? cfg->stokes_maxit : 400, &st2));
+            rep->stokes_resolves++;
+            rep->stokes.iterations += st2.iterations; rep->stokes.converged &= st2.converged;
+            rep->stokes.rel_residual = st2.rel_residual; rep->stokes.solve_ms += st2.solve_ms;
+            rep->stokes.operator_applies += st2.operator_applies; rep->stokes.precond_applies += st2.precond_applies;
+            PL_TRY(reduce_minmax(ctx, S, g, p_vz, nullptr, nullptr, 0, &mn, &vmax_z, &hn));
+            PL_TRY(reduce_minmax(ctx, S, g, p_vx, nullptr, nullptr, 0, &mn, &vmax_x, &hn));
+            const double check = cfg->tstep_modifier * std::fmin(dz, dx) / std::fmax(vmax_z, vmax_x);
+            if (check < tstep) { tstep = check; limiter = 's'; }
+            else break;
+        }
+    }
+    rep->ms_stokes = now_ms() - t0;
     rep->tstep = tstep; rep->limiter = limiter; rep->tstep_heat = tstep_temp; rep->tstep_stokes = tstep_stokes;
 
     // ---- 5. heat (pylamp2.py:412-480) ----------------------------------------------------------------

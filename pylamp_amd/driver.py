@@ -37,6 +37,7 @@ class Options:
         self.stokes_rtol, self.stokes_maxit = 1e-10, 400
         self.heat_rtol, self.heat_maxit = 1e-12, 2000
         self.tracdens, self.tracdens_min, self.inject_seed = 0, 0, 12345     # pylamp2.py:39-40; 0 = no injection
+        self.surface_stabilization, self.surfstab_theta, self.surfstab_tstep = False, 0.5, -1.0   # pylamp2.py:71-73
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise Exception("unknown option " + k)
@@ -165,6 +166,8 @@ class Simulation:
         c.stokes_maxit, c.heat_maxit = int(o.stokes_maxit), int(o.heat_maxit)
         c.length[0], c.length[1] = self.L
         c.tracdens, c.tracdens_min, c.inject_seed = int(o.tracdens), int(o.tracdens_min), int(o.inject_seed)
+        c.surface_stabilization = int(bool(o.surface_stabilization))
+        c.surfstab_theta, c.surfstab_tstep = float(o.surfstab_theta), float(o.surfstab_tstep)
         return c
 
     def step(self):
@@ -177,7 +180,7 @@ class Simulation:
         self.totaltime += rep.tstep
         self.ntrac = rep.ntrac
         out = {k: getattr(rep, k) for k, _ in rep._fields_ if k not in ("stokes", "heat", "limiter")}
-        out["limiter"] = chr(rep.limiter)
+        out["limiter"] = "Ss" if chr(rep.limiter) == "s" else chr(rep.limiter)
         out["stokes"] = rep.stokes.as_dict(); out["heat"] = rep.heat.as_dict()
         out["it"] = self.it; out["time"] = self.totaltime
         self.last = out

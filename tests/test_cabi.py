@@ -31,7 +31,8 @@ def test_struct_layouts_match_header():
     from pylamp_amd import _lib
     # pl_solve_stats: int,int,double,double,int,int -> 32 bytes
     assert C.sizeof(_lib.SolveStats) == 32
-    assert _lib.StepConfig.inject_seed.offset == C.sizeof(_lib.StepConfig) - 8
+    assert _lib.StepConfig.surfstab_tstep.offset == C.sizeof(_lib.StepConfig) - 8
+    assert _lib.StepConfig.inject_seed.offset == _lib.StepConfig.surface_stabilization.offset - 8
     assert _lib.StepConfig.length.offset == _lib.StepConfig.tracdens.offset - 16
 
 

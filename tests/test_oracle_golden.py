@@ -179,3 +179,22 @@ def test_trajectory(oracle, name, heat, model):
         if heat:
             assert relerr(out["temp"], g[p + "temp"]) < 1e-10
             assert relerr(st["tr_f"][:, oracle.TR_TMP], g[p + "tr_T"]) < 1e-10
+
+
+def test_trajectory_surface_stabilisation(oracle):
+    """Model 3 (rising block under sticky air) with the dynamic surfstab re-solve loop
+    (pylamp2.py:387-405) vs the stock driver."""
+    g = golden("traj_surfstab41")
+    gz, gx = g["gz"], g["gx"]
+    nx = [gz.size, gx.size]; L = [gz[-1], gx[-1]]
+    st = dict(nx=nx, L=L, grid=[gz, gx], tr_x=g["init_tr_x"].copy(), tr_f=g["init_tr_f"].copy())
+    cfg = oracle.StepConfig(do_heatdiff=False, tdep_rho=False, tdep_eta=False, surface_stabilization=True)
+    ttot = 0.0
+    for it in range(1, int(g["nsteps"]) + 1):
+        out = oracle.step(st, cfg, it)
+        ttot += out["tstep"]
+        p = "s%d_" % it
+        assert out["nresolve"] >= 1
+        assert relerr(out["velz"], g[p + "velz"]) < 1e-7 and relerr(out["velx"], g[p + "velx"]) < 1e-7
+        assert abs(ttot - float(g[p + "time"])) < 1e-8 * ttot
+        assert relerr(st["tr_x"], g[p + "tr_x"]) < 1e-10
