@@ -86,6 +86,10 @@ typedef struct pl_comm_ops {
 } pl_comm_ops;
 int  pl_set_comm(pl_ctx* ctx, int rank, int nranks, const pl_comm_ops* ops);   /* right after pl_create */
 int  pl_local_rows(pl_ctx* ctx, int* first_row, int* n_rows);
+/* *native = 1 when halo exchange / all-gather run as direct RCCL calls on the context stream
+ * (dlopen'ed librccl, self-tested at pl_set_comm), 0 when they go through the callback table.
+ * PYLAMP_RCCL=0 disables the native path. */
+int  pl_comm_info(pl_ctx* ctx, int* rank, int* nranks, int* native);
 /* raw copies between host and this context's device memory (used by the gloo fallback of the
  * communication layer, which stages through host buffers) */
 int  pl_memcpy_d2h(pl_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);

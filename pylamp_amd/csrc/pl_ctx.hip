@@ -1,6 +1,7 @@
 // Context, memory, geometry tables and host<->device layout conversion.
 #include "pl_internal.h"
 #include <cmath>
+#include <cstdlib>
 
 thread_local std::string pl_tls_error;
 
@@ -86,17 +87,13 @@ void pl_geom_set_rows(PlGeomHost& gh, int gi0, int lnz) {
 
 int pl_halo_rows(pl_ctx* ctx, const PlGeom& g, double* planes, int nplanes, long long plane_stride, bool add) {
     if (ctx->nranks <= 1) return 0;
-    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const long long p = g.pitch;
-    int rc;
     if (!add)   // forward: my first/last owned rows -> neighbours' ring rows
-        rc = ctx->comm.exchange(ctx->comm.user, planes + p, planes, planes + (long long)g.lnz * p,
-                                planes + (long long)(g.lnz + 1) * p, p, nplanes, plane_stride, 0);
-    else        // reverse: my ring rows are added to the neighbours' owned boundary rows
-        rc = ctx->comm.exchange(ctx->comm.user, planes, planes + p, planes + (long long)(g.lnz + 1) * p,
-                                planes + (long long)g.lnz * p, p, nplanes, plane_stride, 1);
-    if (rc) return pl_fail(ctx, "communication callback 'exchange' failed");
-    return 0;
+        return pl_comm_exchange(ctx, planes + p, planes, planes + (long long)g.lnz * p, planes + (long long)(g.lnz + 1) * p,
+                                p, nplanes, plane_stride, 0);
+    // reverse: my ring rows are added to the neighbours' owned boundary rows
+    return pl_comm_exchange(ctx, planes, planes + p, planes + (long long)(g.lnz + 1) * p, planes + (long long)g.lnz * p, p,
+                            nplanes, plane_stride, 1);
 }
 
 int pl_allreduce_host(pl_ctx* ctx, double* buf, long long n, int op) {
@@ -108,7 +105,11 @@ int pl_allreduce_host(pl_ctx* ctx, double* buf, long long n, int op) {
 extern "C" int pl_set_comm(pl_ctx* ctx, int rank, int nranks, const pl_comm_ops* ops) {
     if (!ops || nranks < 1 || rank < 0 || rank >= nranks) return pl_fail(ctx, "pl_set_comm: bad argument");
     if (!ctx->bufs.empty() || ctx->krylov || ctx->step) return pl_fail(ctx, "pl_set_comm must be called right after pl_create");
-    if (nranks == 1) { ctx->rank = 0; ctx->nranks = 1; return 0; }
+    if (nranks == 1) {
+        ctx->rank = 0; ctx->nranks = 1;
+        if (getenv("PYLAMP_RCCL_SELFTEST")) return pl_comm_native_init(ctx);   // single-rank API check (tests)
+        return 0;
+    }
     if (!ops->exchange || !ops->allreduce_host || !ops->allgather || !ops->exchange_var)
         return pl_fail(ctx, "pl_set_comm: incomplete callback table");
     const int cells = ctx->nz - 1;
@@ -117,6 +118,13 @@ extern "C" int pl_set_comm(pl_ctx* ctx, int rank, int nranks, const pl_comm_ops*
     if (C < 8 || (C % 2)) return pl_fail(ctx, "pl_set_comm: need an even number (>= 8) of node rows per rank");
     ctx->rank = rank; ctx->nranks = nranks; ctx->comm = *ops;
     pl_geom_set_rows(ctx->geom, rank * C, (rank == nranks - 1) ? C + 1 : C);
+    return pl_comm_native_init(ctx);      // RCCL directly on the context stream when every rank can
+}
+
+extern "C" int pl_comm_info(pl_ctx* ctx, int* rank, int* nranks, int* native) {
+    if (rank) *rank = ctx->rank;
+    if (nranks) *nranks = ctx->nranks;
+    if (native) *native = pl_comm_native_enabled(ctx);
     return 0;
 }
 
@@ -183,6 +191,7 @@ extern "C" void pl_destroy(pl_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    pl_comm_native_free(ctx);
     pl_step_free(ctx);
     pl_mic_free(ctx);
     pl_solver_free(ctx);

@@ -79,6 +79,7 @@ struct pl_ctx {
     // multi-GPU (row slabs): rank r owns node rows [row0, row0 + geom.d.lnz)
     int rank = 0, nranks = 1;
     pl_comm_ops comm{};
+    void* nccl = nullptr;     // pl_comm.hip: native RCCL transport (optional)
     // opaque extension slots owned by other translation units
     void* krylov = nullptr;   // pl_solver.hip
     void* mic = nullptr;      // pl_mic.hip
@@ -124,6 +125,16 @@ void pl_geom_set_rows(PlGeomHost& gh, int gi0, int lnz);
 // halo exchange of the ring rows of nplanes planes (no-op on one rank); add: reverse (accumulating) halo
 int pl_halo_rows(pl_ctx* ctx, const PlGeom& g, double* planes, int nplanes, long long plane_stride, bool add = false);
 int pl_allreduce_host(pl_ctx* ctx, double* buf, long long n, int op);
+// neighbour exchange / all-gather / tracer migration: native RCCL on the context stream when available,
+// otherwise the host callback table (pl_comm.hip)
+int pl_comm_exchange(pl_ctx* ctx, const double* send_lo, double* recv_lo, const double* send_hi, double* recv_hi,
+                     long long count, int nseg, long long stride, int add);
+int pl_comm_allgather(pl_ctx* ctx, double* recv, long long count, int nseg, long long stride);
+int pl_comm_exchange_var(pl_ctx* ctx, double* const* send_lo, long long n_lo, double* const* send_hi, long long n_hi,
+                         double* const* recv, long long cap, int ncol, long long* got);
+int pl_comm_native_init(pl_ctx* ctx);
+void pl_comm_native_free(pl_ctx* ctx);
+int pl_comm_native_enabled(pl_ctx* ctx);
 void pl_geom_free(PlGeomHost& gh);
 // host (nz,nx) C-order  <->  device plane with ring/pitch
 int pl_plane_upload(pl_ctx* ctx, const PlGeom& g, const double* host, double* dplane);

@@ -191,11 +191,9 @@ int pl_scatter_device(pl_ctx* ctx, PlScatterArgs& a, double* const* out, long lo
     if (slab) {
         if (ctx->nranks > 1) {
             // reverse halo: my ring rows are added to the neighbours' first / last owned rows
-            PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
             const long long nx = a.nx;
-            if (ctx->comm.exchange(ctx->comm.user, accbuf, accbuf + nx, accbuf + (long long)(slab->lnz + 1) * nx,
-                                   accbuf + (long long)slab->lnz * nx, nx, a.nf + 2, (long long)N, 1))
-                return pl_fail(ctx, "communication callback 'exchange' failed");
+            PL_TRY(pl_comm_exchange(ctx, accbuf, accbuf + nx, accbuf + (long long)(slab->lnz + 1) * nx,
+                                    accbuf + (long long)slab->lnz * nx, nx, a.nf + 2, (long long)N, 1));
         }
         frows = slab->lnz; fbase = accbuf + a.nx;           // owned rows only
     }

@@ -743,11 +743,10 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
                 const long long sh = (long long)L->win_rows0 * L->gh.d.pitch;
                 hipLaunchKernelGGL(k_coarsen_visc, grid2d(L->win), dim3(64, 4), 0, ctx->stream, F->gh.d, F->etas, F->etan,
                                    L->win, L->etas + sh, L->etan + sh);
-                PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 const long long cnt = (long long)((L->gh.d.nz - 1) / R) * L->gh.d.pitch;
-                if (ctx->comm.allgather(ctx->comm.user, L->etas + L->gh.d.pitch, cnt, 1, 0) ||
-                    ctx->comm.allgather(ctx->comm.user, L->etan + L->gh.d.pitch, cnt, 1, 0))
-                    return pl_fail(ctx, "communication callback 'allgather' failed");
+                PL_TRY(pl_comm_allgather(ctx, L->etas + L->gh.d.pitch, cnt, 1, 0));
+                PL_TRY(pl_comm_allgather(ctx, L->etan + L->gh.d.pitch, cnt, 1, 0));
+                PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 PL_TRY(share_last_row(ctx, L->gh.d, L->etas));
                 PL_TRY(share_last_row(ctx, L->gh.d, L->etan));
             } else {
@@ -851,9 +850,8 @@ static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const double* f, double**
         PlVvOp wop = C->op; wop.g = C->win;
         const long long sh = (long long)C->win_rows0 * C->gh.d.pitch;
         hipLaunchKernelGGL(k_vv_restrict, grid2d(C->win), dim3(64, 4), 0, ctx->stream, g, wop, L->r, C->f + sh);
-        (void)hipStreamSynchronize(ctx->stream);
         const long long cnt = (long long)((C->gh.d.nz - 1) / ctx->nranks) * C->gh.d.pitch;
-        (void)ctx->comm.allgather(ctx->comm.user, C->f + C->gh.d.pitch, cnt, 2, C->gh.d.plane);
+        (void)pl_comm_allgather(ctx, C->f + C->gh.d.pitch, cnt, 2, C->gh.d.plane);
     } else {
         hipLaunchKernelGGL(k_vv_restrict, grid2d(C->gh.d), dim3(64, 4), 0, ctx->stream, g, C->op, L->r, C->f);
     }

@@ -582,9 +582,8 @@ static int migrate_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, do
         slo[k] = cols[k]; shi[k] = cols[k] + hi_begin; rcv[k] = spare[k] + stay;
     }
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    int64_t got = 0;
-    if (ctx->comm.exchange_var(ctx->comm.user, slo, n_lo, shi, n_hi, rcv, S->cap - stay, NC, &got))
-        return pl_fail(ctx, "communication callback 'exchange_var' failed (tracer migration)");
+    long long got = 0;
+    PL_TRY(pl_comm_exchange_var(ctx, slo, n_lo, shi, n_hi, rcv, S->cap - stay, NC, &got));
     std::swap(S->tz, S->tz2); std::swap(S->tx, S->tx2);
     std::swap(S->vtz, S->tmp[0]); std::swap(S->vtx, S->tmp[1]);
     for (int k = 0; k < NFTRAC; k++) std::swap(S->f[k], S->f2[k]);
@@ -901,9 +900,8 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
         for (int q = 0; q < 2; q++)
             PL_HIP(ctx, hipMemcpyAsync(full + q * gfull.plane + (long long)(1 + g.gi0) * g.pitch, (q ? p_vx : p_vz) + g.pitch,
                                        (size_t)g.lnz * g.pitch * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        PL_TRY(pl_comm_allgather(ctx, full + g.pitch, cnt, 2, gfull.plane));
         PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->comm.allgather(ctx->comm.user, full + g.pitch, cnt, 2, gfull.plane))
-            return pl_fail(ctx, "communication callback 'allgather' failed");
         // the last node row (a wall / ghost row) lives on the last rank only
         std::vector<double> row((size_t)2 * g.pitch, 0.0);
         if (ctx->rank == ctx->nranks - 1)

@@ -66,7 +66,12 @@ class Comm:
         self.errors = []
         self._ops = CommOps(_EXCHANGE(self._exchange), _ALLREDUCE(self._allreduce_host), _ALLGATHER(self._allgather),
                             _EXCHANGE_VAR(self._exchange_var), None)
+        if not self.device_mode:
+            os.environ["PYLAMP_RCCL"] = "0"      # direct RCCL needs one GPU per rank (nccl backend)
         ctx.check(ctx.lib.pl_set_comm(ctx.h, self.rank, self.size, C.byref(self._ops)))
+        nat = C.c_int(0)
+        ctx.check(ctx.lib.pl_comm_info(ctx.h, None, None, C.byref(nat)))
+        self.native = bool(nat.value)
         ctx.comm = self          # keep the callbacks alive as long as the context
 
     # ---- helpers ------------------------------------------------------------------------------

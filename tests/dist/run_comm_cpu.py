@@ -18,6 +18,9 @@ class FakeLib:
     def pl_set_comm(self, h, rank, size, ops):
         return 0
 
+    def pl_comm_info(self, h, rank, size, native):
+        return 0
+
     def pl_memcpy_d2h(self, h, dst, src, nbytes):
         C.memmove(dst, src, nbytes); return 0
 

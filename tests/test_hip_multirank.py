@@ -65,3 +65,26 @@ def test_nccl_staging_fallback_two_ranks():
     collective 'agree on transport' path is exercised explicitly."""
     rc, out = _run("run_stokes_2rank.py", 2, 29541)
     assert rc == 0 and "PASS solve" in out, out[-2000:]
+
+
+def test_native_rccl_single_rank_selftest():
+    """dlopen(librccl), ncclCommInitRank and ncclAllGather through the library's own entry points,
+    on one rank (the neighbour send/recv pairs need >= 2 GPUs and run on the multi-GPU node)."""
+    code = r'''
+import os, sys, ctypes as C
+import numpy as np
+sys.path.insert(0, %r)
+os.environ["PYLAMP_RCCL_SELFTEST"] = "1"
+from pylamp_amd import _lib
+from pylamp_amd._context import Context
+from pylamp_amd.parallel import CommOps
+ctx = Context([17, 17], [np.linspace(0, 1, 17), np.linspace(0, 1, 17)])
+ops = CommOps()
+ctx.check(ctx.lib.pl_set_comm(ctx.h, 0, 1, C.byref(ops)))
+nat = C.c_int(-1)
+ctx.check(ctx.lib.pl_comm_info(ctx.h, None, None, C.byref(nat)))
+print("NATIVE", nat.value)
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "NATIVE 1" in r.stdout, (r.stdout + r.stderr)[-2000:]
