@@ -162,7 +162,9 @@ def main():
             "config": {"workload": "2D %dx%d nodes (%dx%d cells), %d markers/node (%d tracers), T-dependent mantle "
                                    "model, heat + subgrid diffusion on, all free-slip, full time step" %
                                    (args.n, args.n, args.n - 1, args.n - 1, args.tracdens, ntrac_global),
-                       "parallelism": "1 GPU" if world == 1 else "%d row slabs (1 x %d domain decomposition), RCCL halo exchange + all-reduce" % (world, world),
+                       "parallelism": "1 GPU" if world == 1 else "%d row slabs (%d x 1 domain decomposition), halo exchange + all-reduce, transport: %s" %
+                                      (world, world, "direct RCCL on the solver stream" if (sim.ctx.comm is not None and sim.ctx.comm.native)
+                                       else "torch.distributed (%s)" % (dist.get_backend() if dist is not None else "-")),
                        "stokes_rtol": sim.opt.stokes_rtol, "heat_rtol": sim.opt.heat_rtol},
             "time_steps_per_s": round(args.steps / elapsed, 4),
             "stage_ms": stages,

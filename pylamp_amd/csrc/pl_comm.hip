@@ -224,4 +224,13 @@ int pl_comm_native_init(pl_ctx* ctx) {
     return 0;
 }
 
+// in-place sum all-reduce of n doubles in DEVICE memory on the context stream (native path only)
+int pl_comm_allreduce_dev(pl_ctx* ctx, double* dev, int n) {
+    PlNccl* N = nccl_of(ctx);
+    if (!(N && N->ok)) return 1;
+    if (N->AllReduce(dev, dev, (size_t)n, PL_NCCL_DOUBLE, PL_NCCL_SUM, N->comm, ctx->stream))
+        return pl_fail(ctx, "RCCL all-reduce failed");
+    return 0;
+}
+
 int pl_comm_native_enabled(pl_ctx* ctx) { PlNccl* N = nccl_of(ctx); return (N && N->ok) ? 1 : 0; }

@@ -135,6 +135,7 @@ int pl_comm_exchange_var(pl_ctx* ctx, double* const* send_lo, long long n_lo, do
 int pl_comm_native_init(pl_ctx* ctx);
 void pl_comm_native_free(pl_ctx* ctx);
 int pl_comm_native_enabled(pl_ctx* ctx);
+int pl_comm_allreduce_dev(pl_ctx* ctx, double* dev, int n);
 void pl_geom_free(PlGeomHost& gh);
 // host (nz,nx) C-order  <->  device plane with ring/pitch
 int pl_plane_upload(pl_ctx* ctx, const PlGeom& g, const double* host, double* dplane);

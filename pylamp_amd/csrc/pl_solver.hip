@@ -642,11 +642,32 @@ static int dmalloc0(pl_ctx* ctx, double** p, size_t bytes) {
     return 0;
 }
 
+// sum the block partials on the device (one workgroup): out[0], out[1]
+__global__ __launch_bounds__(256) void k_sum_partials(int nb, const double* __restrict__ part, double* __restrict__ out) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = threadIdx.x; k < nb; k += 256) { s0 += part[2 * k]; s1 += part[2 * k + 1]; }
+    __shared__ double sh[2][4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_down(s0, o, 64); s1 += __shfl_down(s1, o, 64); }
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s0; sh[1][threadIdx.x >> 6] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) { out[0] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]; out[1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]; }
+}
+
 static int dots(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const double* a, const double* b, const double* c,
                 const double* d, double* out2) {
     long long rows = (long long)g.lnz * np;
     const int nb = (int)(rows < DOT_BLOCKS ? rows : DOT_BLOCKS);
     hipLaunchKernelGGL(k_dot2, dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 8);
+    if (ctx->nranks > 1 && g.lnz != g.nz && pl_comm_native_enabled(ctx)) {
+        // slab + native RCCL: reduce on the device, all-reduce 2 doubles over xGMI, one 16-byte copy back
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, nb, S->scal + 8, S->scal);
+        PL_TRY(pl_comm_allreduce_dev(ctx, S->scal, 2));
+        PL_HIP(ctx, hipMemcpyAsync(S->hpart, S->scal, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        out2[0] = S->hpart[0]; out2[1] = S->hpart[1];
+        return 0;
+    }
     PL_HIP(ctx, hipMemcpyAsync(S->hpart, S->scal + 8, (size_t)2 * nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     double s0 = 0.0, s1 = 0.0;
