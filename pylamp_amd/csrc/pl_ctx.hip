@@ -57,16 +57,17 @@ int pl_geom_build(pl_ctx* ctx, PlGeomHost& gh, int nz, int nx, const double* zc,
     g.pitch = ((PL_PADL + nx + 1 + 15) / 16) * 16;
     g.plane = (long long)(nz + 2) * g.pitch;
     // tables indexed by global index + 1, length n+3 each
-    size_t lz = nz + 3, lx = nx + 3;
+    const int T0 = PL_TOFF;
+    size_t lz = ((size_t)nz + 2 * T0 + 2 + 1) & ~(size_t)1, lx = ((size_t)nx + 2 * T0 + 2 + 1) & ~(size_t)1;   // even lengths
     std::vector<double> t(3 * lz + 3 * lx, 0.0);
     double* tz = t.data(); double* trdz = tz + lz; double* trDz = trdz + lz;
     double* tx = trDz + lz; double* trdx = tx + lx; double* trDx = trdx + lx;
-    for (int i = 0; i < nz; i++) tz[i + 1] = zc[i];
-    for (int j = 0; j < nx; j++) tx[j + 1] = xc[j];
-    for (int i = 0; i + 1 < nz; i++) trdz[i + 1] = 1.0 / (zc[i + 1] - zc[i]);
-    for (int i = 1; i + 1 < nz; i++) trDz[i + 1] = 1.0 / (zc[i + 1] - zc[i - 1]);
-    for (int j = 0; j + 1 < nx; j++) trdx[j + 1] = 1.0 / (xc[j + 1] - xc[j]);
-    for (int j = 1; j + 1 < nx; j++) trDx[j + 1] = 1.0 / (xc[j + 1] - xc[j - 1]);
+    for (int i = 0; i < nz; i++) tz[i + T0] = zc[i];
+    for (int j = 0; j < nx; j++) tx[j + T0] = xc[j];
+    for (int i = 0; i + 1 < nz; i++) trdz[i + T0] = 1.0 / (zc[i + 1] - zc[i]);
+    for (int i = 1; i + 1 < nz; i++) trDz[i + T0] = 1.0 / (zc[i + 1] - zc[i - 1]);
+    for (int j = 0; j + 1 < nx; j++) trdx[j + T0] = 1.0 / (xc[j + 1] - xc[j]);
+    for (int j = 1; j + 1 < nx; j++) trDx[j + T0] = 1.0 / (xc[j + 1] - xc[j - 1]);
     if (gh.tables) { (void)hipFree(gh.tables); gh.tables = nullptr; }
     PL_HIP(ctx, hipMalloc((void**)&gh.tables, t.size() * sizeof(double)));
     PL_HIP(ctx, hipMemcpy(gh.tables, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));

@@ -4,7 +4,7 @@
 // (T 8 + kz 8 + kx 8 + c 8 + y 8), 48 B/node counted the reference way.
 #include "pl_internal.h"
 
-#define TB(tab, k) (tab)[(k) + 1]
+#define TB(tab, k) (tab)[(k) + PL_TOFF]
 
 __global__ __launch_bounds__(256) void k_heat_apply(PlHeatOp op, const double* __restrict__ T,
                                                     double* __restrict__ y) {
@@ -79,14 +79,15 @@ void pl_launch_heat_coef(pl_ctx* ctx, const PlGeom& g, const double* rho, const 
 int pl_heat_tables(pl_ctx* ctx, const double* zmp, const double* xmp) {
     int nz = ctx->nz, nx = ctx->nx;
     ctx->zmp.assign(zmp, zmp + nz); ctx->xmp.assign(xmp, xmp + nx);
-    std::vector<double> t((size_t)nz + 3 + nx + 3, 0.0);
-    for (int i = 1; i < nz; i++) t[i + 1] = 1.0 / (zmp[i] - zmp[i - 1]);
-    for (int j = 1; j < nx; j++) t[nz + 3 + j + 1] = 1.0 / (xmp[j] - xmp[j - 1]);
+    const size_t lz = (size_t)nz + 2 * PL_TOFF + 2;
+    std::vector<double> t(lz + nx + 2 * PL_TOFF + 2, 0.0);
+    for (int i = 1; i < nz; i++) t[i + PL_TOFF] = 1.0 / (zmp[i] - zmp[i - 1]);
+    for (int j = 1; j < nx; j++) t[lz + j + PL_TOFF] = 1.0 / (xmp[j] - xmp[j - 1]);
     double* d;
     PL_TRY(pl_buf(ctx, "heat_tables", t.size() * sizeof(double), &d));
     PL_HIP(ctx, hipMemcpyAsync(d, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->hop.rdzb = d; ctx->hop.rdxb = d + nz + 3;
+    ctx->hop.rdzb = d; ctx->hop.rdxb = d + lz;
     return 0;
 }
 

@@ -12,6 +12,7 @@
 
 #define PL_PADL 16           // doubles of left padding: interior column 0 is 128-B aligned
 #define PL_WAVE 64
+#define PL_TOFF 2            // 1-D tables are indexed by global node index + PL_TOFF (even: pairs are 16-B aligned)
 
 // ---- device-side view of one grid block (fine grid or a multigrid level) -------------
 // Local block of lnz x lnx nodes whose node (0,0) is global node (gi0,gj0); every 2-D
@@ -22,7 +23,7 @@ struct PlGeom {
     int gi0, gj0;            // global index of local node (0,0)
     int pitch;               // doubles per row
     long long plane;         // doubles per plane = (lnz+2)*pitch
-    // 1-D tables indexed by GLOBAL node index + 1, length n+3, zero padded:
+    // 1-D tables indexed by GLOBAL node index + PL_TOFF, zero padded on both sides, 16-B aligned:
     const double* zc; const double* xc;
     const double* rdz; const double* rdx;   // rdz[i] = 1/(z[i+1]-z[i])
     const double* rDz; const double* rDx;   // rDz[i] = 1/(z[i+1]-z[i-1])

@@ -19,7 +19,7 @@
 #include <functional>
 #include <limits>
 
-#define TB(tab, k) (tab)[(k) + 1]
+#define TB(tab, k) (tab)[(k) + PL_TOFF]
 
 void pl_launch_heat_rhs(pl_ctx* ctx, const PlHeatOp& op, const double* Told, const double* H, double* rhs);
 

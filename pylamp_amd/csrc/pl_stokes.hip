@@ -12,7 +12,7 @@
 #include <cstdlib>
 #include <limits>
 
-#define TB(tab, k) (tab)[(k) + 1]
+#define TB(tab, k) (tab)[(k) + PL_TOFF]
 
 // One thread per node, 64 x 4 thread blocks: each wave owns 64 consecutive columns of ONE
 // row, so every z-table value is wave-uniform (scalar loads) and all plane accesses are
@@ -133,18 +133,159 @@ __global__ __launch_bounds__(256, PL_APPLY_WAVES) void k_stokes_apply(PlStokesOp
     PL_ROW_LOOP(op.g, iters) stokes_apply_node(op, x, y, li, lj);
 }
 
-// XCD-aware variant (1-D grid).  The dispatcher deals consecutive workgroup ids round-robin over
-// the 8 XCDs (MI355X_MICROARCH.md, observed; used for speed only): id % 8 selects the XCD.  Block
-// column bx is served by XCD bx % 8, and inside an XCD the blocks walk row-major, so vertically
-// adjacent blocks - which share a halo row of all five input planes - share that XCD's L2.
-__global__ __launch_bounds__(256, PL_APPLY_WAVES) void k_stokes_apply_xcd(PlStokesOp op, const double* __restrict__ x,
-                                                                          double* __restrict__ y, int gx8) {
-    const int id = blockIdx.x;
-    const int xcd = id & 7, k = id >> 3;
-    const int by = k / gx8, bx = xcd + 8 * (k % gx8);
-    const int lj = bx * 64 + threadIdx.x, li = by * 4 + threadIdx.y;
-    if (lj >= op.g.lnx || li >= op.g.lnz) return;
-    stokes_apply_node(op, x, y, li, lj);
+// ---------------------------------------------------------------------------------------------------
+// Two-columns-per-lane variant: every plane row is read with 16-byte (double2) loads, the j-1 / j+1
+// neighbours come from the adjacent lanes (ds_bpermute), only the two edge lanes issue an extra
+// 8-byte load.  Why: with 8-byte loads the texture-address unit was busy 84 % of the kernel time
+// (PMC TA_TA_BUSY, profiles/r01_pmc_stalls.csv): the L1 path serves 4 lanes per cycle whatever the
+// width, so double2 halves the address cycles per byte and there are 14 instead of 34 loads per wave.
+// A wave covers 128 columns of one row; rows/columns outside the block are never dereferenced past
+// the ring (planes carry a ring row above/below and >= 1 pad column each side).
+struct Row2 { double2 v; double w, e; };           // w = value at j-1 of .x ; e = value at j+1 of .y
+
+__device__ inline Row2 load_row2(const double* __restrict__ row, int lj0, bool active, bool need_w, bool need_e,
+                                 int lane, bool has_right) {
+    Row2 r;
+    r.v = active ? *reinterpret_cast<const double2*>(row + lj0) : make_double2(0.0, 0.0);
+    r.w = 0.0; r.e = 0.0;
+    if (need_w) {
+        const double up = __shfl_up(r.v.y, 1, 64);
+        r.w = (lane == 0) ? (active ? row[lj0 - 1] : 0.0) : up;
+    }
+    if (need_e) {
+        const double dn = __shfl_down(r.v.x, 1, 64);
+        r.e = (lane == 63 || !has_right) ? (active ? row[lj0 + 2] : 0.0) : dn;
+    }
+    return r;
+}
+
+// all values one node needs, as scalars
+struct StokesVals {
+    double vz_c, vz_w, vz_e, vz_n, vz_s, vz_nw;      // n = row i+1, s = row i-1, nw = (i+1, j-1)
+    double vx_c, vx_w, vx_e, vx_n, vx_s, vx_se;      // se = (i-1, j+1)
+    double p_c, p_w, p_e, p_s;
+    double en_c, en_w, en_s;
+    double es_c, es_e, es_n;
+    double rdx_j, rdx_m, rDx_j, rDx_p;
+};
+
+__device__ inline void stokes_node_vals(const PlStokesOp& op, int i, int j, int c, const StokesVals& q,
+                                        const double* __restrict__ x, double& oz, double& ox, double& op_) {
+    const PlGeom& g = op.g;
+    const int nz = g.nz, nx = g.nx, p = g.pitch;
+    const double Kc = op.Kc;
+    const double iKc = 1.0 / Kc;
+    double sz = iKc, sx = iKc, sp = iKc;
+    double yz;
+    if (j == nx - 1 || i == 0 || i == nz - 1) yz = Kc * q.vz_c;
+    else if (j == 0) yz = Kc * (q.vz_c - q.vz_e);
+    else if (j == nx - 2) yz = Kc * (q.vz_c - q.vz_w);
+    else {
+        const double rdz_i = TB(g.rdz, i), rdz_m = TB(g.rdz, i - 1), rDz_i = TB(g.rDz, i);
+        const double cN = 4.0 * q.en_c * rdz_i * rDz_i, cS = 4.0 * q.en_s * rdz_m * rDz_i;
+        const double cE = 2.0 * q.es_e * q.rDx_p * q.rdx_j, cW = 2.0 * q.es_c * q.rDx_j * q.rdx_j;
+        const double xE = 2.0 * q.es_e * rDz_i * q.rdx_j, xW = 2.0 * q.es_c * rDz_i * q.rdx_j;
+        yz = cN * (q.vz_n - q.vz_c) - cS * (q.vz_c - q.vz_s) + cE * (q.vz_e - q.vz_c) - cW * (q.vz_c - q.vz_w) +
+             xE * (q.vx_e - q.vx_se) - xW * (q.vx_c - q.vx_s) - 2.0 * Kc * rDz_i * (q.p_c - q.p_s);
+        sz = 1.0 / (cN + cS + cE + cW);
+        if (op.surfstab) {
+            const double* __restrict__ r = op.rho;
+            yz += op.ss * op.gz * 0.5 * ((r[c + 1] + r[c + p + 1] - r[c - 1] - r[c + p - 1]) * q.rDx_j * q.vx_c +
+                                         (r[c + p] + r[c + p + 1] - r[c - p] - r[c - p + 1]) * rDz_i * q.vz_c);
+        }
+    }
+    double yx;
+    if (i == nz - 1 || j == 0 || j == nx - 1) yx = Kc * q.vx_c;
+    else if (i == 0) {
+        if (op.bc_z0 == PL_BC_FREESLIP) yx = Kc * (q.vx_c - q.vx_n);
+        else yx = Kc * ((-TB(g.rDz, 1) - TB(g.rdz, 0)) * q.vx_c + TB(g.rDz, 1) * q.vx_n);
+    } else if (i == nz - 2) {
+        if (op.bc_zL == PL_BC_FREESLIP) yx = Kc * (q.vx_c - q.vx_s);
+        else yx = Kc * ((TB(g.rDz, nz - 2) + TB(g.rdz, nz - 2)) * q.vx_c - TB(g.rDz, nz - 2) * q.vx_s);
+    } else {
+        const double rdz_i = TB(g.rdz, i), rDz_i = TB(g.rDz, i), rDz_p = TB(g.rDz, i + 1);
+        const double cE = 4.0 * q.en_c * q.rdx_j * q.rDx_j, cW = 4.0 * q.en_w * q.rdx_m * q.rDx_j;
+        const double cN = 2.0 * q.es_n * rDz_p * rdz_i, cS = 2.0 * q.es_c * rDz_i * rdz_i;
+        const double zN = 2.0 * q.es_n * q.rDx_j * rdz_i, zS = 2.0 * q.es_c * q.rDx_j * rdz_i;
+        yx = cE * (q.vx_e - q.vx_c) - cW * (q.vx_c - q.vx_w) + cN * (q.vx_n - q.vx_c) - cS * (q.vx_c - q.vx_s) +
+             zN * (q.vz_n - q.vz_nw) - zS * (q.vz_c - q.vz_w) - 2.0 * Kc * q.rDx_j * (q.p_c - q.p_w);
+        sx = 1.0 / (cE + cW + cN + cS);
+        if (op.surfstab && op.gx != 0.0) {
+            const double* __restrict__ r = op.rho;
+            yx += op.ss * op.gx * 0.5 * ((r[c + 1] + r[c + p + 1] - r[c - 1] - r[c + p - 1]) * q.rDx_j * q.vx_c +
+                                         (r[c + p] + r[c + p + 1] - r[c - p] - r[c - p + 1]) * rDz_i * q.vz_c);
+        }
+    }
+    double yp;
+    if (i == nz - 1 || j == nx - 1 || (i == op.anchor_i && j == op.anchor_j)) yp = Kc * q.p_c;
+    else if ((i == 0 || i == nz - 2) && j == 0) { yp = op.Kb * (q.p_e - q.p_c); sp = 1.0 / op.Kb; }
+    else if ((i == 0 || i == nz - 2) && j == nx - 2) { yp = op.Kb * (q.p_w - q.p_c); sp = 1.0 / op.Kb; }
+    else {
+        yp = Kc * ((q.vx_e - q.vx_c) * q.rdx_j + (q.vz_n - q.vz_c) * TB(g.rdz, i));
+        sp = 1.0 / (Kc * (q.rdx_j + TB(g.rdz, i)));
+    }
+    (void)x;
+    oz = op.scaled ? yz * sz : yz; ox = op.scaled ? yx * sx : yx; op_ = op.scaled ? yp * sp : yp;
+}
+
+template <int ROWS>
+__global__ __launch_bounds__(64 * ROWS) void k_stokes_apply_v2(PlStokesOp op, const double* __restrict__ x,
+                                                               double* __restrict__ y) {
+    const PlGeom& g = op.g;
+    const int lane = threadIdx.x;
+    const int lj0 = (blockIdx.x * 64 + lane) * 2;          // this lane's two columns: lj0, lj0+1
+    const int li = blockIdx.y * ROWS + threadIdx.y;
+    if (li >= g.lnz) return;                                // wave-uniform
+    const bool active = lj0 < g.lnx;                        // lanes beyond the row take part in shuffles only
+    const bool has_right = (lj0 + 2) < g.lnx;               // the lane to the right holds real columns
+    const int p = g.pitch;
+    const int c = (li + 1) * p + PL_PADL + lj0;             // element offset of column A (16-B aligned)
+    const double* __restrict__ vz = x;
+    const double* __restrict__ vx = x + g.plane;
+    const double* __restrict__ P = x + 2 * g.plane;
+    const double* __restrict__ es = op.etas;
+    const double* __restrict__ en = op.etan;
+#define ROW(ptr, dr, w, e) load_row2((ptr) + (long long)c - lj0 + (long long)(dr) * p, lj0, active, w, e, lane, has_right)
+    const Row2 vz_s = ROW(vz, -1, false, false), vz_i = ROW(vz, 0, true, true), vz_n = ROW(vz, 1, true, false);
+    const Row2 vx_s = ROW(vx, -1, false, true), vx_i = ROW(vx, 0, true, true), vx_n = ROW(vx, 1, false, false);
+    const Row2 p_s = ROW(P, -1, false, false), p_i = ROW(P, 0, true, true);
+    const Row2 en_s = ROW(en, -1, false, false), en_i = ROW(en, 0, true, false);
+    const Row2 es_i = ROW(es, 0, false, true), es_n = ROW(es, 1, false, false);
+#undef ROW
+    // x tables: pair at (j, j+1) plus the two outer neighbours (tables are padded by PL_TOFF entries)
+    const int j0 = g.gj0 + lj0;
+    const Row2 t_rdx = load_row2(g.rdx + PL_TOFF + g.gj0, lj0, active, true, false, lane, has_right);
+    const Row2 t_rDx = load_row2(g.rDx + PL_TOFF + g.gj0, lj0, active, false, true, lane, has_right);
+    const double rdx_a = t_rdx.v.x, rdx_b = t_rdx.v.y, rdx_m = t_rdx.w;
+    const double rDx_a = t_rDx.v.x, rDx_b = t_rDx.v.y, rDx_pp = t_rDx.e;
+    if (!active) return;
+    const int i = g.gi0 + li;
+    StokesVals q;
+    double oz[2], ox[2], opv[2];
+    // column A (lj0)
+    q.vz_c = vz_i.v.x; q.vz_w = vz_i.w; q.vz_e = vz_i.v.y; q.vz_n = vz_n.v.x; q.vz_s = vz_s.v.x; q.vz_nw = vz_n.w;
+    q.vx_c = vx_i.v.x; q.vx_w = vx_i.w; q.vx_e = vx_i.v.y; q.vx_n = vx_n.v.x; q.vx_s = vx_s.v.x; q.vx_se = vx_s.v.y;
+    q.p_c = p_i.v.x; q.p_w = p_i.w; q.p_e = p_i.v.y; q.p_s = p_s.v.x;
+    q.en_c = en_i.v.x; q.en_w = en_i.w; q.en_s = en_s.v.x;
+    q.es_c = es_i.v.x; q.es_e = es_i.v.y; q.es_n = es_n.v.x;
+    q.rdx_j = rdx_a; q.rdx_m = rdx_m; q.rDx_j = rDx_a; q.rDx_p = rDx_b;
+    stokes_node_vals(op, i, j0, c, q, x, oz[0], ox[0], opv[0]);
+    // column B (lj0 + 1)
+    q.vz_c = vz_i.v.y; q.vz_w = vz_i.v.x; q.vz_e = vz_i.e; q.vz_n = vz_n.v.y; q.vz_s = vz_s.v.y; q.vz_nw = vz_n.v.x;
+    q.vx_c = vx_i.v.y; q.vx_w = vx_i.v.x; q.vx_e = vx_i.e; q.vx_n = vx_n.v.y; q.vx_s = vx_s.v.y; q.vx_se = vx_s.e;
+    q.p_c = p_i.v.y; q.p_w = p_i.v.x; q.p_e = p_i.e; q.p_s = p_s.v.y;
+    q.en_c = en_i.v.y; q.en_w = en_i.v.x; q.en_s = en_s.v.y;
+    q.es_c = es_i.v.y; q.es_e = es_i.e; q.es_n = es_n.v.y;
+    q.rdx_j = rdx_b; q.rdx_m = rdx_a; q.rDx_j = rDx_b; q.rDx_p = rDx_pp;
+    const bool colB = (lj0 + 1) < g.lnx;
+    if (colB) stokes_node_vals(op, i, j0 + 1, c + 1, q, x, oz[1], ox[1], opv[1]);
+    if (colB) {
+        *reinterpret_cast<double2*>(y + c) = make_double2(oz[0], oz[1]);
+        *reinterpret_cast<double2*>(y + c + g.plane) = make_double2(ox[0], ox[1]);
+        *reinterpret_cast<double2*>(y + c + 2 * g.plane) = make_double2(opv[0], opv[1]);
+    } else {
+        y[c] = oz[0]; y[c + g.plane] = ox[0]; y[c + 2 * g.plane] = opv[0];
+    }
 }
 
 __global__ __launch_bounds__(256) void k_stokes_rhs(PlStokesOp op, double* __restrict__ rhs) {
@@ -163,10 +304,15 @@ __global__ __launch_bounds__(256) void k_stokes_rhs(PlStokesOp op, double* __res
 static dim3 grid2d(const PlGeom& g) { return dim3((g.lnx + 63) / 64, (g.lnz + 3) / 4); }
 
 void pl_launch_stokes_apply(pl_ctx* ctx, const PlStokesOp& op, const double* x, double* y) {
-    static const int use_xcd = getenv("PYLAMP_APPLY_XCD") ? atoi(getenv("PYLAMP_APPLY_XCD")) : 1;
-    if (use_xcd && (long long)op.g.lnz * op.g.lnx >= 8000000LL) {   // measured: +5% at 4097^2, neutral at 2049^2
-        const int gx = (op.g.lnx + 63) / 64, gy = (op.g.lnz + 3) / 4, gx8 = (gx + 7) / 8;
-        hipLaunchKernelGGL(k_stokes_apply_xcd, dim3(8 * gx8 * gy), dim3(64, 4), 0, ctx->stream, op, x, y, gx8);
+    // Variants measured on MI355X: 8-byte loads 84 us; double2 81 us; double2 + register
+    // row marching (R = 8/16) 99/104 us; 1024-thread blocks (16 rows) 84 us at 2049^2 but 342 vs 388 us at
+    // 4097^2; XCD-aware block remap and plane-stride padding: no effect.
+    if ((op.g.plane % 2) == 0) {                  // double2 accesses need even plane strides (pitch is a multiple of 16)
+        const int gx = (op.g.lnx + 127) / 128;
+        if ((long long)op.g.lnz * op.g.lnx >= 8000000LL)
+            hipLaunchKernelGGL(k_stokes_apply_v2<16>, dim3(gx, (op.g.lnz + 15) / 16), dim3(64, 16), 0, ctx->stream, op, x, y);
+        else
+            hipLaunchKernelGGL(k_stokes_apply_v2<4>, dim3(gx, (op.g.lnz + 3) / 4), dim3(64, 4), 0, ctx->stream, op, x, y);
         return;
     }
     hipLaunchKernelGGL(k_stokes_apply, pl_grid_rows(op.g), dim3(64, 4), 0, ctx->stream, op, x, y, pl_row_iters(op.g));
