@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void k_vv_prolong_add(PlVvOp opf, PlGeom gc, c
 #define PL_TAIL_MAX_LEVELS 8
 #define PL_TAIL_MAX_NODES (65 * 65)
 struct TailLevel { PlVvOp op; double* v[3]; double* f; double* r; double lmax; };
-struct TailArgs { int nlev; int nu_pre, nu_post, coarse_sweeps; TailLevel L[PL_TAIL_MAX_LEVELS]; };
+struct TailArgs { int nlev; int nu_pre, nu_post, coarse_sweeps; double ratio; TailLevel L[PL_TAIL_MAX_LEVELS]; };
 
 #define TAIL_FOR_NODES(g)                                                              \
     for (int idx_ = threadIdx.x; idx_ < (g).lnz * (g).lnx; idx_ += blockDim.x)
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(1024) void k_mg_tail(TailArgs a) {
             double ratio = 0.4 * g.nz * g.nx; if (ratio < 30.0) ratio = 30.0;
             tail_smooth(L, buf, a.coarse_sweeps, ratio);
         } else {
-            tail_smooth(L, buf, a.nu_pre, 6.0);
+            tail_smooth(L, buf, a.nu_pre, a.ratio);
             TAIL_FOR_NODES(g) { const int li = idx_ / g.lnx, lj = idx_ % g.lnx; residual_node(L.op, buf[0], L.f, L.r, g.gi0 + li, g.gj0 + lj, pl_idx(g, li, lj)); }
             __syncthreads();
             const TailLevel& C = a.L[l + 1];
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(1024) void k_mg_tail(TailArgs a) {
         TAIL_FOR_NODES(g) { const int li = idx_ / g.lnx, lj = idx_ % g.lnx; prolong_node(L.op, gc, ec, buf[0], buf[2], g.gi0 + li, g.gj0 + lj, pl_idx(g, li, lj)); }
         __syncthreads();
         { double* t = buf[0]; buf[0] = buf[2]; buf[2] = t; }
-        tail_smooth(L, buf, a.nu_post, 6.0);
+        tail_smooth(L, buf, a.nu_post, a.ratio);
         cur[l][0] = buf[0]; cur[l][1] = buf[1]; cur[l][2] = buf[2];
     }
     // result of the first tail level must be in L[0].v[0]
@@ -587,7 +587,7 @@ struct PlSolver {
     int tail_start = -1;        // first replicated level (multi-rank: levels below are distributed)
     // BiCGStab work vectors (3 planes each)
     double *r = nullptr, *rt = nullptr, *p = nullptr, *v = nullptr, *s = nullptr, *t = nullptr, *y = nullptr,
-           *z = nullptr, *b = nullptr, *x = nullptr;
+           *z = nullptr, *b = nullptr, *x = nullptr, *xb = nullptr;
     double* scal = nullptr;     // device scalars [0..8) + dot partials [8..8+2*DOT_BLOCKS)
     double* hpart = nullptr;    // pinned host copy of the dot partials
     int nu_pre = 2, nu_post = 2, coarse_sweeps = 12;
@@ -596,6 +596,7 @@ struct PlSolver {
     // transfer (identical numerics to one rank); 1 = once per level and direction; 0 = none (slab-local
     // smoothing with frozen zero halos; only the replicated coarse tail couples the slabs)
     int mg_halo = 2;
+    double cheb_ratio = 6.0, lmax_safety = 1.1;     // smoothing window [lmax/ratio, lmax]; lmax = safety * power-iteration estimate
     // heat work vectors (1 plane each)
     double* h[9] = {nullptr};
     int napply = 0, nprec = 0;
@@ -609,6 +610,8 @@ static PlSolver* solver_of(pl_ctx* ctx) {
         if (const char* e = getenv("PYLAMP_MG_COARSE")) { int a = atoi(e); if (a > 0) S->coarse_sweeps = a; }
         if (const char* e = getenv("PYLAMP_MG_TAIL")) S->use_tail = atoi(e) != 0;
         if (const char* e = getenv("PYLAMP_MG_HALO")) S->mg_halo = atoi(e);
+        if (const char* e = getenv("PYLAMP_MG_RATIO")) { double v = atof(e); if (v > 1.5) S->cheb_ratio = v; }
+        if (const char* e = getenv("PYLAMP_MG_SAFETY")) { double v = atof(e); if (v >= 1.0) S->lmax_safety = v; }
         ctx->krylov = S;
     }
     return (PlSolver*)ctx->krylov;
@@ -628,7 +631,7 @@ void pl_solver_free(pl_ctx* ctx) {
     PlSolver* S = (PlSolver*)ctx->krylov;
     if (!S) return;
     free_levels(S);
-    for (double* q : {S->r, S->rt, S->p, S->v, S->s, S->t, S->y, S->z, S->b, S->x, S->scal})
+    for (double* q : {S->r, S->rt, S->p, S->v, S->s, S->t, S->y, S->z, S->b, S->x, S->xb, S->scal})
         if (q) (void)hipFree(q);
     for (double* q : S->h) if (q) (void)hipFree(q);
     if (S->hpart) (void)hipHostFree(S->hpart);
@@ -796,7 +799,7 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
             hipLaunchKernelGGL(k_axpy_out, grid1d(n2), dim3(256), 0, ctx->stream, n2, L->v[0], L->v[1], L->v[1],
                                1.0 / std::sqrt(nn[0]) - 1.0);     // v0 = v1 / ||v1||
         }
-        L->lmax = 1.1 * lam;
+        L->lmax = S->lmax_safety * lam;
     }
     return 0;
 }
@@ -842,7 +845,7 @@ static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const double* f, double**
         S->levels.size() - l <= PL_TAIL_MAX_LEVELS && f == L->f) {
         TailArgs ta{};
         ta.nlev = (int)(S->levels.size() - l); ta.nu_pre = S->nu_pre; ta.nu_post = S->nu_post;
-        ta.coarse_sweeps = coarsest_sweeps(S, S->levels.back()->gh.d);
+        ta.coarse_sweeps = coarsest_sweeps(S, S->levels.back()->gh.d); ta.ratio = S->cheb_ratio;
         for (int q = 0; q < ta.nlev; q++) {
             MgLevel* T = S->levels[l + q];
             ta.L[q].op = T->op; ta.L[q].f = T->f; ta.L[q].r = T->r; ta.L[q].lmax = T->lmax;
@@ -861,7 +864,7 @@ static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const double* f, double**
         return;
     }
     const int hp = S->mg_halo;
-    smooth(ctx, L, buf, f, S->nu_pre, 6.0, nullptr, true, hp);
+    smooth(ctx, L, buf, f, S->nu_pre, S->cheb_ratio, nullptr, true, hp);
     if (L->dist && hp >= 1) (void)pl_halo_rows(ctx, g, buf[0], 2, g.plane);
     hipLaunchKernelGGL(k_vv_residual, pl_grid_rows(g), dim3(64, 4), 0, ctx->stream, L->op, buf[0], f, L->r, pl_row_iters(g));
     if (L->dist && hp >= 1) (void)pl_halo_rows(ctx, g, L->r, 2, g.plane);
@@ -881,7 +884,7 @@ static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const double* f, double**
     if (C->dist && hp >= 1) (void)pl_halo_rows(ctx, C->gh.d, ec, 2, C->gh.d.plane);
     hipLaunchKernelGGL(k_vv_prolong_add, grid2d(g), dim3(64, 4), 0, ctx->stream, L->op, C->gh.d, ec, buf[0], buf[2]);
     std::swap(buf[0], buf[2]);
-    smooth(ctx, L, buf, f, S->nu_post, 6.0, final_out, false, hp);
+    smooth(ctx, L, buf, f, S->nu_post, S->cheb_ratio, final_out, false, hp);
     *out = buf[0];
 }
 
@@ -906,7 +909,7 @@ static int stokes_precond(pl_ctx* ctx, PlSolver* S, const double* rs, double* z)
 // =========================================================================================
 typedef std::function<int(const double*, double*)> VecOp;
 
-struct BicgVecs { double *r, *rt, *p, *v, *s, *t, *y, *z; };
+struct BicgVecs { double *r, *rt, *p, *v, *s, *t, *y, *z; double* xbest; };
 
 // ref_norm > 0 replaces ||b|| as the reference of the stopping test and of rel_residual.
 static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const VecOp& A, const VecOp* M,
@@ -939,6 +942,9 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
     PL_TRY(dots(ctx, S, g, np, w.rt, w.r, w.r, w.r, d2));
     double rho_new = d2[0], rnorm = std::sqrt(d2[1]);
     int it = 0;
+    // BiCGStab is not monotone and, past the attainable accuracy, drifts and can blow up: keep the best
+    // iterate, stop after 60 iterations without a new best or when the residual explodes, return the best.
+    double best = rnorm; int best_it = 0; bool have_best = false;
     while (it < maxit && rnorm > rtol * bnorm) {
         it++;
         if (!(std::fabs(rho_new) > 0.0) || !std::isfinite(rho_new)) break;
@@ -966,7 +972,14 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
         PL_TRY(dots(ctx, S, g, np, w.rt, w.r, w.r, w.r, d2));
         rho_new = d2[0]; rnorm = std::sqrt(d2[1]);
         if (!std::isfinite(rnorm) || !(std::fabs(omega) > 0.0)) break;
+        if (rnorm < 0.9 * best && w.xbest) {
+            best = rnorm; best_it = it; have_best = true;
+            PL_HIP(ctx, hipMemcpyAsync(w.xbest, x, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        if (w.xbest && (it - best_it > 60 || rnorm > 1e6 * best)) break;       // stagnation / divergence
     }
+    if (have_best && w.xbest && !(rnorm <= 1.5 * best))
+        PL_HIP(ctx, hipMemcpyAsync(x, w.xbest, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     // true residual
     PL_TRY(A(x, w.t));
     hipLaunchKernelGGL(k_axpy_out, grid1d(n), dim3(256), 0, ctx->stream, n, w.s, b, w.t, -1.0);
@@ -983,7 +996,7 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
 static int stokes_alloc(pl_ctx* ctx, PlSolver* S) {
     if (S->r) return 0;
     size_t vb = (size_t)3 * ctx->geom.d.plane * sizeof(double);
-    for (double** q : {&S->r, &S->rt, &S->p, &S->v, &S->s, &S->t, &S->y, &S->z, &S->b, &S->x})
+    for (double** q : {&S->r, &S->rt, &S->p, &S->v, &S->s, &S->t, &S->y, &S->z, &S->b, &S->x, &S->xb})
         PL_TRY(dmalloc0(ctx, q, vb));
     if (!S->scal) {
         PL_TRY(dmalloc0(ctx, &S->scal, (8 + 2 * DOT_BLOCKS) * sizeof(double)));
@@ -1013,7 +1026,7 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
     if (b_dev != S->b)
         PL_HIP(ctx, hipMemcpyAsync(S->b, b_dev, (size_t)3 * g.plane * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     hipLaunchKernelGGL(k_stokes_scale_rows, grid2d(g), dim3(64, 4), 0, ctx->stream, sop, S->b);
-    BicgVecs w{S->r, S->rt, S->p, S->v, S->s, S->t, S->y, S->z};
+    BicgVecs w{S->r, S->rt, S->p, S->v, S->s, S->t, S->y, S->z, S->xb};
     // hydrostatic pressure x_h (in S->y) and the dynamic-load reference norm ||D_r (b - A x_h)||
     double d2[2], ref = 0.0;
     {
@@ -1150,7 +1163,7 @@ int pl_heat_solve_device(pl_ctx* ctx, const double* b_dev, double rtol, int maxi
     double* b = S->h[8];
     PL_HIP(ctx, hipMemcpyAsync(b, b_dev, pb, hipMemcpyDeviceToDevice, ctx->stream));
     hipLaunchKernelGGL(k_heat_dinv, grid2d(g), dim3(64, 4), 0, ctx->stream, hop, b);
-    BicgVecs w{S->h[0], S->h[1], S->h[2], S->h[3], S->h[4], S->h[5], nullptr, nullptr};
+    BicgVecs w{S->h[0], S->h[1], S->h[2], S->h[3], S->h[4], S->h[5], nullptr, nullptr, S->h[6]};
     PL_TRY(bicgstab(ctx, S, g, 1, A, nullptr, b, S->h[7], false, rtol, maxit, w, st));
     double ms = 0;
     PL_TRY(pl_timer_stop_ms(ctx, &ms));

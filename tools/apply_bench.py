@@ -1,6 +1,6 @@
 import sys, time, ctypes as C
 import numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..'))
 from pylamp_amd import pylamp_stokes as S, _lib
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2049
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 50

@@ -1,7 +1,7 @@
 """PMC target: a few Stokes applies + a streaming calibration kernel (k_axpy_out: 8 B/lane, known
 bytes) at 2049^2, nothing else heavy.  Run under `rocprofv3 --pmc ...` (one counter set per pass)."""
 import sys, ctypes as C
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..'))
 import numpy as np
 from pylamp_amd import pylamp_stokes as S
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2049

@@ -1,6 +1,6 @@
 """Tuning experiment (not part of the product): solver settings vs accuracy / time."""
 import sys, os, time
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..'))
 import numpy as np
 from pylamp_amd import pylamp_stokes as S, driver
 from oracle import pylamp_oracle as O
