@@ -36,7 +36,7 @@ __host__ __device__ inline long long pl_idx(const PlGeom& g, int li, int lj) {
 struct PlStokesOp {
     PlGeom g;
     const double* etas; const double* etan; const double* rho;
-    double Kc, Kb;
+    double Kc, Kb, iKc;      // iKc = 1/Kc
     int bc_z0, bc_zL;        // z-wall BC for the tangential rows (x-walls are FREESLIP)
     int surfstab; double ss; // ss = theta * tstep
     int anchor_i, anchor_j;  // pressure anchor cell (3,2) (pylamp_stokes.py:536-551)

@@ -466,8 +466,8 @@ __global__ __launch_bounds__(256) void k_stokes_scale_rows(PlStokesOp op, double
 
 // S^ solve of one pressure node from the SCALED residual rs (continuity rows only)
 __device__ inline double prec_p_cont(const PlStokesOp& op, const double* __restrict__ rs_p, int i, int j, long long c) {
-    const double unscale = op.Kc * (TB(op.g.rdx, j) + TB(op.g.rdz, i));
-    return rs_p[c] * unscale * op.etan[c] / (op.Kc * op.Kc);
+    // unscale = Kc (1/dx + 1/dz);  S^-1 = eta_n / Kc^2   ->   rs * (1/dx + 1/dz) * eta_n / Kc
+    return rs_p[c] * (TB(op.g.rdx, j) + TB(op.g.rdz, i)) * op.etan[c] * op.iKc;
 }
 
 // z_p = S^-1 r_p at one pressure node, from the SCALED residual (ghost/anchor rows: r/Kc = rs;
@@ -493,15 +493,26 @@ __global__ __launch_bounds__(256) void k_prec_stage1(PlStokesOp op, PlVvOp vop, 
     const long long P = op.g.plane;
     const int p = op.g.pitch;
     const double* rs_p = rs + 2 * P;
-    double sz, sx, sp;
-    stokes_row_scales(op, i, j, c, sz, sx, sp);
     const double zp_c = prec_p_value(op, rs_p, i, j, c);
     int moff; double s;
     double fz = 0.0, fx = 0.0;
-    if (vv_cls_z(vop, i, j, moff, s) == VV_INT)
-        fz = rs[c] / sz + 2.0 * op.Kc * TB(op.g.rDz, i) * (zp_c - prec_p_value(op, rs_p, i - 1, j, c - p));
-    if (vv_cls_x(vop, i, j, moff, s) == VV_INT)
-        fx = rs[c + P] / sx + 2.0 * op.Kc * TB(op.g.rDx, j) * (zp_c - prec_p_value(op, rs_p, i, j - 1, c - 1));
+    // un-scaling an interior momentum row = multiplying by the sum of its 4 own-component coefficients
+    if (vv_cls_z(vop, i, j, moff, s) == VV_INT) {
+        const PlGeom& g = op.g;
+        const double rdz_i = TB(g.rdz, i), rdz_m = TB(g.rdz, i - 1), rDz_i = TB(g.rDz, i);
+        const double rdx_j = TB(g.rdx, j), rDx_j = TB(g.rDx, j), rDx_p = TB(g.rDx, j + 1);
+        const double sum = 4.0 * op.etan[c] * rdz_i * rDz_i + 4.0 * op.etan[c - p] * rdz_m * rDz_i +
+                           2.0 * op.etas[c + 1] * rDx_p * rdx_j + 2.0 * op.etas[c] * rDx_j * rdx_j;
+        fz = rs[c] * sum + 2.0 * op.Kc * rDz_i * (zp_c - prec_p_value(op, rs_p, i - 1, j, c - p));
+    }
+    if (vv_cls_x(vop, i, j, moff, s) == VV_INT) {
+        const PlGeom& g = op.g;
+        const double rdx_j = TB(g.rdx, j), rdx_m = TB(g.rdx, j - 1), rDx_j = TB(g.rDx, j);
+        const double rdz_i = TB(g.rdz, i), rDz_i = TB(g.rDz, i), rDz_p = TB(g.rDz, i + 1);
+        const double sum = 4.0 * op.etan[c] * rdx_j * rDx_j + 4.0 * op.etan[c - 1] * rdx_m * rDx_j +
+                           2.0 * op.etas[c + p] * rDz_p * rdz_i + 2.0 * op.etas[c] * rDz_i * rdz_i;
+        fx = rs[c + P] * sum + 2.0 * op.Kc * rDx_j * (zp_c - prec_p_value(op, rs_p, i, j - 1, c - 1));
+    }
     f[c] = fz; f[c + P] = fx; z[c + 2 * P] = zp_c;
     }
 }
@@ -596,6 +607,7 @@ struct PlSolver {
     // transfer (identical numerics to one rank); 1 = once per level and direction; 0 = none (slab-local
     // smoothing with frozen zero halos; only the replicated coarse tail couples the slabs)
     int mg_halo = 2;
+    int tail_nu_pre = -1, tail_nu_post = -1;        // smoothing sweeps on the replicated tail levels (-1: same as nu)
     double cheb_ratio = 6.0, lmax_safety = 1.1;     // smoothing window [lmax/ratio, lmax]; lmax = safety * power-iteration estimate
     // heat work vectors (1 plane each)
     double* h[9] = {nullptr};
@@ -610,6 +622,7 @@ static PlSolver* solver_of(pl_ctx* ctx) {
         if (const char* e = getenv("PYLAMP_MG_COARSE")) { int a = atoi(e); if (a > 0) S->coarse_sweeps = a; }
         if (const char* e = getenv("PYLAMP_MG_TAIL")) S->use_tail = atoi(e) != 0;
         if (const char* e = getenv("PYLAMP_MG_HALO")) S->mg_halo = atoi(e);
+        if (const char* e = getenv("PYLAMP_MG_TAIL_NU")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a + b > 0) { S->tail_nu_pre = a; S->tail_nu_post = b; } }
         if (const char* e = getenv("PYLAMP_MG_RATIO")) { double v = atof(e); if (v > 1.5) S->cheb_ratio = v; }
         if (const char* e = getenv("PYLAMP_MG_SAFETY")) { double v = atof(e); if (v >= 1.0) S->lmax_safety = v; }
         ctx->krylov = S;
@@ -844,7 +857,8 @@ static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const double* f, double**
     if (S->use_tail && l > 0 && (long long)g.nz * g.nx <= PL_TAIL_MAX_NODES &&
         S->levels.size() - l <= PL_TAIL_MAX_LEVELS && f == L->f) {
         TailArgs ta{};
-        ta.nlev = (int)(S->levels.size() - l); ta.nu_pre = S->nu_pre; ta.nu_post = S->nu_post;
+        ta.nlev = (int)(S->levels.size() - l);
+        ta.nu_pre = S->tail_nu_pre >= 0 ? S->tail_nu_pre : S->nu_pre; ta.nu_post = S->tail_nu_post >= 0 ? S->tail_nu_post : S->nu_post;
         ta.coarse_sweeps = coarsest_sweeps(S, S->levels.back()->gh.d); ta.ratio = S->cheb_ratio;
         for (int q = 0; q < ta.nlev; q++) {
             MgLevel* T = S->levels[l + q];

@@ -1,9 +1,9 @@
 // Device-resident time step: the build's counterpart of the loop body of pylamp2.py:273-581
 // (property update, 4 scatters, time-step selection, Stokes solve, heat solve, temperature
 // to tracers + subgrid diffusion, velocity re-centring + ghost fill, RK4 advection, fence).
+// plus the end-of-step cell sort, slab migration and census / injection (pylamp2.py:588-633).
 // Tracers and every grid field stay in HBM across steps; the host only sees scalars.
-// Not included ("next"): tracer deletion / census / injection
-// (pylamp2.py:574-633).
+// Not included: tracer deletion (pylamp2.py:574-581) - it cannot trigger with the supported walls.
 #include "pl_internal.h"
 #include "pl_mic.h"
 #include <chrono>

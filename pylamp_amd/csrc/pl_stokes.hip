@@ -357,7 +357,7 @@ void pl_stokes_fill_op(pl_ctx* ctx, double* etas, double* etan, double* rho, con
     PlStokesOp& op = ctx->sop;
     op.g = ctx->geom.d;
     op.etas = etas; op.etan = etan; op.rho = rho;
-    op.Kc = Kc; op.Kb = Kb;
+    op.Kc = Kc; op.Kb = Kb; op.iKc = 1.0 / Kc;
     op.bc_z0 = bc[0]; op.bc_zL = bc[2];
     op.surfstab = surfstab ? 1 : 0; op.ss = theta * tstep;
     op.anchor_i = 3; op.anchor_j = 2;
