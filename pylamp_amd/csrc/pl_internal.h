@@ -97,6 +97,26 @@ inline dim3 pl_grid_rows(const PlGeom& g) {
     const int it = pl_row_iters(g);
     return dim3((g.lnx + 63) / 64, (g.lnz + 4 * it - 1) / (4 * it));
 }
+// ---- two-columns-per-lane row loads (see k_stokes_apply_v2) ----
+struct Row2 { double2 v; double w, e; };           // w = value at j-1 of .x ; e = value at j+1 of .y
+
+__device__ inline Row2 load_row2(const double* __restrict__ row, int lj0, bool active, bool need_w, bool need_e,
+                                 int lane, bool has_right) {
+    Row2 r;
+    r.v = active ? *reinterpret_cast<const double2*>(row + lj0) : make_double2(0.0, 0.0);
+    r.w = 0.0; r.e = 0.0;
+    if (need_w) {
+        const double up = __shfl_up(r.v.y, 1, 64);
+        r.w = (lane == 0) ? (active ? row[lj0 - 1] : 0.0) : up;
+    }
+    if (need_e) {
+        const double dn = __shfl_down(r.v.x, 1, 64);
+        r.e = (lane == 63 || !has_right) ? (active ? row[lj0 + 2] : 0.0) : dn;
+    }
+    return r;
+}
+
+
 #define PL_ROW_LOOP(g, iters)                                                           \
     const int lj = blockIdx.x * 64 + threadIdx.x;                                       \
     if (lj >= (g).lnx) return;                                                          \

@@ -102,40 +102,36 @@ __device__ inline void vv_row_x(const PlVvOp& op, const double* __restrict__ vz,
 // update; all inputs are read-only so there is no ordering hazard).  80 B/node/sweep.
 // (32-bit element offsets from wave-uniform plane bases keep the address arithmetic in SGPR-base +
 // VGPR-offset form: fewer VGPRs, more waves per SIMD)
+__device__ inline double cheb_val_z(const PlVvOp& op, const double* __restrict__ vcur, const double* __restrict__ vprev,
+                                    const double* __restrict__ f, double c1, double c2, int i, int j, int c) {
+    int moff = 0; double s = 1.0;
+    if (vv_cls_z(op, i, j, moff, s) == VV_ZERO) return 0.0;
+    const int cm = c + moff;
+    double Av, dg;
+    vv_row_z(op, vcur, vcur + op.g.plane, cm, i, j + moff, Av, dg);   // moff is +-1 for vz
+    const double v0 = vcur[cm];
+    const double mom = (c1 != 0.0) ? c1 * (v0 - (vprev ? vprev[cm] : 0.0)) : 0.0;   // nullptr: previous iterate is zero
+    return s * (v0 + mom + c2 * (Av - f[cm]) / dg);                     // D = -dg
+}
+__device__ inline double cheb_val_x(const PlVvOp& op, const double* __restrict__ vcur, const double* __restrict__ vprev,
+                                    const double* __restrict__ f, double c1, double c2, int i, int j, int c) {
+    const long long P = op.g.plane;
+    int moff = 0; double s = 1.0;
+    if (vv_cls_x(op, i, j, moff, s) == VV_ZERO) return 0.0;
+    const int cm = c + moff;
+    const int im = i + (moff > 0 ? 1 : (moff < 0 ? -1 : 0));
+    double Av, dg;
+    vv_row_x(op, vcur, vcur + P, cm, im, j, Av, dg);
+    const double v0 = (vcur + P)[cm];
+    const double mom = (c1 != 0.0) ? c1 * (v0 - (vprev ? (vprev + P)[cm] : 0.0)) : 0.0;
+    return s * (v0 + mom + c2 * (Av - (f + P)[cm]) / dg);
+}
 __device__ inline void cheb_node(const PlVvOp& op, const double* __restrict__ vcur, const double* __restrict__ vprev,
                                  const double* __restrict__ f, double* __restrict__ vnext, double c1, double c2, int i,
                                  int j, long long c64) {
-    const long long P = op.g.plane;
     const int c = (int)c64;
-    const double* __restrict__ vz = vcur; const double* __restrict__ vx = vcur + P;
-    const double* __restrict__ pz = vprev; const double* __restrict__ px = vprev + P;
-    const bool has_prev = vprev != nullptr;                         // nullptr: previous iterate is zero
-    const double* __restrict__ fz = f; const double* __restrict__ fx = f + P;
-    double* __restrict__ nz_ = vnext; double* __restrict__ nx_ = vnext + P;
-    int moff = 0; double s = 1.0;
-    int cls = vv_cls_z(op, i, j, moff, s);
-    double out = 0.0;
-    if (cls != VV_ZERO) {
-        const int cm = c + moff;
-        double Av, dg;
-        vv_row_z(op, vz, vx, cm, i, j + moff, Av, dg);             // moff is +-1 for vz
-        const double v0 = vz[cm];
-        const double mom = (c1 != 0.0) ? c1 * (v0 - (has_prev ? pz[cm] : 0.0)) : 0.0;
-        out = s * (v0 + mom + c2 * (Av - fz[cm]) / dg);             // D = -dg
-    }
-    nz_[c] = out;
-    cls = vv_cls_x(op, i, j, moff, s);
-    out = 0.0;
-    if (cls != VV_ZERO) {
-        const int cm = c + moff;
-        const int im = i + (moff > 0 ? 1 : (moff < 0 ? -1 : 0));
-        double Av, dg;
-        vv_row_x(op, vz, vx, cm, im, j, Av, dg);
-        const double v0 = vx[cm];
-        const double mom = (c1 != 0.0) ? c1 * (v0 - (has_prev ? px[cm] : 0.0)) : 0.0;
-        out = s * (v0 + mom + c2 * (Av - fx[cm]) / dg);
-    }
-    nx_[c] = out;
+    vnext[c] = cheb_val_z(op, vcur, vprev, f, c1, c2, i, j, c);
+    (vnext + op.g.plane)[c] = cheb_val_x(op, vcur, vprev, f, c1, c2, i, j, c);
 }
 
 // diagonal sums only (no velocity reads)
@@ -209,6 +205,119 @@ __global__ __launch_bounds__(256) void k_vv_residual(PlVvOp op, const double* __
     PL_ROW_LOOP(op.g, iters)
         residual_node(op, v, f, r, op.g.gi0 + li, op.g.gj0 + lj, pl_idx(op.g, li, lj));
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Two-columns-per-lane sweep (same reasoning as k_stokes_apply_v2: the scalar kernels keep the texture
+// address unit busy 88 % of the time).  MODE 0: Chebyshev sweep, MODE 1: residual.  A wave covers 128
+// columns of one row with double2 loads; west/east neighbours come from the adjacent lanes.  The two
+// wall-adjacent rows (vx slaved or zero) and the two slaved vz columns take the scalar path.
+struct VvVals {
+    double vz_c, vz_w, vz_e, vz_n, vz_s, vz_nw;
+    double vx_c, vx_w, vx_e, vx_n, vx_s, vx_se;
+    double en_c, en_w, en_s, es_c, es_e, es_n;
+    double rdx_j, rdx_m, rDx_j, rDx_p;
+};
+__device__ inline void vv_rows_vals(const VvVals& q, double rdz_i, double rdz_m, double rDz_i, double rDz_p,
+                                    double& Az, double& dz, double& Ax, double& dx) {
+    {
+        const double cN = 4.0 * q.en_c * rdz_i * rDz_i, cS = 4.0 * q.en_s * rdz_m * rDz_i;
+        const double cE = 2.0 * q.es_e * q.rDx_p * q.rdx_j, cW = 2.0 * q.es_c * q.rDx_j * q.rdx_j;
+        const double xE = 2.0 * q.es_e * rDz_i * q.rdx_j, xW = 2.0 * q.es_c * rDz_i * q.rdx_j;
+        Az = cN * (q.vz_n - q.vz_c) - cS * (q.vz_c - q.vz_s) + cE * (q.vz_e - q.vz_c) - cW * (q.vz_c - q.vz_w) +
+             xE * (q.vx_e - q.vx_se) - xW * (q.vx_c - q.vx_s);
+        dz = cN + cS + cE + cW;
+    }
+    {
+        const double cE = 4.0 * q.en_c * q.rdx_j * q.rDx_j, cW = 4.0 * q.en_w * q.rdx_m * q.rDx_j;
+        const double cN = 2.0 * q.es_n * rDz_p * rdz_i, cS = 2.0 * q.es_c * rDz_i * rdz_i;
+        const double zN = 2.0 * q.es_n * q.rDx_j * rdz_i, zS = 2.0 * q.es_c * q.rDx_j * rdz_i;
+        Ax = cE * (q.vx_e - q.vx_c) - cW * (q.vx_c - q.vx_w) + cN * (q.vx_n - q.vx_c) - cS * (q.vx_c - q.vx_s) +
+             zN * (q.vz_n - q.vz_nw) - zS * (q.vz_c - q.vz_w);
+        dx = cE + cW + cN + cS;
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_vv_sweep2(PlVvOp op, const double* __restrict__ vcur, const double* __restrict__ vprev,
+                                                   const double* f, double* out, double c1, double c2) {
+    const PlGeom& g = op.g;
+    const int lane = threadIdx.x;
+    const int lj0 = (blockIdx.x * 64 + lane) * 2;
+    const int li = blockIdx.y * 4 + threadIdx.y;
+    if (li >= g.lnz) return;                                // wave-uniform
+    const bool active = lj0 < g.lnx;
+    const bool has_right = (lj0 + 2) < g.lnx;
+    const int p = g.pitch, nz = g.nz, nx = g.nx;
+    const long long PLN = g.plane;
+    const int c = (int)pl_idx(g, li, lj0);
+    const int i = g.gi0 + li, j0 = g.gj0 + lj0;
+    if (i <= 0 || i >= nz - 2) {                            // wall rows and the slaved vx rows (wave-uniform)
+        if (!active) return;
+        for (int q = 0; q < 2 && lj0 + q < g.lnx; q++) {
+            if (MODE == 0) cheb_node(op, vcur, vprev, f, out, c1, c2, i, j0 + q, c + q);
+            else residual_node(op, vcur, f, out, i, j0 + q, c + q);
+        }
+        return;
+    }
+    const double* __restrict__ vz = vcur;
+    const double* __restrict__ vx = vcur + PLN;
+#define ROW(ptr, dr, w, e) load_row2((ptr) + (long long)c - lj0 + (long long)(dr) * p, lj0, active, w, e, lane, has_right)
+    const Row2 vz_s = ROW(vz, -1, false, false), vz_i = ROW(vz, 0, true, true), vz_n = ROW(vz, 1, true, false);
+    const Row2 vx_s = ROW(vx, -1, false, true), vx_i = ROW(vx, 0, true, true), vx_n = ROW(vx, 1, false, false);
+    const Row2 en_s = ROW(op.etan, -1, false, false), en_i = ROW(op.etan, 0, true, false);
+    const Row2 es_i = ROW(op.etas, 0, false, true), es_n = ROW(op.etas, 1, false, false);
+#undef ROW
+    const Row2 t_rdx = load_row2(g.rdx + PL_TOFF + g.gj0, lj0, active, true, false, lane, has_right);
+    const Row2 t_rDx = load_row2(g.rDx + PL_TOFF + g.gj0, lj0, active, false, true, lane, has_right);
+    if (!active) return;
+    const bool colB = (lj0 + 1) < g.lnx;
+    const double2 fz = *reinterpret_cast<const double2*>(f + c), fx = *reinterpret_cast<const double2*>(f + PLN + c);
+    double2 pz = make_double2(0.0, 0.0), px = pz;
+    if (MODE == 0 && c1 != 0.0 && vprev) {
+        pz = *reinterpret_cast<const double2*>(vprev + c); px = *reinterpret_cast<const double2*>(vprev + PLN + c);
+    }
+    const double rdz_i = TB(g.rdz, i), rdz_m = TB(g.rdz, i - 1), rDz_i = TB(g.rDz, i), rDz_p = TB(g.rDz, i + 1);
+    VvVals q;
+    double Az[2], dz[2], Ax[2], dx[2];
+    q.vz_c = vz_i.v.x; q.vz_w = vz_i.w; q.vz_e = vz_i.v.y; q.vz_n = vz_n.v.x; q.vz_s = vz_s.v.x; q.vz_nw = vz_n.w;
+    q.vx_c = vx_i.v.x; q.vx_w = vx_i.w; q.vx_e = vx_i.v.y; q.vx_n = vx_n.v.x; q.vx_s = vx_s.v.x; q.vx_se = vx_s.v.y;
+    q.en_c = en_i.v.x; q.en_w = en_i.w; q.en_s = en_s.v.x;
+    q.es_c = es_i.v.x; q.es_e = es_i.v.y; q.es_n = es_n.v.x;
+    q.rdx_j = t_rdx.v.x; q.rdx_m = t_rdx.w; q.rDx_j = t_rDx.v.x; q.rDx_p = t_rDx.v.y;
+    vv_rows_vals(q, rdz_i, rdz_m, rDz_i, rDz_p, Az[0], dz[0], Ax[0], dx[0]);
+    q.vz_c = vz_i.v.y; q.vz_w = vz_i.v.x; q.vz_e = vz_i.e; q.vz_n = vz_n.v.y; q.vz_s = vz_s.v.y; q.vz_nw = vz_n.v.x;
+    q.vx_c = vx_i.v.y; q.vx_w = vx_i.v.x; q.vx_e = vx_i.e; q.vx_n = vx_n.v.y; q.vx_s = vx_s.v.y; q.vx_se = vx_s.e;
+    q.en_c = en_i.v.y; q.en_w = en_i.v.x; q.en_s = en_s.v.y;
+    q.es_c = es_i.v.y; q.es_e = es_i.e; q.es_n = es_n.v.y;
+    q.rdx_j = t_rdx.v.y; q.rdx_m = t_rdx.v.x; q.rDx_j = t_rDx.v.y; q.rDx_p = t_rDx.e;
+    vv_rows_vals(q, rdz_i, rdz_m, rDz_i, rDz_p, Az[1], dz[1], Ax[1], dx[1]);
+    const double v0z[2] = {vz_i.v.x, vz_i.v.y}, v0x[2] = {vx_i.v.x, vx_i.v.y};
+    const double fzv[2] = {fz.x, fz.y}, fxv[2] = {fx.x, fx.y}, pzv[2] = {pz.x, pz.y}, pxv[2] = {px.x, px.y};
+    double oz[2], ox[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int j = j0 + k;
+        const bool zslave = op.slave_x && (j == 0 || j == nx - 2);
+        const bool zint = j < nx - 1 && !zslave, xint = j > 0 && j < nx - 1;
+        if (MODE == 0) {
+            const double mz = (c1 != 0.0) ? c1 * (v0z[k] - pzv[k]) : 0.0, mx = (c1 != 0.0) ? c1 * (v0x[k] - pxv[k]) : 0.0;
+            oz[k] = zint ? v0z[k] + mz + c2 * (Az[k] - fzv[k]) / dz[k] : 0.0;
+            ox[k] = xint ? v0x[k] + mx + c2 * (Ax[k] - fxv[k]) / dx[k] : 0.0;
+            if (zslave && (k == 0 || colB)) oz[k] = cheb_val_z(op, vcur, vprev, f, c1, c2, i, j, c + k);
+        } else {
+            oz[k] = zint ? fzv[k] - Az[k] : 0.0;
+            ox[k] = xint ? fxv[k] - Ax[k] : 0.0;
+        }
+    }
+    if (colB) {
+        *reinterpret_cast<double2*>(out + c) = make_double2(oz[0], oz[1]);
+        *reinterpret_cast<double2*>(out + PLN + c) = make_double2(ox[0], ox[1]);
+    } else {
+        out[c] = oz[0]; out[PLN + c] = ox[0];
+    }
+}
+
+static inline dim3 pl_grid_rows2(const PlGeom& g) { return dim3((g.lnx + 127) / 128, (g.lnz + 3) / 4); }
 
 // y = D^-1 A v with closure (power iteration for lambda_max)
 __global__ __launch_bounds__(256) void k_vv_dinv_apply(PlVvOp op, const double* __restrict__ v,
@@ -860,6 +969,9 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
     return 0;
 }
 
+// PYLAMP_VV_VEC=0 selects the scalar one-column-per-lane sweep kernels (kept as the cross-check)
+static const bool g_vv_vec = [] { const char* e = getenv("PYLAMP_VV_VEC"); return !(e && e[0] == '0'); }();
+
 // ---- smoothing and V-cycle ----------------------------------------------------------------
 // nsweep Chebyshev-Jacobi sweeps on level L; buf[0] is the current iterate on entry and on exit
 static void smooth(pl_ctx* ctx, MgLevel* L, double* buf[3], const double* f, int nsweep, double ratio,
@@ -878,8 +990,15 @@ static void smooth(pl_ctx* ctx, MgLevel* L, double* buf[3], const double* f, int
             hipLaunchKernelGGL(k_vv_cheb_first, pl_grid_rows(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, f, dst, c2,
                                pl_row_iters(L->gh.d));
         else
-            hipLaunchKernelGGL(k_vv_cheb, pl_grid_rows(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, buf[0],
-                               (k == 1 && zero_guess) ? (const double*)nullptr : buf[1], f, dst, c1, c2, pl_row_iters(L->gh.d));
+        {
+            const double* prev = (k == 1 && zero_guess) ? (const double*)nullptr : buf[1];
+            if (g_vv_vec)
+                hipLaunchKernelGGL(k_vv_sweep2<0>, pl_grid_rows2(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, buf[0], prev, f, dst,
+                                   c1, c2);
+            else
+                hipLaunchKernelGGL(k_vv_cheb, pl_grid_rows(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, buf[0], prev, f, dst, c1,
+                                   c2, pl_row_iters(L->gh.d));
+        }
         if (dst != buf[2]) { buf[1] = buf[0]; buf[0] = dst; }
         else { double* nxt = buf[2]; buf[2] = buf[1]; buf[1] = buf[0]; buf[0] = nxt; }    // (cur, prev, free)
     }
@@ -929,7 +1048,11 @@ static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const double* f, double**
     const int hp = S->mg_halo;
     smooth(ctx, L, buf, f, S->nu_pre, S->cheb_ratio, nullptr, true, hp);
     if (L->dist && hp >= 1) (void)pl_halo_rows(ctx, g, buf[0], 2, g.plane);
-    hipLaunchKernelGGL(k_vv_residual, pl_grid_rows(g), dim3(64, 4), 0, ctx->stream, L->op, buf[0], f, L->r, pl_row_iters(g));
+    if (g_vv_vec)
+        hipLaunchKernelGGL(k_vv_sweep2<1>, pl_grid_rows2(g), dim3(64, 4), 0, ctx->stream, L->op, buf[0], (const double*)nullptr, f,
+                           L->r, 0.0, 0.0);
+    else
+        hipLaunchKernelGGL(k_vv_residual, pl_grid_rows(g), dim3(64, 4), 0, ctx->stream, L->op, buf[0], f, L->r, pl_row_iters(g));
     if (L->dist && hp >= 1) (void)pl_halo_rows(ctx, g, L->r, 2, g.plane);
     MgLevel* C = S->levels[l + 1];
     if (L->dist && !C->dist) {

@@ -141,24 +141,6 @@ __global__ __launch_bounds__(256, PL_APPLY_WAVES) void k_stokes_apply(PlStokesOp
 // width, so double2 halves the address cycles per byte and there are 14 instead of 34 loads per wave.
 // A wave covers 128 columns of one row; rows/columns outside the block are never dereferenced past
 // the ring (planes carry a ring row above/below and >= 1 pad column each side).
-struct Row2 { double2 v; double w, e; };           // w = value at j-1 of .x ; e = value at j+1 of .y
-
-__device__ inline Row2 load_row2(const double* __restrict__ row, int lj0, bool active, bool need_w, bool need_e,
-                                 int lane, bool has_right) {
-    Row2 r;
-    r.v = active ? *reinterpret_cast<const double2*>(row + lj0) : make_double2(0.0, 0.0);
-    r.w = 0.0; r.e = 0.0;
-    if (need_w) {
-        const double up = __shfl_up(r.v.y, 1, 64);
-        r.w = (lane == 0) ? (active ? row[lj0 - 1] : 0.0) : up;
-    }
-    if (need_e) {
-        const double dn = __shfl_down(r.v.x, 1, 64);
-        r.e = (lane == 63 || !has_right) ? (active ? row[lj0 + 2] : 0.0) : dn;
-    }
-    return r;
-}
-
 // all values one node needs, as scalars
 struct StokesVals {
     double vz_c, vz_w, vz_e, vz_n, vz_s, vz_nw;      // n = row i+1, s = row i-1, nw = (i+1, j-1)
