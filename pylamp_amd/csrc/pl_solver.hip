@@ -755,6 +755,9 @@ struct PlSolver {
     double* hpart = nullptr;    // pinned host copy of the dot partials
     int nu_pre = 2, nu_post = 2, coarse_sweeps = 12;
     bool use_tail = true;
+    long long tail_knob = 0;                            // PYLAMP_MG_TAIL_NODES (0: automatic)
+    long long tail_max_nodes = 33 * 33;                 // levels up to this size run in the fused tail kernel
+    int min_cells = 4;                                  // coarsest grid has >= min_cells cells per side (PYLAMP_MG_MINCELLS)
     // halo policy inside the V-cycle on distributed levels: 2 = exchange before every sweep / residual /
     // transfer (identical numerics to one rank); 1 = once per level and direction; 0 = none (slab-local
     // smoothing with frozen zero halos; only the replicated coarse tail couples the slabs)
@@ -773,6 +776,8 @@ static PlSolver* solver_of(pl_ctx* ctx) {
         if (const char* e = getenv("PYLAMP_MG_NU")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b >= 0 && a + b > 0) { S->nu_pre = a; S->nu_post = b; } }
         if (const char* e = getenv("PYLAMP_MG_COARSE")) { int a = atoi(e); if (a > 0) S->coarse_sweeps = a; }
         if (const char* e = getenv("PYLAMP_MG_TAIL")) S->use_tail = atoi(e) != 0;
+        if (const char* e = getenv("PYLAMP_MG_MINCELLS")) { int v = atoi(e); if (v >= 2) S->min_cells = v; }
+        if (const char* e = getenv("PYLAMP_MG_TAIL_NODES")) { long long v = atoll(e); if (v >= 25 && v <= PL_TAIL_MAX_NODES) S->tail_knob = v; }
         if (const char* e = getenv("PYLAMP_MG_HALO")) S->mg_halo = atoi(e);
         if (const char* e = getenv("PYLAMP_MG_TAIL_NU")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a + b > 0) { S->tail_nu_pre = a; S->tail_nu_post = b; } }
         if (const char* e = getenv("PYLAMP_MG_RATIO")) { double v = atof(e); if (v > 1.5) S->cheb_ratio = v; }
@@ -880,11 +885,15 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
         free_levels(S);
         int nz = ctx->nz, nx = ctx->nx;
         std::vector<double> zc = ctx->geom.zc, xc = ctx->geom.xc;
+        // one GPU: the 65^2 level is faster as ordinary kernels (64 workgroups) than inside the single-workgroup
+        // tail (94 vs 99 ms per solve at 2049^2); several ranks: every distributed level costs halo exchanges, so
+        // the replicated tail starts as early as it can
+        S->tail_max_nodes = S->tail_knob ? S->tail_knob : (R > 1 ? (long long)PL_TAIL_MAX_NODES : 33LL * 33);
         S->tail_start = -1;
         for (int l = 0;; l++) {
             MgLevel* L = new MgLevel();
             if (pl_geom_build(ctx, L->gh, nz, nx, zc.data(), xc.data())) { delete L; return 1; }
-            if (S->tail_start < 0 && l > 0 && (long long)nz * nx <= PL_TAIL_MAX_NODES) S->tail_start = l;
+            if (S->tail_start < 0 && l > 0 && (long long)nz * nx <= S->tail_max_nodes) S->tail_start = l;
             if (R > 1 && S->tail_start < 0) {                     // distributed level
                 const int C = (nz - 1) / R;
                 if ((nz - 1) % R || C < 2 || (C % 2)) { delete L; return pl_fail(ctx, "multigrid: (nz-1) must be divisible by ranks*2^levels down to the replicated coarse grid"); }
@@ -905,7 +914,7 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
             for (int q = 0; q < 3; q++) PL_TRY(dmalloc0(ctx, &L->v[q], vb));
             PL_TRY(dmalloc0(ctx, &L->f, vb)); PL_TRY(dmalloc0(ctx, &L->r, vb));
             S->levels.push_back(L);
-            if ((nz - 1) % 2 || (nx - 1) % 2 || (nz - 1) / 2 < 4 || (nx - 1) / 2 < 4) break;
+            if ((nz - 1) % 2 || (nx - 1) % 2 || (nz - 1) / 2 < S->min_cells || (nx - 1) / 2 < S->min_cells) break;
             std::vector<double> z2, x2;
             for (int i = 0; i < nz; i += 2) z2.push_back(zc[i]);
             for (int j = 0; j < nx; j += 2) x2.push_back(xc[j]);
@@ -1020,7 +1029,7 @@ static int coarsest_sweeps(const PlSolver* S, const PlGeom& g) {
 static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const double* f, double** out, double* final_out = nullptr) {
     MgLevel* L = S->levels[l];
     const PlGeom& g = L->gh.d;
-    if (S->use_tail && l > 0 && (long long)g.nz * g.nx <= PL_TAIL_MAX_NODES &&
+    if (S->use_tail && l > 0 && (long long)g.nz * g.nx <= S->tail_max_nodes &&
         S->levels.size() - l <= PL_TAIL_MAX_LEVELS && f == L->f) {
         TailArgs ta{};
         ta.nlev = (int)(S->levels.size() - l);
