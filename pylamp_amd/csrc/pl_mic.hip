@@ -74,6 +74,23 @@ __global__ __launch_bounds__(256) void k_scatter_atomic(PlScatterArgs a) {
     }
 }
 
+// inclusive sum over the run of lanes [lane - reach, lane] inside a row of 16 lanes (DPP row_shr: pure VALU,
+// lanes without a source read 0)
+template <int D> __device__ inline double dpp_row_shr(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x110 + D, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x110 + D, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline double run_sum(double v, int reach) {
+    double o;
+    o = dpp_row_shr<1>(v); v += (reach >= 1) ? o : 0.0;
+    o = dpp_row_shr<2>(v); v += (reach >= 2) ? o : 0.0;
+    o = dpp_row_shr<4>(v); v += (reach >= 4) ? o : 0.0;
+    o = dpp_row_shr<8>(v); v += (reach >= 8) ? o : 0.0;
+    return v;
+}
+
 // Cell-sorted tracers: one workgroup per tile of PL_TILE_R x PL_TILE_C sort cells.  The tile's
 // tracers are PL_TILE_R contiguous runs; their contributions are accumulated with LDS atomics
 // (ds_add_f64) into a (R+2) x (C+2) node window (one extra ring so that every staggering of the
@@ -85,7 +102,7 @@ __global__ __launch_bounds__(256) void k_scatter_binned(PlScatterArgs a, int til
     extern __shared__ double lds[];
     const int W = PL_TILE_C + 2, H = PL_TILE_R + 2, WH = W * H;
     const int nacc = a.nf + 2;                                  // [0]=wsum, [1]=cnt, [2+k]=field k
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int ti = blockIdx.x / tiles_x, tj = blockIdx.x % tiles_x;
     const int ci0 = ti * PL_TILE_R, cj0 = tj * PL_TILE_C;
     const int ni0 = a.crow0 + ci0 - 1;                          // global node row of window row 0
@@ -96,35 +113,48 @@ __global__ __launch_bounds__(256) void k_scatter_binned(PlScatterArgs a, int til
         const int ci = ci0 + r;
         if (ci >= a.ncz) break;
         const long long t0 = a.cell_start[(long long)ci * a.ncx + cj0], t1 = a.cell_start[(long long)ci * a.ncx + cj1];
-        for (long long t = t0 + tid; t < t1; t += 256) {
-            const double z = a.tz[t], x = a.tx[t];
+        for (long long base = t0; base < t1; base += 256) {          // uniform trip count: every lane takes part in the DPP steps
+            const long long t = base + tid;
+            const bool valid = t < t1;
+            double z = 0.0, x = 0.0;
+            if (valid) { z = a.tz[t]; x = a.tx[t]; }
             const double fz = floor((z - a.z0) / a.hz), fx = floor((x - a.x0) / a.hx);
-            const int ie = (int)fz, je = (int)fx;
+            const int ie = valid ? (int)fz : -0x40000000 - lane, je = (int)fx;   // invalid lanes never share a segment
             const double ca = (z - (a.z0 + fz * a.hz)) / a.hz, cb = (x - (a.x0 + fx * a.hx)) / a.hx;
             const double w[4] = {(1 - cb) * (1 - ca), (1 - cb) * ca, cb * (1 - ca), cb * ca};
             double val[PL_MAX_SCATTER_FIELDS];
             for (int k = 0; k < a.nf; k++) {
-                const double v = a.f[k][t];
+                const double v = valid ? a.f[k][t] : 1.0;
                 val[k] = (a.scheme[k] & PL_AVG_GEOMETRIC) && !(a.scheme[k] & PL_AVG_ARITHMETIC) ? log(v) : v;
             }
+            // runs of consecutive lanes in the same target cell (the tracers are cell-sorted) are summed in registers
+            // first, so that one lane per run issues the LDS atomics: 16 markers per cell made every ds_add_f64 a
+            // 16-way same-address conflict (~150 cycles per wave instruction)
+            const int ie_p = __builtin_amdgcn_update_dpp(0, ie, 0x111, 0xf, 0xf, false);
+            const int je_p = __builtin_amdgcn_update_dpp(0, je, 0x111, 0xf, 0xf, false);
+            const bool head = (lane & 15) == 0 || ie_p != ie || je_p != je;
+            const unsigned long long heads = __ballot(head);
+            const int seg0 = 63 - __clzll(heads & (~0ull >> (63 - lane)));       // first lane of my run (same row of 16)
+            const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
+            const int reach = lane - seg0;                                        // lanes to my left in the run
 #pragma unroll
             for (int cnr = 0; cnr < 4; cnr++) {
                 const int ni = ie + (cnr & 1), nj = je + (cnr >> 1);
-                if (ni < 0 || ni >= a.nz || nj < 0 || nj >= a.nx) continue;
-                if (ni < a.row0 || ni >= a.row0 + a.nrows) continue;
+                const bool ok = valid && ni >= 0 && ni < a.nz && nj >= 0 && nj < a.nx && ni >= a.row0 && ni < a.row0 + a.nrows;
                 const int li = ni - ni0, lj = nj - (cj0 - 1);
-                if (li >= 0 && li < H && lj >= 0 && lj < W) {
-                    const int o = li * W + lj;
-                    if (a.wsum) unsafeAtomicAdd(&lds[o], w[cnr]);
-                    if (a.cnt) unsafeAtomicAdd(&lds[WH + o], 1.0);
-                    for (int k = 0; k < a.nf; k++)
-                        unsafeAtomicAdd(&lds[(2 + k) * WH + o], (a.scheme[k] & PL_AVG_WEIGHTED) ? val[k] * w[cnr] : val[k]);
-                } else {
-                    const long long o = (long long)(ni - a.row0) * a.nx + nj;
-                    if (a.wsum) mic_atomic_add(a.wsum + o, w[cnr]);
-                    if (a.cnt) mic_atomic_add(a.cnt + o, 1.0);
-                    for (int k = 0; k < a.nf; k++)
-                        mic_atomic_add(a.acc[k] + o, (a.scheme[k] & PL_AVG_WEIGHTED) ? val[k] * w[cnr] : val[k]);
+                const bool in_win = li >= 0 && li < H && lj >= 0 && lj < W;
+                const int o = li * W + lj;
+                const long long go = (long long)(ni - a.row0) * a.nx + nj;
+                for (int q = 0; q < nacc; q++) {
+                    if (q == 0 && !a.wsum) continue;                              // wave-uniform
+                    if (q == 1 && !a.cnt) continue;
+                    double v = (q == 0) ? w[cnr] : (q == 1) ? 1.0 : ((a.scheme[q - 2] & PL_AVG_WEIGHTED) ? val[q - 2] * w[cnr] : val[q - 2]);
+                    if (!valid) v = 0.0;
+                    v = run_sum(v, reach);
+                    if (tail && ok) {
+                        if (in_win) unsafeAtomicAdd(&lds[q * WH + o], v);
+                        else mic_atomic_add((q == 0 ? a.wsum : q == 1 ? a.cnt : a.acc[q - 2]) + go, v);
+                    }
                 }
             }
         }
