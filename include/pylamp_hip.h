@@ -105,7 +105,9 @@ int  pl_timer_stop_ms(pl_ctx* ctx, double* ms);
 /* Upload viscosity/density and fix the operator.  bc = [z0, x0, zL, xL]
  * (index DIM*wall+dir as in pylamp_stokes.py:163,202,242,289).  Computes Kcont/Kbond
  * exactly as pylamp_stokes.py:116-122.  surfstab != 0 adds the stabilisation terms of
- * pylamp_stokes.py:422-426,483-487 with the given tstep and theta. */
+ * pylamp_stokes.py:422-426,483-487 with the given tstep and theta.  The terms are linear in
+ * theta; the reference's sign makes them ANTI-stabilising (they reduce the momentum diagonal, see
+ * DESIGN.md section 5), a negative theta gives the damping sign of Duretz et al. (2011). */
 int  pl_stokes_set_coeffs(pl_ctx* ctx, const double* etas, const double* etan, const double* rho,
                           const int bc[4], int surfstab, double tstep, double theta);
 int  pl_stokes_get_scaling(pl_ctx* ctx, double* kcont, double* kbond);
@@ -182,7 +184,8 @@ typedef struct pl_step_config {
     uint64_t inject_seed;
     /* Free-surface stabilisation (pylamp2.py:71-73,352-355,368-372,387-405): with
      * surfstab_tstep < 0 the Stokes system is re-assembled with the chosen time step and re-solved
-     * until the step no longer shrinks (limiter 's' = the reference's "Ss"). */
+     * until the step no longer shrinks (limiter 's' = the reference's "Ss").  surfstab_theta < 0
+     * selects the corrected (damping) sign, see pl_stokes_set_coeffs. */
     int    surface_stabilization;
     double surfstab_theta, surfstab_tstep;
 } pl_step_config;

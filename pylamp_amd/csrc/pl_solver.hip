@@ -32,6 +32,9 @@ struct PlVvOp {
     int slave_x;            // vz rows j=0 / j=nx-2 slaved to their inner neighbour (reference rows)
     int slave_z0, slave_zL; // vx rows i=0 / i=nz-2 slaved (reference rows, or NOSLIP on any level)
     double s0, sL;          // slave factor: v_slave = s * v_master
+    // free-surface stabilisation terms of the z-momentum rows (pylamp_stokes.py:422-426), or NULL:
+    // row_z += szz * vz[c] + szx * vx[c]   (the x rows carry G[IX] = 0 and are left alone)
+    const double* szz; const double* szx;
 };
 
 enum { VV_ZERO = 0, VV_INT = 1, VV_SLAVE = 2 };
@@ -56,6 +59,10 @@ __device__ inline int vv_cls_x(const PlVvOp& op, int i, int j, int& moff, double
     return VV_INT;
 }
 
+// diagonal of a stabilised row is -dg + szz; the smoother keeps it at least half the viscous one
+// (the reference's sign of the term REDUCES the diagonal)
+__device__ inline double vv_stab_diag(double dg, double szz) { const double d = dg - szz; return d > 0.5 * dg ? d : 0.5 * dg; }
+
 // (A_vv v)_z and -diag at global node (i,j), plane offset c.  Zero-padded tables make the
 // mirror terms of the natural rows vanish (rDx[0] = rDx[nx-1] = 0, same in z).
 __device__ inline void vv_row_z(const PlVvOp& op, const double* __restrict__ vz, const double* __restrict__ vx,
@@ -72,6 +79,11 @@ __device__ inline void vv_row_z(const PlVvOp& op, const double* __restrict__ vz,
     Av = cN * (vz[c + p] - v0) - cS * (v0 - vz[c - p]) + cE * (vz[c + 1] - v0) - cW * (v0 - vz[c - 1]) +
          xE * (vx[c + 1] - vx[c - p + 1]) - xW * (vx[c] - vx[c - p]);
     dg = cN + cS + cE + cW;
+    if (op.szz) {                                   // wave-uniform
+        const double sd = op.szz[c];
+        Av += sd * v0 + op.szx[c] * vx[c];
+        dg = vv_stab_diag(dg, sd);
+    }
 }
 
 __device__ inline void vv_row_x(const PlVvOp& op, const double* __restrict__ vz, const double* __restrict__ vx,
@@ -138,8 +150,9 @@ __device__ inline void cheb_node(const PlVvOp& op, const double* __restrict__ vc
 __device__ inline double vv_diag_z(const PlVvOp& op, int c, int i, int j) {
     const PlGeom& g = op.g; const int p = g.pitch;
     const double rDz_i = TB(g.rDz, i), rdx_j = TB(g.rdx, j);
-    return 4.0 * op.etan[c] * TB(g.rdz, i) * rDz_i + 4.0 * op.etan[c - p] * TB(g.rdz, i - 1) * rDz_i +
-           2.0 * op.etas[c + 1] * TB(g.rDx, j + 1) * rdx_j + 2.0 * op.etas[c] * TB(g.rDx, j) * rdx_j;
+    const double dg = 4.0 * op.etan[c] * TB(g.rdz, i) * rDz_i + 4.0 * op.etan[c - p] * TB(g.rdz, i - 1) * rDz_i +
+                      2.0 * op.etas[c + 1] * TB(g.rDx, j + 1) * rdx_j + 2.0 * op.etas[c] * TB(g.rDx, j) * rdx_j;
+    return op.szz ? vv_stab_diag(dg, op.szz[c]) : dg;
 }
 __device__ inline double vv_diag_x(const PlVvOp& op, int c, int i, int j) {
     const PlGeom& g = op.g; const int p = g.pitch;
@@ -292,6 +305,11 @@ __global__ __launch_bounds__(256) void k_vv_sweep2(PlVvOp op, const double* __re
     q.rdx_j = t_rdx.v.y; q.rdx_m = t_rdx.v.x; q.rDx_j = t_rDx.v.y; q.rDx_p = t_rDx.e;
     vv_rows_vals(q, rdz_i, rdz_m, rDz_i, rDz_p, Az[1], dz[1], Ax[1], dx[1]);
     const double v0z[2] = {vz_i.v.x, vz_i.v.y}, v0x[2] = {vx_i.v.x, vx_i.v.y};
+    if (op.szz) {                                                   // wave-uniform
+        const double2 sd = *reinterpret_cast<const double2*>(op.szz + c), sx = *reinterpret_cast<const double2*>(op.szx + c);
+        Az[0] += sd.x * v0z[0] + sx.x * v0x[0]; dz[0] = vv_stab_diag(dz[0], sd.x);
+        Az[1] += sd.y * v0z[1] + sx.y * v0x[1]; dz[1] = vv_stab_diag(dz[1], sd.y);
+    }
     const double fzv[2] = {fz.x, fz.y}, fxv[2] = {fx.x, fx.y}, pzv[2] = {pz.x, pz.y}, pxv[2] = {px.x, px.y};
     double oz[2], ox[2];
 #pragma unroll
@@ -487,6 +505,39 @@ __global__ __launch_bounds__(1024) void k_mg_tail(TailArgs a) {
         const double* src = cur[0][0]; double* dst = a.L[0].v[0];
         TAIL_FOR_NODES(g) { const long long c = pl_idx(g, idx_ / g.lnx, idx_ % g.lnx); dst[c] = src[c]; dst[c + g.plane] = src[c + g.plane]; }
     }
+}
+
+// node field (density) by the same [1 2 1]x[1 2 1]/16 stencil
+__global__ __launch_bounds__(256) void k_coarsen_node(PlGeom gf, const double* __restrict__ ff, PlGeom gc,
+                                                      double* __restrict__ fc) {
+    PL_NODE_PROLOGUE(gc)
+    double acc = 0.0;
+#pragma unroll
+    for (int a = -1; a <= 1; a++)
+#pragma unroll
+        for (int q = -1; q <= 1; q++) {
+            const int fi = min(max(2 * i + a, 0), gf.nz - 1), fj = min(max(2 * j + q, 0), gf.nx - 1);
+            acc += (a == 0 ? 2.0 : 1.0) * (q == 0 ? 2.0 : 1.0) * ff[pl_idx(gf, fi - gf.gi0, fj - gf.gj0)];
+        }
+    fc[c] = acc * (1.0 / 16.0);
+}
+
+// stabilisation coefficients of the interior z-momentum rows of one level (rediscretised on its own grid):
+//   szz = coef * 1/2 (rho[i+1,j] + rho[i+1,j+1] - rho[i-1,j] - rho[i-1,j+1]) / (z[i+1]-z[i-1])
+//   szx = coef * 1/2 (rho[i,j+1] + rho[i+1,j+1] - rho[i,j-1] - rho[i+1,j-1]) / (x[j+1]-x[j-1]),  coef = theta dt G[IZ]
+__global__ __launch_bounds__(256) void k_stab_coeffs(PlVvOp op, const double* __restrict__ rho, double coef,
+                                                     double* __restrict__ szz, double* __restrict__ szx) {
+    PL_NODE_PROLOGUE(op.g)
+    int moff; double s;
+    double a = 0.0, b = 0.0;
+    if (vv_cls_z(op, i, j, moff, s) == VV_INT) {
+        const int p = op.g.pitch;
+        const int jm = (j > 0) ? -1 : 0, jp = (j < op.g.nx - 1) ? 1 : 0;      // natural coarse rows reach the wall column
+        const double hx = (jm && jp) ? TB(op.g.rDx, j) : TB(op.g.rdx, j);     // one-sided at the wall
+        a = coef * 0.5 * (rho[c + p] + rho[c + p + jp] - rho[c - p] - rho[c - p + jp]) * TB(op.g.rDz, i);
+        b = coef * 0.5 * (rho[c + jp] + rho[c + p + jp] - rho[c + jm] - rho[c + p + jm]) * hx;
+    }
+    szz[c] = a; szx[c] = b;
 }
 
 // arithmetic viscosity coarsening: nodes by a [1 2 1]x[1 2 1]/16 stencil (edge-clamped),
@@ -739,6 +790,8 @@ struct MgLevel {
     int win_rows0 = 0;
     PlVvOp op{};
     double* etas = nullptr; double* etan = nullptr; bool own_visc = false;
+    double *rho = nullptr, *szz = nullptr, *szx = nullptr;     // free-surface stabilisation (allocated on first use)
+    bool own_rho = false;
     double* v[3] = {nullptr, nullptr, nullptr};      // rotating Chebyshev buffers (2 planes each)
     double *f = nullptr, *r = nullptr;
     double lmax = 3.0;
@@ -790,6 +843,8 @@ static PlSolver* solver_of(pl_ctx* ctx) {
 static void free_levels(PlSolver* S) {
     for (MgLevel* L : S->levels) {
         if (L->own_visc) { (void)hipFree(L->etas); (void)hipFree(L->etan); }
+        if (L->own_rho && L->rho) (void)hipFree(L->rho);
+        for (double* q : {L->szz, L->szx}) if (q) (void)hipFree(q);
         for (double* q : {L->v[0], L->v[1], L->v[2], L->f, L->r}) if (q) (void)hipFree(q);
         pl_geom_free(L->gh);
         delete L;
@@ -854,6 +909,7 @@ static int dots(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const double*
 static void level_flags(MgLevel* L, const PlStokesOp& sop, bool finest) {
     PlVvOp& o = L->op;
     o.g = L->gh.d; o.etas = L->etas; o.etan = L->etan;
+    o.szz = nullptr; o.szx = nullptr;               // attached by build_hierarchy when the operator is stabilised
     o.slave_x = finest ? 1 : 0;
     const bool ns0 = sop.bc_z0 != PL_BC_FREESLIP, nsL = sop.bc_zL != PL_BC_FREESLIP;
     o.slave_z0 = (finest || ns0) ? 1 : 0;
@@ -956,6 +1012,37 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
         if (R > 1 && (int)l == S->tail_start) {           // window view shares flags and pointers (shifted)
             const PlGeom w = L->win;
             (void)w;
+        }
+    }
+    if (sop.surfstab && sop.ss != 0.0 && sop.gz != 0.0) {
+        // stabilisation-aware velocity block: density coarsened like the nodal viscosity, terms rediscretised per level
+        const double coef = sop.ss * sop.gz;
+        for (size_t l = 0; l < S->levels.size(); l++) {
+            MgLevel* L = S->levels[l];
+            const size_t pb = (size_t)L->gh.d.plane * sizeof(double);
+            if (!L->szz) {
+                PL_TRY(dmalloc0(ctx, &L->szz, pb)); PL_TRY(dmalloc0(ctx, &L->szx, pb));
+                if (l > 0) { PL_TRY(dmalloc0(ctx, &L->rho, pb)); L->own_rho = true; }
+            }
+            if (l == 0) { L->rho = (double*)sop.rho; continue; }
+            MgLevel* F = S->levels[l - 1];
+            if (F->dist && l > 1) PL_TRY(pl_halo_rows(ctx, F->gh.d, F->rho, 1, F->gh.d.plane));
+            if (R > 1 && (int)l == S->tail_start) {
+                const long long sh = (long long)L->win_rows0 * L->gh.d.pitch;
+                hipLaunchKernelGGL(k_coarsen_node, grid2d(L->win), dim3(64, 4), 0, ctx->stream, F->gh.d, F->rho, L->win, L->rho + sh);
+                const long long cnt = (long long)((L->gh.d.nz - 1) / R) * L->gh.d.pitch;
+                PL_TRY(pl_comm_allgather(ctx, L->rho + L->gh.d.pitch, cnt, 1, 0));
+                PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                PL_TRY(share_last_row(ctx, L->gh.d, L->rho));
+            } else {
+                hipLaunchKernelGGL(k_coarsen_node, grid2d(L->gh.d), dim3(64, 4), 0, ctx->stream, F->gh.d, F->rho, L->gh.d, L->rho);
+            }
+        }
+        for (size_t l = 0; l < S->levels.size(); l++) {
+            MgLevel* L = S->levels[l];
+            if (L->dist && l > 0) PL_TRY(pl_halo_rows(ctx, L->gh.d, L->rho, 1, L->gh.d.plane));
+            hipLaunchKernelGGL(k_stab_coeffs, grid2d(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, L->rho, coef, L->szz, L->szx);
+            L->op.szz = L->szz; L->op.szx = L->szx;
         }
     }
     PL_HIP(ctx, hipGetLastError());

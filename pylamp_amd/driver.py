@@ -38,6 +38,8 @@ class Options:
         self.heat_rtol, self.heat_maxit = 1e-12, 2000
         self.tracdens, self.tracdens_min, self.inject_seed = 0, 0, 12345     # pylamp2.py:39-40; 0 = no injection
         self.surface_stabilization, self.surfstab_theta, self.surfstab_tstep = False, 0.5, -1.0   # pylamp2.py:71-73
+        # False: corrected (damping) sign of the stabilisation terms, see pylamp_stokes.makeStokesMatrix
+        self.surfstab_strict_reference = True
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise Exception("unknown option " + k)
@@ -167,7 +169,8 @@ class Simulation:
         c.length[0], c.length[1] = self.L
         c.tracdens, c.tracdens_min, c.inject_seed = int(o.tracdens), int(o.tracdens_min), int(o.inject_seed)
         c.surface_stabilization = int(bool(o.surface_stabilization))
-        c.surfstab_theta, c.surfstab_tstep = float(o.surfstab_theta), float(o.surfstab_tstep)
+        theta = float(o.surfstab_theta)
+        c.surfstab_theta, c.surfstab_tstep = (theta if o.surfstab_strict_reference else -theta), float(o.surfstab_tstep)
         return c
 
     def step(self):

@@ -125,8 +125,14 @@ class StokesOperator:
         return A.tocsc()
 
 
-def makeStokesMatrix(nx, grid, f_etas, f_etan, f_rho, bc, surfstab=False, tstep=None, surfstab_theta=0.5):
-    """Set up the matrix-free Stokes operator and its rhs (pylamp_stokes.py:104-563)."""
+def makeStokesMatrix(nx, grid, f_etas, f_etan, f_rho, bc, surfstab=False, tstep=None, surfstab_theta=0.5,
+                     strict_reference=True):
+    """Set up the matrix-free Stokes operator and its rhs (pylamp_stokes.py:104-563).
+
+    strict_reference=False flips the sign of the free-surface stabilisation terms: as written in the
+    reference (pylamp_stokes.py:422-426,483-487) they are ADDED to the negative diagonal, which amplifies
+    interface velocities instead of damping them; the flipped sign is the
+    stabilisation of Duretz et al. (2011).  It has no effect when surfstab is off."""
     ctx = get_context(nx, grid)
     if surfstab and tstep is None:
         raise Exception("surface stabilization needs predetermined tstep")
@@ -137,7 +143,7 @@ def makeStokesMatrix(nx, grid, f_etas, f_etan, f_rho, bc, surfstab=False, tstep=
             raise Exception("field shape does not match nx")
     ctx.check(ctx.lib.pl_stokes_set_coeffs(ctx.h, _lib.dptr(es), _lib.dptr(en), _lib.dptr(rho), bc_arr,
                                            1 if surfstab else 0, float(tstep) if tstep is not None else 0.0,
-                                           float(surfstab_theta)))
+                                           float(surfstab_theta) if strict_reference else -float(surfstab_theta)))
     A = StokesOperator(ctx, nx)
     return (A, A.rhs())
 

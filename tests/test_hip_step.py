@@ -119,11 +119,12 @@ def test_census_and_injection():
 
 
 def test_surface_stabilisation_loop_reports_honestly():
-    """The surfstab re-solve loop (pylamp2.py:387-405) runs on the device, but the stabilised system
-    is NOT yet within reach of the preconditioner (it ignores the stabilisation terms; a re-solve
-    exceeds maxit).  Until that is fixed the step must say so instead of returning silently wrong
-    fields: converged == 0 is reported.  (The oracle reproduces the reference trajectory:
-    tests/test_oracle_golden.py::test_trajectory_surface_stabilisation.)"""
+    """Strict (reference-sign) surfstab loop (pylamp2.py:387-405): at the reference's own time step the sign
+    of the stabilisation terms makes the velocity block indefinite, which an iterative
+    solver cannot be expected to handle.  The step must then say so instead of returning silently wrong
+    fields: converged == 0 is reported.  (The oracle reproduces the reference trajectory with direct solves:
+    tests/test_oracle_golden.py::test_trajectory_surface_stabilisation; the damping sign is covered by
+    test_corrected_stabilisation_loop_vs_oracle below.)"""
     from pylamp_amd import driver
     g = golden("traj_surfstab41")
     gz, gx = g["gz"], g["gx"]
@@ -134,4 +135,74 @@ def test_surface_stabilisation_loop_reports_honestly():
     assert rep["stokes_resolves"] >= 1
     ok = relerr(sim.field("velz"), g["s1_velz"]) < 1e-6
     assert ok or rep["stokes"]["converged"] == 0, rep
+    sim.close()
+
+
+def _surfstab_fields(oracle):
+    g = golden("traj_surfstab41")
+    gz, gx = g["gz"], g["gx"]
+    nx = [gz.size, gx.size]; grid = [gz, gx]
+    tr_x = g["init_tr_x"]; tr_f = g["init_tr_f"].copy()
+    oracle.property_update(tr_f, False, False)
+    rho, etas = oracle.trac2grid(tr_x, tr_f[:, [0, 1]], grid, nx, [5, 6])
+    etan, = oracle.trac2grid(tr_x, tr_f[:, [1]], oracle.gridmp_of(grid), nx, [2])
+    (vz, vx), _ = oracle.x2vp(oracle.stokes_solve(nx, grid, etas, etan, rho, [1, 1, 1, 1]), nx)
+    courant = 0.67 * (gz[1] - gz[0]) / max(vz.max(), vx.max())
+    return nx, grid, etas, etan, rho, courant
+
+
+@pytest.mark.parametrize("strict,dtfac", [(False, 1.0), (False, 0.25), (True, 0.05)])
+def test_stabilised_solve_vs_oracle(oracle, strict, dtfac):
+    """Sticky-air model 3 (air 1e18 Pa s / 1000 kg m^-3 over rock): the stabilised system against the oracle's
+    direct solve.  strict=False is the damping sign; the reference's own sign is only solvable iteratively while
+    the terms stay below the viscous diagonal (here 5 % of the Courant step) -- at the full Courant step 38 rows
+    of the 41^2 velocity block change sign and the block is indefinite (see the next test)."""
+    from pylamp_amd import pylamp_stokes as S
+    nx, grid, etas, etan, rho, courant = _surfstab_fields(oracle)
+    bc = [1, 1, 1, 1]; tstep = dtfac * courant
+    A, rhs = S.makeStokesMatrix(nx, grid, etas, etan, rho, bc, surfstab=True, tstep=tstep, surfstab_theta=0.5,
+                                strict_reference=strict)
+    x = S.solve(A, rhs)
+    assert A.last_stats["converged"] == 1, A.last_stats
+    xr = oracle.stokes_solve(nx, grid, etas, etan, rho, bc, surfstab=True, tstep=tstep, theta=0.5 if strict else -0.5)
+    (vz, vx), _ = S.x2vp(x, nx); (rz, rx), _ = oracle.x2vp(xr, nx)
+    err = np.sqrt((np.sum((vz - rz) ** 2) + np.sum((vx - rx) ** 2)) / (np.sum(rz ** 2) + np.sum(rx ** 2)))
+    assert err < 1e-6, err
+
+
+def test_reference_sign_amplifies_instead_of_damping(oracle):
+    """Why the reference-sign loop cannot be handed to an iterative solver: with the sign of pylamp_stokes.py:
+    422-426 the 'stabilised' solution is FASTER than the unstabilised one (x230 at the Courant step in this
+    model), the flipped sign damps it.  Pure oracle arithmetic, kept next to the GPU tests it explains."""
+    nx, grid, etas, etan, rho, courant = _surfstab_fields(oracle)
+    bc = [1, 1, 1, 1]
+    v = {}
+    for name, kw in (("off", {}), ("ref", dict(surfstab=True, tstep=courant, theta=0.5)),
+                     ("flip", dict(surfstab=True, tstep=courant, theta=-0.5))):
+        (vz, vx), _ = oracle.x2vp(oracle.stokes_solve(nx, grid, etas, etan, rho, bc, **kw), nx)
+        v[name] = np.abs(vz).max()
+    assert v["ref"] > 50 * v["off"] and v["flip"] < v["off"]
+
+
+def test_corrected_stabilisation_loop_vs_oracle(oracle):
+    """The re-solve loop (pylamp2.py:387-405) with the damping sign, every step against the oracle's step()."""
+    from pylamp_amd import driver
+    g = golden("traj_surfstab41")
+    gz, gx = g["gz"], g["gx"]
+    nx = [gz.size, gx.size]; L = [gz[-1], gx[-1]]
+    opt = driver.Options(do_heatdiff=False, tdep_rho=False, tdep_eta=False, surface_stabilization=True,
+                         surfstab_strict_reference=False)
+    sim = driver.Simulation(nx, L, g["init_tr_x"], g["init_tr_f"], opt)
+    st = dict(nx=nx, L=L, grid=[gz, gx], tr_x=g["init_tr_x"].copy(), tr_f=g["init_tr_f"].copy())
+    cfg = oracle.StepConfig(do_heatdiff=False, tdep_rho=False, tdep_eta=False, surface_stabilization=True,
+                            surfstab_theta=-0.5)
+    for it in (1, 2):
+        rep = sim.step()
+        out = oracle.step(st, cfg, it)
+        assert rep["stokes"]["converged"] == 1, rep
+        assert rep["stokes_resolves"] == out["nresolve"]
+        assert rep["tstep"] == pytest.approx(out["tstep"], rel=1e-6)
+        assert relerr(sim.field("velz"), out["velz"]) < 1e-6 and relerr(sim.field("velx"), out["velx"]) < 1e-6
+        X, _ = sim.tracers()
+        assert relerr(X, st["tr_x"]) < 1e-7
     sim.close()
