@@ -26,14 +26,15 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~
 
 
 def build_sim(n, tracdens, seed, device, rank, world):
-    """The SAME global problem for every N: the grid is split into N row slabs and every rank
-    draws the tracers of its own slab (strong scaling)."""
+    """Weak scaling: every GPU holds one (n-1) x (n-1)-cell slab of ONE global problem -- the grid is
+    ((n-1) N + 1) x n nodes over a domain N times as deep (square cells), split into N row slabs, and
+    every rank draws the tracers of its own slab.  N = 1 is BASELINE's config 3."""
     from pylamp_amd import driver
-    nx = [n, n]; L = [660e3, 660e3]
+    nx = [(n - 1) * world + 1, n]; L = [660e3 * world, 660e3]
     sim = driver.Simulation(nx, L, options=driver.Options(), device=device)
     rng = np.random.default_rng(seed + rank)
     lo, hi = sim.slab()
-    per_rank = n * n * tracdens // max(world, 1)
+    per_rank = nx[0] * nx[1] * tracdens // max(world, 1)
     tr_x, tr_f = driver.mantle_tracers(nx, L, tracdens, rng, zrange=None if world == 1 else (lo, hi), id0=rank * per_rank)
     sim.upload(tr_x, tr_f)
     del tr_x, tr_f
@@ -49,14 +50,15 @@ def kernel_roofline(sim, reps):
         ctx.check(ctx.lib.pl_stokes_apply_bench(ctx.h, reps, C.byref(ms)))
         best = ms.value if best is None else min(best, ms.value)
     avg_ms = ms.value                       # report the LAST average (not the best) as the measured value
-    n = sim.nx[0] * sim.nx[1]
+    first, count = ctx.local_rows()
+    n = count * sim.nx[1]                   # nodes of this rank's slab (the whole grid on one GPU)
     alg_bytes = 64.0 * n                    # x 24 + etas 8 + etan 8 + y 24 B per node
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
     traffic = None
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tf):
         try:
-            traffic = json.load(open(tf)).get("k_stokes_apply", {}).get(str(sim.nx[0]))
+            traffic = json.load(open(tf)).get("k_stokes_apply", {}).get(str(sim.nx[1]) if abs(count - sim.nx[1]) <= 1 else "-")
         except Exception:
             traffic = None
     return {"kernel": "k_stokes_apply", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
@@ -140,10 +142,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    cells = (args.n - 1) * (args.n - 1)
+    cells = (sim.nx[0] - 1) * (sim.nx[1] - 1)
     ms_per_step = 1e3 * elapsed / args.steps
-    # N > 1: ONE global problem, grid decomposed into N row slabs (halo exchange + all-reduce over
-    # RCCL through torch.distributed): strong scaling, value = global cells * steps / time.
+    # N > 1: ONE global problem of N slabs (halo exchange + all-reduce over RCCL), per-GPU work fixed:
+    # weak scaling, value = global cells * steps / time.
     value = cells * args.steps / elapsed
     ntrac_global = sim.ntrac
     if dist is not None:
@@ -158,10 +160,10 @@ def main():
         out = {
             "metric": "stokes_heat_mic_cell_updates_per_s", "value": round(value, 1), "unit": "cell-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "2D %dx%d nodes (%dx%d cells), %d markers/node (%d tracers), T-dependent mantle "
                                    "model, heat + subgrid diffusion on, all free-slip, full time step" %
-                                   (args.n, args.n, args.n - 1, args.n - 1, args.tracdens, ntrac_global),
+                                   (sim.nx[0], sim.nx[1], sim.nx[0] - 1, sim.nx[1] - 1, args.tracdens, ntrac_global),
                        "parallelism": "1 GPU" if world == 1 else "%d row slabs (%d x 1 domain decomposition), halo exchange + all-reduce, transport: %s" %
                                       (world, world, "direct RCCL on the solver stream" if (sim.ctx.comm is not None and sim.ctx.comm.native)
                                        else "torch.distributed (%s)" % (dist.get_backend() if dist is not None else "-")),
