@@ -97,6 +97,15 @@ inline dim3 pl_grid_rows(const PlGeom& g) {
     const int it = pl_row_iters(g);
     return dim3((g.lnx + 63) / 64, (g.lnz + 4 * it - 1) / (4 * it));
 }
+// reciprocal to full double precision: v_rcp_f64 seed + two Newton steps (5 instructions; the IEEE division
+// sequence is ~15).  Operands here are O(1e-30 .. 1e30), no scaling needed.
+__device__ inline double pl_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
 // ---- two-columns-per-lane row loads (see k_stokes_apply_v2) ----
 struct Row2 { double2 v; double w, e; };           // w = value at j-1 of .x ; e = value at j+1 of .y
 

@@ -151,25 +151,33 @@ struct StokesVals {
     double rdx_j, rdx_m, rDx_j, rDx_p;
 };
 
+// The memory-only twin of this kernel runs in 58 us against 80 us (2049^2): the arithmetic is NOT free.  The
+// row scales of the scaled operator are therefore a template switch (the plain operator performs no division
+// at all) and use v_rcp_f64 + two Newton steps instead of the ~15-instruction IEEE division sequence.
+template <bool SCALED>
 __device__ inline void stokes_node_vals(const PlStokesOp& op, int i, int j, int c, const StokesVals& q,
                                         const double* __restrict__ x, double& oz, double& ox, double& op_) {
     const PlGeom& g = op.g;
     const int nz = g.nz, nx = g.nx, p = g.pitch;
     const double Kc = op.Kc;
-    const double iKc = 1.0 / Kc;
+    const double iKc = op.iKc;
     double sz = iKc, sx = iKc, sp = iKc;
     double yz;
     if (j == nx - 1 || i == 0 || i == nz - 1) yz = Kc * q.vz_c;
     else if (j == 0) yz = Kc * (q.vz_c - q.vz_e);
     else if (j == nx - 2) yz = Kc * (q.vz_c - q.vz_w);
     else {
+        // factored so that the row-only products are shared by the lane's two columns and each viscosity is
+        // multiplied once (the arithmetic of this kernel is ~1/3 of its run time: FP64 issues at half rate)
         const double rdz_i = TB(g.rdz, i), rdz_m = TB(g.rdz, i - 1), rDz_i = TB(g.rDz, i);
-        const double cN = 4.0 * q.en_c * rdz_i * rDz_i, cS = 4.0 * q.en_s * rdz_m * rDz_i;
-        const double cE = 2.0 * q.es_e * q.rDx_p * q.rdx_j, cW = 2.0 * q.es_c * q.rDx_j * q.rdx_j;
-        const double xE = 2.0 * q.es_e * rDz_i * q.rdx_j, xW = 2.0 * q.es_c * rDz_i * q.rdx_j;
+        const double Az = 4.0 * rdz_i * rDz_i, Azm = 4.0 * rdz_m * rDz_i, Pz = 2.0 * Kc * rDz_i;     // row constants
+        const double k2 = 2.0 * q.rdx_j;                                                              // column constant
+        const double tE = q.es_e * k2, tW = q.es_c * k2;
+        const double cN = q.en_c * Az, cS = q.en_s * Azm, cE = tE * q.rDx_p, cW = tW * q.rDx_j;
+        const double xE = tE * rDz_i, xW = tW * rDz_i;
         yz = cN * (q.vz_n - q.vz_c) - cS * (q.vz_c - q.vz_s) + cE * (q.vz_e - q.vz_c) - cW * (q.vz_c - q.vz_w) +
-             xE * (q.vx_e - q.vx_se) - xW * (q.vx_c - q.vx_s) - 2.0 * Kc * rDz_i * (q.p_c - q.p_s);
-        sz = 1.0 / (cN + cS + cE + cW);
+             xE * (q.vx_e - q.vx_se) - xW * (q.vx_c - q.vx_s) - Pz * (q.p_c - q.p_s);
+        if (SCALED) sz = pl_rcp(cN + cS + cE + cW);
         if (op.surfstab) {
             const double* __restrict__ r = op.rho;
             yz += op.ss * op.gz * 0.5 * ((r[c + 1] + r[c + p + 1] - r[c - 1] - r[c + p - 1]) * q.rDx_j * q.vx_c +
@@ -186,12 +194,15 @@ __device__ inline void stokes_node_vals(const PlStokesOp& op, int i, int j, int 
         else yx = Kc * ((TB(g.rDz, nz - 2) + TB(g.rdz, nz - 2)) * q.vx_c - TB(g.rDz, nz - 2) * q.vx_s);
     } else {
         const double rdz_i = TB(g.rdz, i), rDz_i = TB(g.rDz, i), rDz_p = TB(g.rDz, i + 1);
-        const double cE = 4.0 * q.en_c * q.rdx_j * q.rDx_j, cW = 4.0 * q.en_w * q.rdx_m * q.rDx_j;
-        const double cN = 2.0 * q.es_n * rDz_p * rdz_i, cS = 2.0 * q.es_c * rDz_i * rdz_i;
-        const double zN = 2.0 * q.es_n * q.rDx_j * rdz_i, zS = 2.0 * q.es_c * q.rDx_j * rdz_i;
+        const double r2 = 2.0 * rdz_i, twoKc = 2.0 * Kc;                                             // row constants
+        const double B4 = 4.0 * q.rDx_j;                                                              // column constants
+        const double Bx = B4 * q.rdx_j, Bxm = B4 * q.rdx_m, Px = twoKc * q.rDx_j;
+        const double uN = q.es_n * r2, uS = q.es_c * r2;
+        const double cE = q.en_c * Bx, cW = q.en_w * Bxm, cN = uN * rDz_p, cS = uS * rDz_i;
+        const double zN = uN * q.rDx_j, zS = uS * q.rDx_j;
         yx = cE * (q.vx_e - q.vx_c) - cW * (q.vx_c - q.vx_w) + cN * (q.vx_n - q.vx_c) - cS * (q.vx_c - q.vx_s) +
-             zN * (q.vz_n - q.vz_nw) - zS * (q.vz_c - q.vz_w) - 2.0 * Kc * q.rDx_j * (q.p_c - q.p_w);
-        sx = 1.0 / (cE + cW + cN + cS);
+             zN * (q.vz_n - q.vz_nw) - zS * (q.vz_c - q.vz_w) - Px * (q.p_c - q.p_w);
+        if (SCALED) sx = pl_rcp(cE + cW + cN + cS);
         if (op.surfstab && op.gx != 0.0) {
             const double* __restrict__ r = op.rho;
             yx += op.ss * op.gx * 0.5 * ((r[c + 1] + r[c + p + 1] - r[c - 1] - r[c + p - 1]) * q.rDx_j * q.vx_c +
@@ -200,17 +211,92 @@ __device__ inline void stokes_node_vals(const PlStokesOp& op, int i, int j, int 
     }
     double yp;
     if (i == nz - 1 || j == nx - 1 || (i == op.anchor_i && j == op.anchor_j)) yp = Kc * q.p_c;
-    else if ((i == 0 || i == nz - 2) && j == 0) { yp = op.Kb * (q.p_e - q.p_c); sp = 1.0 / op.Kb; }
-    else if ((i == 0 || i == nz - 2) && j == nx - 2) { yp = op.Kb * (q.p_w - q.p_c); sp = 1.0 / op.Kb; }
+    else if ((i == 0 || i == nz - 2) && j == 0) { yp = op.Kb * (q.p_e - q.p_c); if (SCALED) sp = pl_rcp(op.Kb); }
+    else if ((i == 0 || i == nz - 2) && j == nx - 2) { yp = op.Kb * (q.p_w - q.p_c); if (SCALED) sp = pl_rcp(op.Kb); }
     else {
         yp = Kc * ((q.vx_e - q.vx_c) * q.rdx_j + (q.vz_n - q.vz_c) * TB(g.rdz, i));
-        sp = 1.0 / (Kc * (q.rdx_j + TB(g.rdz, i)));
+        if (SCALED) sp = iKc * pl_rcp(q.rdx_j + TB(g.rdz, i));
     }
     (void)x;
-    oz = op.scaled ? yz * sz : yz; ox = op.scaled ? yx * sx : yx; op_ = op.scaled ? yp * sp : yp;
+    oz = SCALED ? yz * sz : yz; ox = SCALED ? yx * sx : yx; op_ = SCALED ? yp * sp : yp;
 }
 
-template <int ROWS>
+// Straight-line twin of stokes_node_vals for a node whose three rows are all of the interior class
+// (1 <= i <= nz-3, 1 <= j <= nx-3, not the anchor, no stabilisation): no classification, no exec-mask regions.
+struct StokesRowK { double Az, Azm, Pz, rDz_i, rDz_p, r2, twoKc, rdz_i, Kc, iKc; };
+template <bool SCALED>
+__device__ inline void stokes_interior_vals(const StokesRowK& k, const StokesVals& q, double& oz, double& ox, double& op_) {
+    const double dzn = q.vz_n - q.vz_c, dxe = q.vx_e - q.vx_c;
+    const double k2 = 2.0 * q.rdx_j;
+    const double tE = q.es_e * k2, tW = q.es_c * k2;
+    const double cN = q.en_c * k.Az, cS = q.en_s * k.Azm, cE = tE * q.rDx_p, cW = tW * q.rDx_j;
+    const double yz = cN * dzn - cS * (q.vz_c - q.vz_s) + cE * (q.vz_e - q.vz_c) - cW * (q.vz_c - q.vz_w) +
+                      (tE * k.rDz_i) * (q.vx_e - q.vx_se) - (tW * k.rDz_i) * (q.vx_c - q.vx_s) - k.Pz * (q.p_c - q.p_s);
+    const double B4 = 4.0 * q.rDx_j;
+    const double uN = q.es_n * k.r2, uS = q.es_c * k.r2;
+    const double dE = q.en_c * (B4 * q.rdx_j), dW = q.en_w * (B4 * q.rdx_m), dN = uN * k.rDz_p, dS = uS * k.rDz_i;
+    const double yx = dE * dxe - dW * (q.vx_c - q.vx_w) + dN * (q.vx_n - q.vx_c) - dS * (q.vx_c - q.vx_s) +
+                      (uN * q.rDx_j) * (q.vz_n - q.vz_nw) - (uS * q.rDx_j) * (q.vz_c - q.vz_w) -
+                      (k.twoKc * q.rDx_j) * (q.p_c - q.p_w);
+    const double yp = k.Kc * (dxe * q.rdx_j + dzn * k.rdz_i);
+    if (SCALED) {
+        oz = yz * pl_rcp(cN + cS + cE + cW);
+        ox = yx * pl_rcp(dE + dW + dN + dS);
+        op_ = yp * (k.iKc * pl_rcp(q.rdx_j + k.rdz_i));
+    } else { oz = yz; ox = yx; op_ = yp; }
+}
+
+// Both columns of one lane from the twelve loaded rows, then the (double2) stores.
+struct StokesRows { Row2 vz_s, vz_i, vz_n, vx_s, vx_i, vx_n, p_s, p_i, en_s, en_i, es_i, es_n, t_rdx, t_rDx; };
+template <bool SCALED>
+__device__ inline void stokes_compute_store(const PlStokesOp& op, const StokesRows& R, int i, int jw, int lj0, int c,
+                                            const double* __restrict__ x, double* __restrict__ y) {
+    const PlGeom& g = op.g;
+    const Row2 &vz_s = R.vz_s, &vz_i = R.vz_i, &vz_n = R.vz_n, &vx_s = R.vx_s, &vx_i = R.vx_i, &vx_n = R.vx_n;
+    const Row2 &p_s = R.p_s, &p_i = R.p_i, &en_s = R.en_s, &en_i = R.en_i, &es_i = R.es_i, &es_n = R.es_n;
+    const double rdx_a = R.t_rdx.v.x, rdx_b = R.t_rdx.v.y, rdx_m = R.t_rdx.w;
+    const double rDx_a = R.t_rDx.v.x, rDx_b = R.t_rDx.v.y, rDx_pp = R.t_rDx.e;
+    const int j0 = g.gj0 + lj0;
+    StokesVals q;
+    double oz[2], ox[2], opv[2];
+    const bool colB = (lj0 + 1) < g.lnx;
+    // wave-uniform: every node of this wave is of the interior class in all three equations
+    const bool fast = !op.surfstab && i >= 1 && i <= g.nz - 3 && jw >= 1 && jw + 127 <= g.nx - 3 &&
+                      !(i == op.anchor_i && op.anchor_j >= jw && op.anchor_j < jw + 128);
+    StokesRowK rk;
+    if (fast) {
+        const double rdz_i = TB(g.rdz, i), rdz_m = TB(g.rdz, i - 1), rDz_i = TB(g.rDz, i);
+        rk.Az = 4.0 * rdz_i * rDz_i; rk.Azm = 4.0 * rdz_m * rDz_i; rk.Pz = 2.0 * op.Kc * rDz_i; rk.rDz_i = rDz_i;
+        rk.rDz_p = TB(g.rDz, i + 1); rk.r2 = 2.0 * rdz_i; rk.twoKc = 2.0 * op.Kc; rk.rdz_i = rdz_i; rk.Kc = op.Kc; rk.iKc = op.iKc;
+    }
+    // column A (lj0)
+    q.vz_c = vz_i.v.x; q.vz_w = vz_i.w; q.vz_e = vz_i.v.y; q.vz_n = vz_n.v.x; q.vz_s = vz_s.v.x; q.vz_nw = vz_n.w;
+    q.vx_c = vx_i.v.x; q.vx_w = vx_i.w; q.vx_e = vx_i.v.y; q.vx_n = vx_n.v.x; q.vx_s = vx_s.v.x; q.vx_se = vx_s.v.y;
+    q.p_c = p_i.v.x; q.p_w = p_i.w; q.p_e = p_i.v.y; q.p_s = p_s.v.x;
+    q.en_c = en_i.v.x; q.en_w = en_i.w; q.en_s = en_s.v.x;
+    q.es_c = es_i.v.x; q.es_e = es_i.v.y; q.es_n = es_n.v.x;
+    q.rdx_j = rdx_a; q.rdx_m = rdx_m; q.rDx_j = rDx_a; q.rDx_p = rDx_b;
+    if (fast) stokes_interior_vals<SCALED>(rk, q, oz[0], ox[0], opv[0]);
+    else stokes_node_vals<SCALED>(op, i, j0, c, q, x, oz[0], ox[0], opv[0]);
+    // column B (lj0 + 1)
+    q.vz_c = vz_i.v.y; q.vz_w = vz_i.v.x; q.vz_e = vz_i.e; q.vz_n = vz_n.v.y; q.vz_s = vz_s.v.y; q.vz_nw = vz_n.v.x;
+    q.vx_c = vx_i.v.y; q.vx_w = vx_i.v.x; q.vx_e = vx_i.e; q.vx_n = vx_n.v.y; q.vx_s = vx_s.v.y; q.vx_se = vx_s.e;
+    q.p_c = p_i.v.y; q.p_w = p_i.v.x; q.p_e = p_i.e; q.p_s = p_s.v.y;
+    q.en_c = en_i.v.y; q.en_w = en_i.v.x; q.en_s = en_s.v.y;
+    q.es_c = es_i.v.y; q.es_e = es_i.e; q.es_n = es_n.v.y;
+    q.rdx_j = rdx_b; q.rdx_m = rdx_a; q.rDx_j = rDx_b; q.rDx_p = rDx_pp;
+    if (fast) stokes_interior_vals<SCALED>(rk, q, oz[1], ox[1], opv[1]);
+    else if (colB) stokes_node_vals<SCALED>(op, i, j0 + 1, c + 1, q, x, oz[1], ox[1], opv[1]);
+    if (colB) {
+        *reinterpret_cast<double2*>(y + c) = make_double2(oz[0], oz[1]);
+        *reinterpret_cast<double2*>(y + c + g.plane) = make_double2(ox[0], ox[1]);
+        *reinterpret_cast<double2*>(y + c + 2 * g.plane) = make_double2(opv[0], opv[1]);
+    } else {
+        y[c] = oz[0]; y[c + g.plane] = ox[0]; y[c + 2 * g.plane] = opv[0];
+    }
+}
+
+template <int ROWS, bool SCALED>
 __global__ __launch_bounds__(64 * ROWS) void k_stokes_apply_v2(PlStokesOp op, const double* __restrict__ x,
                                                                double* __restrict__ y) {
     const PlGeom& g = op.g;
@@ -235,39 +321,12 @@ __global__ __launch_bounds__(64 * ROWS) void k_stokes_apply_v2(PlStokesOp op, co
     const Row2 es_i = ROW(es, 0, false, true), es_n = ROW(es, 1, false, false);
 #undef ROW
     // x tables: pair at (j, j+1) plus the two outer neighbours (tables are padded by PL_TOFF entries)
-    const int j0 = g.gj0 + lj0;
     const Row2 t_rdx = load_row2(g.rdx + PL_TOFF + g.gj0, lj0, active, true, false, lane, has_right);
     const Row2 t_rDx = load_row2(g.rDx + PL_TOFF + g.gj0, lj0, active, false, true, lane, has_right);
-    const double rdx_a = t_rdx.v.x, rdx_b = t_rdx.v.y, rdx_m = t_rdx.w;
-    const double rDx_a = t_rDx.v.x, rDx_b = t_rDx.v.y, rDx_pp = t_rDx.e;
     if (!active) return;
     const int i = g.gi0 + li;
-    StokesVals q;
-    double oz[2], ox[2], opv[2];
-    // column A (lj0)
-    q.vz_c = vz_i.v.x; q.vz_w = vz_i.w; q.vz_e = vz_i.v.y; q.vz_n = vz_n.v.x; q.vz_s = vz_s.v.x; q.vz_nw = vz_n.w;
-    q.vx_c = vx_i.v.x; q.vx_w = vx_i.w; q.vx_e = vx_i.v.y; q.vx_n = vx_n.v.x; q.vx_s = vx_s.v.x; q.vx_se = vx_s.v.y;
-    q.p_c = p_i.v.x; q.p_w = p_i.w; q.p_e = p_i.v.y; q.p_s = p_s.v.x;
-    q.en_c = en_i.v.x; q.en_w = en_i.w; q.en_s = en_s.v.x;
-    q.es_c = es_i.v.x; q.es_e = es_i.v.y; q.es_n = es_n.v.x;
-    q.rdx_j = rdx_a; q.rdx_m = rdx_m; q.rDx_j = rDx_a; q.rDx_p = rDx_b;
-    stokes_node_vals(op, i, j0, c, q, x, oz[0], ox[0], opv[0]);
-    // column B (lj0 + 1)
-    q.vz_c = vz_i.v.y; q.vz_w = vz_i.v.x; q.vz_e = vz_i.e; q.vz_n = vz_n.v.y; q.vz_s = vz_s.v.y; q.vz_nw = vz_n.v.x;
-    q.vx_c = vx_i.v.y; q.vx_w = vx_i.v.x; q.vx_e = vx_i.e; q.vx_n = vx_n.v.y; q.vx_s = vx_s.v.y; q.vx_se = vx_s.e;
-    q.p_c = p_i.v.y; q.p_w = p_i.v.x; q.p_e = p_i.e; q.p_s = p_s.v.y;
-    q.en_c = en_i.v.y; q.en_w = en_i.v.x; q.en_s = en_s.v.y;
-    q.es_c = es_i.v.y; q.es_e = es_i.e; q.es_n = es_n.v.y;
-    q.rdx_j = rdx_b; q.rdx_m = rdx_a; q.rDx_j = rDx_b; q.rDx_p = rDx_pp;
-    const bool colB = (lj0 + 1) < g.lnx;
-    if (colB) stokes_node_vals(op, i, j0 + 1, c + 1, q, x, oz[1], ox[1], opv[1]);
-    if (colB) {
-        *reinterpret_cast<double2*>(y + c) = make_double2(oz[0], oz[1]);
-        *reinterpret_cast<double2*>(y + c + g.plane) = make_double2(ox[0], ox[1]);
-        *reinterpret_cast<double2*>(y + c + 2 * g.plane) = make_double2(opv[0], opv[1]);
-    } else {
-        y[c] = oz[0]; y[c + g.plane] = ox[0]; y[c + 2 * g.plane] = opv[0];
-    }
+    StokesRows R{vz_s, vz_i, vz_n, vx_s, vx_i, vx_n, p_s, p_i, en_s, en_i, es_i, es_n, t_rdx, t_rDx};
+    stokes_compute_store<SCALED>(op, R, i, g.gj0 + blockIdx.x * 128, lj0, c, x, y);
 }
 
 __global__ __launch_bounds__(256) void k_stokes_rhs(PlStokesOp op, double* __restrict__ rhs) {
@@ -286,15 +345,22 @@ __global__ __launch_bounds__(256) void k_stokes_rhs(PlStokesOp op, double* __res
 static dim3 grid2d(const PlGeom& g) { return dim3((g.lnx + 63) / 64, (g.lnz + 3) / 4); }
 
 void pl_launch_stokes_apply(pl_ctx* ctx, const PlStokesOp& op, const double* x, double* y) {
-    // Variants measured on MI355X: 8-byte loads 84 us; double2 81 us; double2 + register
-    // row marching (R = 8/16) 99/104 us; 1024-thread blocks (16 rows) 84 us at 2049^2 but 342 vs 388 us at
-    // 4097^2; XCD-aware block remap and plane-stride padding: no effect.
+    // Variants measured on MI355X at 2049^2: 8-byte loads 84 us; double2 81 us; + register row
+    // marching (R = 8/16) 99/104 us; XCD-aware block remap, plane-stride padding: no effect; a memory-only twin
+    // (same loads and stores, no arithmetic) 58 us -> the arithmetic was exposed: no divisions in the plain
+    // operator 76 us, factored coefficients 73 us, branch-free interior path 64 us.  Sharing the rows of a
+    // 4- or 8-row tile through LDS (5 instead of 12 global row loads per wave) is SLOWER (68 us): the L1 re-reads
+    // were never the limit, the barrier is one.
     if ((op.g.plane % 2) == 0) {                  // double2 accesses need even plane strides (pitch is a multiple of 16)
         const int gx = (op.g.lnx + 127) / 128;
-        if ((long long)op.g.lnz * op.g.lnx >= 8000000LL)
-            hipLaunchKernelGGL(k_stokes_apply_v2<16>, dim3(gx, (op.g.lnz + 15) / 16), dim3(64, 16), 0, ctx->stream, op, x, y);
-        else
-            hipLaunchKernelGGL(k_stokes_apply_v2<4>, dim3(gx, (op.g.lnz + 3) / 4), dim3(64, 4), 0, ctx->stream, op, x, y);
+#define PL_APPLY_LAUNCH(KERNEL, ROWS)                                                                                   \
+        do {                                                                                                            \
+            if (op.scaled) hipLaunchKernelGGL((KERNEL<ROWS, true>), dim3(gx, (op.g.lnz + ROWS - 1) / ROWS), dim3(64, ROWS), 0, ctx->stream, op, x, y);  \
+            else hipLaunchKernelGGL((KERNEL<ROWS, false>), dim3(gx, (op.g.lnz + ROWS - 1) / ROWS), dim3(64, ROWS), 0, ctx->stream, op, x, y);           \
+        } while (0)
+        if ((long long)op.g.lnz * op.g.lnx >= 8000000LL) PL_APPLY_LAUNCH(k_stokes_apply_v2, 16);
+        else PL_APPLY_LAUNCH(k_stokes_apply_v2, 4);
+#undef PL_APPLY_LAUNCH
         return;
     }
     hipLaunchKernelGGL(k_stokes_apply, pl_grid_rows(op.g), dim3(64, 4), 0, ctx->stream, op, x, y, pl_row_iters(op.g));
