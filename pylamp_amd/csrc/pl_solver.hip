@@ -230,24 +230,23 @@ struct VvVals {
     double en_c, en_w, en_s, es_c, es_e, es_n;
     double rdx_j, rdx_m, rDx_j, rDx_p;
 };
-__device__ inline void vv_rows_vals(const VvVals& q, double rdz_i, double rdz_m, double rDz_i, double rDz_p,
-                                    double& Az, double& dz, double& Ax, double& dx) {
-    {
-        const double cN = 4.0 * q.en_c * rdz_i * rDz_i, cS = 4.0 * q.en_s * rdz_m * rDz_i;
-        const double cE = 2.0 * q.es_e * q.rDx_p * q.rdx_j, cW = 2.0 * q.es_c * q.rDx_j * q.rdx_j;
-        const double xE = 2.0 * q.es_e * rDz_i * q.rdx_j, xW = 2.0 * q.es_c * rDz_i * q.rdx_j;
-        Az = cN * (q.vz_n - q.vz_c) - cS * (q.vz_c - q.vz_s) + cE * (q.vz_e - q.vz_c) - cW * (q.vz_c - q.vz_w) +
-             xE * (q.vx_e - q.vx_se) - xW * (q.vx_c - q.vx_s);
-        dz = cN + cS + cE + cW;
-    }
-    {
-        const double cE = 4.0 * q.en_c * q.rdx_j * q.rDx_j, cW = 4.0 * q.en_w * q.rdx_m * q.rDx_j;
-        const double cN = 2.0 * q.es_n * rDz_p * rdz_i, cS = 2.0 * q.es_c * rDz_i * rdz_i;
-        const double zN = 2.0 * q.es_n * q.rDx_j * rdz_i, zS = 2.0 * q.es_c * q.rDx_j * rdz_i;
-        Ax = cE * (q.vx_e - q.vx_c) - cW * (q.vx_c - q.vx_w) + cN * (q.vx_n - q.vx_c) - cS * (q.vx_c - q.vx_s) +
-             zN * (q.vz_n - q.vz_nw) - zS * (q.vz_c - q.vz_w);
-        dx = cE + cW + cN + cS;
-    }
+// Row-only products are shared by the lane's two columns, every viscosity is multiplied once (the arithmetic
+// of these sweeps is not hidden behind the memory traffic: FP64 issues at half rate on CDNA4).
+struct VvRowK { double Az, Azm, rDz_i, rDz_p, r2; };
+template <bool NEED_D>
+__device__ inline void vv_rows_vals(const VvVals& q, const VvRowK& k, double& Az, double& dz, double& Ax, double& dx) {
+    const double k2 = 2.0 * q.rdx_j;
+    const double tE = q.es_e * k2, tW = q.es_c * k2;
+    const double cN = q.en_c * k.Az, cS = q.en_s * k.Azm, cE = tE * q.rDx_p, cW = tW * q.rDx_j;
+    Az = cN * (q.vz_n - q.vz_c) - cS * (q.vz_c - q.vz_s) + cE * (q.vz_e - q.vz_c) - cW * (q.vz_c - q.vz_w) +
+         (tE * k.rDz_i) * (q.vx_e - q.vx_se) - (tW * k.rDz_i) * (q.vx_c - q.vx_s);
+    if (NEED_D) dz = cN + cS + cE + cW;
+    const double B4 = 4.0 * q.rDx_j;
+    const double uN = q.es_n * k.r2, uS = q.es_c * k.r2;
+    const double dE = q.en_c * (B4 * q.rdx_j), dW = q.en_w * (B4 * q.rdx_m), dN = uN * k.rDz_p, dS = uS * k.rDz_i;
+    Ax = dE * (q.vx_e - q.vx_c) - dW * (q.vx_c - q.vx_w) + dN * (q.vx_n - q.vx_c) - dS * (q.vx_c - q.vx_s) +
+         (uN * q.rDx_j) * (q.vz_n - q.vz_nw) - (uS * q.rDx_j) * (q.vz_c - q.vz_w);
+    if (NEED_D) dx = dE + dW + dN + dS;
 }
 
 template <int MODE>
@@ -289,21 +288,25 @@ __global__ __launch_bounds__(256) void k_vv_sweep2(PlVvOp op, const double* __re
     if (MODE == 0 && c1 != 0.0 && vprev) {
         pz = *reinterpret_cast<const double2*>(vprev + c); px = *reinterpret_cast<const double2*>(vprev + PLN + c);
     }
-    const double rdz_i = TB(g.rdz, i), rdz_m = TB(g.rdz, i - 1), rDz_i = TB(g.rDz, i), rDz_p = TB(g.rDz, i + 1);
+    VvRowK rk;
+    {
+        const double rdz_i = TB(g.rdz, i), rdz_m = TB(g.rdz, i - 1), rDz_i = TB(g.rDz, i);
+        rk.Az = 4.0 * rdz_i * rDz_i; rk.Azm = 4.0 * rdz_m * rDz_i; rk.rDz_i = rDz_i; rk.rDz_p = TB(g.rDz, i + 1); rk.r2 = 2.0 * rdz_i;
+    }
     VvVals q;
-    double Az[2], dz[2], Ax[2], dx[2];
+    double Az[2], dz[2] = {1.0, 1.0}, Ax[2], dx[2] = {1.0, 1.0};
     q.vz_c = vz_i.v.x; q.vz_w = vz_i.w; q.vz_e = vz_i.v.y; q.vz_n = vz_n.v.x; q.vz_s = vz_s.v.x; q.vz_nw = vz_n.w;
     q.vx_c = vx_i.v.x; q.vx_w = vx_i.w; q.vx_e = vx_i.v.y; q.vx_n = vx_n.v.x; q.vx_s = vx_s.v.x; q.vx_se = vx_s.v.y;
     q.en_c = en_i.v.x; q.en_w = en_i.w; q.en_s = en_s.v.x;
     q.es_c = es_i.v.x; q.es_e = es_i.v.y; q.es_n = es_n.v.x;
     q.rdx_j = t_rdx.v.x; q.rdx_m = t_rdx.w; q.rDx_j = t_rDx.v.x; q.rDx_p = t_rDx.v.y;
-    vv_rows_vals(q, rdz_i, rdz_m, rDz_i, rDz_p, Az[0], dz[0], Ax[0], dx[0]);
+    vv_rows_vals<MODE == 0>(q, rk, Az[0], dz[0], Ax[0], dx[0]);
     q.vz_c = vz_i.v.y; q.vz_w = vz_i.v.x; q.vz_e = vz_i.e; q.vz_n = vz_n.v.y; q.vz_s = vz_s.v.y; q.vz_nw = vz_n.v.x;
     q.vx_c = vx_i.v.y; q.vx_w = vx_i.v.x; q.vx_e = vx_i.e; q.vx_n = vx_n.v.y; q.vx_s = vx_s.v.y; q.vx_se = vx_s.e;
     q.en_c = en_i.v.y; q.en_w = en_i.v.x; q.en_s = en_s.v.y;
     q.es_c = es_i.v.y; q.es_e = es_i.e; q.es_n = es_n.v.y;
     q.rdx_j = t_rdx.v.y; q.rdx_m = t_rdx.v.x; q.rDx_j = t_rDx.v.y; q.rDx_p = t_rDx.e;
-    vv_rows_vals(q, rdz_i, rdz_m, rDz_i, rDz_p, Az[1], dz[1], Ax[1], dx[1]);
+    vv_rows_vals<MODE == 0>(q, rk, Az[1], dz[1], Ax[1], dx[1]);
     const double v0z[2] = {vz_i.v.x, vz_i.v.y}, v0x[2] = {vx_i.v.x, vx_i.v.y};
     if (op.szz) {                                                   // wave-uniform
         const double2 sd = *reinterpret_cast<const double2*>(op.szz + c), sx = *reinterpret_cast<const double2*>(op.szx + c);
@@ -312,6 +315,23 @@ __global__ __launch_bounds__(256) void k_vv_sweep2(PlVvOp op, const double* __re
     }
     const double fzv[2] = {fz.x, fz.y}, fxv[2] = {fx.x, fx.y}, pzv[2] = {pz.x, pz.y}, pxv[2] = {px.x, px.y};
     double oz[2], ox[2];
+    // wave-uniform: all 128 columns are interior in both components (no slaves, no zero rows): straight-line code
+    const int jw = g.gj0 + blockIdx.x * 128;
+    if (jw >= 1 && jw + 127 <= nx - 3) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            if (MODE == 0) {
+                const double mz = c1 * (v0z[k] - pzv[k]), mx = c1 * (v0x[k] - pxv[k]);      // c1 = 0 on the first sweep
+                oz[k] = v0z[k] + mz + (c2 * (Az[k] - fzv[k])) * pl_rcp(dz[k]);
+                ox[k] = v0x[k] + mx + (c2 * (Ax[k] - fxv[k])) * pl_rcp(dx[k]);
+            } else {
+                oz[k] = fzv[k] - Az[k]; ox[k] = fxv[k] - Ax[k];
+            }
+        }
+        *reinterpret_cast<double2*>(out + c) = make_double2(oz[0], oz[1]);
+        *reinterpret_cast<double2*>(out + PLN + c) = make_double2(ox[0], ox[1]);
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         const int j = j0 + k;
@@ -319,8 +339,8 @@ __global__ __launch_bounds__(256) void k_vv_sweep2(PlVvOp op, const double* __re
         const bool zint = j < nx - 1 && !zslave, xint = j > 0 && j < nx - 1;
         if (MODE == 0) {
             const double mz = (c1 != 0.0) ? c1 * (v0z[k] - pzv[k]) : 0.0, mx = (c1 != 0.0) ? c1 * (v0x[k] - pxv[k]) : 0.0;
-            oz[k] = zint ? v0z[k] + mz + c2 * (Az[k] - fzv[k]) / dz[k] : 0.0;
-            ox[k] = xint ? v0x[k] + mx + c2 * (Ax[k] - fxv[k]) / dx[k] : 0.0;
+            oz[k] = zint ? v0z[k] + mz + (c2 * (Az[k] - fzv[k])) * pl_rcp(dz[k]) : 0.0;
+            ox[k] = xint ? v0x[k] + mx + (c2 * (Ax[k] - fxv[k])) * pl_rcp(dx[k]) : 0.0;
             if (zslave && (k == 0 || colB)) oz[k] = cheb_val_z(op, vcur, vprev, f, c1, c2, i, j, c + k);
         } else {
             oz[k] = zint ? fzv[k] - Az[k] : 0.0;
