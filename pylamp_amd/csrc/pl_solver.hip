@@ -355,6 +355,51 @@ __global__ __launch_bounds__(256) void k_vv_sweep2(PlVvOp op, const double* __re
     }
 }
 
+// First sweep from the zero guess, two columns per lane (see cheb_first_node): v1 = -c2 f / diag.
+__global__ __launch_bounds__(256) void k_vv_first2(PlVvOp op, const double* __restrict__ f, double* __restrict__ out, double c2) {
+    const PlGeom& g = op.g;
+    const int lane = threadIdx.x;
+    const int lj0 = (blockIdx.x * 64 + lane) * 2;
+    const int li = blockIdx.y * 4 + threadIdx.y;
+    if (li >= g.lnz) return;                                // wave-uniform
+    const bool active = lj0 < g.lnx;
+    const bool has_right = (lj0 + 2) < g.lnx;
+    const int p = g.pitch, nz = g.nz, nx = g.nx;
+    const long long PLN = g.plane;
+    const int c = (int)pl_idx(g, li, lj0);
+    const int i = g.gi0 + li, j0 = g.gj0 + lj0;
+    const int jw = g.gj0 + blockIdx.x * 128;
+    if (i <= 0 || i >= nz - 2 || jw < 1 || jw + 127 > nx - 3 || op.szz) {     // walls, slaves, stabilised rows (wave-uniform)
+        if (!active) return;
+        for (int q = 0; q < 2 && lj0 + q < g.lnx; q++) cheb_first_node(op, f, out, c2, i, j0 + q, c + q);
+        return;
+    }
+#define ROW(ptr, dr, w, e) load_row2((ptr) + (long long)c - lj0 + (long long)(dr) * p, lj0, true, w, e, lane, has_right)
+    const Row2 en_s = ROW(op.etan, -1, false, false), en_i = ROW(op.etan, 0, true, false);
+    const Row2 es_i = ROW(op.etas, 0, false, true), es_n = ROW(op.etas, 1, false, false);
+#undef ROW
+    const Row2 t_rdx = load_row2(g.rdx + PL_TOFF + g.gj0, lj0, true, true, false, lane, has_right);
+    const Row2 t_rDx = load_row2(g.rDx + PL_TOFF + g.gj0, lj0, true, false, true, lane, has_right);
+    const double2 fz = *reinterpret_cast<const double2*>(f + c), fx = *reinterpret_cast<const double2*>(f + PLN + c);
+    const double rdz_i = TB(g.rdz, i), rdz_m = TB(g.rdz, i - 1), rDz_i = TB(g.rDz, i), rDz_p = TB(g.rDz, i + 1);
+    const double Az = 4.0 * rdz_i * rDz_i, Azm = 4.0 * rdz_m * rDz_i, r2 = 2.0 * rdz_i, nc2 = -c2;
+    double oz[2], ox[2];
+    {   // column A
+        const double rdx_j = t_rdx.v.x, rdx_m = t_rdx.w, rDx_j = t_rDx.v.x, rDx_p = t_rDx.v.y, k2 = 2.0 * rdx_j, B4 = 4.0 * rDx_j;
+        const double dz = en_i.v.x * Az + en_s.v.x * Azm + (es_i.v.y * k2) * rDx_p + (es_i.v.x * k2) * rDx_j;
+        const double dx = en_i.v.x * (B4 * rdx_j) + en_i.w * (B4 * rdx_m) + (es_n.v.x * r2) * rDz_p + (es_i.v.x * r2) * rDz_i;
+        oz[0] = (nc2 * fz.x) * pl_rcp(dz); ox[0] = (nc2 * fx.x) * pl_rcp(dx);
+    }
+    {   // column B
+        const double rdx_j = t_rdx.v.y, rdx_m = t_rdx.v.x, rDx_j = t_rDx.v.y, rDx_p = t_rDx.e, k2 = 2.0 * rdx_j, B4 = 4.0 * rDx_j;
+        const double dz = en_i.v.y * Az + en_s.v.y * Azm + (es_i.e * k2) * rDx_p + (es_i.v.y * k2) * rDx_j;
+        const double dx = en_i.v.y * (B4 * rdx_j) + en_i.v.x * (B4 * rdx_m) + (es_n.v.y * r2) * rDz_p + (es_i.v.y * r2) * rDz_i;
+        oz[1] = (nc2 * fz.y) * pl_rcp(dz); ox[1] = (nc2 * fx.y) * pl_rcp(dx);
+    }
+    *reinterpret_cast<double2*>(out + c) = make_double2(oz[0], oz[1]);
+    *reinterpret_cast<double2*>(out + PLN + c) = make_double2(ox[0], ox[1]);
+}
+
 static inline dim3 pl_grid_rows2(const PlGeom& g) { return dim3((g.lnx + 127) / 128, (g.lnz + 3) / 4); }
 
 // y = D^-1 A v with closure (power iteration for lambda_max)
@@ -708,9 +753,8 @@ __device__ inline double prec_p_value(const PlStokesOp& op, const double* __rest
 // Constraint-row residuals are NOT lifted: inside the Krylov iteration they are identically zero,
 // because x0 is closed with k_close_constraints and every preconditioned direction satisfies the
 // homogeneous wall/slave rows, so (A y)_constraint = 0 for all iterates.
-__global__ __launch_bounds__(256) void k_prec_stage1(PlStokesOp op, PlVvOp vop, const double* __restrict__ rs,
-                                                     double* __restrict__ z, double* __restrict__ f, int iters) {
-    PL_ROW_LOOP(op.g, iters) {
+__device__ inline void stage1_node(const PlStokesOp& op, const PlVvOp& vop, const double* __restrict__ rs,
+                                   double* __restrict__ z, double* __restrict__ f, int li, int lj) {
     const int i = op.g.gi0 + li, j = op.g.gj0 + lj;
     const long long c = pl_idx(op.g, li, lj);
     const long long P = op.g.plane;
@@ -737,7 +781,65 @@ __global__ __launch_bounds__(256) void k_prec_stage1(PlStokesOp op, PlVvOp vop, 
         fx = rs[c + P] * sum + 2.0 * op.Kc * rDx_j * (zp_c - prec_p_value(op, rs_p, i, j - 1, c - 1));
     }
     f[c] = fz; f[c + P] = fx; z[c + 2 * P] = zp_c;
+}
+
+__global__ __launch_bounds__(256) void k_prec_stage1(PlStokesOp op, PlVvOp vop, const double* __restrict__ rs,
+                                                     double* __restrict__ z, double* __restrict__ f, int iters) {
+    PL_ROW_LOOP(op.g, iters) stage1_node(op, vop, rs, z, f, li, lj);
+}
+
+// Two columns per lane; interior waves run straight-line code, the others the per-node function above.
+__global__ __launch_bounds__(256) void k_prec_stage1_v2(PlStokesOp op, PlVvOp vop, const double* __restrict__ rs,
+                                                        double* __restrict__ z, double* __restrict__ f) {
+    const PlGeom& g = op.g;
+    const int lane = threadIdx.x;
+    const int lj0 = (blockIdx.x * 64 + lane) * 2;
+    const int li = blockIdx.y * 4 + threadIdx.y;
+    if (li >= g.lnz) return;                                // wave-uniform
+    const bool has_right = (lj0 + 2) < g.lnx;
+    const int p = g.pitch, nz = g.nz, nx = g.nx;
+    const long long PLN = g.plane;
+    const int c = (int)pl_idx(g, li, lj0);
+    const int i = g.gi0 + li;
+    const int jw = g.gj0 + blockIdx.x * 128;
+    const bool anchor_near = (op.anchor_i == i || op.anchor_i == i - 1) && op.anchor_j >= jw - 1 && op.anchor_j <= jw + 127;
+    if (i < 1 || i > nz - 3 || jw < 1 || jw + 127 > nx - 3 || anchor_near) {
+        for (int q = 0; q < 2 && lj0 + q < g.lnx; q++) stage1_node(op, vop, rs, z, f, li, lj0 + q);
+        return;
     }
+#define ROW(ptr, dr, w, e) load_row2((ptr) + (long long)c - lj0 + (long long)(dr) * p, lj0, true, w, e, lane, has_right)
+    const double2 rz = *reinterpret_cast<const double2*>(rs + c), rx = *reinterpret_cast<const double2*>(rs + PLN + c);
+    const Row2 rp_i = ROW(rs + 2 * PLN, 0, true, false), rp_s = ROW(rs + 2 * PLN, -1, false, false);
+    const Row2 en_s = ROW(op.etan, -1, false, false), en_i = ROW(op.etan, 0, true, false);
+    const Row2 es_i = ROW(op.etas, 0, false, true), es_n = ROW(op.etas, 1, false, false);
+#undef ROW
+    const Row2 t_rdx = load_row2(g.rdx + PL_TOFF + g.gj0, lj0, true, true, false, lane, has_right);
+    const Row2 t_rDx = load_row2(g.rDx + PL_TOFF + g.gj0, lj0, true, false, true, lane, has_right);
+    const double rdz_i = TB(g.rdz, i), rdz_m = TB(g.rdz, i - 1), rDz_i = TB(g.rDz, i), rDz_p = TB(g.rDz, i + 1);
+    const double Az = 4.0 * rdz_i * rDz_i, Azm = 4.0 * rdz_m * rDz_i, r2 = 2.0 * rdz_i, twoKc = 2.0 * op.Kc, Pz = twoKc * rDz_i;
+    const double iKc = op.iKc;
+    double fz[2], fx[2], zp[2];
+    {   // column A
+        const double rdx_j = t_rdx.v.x, rdx_m = t_rdx.w, rDx_j = t_rDx.v.x, rDx_p = t_rDx.v.y, k2 = 2.0 * rdx_j, B4 = 4.0 * rDx_j;
+        zp[0] = rp_i.v.x * (rdx_j + rdz_i) * en_i.v.x * iKc;
+        const double zp_s = rp_s.v.x * (rdx_j + rdz_m) * en_s.v.x * iKc, zp_w = rp_i.w * (rdx_m + rdz_i) * en_i.w * iKc;
+        const double sz = en_i.v.x * Az + en_s.v.x * Azm + (es_i.v.y * k2) * rDx_p + (es_i.v.x * k2) * rDx_j;
+        const double sx = en_i.v.x * (B4 * rdx_j) + en_i.w * (B4 * rdx_m) + (es_n.v.x * r2) * rDz_p + (es_i.v.x * r2) * rDz_i;
+        fz[0] = rz.x * sz + Pz * (zp[0] - zp_s);
+        fx[0] = rx.x * sx + (twoKc * rDx_j) * (zp[0] - zp_w);
+    }
+    {   // column B (its west neighbour is column A)
+        const double rdx_j = t_rdx.v.y, rdx_m = t_rdx.v.x, rDx_j = t_rDx.v.y, rDx_p = t_rDx.e, k2 = 2.0 * rdx_j, B4 = 4.0 * rDx_j;
+        zp[1] = rp_i.v.y * (rdx_j + rdz_i) * en_i.v.y * iKc;
+        const double zp_s = rp_s.v.y * (rdx_j + rdz_m) * en_s.v.y * iKc;
+        const double sz = en_i.v.y * Az + en_s.v.y * Azm + (es_i.e * k2) * rDx_p + (es_i.v.y * k2) * rDx_j;
+        const double sx = en_i.v.y * (B4 * rdx_j) + en_i.v.x * (B4 * rdx_m) + (es_n.v.y * r2) * rDz_p + (es_i.v.y * r2) * rDz_i;
+        fz[1] = rz.y * sz + Pz * (zp[1] - zp_s);
+        fx[1] = rx.y * sx + (twoKc * rDx_j) * (zp[1] - zp[0]);
+    }
+    *reinterpret_cast<double2*>(f + c) = make_double2(fz[0], fz[1]);
+    *reinterpret_cast<double2*>(f + PLN + c) = make_double2(fx[0], fx[1]);
+    *reinterpret_cast<double2*>(z + 2 * PLN + c) = make_double2(zp[0], zp[1]);
 }
 
 // Make x satisfy the constraint rows of A x = b exactly (b given SCALED, bs = b / Kc on these rows):
@@ -1102,9 +1204,11 @@ static void smooth(pl_ctx* ctx, MgLevel* L, double* buf[3], const double* f, int
         if (L->dist && !(k == 0 && zero_guess) && (halo == 2 || (halo == 1 && k == 0)))
             (void)pl_halo_rows(ctx, L->gh.d, buf[0], 2, L->gh.d.plane);
         double* dst = (final_out && k == nsweep - 1) ? final_out : buf[2];
-        if (k == 0 && zero_guess)          // buf[0] is NOT read (and need not be zeroed)
-            hipLaunchKernelGGL(k_vv_cheb_first, pl_grid_rows(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, f, dst, c2,
-                               pl_row_iters(L->gh.d));
+        if (k == 0 && zero_guess) {        // buf[0] is NOT read (and need not be zeroed)
+            if (g_vv_vec) hipLaunchKernelGGL(k_vv_first2, pl_grid_rows2(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, f, dst, c2);
+            else hipLaunchKernelGGL(k_vv_cheb_first, pl_grid_rows(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, f, dst, c2,
+                                    pl_row_iters(L->gh.d));
+        }
         else
         {
             const double* prev = (k == 1 && zero_guess) ? (const double*)nullptr : buf[1];
@@ -1196,7 +1300,10 @@ static int stokes_precond(pl_ctx* ctx, PlSolver* S, const double* rs, double* z)
     MgLevel* L0 = S->levels[0];
     const PlGeom& g = op.g;
     if (L0->dist) PL_TRY(pl_halo_rows(ctx, g, (double*)rs + 2 * g.plane, 1, g.plane));      // rs_p row above
-    hipLaunchKernelGGL(k_prec_stage1, pl_grid_rows(g), dim3(64, 4), 0, ctx->stream, op, L0->op, rs, z, L0->f, pl_row_iters(g));
+    if (g_vv_vec && (g.plane % 2) == 0)
+        hipLaunchKernelGGL(k_prec_stage1_v2, pl_grid_rows2(g), dim3(64, 4), 0, ctx->stream, op, L0->op, rs, z, L0->f);
+    else
+        hipLaunchKernelGGL(k_prec_stage1, pl_grid_rows(g), dim3(64, 4), 0, ctx->stream, op, L0->op, rs, z, L0->f, pl_row_iters(g));
     double* e = nullptr;
     const bool direct = S->levels.size() > 1 && S->nu_post > 0;     // last sweep writes into z
     vcycle(ctx, S, 0, L0->f, &e, direct ? z : nullptr);
