@@ -633,18 +633,32 @@ __global__ __launch_bounds__(256) void k_coarsen_visc(PlGeom gf, const double* _
 // no atomics; the host adds the (<= DOT_BLOCKS) partials in a fixed order, so the result is
 // deterministic.
 #define DOT_BLOCKS 1024
+template <bool HAS_A, bool HAS_C>
 __global__ __launch_bounds__(256) void k_dot2(PlGeom g, int nplanes, const double* __restrict__ a,
                                               const double* __restrict__ b, const double* __restrict__ cc,
                                               const double* __restrict__ dd, double* __restrict__ part) {
     double s0 = 0.0, s1 = 0.0;
     const long long rows = (long long)g.lnz * nplanes;
+    const int npair = g.lnx >> 1;                              // columns (2k, 2k+1) as one 16-byte load; rows start 16-B aligned
     for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
         const int q = (int)(r / g.lnz), li = (int)(r % g.lnz);
         const long long base = pl_idx(g, li, 0) + q * g.plane;
-        for (int lj = threadIdx.x; lj < g.lnx; lj += 256) {
-            const long long o = base + lj;
-            if (a) s0 += a[o] * b[o];
-            if (cc) s1 += cc[o] * dd[o];
+#pragma unroll 4
+        for (int k = threadIdx.x; k < npair; k += 256) {
+            const long long o = base + 2 * k;
+            if (HAS_A) {
+                const double2 x = *reinterpret_cast<const double2*>(a + o), y = *reinterpret_cast<const double2*>(b + o);
+                s0 += x.x * y.x + x.y * y.y;
+            }
+            if (HAS_C) {
+                const double2 x = *reinterpret_cast<const double2*>(cc + o), y = *reinterpret_cast<const double2*>(dd + o);
+                s1 += x.x * y.x + x.y * y.y;
+            }
+        }
+        if ((g.lnx & 1) && threadIdx.x == 0) {
+            const long long o = base + g.lnx - 1;
+            if (HAS_A) s0 += a[o] * b[o];
+            if (HAS_C) s1 += cc[o] * dd[o];
         }
     }
     __shared__ double sh[2][4];
@@ -1008,7 +1022,9 @@ static int dots(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const double*
                 const double* d, double* out2) {
     long long rows = (long long)g.lnz * np;
     const int nb = (int)(rows < DOT_BLOCKS ? rows : DOT_BLOCKS);
-    hipLaunchKernelGGL(k_dot2, dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 8);
+    if (a && c) hipLaunchKernelGGL((k_dot2<true, true>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 8);
+    else if (a) hipLaunchKernelGGL((k_dot2<true, false>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 8);
+    else hipLaunchKernelGGL((k_dot2<false, true>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 8);
     if (ctx->nranks > 1 && g.lnz != g.nz && pl_comm_native_enabled(ctx)) {
         // slab + native RCCL: reduce on the device, all-reduce 2 doubles over xGMI, one 16-byte copy back
         hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, nb, S->scal + 8, S->scal);
