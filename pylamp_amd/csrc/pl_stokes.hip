@@ -358,7 +358,11 @@ void pl_launch_stokes_apply(pl_ctx* ctx, const PlStokesOp& op, const double* x, 
             if (op.scaled) hipLaunchKernelGGL((KERNEL<ROWS, true>), dim3(gx, (op.g.lnz + ROWS - 1) / ROWS), dim3(64, ROWS), 0, ctx->stream, op, x, y);  \
             else hipLaunchKernelGGL((KERNEL<ROWS, false>), dim3(gx, (op.g.lnz + ROWS - 1) / ROWS), dim3(64, ROWS), 0, ctx->stream, op, x, y);           \
         } while (0)
-        if ((long long)op.g.lnz * op.g.lnx >= 8000000LL) PL_APPLY_LAUNCH(k_stokes_apply_v2, 16);
+        static const int rows_knob = [] { const char* e = getenv("PYLAMP_APPLY_ROWS"); return e ? atoi(e) : 0; }();
+        const int rows = rows_knob ? rows_knob : ((long long)op.g.lnz * op.g.lnx >= 8000000LL ? 16 : 4);
+        if (rows == 16) PL_APPLY_LAUNCH(k_stokes_apply_v2, 16);
+        else if (rows == 8) PL_APPLY_LAUNCH(k_stokes_apply_v2, 8);
+        else if (rows == 2) PL_APPLY_LAUNCH(k_stokes_apply_v2, 2);
         else PL_APPLY_LAUNCH(k_stokes_apply_v2, 4);
 #undef PL_APPLY_LAUNCH
         return;
