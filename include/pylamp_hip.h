@@ -151,6 +151,15 @@ int  pl_heat_apply_bench(pl_ctx* ctx, int reps, double* avg_ms);
 int  pl_trac2grid(pl_ctx* ctx, int64_t n, const double* tr_x, const double* tr_f, int64_t ld_f,
                   int nf, const int* avgscheme, double z0, double hz, double x0, double hx,
                   double* const* out);
+/* Rectilinear (non-uniform) grids, SURVEY 8 f4 -- beyond the reference, whose marker code is regular-grid
+ * only (it picks the cell with the regular-grid formula, pylamp_trac.py:46-47,226-227).  pl_trac2grid_rect takes
+ * the coordinates zc[nz], xc[nx] of the target node set and locates cells by per-axis search (outside the
+ * axis the grid continues with the spacing of its end cell, as the reference's extension does).
+ * pl_mic_set_search(ctx, 1) makes pl_grid2trac and pl_rk4 locate cells the same way in their gz/gx arrays;
+ * 0 (default) restores the reference's formula.  On a uniform grid both give the same result. */
+int  pl_trac2grid_rect(pl_ctx* ctx, int64_t n, const double* tr_x, const double* tr_f, int64_t ld_f,
+                       int nf, const int* avgscheme, const double* zc, const double* xc, double* const* out);
+int  pl_mic_set_search(pl_ctx* ctx, int on);
 /* Grid -> tracer (pylamp_trac.py:30-158).  fields: nf host arrays (gnz,gnx) on the regular
  * grid gz[gnz], gx[gnx]; out is (n,nf) with leading dimension ld_out (may be a strided
  * view like pylamp2.py:445).  *n_outside returns how many tracers used defval; with

@@ -486,8 +486,31 @@ def heat_solve(nx, grid, gridmp, T, k, Cp, rho, H, bc, bcvalue, tstep):
 # =======================================================================================
 # Marker-in-cell
 # =======================================================================================
+# Rectilinear (non-uniform) grids -- SURVEY section 8 f4.  The reference's marker code is regular-grid only: it
+# finds the cell with the regular-grid formula and then reads the coordinates of THAT cell from the grid
+# arrays (pylamp_trac.py:46-47,226-227,249-250), so on a non-uniform grid the weights leave [0,1].  With
+# RECT_SEARCH the cell comes from a per-axis search instead; everything else is unchanged, and on a uniform
+# grid both lookups agree.  This mode is DEFINED HERE (no reference behaviour to pin it to).
+RECT_SEARCH = False
+
+
+class rect_search:
+    """with rect_search(): ... -- marker <-> grid transfers locate cells by per-axis search"""
+    def __init__(self, on=True): self.on = on
+    def __enter__(self):
+        global RECT_SEARCH
+        self.old = RECT_SEARCH; RECT_SEARCH = self.on
+    def __exit__(self, *a):
+        global RECT_SEARCH
+        RECT_SEARCH = self.old
+
+
 def _cell_lookup(tr_x, grid, nx):
     """Regular-grid cell formula shared by both directions (pylamp_trac.py:42-47,222-227)."""
+    if RECT_SEARCH:
+        ie = np.searchsorted(np.asarray(grid[IZ]), tr_x[:, IZ], side='right').astype(np.int64) - 1
+        je = np.searchsorted(np.asarray(grid[IX]), tr_x[:, IX], side='right').astype(np.int64) - 1
+        return ie, je
     Lmin = [grid[d][0] for d in range(DIM)]
     L = [grid[d][-1] - grid[d][0] for d in range(DIM)]
     ie = np.floor((nx[IZ] - 1) * (tr_x[:, IZ] - Lmin[IZ]) / L[IZ]).astype(np.int64)
@@ -517,6 +540,8 @@ def trac2grid(tr_x, tr_f, grid, nx, avgscheme=None):
     # NOTE the accumulator shape in the reference is mesh[0].shape, i.e. the *extended*
     # shape when the grid was modified and the caller's mesh shape otherwise.
     ie, je = _cell_lookup(tr_x, g, n)
+    if RECT_SEARCH:      # a marker exactly on the last coordinate belongs to the last cell (a = 1)
+        ie = np.minimum(ie, n[0] - 2); je = np.minimum(je, n[1] - 2)
     a = (tr_x[:, IZ] - g[IZ][ie]) / (g[IZ][ie + 1] - g[IZ][ie])
     b = (tr_x[:, IX] - g[IX][je]) / (g[IX][je + 1] - g[IX][je])
     w = [(1 - b) * (1 - a), (1 - b) * a, b * (1 - a), b * a]
@@ -557,6 +582,8 @@ def grid2trac(tr_x, grid, gridfield, nx, defval=np.nan, method=M_LINEAR, stop_on
     nz, nxx = int(nx[0]), int(nx[1])
     ie, je = _cell_lookup(tr_x, grid, nx)
     bad = (ie < 0) | (ie > nz - 1) | (je < 0) | (je > nxx - 1)
+    if RECT_SEARCH:      # at or beyond the last coordinate = outside (the strict path raises IndexError there)
+        bad |= (ie > nz - 2) | (je > nxx - 2)
     if stop_on_error and bad.any():
         raise Exception("stopOnError in grid2trac")
     ie = np.where(bad, 0, ie); je = np.where(bad, 0, je)

@@ -76,6 +76,9 @@ SIGNATURES = {
     "pl_heat_apply_bench": (C.c_int, [C.c_void_p, C.c_int, c_double_p]),
     "pl_trac2grid": (C.c_int, [C.c_void_p, C.c_int64, c_double_p, c_double_p, C.c_int64, C.c_int, c_int_p,
                                C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(c_double_p)]),
+    "pl_trac2grid_rect": (C.c_int, [C.c_void_p, C.c_int64, c_double_p, c_double_p, C.c_int64, C.c_int, c_int_p,
+                                    c_double_p, c_double_p, C.POINTER(c_double_p)]),
+    "pl_mic_set_search": (C.c_int, [C.c_void_p, C.c_int]),
     "pl_grid2trac": (C.c_int, [C.c_void_p, C.c_int64, c_double_p, C.c_int, C.POINTER(c_double_p), C.c_int,
                                C.c_int, c_double_p, c_double_p, C.c_int, C.c_double, C.c_int, c_double_p,
                                C.c_int64, C.POINTER(C.c_int64)]),

@@ -76,6 +76,7 @@ struct pl_ctx {
     PlStokesOp sop{}; bool sop_ready = false;
     // Heat
     PlHeatOp hop{}; bool hop_ready = false; double heat_bcvalue[4] = {0, 0, 0, 0};
+    int mic_search = 0;          // host-API gathers locate cells by per-axis search (pl_mic_set_search)
     std::vector<double> zmp, xmp;
     // multi-GPU (row slabs): rank r owns node rows [row0, row0 + geom.d.lnz)
     int rank = 0, nranks = 1;

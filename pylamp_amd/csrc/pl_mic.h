@@ -13,6 +13,8 @@ struct PlScatterArgs {
     int scheme[PL_MAX_SCATTER_FIELDS];
     // regular target node set: node k at z0 + k*hz (k < nz), x0 + k*hx (k < nx)
     double z0, hz, x0, hx;
+    // rectilinear target node set: coordinates of the nz / nx nodes; NULL = regular (z0, hz, x0, hx)
+    const double* zc; const double* xc;
     int nz, nx;
     // dense accumulators of nrows x nx doubles; accumulator row 0 is GLOBAL node row `row0`
     // (single rank / host API: row0 = 0, nrows = nz; slab: row0 = gi0-1, nrows = lnz+2)
@@ -33,6 +35,7 @@ struct PlGatherGrid {
     int nz, nx;                 // node counts of the field being interpolated
     const double* gz; const double* gx;
     double zmin, xmin, Lz, Lx;
+    int rect;                   // 1: cells located by per-axis search in gz/gx (non-uniform grids), 0: the reference's regular formula
     long long pitch, off;       // field element (i,j) is F[off + i*pitch + j] (dense: pitch = nx, off = 0)
 };
 
@@ -58,6 +61,25 @@ struct PlRk4Args {
     double* tz_out; double* tx_out; double* vz_out; double* vx_out;
     int fence; double eps, Lz, Lx;                 // optional fence of pylamp2.py:563-570
 };
+
+// Cell index and in-cell coordinate on a rectilinear axis c[0..n-1] (largest ie with c[ie] <= z; a marker exactly
+// on the last coordinate belongs to the last cell with a = 1).  Outside the axis the grid continues with the
+// spacing of its end cell, like the reference's auto-extension (pylamp_trac.py:207-220): ie < 0 or ie >= n-1.
+__device__ inline void mic_axis_locate(const double* __restrict__ c, int n, double z, int& ie, double& a) {
+    if (z < c[0]) {
+        const double h = c[1] - c[0], f = floor((z - c[0]) / h);
+        ie = (int)f; a = (z - (c[0] + f * h)) / h;
+        return;
+    }
+    if (z > c[n - 1]) {
+        const double h = c[n - 1] - c[n - 2], f = floor((z - c[n - 1]) / h);
+        ie = n - 1 + (int)f; a = (z - (c[n - 1] + f * h)) / h;
+        return;
+    }
+    int lo = 0, hi = n - 1;                      // c[lo] <= z <= c[hi]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (c[mid] <= z) lo = mid; else hi = mid; }
+    ie = lo; a = (z - c[lo]) / (c[lo + 1] - c[lo]);
+}
 
 // slab != NULL: accumulators carry one ring row on each side; they are summed across ranks
 // (reverse halo), only the owned rows are finalised into the ring planes `out`, whose ring rows are

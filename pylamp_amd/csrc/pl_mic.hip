@@ -45,16 +45,24 @@ __device__ inline void mic_atomic_add(double* p, double v) {
     unsafeAtomicAdd(p, v);
 }
 
+__device__ inline void mic_scatter_locate(const PlScatterArgs& a, double z, double x, int& ie, int& je, double& ca, double& cb) {
+    if (a.zc) {                                           // wave-uniform
+        mic_axis_locate(a.zc, a.nz, z, ie, ca);
+        mic_axis_locate(a.xc, a.nx, x, je, cb);
+    } else {
+        const double fz = floor((z - a.z0) / a.hz), fx = floor((x - a.x0) / a.hx);
+        ie = (int)fz; je = (int)fx;
+        ca = (z - (a.z0 + fz * a.hz)) / a.hz; cb = (x - (a.x0 + fx * a.hx)) / a.hx;
+    }
+}
+
 // Unsorted tracers: one thread per tracer, global FP64 atomics.
 __global__ __launch_bounds__(256) void k_scatter_atomic(PlScatterArgs a) {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= a.n) return;
     const double z = a.tz[t], x = a.tx[t];
-    const double sz = (z - a.z0) / a.hz, sx = (x - a.x0) / a.hx;
-    const double fz = floor(sz), fx = floor(sx);
-    const int ie = (int)fz, je = (int)fx;
-    const double ca = (z - (a.z0 + fz * a.hz)) / a.hz;    // a in pylamp_trac.py:247
-    const double cb = (x - (a.x0 + fx * a.hx)) / a.hx;
+    int ie, je; double ca, cb;                            // cell and in-cell coordinates (a, b in pylamp_trac.py:247)
+    mic_scatter_locate(a, z, x, ie, je, ca, cb);
     double w[4] = {(1 - cb) * (1 - ca), (1 - cb) * ca, cb * (1 - ca), cb * ca};
     double val[PL_MAX_SCATTER_FIELDS];
     for (int k = 0; k < a.nf; k++) {
@@ -118,9 +126,9 @@ __global__ __launch_bounds__(256) void k_scatter_binned(PlScatterArgs a, int til
             const bool valid = t < t1;
             double z = 0.0, x = 0.0;
             if (valid) { z = a.tz[t]; x = a.tx[t]; }
-            const double fz = floor((z - a.z0) / a.hz), fx = floor((x - a.x0) / a.hx);
-            const int ie = valid ? (int)fz : -0x40000000 - lane, je = (int)fx;   // invalid lanes never share a segment
-            const double ca = (z - (a.z0 + fz * a.hz)) / a.hz, cb = (x - (a.x0 + fx * a.hx)) / a.hx;
+            int ie, je; double ca, cb;
+            mic_scatter_locate(a, z, x, ie, je, ca, cb);
+            if (!valid) ie = -0x40000000 - lane;                                  // invalid lanes never share a segment
             const double w[4] = {(1 - cb) * (1 - ca), (1 - cb) * ca, cb * (1 - ca), cb * ca};
             double val[PL_MAX_SCATTER_FIELDS];
             for (int k = 0; k < a.nf; k++) {
@@ -249,6 +257,13 @@ struct CellLoc { int ie, je; bool bad; double a, b; };
 // its coordinate array (IndexError); here it is treated as outside.
 __device__ inline CellLoc mic_locate(const PlGatherGrid& g, double z, double x) {
     CellLoc c;
+    if (g.rect) {                                         // wave-uniform; at or beyond the last coordinate = outside
+        c.bad = !(z >= g.gz[0] && z < g.gz[g.nz - 1] && x >= g.gx[0] && x < g.gx[g.nx - 1]);
+        c.ie = 0; c.je = 0; c.a = 0.0; c.b = 0.0;
+        if (!c.bad) { mic_axis_locate(g.gz, g.nz, z, c.ie, c.a); mic_axis_locate(g.gx, g.nx, x, c.je, c.b); }
+        else { c.a = (z - g.gz[0]) / (g.gz[1] - g.gz[0]); c.b = (x - g.gx[0]) / (g.gx[1] - g.gx[0]); }   // cell (0,0), as the strict path
+        return c;
+    }
     const double fi = floor((g.nz - 1) * (z - g.zmin) / g.Lz);
     const double fj = floor((g.nx - 1) * (x - g.xmin) / g.Lx);
     c.bad = !(fi >= 0.0 && fi <= (double)(g.nz - 2) && fj >= 0.0 && fj <= (double)(g.nx - 2));
@@ -359,12 +374,15 @@ static int upload_grid(pl_ctx* ctx, const char* name, int gnz, int gnx, const do
     PL_HIP(ctx, hipMemcpyAsync(d + gnz, gx, gnx * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     g.nz = gnz; g.nx = gnx; g.gz = d; g.gx = d + gnz;
     g.zmin = gz[0]; g.xmin = gx[0]; g.Lz = gz[gnz - 1] - gz[0]; g.Lx = gx[gnx - 1] - gx[0];
-    g.pitch = gnx; g.off = 0;
+    g.pitch = gnx; g.off = 0; g.rect = ctx->mic_search ? 1 : 0;
     return 0;
 }
 
-extern "C" int pl_trac2grid(pl_ctx* ctx, int64_t n, const double* tr_x, const double* tr_f, int64_t ld_f, int nf,
-                            const int* avgscheme, double z0, double hz, double x0, double hx, double* const* out) {
+extern "C" int pl_mic_set_search(pl_ctx* ctx, int on) { ctx->mic_search = on ? 1 : 0; return 0; }
+
+static int trac2grid_host(pl_ctx* ctx, int64_t n, const double* tr_x, const double* tr_f, int64_t ld_f, int nf,
+                          const int* avgscheme, double z0, double hz, double x0, double hx, const double* zc,
+                          const double* xc, double* const* out) {
     if (n < 0 || !tr_x || !tr_f || !avgscheme || !out) return pl_fail(ctx, "pl_trac2grid: bad argument");
     if (nf < 1 || nf > PL_MAX_SCATTER_FIELDS) return pl_fail(ctx, "pl_trac2grid: 1..8 fields per call");
     PL_HIP(ctx, hipSetDevice(ctx->device));
@@ -386,6 +404,13 @@ extern "C" int pl_trac2grid(pl_ctx* ctx, int64_t n, const double* tr_x, const do
     a.n = n; a.tz = d_soa; a.tx = d_soa + n; a.nf = nf;
     for (int k = 0; k < nf; k++) { a.f[k] = d_soa + (size_t)(2 + k) * n; a.scheme[k] = avgscheme[k]; }
     a.z0 = z0; a.hz = hz; a.x0 = x0; a.hx = hx; a.nz = nz; a.nx = nx;
+    if (zc) {
+        double* d_c;
+        PL_TRY(pl_buf(ctx, "mic_tcoords", (size_t)(nz + nx) * sizeof(double), &d_c, false));
+        PL_HIP(ctx, hipMemcpyAsync(d_c, zc, (size_t)nz * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        PL_HIP(ctx, hipMemcpyAsync(d_c + nz, xc, (size_t)nx * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        a.zc = d_c; a.xc = d_c + nz;
+    }
     double* outs[PL_MAX_SCATTER_FIELDS];
     for (int k = 0; k < nf; k++) outs[k] = d_out + (size_t)k * N;
     if (ctx->nranks > 1) return pl_fail(ctx, "pl_trac2grid: host-array MIC calls are single-rank; use the resident step");
@@ -394,6 +419,19 @@ extern "C" int pl_trac2grid(pl_ctx* ctx, int64_t n, const double* tr_x, const do
         PL_HIP(ctx, hipMemcpyAsync(out[k], outs[k], N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
+}
+
+extern "C" int pl_trac2grid(pl_ctx* ctx, int64_t n, const double* tr_x, const double* tr_f, int64_t ld_f, int nf,
+                            const int* avgscheme, double z0, double hz, double x0, double hx, double* const* out) {
+    return trac2grid_host(ctx, n, tr_x, tr_f, ld_f, nf, avgscheme, z0, hz, x0, hx, nullptr, nullptr, out);
+}
+
+extern "C" int pl_trac2grid_rect(pl_ctx* ctx, int64_t n, const double* tr_x, const double* tr_f, int64_t ld_f, int nf,
+                                 const int* avgscheme, const double* zc, const double* xc, double* const* out) {
+    if (!zc || !xc) return pl_fail(ctx, "pl_trac2grid_rect: NULL coordinates");
+    for (int i = 0; i + 1 < ctx->nz; i++) if (!(zc[i + 1] > zc[i])) return pl_fail(ctx, "pl_trac2grid_rect: coordinates must increase");
+    for (int j = 0; j + 1 < ctx->nx; j++) if (!(xc[j + 1] > xc[j])) return pl_fail(ctx, "pl_trac2grid_rect: coordinates must increase");
+    return trac2grid_host(ctx, n, tr_x, tr_f, ld_f, nf, avgscheme, 0.0, 1.0, 0.0, 1.0, zc, xc, out);
 }
 
 extern "C" int pl_grid2trac(pl_ctx* ctx, int64_t n, const double* tr_x, int nf, const double* const* fields, int gnz,

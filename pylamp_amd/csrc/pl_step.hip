@@ -96,13 +96,16 @@ __device__ inline void wave_runs(int c, int lane, int& seg0, int& len) {
     len = above ? __ffsll((long long)above) : 64 - seg0;            // lanes in my run
 }
 __global__ __launch_bounds__(256) void k_cell_count(long long n, const double* __restrict__ tz, const double* __restrict__ tx,
-                                                    double z0, double hz, double x0, double hx, int ncz, int ncx, int crow0,
+                                                    double z0, double hz, double x0, double hx, const double* __restrict__ zc,
+                                                    const double* __restrict__ xc, int ncz, int ncx, int crow0,
                                                     int gcz, int* __restrict__ cell, int* __restrict__ count) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int c = -1;                                          // lanes past the end form their own run and add nothing
     if (t < n) {
-        int ci = (int)floor((tz[t] - z0) / hz), cj = (int)floor((tx[t] - x0) / hx);
+        int ci, cj;
+        if (zc) { double a_; mic_axis_locate(zc, gcz + 1, tz[t], ci, a_); mic_axis_locate(xc, ncx + 1, tx[t], cj, a_); }   // rectilinear node grid
+        else { ci = (int)floor((tz[t] - z0) / hz); cj = (int)floor((tx[t] - x0) / hx); }
         ci = min(max(ci, 0), gcz - 1) - crow0;              // global cell row (clamped to the domain) -> sort row
         ci = min(max(ci, 0), ncz - 1); cj = min(max(cj, 0), ncx - 1);
         c = ci * ncx + cj;
@@ -211,6 +214,7 @@ struct InjectArgs {
     const int* start; const int* need; const int* off;
     double* tz; double* tx; double* f[NFTRAC]; double* vtz; double* vtx;
     double z0, hz, x0, hx; unsigned long long seed; unsigned step; double id0;
+    const double* zc; const double* xc;          // rectilinear node grid (NULL: regular)
 };
 // one thread per deficient cell: field means of the resident tracers, then the new tracers
 __global__ __launch_bounds__(64) void k_inject(InjectArgs a) {
@@ -228,8 +232,9 @@ __global__ __launch_bounds__(64) void k_inject(InjectArgs a) {
     }
     for (int q = 0; q < m; q++) {
         const long long d = a.n + a.off[c] + q;
-        a.tz[d] = a.z0 + (ci + inj_uniform(a.seed, (unsigned)c, (unsigned)q, 2 * a.step)) * a.hz;
-        a.tx[d] = a.x0 + (cj + inj_uniform(a.seed, (unsigned)c, (unsigned)q, 2 * a.step + 1)) * a.hx;
+        const double uz = inj_uniform(a.seed, (unsigned)c, (unsigned)q, 2 * a.step), ux = inj_uniform(a.seed, (unsigned)c, (unsigned)q, 2 * a.step + 1);
+        a.tz[d] = a.zc ? a.zc[ci] + uz * (a.zc[ci + 1] - a.zc[ci]) : a.z0 + (ci + uz) * a.hz;
+        a.tx[d] = a.xc ? a.xc[cj] + ux * (a.xc[cj + 1] - a.xc[cj]) : a.x0 + (cj + ux) * a.hx;
         for (int k = 0; k < NFTRAC; k++) a.f[k][d] = mean[k];
         a.f[TR__ID][d] = a.id0 + a.off[c] + q;
         a.vtz[d] = 0.0; a.vtx[d] = 0.0;                             // injected tracers have not been advected yet
@@ -435,6 +440,37 @@ static int ensure_tracers(pl_ctx* ctx, PlStepState* S, long long n) {
 
 static void unpermute(pl_ctx* ctx, PlStepState* S, int na, const double* const* in, double* const* out);
 static int sort_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, double x0, double hx);
+// Host midpoint grids (pylamp2.py:92-95) and device copies of all coordinate arrays the marker kernels use:
+// gcoords = [ node z (nz) | node x (nx) | padded centres z (nz+1) | padded centres x (nx+1) ]; the centre
+// (midpoint) grids of the staggered targets are the padded ones without their first entry.
+static int ensure_coords(pl_ctx* ctx, PlStepState* S) {
+    if (S->gcoords) return 0;
+    if (S->gmz.empty()) {
+        for (int d = 0; d < 2; d++) {
+            const std::vector<double>& c = d ? ctx->geom.xc : ctx->geom.zc;
+            std::vector<double>& m = d ? S->gmx : S->gmz;
+            for (size_t k = 0; k + 1 < c.size(); k++) m.push_back(0.5 * (c[k + 1] + c[k]));
+            m.push_back(m.back() + (m.back() - m[m.size() - 2]));
+        }
+    }
+    std::vector<double> h;
+    h.insert(h.end(), ctx->geom.zc.begin(), ctx->geom.zc.end());
+    h.insert(h.end(), ctx->geom.xc.begin(), ctx->geom.xc.end());
+    h.push_back(S->gmz[0] - (S->gmz[1] - S->gmz[0])); h.insert(h.end(), S->gmz.begin(), S->gmz.end());   // padded centres
+    h.push_back(S->gmx[0] - (S->gmx[1] - S->gmx[0])); h.insert(h.end(), S->gmx.begin(), S->gmx.end());
+    PL_HIP(ctx, hipMalloc((void**)&S->gcoords, h.size() * sizeof(double)));
+    PL_HIP(ctx, hipMemcpy(S->gcoords, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+    return 0;
+}
+// device coordinates of a (possibly staggered) target node set; NULL on a regular grid (arithmetic lookup)
+static const double* coords_z(pl_ctx* ctx, PlStepState* S, int stag) {
+    if (ctx->geom.uniform) return nullptr;
+    return stag ? S->gcoords + ctx->nz + ctx->nx + 1 : S->gcoords;
+}
+static const double* coords_x(pl_ctx* ctx, PlStepState* S, int stag) {
+    if (ctx->geom.uniform) return nullptr;
+    return stag ? S->gcoords + ctx->nz + ctx->nx + (ctx->nz + 1) + 1 : S->gcoords + ctx->nz;
+}
 static int migrate_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, double x0, double hx);
 
 extern "C" int pl_tracers_upload(pl_ctx* ctx, int64_t n, const double* tr_x, const double* tr_f) {
@@ -464,6 +500,7 @@ extern "C" int pl_tracers_upload(pl_ctx* ctx, int64_t n, const double* tr_x, con
     PL_TRY(pl_allreduce_host(ctx, idmax, 1, 2));
     S->next_id = idmax[0] + 1.0;
     // cell-sort (and, on a slab, hand over anything that does not belong here)
+    PL_TRY(ensure_coords(ctx, S));
     const int nz = ctx->nz, nx = ctx->nx;
     const double z0 = ctx->geom.zc[0], x0 = ctx->geom.xc[0];
     const double hz = (ctx->geom.zc[nz - 1] - z0) / (nz - 1), hx = (ctx->geom.xc[nx - 1] - x0) / (nx - 1);
@@ -550,8 +587,8 @@ static int sort_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, doubl
     }
     PL_HIP(ctx, hipMemsetAsync(S->cell_count, 0, (size_t)(nc + 1) * sizeof(int), ctx->stream));
     if (n > 0)
-        hipLaunchKernelGGL(k_cell_count, grid1d(n), dim3(256), 0, ctx->stream, n, S->tz, S->tx, z0, hz, x0, hx, ncz, ncx,
-                           S->crow0, g.nz - 1, S->cell, S->cell_count);
+        hipLaunchKernelGGL(k_cell_count, grid1d(n), dim3(256), 0, ctx->stream, n, S->tz, S->tx, z0, hz, x0, hx, coords_z(ctx, S, 0),
+                           coords_x(ctx, S, 0), ncz, ncx, S->crow0, g.nz - 1, S->cell, S->cell_count);
     const int m = nc + 1, nb = (m + 1023) / 1024;
     hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(256), 0, ctx->stream, m, S->cell_count, S->cell_start, S->block_sums);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, ctx->stream, nb, S->block_sums);
@@ -655,6 +692,7 @@ static int inject_tracers(pl_ctx* ctx, PlStepState* S, const pl_step_config* cfg
     a.tz = S->tz; a.tx = S->tx; for (int k = 0; k < NFTRAC; k++) a.f[k] = S->f[k];
     a.vtz = S->vtz; a.vtx = S->vtx;
     a.z0 = z0; a.hz = hz; a.x0 = x0; a.hx = hx; a.seed = cfg->inject_seed; a.step = (unsigned)it; a.id0 = id0;
+    a.zc = coords_z(ctx, S, 0); a.xc = coords_x(ctx, S, 0);
     hipLaunchKernelGGL(k_inject, dim3((nc + 63) / 64), dim3(64), 0, ctx->stream, a);
     hipLaunchKernelGGL(k_iota, grid1d(m), dim3(256), 0, ctx->stream, (long long)m, S->orig + S->n, (int)S->n);
     PL_HIP(ctx, hipGetLastError());
@@ -669,12 +707,13 @@ static double now_ms() {
 
 // scatter a set of tracer fields onto a staggered node set, writing ring planes
 static int scatter_to_planes(pl_ctx* ctx, PlStepState* S, int nf, const int* fidx, const int* schemes, double z0, double hz,
-                             double x0, double hx, double* const* planes) {
+                             double x0, double hx, double* const* planes, int stag_z = 0, int stag_x = 0) {
     const PlGeom& g = ctx->geom.d;
     PlScatterArgs a{};
     a.n = S->n; a.tz = S->tz; a.tx = S->tx; a.nf = nf;
     for (int k = 0; k < nf; k++) { a.f[k] = fidx[k] >= 0 ? S->f[fidx[k]] : S->tmp[-fidx[k] - 1]; a.scheme[k] = schemes[k]; }
     a.z0 = z0; a.hz = hz; a.x0 = x0; a.hx = hx; a.nz = g.nz; a.nx = g.nx;
+    a.zc = coords_z(ctx, S, stag_z); a.xc = coords_x(ctx, S, stag_x);
     a.cell_start = S->cell_start; a.ncz = S->ncz; a.ncx = S->ncx; a.crow0 = S->crow0;     // cell-sorted (sort_tracers)
     return pl_scatter_device(ctx, a, planes, g.pitch, pl_idx(g, 0, 0), &g);
 }
@@ -684,7 +723,7 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
     PL_HIP(ctx, hipSetDevice(ctx->device));
     PlStepState* S = state_of(ctx);
     if (S->n <= 0 && ctx->nranks == 1) return pl_fail(ctx, "pl_step: no tracers resident (call pl_tracers_upload)");
-    if (!ctx->geom.uniform) return pl_fail(ctx, "pl_step: marker-in-cell needs a regular grid (pylamp_trac.py:34,162)");
+    PL_TRY(ensure_coords(ctx, S));
     PL_TRY(pl_stokes_check_bc(ctx, cfg->bcstokes));
     if (cfg->do_heatdiff) PL_TRY(pl_heat_check_bc(ctx, cfg->bcheat));
     const PlGeom& g = ctx->geom.d;
@@ -727,12 +766,12 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
         double* pl6[6] = {p_rho, p_etas, p_cp, p_T, p_H, p_mat};
         PL_TRY(scatter_to_planes(ctx, S, 6, fi, sc, z0, hz, x0, hx, pl6));
         const int f1[1] = {TR_ETA}; const int s1[1] = {GW}; double* pn[1] = {p_etan};
-        PL_TRY(scatter_to_planes(ctx, S, 1, f1, s1, z0 + 0.5 * hz, hz, x0 + 0.5 * hx, hx, pn));
+        PL_TRY(scatter_to_planes(ctx, S, 1, f1, s1, z0 + 0.5 * hz, hz, x0 + 0.5 * hx, hx, pn, 1, 1));
         const int f2[1] = {TR_HCD}; const int s2[1] = {AW};
         double* pk[1] = {p_kz};
-        PL_TRY(scatter_to_planes(ctx, S, 1, f2, s2, z0 + 0.5 * hz, hz, x0, hx, pk));
+        PL_TRY(scatter_to_planes(ctx, S, 1, f2, s2, z0 + 0.5 * hz, hz, x0, hx, pk, 1, 0));
         pk[0] = p_kx;
-        PL_TRY(scatter_to_planes(ctx, S, 1, f2, s2, z0, hz, x0 + 0.5 * hx, hx, pk));
+        PL_TRY(scatter_to_planes(ctx, S, 1, f2, s2, z0, hz, x0 + 0.5 * hx, hx, pk, 0, 1));
         if (it > 1 && S->have_newtemp)
             hipLaunchKernelGGL(k_copy_boundary, grid2d(g), dim3(64, 4), 0, ctx->stream, g, p_newT, p_T);
     } else {
@@ -740,7 +779,7 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
         double* pl2[2] = {p_rho, p_etas};
         PL_TRY(scatter_to_planes(ctx, S, 2, fi, sc, z0, hz, x0, hx, pl2));
         const int f1[1] = {TR_ETA}; const int s1[1] = {PL_AVG_GEOMETRIC}; double* pn[1] = {p_etan};   // pylamp2.py:319 (unweighted)
-        PL_TRY(scatter_to_planes(ctx, S, 1, f1, s1, z0 + 0.5 * hz, hz, x0 + 0.5 * hx, hx, pn));
+        PL_TRY(scatter_to_planes(ctx, S, 1, f1, s1, z0 + 0.5 * hz, hz, x0 + 0.5 * hx, hx, pn, 1, 1));
     }
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     rep->ms_scatter = now_ms() - t0;
@@ -814,14 +853,6 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
     // ---- 5. heat (pylamp2.py:412-480) ----------------------------------------------------------------
     if (cfg->do_heatdiff) {
         t0 = now_ms();
-        if (S->gmz.empty()) {
-            for (int d = 0; d < 2; d++) {
-                const std::vector<double>& c = d ? ctx->geom.xc : ctx->geom.zc;
-                std::vector<double>& m = d ? S->gmx : S->gmz;
-                for (size_t k = 0; k + 1 < c.size(); k++) m.push_back(0.5 * (c[k + 1] + c[k]));
-                m.push_back(m.back() + (m.back() - m[m.size() - 2]));
-            }
-        }
         PL_TRY(pl_heat_tables(ctx, S->gmz.data(), S->gmx.data()));
         PlHeatOp& hop = ctx->hop;
         hop.g = g; hop.kz = p_kz; hop.kx = p_kx; hop.rhocp_inv_dt = p_c; hop.dt = tstep;
@@ -841,15 +872,6 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
 
         // temperature to tracers
         t0 = now_ms();
-        if (!S->gcoords) {
-            std::vector<double> h;
-            h.insert(h.end(), ctx->geom.zc.begin(), ctx->geom.zc.end());
-            h.insert(h.end(), ctx->geom.xc.begin(), ctx->geom.xc.end());
-            h.push_back(S->gmz[0] - (S->gmz[1] - S->gmz[0])); h.insert(h.end(), S->gmz.begin(), S->gmz.end());   // padded centres
-            h.push_back(S->gmx[0] - (S->gmx[1] - S->gmx[0])); h.insert(h.end(), S->gmx.begin(), S->gmx.end());
-            PL_HIP(ctx, hipMalloc((void**)&S->gcoords, h.size() * sizeof(double)));
-            PL_HIP(ctx, hipMemcpy(S->gcoords, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
-        }
         double* cnt;
         PL_TRY(pl_buf(ctx, "mic_counter", 64, &cnt, false));
         PL_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
@@ -859,6 +881,7 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
         ga.g.nz = nz; ga.g.nx = nx; ga.g.gz = S->gcoords; ga.g.gx = S->gcoords + nz;
         ga.g.zmin = ctx->geom.zc[0]; ga.g.xmin = ctx->geom.xc[0];
         ga.g.Lz = ctx->geom.zc[nz - 1] - ctx->geom.zc[0]; ga.g.Lx = ctx->geom.xc[nx - 1] - ctx->geom.xc[0];
+        ga.g.rect = ctx->geom.uniform ? 0 : 1;
         ga.g.pitch = g.pitch; ga.g.off = pl_idx(g, -g.gi0, 0);      // field row index is GLOBAL
         if (it == 1 || !S->have_newtemp) {
             ga.fields[0] = p_newT; ga.out[0] = S->f[TR_TMP];
@@ -891,23 +914,6 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
 
     // ---- 6. advection (pylamp2.py:484-572) ------------------------------------------------------------
     t0 = now_ms();
-    if (!S->gcoords) {
-        if (S->gmz.empty()) {
-            for (int d = 0; d < 2; d++) {
-                const std::vector<double>& c = d ? ctx->geom.xc : ctx->geom.zc;
-                std::vector<double>& m = d ? S->gmx : S->gmz;
-                for (size_t k = 0; k + 1 < c.size(); k++) m.push_back(0.5 * (c[k + 1] + c[k]));
-                m.push_back(m.back() + (m.back() - m[m.size() - 2]));
-            }
-        }
-        std::vector<double> h;
-        h.insert(h.end(), ctx->geom.zc.begin(), ctx->geom.zc.end());
-        h.insert(h.end(), ctx->geom.xc.begin(), ctx->geom.xc.end());
-        h.push_back(S->gmz[0] - (S->gmz[1] - S->gmz[0])); h.insert(h.end(), S->gmz.begin(), S->gmz.end());
-        h.push_back(S->gmx[0] - (S->gmx[1] - S->gmx[0])); h.insert(h.end(), S->gmx.begin(), S->gmx.end());
-        PL_HIP(ctx, hipMalloc((void**)&S->gcoords, h.size() * sizeof(double)));
-        PL_HIP(ctx, hipMemcpy(S->gcoords, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
-    }
     double* V;
     const size_t VN = (size_t)(nz + 1) * (nx + 1);
     PL_TRY(pl_buf(ctx, "advect_vel", 2 * VN * sizeof(double), &V, false));
@@ -948,6 +954,7 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
         const double gz0 = S->gmz[0] - (S->gmz[1] - S->gmz[0]), gx0 = S->gmx[0] - (S->gmx[1] - S->gmx[0]);
         ra.g.zmin = gz0; ra.g.xmin = gx0; ra.g.Lz = S->gmz[nz - 1] - gz0; ra.g.Lx = S->gmx[nx - 1] - gx0;
     }
+    ra.g.rect = ctx->geom.uniform ? 0 : 1;
     ra.g.pitch = nx + 1; ra.g.off = 0;
     ra.Vz = V; ra.Vx = V + VN; ra.dt = tstep;
     ra.tz_out = S->tz2; ra.tx_out = S->tx2; ra.vz_out = S->vtz; ra.vx_out = S->vtx;

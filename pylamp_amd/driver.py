@@ -79,10 +79,21 @@ def mantle_tracers(nx, L, tracdens, rng, perturb=20.0, zrange=None, id0=0):
 
 
 class Simulation:
-    def __init__(self, nx, L, tr_x=None, tr_f=None, options=None, device=None):
+    def __init__(self, nx, L, tr_x=None, tr_f=None, options=None, device=None, grid=None):
+        """grid: optional [z, x] node coordinates from 0 to L (rectilinear, strictly increasing).  The stock
+        driver only builds regular grids (pylamp2.py:90); a non-uniform one makes the marker kernels locate
+        cells by per-axis search."""
         self.nx = [int(nx[0]), int(nx[1])]
         self.L = [float(L[0]), float(L[1])]
-        self.grid = [np.linspace(0, self.L[i], self.nx[i]) for i in range(DIM)]       # pylamp2.py:90
+        if grid is None:
+            self.grid = [np.linspace(0, self.L[i], self.nx[i]) for i in range(DIM)]   # pylamp2.py:90
+        else:
+            self.grid = [np.ascontiguousarray(grid[i], dtype=np.float64) for i in range(DIM)]
+            for i in range(DIM):
+                if self.grid[i].size != self.nx[i] or np.any(np.diff(self.grid[i]) <= 0):
+                    raise Exception("grid: need nx strictly increasing coordinates per axis")
+                if abs(self.grid[i][0]) > 0 or abs(self.grid[i][-1] - self.L[i]) > 1e-12 * self.L[i]:
+                    raise Exception("grid: coordinates must run from 0 to L")
         self.opt = options or Options()
         self.ctx = Context(self.nx, self.grid, device=device)
         self.it = 0

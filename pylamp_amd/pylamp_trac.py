@@ -25,6 +25,15 @@ INTERP_METHOD_VELDIV = 32
 _MAXF = 8
 
 
+def _is_uniform(c):
+    """True for a regular coordinate array (the only kind the reference's marker code handles)."""
+    c = np.asarray(c, dtype=np.float64)
+    if c.size < 3:
+        return True
+    d = np.diff(c)
+    return bool(np.all(np.abs(d - d.mean()) <= 1e-9 * abs(d.mean())))
+
+
 def _ctx_for(nz, nxx):
     # MIC kernels need a device context only for memory/stream; key it by the node counts
     return get_context([nz, nxx], [np.arange(nz, dtype=np.float64), np.arange(nxx, dtype=np.float64)])
@@ -32,8 +41,10 @@ def _ctx_for(nz, nxx):
 
 def grid2trac(tr_x, tr_f, grid, gridfield, nx, defval=np.nan, method=INTERP_METHOD_LINEAR, stopOnError=False):
     """Interpolate gridfield (list of 2-D arrays) to tracer positions, writing tr_f in
-    place (pylamp_trac.py:30-158).  Regular grids only, like the reference."""
+    place (pylamp_trac.py:30-158).  On a non-uniform grid -- which the reference does not support: it
+    picks the cell with the regular-grid formula -- cells are located by per-axis search."""
     assert len(gridfield) == tr_f.shape[1]
+    assert tr_x.shape[0] == tr_f.shape[0] and tr_x.shape[1] == 2      # the reference fails on broadcasting here
     assert (method & INTERP_METHOD_LINEAR) or (method & INTERP_METHOD_NEAREST) or (method & INTERP_METHOD_VELDIV)
     nf = len(gridfield)
     gnz, gnx = int(nx[IZ]), int(nx[IX])
@@ -43,6 +54,7 @@ def grid2trac(tr_x, tr_f, grid, gridfield, nx, defval=np.nan, method=INTERP_METH
     gz, gx = _lib.f64(grid[IZ]), _lib.f64(grid[IX])
     out = np.empty((n, nf))
     nout = C.c_int64(0)
+    ctx.check(ctx.lib.pl_mic_set_search(ctx.h, 0 if (_is_uniform(gz) and _is_uniform(gx)) else 1))
     for k0 in range(0, nf, _MAXF):
         k1 = min(nf, k0 + _MAXF)
         fl = [_lib.f64(gridfield[k]) for k in range(k0, k1)]
@@ -64,6 +76,7 @@ def trac2grid(tr_x, tr_f, mesh, grid, gridfield, nx, distweight=None, avgscheme=
     (pylamp_trac.py:161-318, method ELEM).  `mesh`, `distweight`, `debug` are accepted for
     signature compatibility (the reference uses mesh only for its shape)."""
     assert len(gridfield) == tr_f.shape[1]
+    assert tr_x.shape[0] == tr_f.shape[0] and tr_x.shape[1] == 2      # np.add.at raises on the mismatch in the reference
     if avgscheme is None:
         avgscheme = [INTERP_AVG_ARITHMETIC + INTERP_AVG_WEIGHTED for i in range(len(gridfield))]
     assert type(avgscheme) == type([])
@@ -78,6 +91,10 @@ def trac2grid(tr_x, tr_f, mesh, grid, gridfield, nx, distweight=None, avgscheme=
     z0, x0 = float(gz[0]), float(gx[0])
     hz = float(gz[-1] - gz[0]) / (nz - 1)
     hx = float(gx[-1] - gx[0]) / (nxx - 1)
+    rect = not (_is_uniform(gz) and _is_uniform(gx))       # beyond the reference: per-axis search
+    if rect:
+        gz, gx = np.ascontiguousarray(gz), np.ascontiguousarray(gx)
+        assert gz.size == nz and gx.size == nxx
     nf = len(gridfield)
     for k0 in range(0, nf, _MAXF):
         k1 = min(nf, k0 + _MAXF)
@@ -85,8 +102,12 @@ def trac2grid(tr_x, tr_f, mesh, grid, gridfield, nx, distweight=None, avgscheme=
         outs = [np.empty((nz, nxx)) for _ in range(k1 - k0)]
         op = (_lib.c_double_p * (k1 - k0))(*[_lib.dptr(a) for a in outs])
         sch = (C.c_int * (k1 - k0))(*[int(s) for s in avgscheme[k0:k1]])
-        ctx.check(ctx.lib.pl_trac2grid(ctx.h, n, _lib.dptr(txc), _lib.dptr(sub), k1 - k0, k1 - k0, sch, z0, hz,
-                                       x0, hx, op))
+        if rect:
+            ctx.check(ctx.lib.pl_trac2grid_rect(ctx.h, n, _lib.dptr(txc), _lib.dptr(sub), k1 - k0, k1 - k0, sch,
+                                                _lib.dptr(gz), _lib.dptr(gx), op))
+        else:
+            ctx.check(ctx.lib.pl_trac2grid(ctx.h, n, _lib.dptr(txc), _lib.dptr(sub), k1 - k0, k1 - k0, sch, z0, hz,
+                                           x0, hx, op))
         for k in range(k0, k1):
             gridfield[k][:, :] = outs[k - k0]
     return
@@ -111,6 +132,7 @@ def RK(tr_x, grids, vels, nx, tstep, order=4):
     if vz.shape != (gnz, gnx) or vx.shape != (gnz, gnx) or gz.size != gnz or gx.size != gnx:
         raise Exception("RK: velocity grids must have shape (nz+1, nx+1)")
     v = np.empty((n, DIM)); xn = np.empty((n, DIM))
+    ctx.check(ctx.lib.pl_mic_set_search(ctx.h, 0 if (_is_uniform(gz) and _is_uniform(gx)) else 1))
     ctx.check(ctx.lib.pl_rk4(ctx.h, n, _lib.dptr(txc), gnz, gnx, _lib.dptr(gz), _lib.dptr(gx), _lib.dptr(vz),
                              _lib.dptr(vx), float(tstep), _lib.dptr(v), _lib.dptr(xn)))
     return v, xn

@@ -226,3 +226,74 @@ def test_mic_large_vs_oracle(mods, oracle):
     Z, X = mesh
     exact = 2.0 + Z / L[0] + 3 * X / L[1]
     assert np.max(np.abs(gl[0] - exact)[2:-2, 2:-2]) < 2e-2
+
+
+def test_mic_empty_and_mismatched_inputs(mods):
+    """Edge cases: no tracers at all (every node empty -> NaN, as 0/0 in the reference), ragged inputs raise."""
+    S, D, T = mods
+    nx = [9, 7]; grid = [np.linspace(0, 1, 9), np.linspace(0, 2, 7)]
+    mesh = np.meshgrid(*grid, indexing="ij")
+    gf = [np.zeros(nx)]
+    T.trac2grid(np.zeros((0, 2)), np.zeros((0, 1)), mesh, grid, gf, nx, avgscheme=[T.INTERP_AVG_ARITHW])
+    assert np.isnan(gf[0]).all()
+    tf = np.zeros((0, 1))
+    T.grid2trac(np.zeros((0, 2)), tf, grid, [np.ones(nx)], nx)
+    gr = [np.linspace(-0.1, 1.1, 10), np.linspace(-0.2, 2.2, 8)]
+    v, x = T.RK(np.zeros((0, 2)), gr, [np.ones((10, 8)), np.ones((10, 8))], nx, 1.0)
+    assert v.shape == (0, 2) and x.shape == (0, 2)
+    with pytest.raises(AssertionError):
+        T.trac2grid(np.zeros((3, 2)), np.zeros((4, 1)), mesh, grid, [np.zeros(nx)], nx, avgscheme=[T.INTERP_AVG_ARITHW])
+    with pytest.raises(AssertionError):
+        T.grid2trac(np.zeros((3, 2)), np.zeros((4, 1)), grid, [np.ones(nx)], nx)
+
+
+def _stretched(n, L, rng, ratio=3.0):
+    """strictly increasing coordinates 0..L whose spacings vary smoothly by `ratio`"""
+    h = 1.0 + (ratio - 1.0) * (0.5 + 0.5 * np.sin(np.linspace(0, 2 * np.pi, n - 1) + rng.uniform(0, 6)))
+    c = np.concatenate([[0.0], np.cumsum(h)])
+    return c * (L / c[-1])
+
+
+def test_mic_rectilinear_vs_oracle(mods, oracle):
+    """SURVEY 8 f4 (beyond the reference): on a non-uniform grid the three marker functions locate cells by
+    per-axis search; the oracle's rect_search mode defines the expected values (it reproduces the reference on
+    the reference's own uniform fixtures, tests/test_oracle_golden.py)."""
+    S, D, T = mods
+    rng = np.random.default_rng(11)
+    nx = [33, 41]; L = [2.0, 5.0]
+    grid = [_stretched(nx[0], L[0], rng), _stretched(nx[1], L[1], rng, 4.0)]
+    gridmp = oracle.gridmp_of(grid)
+    n = 20000
+    tr_x = rng.random((n, 2)) * np.array(L)
+    tr_f = np.stack([rng.uniform(1, 2, n), 10 ** rng.uniform(18, 23, n), rng.uniform(0, 1, n), rng.uniform(1, 3, n)], axis=1)
+    sch = [5, 6, 1, 2]
+    mesh = np.meshgrid(*grid, indexing="ij")
+    for tg in ([grid[0], grid[1]], [gridmp[0], gridmp[1]], [gridmp[0], grid[1]], [grid[0], gridmp[1]]):
+        gf = [np.zeros(nx) for _ in sch]
+        T.trac2grid(tr_x, tr_f, mesh, tg, gf, nx, avgscheme=sch)
+        with oracle.rect_search():
+            ref = oracle.trac2grid(tr_x, tr_f, tg, nx, sch)
+        for k in range(len(sch)):
+            assert maxrel(gf[k], ref[k]) < 1e-11, (k,)
+    # gathers: inside and outside points, all three methods
+    pts = np.concatenate([tr_x[:4000], rng.uniform(-0.3, 1.3, (500, 2)) * np.array(L)])
+    F = [rng.standard_normal(nx), rng.standard_normal(nx)]
+    for meth in (T.INTERP_METHOD_LINEAR, T.INTERP_METHOD_NEAREST, T.INTERP_METHOD_VELDIV):
+        tf = np.zeros((pts.shape[0], 2))
+        T.grid2trac(pts, tf, grid, F, nx, defval=-3.0, method=meth)
+        with oracle.rect_search():
+            ref = oracle.grid2trac(pts, grid, F, nx, defval=-3.0, method=meth)
+        assert maxrel(tf, ref) < 1e-11, meth
+    # RK4 on the padded centre grid of the same non-uniform mesh
+    gz = np.insert(gridmp[0], 0, gridmp[0][0] - (gridmp[0][1] - gridmp[0][0]))
+    gx = np.insert(gridmp[1], 0, gridmp[1][0] - (gridmp[1][1] - gridmp[1][0]))
+    Vz = 0.05 * rng.standard_normal((nx[0] + 1, nx[1] + 1)); Vx = 0.05 * rng.standard_normal((nx[0] + 1, nx[1] + 1))
+    v, xn = T.RK(tr_x[:5000], [gz, gx], [Vz, Vx], nx, 0.7)
+    with oracle.rect_search():
+        vr, xr = oracle.rk4(tr_x[:5000], [gz, gx], [Vz, Vx], nx, 0.7)
+    assert maxrel(xn, xr) < 1e-12 and maxrel(v, vr) < 1e-9
+    # a uniform grid still takes the reference path
+    ug = [np.linspace(0, L[0], nx[0]), np.linspace(0, L[1], nx[1])]
+    gf = [np.zeros(nx)]
+    T.trac2grid(tr_x, tr_f[:, :1], mesh, ug, gf, nx, avgscheme=[5])
+    assert maxrel(gf[0], oracle.trac2grid(tr_x, tr_f[:, :1], ug, nx, [5])[0]) < 1e-12

@@ -198,3 +198,14 @@ def test_trajectory_surface_stabilisation(oracle):
         assert relerr(out["velz"], g[p + "velz"]) < 1e-7 and relerr(out["velx"], g[p + "velx"]) < 1e-7
         assert abs(ttot - float(g[p + "time"])) < 1e-8 * ttot
         assert relerr(st["tr_x"], g[p + "tr_x"]) < 1e-10
+
+
+def test_rect_search_equals_regular_formula_on_uniform_grids(oracle):
+    """the per-axis search mode of the oracle (defined here, the reference has none) must reproduce
+    the reference wherever the reference is defined, i.e. on its own uniform-grid fixtures."""
+    with oracle.rect_search():
+        for case in ("dense", "sparse", "outside"):
+            test_trac2grid(oracle, case)
+        test_grid2trac(oracle)
+        test_rk4(oracle)
+    assert oracle.RECT_SEARCH is False
