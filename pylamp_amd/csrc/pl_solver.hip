@@ -943,6 +943,8 @@ struct PlSolver {
     double* scal = nullptr;     // device scalars [0..8) + dot partials [8..8+2*DOT_BLOCKS)
     double* hpart = nullptr;    // pinned host copy of the dot partials
     int nu_pre = 2, nu_post = 2, coarse_sweeps = 12;
+    int nu0_pre = -1, nu0_post = -1;                    // finest level only (PYLAMP_MG_NU0), -1: as the other levels
+    bool nu_auto = true;                                // no PYLAMP_MG_NU / PYLAMP_MG_NU0 given: chosen from the grid size
     bool use_tail = true;
     long long tail_knob = 0;                            // PYLAMP_MG_TAIL_NODES (0: automatic)
     long long tail_max_nodes = 33 * 33;                 // levels up to this size run in the fused tail kernel
@@ -962,7 +964,8 @@ static PlSolver* solver_of(pl_ctx* ctx) {
     if (!ctx->krylov) {
         PlSolver* S = new PlSolver();
         // tuning knobs (defaults chosen on MI355X at 2049^2): PYLAMP_MG_NU="pre,post", PYLAMP_MG_COARSE=sweeps
-        if (const char* e = getenv("PYLAMP_MG_NU")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b >= 0 && a + b > 0) { S->nu_pre = a; S->nu_post = b; } }
+        if (const char* e = getenv("PYLAMP_MG_NU")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b >= 0 && a + b > 0) { S->nu_pre = a; S->nu_post = b; S->nu_auto = false; } }
+        if (const char* e = getenv("PYLAMP_MG_NU0")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 1 && b >= 1) { S->nu0_pre = a; S->nu0_post = b; S->nu_auto = false; } }
         if (const char* e = getenv("PYLAMP_MG_COARSE")) { int a = atoi(e); if (a > 0) S->coarse_sweeps = a; }
         if (const char* e = getenv("PYLAMP_MG_TAIL")) S->use_tail = atoi(e) != 0;
         if (const char* e = getenv("PYLAMP_MG_MINCELLS")) { int v = atoi(e); if (v >= 2) S->min_cells = v; }
@@ -1082,6 +1085,15 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
         // one GPU: the 65^2 level is faster as ordinary kernels (64 workgroups) than inside the single-workgroup
         // tail (94 vs 99 ms per solve at 2049^2); several ranks: every distributed level costs halo exchanges, so
         // the replicated tail starts as early as it can
+        // Smoothing sweeps.  On large grids the finest level is ~2/3 of a V-cycle's time: V(1,1) there (the first
+        // sweep from the zero guess is nearly free) and V(3,3) below measured 80 vs 85 ms (mantle 2049^2),
+        // 148 vs 196 ms (1e3 block 2049^2), 62 vs 76 ms (block 1025^2); small grids are launch-bound and keep
+        // V(2,2) everywhere (257^2: 25.6 vs 27.7 ms).
+        if (S->nu_auto) {
+            const bool large = (long long)ctx->nz * ctx->nx >= 1000000LL;
+            S->nu_pre = S->nu_post = large ? 3 : 2;
+            S->nu0_pre = S->nu0_post = large ? 1 : -1;
+        }
         S->tail_max_nodes = S->tail_knob ? S->tail_knob : (R > 1 ? (long long)PL_TAIL_MAX_NODES : 33LL * 33);
         S->tail_start = -1;
         for (int l = 0;; l++) {
@@ -1282,7 +1294,8 @@ static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const double* f, double**
         return;
     }
     const int hp = S->mg_halo;
-    smooth(ctx, L, buf, f, S->nu_pre, S->cheb_ratio, nullptr, true, hp);
+    const int npre = (l == 0 && S->nu0_pre > 0) ? S->nu0_pre : S->nu_pre, npost = (l == 0 && S->nu0_post > 0) ? S->nu0_post : S->nu_post;
+    smooth(ctx, L, buf, f, npre, S->cheb_ratio, nullptr, true, hp);
     if (L->dist && hp >= 1) (void)pl_halo_rows(ctx, g, buf[0], 2, g.plane);
     if (g_vv_vec)
         hipLaunchKernelGGL(k_vv_sweep2<1>, pl_grid_rows2(g), dim3(64, 4), 0, ctx->stream, L->op, buf[0], (const double*)nullptr, f,
@@ -1306,7 +1319,7 @@ static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const double* f, double**
     if (C->dist && hp >= 1) (void)pl_halo_rows(ctx, C->gh.d, ec, 2, C->gh.d.plane);
     hipLaunchKernelGGL(k_vv_prolong_add, grid2d(g), dim3(64, 4), 0, ctx->stream, L->op, C->gh.d, ec, buf[0], buf[2]);
     std::swap(buf[0], buf[2]);
-    smooth(ctx, L, buf, f, S->nu_post, S->cheb_ratio, final_out, false, hp);
+    smooth(ctx, L, buf, f, npost, S->cheb_ratio, final_out, false, hp);
     *out = buf[0];
 }
 
