@@ -936,7 +936,10 @@ struct MgLevel {
 struct PlSolver {
     std::vector<MgLevel*> levels;
     int bc_key[4] = {-1, -1, -1, -1};
-    int tail_start = -1;        // first replicated level (multi-rank: levels below are distributed)
+    int repl_start = -1;        // multi-rank: first REPLICATED level (all-gathered, solved redundantly by every rank);
+                                // the finer levels are distributed row slabs with halo exchanges
+    long long repl_max_nodes = 150000;   // PYLAMP_MG_REPL_NODES: a level this small costs less to compute redundantly
+                                         // (~9 launch-bound kernels) than its 8 halo exchanges per cycle
     // BiCGStab work vectors (3 planes each)
     double *r = nullptr, *rt = nullptr, *p = nullptr, *v = nullptr, *s = nullptr, *t = nullptr, *y = nullptr,
            *z = nullptr, *b = nullptr, *x = nullptr, *xb = nullptr;
@@ -969,6 +972,7 @@ static PlSolver* solver_of(pl_ctx* ctx) {
         if (const char* e = getenv("PYLAMP_MG_COARSE")) { int a = atoi(e); if (a > 0) S->coarse_sweeps = a; }
         if (const char* e = getenv("PYLAMP_MG_TAIL")) S->use_tail = atoi(e) != 0;
         if (const char* e = getenv("PYLAMP_MG_MINCELLS")) { int v = atoi(e); if (v >= 2) S->min_cells = v; }
+        if (const char* e = getenv("PYLAMP_MG_REPL_NODES")) { long long v = atoll(e); if (v >= 25) S->repl_max_nodes = v; }
         if (const char* e = getenv("PYLAMP_MG_TAIL_NODES")) { long long v = atoll(e); if (v >= 25 && v <= PL_TAIL_MAX_NODES) S->tail_knob = v; }
         if (const char* e = getenv("PYLAMP_MG_HALO")) S->mg_halo = atoi(e);
         if (const char* e = getenv("PYLAMP_MG_TAIL_NU")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a + b > 0) { S->tail_nu_pre = a; S->tail_nu_post = b; } }
@@ -1095,18 +1099,18 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
             S->nu0_pre = S->nu0_post = large ? 1 : -1;
         }
         S->tail_max_nodes = S->tail_knob ? S->tail_knob : (R > 1 ? (long long)PL_TAIL_MAX_NODES : 33LL * 33);
-        S->tail_start = -1;
+        S->repl_start = -1;
         for (int l = 0;; l++) {
             MgLevel* L = new MgLevel();
             if (pl_geom_build(ctx, L->gh, nz, nx, zc.data(), xc.data())) { delete L; return 1; }
-            if (S->tail_start < 0 && l > 0 && (long long)nz * nx <= S->tail_max_nodes) S->tail_start = l;
-            if (R > 1 && S->tail_start < 0) {                     // distributed level
+            if (S->repl_start < 0 && l > 0 && (long long)nz * nx <= S->repl_max_nodes) S->repl_start = l;
+            if (R > 1 && S->repl_start < 0) {                     // distributed level
                 const int C = (nz - 1) / R;
                 if ((nz - 1) % R || C < 2 || (C % 2)) { delete L; return pl_fail(ctx, "multigrid: (nz-1) must be divisible by ranks*2^levels down to the replicated coarse grid"); }
                 L->dist = true;
                 pl_geom_set_rows(L->gh, ctx->rank * C, (ctx->rank == R - 1) ? C + 1 : C);
             }
-            if (R > 1 && l == S->tail_start) {                    // window of the replicated arrays
+            if (R > 1 && l == S->repl_start) {                    // window of the replicated arrays
                 const int C = (nz - 1) / R;
                 if ((nz - 1) % R || C < 1) { delete L; return pl_fail(ctx, "multigrid: coarse grid smaller than the number of ranks"); }
                 L->win = L->gh.d; L->win.gi0 = ctx->rank * C; L->win.lnz = (ctx->rank == R - 1) ? C + 1 : C;
@@ -1127,8 +1131,8 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
             zc.swap(z2); xc.swap(x2); nz = (nz - 1) / 2 + 1; nx = (nx - 1) / 2 + 1;
         }
         if (R > 1) {
-            if (S->tail_start < 0 || !S->use_tail || (int)S->levels.size() - S->tail_start > PL_TAIL_MAX_LEVELS)
-                return pl_fail(ctx, "multigrid: the multi-rank solver needs a replicated coarse tail (grid too small or too deep)");
+            if (S->repl_start < 0)
+                return pl_fail(ctx, "multigrid: the multi-rank solver needs replicated coarse levels (grid too small to coarsen)");
         }
         S->bc_key[0] = key[0]; S->bc_key[2] = key[2];
     }
@@ -1142,7 +1146,7 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
                 PL_TRY(pl_halo_rows(ctx, F->gh.d, F->etas, 1, F->gh.d.plane));
                 PL_TRY(pl_halo_rows(ctx, F->gh.d, F->etan, 1, F->gh.d.plane));
             }
-            if (R > 1 && (int)l == S->tail_start) {
+            if (R > 1 && (int)l == S->repl_start) {
                 // my rows of the replicated arrays, then all-gather (+ the last node row)
                 const long long sh = (long long)L->win_rows0 * L->gh.d.pitch;
                 hipLaunchKernelGGL(k_coarsen_visc, grid2d(L->win), dim3(64, 4), 0, ctx->stream, F->gh.d, F->etas, F->etan,
@@ -1159,7 +1163,7 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
             }
         }
         level_flags(L, sop, l == 0);
-        if (R > 1 && (int)l == S->tail_start) {           // window view shares flags and pointers (shifted)
+        if (R > 1 && (int)l == S->repl_start) {           // window view shares flags and pointers (shifted)
             const PlGeom w = L->win;
             (void)w;
         }
@@ -1177,7 +1181,7 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
             if (l == 0) { L->rho = (double*)sop.rho; continue; }
             MgLevel* F = S->levels[l - 1];
             if (F->dist && l > 1) PL_TRY(pl_halo_rows(ctx, F->gh.d, F->rho, 1, F->gh.d.plane));
-            if (R > 1 && (int)l == S->tail_start) {
+            if (R > 1 && (int)l == S->repl_start) {
                 const long long sh = (long long)L->win_rows0 * L->gh.d.pitch;
                 hipLaunchKernelGGL(k_coarsen_node, grid2d(L->win), dim3(64, 4), 0, ctx->stream, F->gh.d, F->rho, L->win, L->rho + sh);
                 const long long cnt = (long long)((L->gh.d.nz - 1) / R) * L->gh.d.pitch;
