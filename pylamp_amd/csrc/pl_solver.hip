@@ -1013,6 +1013,28 @@ static int dmalloc0(pl_ctx* ctx, double** p, size_t bytes) {
     return 0;
 }
 
+// ---- BiCGStab scalars kept on the device -------------------------------------------------------------
+// alpha and omega are produced and consumed on the device (sc[0], sc[1] hold the two sums of the last
+// dots_dev call; sc[2] = alpha, sc[3] = omega): two of the three host round trips per iteration (~30 us of
+// idle GPU each) disappear; the third (rho, ||r||) stays because the host decides whether to go on.
+__global__ void k_scalar_alpha(double* __restrict__ sc, double rho_new) { sc[2] = rho_new / sc[0]; }
+__global__ void k_scalar_omega(double* __restrict__ sc) { sc[3] = (sc[1] > 0.0) ? sc[0] / sc[1] : 0.0; }   // t = 0: s is already the residual
+// y = a - alpha b
+__global__ void k_s_update_dev(long long n, double* __restrict__ y, const double* __restrict__ a, const double* __restrict__ b,
+                               const double* __restrict__ sc) {
+    const double alpha = sc[2];
+    long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; k < n; k += (long long)gridDim.x * blockDim.x) y[k] = a[k] - alpha * b[k];
+}
+// x += alpha y + omega z ; r = s - omega t
+__global__ void k_xr_update_dev(long long n, double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z,
+                                double* __restrict__ r, const double* __restrict__ s, const double* __restrict__ t,
+                                const double* __restrict__ sc) {
+    const double alpha = sc[2], omega = sc[3];
+    long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; k < n; k += (long long)gridDim.x * blockDim.x) { x[k] += alpha * y[k] + omega * z[k]; r[k] = s[k] - omega * t[k]; }
+}
+
 // sum the block partials on the device (one workgroup): out[0], out[1]
 __global__ __launch_bounds__(256) void k_sum_partials(int nb, const double* __restrict__ part, double* __restrict__ out) {
     double s0 = 0.0, s1 = 0.0;
@@ -1047,6 +1069,23 @@ static int dots(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const double*
     for (int k = 0; k < nb; k++) { s0 += S->hpart[2 * k]; s1 += S->hpart[2 * k + 1]; }
     out2[0] = s0; out2[1] = s1;
     if (ctx->nranks > 1 && g.lnz != g.nz) PL_TRY(pl_allreduce_host(ctx, out2, 2, 0));
+    return 0;
+}
+
+// the device-scalar path needs the global sums on the device: one rank, or the native (stream-ordered) all-reduce
+static bool dots_on_device(pl_ctx* ctx, const PlGeom& g) {
+    return ctx->nranks == 1 || g.lnz == g.nz || pl_comm_native_enabled(ctx);
+}
+// sums of the two dot products into S->scal[0..1], no host synchronisation
+static int dots_dev(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const double* a, const double* b, const double* c,
+                    const double* d) {
+    long long rows = (long long)g.lnz * np;
+    const int nb = (int)(rows < DOT_BLOCKS ? rows : DOT_BLOCKS);
+    if (a && c) hipLaunchKernelGGL((k_dot2<true, true>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 8);
+    else if (a) hipLaunchKernelGGL((k_dot2<true, false>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 8);
+    else hipLaunchKernelGGL((k_dot2<false, true>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 8);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, nb, S->scal + 8, S->scal);
+    if (ctx->nranks > 1 && g.lnz != g.nz) PL_TRY(pl_comm_allreduce_dev(ctx, S->scal, 2));
     return 0;
 }
 
@@ -1381,6 +1420,7 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
     PL_HIP(ctx, hipMemsetAsync(w.p, 0, bytes, ctx->stream));
     PL_HIP(ctx, hipMemsetAsync(w.v, 0, bytes, ctx->stream));
     double rho = 1.0, alpha = 1.0, omega = 1.0;
+    const bool on_device = dots_on_device(ctx, g) && !getenv("PYLAMP_HOST_SCALARS");
     PL_TRY(dots(ctx, S, g, np, w.rt, w.r, w.r, w.r, d2));
     double rho_new = d2[0], rnorm = std::sqrt(d2[1]);
     int it = 0;
@@ -1395,24 +1435,42 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
         const double* yv = w.p;
         if (M) { PL_TRY((*M)(w.p, w.y)); yv = w.y; }
         PL_TRY(A(yv, w.v));
-        PL_TRY(dots(ctx, S, g, np, w.rt, w.v, nullptr, nullptr, d2));
-        if (!(std::fabs(d2[0]) > 0.0) || !std::isfinite(d2[0])) break;
-        alpha = rho_new / d2[0];
-        hipLaunchKernelGGL(k_axpy_out, grid1d(n), dim3(256), 0, ctx->stream, n, w.s, w.r, w.v, -alpha);
         const double* zv = w.s;
-        if (M) { PL_TRY((*M)(w.s, w.z)); zv = w.z; }
-        PL_TRY(A(zv, w.t));
-        PL_TRY(dots(ctx, S, g, np, w.t, w.s, w.t, w.t, d2));
-        if (!(d2[1] > 0.0) || !std::isfinite(d2[1])) {        // s is already (numerically) zero
-            hipLaunchKernelGGL(k_xr_update, grid1d(n), dim3(256), 0, ctx->stream, n, x, yv, zv, w.r, w.s, w.t, alpha, 0.0);
-            rnorm = 0.0;
-            break;
+        if (on_device) {
+            // alpha, omega stay on the device; a breakdown (rt.v = 0) shows up as a non-finite alpha / ||r|| below
+            PL_TRY(dots_dev(ctx, S, g, np, w.rt, w.v, nullptr, nullptr));
+            hipLaunchKernelGGL(k_scalar_alpha, dim3(1), dim3(1), 0, ctx->stream, S->scal, rho_new);
+            hipLaunchKernelGGL(k_s_update_dev, grid1d(n), dim3(256), 0, ctx->stream, n, w.s, w.r, w.v, S->scal);
+            if (M) { PL_TRY((*M)(w.s, w.z)); zv = w.z; }
+            PL_TRY(A(zv, w.t));
+            PL_TRY(dots_dev(ctx, S, g, np, w.t, w.s, w.t, w.t));
+            hipLaunchKernelGGL(k_scalar_omega, dim3(1), dim3(1), 0, ctx->stream, S->scal);
+            hipLaunchKernelGGL(k_xr_update_dev, grid1d(n), dim3(256), 0, ctx->stream, n, x, yv, zv, w.r, w.s, w.t, S->scal);
+            PL_HIP(ctx, hipMemcpyAsync(S->hpart + 2 * DOT_BLOCKS, S->scal + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            rho = rho_new;
+            PL_TRY(dots(ctx, S, g, np, w.rt, w.r, w.r, w.r, d2));       // synchronises: alpha, omega have arrived too
+            alpha = S->hpart[2 * DOT_BLOCKS]; omega = S->hpart[2 * DOT_BLOCKS + 1];
+            rho_new = d2[0]; rnorm = std::sqrt(d2[1]);
+            if (!std::isfinite(alpha)) break;
+        } else {
+            PL_TRY(dots(ctx, S, g, np, w.rt, w.v, nullptr, nullptr, d2));
+            if (!(std::fabs(d2[0]) > 0.0) || !std::isfinite(d2[0])) break;
+            alpha = rho_new / d2[0];
+            hipLaunchKernelGGL(k_axpy_out, grid1d(n), dim3(256), 0, ctx->stream, n, w.s, w.r, w.v, -alpha);
+            if (M) { PL_TRY((*M)(w.s, w.z)); zv = w.z; }
+            PL_TRY(A(zv, w.t));
+            PL_TRY(dots(ctx, S, g, np, w.t, w.s, w.t, w.t, d2));
+            if (!(d2[1] > 0.0) || !std::isfinite(d2[1])) {        // s is already (numerically) zero
+                hipLaunchKernelGGL(k_xr_update, grid1d(n), dim3(256), 0, ctx->stream, n, x, yv, zv, w.r, w.s, w.t, alpha, 0.0);
+                rnorm = 0.0;
+                break;
+            }
+            omega = d2[0] / d2[1];
+            hipLaunchKernelGGL(k_xr_update, grid1d(n), dim3(256), 0, ctx->stream, n, x, yv, zv, w.r, w.s, w.t, alpha, omega);
+            rho = rho_new;
+            PL_TRY(dots(ctx, S, g, np, w.rt, w.r, w.r, w.r, d2));
+            rho_new = d2[0]; rnorm = std::sqrt(d2[1]);
         }
-        omega = d2[0] / d2[1];
-        hipLaunchKernelGGL(k_xr_update, grid1d(n), dim3(256), 0, ctx->stream, n, x, yv, zv, w.r, w.s, w.t, alpha, omega);
-        rho = rho_new;
-        PL_TRY(dots(ctx, S, g, np, w.rt, w.r, w.r, w.r, d2));
-        rho_new = d2[0]; rnorm = std::sqrt(d2[1]);
         if (!std::isfinite(rnorm) || !(std::fabs(omega) > 0.0)) break;
         if (rnorm < 0.9 * best && w.xbest) {
             best = rnorm; best_it = it; have_best = true;
@@ -1442,7 +1500,7 @@ static int stokes_alloc(pl_ctx* ctx, PlSolver* S) {
         PL_TRY(dmalloc0(ctx, q, vb));
     if (!S->scal) {
         PL_TRY(dmalloc0(ctx, &S->scal, (8 + 2 * DOT_BLOCKS) * sizeof(double)));
-        PL_HIP(ctx, hipHostMalloc((void**)&S->hpart, 2 * DOT_BLOCKS * sizeof(double)));
+        PL_HIP(ctx, hipHostMalloc((void**)&S->hpart, (2 * DOT_BLOCKS + 8) * sizeof(double)));
     }
     return 0;
 }
@@ -1590,7 +1648,7 @@ int pl_heat_solve_device(pl_ctx* ctx, const double* b_dev, double rtol, int maxi
     for (int k = 0; k < 9; k++) if (!S->h[k]) PL_TRY(dmalloc0(ctx, &S->h[k], pb));
     if (!S->scal) {
         PL_TRY(dmalloc0(ctx, &S->scal, (8 + 2 * DOT_BLOCKS) * sizeof(double)));
-        PL_HIP(ctx, hipHostMalloc((void**)&S->hpart, 2 * DOT_BLOCKS * sizeof(double)));
+        PL_HIP(ctx, hipHostMalloc((void**)&S->hpart, (2 * DOT_BLOCKS + 8) * sizeof(double)));
     }
     PL_TRY(pl_timer_start(ctx));
     PlHeatOp hop = ctx->hop;
