@@ -6,6 +6,9 @@
 
 #define TB(tab, k) (tab)[(k) + PL_TOFF]
 
+// SCALED: y = D^-1 A T (the Jacobi-scaled operator the heat solver iterates on), diagonal from the values
+// already loaded.
+template <bool SCALED>
 __global__ __launch_bounds__(256) void k_heat_apply(PlHeatOp op, const double* __restrict__ T,
                                                     double* __restrict__ y) {
     const PlGeom& g = op.g;
@@ -14,23 +17,29 @@ __global__ __launch_bounds__(256) void k_heat_apply(PlHeatOp op, const double* _
     const int i = g.gi0 + li, j = g.gj0 + lj, nz = g.nz, nx = g.nx, p = g.pitch;
     const long long c = pl_idx(g, li, lj);
     const double t = T[c];
-    double r;
+    double r, dg = 1.0;
     if (i == 0) {                                   // z = 0 owns its corners (pylamp_diff.py:99-110)
-        r = (op.bc[0] == PL_BC_FIXTEMP) ? t : op.kz[c] * (T[c + p] - t) * TB(g.rdz, 0);
+        if (op.bc[0] == PL_BC_FIXTEMP) r = t;
+        else { const double k = op.kz[c] * TB(g.rdz, 0); r = k * (T[c + p] - t); dg = -k; }
     } else if (i == nz - 1) {                       // z = Lz (pylamp_diff.py:112-124)
-        r = (op.bc[2] == PL_BC_FIXTEMP) ? t : op.kz[c - p] * (t - T[c - p]) * TB(g.rdz, nz - 2);
+        if (op.bc[2] == PL_BC_FIXTEMP) r = t;
+        else { const double k = op.kz[c - p] * TB(g.rdz, nz - 2); r = k * (t - T[c - p]); dg = k; }
     } else if (j == 0) {                            // x = 0 (pylamp_diff.py:126-138)
-        r = (op.bc[1] == PL_BC_FIXTEMP) ? t : op.kx[c] * (T[c + 1] - t) * TB(g.rdx, 0);
+        if (op.bc[1] == PL_BC_FIXTEMP) r = t;
+        else { const double k = op.kx[c] * TB(g.rdx, 0); r = k * (T[c + 1] - t); dg = -k; }
     } else if (j == nx - 1) {                       // x = Lx (pylamp_diff.py:140-152)
-        r = (op.bc[3] == PL_BC_FIXTEMP) ? t : op.kx[c - 1] * (t - T[c - 1]) * TB(g.rdx, nx - 2);
+        if (op.bc[3] == PL_BC_FIXTEMP) r = t;
+        else { const double k = op.kx[c - 1] * TB(g.rdx, nx - 2); r = k * (t - T[c - 1]); dg = k; }
     } else {                                        // interior (pylamp_diff.py:157-177)
-        const double fx = (op.kx[c] * (T[c + 1] - t) * TB(g.rdx, j) - op.kx[c - 1] * (t - T[c - 1]) * TB(g.rdx, j - 1)) *
-                          TB(op.rdxb, j);
-        const double fz = (op.kz[c] * (T[c + p] - t) * TB(g.rdz, i) - op.kz[c - p] * (t - T[c - p]) * TB(g.rdz, i - 1)) *
-                          TB(op.rdzb, i);
-        r = op.rhocp_inv_dt[c] * (fx + fz) - t;
+        const double ke = op.kx[c] * TB(g.rdx, j), kw = op.kx[c - 1] * TB(g.rdx, j - 1);
+        const double kn = op.kz[c] * TB(g.rdz, i), ks = op.kz[c - p] * TB(g.rdz, i - 1);
+        const double fx = (ke * (T[c + 1] - t) - kw * (t - T[c - 1])) * TB(op.rdxb, j);
+        const double fz = (kn * (T[c + p] - t) - ks * (t - T[c - p])) * TB(op.rdzb, i);
+        const double cc = op.rhocp_inv_dt[c];
+        r = cc * (fx + fz) - t;
+        if (SCALED) dg = -cc * ((ke + kw) * TB(op.rdxb, j) + (kn + ks) * TB(op.rdzb, i)) - 1.0;
     }
-    y[c] = r;
+    y[c] = SCALED ? r / dg : r;
 }
 
 __global__ __launch_bounds__(256) void k_heat_rhs(PlHeatOp op, const double* __restrict__ Told,
@@ -62,8 +71,9 @@ __global__ __launch_bounds__(256) void k_heat_coef(PlGeom g, const double* __res
 
 static dim3 grid2d(const PlGeom& g) { return dim3((g.lnx + 63) / 64, (g.lnz + 3) / 4); }
 
-void pl_launch_heat_apply(pl_ctx* ctx, const PlHeatOp& op, const double* x, double* y) {
-    hipLaunchKernelGGL(k_heat_apply, grid2d(op.g), dim3(64, 4), 0, ctx->stream, op, x, y);
+void pl_launch_heat_apply(pl_ctx* ctx, const PlHeatOp& op, const double* x, double* y, bool scaled) {
+    if (scaled) hipLaunchKernelGGL(k_heat_apply<true>, grid2d(op.g), dim3(64, 4), 0, ctx->stream, op, x, y);
+    else hipLaunchKernelGGL(k_heat_apply<false>, grid2d(op.g), dim3(64, 4), 0, ctx->stream, op, x, y);
 }
 
 void pl_launch_heat_rhs(pl_ctx* ctx, const PlHeatOp& op, const double* Told, const double* H, double* rhs) {

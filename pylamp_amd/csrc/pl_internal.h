@@ -177,7 +177,7 @@ int pl_vec3_download(pl_ctx* ctx, const PlGeom& g, const double* dvec, double* h
 // ---- kernels launched from several units -------------------------------------------------
 void pl_launch_stokes_apply(pl_ctx* ctx, const PlStokesOp& op, const double* x, double* y);
 void pl_launch_stokes_rhs(pl_ctx* ctx, const PlStokesOp& op, double* rhs);
-void pl_launch_heat_apply(pl_ctx* ctx, const PlHeatOp& op, const double* x, double* y);
+void pl_launch_heat_apply(pl_ctx* ctx, const PlHeatOp& op, const double* x, double* y, bool scaled = false);
 
 // ---- device-resident entry points shared between units -----------------------------------
 void pl_launch_heat_rhs(pl_ctx* ctx, const PlHeatOp& op, const double* Told, const double* H, double* rhs);

@@ -1655,8 +1655,7 @@ int pl_heat_solve_device(pl_ctx* ctx, const double* b_dev, double rtol, int maxi
     S->napply = 0;
     VecOp A = [&](const double* in, double* out) -> int {
         PL_TRY(pl_halo_rows(ctx, g, (double*)in, 1, g.plane));
-        pl_launch_heat_apply(ctx, hop, in, out);
-        hipLaunchKernelGGL(k_heat_dinv, grid2d(g), dim3(64, 4), 0, ctx->stream, hop, out);
+        pl_launch_heat_apply(ctx, hop, in, out, true);          // D^-1 A in one pass
         S->napply++;
         return 0;
     };
