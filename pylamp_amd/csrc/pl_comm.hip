@@ -197,10 +197,11 @@ int pl_comm_native_init(pl_ctx* ctx) {
     N->ok = true;
     const long long cnt = 64; const int R = ctx->nranks, r = ctx->rank;
     double* t = nullptr;
-    bool pass = pl_buf(ctx, "nccl_selftest", (size_t)(6 * cnt + R * cnt) * sizeof(double), &t, true) == 0;
-    std::vector<double> h((size_t)(6 * cnt + R * cnt), 0.0);
+    bool pass = pl_buf(ctx, "nccl_selftest", (size_t)(6 * cnt + R * cnt + 2) * sizeof(double), &t, true) == 0;
+    std::vector<double> h((size_t)(6 * cnt + R * cnt + 2), 0.0);
     if (pass) {
-        // layout: [recv_lo | own_first | own_last | recv_hi | acc_lo | acc_hi | gather(R*cnt)]
+        // layout: [recv_lo | own_first | own_last | recv_hi | acc_lo | acc_hi | gather(R*cnt) | all-reduce(2)]
+        hipLaunchKernelGGL(k_comm_fill, dim3(1), dim3(64), 0, ctx->stream, 2, t + 6 * cnt + (long long)R * cnt, 1.0 + r);
         hipLaunchKernelGGL(k_comm_fill, dim3(1), dim3(64), 0, ctx->stream, cnt, t + cnt, 100.0 + r);
         hipLaunchKernelGGL(k_comm_fill, dim3(1), dim3(64), 0, ctx->stream, cnt, t + 2 * cnt, 200.0 + r);
         hipLaunchKernelGGL(k_comm_fill, dim3(1), dim3(64), 0, ctx->stream, 2 * cnt, t + 4 * cnt, 1.0);
@@ -208,6 +209,7 @@ int pl_comm_native_init(pl_ctx* ctx) {
         pass = native_exchange(ctx, t + cnt, t, t + 2 * cnt, t + 3 * cnt, cnt, 1, 0, 0) == 0 &&
                native_exchange(ctx, t + cnt, t + 4 * cnt, t + 2 * cnt, t + 5 * cnt, cnt, 1, 0, 1) == 0 &&
                native_allgather(ctx, t + 6 * cnt, cnt, 1, 0) == 0 &&
+               pl_comm_allreduce_dev(ctx, t + 6 * cnt + (long long)R * cnt, 2) == 0 &&
                hipMemcpyAsync(h.data(), t, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
                hipStreamSynchronize(ctx->stream) == hipSuccess;
     }
@@ -217,6 +219,8 @@ int pl_comm_native_init(pl_ctx* ctx) {
             if (r < R - 1 && (h[3 * cnt + k] != 100.0 + (r + 1) || h[5 * cnt + k] != 1.0 + 100.0 + (r + 1))) pass = false;
             for (int q = 0; q < R && pass; q++) if (h[6 * cnt + (long long)q * cnt + k] != 300.0 + q) pass = false;
         }
+        const double want = 0.5 * R * (R + 1);                     // sum over ranks of (1 + r)
+        if (h[6 * cnt + (long long)R * cnt] != want || h[6 * cnt + (long long)R * cnt + 1] != want) pass = false;
     }
     flag[0] = pass ? 1.0 : 0.0;
     PL_TRY(pl_allreduce_host(ctx, flag, 1, 1));
