@@ -54,17 +54,30 @@ def kernel_roofline(sim, reps):
     n = count * sim.nx[1]                   # nodes of this rank's slab (the whole grid on one GPU)
     alg_bytes = 64.0 * n                    # x 24 + etas 8 + etan 8 + y 24 B per node
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-    traffic = None
+    traffic = None; tj = {}
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tf):
         try:
-            traffic = json.load(open(tf)).get("k_stokes_apply", {}).get(str(sim.nx[1]) if abs(count - sim.nx[1]) <= 1 else "-")
+            tj = json.load(open(tf))
+            traffic = tj.get("k_stokes_apply", {}).get(str(sim.nx[1]) if abs(count - sim.nx[1]) <= 1 else "-")
         except Exception:
             traffic = None
+    # the kernel with the largest share of the step: one Chebyshev sweep of the finest multigrid level
+    sweep = None
+    try:
+        ctx.check(ctx.lib.pl_stokes_sweep_bench(ctx.h, reps, C.byref(ms)))
+        sb = 80.0 * n                       # v 16 + v_prev 16 + f 16 + etas 8 + etan 8 + write 16 B per node
+        sweep = {"kernel": "k_vv_sweep2<0> (Chebyshev sweep, finest level)", "bound": "hbm",
+                 "achieved": round(sb / (ms.value * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(sb / (ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                 "traffic": tj.get("k_vv_sweep2_cheb", {}).get(str(sim.nx[1]) if abs(count - sim.nx[1]) <= 1 else "-"),
+                 "algorithmic_bytes_per_launch": sb, "avg_launch_ms": round(ms.value, 5), "launches_timed": reps}
+    except Exception:
+        sweep = None
     return {"kernel": "k_stokes_apply", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 5),
-            "best_launch_ms": round(best, 5), "launches_timed": reps}
+            "best_launch_ms": round(best, 5), "launches_timed": reps, "smoother": sweep}
 
 
 def cpu_baseline(n=257, tracdens=16, steps=1):

@@ -130,6 +130,9 @@ int  pl_stokes_apply_bench(pl_ctx* ctx, int reps, double* avg_ms);
  * the hierarchy's level count / per-level Chebyshev lambda_max. */
 int  pl_stokes_precond_apply(pl_ctx* ctx, const double* r, double* z);
 int  pl_stokes_mg_info(pl_ctx* ctx, int* nlevels, double* lmax, int max_levels);
+/* Average duration (HIP events) of one Chebyshev smoothing sweep on the finest multigrid level -- the kernel
+ * with the largest share of a time step (80 B/node algorithmic).  Call after at least one solve. */
+int  pl_stokes_sweep_bench(pl_ctx* ctx, int reps, double* avg_ms);
 
 /* ---- Heat: replaces makeDiffusionMatrix (pylamp_diff.py:85-183) + spsolve
  *      (pylamp2.py:419) --------------------------------------------------------------- */

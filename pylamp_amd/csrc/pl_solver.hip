@@ -1623,6 +1623,32 @@ extern "C" int pl_stokes_mg_info(pl_ctx* ctx, int* nlevels, double* lmax, int ma
     return 0;
 }
 
+// Average duration (HIP events on the context stream) of one Chebyshev sweep of the finest multigrid level,
+// the kernel that takes the largest share of a time step.  Needs a built hierarchy (one solve).
+extern "C" int pl_stokes_sweep_bench(pl_ctx* ctx, int reps, double* avg_ms) {
+    if (!ctx->sop_ready) return pl_fail(ctx, "stokes operator not set");
+    PlSolver* S = solver_of(ctx);
+    if (S->levels.empty()) return pl_fail(ctx, "pl_stokes_sweep_bench: no multigrid hierarchy yet (solve once first)");
+    if (reps < 1) reps = 1;
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    MgLevel* L = S->levels[0];
+    const PlGeom& g = L->gh.d;
+    const double lmax = L->lmax, lmin = lmax / S->cheb_ratio, theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
+    const double sigma = theta / delta, rho1 = 1.0 / (2.0 * sigma - 1.0 / sigma);
+    const double c1 = rho1 / sigma, c2 = 2.0 * rho1 / delta;           // coefficients of a second sweep
+    auto launch = [&]() {
+        hipLaunchKernelGGL(k_vv_sweep2<0>, pl_grid_rows2(g), dim3(64, 4), 0, ctx->stream, L->op, L->v[0], L->v[1], L->f, L->v[2], c1, c2);
+    };
+    launch();
+    PL_TRY(pl_timer_start(ctx));
+    for (int r = 0; r < reps; r++) launch();
+    double ms = 0;
+    PL_TRY(pl_timer_stop_ms(ctx, &ms));
+    PL_HIP(ctx, hipGetLastError());
+    if (avg_ms) *avg_ms = ms / reps;
+    return 0;
+}
+
 // =========================================================================================
 // Heat solve: BiCGStab on the Jacobi-scaled operator D^-1 A
 // =========================================================================================
