@@ -150,3 +150,42 @@ def test_unattainable_tolerance_returns_best_iterate():
     ev, ep = _vel_err(S, x, g["x"], nx)
     assert np.isfinite(x).all() and ev < VEL_TOL, (ev, st)
     assert st["rel_residual"] < 1e-9 and st["iterations"] < 600, st
+
+
+def test_cross_check_kernel_variants(oracle):
+    """The scalar one-column-per-lane multigrid kernels (PYLAMP_VV_VEC=0) and the host-scalar BiCGStab loop
+    (PYLAMP_HOST_SCALARS=1) are kept as cross-checks of the vectorised / device-scalar defaults: same problem,
+    every variant must reach the oracle's direct solution, with iteration counts in the same range."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, json
+sys.path.insert(0, %r)
+import numpy as np
+from pylamp_amd import pylamp_stokes as S
+from oracle import pylamp_oracle as O
+rng = np.random.default_rng(9)
+n = 129; nx = [n, n]; grid = [np.linspace(0, 660e3, n), np.linspace(0, 660e3, n)]
+def fld():            # smooth random field over 2 decades (8 passes of a 5-point average)
+    a = rng.uniform(0, 2, nx)
+    for _ in range(8):
+        p = np.pad(a, 1, mode="edge")
+        a = (p[:-2, 1:-1] + p[2:, 1:-1] + p[1:-1, :-2] + p[1:-1, 2:] + 4 * a) / 8
+    return 1e19 * 10 ** ((a - a.min()) / (a.max() - a.min()) * 2)
+etas = fld(); etan = fld(); rho = 3300 + rng.uniform(-50, 50, nx)
+A, rhs = S.makeStokesMatrix(nx, grid, etas, etan, rho, [1, 1, 1, 1])
+x = S.solve(A, rhs)
+xr = O.stokes_solve(nx, grid, etas, etan, rho, [1, 1, 1, 1])
+(vz, vx), _ = S.x2vp(x, nx); (rz, rx), _ = O.x2vp(xr, nx)
+err = float(np.sqrt((np.sum((vz - rz) ** 2) + np.sum((vx - rx) ** 2)) / (np.sum(rz ** 2) + np.sum(rx ** 2))))
+print("RESULT", json.dumps(dict(its=A.last_stats["iterations"], conv=A.last_stats["converged"], err=err)))
+''' % root
+    res = {}
+    for name, env in (("default", {}), ("scalar_kernels", {"PYLAMP_VV_VEC": "0"}), ("host_scalars", {"PYLAMP_HOST_SCALARS": "1"})):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0, (name, r.stderr[-1500:])
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0]
+        res[name] = json.loads(line[7:])
+        assert res[name]["conv"] == 1 and res[name]["err"] < 1e-6, (name, res[name])
+    its = [v["its"] for v in res.values()]
+    assert max(its) <= 1.5 * min(its) + 5, res
