@@ -238,3 +238,15 @@ def test_step_on_nonuniform_grid_vs_oracle(oracle):
         X, F = sim.tracers()
         assert relerr(X, st["tr_x"]) < 1e-7 and relerr(F[:, 3], st["tr_f"][:, 3]) < 1e-6
     sim.close()
+
+
+def test_randomised_step_campaign():
+    """tools/fuzz_step.py: 16 seeded random configurations (grid sizes incl. non-coarsenable ones, NOSLIP/FREESLIP
+    z-walls, heat and T-dependence on/off, uniform and graded grids, block / mantle models, cell aspect 0.7-1.4),
+    two resident steps each against the oracle's step(): velocities, time step, positions and temperature to 1e-5."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_step.py"), "16", "11"], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "failures: 0" in r.stdout, r.stdout[-3000:]
