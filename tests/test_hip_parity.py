@@ -297,3 +297,15 @@ def test_mic_rectilinear_vs_oracle(mods, oracle):
     gf = [np.zeros(nx)]
     T.trac2grid(tr_x, tr_f[:, :1], mesh, ug, gf, nx, avgscheme=[5])
     assert maxrel(gf[0], oracle.trac2grid(tr_x, tr_f[:, :1], ug, nx, [5])[0]) < 1e-12
+
+
+def test_randomised_module_campaign():
+    """tools/fuzz_modules.py: 40 seeded random shapes (5x5 up, uniform and stretched grids, all supported walls,
+    stabilisation on/off): Stokes apply / rhs / explicit matrix, heat apply / rhs / solve, trac2grid (random schemes
+    and staggerings, markers outside the grid) and grid2trac (all methods) against the oracle to 1e-9."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_modules.py"), "40", "5"], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "failures: 0" in r.stdout, r.stdout[-3000:]
