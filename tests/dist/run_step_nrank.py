@@ -59,5 +59,52 @@ for it in (1, 2, 3):
 sim.close()
 if rank == 0:
     print("PASS mantle steps", flush=True)
+
+# ---- 3. graded (non-uniform) grid: per-axis cell search in every marker kernel, slabs of unequal thickness
+nx = [97, 81]; L = [660e3, 550e3]
+
+
+def graded(n, Lx):
+    h = np.linspace(1.0, 2.5, n - 1)
+    c = np.concatenate([[0.0], np.cumsum(h)]); c *= Lx / c[-1]; c[-1] = Lx
+    return c
+
+
+grid = [graded(nx[0], L[0]), graded(nx[1], L[1])]
+rng = np.random.default_rng(8)
+tr_x, tr_f = driver.mantle_tracers(nx, L, 20, rng)
+sim = driver.Simulation(nx, L, tr_x, tr_f, driver.Options(), grid=grid)
+st = dict(nx=nx, L=L, grid=grid, tr_x=tr_x.copy(), tr_f=tr_f.copy())
+for it in (1, 2):
+    rep = sim.step()
+    with O.rect_search():
+        out = O.step(st, cfg, it)
+    assert rep["stokes"]["converged"] == 1 and abs(rep["tstep"] / out["tstep"] - 1) < 1e-6, rep
+    assert relerr(sim.field("velz"), out["velz"]) < 1e-6 and relerr(sim.field("velx"), out["velx"]) < 1e-6
+    assert relerr(sim.field("temp"), out["temp"]) < 1e-6
+    X, F, V = sim.gather_tracers()
+    assert X.shape[0] == tr_x.shape[0]
+    assert relerr(X, st["tr_x"]) < 1e-7 and relerr(F[:, 3], st["tr_f"][:, 3]) < 1e-6
+sim.close()
+if rank == 0:
+    print("PASS graded grid steps", flush=True)
+
+# ---- 4. free-surface stabilisation loop (damping sign): stabilisation-aware multigrid levels across ranks
+g = np.load(os.path.join(ROOT, "tests", "golden", "traj_surfstab41.npz"))
+gz, gx = g["gz"], g["gx"]
+nx = [gz.size, gx.size]; L = [gz[-1], gx[-1]]
+opt = driver.Options(do_heatdiff=False, tdep_rho=False, tdep_eta=False, surface_stabilization=True, surfstab_strict_reference=False)
+sim = driver.Simulation(nx, L, g["init_tr_x"], g["init_tr_f"], opt)
+st = dict(nx=nx, L=L, grid=[gz, gx], tr_x=g["init_tr_x"].copy(), tr_f=g["init_tr_f"].copy())
+cfg2 = O.StepConfig(do_heatdiff=False, tdep_rho=False, tdep_eta=False, surface_stabilization=True, surfstab_theta=-0.5)
+for it in (1, 2):
+    rep = sim.step()
+    out = O.step(st, cfg2, it)
+    assert rep["stokes"]["converged"] == 1 and rep["stokes_resolves"] == out["nresolve"], rep
+    assert abs(rep["tstep"] / out["tstep"] - 1) < 1e-6
+    assert relerr(sim.field("velz"), out["velz"]) < 1e-6 and relerr(sim.field("velx"), out["velx"]) < 1e-6
+sim.close()
+if rank == 0:
+    print("PASS stabilisation loop", flush=True)
 dist.barrier()
 dist.destroy_process_group()

@@ -31,10 +31,11 @@ def test_stokes_heat_row_slabs(nproc):
 
 @pytest.mark.parametrize("nproc", [2, 4])
 def test_resident_step_row_slabs(nproc):
-    """Full time step (scatter with reverse halo, solves, gathers, RK4, tracer migration)."""
+    """Full time step (scatter with reverse halo, solves, gathers, RK4, tracer migration); also on a graded grid
+    (slabs of unequal thickness, per-axis cell search) and with the stabilisation-aware multigrid levels."""
     rc, out = _run("run_step_nrank.py", nproc, 29520 + nproc)
     assert rc == 0, out[-3000:]
-    for tag in ("PASS block trajectory", "PASS mantle steps"):
+    for tag in ("PASS block trajectory", "PASS mantle steps", "PASS graded grid steps", "PASS stabilisation loop"):
         assert tag in out, out[-3000:]
 
 
