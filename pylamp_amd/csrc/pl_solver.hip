@@ -947,6 +947,7 @@ struct PlSolver {
     double* hpart = nullptr;    // pinned host copy of the dot partials
     int nu_pre = 2, nu_post = 2, coarse_sweeps = 12;
     int nu0_pre = -1, nu0_post = -1;                    // finest level only (PYLAMP_MG_NU0), -1: as the other levels
+    bool aniso_auto = true, ratio_knob = false;        // PYLAMP_MG_ANISO=0 / an explicit PYLAMP_MG_RATIO disable the anisotropy rule
     bool nu_auto = true;                                // no PYLAMP_MG_NU / PYLAMP_MG_NU0 given: chosen from the grid size
     bool use_tail = true;
     long long tail_knob = 0;                            // PYLAMP_MG_TAIL_NODES (0: automatic)
@@ -976,7 +977,8 @@ static PlSolver* solver_of(pl_ctx* ctx) {
         if (const char* e = getenv("PYLAMP_MG_TAIL_NODES")) { long long v = atoll(e); if (v >= 25 && v <= PL_TAIL_MAX_NODES) S->tail_knob = v; }
         if (const char* e = getenv("PYLAMP_MG_HALO")) S->mg_halo = atoi(e);
         if (const char* e = getenv("PYLAMP_MG_TAIL_NU")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a + b > 0) { S->tail_nu_pre = a; S->tail_nu_post = b; } }
-        if (const char* e = getenv("PYLAMP_MG_RATIO")) { double v = atof(e); if (v > 1.5) S->cheb_ratio = v; }
+        if (const char* e = getenv("PYLAMP_MG_RATIO")) { double v = atof(e); if (v > 1.5) { S->cheb_ratio = v; S->ratio_knob = true; } }
+        if (const char* e = getenv("PYLAMP_MG_ANISO")) S->aniso_auto = atoi(e) != 0;
         if (const char* e = getenv("PYLAMP_MG_SAFETY")) { double v = atof(e); if (v >= 1.0) S->lmax_safety = v; }
         ctx->krylov = S;
     }
@@ -1136,6 +1138,20 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
             const bool large = (long long)ctx->nz * ctx->nx >= 1000000LL;
             S->nu_pre = S->nu_post = large ? 3 : 2;
             S->nu0_pre = S->nu0_post = large ? 1 : -1;
+        }
+        // Anisotropic cells: with aspect ratio a the modes that oscillate only along the weakly coupled axis sit at
+        // lmax / a^2 -- full coarsening cannot carry them and the default window [lmax/6, lmax] never touches
+        // them.  Widen the window by a^2 and smooth ~a times longer (PYLAMP_MG_ANISO=0 switches this off).
+        if (S->aniso_auto && S->nu_auto && !S->ratio_knob) {
+            const double hz = (ctx->geom.zc.back() - ctx->geom.zc.front()) / (ctx->nz - 1);
+            const double hx = (ctx->geom.xc.back() - ctx->geom.xc.front()) / (ctx->nx - 1);
+            const double a = hz > hx ? hz / hx : hx / hz;
+            S->cheb_ratio = 6.0;
+            if (a > 1.5) {
+                S->cheb_ratio = 6.0 * a * a;
+                int nu = (int)std::ceil(2.0 * a); if (nu > 10) nu = 10;
+                S->nu_pre = S->nu_post = nu; S->nu0_pre = S->nu0_post = -1;
+            }
         }
         S->tail_max_nodes = S->tail_knob ? S->tail_knob : (R > 1 ? (long long)PL_TAIL_MAX_NODES : 33LL * 33);
         S->repl_start = -1;
