@@ -849,6 +849,10 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
     }
     rep->ms_stokes = now_ms() - t0;
     rep->tstep = tstep; rep->limiter = limiter; rep->tstep_heat = tstep_temp; rep->tstep_stokes = tstep_stokes;
+    // the reference would carry a NaN time step on (NaN positions from the next advection); say what happened instead
+    if (!std::isfinite(tstep))
+        return pl_fail(ctx, "pl_step: the time step is not finite - a grid node without any marker in reach makes the interpolated "
+                            "fields NaN (raise the marker density or enable injection)");
 
     // ---- 5. heat (pylamp2.py:412-480) ----------------------------------------------------------------
     if (cfg->do_heatdiff) {

@@ -250,3 +250,16 @@ def test_randomised_step_campaign():
                        timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "failures: 0" in r.stdout, r.stdout[-3000:]
+
+
+def test_step_with_unreachable_nodes_fails_loudly():
+    """Far too few markers: some node has none in reach, its averages are 0/0 = NaN and so is the time step.  The
+    reference would silently carry the NaN into the marker positions; the resident step stops with a message."""
+    from pylamp_amd import driver
+    nx = [41, 41]; L = [660e3, 660e3]
+    rng = np.random.default_rng(2)
+    tr_x, tr_f = driver.mantle_tracers(nx, L, 1, rng)
+    sim = driver.Simulation(nx, L, tr_x[:300], tr_f[:300], driver.Options())
+    with pytest.raises(Exception, match="time step is not finite"):
+        sim.step()
+    sim.close()
