@@ -4,6 +4,13 @@ densities).  Usage: python tools/fuzz_step.py [ncases] [seed] [cell aspect ratio
 import sys, os, traceback
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np
+DIST = "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1
+if DIST:      # torchrun --nproc-per-node N tools/fuzz_step.py ...: N row slabs sharing GPU 0 through the gloo transport
+    os.environ.setdefault("PYLAMP_DEVICE", "0")
+    import torch.distributed as dist
+    dist.init_process_group(backend="gloo")
+R = int(os.environ.get("WORLD_SIZE", "1")) if DIST else 1
+RANK = int(os.environ.get("RANK", "0")) if DIST else 0
 from pylamp_amd import driver
 from oracle import pylamp_oracle as O
 
@@ -16,6 +23,7 @@ relv = lambda a, b: float(np.linalg.norm(np.nan_to_num(a - b)) / max(np.linalg.n
 bad = 0
 for case in range(ncases):
     nz, nxx = int(rng.integers(17, 90)), int(rng.integers(17, 90))
+    if DIST: nz = 16 * R * int(rng.integers(1, 4)) + 1        # even slabs of >= 8 rows that coarsen at least once
     aspect = float(rng.uniform(0.7, 1.4)) if len(sys.argv) <= 3 else float(sys.argv[3])      # cell aspect ratio dx/dz
     nx = [nz, nxx]; L = [660e3, 660e3 * (nxx - 1) / (nz - 1) * aspect]
     heat = bool(rng.integers(0, 2)); tdep = bool(rng.integers(0, 2)) and heat
@@ -46,7 +54,7 @@ for case in range(ncases):
             empty = any(np.isnan(O.trac2grid(tr_x, tr_f[:, [1]] * 0 + 1.0, tg, nx, [5])[0][:nz - 1 + sz, :nxx - 1 + sx]).any()
                         for tg, sz, sx in (([gchk[0], gchk[1]], 1, 1), ([gmp[0], gmp[1]], 0, 0), ([gmp[0], gchk[1]], 1, 1), ([gchk[0], gmp[1]], 1, 0)))
         if empty:
-            print("skip " + desc + "  (a node has no marker in reach)", flush=True)
+            if RANK == 0: print("skip " + desc + "  (a node has no marker in reach)", flush=True)
             continue
         opt = driver.Options(do_heatdiff=heat, tdep_rho=tdep, tdep_eta=tdep, bcstokes=bc)
         sim = driver.Simulation(nx, L, tr_x, tr_f, opt, grid=grid)
@@ -57,16 +65,20 @@ for case in range(ncases):
             rep = sim.step()
             with O.rect_search(graded):
                 out = O.step(st, cfg, it)
+            X = sim.gather_tracers()[0] if DIST else sim.tracers()[0]
             e = dict(vz=relv(sim.field("velz"), out["velz"]), vx=relv(sim.field("velx"), out["velx"]),
-                     dt=abs(rep["tstep"] - out["tstep"]) / out["tstep"], x=rel(sim.tracers()[0], st["tr_x"]))
+                     dt=abs(rep["tstep"] - out["tstep"]) / out["tstep"], x=rel(X, st["tr_x"]) if X.shape == st["tr_x"].shape else 1.0)
             if heat: e["T"] = rel(sim.field("temp"), out["temp"])
             for k, v in e.items(): worst[k] = max(worst.get(k, 0.0), v)
             if not rep["stokes"]["converged"]: worst["noconv"] = 1.0
         sim.close()
         ok = all(v < 1e-5 for k, v in worst.items())
-        print(("ok   " if ok else "FAIL ") + desc + "  " + " ".join("%s=%.1e" % kv for kv in worst.items()), flush=True)
+        if RANK == 0: print(("ok   " if ok else "FAIL ") + desc + "  " + " ".join("%s=%.1e" % kv for kv in worst.items()), flush=True)
         bad += 0 if ok else 1
     except Exception as ex:
         bad += 1
-        print("EXC  " + desc + "  " + repr(ex)[:200], flush=True)
-print("failures:", bad)
+        print("EXC  rank %d " % RANK + desc + "  " + repr(ex)[:200], flush=True)
+        if DIST: raise          # the other ranks would wait forever in the next collective
+if RANK == 0: print("failures:", bad)
+if DIST:
+    dist.barrier(); dist.destroy_process_group()
