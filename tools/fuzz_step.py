@@ -22,7 +22,8 @@ rel = lambda a, b: float(np.linalg.norm(np.nan_to_num(a - b)) / max(np.linalg.no
 relv = lambda a, b: float(np.linalg.norm(np.nan_to_num(a - b)) / max(np.linalg.norm(np.nan_to_num(b)), 1e-13 * np.sqrt(b.size)))
 bad = 0
 for case in range(ncases):
-    nz, nxx = int(rng.integers(17, 90)), int(rng.integers(17, 90))
+    lo_n, hi_n = (int(os.environ.get("FUZZ_NMIN", "17")), int(os.environ.get("FUZZ_NMAX", "90")))
+    nz, nxx = int(rng.integers(lo_n, hi_n)), int(rng.integers(lo_n, hi_n))
     if DIST: nz = 16 * R * int(rng.integers(1, 4)) + 1        # even slabs of >= 8 rows that coarsen at least once
     aspect = float(rng.uniform(0.7, 1.4)) if len(sys.argv) <= 3 else float(sys.argv[3])      # cell aspect ratio dx/dz
     nx = [nz, nxx]; L = [660e3, 660e3 * (nxx - 1) / (nz - 1) * aspect]
