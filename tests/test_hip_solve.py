@@ -189,3 +189,14 @@ print("RESULT", json.dumps(dict(its=A.last_stats["iterations"], conv=A.last_stat
         assert res[name]["conv"] == 1 and res[name]["err"] < 1e-6, (name, res[name])
     its = [v["its"] for v in res.values()]
     assert max(its) <= 1.5 * min(its) + 5, res
+
+
+def test_randomised_solve_campaign():
+    """tools/fuzz_solve.py: 40 seeded random Stokes problems (shapes from 5x5, stretched grids, wall types, smooth
+    viscosity over up to 4 decades) against the oracle's direct solve."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_solve.py"), "40", "2"], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "failures: 0" in r.stdout, r.stdout[-3000:]
