@@ -11,7 +11,9 @@
 // on a single GPU.
 #include "pl_internal.h"
 #include <dlfcn.h>
+#include <chrono>
 #include <cstdlib>
+#include <thread>
 
 typedef struct { char internal[128]; } pl_ncclUniqueId;
 typedef void* pl_ncclComm_t;
@@ -24,6 +26,7 @@ struct PlNccl {
     int (*GetUniqueId)(pl_ncclUniqueId*) = nullptr;
     int (*CommInitRank)(pl_ncclComm_t*, int, pl_ncclUniqueId, int) = nullptr;
     int (*CommDestroy)(pl_ncclComm_t) = nullptr;
+    int (*CommAbort)(pl_ncclComm_t) = nullptr;
     int (*Send)(const void*, size_t, int, int, pl_ncclComm_t, hipStream_t) = nullptr;
     int (*Recv)(void*, size_t, int, int, pl_ncclComm_t, hipStream_t) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, pl_ncclComm_t, hipStream_t) = nullptr;
@@ -174,6 +177,7 @@ int pl_comm_native_init(pl_ctx* ctx) {
         PL_SYM(GetUniqueId, "ncclGetUniqueId") PL_SYM(CommInitRank, "ncclCommInitRank") PL_SYM(CommDestroy, "ncclCommDestroy")
         PL_SYM(Send, "ncclSend") PL_SYM(Recv, "ncclRecv") PL_SYM(AllGather, "ncclAllGather") PL_SYM(AllReduce, "ncclAllReduce")
         PL_SYM(GroupStart, "ncclGroupStart") PL_SYM(GroupEnd, "ncclGroupEnd")
+        N->CommAbort = (decltype(N->CommAbort))dlsym(N->lib, "ncclCommAbort");      // optional
     }
     // 1. does every rank have the library?
     double flag[1] = {good ? 1.0 : 0.0};
@@ -198,6 +202,12 @@ int pl_comm_native_init(pl_ctx* ctx) {
     const long long cnt = 64; const int R = ctx->nranks, r = ctx->rank;
     double* t = nullptr;
     bool pass = pl_buf(ctx, "nccl_selftest", (size_t)(6 * cnt + R * cnt + 2) * sizeof(double), &t, true) == 0;
+    // The self-test runs on a stream of its own and is given 60 s: a transport that hangs must not take the solver
+    // stream (and the whole job) with it - the communicator is aborted and the callback table is used instead.
+    hipStream_t main_stream = ctx->stream, test_stream = nullptr;
+    if (pass && hipStreamCreateWithFlags(&test_stream, hipStreamNonBlocking) != hipSuccess) pass = false;
+    if (pass) { (void)hipStreamSynchronize(main_stream); ctx->stream = test_stream; }
+    bool hung = false;
     std::vector<double> h((size_t)(6 * cnt + R * cnt + 2), 0.0);
     if (pass) {
         // layout: [recv_lo | own_first | own_last | recv_hi | acc_lo | acc_hi | gather(R*cnt) | all-reduce(2)]
@@ -210,9 +220,19 @@ int pl_comm_native_init(pl_ctx* ctx) {
                native_exchange(ctx, t + cnt, t + 4 * cnt, t + 2 * cnt, t + 5 * cnt, cnt, 1, 0, 1) == 0 &&
                native_allgather(ctx, t + 6 * cnt, cnt, 1, 0) == 0 &&
                pl_comm_allreduce_dev(ctx, t + 6 * cnt + (long long)R * cnt, 2) == 0 &&
-               hipMemcpyAsync(h.data(), t, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
-               hipStreamSynchronize(ctx->stream) == hipSuccess;
+               hipMemcpyAsync(h.data(), t, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+        if (pass) {
+            const auto t0 = std::chrono::steady_clock::now();
+            hipError_t q;
+            while ((q = hipStreamQuery(ctx->stream)) == hipErrorNotReady) {
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 60.0) { hung = true; break; }
+                std::this_thread::sleep_for(std::chrono::milliseconds(1));
+            }
+            if (hung || q != hipSuccess) pass = false;
+        }
     }
+    ctx->stream = main_stream;
+    if (test_stream && !hung) (void)hipStreamDestroy(test_stream);       // a hung stream is abandoned
     if (pass) {
         for (long long k = 0; k < cnt && pass; k++) {
             if (r > 0 && (h[k] != 200.0 + (r - 1) || h[4 * cnt + k] != 1.0 + 200.0 + (r - 1))) pass = false;
@@ -225,6 +245,10 @@ int pl_comm_native_init(pl_ctx* ctx) {
     flag[0] = pass ? 1.0 : 0.0;
     PL_TRY(pl_allreduce_host(ctx, flag, 1, 1));
     N->ok = flag[0] > 0.5;
+    if (!N->ok && N->comm) {               // some rank failed or hung: nobody uses the communicator
+        if (N->CommAbort) (void)N->CommAbort(N->comm);
+        N->comm = nullptr;
+    }
     return 0;
 }
 
