@@ -68,16 +68,22 @@ def test_step_vs_oracle_midsize(oracle):
     sim.close()
 
 
-def test_census_and_injection():
+@pytest.mark.parametrize("graded", [False, True])
+def test_census_and_injection(graded):
     """Cells that fall below tracdens_min are refilled to tracdens with tracers carrying the cell
     mean of every field (pylamp2.py:588-633); IDs stay unique; nothing else is touched."""
     from pylamp_amd import driver
     nx = [41, 41]; L = [660e3, 660e3]
     rng = np.random.default_rng(21)
     tr_x, tr_f = driver.falling_block_tracers(nx, L, 8, rng)
-    h = L[0] / 40
+    if graded:          # refined towards the top-left: cells differ 2.5x in size, located by per-axis search
+        hh = np.linspace(1.0, 2.5, 40); c = np.concatenate([[0.0], np.cumsum(hh)]); c *= L[0] / c[-1]; c[-1] = L[0]
+        grid = [c, c.copy()]
+    else:
+        grid = [np.linspace(0, L[0], 41), np.linspace(0, L[1], 41)]
+    cell = lambda x, d: np.clip(np.searchsorted(grid[d], x, side="right") - 1, 0, 39)
     # deplete a patch of cells: keep at most one tracer per cell there
-    ci = np.floor(tr_x[:, 0] / h).astype(int); cj = np.floor(tr_x[:, 1] / h).astype(int)
+    ci = cell(tr_x[:, 0], 0); cj = cell(tr_x[:, 1], 1)
     patch = (ci >= 5) & (ci < 12) & (cj >= 20) & (cj < 30)
     key = ci * 40 + cj
     first = np.zeros(tr_x.shape[0], bool)
@@ -87,7 +93,7 @@ def test_census_and_injection():
     tr_x, tr_f = tr_x[keep], tr_f[keep]
     n0 = tr_x.shape[0]
     opt = driver.Options(do_heatdiff=False, tdep_rho=False, tdep_eta=False, tracdens=8, tracdens_min=3)
-    sim = driver.Simulation(nx, L, tr_x, tr_f, opt)
+    sim = driver.Simulation(nx, L, tr_x, tr_f, opt, grid=grid if graded else None)
     rep = sim.step()
     assert rep["ninjected"] > 0 and rep["ntrac"] == n0 + rep["ninjected"]
     X, F = sim.tracers()
@@ -96,7 +102,7 @@ def test_census_and_injection():
     assert np.array_equal(F[old, 12], tr_f[:, 12])          # resident tracers keep order and identity
     ids = F[:, 12]
     assert np.unique(ids).size == ids.size and ids[new].min() > tr_f[:, 12].max()
-    ci = np.clip(np.floor(X[:, 0] / h).astype(int), 0, 39); cj = np.clip(np.floor(X[:, 1] / h).astype(int), 0, 39)
+    ci = cell(X[:, 0], 0); cj = cell(X[:, 1], 1)
     cnt_all = np.bincount(ci * 40 + cj, minlength=1600)
     cnt_old = np.bincount(ci[old] * 40 + cj[old], minlength=1600)
     deficient = cnt_old < 3
