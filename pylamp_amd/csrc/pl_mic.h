@@ -13,6 +13,7 @@ struct PlScatterArgs {
     int scheme[PL_MAX_SCATTER_FIELDS];
     // regular target node set: node k at z0 + k*hz (k < nz), x0 + k*hx (k < nx)
     double z0, hz, x0, hx;
+    double rhz, rhx;            // 1/hz, 1/hx (filled by pl_scatter_device)
     // rectilinear target node set: coordinates of the nz / nx nodes; NULL = regular (z0, hz, x0, hx)
     const double* zc; const double* xc;
     int nz, nx;
@@ -35,6 +36,7 @@ struct PlGatherGrid {
     int nz, nx;                 // node counts of the field being interpolated
     const double* gz; const double* gx;
     double zmin, xmin, Lz, Lx;
+    double sz, sx;              // (nz-1)/Lz, (nx-1)/Lx (filled by the launch wrappers)
     int rect;                   // 1: cells located by per-axis search in gz/gx (non-uniform grids), 0: the reference's regular formula
     long long pitch, off;       // field element (i,j) is F[off + i*pitch + j] (dense: pitch = nx, off = 0)
 };

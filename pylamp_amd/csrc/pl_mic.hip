@@ -50,9 +50,11 @@ __device__ inline void mic_scatter_locate(const PlScatterArgs& a, double z, doub
         mic_axis_locate(a.zc, a.nz, z, ie, ca);
         mic_axis_locate(a.xc, a.nx, x, je, cb);
     } else {
-        const double fz = floor((z - a.z0) / a.hz), fx = floor((x - a.x0) / a.hx);
+        // reciprocal spacings: four FP64 divisions per marker were a visible share of this ALU-bound kernel
+        const double rhz = a.rhz, rhx = a.rhx;
+        const double fz = floor((z - a.z0) * rhz), fx = floor((x - a.x0) * rhx);
         ie = (int)fz; je = (int)fx;
-        ca = (z - (a.z0 + fz * a.hz)) / a.hz; cb = (x - (a.x0 + fx * a.hx)) / a.hx;
+        ca = (z - (a.z0 + fz * a.hz)) * rhz; cb = (x - (a.x0 + fx * a.hx)) * rhx;
     }
 }
 
@@ -207,6 +209,7 @@ int pl_scatter_device(pl_ctx* ctx, PlScatterArgs& a, double* const* out, long lo
         if (!(s & (PL_AVG_ARITHMETIC | PL_AVG_GEOMETRIC))) return pl_fail(ctx, "!!! ERROR INVALID AVERAGING SCHEME");
         if (s & PL_AVG_WEIGHTED) has_w = true; else has_c = true;
     }
+    a.rhz = 1.0 / a.hz; a.rhx = 1.0 / a.hx;
     if (slab) { a.row0 = slab->gi0 - 1; a.nrows = slab->lnz + 2; }
     else { a.row0 = 0; a.nrows = a.nz; }
     size_t N = (size_t)a.nrows * a.nx;
@@ -264,8 +267,8 @@ __device__ inline CellLoc mic_locate(const PlGatherGrid& g, double z, double x) 
         else { c.a = (z - g.gz[0]) / (g.gz[1] - g.gz[0]); c.b = (x - g.gx[0]) / (g.gx[1] - g.gx[0]); }   // cell (0,0), as the strict path
         return c;
     }
-    const double fi = floor((g.nz - 1) * (z - g.zmin) / g.Lz);
-    const double fj = floor((g.nx - 1) * (x - g.xmin) / g.Lx);
+    const double fi = floor((z - g.zmin) * g.sz);          // the reference divides, (nz-1)(z-zmin)/Lz: same cell except within
+    const double fj = floor((x - g.xmin) * g.sx);          // an ulp of a grid line, where both cells give the same value
     c.bad = !(fi >= 0.0 && fi <= (double)(g.nz - 2) && fj >= 0.0 && fj <= (double)(g.nx - 2));
     c.ie = c.bad ? 0 : (int)fi;
     c.je = c.bad ? 0 : (int)fj;
@@ -353,13 +356,17 @@ __global__ __launch_bounds__(256) void k_rk4(PlRk4Args a) {
     a.tz_out[t] = zf; a.tx_out[t] = xf;
 }
 
-void pl_launch_gather(pl_ctx* ctx, const PlGatherArgs& a) {
-    if (a.n <= 0) return;
+void pl_launch_gather(pl_ctx* ctx, const PlGatherArgs& a_in) {
+    if (a_in.n <= 0) return;
+    PlGatherArgs a = a_in;
+    a.g.sz = (a.g.nz - 1) / a.g.Lz; a.g.sx = (a.g.nx - 1) / a.g.Lx;
     hipLaunchKernelGGL(k_gather, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, ctx->stream, a);
 }
 
-void pl_launch_rk4(pl_ctx* ctx, const PlRk4Args& a) {
-    if (a.n <= 0) return;
+void pl_launch_rk4(pl_ctx* ctx, const PlRk4Args& a_in) {
+    if (a_in.n <= 0) return;
+    PlRk4Args a = a_in;
+    a.g.sz = (a.g.nz - 1) / a.g.Lz; a.g.sx = (a.g.nx - 1) / a.g.Lx;
     hipLaunchKernelGGL(k_rk4, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, ctx->stream, a);
 }
 
