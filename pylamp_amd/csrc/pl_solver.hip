@@ -927,6 +927,7 @@ struct MgLevel {
     PlVvOp op{};
     double* etas = nullptr; double* etan = nullptr; bool own_visc = false;
     double *rho = nullptr, *szz = nullptr, *szx = nullptr;     // free-surface stabilisation (allocated on first use)
+    double* eig = nullptr; bool eig_valid = false;             // dominant eigenvector of D^-1 A from the last solve
     bool own_rho = false;
     double* v[3] = {nullptr, nullptr, nullptr};      // rotating Chebyshev buffers (2 planes each)
     double *f = nullptr, *r = nullptr;
@@ -948,6 +949,7 @@ struct PlSolver {
     int nu_pre = 2, nu_post = 2, coarse_sweeps = 12;
     int nu0_pre = -1, nu0_post = -1;                    // finest level only (PYLAMP_MG_NU0), -1: as the other levels
     bool aniso_auto = true, ratio_knob = false;        // PYLAMP_MG_ANISO=0 / an explicit PYLAMP_MG_RATIO disable the anisotropy rule
+    int power_its_warm = 3;                             // PYLAMP_MG_POWER: power iterations when restarting from the last eigenvector
     bool nu_auto = true;                                // no PYLAMP_MG_NU / PYLAMP_MG_NU0 given: chosen from the grid size
     bool use_tail = true;
     long long tail_knob = 0;                            // PYLAMP_MG_TAIL_NODES (0: automatic)
@@ -970,6 +972,7 @@ static PlSolver* solver_of(pl_ctx* ctx) {
         // tuning knobs (defaults chosen on MI355X at 2049^2): PYLAMP_MG_NU="pre,post", PYLAMP_MG_COARSE=sweeps
         if (const char* e = getenv("PYLAMP_MG_NU")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b >= 0 && a + b > 0) { S->nu_pre = a; S->nu_post = b; S->nu_auto = false; } }
         if (const char* e = getenv("PYLAMP_MG_NU0")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 1 && b >= 1) { S->nu0_pre = a; S->nu0_post = b; S->nu_auto = false; } }
+        if (const char* e = getenv("PYLAMP_MG_POWER")) { int a = atoi(e); if (a >= 1) S->power_its_warm = a; }
         if (const char* e = getenv("PYLAMP_MG_COARSE")) { int a = atoi(e); if (a > 0) S->coarse_sweeps = a; }
         if (const char* e = getenv("PYLAMP_MG_TAIL")) S->use_tail = atoi(e) != 0;
         if (const char* e = getenv("PYLAMP_MG_MINCELLS")) { int v = atoi(e); if (v >= 2) S->min_cells = v; }
@@ -989,7 +992,7 @@ static void free_levels(PlSolver* S) {
     for (MgLevel* L : S->levels) {
         if (L->own_visc) { (void)hipFree(L->etas); (void)hipFree(L->etan); }
         if (L->own_rho && L->rho) (void)hipFree(L->rho);
-        for (double* q : {L->szz, L->szx}) if (q) (void)hipFree(q);
+        for (double* q : {L->szz, L->szx, L->eig}) if (q) (void)hipFree(q);
         for (double* q : {L->v[0], L->v[1], L->v[2], L->f, L->r}) if (q) (void)hipFree(q);
         pl_geom_free(L->gh);
         delete L;
@@ -1257,9 +1260,18 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
     for (MgLevel* L : S->levels) {
         const PlGeom& g = L->gh.d;
         long long n2 = 2 * g.plane;
-        hipLaunchKernelGGL(k_random_interior, grid2d(g), dim3(64, 4), 0, ctx->stream, g, 2, L->v[0], 777u);
-        double lam = 2.5, nn[2];
+        // The viscosity changes little from one time step to the next: the power iteration restarts from the
+        // eigenvector of the previous solve with 3 instead of 12 iterations (each is a kernel + a host round trip;
+        // 12 x 9 levels were ~4 ms of every solve).
+        if (!L->eig) { PL_TRY(dmalloc0(ctx, &L->eig, (size_t)n2 * sizeof(double))); L->eig_valid = false; }
+        if (L->eig_valid) PL_HIP(ctx, hipMemcpyAsync(L->v[0], L->eig, (size_t)n2 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        else hipLaunchKernelGGL(k_random_interior, grid2d(g), dim3(64, 4), 0, ctx->stream, g, 2, L->v[0], 777u);
+        const bool warm = L->eig_valid;
+        double lam = 2.5, lam_prev = 0.0, nn[2];
         for (int it = 0; it < 12; it++) {
+            // warm restart: at least power_its_warm iterations, then stop once the estimate moves by < 1 %
+            if (warm && it >= S->power_its_warm && std::fabs(lam - lam_prev) < 0.01 * lam) break;
+            lam_prev = lam;
             if (L->dist) PL_TRY(pl_halo_rows(ctx, g, L->v[0], 2, g.plane));
             hipLaunchKernelGGL(k_vv_dinv_apply, grid2d(g), dim3(64, 4), 0, ctx->stream, L->op, L->v[0], L->v[1]);
             PL_TRY(dots(ctx, S, g, 2, L->v[1], L->v[1], L->v[0], L->v[0], nn));
@@ -1269,6 +1281,8 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
                                1.0 / std::sqrt(nn[0]) - 1.0);     // v0 = v1 / ||v1||
         }
         L->lmax = S->lmax_safety * lam;
+        PL_HIP(ctx, hipMemcpyAsync(L->eig, L->v[0], (size_t)n2 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        L->eig_valid = std::isfinite(lam) && lam > 0.0;
     }
     return 0;
 }
