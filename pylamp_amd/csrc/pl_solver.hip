@@ -887,23 +887,38 @@ __global__ __launch_bounds__(256) void k_copy_vel(PlGeom g, const double* __rest
 //   -2 Kc rDz_i (P[i,j] - P[i-1,j]) = -1/2 (rho[i,j] + rho[i,j+1]) g
 // which is integrated down every column (one thread per column), then shifted so that the
 // anchor cell is 0.  b - A x_h is the DYNAMIC load the solver's tolerance is measured against.
-__global__ void k_hydrostatic_columns(PlStokesOp op, double* __restrict__ x, double* __restrict__ coltot) {
+// The column integral runs in chunks of PL_HYDRO_CHUNK rows (one thread per column and chunk; a single thread per
+// column took ~1 ms of every solve at 2049 rows): local prefix, exclusive scan of the chunk totals, add back.
+#define PL_HYDRO_CHUNK 64
+__global__ __launch_bounds__(64) void k_hydro_chunk(PlStokesOp op, double* __restrict__ x, double* __restrict__ ctot) {
     const PlGeom& g = op.g;
-    const int lj = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lj = blockIdx.x * 64 + threadIdx.x, ch = blockIdx.y;
     if (lj >= g.lnx) return;
     double* P = x + 2 * g.plane;
     const double* r = op.rho;
+    const int l0 = ch * PL_HYDRO_CHUNK, l1 = min(l0 + PL_HYDRO_CHUNK, g.lnz);
+    const int jn = (lj + 1 < g.nx) ? 1 : 0;
     double acc = 0.0;
-    for (int li = 0; li < g.lnz; li++) {
+    for (int li = l0; li < l1; li++) {
         const int i = g.gi0 + li;
         const long long c = pl_idx(g, li, lj);
-        if (i >= 1 && i <= g.nz - 2) {
-            const int jn = (lj + 1 < g.nx) ? 1 : 0;
-            acc += 0.5 * (r[c] + r[c + jn]) * op.gz / (2.0 * op.Kc * TB(g.rDz, i));
-        }
-        P[c] = acc;                       // relative to the top of this slab; ghost row fixed below
+        if (i >= 1 && i <= g.nz - 2) acc += 0.5 * (r[c] + r[c + jn]) * op.gz / (2.0 * op.Kc * TB(g.rDz, i));
+        P[c] = acc;                       // relative to the top of this chunk
     }
+    ctot[(long long)ch * g.lnx + lj] = acc;
+}
+// per column: chunk totals -> exclusive prefix (in place), column total of the slab
+__global__ __launch_bounds__(64) void k_hydro_chunk_scan(PlGeom g, int nch, double* __restrict__ ctot, double* __restrict__ coltot) {
+    const int lj = blockIdx.x * 64 + threadIdx.x;
+    if (lj >= g.lnx) return;
+    double acc = 0.0;
+    for (int ch = 0; ch < nch; ch++) { const double t = ctot[(long long)ch * g.lnx + lj]; ctot[(long long)ch * g.lnx + lj] = acc; acc += t; }
     coltot[lj] = acc;
+}
+__global__ __launch_bounds__(256) void k_hydro_add(PlGeom g, double* __restrict__ x, const double* __restrict__ cpre) {
+    PL_NODE_PROLOGUE(g)
+    (void)i; (void)j;
+    x[2 * g.plane + c] += cpre[(long long)(li / PL_HYDRO_CHUNK) * g.lnx + lj];      // relative to the top of this slab
 }
 
 // P += prefix[j] (sum of the slabs above) - pa (anchor value); ghosts 0; velocities 0
@@ -1563,7 +1578,14 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
         double *coltot, *prefix;
         PL_TRY(pl_buf(ctx, "hydro_coltot", (size_t)g.lnx * sizeof(double), &coltot));
         PL_TRY(pl_buf(ctx, "hydro_prefix", (size_t)g.lnx * sizeof(double), &prefix));
-        hipLaunchKernelGGL(k_hydrostatic_columns, dim3((g.lnx + 63) / 64), dim3(64), 0, ctx->stream, sop, S->y, coltot);
+        {
+            const int nch = (g.lnz + PL_HYDRO_CHUNK - 1) / PL_HYDRO_CHUNK;
+            double* ctot;
+            PL_TRY(pl_buf(ctx, "hydro_chunks", (size_t)nch * g.lnx * sizeof(double), &ctot));
+            hipLaunchKernelGGL(k_hydro_chunk, dim3((g.lnx + 63) / 64, nch), dim3(64), 0, ctx->stream, sop, S->y, ctot);
+            hipLaunchKernelGGL(k_hydro_chunk_scan, dim3((g.lnx + 63) / 64), dim3(64), 0, ctx->stream, g, nch, ctot, coltot);
+            hipLaunchKernelGGL(k_hydro_add, grid2d(g), dim3(64, 4), 0, ctx->stream, g, S->y, ctot);
+        }
         // prefix over the slabs above + anchor value, through the host
         const int R = ctx->nranks;
         std::vector<double> hb((size_t)R * g.lnx + 1, 0.0);
