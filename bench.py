@@ -141,6 +141,8 @@ def main():
     for _ in range(args.warmup):
         reports.append(sim.step())
     ctx.check(ctx.lib.pl_sync(ctx.h))
+    cc = (C.c_int64 * 4)()
+    ctx.check(ctx.lib.pl_comm_stats(ctx.h, cc, 1))          # counts of the timed region only
     barrier()
     t0 = time.perf_counter()
     timed = []
@@ -149,6 +151,8 @@ def main():
     ctx.check(ctx.lib.pl_sync(ctx.h))
     barrier()
     elapsed = time.perf_counter() - t0
+    ctx.check(ctx.lib.pl_comm_stats(ctx.h, cc, 0))
+    comm_calls = [int(v) for v in cc]
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -189,6 +193,8 @@ def main():
             "heat_iterations": [r["heat"]["iterations"] for r in timed],
             "roofline": roof,
         }
+        if world > 1:       # communication calls of rank 0 per timed step (halo exchanges, all-gathers, device / host all-reduces)
+            out["comm_calls_per_step"] = [round(c / float(args.steps), 1) for c in comm_calls]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -90,6 +90,9 @@ int  pl_local_rows(pl_ctx* ctx, int* first_row, int* n_rows);
  * (dlopen'ed librccl, self-tested at pl_set_comm), 0 when they go through the callback table.
  * PYLAMP_RCCL=0 disables the native path. */
 int  pl_comm_info(pl_ctx* ctx, int* rank, int* nranks, int* native);
+/* Cumulative numbers of communication calls of this context: out[0] neighbour (halo) exchanges, [1] all-gathers,
+ * [2] device all-reduces, [3] host all-reduces; reset != 0 clears the counters after reading. */
+int  pl_comm_stats(pl_ctx* ctx, int64_t out[4], int reset);
 /* raw copies between host and this context's device memory (used by the gloo fallback of the
  * communication layer, which stages through host buffers) */
 int  pl_memcpy_d2h(pl_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);

@@ -102,6 +102,7 @@ static int native_allgather(pl_ctx* ctx, double* recv, long long count, int nseg
 int pl_comm_exchange(pl_ctx* ctx, const double* send_lo, double* recv_lo, const double* send_hi, double* recv_hi,
                      long long count, int nseg, long long stride, int add) {
     if (ctx->nranks <= 1) return 0;
+    ctx->comm_calls[0]++;
     PlNccl* N = nccl_of(ctx);
     if (N && N->ok) return native_exchange(ctx, send_lo, recv_lo, send_hi, recv_hi, count, nseg, stride, add);
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -112,6 +113,7 @@ int pl_comm_exchange(pl_ctx* ctx, const double* send_lo, double* recv_lo, const 
 
 int pl_comm_allgather(pl_ctx* ctx, double* recv, long long count, int nseg, long long stride) {
     if (ctx->nranks <= 1) return 0;
+    ctx->comm_calls[1]++;
     PlNccl* N = nccl_of(ctx);
     if (N && N->ok) return native_allgather(ctx, recv, count, nseg, stride);
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -256,6 +258,7 @@ int pl_comm_native_init(pl_ctx* ctx) {
 int pl_comm_allreduce_dev(pl_ctx* ctx, double* dev, int n) {
     PlNccl* N = nccl_of(ctx);
     if (!(N && N->ok)) return 1;
+    ctx->comm_calls[2]++;
     if (N->AllReduce(dev, dev, (size_t)n, PL_NCCL_DOUBLE, PL_NCCL_SUM, N->comm, ctx->stream))
         return pl_fail(ctx, "RCCL all-reduce failed");
     return 0;

@@ -99,6 +99,7 @@ int pl_halo_rows(pl_ctx* ctx, const PlGeom& g, double* planes, int nplanes, long
 
 int pl_allreduce_host(pl_ctx* ctx, double* buf, long long n, int op) {
     if (ctx->nranks <= 1) return 0;
+    ctx->comm_calls[3]++;
     if (ctx->comm.allreduce_host(ctx->comm.user, buf, n, op)) return pl_fail(ctx, "communication callback 'allreduce_host' failed");
     return 0;
 }
@@ -120,6 +121,12 @@ extern "C" int pl_set_comm(pl_ctx* ctx, int rank, int nranks, const pl_comm_ops*
     ctx->rank = rank; ctx->nranks = nranks; ctx->comm = *ops;
     pl_geom_set_rows(ctx->geom, rank * C, (rank == nranks - 1) ? C + 1 : C);
     return pl_comm_native_init(ctx);      // RCCL directly on the context stream when every rank can
+}
+
+// cumulative counts of the communication calls issued by this context (reset = 1 clears them afterwards)
+extern "C" int pl_comm_stats(pl_ctx* ctx, int64_t out[4], int reset) {
+    for (int k = 0; k < 4; k++) { if (out) out[k] = ctx->comm_calls[k]; if (reset) ctx->comm_calls[k] = 0; }
+    return 0;
 }
 
 extern "C" int pl_comm_info(pl_ctx* ctx, int* rank, int* nranks, int* native) {

@@ -80,6 +80,7 @@ struct pl_ctx {
     std::vector<double> zmp, xmp;
     // multi-GPU (row slabs): rank r owns node rows [row0, row0 + geom.d.lnz)
     int rank = 0, nranks = 1;
+    long long comm_calls[4] = {0, 0, 0, 0};     // neighbour exchanges, all-gathers, device all-reduces, host all-reduces (pl_comm_stats)
     pl_comm_ops comm{};
     void* nccl = nullptr;     // pl_comm.hip: native RCCL transport (optional)
     // opaque extension slots owned by other translation units
