@@ -123,7 +123,7 @@ __device__ inline double cheb_val_z(const PlVvOp& op, const double* __restrict__
     vv_row_z(op, vcur, vcur + op.g.plane, cm, i, j + moff, Av, dg);   // moff is +-1 for vz
     const double v0 = vcur[cm];
     const double mom = (c1 != 0.0) ? c1 * (v0 - (vprev ? vprev[cm] : 0.0)) : 0.0;   // nullptr: previous iterate is zero
-    return s * (v0 + mom + c2 * (Av - f[cm]) / dg);                     // D = -dg
+    return s * (v0 + mom + (c2 * (Av - f[cm])) * pl_rcp(dg));                     // D = -dg
 }
 __device__ inline double cheb_val_x(const PlVvOp& op, const double* __restrict__ vcur, const double* __restrict__ vprev,
                                     const double* __restrict__ f, double c1, double c2, int i, int j, int c) {
@@ -136,7 +136,7 @@ __device__ inline double cheb_val_x(const PlVvOp& op, const double* __restrict__
     vv_row_x(op, vcur, vcur + P, cm, im, j, Av, dg);
     const double v0 = (vcur + P)[cm];
     const double mom = (c1 != 0.0) ? c1 * (v0 - (vprev ? (vprev + P)[cm] : 0.0)) : 0.0;
-    return s * (v0 + mom + c2 * (Av - (f + P)[cm]) / dg);
+    return s * (v0 + mom + (c2 * (Av - (f + P)[cm])) * pl_rcp(dg));
 }
 __device__ inline void cheb_node(const PlVvOp& op, const double* __restrict__ vcur, const double* __restrict__ vprev,
                                  const double* __restrict__ f, double* __restrict__ vnext, double c1, double c2, int i,
@@ -171,14 +171,14 @@ __device__ inline void cheb_first_node(const PlVvOp& op, const double* __restric
     int moff = 0; double s = 1.0;
     int cls = vv_cls_z(op, i, j, moff, s);
     double out = 0.0;
-    if (cls != VV_ZERO) { const int cm = c + moff; out = -s * c2 * fz[cm] / vv_diag_z(op, cm, i, j + moff); }
+    if (cls != VV_ZERO) { const int cm = c + moff; out = (-s * c2 * fz[cm]) * pl_rcp(vv_diag_z(op, cm, i, j + moff)); }
     vnext[c] = out;
     cls = vv_cls_x(op, i, j, moff, s);
     out = 0.0;
     if (cls != VV_ZERO) {
         const int cm = c + moff;
         const int im = i + (moff > 0 ? 1 : (moff < 0 ? -1 : 0));
-        out = -s * c2 * fx[cm] / vv_diag_x(op, cm, im, j);
+        out = (-s * c2 * fx[cm]) * pl_rcp(vv_diag_x(op, cm, im, j));
     }
     (vnext + P)[c] = out;
 }
