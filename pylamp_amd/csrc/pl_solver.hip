@@ -510,7 +510,8 @@ struct TailArgs { int nlev; int nu_pre, nu_post, coarse_sweeps; double ratio; Ta
 #define TAIL_FOR_NODES(g)                                                              \
     for (int idx_ = threadIdx.x; idx_ < (g).lnz * (g).lnx; idx_ += blockDim.x)
 
-__device__ inline void tail_smooth(const TailLevel& L, double* buf[3], int nsweep, double ratio) {
+// zero_guess: buf[0] is taken as zero without being read (first sweep = -c2 f / diag, second without v_prev)
+__device__ inline void tail_smooth(const TailLevel& L, double* buf[3], int nsweep, double ratio, bool zero_guess = false) {
     const double lmax = L.lmax, lmin = lmax / ratio;
     const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
     double rho_old = 1.0 / sigma;
@@ -521,7 +522,9 @@ __device__ inline void tail_smooth(const TailLevel& L, double* buf[3], int nswee
         else { const double rho = 1.0 / (2.0 * sigma - rho_old); c1 = rho * rho_old; c2 = 2.0 * rho / delta; rho_old = rho; }
         TAIL_FOR_NODES(g) {
             const int li = idx_ / g.lnx, lj = idx_ % g.lnx;
-            cheb_node(L.op, buf[0], buf[1], L.f, buf[2], c1, c2, g.gi0 + li, g.gj0 + lj, pl_idx(g, li, lj));
+            if (k == 0 && zero_guess) cheb_first_node(L.op, L.f, buf[2], c2, g.gi0 + li, g.gj0 + lj, pl_idx(g, li, lj));
+            else cheb_node(L.op, buf[0], (k == 1 && zero_guess) ? (const double*)nullptr : buf[1], L.f, buf[2], c1, c2, g.gi0 + li,
+                           g.gj0 + lj, pl_idx(g, li, lj));
         }
         __syncthreads();
         double* nxt = buf[2]; buf[2] = buf[1]; buf[1] = buf[0]; buf[0] = nxt;
@@ -535,13 +538,16 @@ __global__ __launch_bounds__(1024) void k_mg_tail(TailArgs a) {
         const TailLevel& L = a.L[l];
         const PlGeom& g = L.op.g;
         double* buf[3] = {L.v[0], L.v[1], L.v[2]};
-        TAIL_FOR_NODES(g) { const long long c = pl_idx(g, idx_ / g.lnx, idx_ % g.lnx); buf[0][c] = 0.0; buf[0][c + g.plane] = 0.0; }
-        __syncthreads();
-        if (l == a.nlev - 1) {
+        const bool coarsest = l == a.nlev - 1;
+        if ((coarsest ? a.coarse_sweeps : a.nu_pre) < 1) {             // nothing will write the zero guess: do it here
+            TAIL_FOR_NODES(g) { const long long c = pl_idx(g, idx_ / g.lnx, idx_ % g.lnx); buf[0][c] = 0.0; buf[0][c + g.plane] = 0.0; }
+            __syncthreads();
+        }
+        if (coarsest) {
             double ratio = 0.4 * g.nz * g.nx; if (ratio < 30.0) ratio = 30.0;
-            tail_smooth(L, buf, a.coarse_sweeps, ratio);
+            tail_smooth(L, buf, a.coarse_sweeps, ratio, true);
         } else {
-            tail_smooth(L, buf, a.nu_pre, a.ratio);
+            tail_smooth(L, buf, a.nu_pre, a.ratio, true);
             TAIL_FOR_NODES(g) { const int li = idx_ / g.lnx, lj = idx_ % g.lnx; residual_node(L.op, buf[0], L.f, L.r, g.gi0 + li, g.gj0 + lj, pl_idx(g, li, lj)); }
             __syncthreads();
             const TailLevel& C = a.L[l + 1];
