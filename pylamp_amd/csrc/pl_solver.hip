@@ -1062,7 +1062,9 @@ __global__ void k_xr_update_dev(long long n, double* __restrict__ x, const doubl
 }
 
 // sum the block partials on the device (one workgroup): out[0], out[1]
-__global__ __launch_bounds__(256) void k_sum_partials(int nb, const double* __restrict__ part, double* __restrict__ out) {
+// mode 1 / 2 (single rank): also derive alpha = rho_new / out[0] -> out[2], resp. omega = out[0] / out[1] -> out[3]
+__global__ __launch_bounds__(256) void k_sum_partials(int nb, const double* __restrict__ part, double* __restrict__ out,
+                                                      int mode = 0, double rho_new = 0.0) {
     double s0 = 0.0, s1 = 0.0;
     for (int k = threadIdx.x; k < nb; k += 256) { s0 += part[2 * k]; s1 += part[2 * k + 1]; }
     __shared__ double sh[2][4];
@@ -1070,7 +1072,12 @@ __global__ __launch_bounds__(256) void k_sum_partials(int nb, const double* __re
     for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_down(s0, o, 64); s1 += __shfl_down(s1, o, 64); }
     if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s0; sh[1][threadIdx.x >> 6] = s1; }
     __syncthreads();
-    if (threadIdx.x == 0) { out[0] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]; out[1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]; }
+    if (threadIdx.x == 0) {
+        const double a0 = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3], a1 = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+        out[0] = a0; out[1] = a1;
+        if (mode == 1) out[2] = rho_new / a0;
+        if (mode == 2) out[3] = (a1 > 0.0) ? a0 / a1 : 0.0;
+    }
 }
 
 static int dots(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const double* a, const double* b, const double* c,
@@ -1103,15 +1110,22 @@ static bool dots_on_device(pl_ctx* ctx, const PlGeom& g) {
     return ctx->nranks == 1 || g.lnz == g.nz || pl_comm_native_enabled(ctx);
 }
 // sums of the two dot products into S->scal[0..1], no host synchronisation
+// mode 1 / 2: alpha resp. omega are derived in the same pass (see k_sum_partials); with several ranks the sums
+// are all-reduced first and a one-thread kernel derives the scalar
 static int dots_dev(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const double* a, const double* b, const double* c,
-                    const double* d) {
+                    const double* d, int mode, double rho_new) {
     long long rows = (long long)g.lnz * np;
     const int nb = (int)(rows < DOT_BLOCKS ? rows : DOT_BLOCKS);
     if (a && c) hipLaunchKernelGGL((k_dot2<true, true>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 8);
     else if (a) hipLaunchKernelGGL((k_dot2<true, false>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 8);
     else hipLaunchKernelGGL((k_dot2<false, true>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 8);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, nb, S->scal + 8, S->scal);
-    if (ctx->nranks > 1 && g.lnz != g.nz) PL_TRY(pl_comm_allreduce_dev(ctx, S->scal, 2));
+    const bool reduce = ctx->nranks > 1 && g.lnz != g.nz;
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, nb, S->scal + 8, S->scal, reduce ? 0 : mode, rho_new);
+    if (reduce) {
+        PL_TRY(pl_comm_allreduce_dev(ctx, S->scal, 2));
+        if (mode == 1) hipLaunchKernelGGL(k_scalar_alpha, dim3(1), dim3(1), 0, ctx->stream, S->scal, rho_new);
+        if (mode == 2) hipLaunchKernelGGL(k_scalar_omega, dim3(1), dim3(1), 0, ctx->stream, S->scal);
+    }
     return 0;
 }
 
@@ -1488,13 +1502,11 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
         const double* zv = w.s;
         if (on_device) {
             // alpha, omega stay on the device; a breakdown (rt.v = 0) shows up as a non-finite alpha / ||r|| below
-            PL_TRY(dots_dev(ctx, S, g, np, w.rt, w.v, nullptr, nullptr));
-            hipLaunchKernelGGL(k_scalar_alpha, dim3(1), dim3(1), 0, ctx->stream, S->scal, rho_new);
+            PL_TRY(dots_dev(ctx, S, g, np, w.rt, w.v, nullptr, nullptr, 1, rho_new));
             hipLaunchKernelGGL(k_s_update_dev, grid1d(n), dim3(256), 0, ctx->stream, n, w.s, w.r, w.v, S->scal);
             if (M) { PL_TRY((*M)(w.s, w.z)); zv = w.z; }
             PL_TRY(A(zv, w.t));
-            PL_TRY(dots_dev(ctx, S, g, np, w.t, w.s, w.t, w.t));
-            hipLaunchKernelGGL(k_scalar_omega, dim3(1), dim3(1), 0, ctx->stream, S->scal);
+            PL_TRY(dots_dev(ctx, S, g, np, w.t, w.s, w.t, w.t, 2, 0.0));
             hipLaunchKernelGGL(k_xr_update_dev, grid1d(n), dim3(256), 0, ctx->stream, n, x, yv, zv, w.r, w.s, w.t, S->scal);
             PL_HIP(ctx, hipMemcpyAsync(S->hpart + 2 * DOT_BLOCKS, S->scal + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
             rho = rho_new;
