@@ -351,7 +351,9 @@ void pl_launch_stokes_apply(pl_ctx* ctx, const PlStokesOp& op, const double* x, 
     // operator 76 us, factored coefficients 73 us, branch-free interior path 64 us.  Sharing the rows of a
     // 4- or 8-row tile through LDS (5 instead of 12 global row loads per wave) is SLOWER (68 us): the L1 re-reads
     // were never the limit, the barrier is one.
-    if ((op.g.plane % 2) == 0) {                  // double2 accesses need even plane strides (pitch is a multiple of 16)
+    // PYLAMP_VV_VEC=0 selects the scalar one-column-per-lane kernel (cross-check of the vectorised one, like the multigrid kernels)
+    static const bool vec = [] { const char* e = getenv("PYLAMP_VV_VEC"); return !(e && e[0] == '0'); }();
+    if (vec && (op.g.plane % 2) == 0) {           // double2 accesses need even plane strides (pitch is a multiple of 16)
         const int gx = (op.g.lnx + 127) / 128;
 #define PL_APPLY_LAUNCH(KERNEL, ROWS)                                                                                   \
         do {                                                                                                            \
