@@ -1328,7 +1328,7 @@ static const bool g_vv_vec = [] { const char* e = getenv("PYLAMP_VV_VEC"); retur
 // ---- smoothing and V-cycle ----------------------------------------------------------------
 // nsweep Chebyshev-Jacobi sweeps on level L; buf[0] is the current iterate on entry and on exit
 static void smooth(pl_ctx* ctx, MgLevel* L, double* buf[3], const double* f, int nsweep, double ratio,
-                   double* final_out = nullptr, bool zero_guess = false, int halo = 2) {
+                   double* final_out = nullptr, bool zero_guess = false, int halo = 2, bool first_halo_valid = false) {
     const double lmax = L->lmax, lmin = lmax / ratio;
     const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
     double rho_old = 1.0 / sigma;
@@ -1336,7 +1336,7 @@ static void smooth(pl_ctx* ctx, MgLevel* L, double* buf[3], const double* f, int
         double c1, c2;
         if (k == 0) { c1 = 0.0; c2 = 1.0 / theta; }
         else { const double rho = 1.0 / (2.0 * sigma - rho_old); c1 = rho * rho_old; c2 = 2.0 * rho / delta; rho_old = rho; }
-        if (L->dist && !(k == 0 && zero_guess) && (halo == 2 || (halo == 1 && k == 0)))
+        if (L->dist && !(k == 0 && (zero_guess || first_halo_valid)) && (halo == 2 || (halo == 1 && k == 0)))
             (void)pl_halo_rows(ctx, L->gh.d, buf[0], 2, L->gh.d.plane);
         double* dst = (final_out && k == nsweep - 1) ? final_out : buf[2];
         if (k == 0 && zero_guess) {        // buf[0] is NOT read (and need not be zeroed)
@@ -1424,9 +1424,17 @@ static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const double* f, double**
     double* ec = nullptr;
     vcycle(ctx, S, l + 1, C->f, &ec);
     if (C->dist && hp >= 1) (void)pl_halo_rows(ctx, C->gh.d, ec, 2, C->gh.d.plane);
-    hipLaunchKernelGGL(k_vv_prolong_add, grid2d(g), dim3(64, 4), 0, ctx->stream, L->op, C->gh.d, ec, buf[0], buf[2]);
+    // On a distributed level the correction is also prolonged into the two halo rows (their coarse neighbours are in
+    // the coarse halo / the replicated coarse array, and the halo of the pre-smoothed iterate is still valid from the
+    // residual): the first post-smoothing sweep then needs no exchange of its own.
+    const bool ext = L->dist && hp == 2;
+    const int lo = (ext && ctx->rank > 0) ? 1 : 0, hi = (ext && ctx->rank < ctx->nranks - 1) ? 1 : 0;
+    PlVvOp ope = L->op;
+    ope.g.gi0 -= lo; ope.g.lnz += lo + hi;
+    hipLaunchKernelGGL(k_vv_prolong_add, grid2d(ope.g), dim3(64, 4), 0, ctx->stream, ope, C->gh.d, ec, buf[0] - (long long)lo * g.pitch,
+                       buf[2] - (long long)lo * g.pitch);
     std::swap(buf[0], buf[2]);
-    smooth(ctx, L, buf, f, npost, S->cheb_ratio, final_out, false, hp);
+    smooth(ctx, L, buf, f, npost, S->cheb_ratio, final_out, false, hp, ext);
     *out = buf[0];
 }
 
