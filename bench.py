@@ -25,12 +25,16 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 
-def build_sim(n, tracdens, seed, device, rank, world):
-    """Weak scaling: every GPU holds one (n-1) x (n-1)-cell slab of ONE global problem -- the grid is
-    ((n-1) N + 1) x n nodes over a domain N times as deep (square cells), split into N row slabs, and
-    every rank draws the tracers of its own slab.  N = 1 is BASELINE's config 3."""
+def build_sim(n, tracdens, seed, device, rank, world, scaling):
+    """strong (default, what BASELINE.json's metric names: the 2048^2-cell problem at 1/2/4/8 GPUs): the SAME n x n
+    grid for every N, split into N row slabs.  weak (--scaling weak): every GPU holds one (n-1) x (n-1)-cell slab of a
+    ((n-1) N + 1) x n grid over a domain N times as deep (square cells).  Every rank draws the tracers of its own
+    slab; N = 1 is BASELINE's config 3 either way."""
     from pylamp_amd import driver
-    nx = [(n - 1) * world + 1, n]; L = [660e3 * world, 660e3]
+    if scaling == "weak":
+        nx = [(n - 1) * world + 1, n]; L = [660e3 * world, 660e3]
+    else:
+        nx = [n, n]; L = [660e3, 660e3]
     sim = driver.Simulation(nx, L, options=driver.Options(), device=device)
     rng = np.random.default_rng(seed + rank)
     lo, hi = sim.slab()
@@ -108,6 +112,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--grid", dest="n", type=int, default=2049, help="nodes per side (default 2049: BASELINE config 3)")
     ap.add_argument("--tracdens", type=int, default=16)
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: strong = the same grid split over N GPUs (BASELINE's metric); weak = one --grid slab per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--apply-reps", type=int, default=50)
     args = ap.parse_args()
@@ -135,7 +141,7 @@ def main():
                 torch.cuda.synchronize()
 
     device = int(os.environ["PYLAMP_DEVICE"]) if os.environ.get("PYLAMP_DEVICE") else local_rank
-    sim = build_sim(args.n, args.tracdens, 20260103, device, rank, world)
+    sim = build_sim(args.n, args.tracdens, 20260103, device, rank, world, args.scaling)
     ctx = sim.ctx
     reports = []
     for _ in range(args.warmup):
@@ -161,8 +167,8 @@ def main():
 
     cells = (sim.nx[0] - 1) * (sim.nx[1] - 1)
     ms_per_step = 1e3 * elapsed / args.steps
-    # N > 1: ONE global problem of N slabs (halo exchange + all-reduce over RCCL), per-GPU work fixed:
-    # weak scaling, value = global cells * steps / time.
+    # N > 1: ONE global problem of N row slabs (halo exchange + all-reduce over RCCL); value = global cells * steps / time
+    # (strong scaling: the global problem is fixed; weak: it grows with N).
     value = cells * args.steps / elapsed
     ntrac_global = sim.ntrac
     if dist is not None:
@@ -177,7 +183,7 @@ def main():
         out = {
             "metric": "stokes_heat_mic_cell_updates_per_s", "value": round(value, 1), "unit": "cell-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "2D %dx%d nodes (%dx%d cells), %d markers/node (%d tracers), T-dependent mantle "
                                    "model, heat + subgrid diffusion on, all free-slip, full time step" %
                                    (sim.nx[0], sim.nx[1], sim.nx[0] - 1, sim.nx[1] - 1, args.tracdens, ntrac_global),
