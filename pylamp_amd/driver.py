@@ -202,14 +202,20 @@ class Simulation:
 
     # -- snapshot writer (pylamp2.py:637-650) ----------------------------------------------------------
     def write_snapshot(self, outdir="out"):
-        os.makedirs(outdir, exist_ok=True)
+        """Collective under several ranks: fields and tracers are gathered, rank 0 writes the two files."""
         velz, velx, pres, rho = self.field("velz"), self.field("velx"), self.field("pres"), self.field("rho")
         temp = self.field("temp") if self.opt.do_heatdiff else velx * 0.0
+        if self.ctx.nranks > 1:
+            tr_x, tr_f, tr_v = self.gather_tracers()
+            if self.ctx.rank != 0:
+                return
+        else:
+            tr_x, tr_f = self.tracers(); tr_v = self.tracer_velocity()
+        os.makedirs(outdir, exist_ok=True)
         np.savez(os.path.join(outdir, "griddata.{:06d}.npz".format(self.it)), gridz=self.grid[IZ], gridx=self.grid[IX],
                  velz=velz, velx=velx, pres=pres, rho=rho, temp=temp, tstep=self.it, time=self.totaltime)
-        tr_x, tr_f = self.tracers()
         np.savez(os.path.join(outdir, "tracs.{:06d}.npz".format(self.it)), tr_x=tr_x, tr_f=tr_f,
-                 tr_v=self.tracer_velocity(), tstep=self.it, time=self.totaltime)
+                 tr_v=tr_v, tstep=self.it, time=self.totaltime)
 
     def close(self):
         self.ctx.close()

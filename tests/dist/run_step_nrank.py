@@ -56,6 +56,16 @@ for it in (1, 2, 3):
     X, F, V = sim.gather_tracers()
     assert X.shape[0] == tr_x.shape[0]
     assert relerr(X, st["tr_x"]) < 1e-7 and relerr(F[:, 3], st["tr_f"][:, 3]) < 1e-6
+# snapshot files are written once (rank 0) and hold ALL tracers
+import tempfile                                      # noqa: E402
+snapdir = os.path.join(tempfile.gettempdir(), "pylamp_snap_%d" % size)
+sim.write_snapshot(snapdir)
+dist.barrier()
+if rank == 0:
+    tc = np.load(os.path.join(snapdir, "tracs.%06d.npz" % sim.it))
+    assert tc["tr_x"].shape[0] == tr_x.shape[0] and tc["tr_v"].shape == tc["tr_x"].shape
+    gd = np.load(os.path.join(snapdir, "griddata.%06d.npz" % sim.it))
+    assert gd["velz"].shape == tuple(nx)
 sim.close()
 if rank == 0:
     print("PASS mantle steps", flush=True)
