@@ -39,8 +39,9 @@ enum { PL_INTERP_NEAREST = 8, PL_INTERP_LINEAR = 16, PL_INTERP_VELDIV = 32 };
 
 typedef struct pl_solve_stats {
     int    iterations;      /* outer Krylov iterations used                       */
-    int    converged;       /* 1 if the TRUE residual met rtol                    */
-    double rel_residual;    /* TRUE residual ||D(b - A x)|| / ref, recomputed (not the recurrence);
+    int    converged;       /* 1 iff rel_residual <= rtol (the recomputed residual, never the recurrence) */
+    double rel_residual;    /* TRUE residual ||D(r0 - A dx)|| / ref, recomputed with the operator, where
+                             * r0 = b - A x0 is evaluated once and x = x0 + dx (correction form);
                              * D = row scaling; ref = ||D b|| (heat) or the dynamic load
                              * ||D(b - A x_hydrostatic)|| (Stokes) */
     double solve_ms;        /* device time of the solve (HIP events)              */
@@ -88,7 +89,7 @@ int  pl_set_comm(pl_ctx* ctx, int rank, int nranks, const pl_comm_ops* ops);   /
 int  pl_local_rows(pl_ctx* ctx, int* first_row, int* n_rows);
 /* *native = 1 when halo exchange / all-gather run as direct RCCL calls on the context stream
  * (dlopen'ed librccl, self-tested at pl_set_comm), 0 when they go through the callback table.
- * PYLAMP_RCCL=0 disables the native path. */
+ * The native path is opt-in: PYLAMP_RCCL=1 (bench.py sets it under the nccl backend). */
 int  pl_comm_info(pl_ctx* ctx, int* rank, int* nranks, int* native);
 /* Cumulative numbers of communication calls of this context: out[0] neighbour (halo) exchanges, [1] all-gathers,
  * [2] device all-reduces, [3] host all-reduces; reset != 0 clears the counters after reading. */
@@ -220,6 +221,9 @@ typedef struct pl_step_report {
 int  pl_tracers_upload(pl_ctx* ctx, int64_t n, const double* tr_x, const double* tr_f);
 int  pl_tracers_download(pl_ctx* ctx, int64_t n, double* tr_x, double* tr_f);
 int  pl_tracers_count(pl_ctx* ctx, int64_t* n);
+/* Census of the resident tracers (pylamp2.py:588-598: np.bincount of the cell index): counts[c] for this rank's
+ * owned cells, row-major (n_cell_rows x (nx-1)), ncells = their number.  counts == NULL only queries the rows. */
+int  pl_tracers_census(pl_ctx* ctx, int64_t ncells, int32_t* counts, int* first_cell_row, int* n_cell_rows);
 /* One full time step on the device-resident state. */
 int  pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_report* rep);
 /* Copy a named grid field of the last step to host, shape (nz,nx): "velz","velx","pres",

@@ -1,4 +1,5 @@
 """One device context per (grid) — owner of all HIP memory behind the module API."""
+import collections
 import ctypes as C
 import os
 import weakref
@@ -27,6 +28,12 @@ class Context:
             raise Exception(msg.decode() if msg else "pl_create failed")
         self.h = h
         self._fin = weakref.finalize(self, lib.pl_destroy, h)
+        # operators handed out by makeStokesMatrix / makeDiffusionMatrix on this context (weak: an operator that
+        # is still alive keeps its context from being evicted; see get_context) and the generation of the
+        # coefficients currently resident on the device (an operator of an older generation re-uploads its own)
+        self.operators = weakref.WeakSet()
+        self.stokes_gen = 0
+        self.heat_gen = 0
         self.comm = None
         self.rank, self.nranks = 0, 1
         # under torch.distributed (torchrun) every rank owns a row slab of the grid
@@ -39,7 +46,19 @@ class Context:
         except ImportError:
             pass
 
+    @property
+    def closed(self):
+        return self.h is None
+
+    def handle(self):
+        """Native handle for a library call; a closed context raises instead of passing freed memory to C."""
+        if self.h is None:
+            raise Exception("pylamp_amd: this device context has been closed")
+        return self.h
+
     def check(self, rc):
+        if self.h is None:
+            raise Exception("pylamp_amd: this device context has been closed")
         if rc != 0 and self.comm is not None and self.comm.errors:
             raise Exception("communication layer: " + "; ".join(self.comm.errors[-3:]))
         _lib.check(self.h, rc)
@@ -51,7 +70,9 @@ class Context:
         return a.value, b.value
 
     def close(self):
-        self._fin()
+        if self.h is not None:
+            self._fin()
+            self.h = None
 
     def device_info(self):
         name = C.create_string_buffer(256)
@@ -60,20 +81,30 @@ class Context:
         return name.value.decode(), cu.value, mem.value
 
 
-_cache = {}
+_cache = collections.OrderedDict()
+_CACHE_MAX = 4
 
 
 def get_context(nx, grid):
-    """Context for this grid; cached so consecutive module calls share device state."""
+    """Context for this grid; cached so consecutive module calls share device state.  Least-recently-used
+    contexts are closed once more than _CACHE_MAX are held -- but never one that still backs a live operator
+    (A @ x / solve(A, ...) on it must keep working, like the reference's independent matrices)."""
     gz = _lib.f64(grid[0]); gx = _lib.f64(grid[1])
     key = (int(nx[0]), int(nx[1]), gz.tobytes(), gx.tobytes())
     ctx = _cache.get(key)
+    if ctx is not None and ctx.closed:
+        del _cache[key]; ctx = None
     if ctx is None:
-        if len(_cache) >= 4:                 # keep device memory bounded
-            _, old = _cache.popitem()
-            old.close()
+        if len(_cache) >= _CACHE_MAX:            # keep device memory bounded
+            for k in list(_cache.keys()):        # oldest first
+                if len(_cache) < _CACHE_MAX:
+                    break
+                if len(_cache[k].operators) == 0:
+                    _cache.pop(k).close()
         ctx = Context(nx, [gz, gx])
         _cache[key] = ctx
+    else:
+        _cache.move_to_end(key)
     return ctx
 
 

@@ -33,6 +33,7 @@ struct PlNccl {
     int (*AllReduce)(const void*, void*, size_t, int, int, pl_ncclComm_t, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
+    std::vector<double> selftest_host;      // lives as long as the context: a late copy of an abandoned self-test lands here
 };
 
 static PlNccl* nccl_of(pl_ctx* ctx) { return (PlNccl*)ctx->nccl; }
@@ -165,8 +166,10 @@ int pl_comm_exchange_var(pl_ctx* ctx, double* const* send_lo, long long n_lo, do
 // Called from pl_set_comm on every rank (collective).  Never fails hard: on any problem the native
 // path is simply left disabled - but the decision is taken collectively so that all ranks agree.
 int pl_comm_native_init(pl_ctx* ctx) {
+    // Opt-in (PYLAMP_RCCL=1; bench.py sets it for the nccl backend): the native path is self-tested at start-up and
+    // falls back to the callback table, but it has not yet been exercised on a multi-GPU node.
     const char* e = getenv("PYLAMP_RCCL");
-    const bool want = !(e && atoi(e) == 0);
+    const bool want = (e && atoi(e) != 0) || getenv("PYLAMP_RCCL_SELFTEST");
     PlNccl* N = new PlNccl();
     ctx->nccl = N;
     bool good = want;
@@ -210,7 +213,8 @@ int pl_comm_native_init(pl_ctx* ctx) {
     if (pass && hipStreamCreateWithFlags(&test_stream, hipStreamNonBlocking) != hipSuccess) pass = false;
     if (pass) { (void)hipStreamSynchronize(main_stream); ctx->stream = test_stream; }
     bool hung = false;
-    std::vector<double> h((size_t)(6 * cnt + R * cnt + 2), 0.0);
+    std::vector<double>& h = N->selftest_host;
+    h.assign((size_t)(6 * cnt + R * cnt + 2), 0.0);
     if (pass) {
         // layout: [recv_lo | own_first | own_last | recv_hi | acc_lo | acc_hi | gather(R*cnt) | all-reduce(2)]
         hipLaunchKernelGGL(k_comm_fill, dim3(1), dim3(64), 0, ctx->stream, 2, t + 6 * cnt + (long long)R * cnt, 1.0 + r);
@@ -234,6 +238,10 @@ int pl_comm_native_init(pl_ctx* ctx) {
         }
     }
     ctx->stream = main_stream;
+    if (hung && N->comm) {                 // abort the communicator BEFORE the stream is abandoned: its kernels must leave the device
+        if (N->CommAbort) (void)N->CommAbort(N->comm);
+        N->comm = nullptr;
+    }
     if (test_stream && !hung) (void)hipStreamDestroy(test_stream);       // a hung stream is abandoned
     if (pass) {
         for (long long k = 0; k < cnt && pass; k++) {

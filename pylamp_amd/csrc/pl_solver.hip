@@ -700,6 +700,11 @@ __global__ void k_xr_update(long long n, double* __restrict__ x, const double* _
         r[k] = s[k] - omega * t[k];
     }
 }
+// x += d
+__global__ void k_add_inplace(long long n, double* __restrict__ x, const double* __restrict__ d) {
+    long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; k < n; k += (long long)gridDim.x * blockDim.x) x[k] += d[k];
+}
 __global__ void k_scale(long long n, double* __restrict__ x, double a) {
     long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     for (; k < n; k += (long long)gridDim.x * blockDim.x) x[k] *= a;
@@ -964,7 +969,7 @@ struct PlSolver {
                                          // (~9 launch-bound kernels) than its 8 halo exchanges per cycle
     // BiCGStab work vectors (3 planes each)
     double *r = nullptr, *rt = nullptr, *p = nullptr, *v = nullptr, *s = nullptr, *t = nullptr, *y = nullptr,
-           *z = nullptr, *b = nullptr, *x = nullptr, *xb = nullptr;
+           *z = nullptr, *b = nullptr, *x = nullptr, *xb = nullptr, *dx = nullptr, *r0 = nullptr;
     double* scal = nullptr;     // device scalars [0..8) + dot partials [8..8+2*DOT_BLOCKS)
     double* hpart = nullptr;    // pinned host copy of the dot partials
     int nu_pre = 2, nu_post = 2, coarse_sweeps = 12;
@@ -983,7 +988,7 @@ struct PlSolver {
     int tail_nu_pre = -1, tail_nu_post = -1;        // smoothing sweeps on the replicated tail levels (-1: same as nu)
     double cheb_ratio = 6.0, lmax_safety = 1.1;     // smoothing window [lmax/ratio, lmax]; lmax = safety * power-iteration estimate
     // heat work vectors (1 plane each)
-    double* h[9] = {nullptr};
+    double* h[11] = {nullptr};
     int napply = 0, nprec = 0;
 };
 
@@ -1025,7 +1030,7 @@ void pl_solver_free(pl_ctx* ctx) {
     PlSolver* S = (PlSolver*)ctx->krylov;
     if (!S) return;
     free_levels(S);
-    for (double* q : {S->r, S->rt, S->p, S->v, S->s, S->t, S->y, S->z, S->b, S->x, S->xb, S->scal})
+    for (double* q : {S->r, S->rt, S->p, S->v, S->s, S->t, S->y, S->z, S->b, S->x, S->xb, S->dx, S->r0, S->scal})
         if (q) (void)hipFree(q);
     for (double* q : S->h) if (q) (void)hipFree(q);
     if (S->hpart) (void)hipHostFree(S->hpart);
@@ -1462,9 +1467,20 @@ static int stokes_precond(pl_ctx* ctx, PlSolver* S, const double* rs, double* z)
 // =========================================================================================
 typedef std::function<int(const double*, double*)> VecOp;
 
-struct BicgVecs { double *r, *rt, *p, *v, *s, *t, *y, *z; double* xbest; };
+struct BicgVecs { double *r, *rt, *p, *v, *s, *t, *y, *z; double* xbest; double *dx, *r0; };
 
+// Solves for the CORRECTION of the initial guess:  A dx = r0 := b - A x0,  dx from 0,  x = x0 + dx at the end.
+// The Stokes solve starts from the hydrostatic state (or the previous step's solution), whose pressure is ~1e5 times
+// the dynamic part: accumulating the iterate in x itself loses those digits in every update and puts the floor of the
+// recomputed residual b - A x at ~1e-10 of the dynamic load -- the very tolerance asked for.  In correction form the
+// floor is eps ||A|| ||dx||.  r0 is evaluated once in FP64; the residual that is reported and tested is
+// r0 - A dx, recomputed with the operator (not the recurrence).
+// The recurrence residual drifts away from the true one; whenever the recurrence meets the tolerance the true
+// residual is recomputed, and if it does not meet it the iteration restarts from it (residual replacement, at most
+// PL_MAX_RESTARTS times, and only while a restart still gains a factor 2).  converged = 1 only if the TRUE residual
+// meets rtol.
 // ref_norm > 0 replaces ||b|| as the reference of the stopping test and of rel_residual.
+#define PL_MAX_RESTARTS 4
 static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const VecOp& A, const VecOp* M,
                     const double* b, double* x, bool use_x0, double rtol, int maxit, BicgVecs w,
                     pl_solve_stats* st, double ref_norm = 0.0) {
@@ -1480,83 +1496,99 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
         st->converged = 1;
         return 0;
     }
+    double* dx = x; const double* r0 = b;       // no initial guess: the correction IS the solution
     if (use_x0) {
+        dx = w.dx;
         PL_TRY(A(x, w.v));
-        hipLaunchKernelGGL(k_axpy_out, grid1d(n), dim3(256), 0, ctx->stream, n, w.r, b, w.v, -1.0);
-    } else {
-        PL_HIP(ctx, hipMemsetAsync(x, 0, bytes, ctx->stream));
-        PL_HIP(ctx, hipMemcpyAsync(w.r, b, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_axpy_out, grid1d(n), dim3(256), 0, ctx->stream, n, w.r0, b, w.v, -1.0);
+        r0 = w.r0;
     }
+    PL_HIP(ctx, hipMemsetAsync(dx, 0, bytes, ctx->stream));
+    PL_HIP(ctx, hipMemcpyAsync(w.r, r0, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     PL_HIP(ctx, hipMemsetAsync(w.rt, 0, bytes, ctx->stream));
     hipLaunchKernelGGL(k_random_interior, grid2d(g), dim3(64, 4), 0, ctx->stream, g, np, w.rt, 1234u);
-    PL_HIP(ctx, hipMemsetAsync(w.p, 0, bytes, ctx->stream));
-    PL_HIP(ctx, hipMemsetAsync(w.v, 0, bytes, ctx->stream));
-    double rho = 1.0, alpha = 1.0, omega = 1.0;
     const bool on_device = dots_on_device(ctx, g) && !getenv("PYLAMP_HOST_SCALARS");
-    PL_TRY(dots(ctx, S, g, np, w.rt, w.r, w.r, w.r, d2));
-    double rho_new = d2[0], rnorm = std::sqrt(d2[1]);
-    int it = 0;
+    int it = 0, restarts = 0;
+    double true_norm = -1.0, last_true = -1.0;          // ||r0 - A dx|| of the current dx (< 0: not evaluated)
     // BiCGStab is not monotone and, past the attainable accuracy, drifts and can blow up: keep the best
     // iterate, stop after 60 iterations without a new best or when the residual explodes, return the best.
-    double best = rnorm; int best_it = 0; bool have_best = false;
-    while (it < maxit && rnorm > rtol * bnorm) {
-        it++;
-        if (!(std::fabs(rho_new) > 0.0) || !std::isfinite(rho_new)) break;
-        const double beta = (rho_new / rho) * (alpha / omega);
-        hipLaunchKernelGGL(k_p_update, grid1d(n), dim3(256), 0, ctx->stream, n, w.p, w.r, w.v, beta, omega);
-        const double* yv = w.p;
-        if (M) { PL_TRY((*M)(w.p, w.y)); yv = w.y; }
-        PL_TRY(A(yv, w.v));
-        const double* zv = w.s;
-        if (on_device) {
-            // alpha, omega stay on the device; a breakdown (rt.v = 0) shows up as a non-finite alpha / ||r|| below
-            PL_TRY(dots_dev(ctx, S, g, np, w.rt, w.v, nullptr, nullptr, 1, rho_new));
-            hipLaunchKernelGGL(k_s_update_dev, grid1d(n), dim3(256), 0, ctx->stream, n, w.s, w.r, w.v, S->scal);
-            if (M) { PL_TRY((*M)(w.s, w.z)); zv = w.z; }
-            PL_TRY(A(zv, w.t));
-            PL_TRY(dots_dev(ctx, S, g, np, w.t, w.s, w.t, w.t, 2, 0.0));
-            hipLaunchKernelGGL(k_xr_update_dev, grid1d(n), dim3(256), 0, ctx->stream, n, x, yv, zv, w.r, w.s, w.t, S->scal);
-            PL_HIP(ctx, hipMemcpyAsync(S->hpart + 2 * DOT_BLOCKS, S->scal + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-            rho = rho_new;
-            PL_TRY(dots(ctx, S, g, np, w.rt, w.r, w.r, w.r, d2));       // synchronises: alpha, omega have arrived too
-            alpha = S->hpart[2 * DOT_BLOCKS]; omega = S->hpart[2 * DOT_BLOCKS + 1];
-            rho_new = d2[0]; rnorm = std::sqrt(d2[1]);
-            if (!std::isfinite(alpha)) break;
-        } else {
-            PL_TRY(dots(ctx, S, g, np, w.rt, w.v, nullptr, nullptr, d2));
-            if (!(std::fabs(d2[0]) > 0.0) || !std::isfinite(d2[0])) break;
-            alpha = rho_new / d2[0];
-            hipLaunchKernelGGL(k_axpy_out, grid1d(n), dim3(256), 0, ctx->stream, n, w.s, w.r, w.v, -alpha);
-            if (M) { PL_TRY((*M)(w.s, w.z)); zv = w.z; }
-            PL_TRY(A(zv, w.t));
-            PL_TRY(dots(ctx, S, g, np, w.t, w.s, w.t, w.t, d2));
-            if (!(d2[1] > 0.0) || !std::isfinite(d2[1])) {        // s is already (numerically) zero
-                hipLaunchKernelGGL(k_xr_update, grid1d(n), dim3(256), 0, ctx->stream, n, x, yv, zv, w.r, w.s, w.t, alpha, 0.0);
-                rnorm = 0.0;
-                break;
+    double best = 0.0; int best_it = 0; bool have_best = false;
+    for (;;) {
+        // ---- (re)start from the residual in w.r
+        PL_HIP(ctx, hipMemsetAsync(w.p, 0, bytes, ctx->stream));
+        PL_HIP(ctx, hipMemsetAsync(w.v, 0, bytes, ctx->stream));
+        double rho = 1.0, alpha = 1.0, omega = 1.0;
+        PL_TRY(dots(ctx, S, g, np, w.rt, w.r, w.r, w.r, d2));
+        double rho_new = d2[0], rnorm = std::sqrt(d2[1]);
+        if (restarts == 0) best = rnorm;
+        bool broke = false;
+        while (it < maxit && rnorm > rtol * bnorm) {
+            it++;
+            if (!(std::fabs(rho_new) > 0.0) || !std::isfinite(rho_new)) { broke = true; break; }
+            const double beta = (rho_new / rho) * (alpha / omega);
+            hipLaunchKernelGGL(k_p_update, grid1d(n), dim3(256), 0, ctx->stream, n, w.p, w.r, w.v, beta, omega);
+            const double* yv = w.p;
+            if (M) { PL_TRY((*M)(w.p, w.y)); yv = w.y; }
+            PL_TRY(A(yv, w.v));
+            const double* zv = w.s;
+            if (on_device) {
+                // alpha, omega stay on the device; a breakdown (rt.v = 0) shows up as a non-finite alpha / ||r|| below
+                PL_TRY(dots_dev(ctx, S, g, np, w.rt, w.v, nullptr, nullptr, 1, rho_new));
+                hipLaunchKernelGGL(k_s_update_dev, grid1d(n), dim3(256), 0, ctx->stream, n, w.s, w.r, w.v, S->scal);
+                if (M) { PL_TRY((*M)(w.s, w.z)); zv = w.z; }
+                PL_TRY(A(zv, w.t));
+                PL_TRY(dots_dev(ctx, S, g, np, w.t, w.s, w.t, w.t, 2, 0.0));
+                hipLaunchKernelGGL(k_xr_update_dev, grid1d(n), dim3(256), 0, ctx->stream, n, dx, yv, zv, w.r, w.s, w.t, S->scal);
+                PL_HIP(ctx, hipMemcpyAsync(S->hpart + 2 * DOT_BLOCKS, S->scal + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+                rho = rho_new;
+                PL_TRY(dots(ctx, S, g, np, w.rt, w.r, w.r, w.r, d2));       // synchronises: alpha, omega have arrived too
+                alpha = S->hpart[2 * DOT_BLOCKS]; omega = S->hpart[2 * DOT_BLOCKS + 1];
+                rho_new = d2[0]; rnorm = std::sqrt(d2[1]);
+                if (!std::isfinite(alpha)) { broke = true; break; }
+            } else {
+                PL_TRY(dots(ctx, S, g, np, w.rt, w.v, nullptr, nullptr, d2));
+                if (!(std::fabs(d2[0]) > 0.0) || !std::isfinite(d2[0])) { broke = true; break; }
+                alpha = rho_new / d2[0];
+                hipLaunchKernelGGL(k_axpy_out, grid1d(n), dim3(256), 0, ctx->stream, n, w.s, w.r, w.v, -alpha);
+                if (M) { PL_TRY((*M)(w.s, w.z)); zv = w.z; }
+                PL_TRY(A(zv, w.t));
+                PL_TRY(dots(ctx, S, g, np, w.t, w.s, w.t, w.t, d2));
+                if (!(d2[1] > 0.0) || !std::isfinite(d2[1])) {        // s is already (numerically) zero
+                    hipLaunchKernelGGL(k_xr_update, grid1d(n), dim3(256), 0, ctx->stream, n, dx, yv, zv, w.r, w.s, w.t, alpha, 0.0);
+                    rnorm = 0.0;
+                    break;
+                }
+                omega = d2[0] / d2[1];
+                hipLaunchKernelGGL(k_xr_update, grid1d(n), dim3(256), 0, ctx->stream, n, dx, yv, zv, w.r, w.s, w.t, alpha, omega);
+                rho = rho_new;
+                PL_TRY(dots(ctx, S, g, np, w.rt, w.r, w.r, w.r, d2));
+                rho_new = d2[0]; rnorm = std::sqrt(d2[1]);
             }
-            omega = d2[0] / d2[1];
-            hipLaunchKernelGGL(k_xr_update, grid1d(n), dim3(256), 0, ctx->stream, n, x, yv, zv, w.r, w.s, w.t, alpha, omega);
-            rho = rho_new;
-            PL_TRY(dots(ctx, S, g, np, w.rt, w.r, w.r, w.r, d2));
-            rho_new = d2[0]; rnorm = std::sqrt(d2[1]);
+            if (!std::isfinite(rnorm) || !(std::fabs(omega) > 0.0)) { broke = true; break; }
+            if (rnorm < 0.9 * best && w.xbest) {
+                best = rnorm; best_it = it; have_best = true;
+                PL_HIP(ctx, hipMemcpyAsync(w.xbest, dx, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+            }
+            if (w.xbest && (it - best_it > 60 || rnorm > 1e6 * best)) { broke = true; break; }       // stagnation / divergence
         }
-        if (!std::isfinite(rnorm) || !(std::fabs(omega) > 0.0)) break;
-        if (rnorm < 0.9 * best && w.xbest) {
-            best = rnorm; best_it = it; have_best = true;
-            PL_HIP(ctx, hipMemcpyAsync(w.xbest, x, bytes, hipMemcpyDeviceToDevice, ctx->stream));
-        }
-        if (w.xbest && (it - best_it > 60 || rnorm > 1e6 * best)) break;       // stagnation / divergence
+        if (have_best && w.xbest && !(rnorm <= 1.5 * best))
+            PL_HIP(ctx, hipMemcpyAsync(dx, w.xbest, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        // ---- true residual of the current dx
+        PL_TRY(A(dx, w.t));
+        hipLaunchKernelGGL(k_axpy_out, grid1d(n), dim3(256), 0, ctx->stream, n, w.s, r0, w.t, -1.0);
+        PL_TRY(dots(ctx, S, g, np, w.s, w.s, nullptr, nullptr, d2));
+        last_true = true_norm; true_norm = std::sqrt(d2[0]);
+        if (true_norm <= rtol * bnorm || broke || it >= maxit || restarts >= PL_MAX_RESTARTS) break;
+        if (last_true >= 0.0 && !(true_norm < 0.5 * last_true)) break;      // a restart no longer pays: attainable accuracy
+        // ---- residual replacement: continue from the TRUE residual
+        restarts++;
+        PL_HIP(ctx, hipMemcpyAsync(w.r, w.s, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        best = true_norm; best_it = it; have_best = false;
     }
-    if (have_best && w.xbest && !(rnorm <= 1.5 * best))
-        PL_HIP(ctx, hipMemcpyAsync(x, w.xbest, bytes, hipMemcpyDeviceToDevice, ctx->stream));
-    // true residual
-    PL_TRY(A(x, w.t));
-    hipLaunchKernelGGL(k_axpy_out, grid1d(n), dim3(256), 0, ctx->stream, n, w.s, b, w.t, -1.0);
-    PL_TRY(dots(ctx, S, g, np, w.s, w.s, nullptr, nullptr, d2));
+    if (dx != x) hipLaunchKernelGGL(k_add_inplace, grid1d(n), dim3(256), 0, ctx->stream, n, x, dx);     // x = x0 + dx
     st->iterations = it;
-    st->rel_residual = std::sqrt(d2[0]) / bnorm;
-    st->converged = (st->rel_residual <= 10.0 * rtol) ? 1 : 0;
+    st->rel_residual = true_norm / bnorm;
+    st->converged = (st->rel_residual <= rtol) ? 1 : 0;
     return 0;
 }
 
@@ -1566,7 +1598,7 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
 static int stokes_alloc(pl_ctx* ctx, PlSolver* S) {
     if (S->r) return 0;
     size_t vb = (size_t)3 * ctx->geom.d.plane * sizeof(double);
-    for (double** q : {&S->r, &S->rt, &S->p, &S->v, &S->s, &S->t, &S->y, &S->z, &S->b, &S->x, &S->xb})
+    for (double** q : {&S->r, &S->rt, &S->p, &S->v, &S->s, &S->t, &S->y, &S->z, &S->b, &S->x, &S->xb, &S->dx, &S->r0})
         PL_TRY(dmalloc0(ctx, q, vb));
     if (!S->scal) {
         PL_TRY(dmalloc0(ctx, &S->scal, (8 + 2 * DOT_BLOCKS) * sizeof(double)));
@@ -1596,7 +1628,7 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
     if (b_dev != S->b)
         PL_HIP(ctx, hipMemcpyAsync(S->b, b_dev, (size_t)3 * g.plane * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     hipLaunchKernelGGL(k_stokes_scale_rows, grid2d(g), dim3(64, 4), 0, ctx->stream, sop, S->b);
-    BicgVecs w{S->r, S->rt, S->p, S->v, S->s, S->t, S->y, S->z, S->xb};
+    BicgVecs w{S->r, S->rt, S->p, S->v, S->s, S->t, S->y, S->z, S->xb, S->dx, S->r0};
     // hydrostatic pressure x_h (in S->y) and the dynamic-load reference norm ||D_r (b - A x_h)||
     double d2[2], ref = 0.0;
     {
@@ -1750,7 +1782,7 @@ int pl_heat_solve_device(pl_ctx* ctx, const double* b_dev, double rtol, int maxi
     PlSolver* S = solver_of(ctx);
     const PlGeom& g = ctx->geom.d;
     size_t pb = (size_t)g.plane * sizeof(double);
-    for (int k = 0; k < 9; k++) if (!S->h[k]) PL_TRY(dmalloc0(ctx, &S->h[k], pb));
+    for (int k = 0; k < 11; k++) if (!S->h[k]) PL_TRY(dmalloc0(ctx, &S->h[k], pb));
     if (!S->scal) {
         PL_TRY(dmalloc0(ctx, &S->scal, (8 + 2 * DOT_BLOCKS) * sizeof(double)));
         PL_HIP(ctx, hipHostMalloc((void**)&S->hpart, (2 * DOT_BLOCKS + 8) * sizeof(double)));
@@ -1767,7 +1799,7 @@ int pl_heat_solve_device(pl_ctx* ctx, const double* b_dev, double rtol, int maxi
     double* b = S->h[8];
     PL_HIP(ctx, hipMemcpyAsync(b, b_dev, pb, hipMemcpyDeviceToDevice, ctx->stream));
     hipLaunchKernelGGL(k_heat_dinv, grid2d(g), dim3(64, 4), 0, ctx->stream, hop, b);
-    BicgVecs w{S->h[0], S->h[1], S->h[2], S->h[3], S->h[4], S->h[5], nullptr, nullptr, S->h[6]};
+    BicgVecs w{S->h[0], S->h[1], S->h[2], S->h[3], S->h[4], S->h[5], nullptr, nullptr, S->h[6], S->h[9], S->h[10]};
     PL_TRY(bicgstab(ctx, S, g, 1, A, nullptr, b, S->h[7], false, rtol, maxit, w, st));
     double ms = 0;
     PL_TRY(pl_timer_stop_ms(ctx, &ms));

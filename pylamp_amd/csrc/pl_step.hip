@@ -547,6 +547,24 @@ extern "C" int pl_tracers_count(pl_ctx* ctx, int64_t* n) {
     return 0;
 }
 
+// Per-cell tracer counts of the resident (cell-sorted) state: the census of pylamp2.py:588-598 (np.bincount of the
+// cell index), for this rank's owned cells, row-major (rows x (nx-1)).
+extern "C" int pl_tracers_census(pl_ctx* ctx, int64_t ncells, int32_t* counts, int* first_cell_row, int* n_cell_rows) {
+    PlStepState* S = state_of(ctx);
+    if (!S->sorted || !S->cell_start) return pl_fail(ctx, "pl_tracers_census: no cell-sorted tracers resident");
+    const int rows = S->ncz - S->lo_ext - S->hi_ext;
+    if (first_cell_row) *first_cell_row = S->crow0 + S->lo_ext;
+    if (n_cell_rows) *n_cell_rows = rows;
+    if (!counts) return 0;
+    if (ncells != (int64_t)rows * S->ncx) return pl_fail(ctx, "pl_tracers_census: ncells does not match the owned cells");
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<int> st((size_t)ncells + 1);
+    PL_HIP(ctx, hipMemcpyAsync(st.data(), S->cell_start + (size_t)S->lo_ext * S->ncx, st.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int64_t c = 0; c < ncells; c++) counts[c] = st[c + 1] - st[c];
+    return 0;
+}
+
 extern "C" int pl_get_tracer_velocity(pl_ctx* ctx, int64_t n, double* out) {
     PlStepState* S = state_of(ctx);
     if (n != S->n || !out) return pl_fail(ctx, "pl_get_tracer_velocity: bad argument");

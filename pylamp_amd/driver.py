@@ -125,18 +125,18 @@ class Simulation:
             keep = (tr_x[:, IZ] >= lo) & (tr_x[:, IZ] < hi)
             tr_x = np.ascontiguousarray(tr_x[keep]); tr_f = np.ascontiguousarray(tr_f[keep])
         self.ntrac = tr_x.shape[0]
-        self.ctx.check(self.ctx.lib.pl_tracers_upload(self.ctx.h, self.ntrac, _lib.dptr(tr_x), _lib.dptr(tr_f)))
+        self.ctx.check(self.ctx.lib.pl_tracers_upload(self.ctx.handle(), self.ntrac, _lib.dptr(tr_x), _lib.dptr(tr_f)))
 
     def _refresh_count(self):
         n = C.c_int64()
-        self.ctx.check(self.ctx.lib.pl_tracers_count(self.ctx.h, C.byref(n)))
+        self.ctx.check(self.ctx.lib.pl_tracers_count(self.ctx.handle(), C.byref(n)))
         self.ntrac = n.value
 
     def tracers(self):
         """Tracers resident on THIS rank (all of them on one rank, in upload order)."""
         self._refresh_count()
         tr_x = np.empty((self.ntrac, DIM)); tr_f = np.empty((self.ntrac, NFTRAC))
-        self.ctx.check(self.ctx.lib.pl_tracers_download(self.ctx.h, self.ntrac, _lib.dptr(tr_x), _lib.dptr(tr_f)))
+        self.ctx.check(self.ctx.lib.pl_tracers_download(self.ctx.handle(), self.ntrac, _lib.dptr(tr_x), _lib.dptr(tr_f)))
         return tr_x, tr_f
 
     def gather_tracers(self):
@@ -152,15 +152,24 @@ class Simulation:
         o = np.argsort(tr_f[:, TR__ID], kind="stable")
         return tr_x[o], tr_f[o], v[o]
 
+    def census(self):
+        """Tracers per cell of this rank's owned cells, shape (rows, nx-1) (pylamp2.py:588-598)."""
+        r0 = C.c_int(); nr = C.c_int()
+        self.ctx.check(self.ctx.lib.pl_tracers_census(self.ctx.handle(), 0, None, C.byref(r0), C.byref(nr)))
+        cnt = np.empty((nr.value, self.nx[1] - 1), dtype=np.int32)
+        self.ctx.check(self.ctx.lib.pl_tracers_census(self.ctx.handle(), cnt.size, cnt.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                      C.byref(r0), C.byref(nr)))
+        return cnt
+
     def tracer_velocity(self):
         self._refresh_count()
         v = np.empty((self.ntrac, DIM))
-        self.ctx.check(self.ctx.lib.pl_get_tracer_velocity(self.ctx.h, self.ntrac, _lib.dptr(v)))
+        self.ctx.check(self.ctx.lib.pl_get_tracer_velocity(self.ctx.handle(), self.ntrac, _lib.dptr(v)))
         return v
 
     def field(self, name):
         out = np.empty(self.nx)
-        self.ctx.check(self.ctx.lib.pl_get_field(self.ctx.h, name.encode(), _lib.dptr(out)))
+        self.ctx.check(self.ctx.lib.pl_get_field(self.ctx.handle(), name.encode(), _lib.dptr(out)))
         return out
 
     # -- one time step ------------------------------------------------------------------------------
@@ -190,7 +199,7 @@ class Simulation:
         self.it += 1
         cfg = self._config()
         rep = _lib.StepReport()
-        self.ctx.check(self.ctx.lib.pl_step(self.ctx.h, C.byref(cfg), self.it, C.byref(rep)))
+        self.ctx.check(self.ctx.lib.pl_step(self.ctx.handle(), C.byref(cfg), self.it, C.byref(rep)))
         self.totaltime += rep.tstep
         self.ntrac = rep.ntrac
         out = {k: getattr(rep, k) for k, _ in rep._fields_ if k not in ("stokes", "heat", "limiter")}

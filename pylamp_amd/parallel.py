@@ -68,9 +68,9 @@ class Comm:
                             _EXCHANGE_VAR(self._exchange_var), None)
         if not self.device_mode:
             os.environ["PYLAMP_RCCL"] = "0"      # direct RCCL needs one GPU per rank (nccl backend)
-        ctx.check(ctx.lib.pl_set_comm(ctx.h, self.rank, self.size, C.byref(self._ops)))
+        ctx.check(ctx.lib.pl_set_comm(ctx.handle(), self.rank, self.size, C.byref(self._ops)))
         nat = C.c_int(0)
-        ctx.check(ctx.lib.pl_comm_info(ctx.h, None, None, C.byref(nat)))
+        ctx.check(ctx.lib.pl_comm_info(ctx.handle(), None, None, C.byref(nat)))
         self.native = bool(nat.value)
         ctx.comm = self          # keep the callbacks alive as long as the context
 
@@ -80,12 +80,12 @@ class Comm:
 
     def _d2h(self, ptr, n):
         a = np.empty(int(n))
-        self.ctx.check(self.ctx.lib.pl_memcpy_d2h(self.ctx.h, a.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), a.nbytes))
+        self.ctx.check(self.ctx.lib.pl_memcpy_d2h(self.ctx.handle(), a.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), a.nbytes))
         return a
 
     def _h2d(self, ptr, a):
         a = np.ascontiguousarray(a)
-        self.ctx.check(self.ctx.lib.pl_memcpy_h2d(self.ctx.h, C.c_void_p(ptr), a.ctypes.data_as(C.c_void_p), a.nbytes))
+        self.ctx.check(self.ctx.lib.pl_memcpy_h2d(self.ctx.handle(), C.c_void_p(ptr), a.ctypes.data_as(C.c_void_p), a.nbytes))
 
     def _guard(self, fn, *a):
         try:

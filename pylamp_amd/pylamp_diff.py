@@ -28,20 +28,37 @@ def x2t(x, nx):
 
 
 class HeatOperator:
-    def __init__(self, ctx, nx):
+    def __init__(self, ctx, nx, coeffs):
         self._ctx = ctx
         self.nx = [int(nx[0]), int(nx[1])]
         n = self.nx[0] * self.nx[1]
         self.shape = (n, n)
         self.dtype = np.dtype(np.float64)
         self.last_stats = None
+        self._coeffs = coeffs          # host copies: re-uploaded when another operator took the context's device slot
+        self._gen = -1
+        self._activate()
+        ctx.operators.add(self)
+
+    def _activate(self):
+        ctx = self._ctx
+        if self._gen == ctx.heat_gen and self._gen >= 0:
+            return
+        zm, xm, arrs, bc, bcvalue, tstep = self._coeffs
+        bc_arr = (C.c_int * 4)(*bc)
+        bv = (C.c_double * 4)(*bcvalue)
+        ctx.check(ctx.lib.pl_heat_set_coeffs(ctx.handle(), _lib.dptr(zm), _lib.dptr(xm), *[_lib.dptr(a) for a in arrs],
+                                             bc_arr, bv, tstep))
+        ctx.heat_gen += 1
+        self._gen = ctx.heat_gen
 
     def matvec(self, x):
         x = _lib.f64(x).reshape(-1)
         if x.size != self.shape[0]:
             raise Exception("dimension mismatch")
+        self._activate()
         y = np.empty_like(x)
-        self._ctx.check(self._ctx.lib.pl_heat_apply(self._ctx.h, _lib.dptr(x), _lib.dptr(y)))
+        self._ctx.check(self._ctx.lib.pl_heat_apply(self._ctx.handle(), _lib.dptr(x), _lib.dptr(y)))
         return y
 
     dot = matvec
@@ -50,8 +67,9 @@ class HeatOperator:
         return self.matvec(x)
 
     def rhs(self):
+        self._activate()
         r = np.empty(self.shape[0])
-        self._ctx.check(self._ctx.lib.pl_heat_rhs(self._ctx.h, _lib.dptr(r)))
+        self._ctx.check(self._ctx.lib.pl_heat_rhs(self._ctx.handle(), _lib.dptr(r)))
         return r
 
     def tocsc(self):
@@ -76,25 +94,23 @@ def makeDiffusionMatrix(nx, grid, gridmp, f_T, f_k, f_Cp, f_rho, f_H, bc, bcvalu
     """Set up the matrix-free heat operator and rhs (pylamp_diff.py:85-183)."""
     ctx = get_context(nx, grid)
     shp = (int(nx[0]), int(nx[1]))
-    arrs = [_lib.f64(a) for a in (f_T, f_k[IZ], f_k[IX], f_Cp, f_rho, f_H)]
+    arrs = [np.array(a, dtype=np.float64, order="C") for a in (f_T, f_k[IZ], f_k[IX], f_Cp, f_rho, f_H)]   # own copies
     for a in arrs:
         if a.shape != shp:
             raise Exception("field shape does not match nx")
-    zm, xm = _lib.f64(gridmp[IZ]), _lib.f64(gridmp[IX])
-    bc_arr = (C.c_int * 4)(*[int(b) for b in bc])
-    bv = (C.c_double * 4)(*[float(b) for b in bcvalue])
-    ctx.check(ctx.lib.pl_heat_set_coeffs(ctx.h, _lib.dptr(zm), _lib.dptr(xm), *[_lib.dptr(a) for a in arrs],
-                                         bc_arr, bv, float(tstep)))
-    A = HeatOperator(ctx, nx)
+    zm, xm = np.array(gridmp[IZ], dtype=np.float64), np.array(gridmp[IX], dtype=np.float64)
+    coeffs = (zm, xm, arrs, [int(b) for b in bc], [float(b) for b in bcvalue], float(tstep))
+    A = HeatOperator(ctx, nx, coeffs)
     return (A, A.rhs())
 
 
 def solve(A, rhs, rtol=DEFAULT_RTOL, maxit=DEFAULT_MAXIT):
     """x = A^-1 rhs on the GPU; stands in for spsolve at pylamp2.py:419."""
     ctx = A._ctx
+    A._activate()
     rhs = _lib.f64(rhs).reshape(-1)
     x = np.zeros_like(rhs)
     st = _lib.SolveStats()
-    ctx.check(ctx.lib.pl_heat_solve(ctx.h, _lib.dptr(rhs), _lib.dptr(x), float(rtol), int(maxit), C.byref(st)))
+    ctx.check(ctx.lib.pl_heat_solve(ctx.handle(), _lib.dptr(rhs), _lib.dptr(x), float(rtol), int(maxit), C.byref(st)))
     A.last_stats = st.as_dict()
     return x

@@ -57,23 +57,42 @@ class StokesOperator:
     .matvec, and .tocsc() (materialised by 27 coloured probe applies; for tests).
     """
 
-    def __init__(self, ctx, nx):
+    def __init__(self, ctx, nx, coeffs):
         self._ctx = ctx
         self.nx = [int(nx[0]), int(nx[1])]
         n = 3 * self.nx[0] * self.nx[1]
         self.shape = (n, n)
         self.dtype = np.dtype(np.float64)
         self.last_stats = None
+        # The operator owns host copies of its coefficients: the device holds ONE coefficient set per context, so
+        # a later makeStokesMatrix on the same grid replaces it; this operator then uploads its own again before
+        # it is applied or solved (the reference returns independent matrices).
+        self._coeffs = coeffs
+        self._gen = -1
+        self._activate()
         kc = C.c_double(); kb = C.c_double()
-        ctx.check(ctx.lib.pl_stokes_get_scaling(ctx.h, C.byref(kc), C.byref(kb)))
+        ctx.check(ctx.lib.pl_stokes_get_scaling(ctx.handle(), C.byref(kc), C.byref(kb)))
         self.Kcont, self.Kbond = kc.value, kb.value
+        ctx.operators.add(self)
+
+    def _activate(self):
+        ctx = self._ctx
+        if self._gen == ctx.stokes_gen and self._gen >= 0:
+            return
+        es, en, rho, bc, surfstab, tstep, theta = self._coeffs
+        bc_arr = (C.c_int * 4)(*bc)
+        ctx.check(ctx.lib.pl_stokes_set_coeffs(ctx.handle(), _lib.dptr(es), _lib.dptr(en), _lib.dptr(rho), bc_arr,
+                                               surfstab, tstep, theta))
+        ctx.stokes_gen += 1
+        self._gen = ctx.stokes_gen
 
     def matvec(self, x):
         x = _lib.f64(x).reshape(-1)
         if x.size != self.shape[0]:
             raise Exception("dimension mismatch")
+        self._activate()
         y = np.empty_like(x)
-        self._ctx.check(self._ctx.lib.pl_stokes_apply(self._ctx.h, _lib.dptr(x), _lib.dptr(y)))
+        self._ctx.check(self._ctx.lib.pl_stokes_apply(self._ctx.handle(), _lib.dptr(x), _lib.dptr(y)))
         return y
 
     dot = matvec
@@ -82,20 +101,22 @@ class StokesOperator:
         return self.matvec(x)
 
     def rhs(self):
+        self._activate()
         r = np.empty(self.shape[0])
-        self._ctx.check(self._ctx.lib.pl_stokes_rhs(self._ctx.h, _lib.dptr(r)))
+        self._ctx.check(self._ctx.lib.pl_stokes_rhs(self._ctx.handle(), _lib.dptr(r)))
         return r
 
     def precond(self, r):
         """z = M^-1 r of the solver's preconditioner (diagnostic; r unscaled)."""
         r = _lib.f64(r).reshape(-1)
         z = np.empty_like(r)
-        self._ctx.check(self._ctx.lib.pl_stokes_precond_apply(self._ctx.h, _lib.dptr(r), _lib.dptr(z)))
+        self._activate()
+        self._ctx.check(self._ctx.lib.pl_stokes_precond_apply(self._ctx.handle(), _lib.dptr(r), _lib.dptr(z)))
         return z
 
     def mg_info(self):
         n = C.c_int(); lm = (C.c_double * 32)()
-        self._ctx.check(self._ctx.lib.pl_stokes_mg_info(self._ctx.h, C.byref(n), lm, 32))
+        self._ctx.check(self._ctx.lib.pl_stokes_mg_info(self._ctx.handle(), C.byref(n), lm, 32))
         return n.value, [lm[k] for k in range(n.value)]
 
     def tocsc(self):
@@ -136,25 +157,24 @@ def makeStokesMatrix(nx, grid, f_etas, f_etan, f_rho, bc, surfstab=False, tstep=
     ctx = get_context(nx, grid)
     if surfstab and tstep is None:
         raise Exception("surface stabilization needs predetermined tstep")
-    bc_arr = (C.c_int * 4)(*[int(b) for b in bc])
-    es, en, rho = _lib.f64(f_etas), _lib.f64(f_etan), _lib.f64(f_rho)
+    es, en, rho = (np.array(a, dtype=np.float64, order="C") for a in (f_etas, f_etan, f_rho))    # own copies
     for a in (es, en, rho):
         if a.shape != (int(nx[0]), int(nx[1])):
             raise Exception("field shape does not match nx")
-    ctx.check(ctx.lib.pl_stokes_set_coeffs(ctx.h, _lib.dptr(es), _lib.dptr(en), _lib.dptr(rho), bc_arr,
-                                           1 if surfstab else 0, float(tstep) if tstep is not None else 0.0,
-                                           float(surfstab_theta) if strict_reference else -float(surfstab_theta)))
-    A = StokesOperator(ctx, nx)
+    coeffs = (es, en, rho, [int(b) for b in bc], 1 if surfstab else 0, float(tstep) if tstep is not None else 0.0,
+              float(surfstab_theta) if strict_reference else -float(surfstab_theta))
+    A = StokesOperator(ctx, nx, coeffs)
     return (A, A.rhs())
 
 
 def solve(A, rhs, x0=None, rtol=DEFAULT_RTOL, maxit=DEFAULT_MAXIT):
     """x = A^-1 rhs on the GPU; stands in for spsolve(csc_matrix(A), rhs) (pylamp2.py:360)."""
     ctx = A._ctx
+    A._activate()
     rhs = _lib.f64(rhs).reshape(-1)
     x = np.zeros_like(rhs) if x0 is None else _lib.f64(x0).reshape(-1).copy()
     st = _lib.SolveStats()
-    ctx.check(ctx.lib.pl_stokes_solve(ctx.h, _lib.dptr(rhs), _lib.dptr(x), 0 if x0 is None else 1, float(rtol),
+    ctx.check(ctx.lib.pl_stokes_solve(ctx.handle(), _lib.dptr(rhs), _lib.dptr(x), 0 if x0 is None else 1, float(rtol),
                                       int(maxit), C.byref(st)))
     A.last_stats = st.as_dict()
     return x

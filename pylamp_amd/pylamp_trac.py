@@ -54,13 +54,13 @@ def grid2trac(tr_x, tr_f, grid, gridfield, nx, defval=np.nan, method=INTERP_METH
     gz, gx = _lib.f64(grid[IZ]), _lib.f64(grid[IX])
     out = np.empty((n, nf))
     nout = C.c_int64(0)
-    ctx.check(ctx.lib.pl_mic_set_search(ctx.h, 0 if (_is_uniform(gz) and _is_uniform(gx)) else 1))
+    ctx.check(ctx.lib.pl_mic_set_search(ctx.handle(), 0 if (_is_uniform(gz) and _is_uniform(gx)) else 1))
     for k0 in range(0, nf, _MAXF):
         k1 = min(nf, k0 + _MAXF)
         fl = [_lib.f64(gridfield[k]) for k in range(k0, k1)]
         fp = (_lib.c_double_p * (k1 - k0))(*[_lib.dptr(a) for a in fl])
         sub = np.empty((n, k1 - k0))
-        ctx.check(ctx.lib.pl_grid2trac(ctx.h, n, _lib.dptr(txc), k1 - k0, fp, gnz, gnx, _lib.dptr(gz),
+        ctx.check(ctx.lib.pl_grid2trac(ctx.handle(), n, _lib.dptr(txc), k1 - k0, fp, gnz, gnx, _lib.dptr(gz),
                                        _lib.dptr(gx), int(method), float(defval), 1 if stopOnError else 0,
                                        _lib.dptr(sub), k1 - k0, C.byref(nout)))
         out[:, k0:k1] = sub
@@ -103,10 +103,10 @@ def trac2grid(tr_x, tr_f, mesh, grid, gridfield, nx, distweight=None, avgscheme=
         op = (_lib.c_double_p * (k1 - k0))(*[_lib.dptr(a) for a in outs])
         sch = (C.c_int * (k1 - k0))(*[int(s) for s in avgscheme[k0:k1]])
         if rect:
-            ctx.check(ctx.lib.pl_trac2grid_rect(ctx.h, n, _lib.dptr(txc), _lib.dptr(sub), k1 - k0, k1 - k0, sch,
+            ctx.check(ctx.lib.pl_trac2grid_rect(ctx.handle(), n, _lib.dptr(txc), _lib.dptr(sub), k1 - k0, k1 - k0, sch,
                                                 _lib.dptr(gz), _lib.dptr(gx), op))
         else:
-            ctx.check(ctx.lib.pl_trac2grid(ctx.h, n, _lib.dptr(txc), _lib.dptr(sub), k1 - k0, k1 - k0, sch, z0, hz,
+            ctx.check(ctx.lib.pl_trac2grid(ctx.handle(), n, _lib.dptr(txc), _lib.dptr(sub), k1 - k0, k1 - k0, sch, z0, hz,
                                            x0, hx, op))
         for k in range(k0, k1):
             gridfield[k][:, :] = outs[k - k0]
@@ -132,7 +132,7 @@ def RK(tr_x, grids, vels, nx, tstep, order=4):
     if vz.shape != (gnz, gnx) or vx.shape != (gnz, gnx) or gz.size != gnz or gx.size != gnx:
         raise Exception("RK: velocity grids must have shape (nz+1, nx+1)")
     v = np.empty((n, DIM)); xn = np.empty((n, DIM))
-    ctx.check(ctx.lib.pl_mic_set_search(ctx.h, 0 if (_is_uniform(gz) and _is_uniform(gx)) else 1))
-    ctx.check(ctx.lib.pl_rk4(ctx.h, n, _lib.dptr(txc), gnz, gnx, _lib.dptr(gz), _lib.dptr(gx), _lib.dptr(vz),
+    ctx.check(ctx.lib.pl_mic_set_search(ctx.handle(), 0 if (_is_uniform(gz) and _is_uniform(gx)) else 1))
+    ctx.check(ctx.lib.pl_rk4(ctx.handle(), n, _lib.dptr(txc), gnz, gnx, _lib.dptr(gz), _lib.dptr(gx), _lib.dptr(vz),
                              _lib.dptr(vx), float(tstep), _lib.dptr(v), _lib.dptr(xn)))
     return v, xn

@@ -1,0 +1,135 @@
+"""BASELINE.json's single-GPU configurations at FULL size, inside the driver-run suite.
+
+config 2: 513x513 thermal convection with T-dependent viscosity, matrix-free BiCGStab against scipy's direct
+          solve (the reference's pylamp2.py:353-366,415-421 path restated by the oracle), at the DEFAULT tolerance;
+config 3: 2049x2049 nodes, 16 markers per node (67 174 416 tracers): two resident steps, size-independent properties
+          at full size, and the marker kernels against the oracle on the same grid with a 4 M-tracer subset.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config2_513_mantle_vs_direct_solve(oracle):
+    """513^2, T-dependent viscosity clamped to 1e17..1e23 (a smooth 1e3 contrast under a stiff lid), fields built
+    from 16 markers per node exactly as the step does; Stokes and heat solves at the default tolerances against
+    scipy spsolve on the oracle's explicit matrices (~1 min of CPU)."""
+    from pylamp_amd import driver, pylamp_stokes as S, pylamp_diff as D
+    n = 513; nx = [n, n]; L = [660e3, 660e3]
+    grid = [np.linspace(0, L[0], n), np.linspace(0, L[1], n)]
+    gmp = oracle.gridmp_of(grid)
+    rng = np.random.default_rng(20260102)
+    tr_x, tr_f = driver.mantle_tracers(nx, L, 16, rng)
+    oracle.property_update(tr_f, True, True)
+    rho, etas, cp, T, H = oracle.trac2grid(tr_x, tr_f[:, [0, 1, 5, 3, 11]], grid, nx, [5, 6, 5, 5, 5])
+    etan, = oracle.trac2grid(tr_x, tr_f[:, [1]], gmp, nx, [6])
+    kz, = oracle.trac2grid(tr_x, tr_f[:, [4]], [gmp[0], grid[1]], nx, [5])
+    kx, = oracle.trac2grid(tr_x, tr_f[:, [4]], [grid[0], gmp[1]], nx, [5])
+    assert etas.max() / etas.min() > 500.0                       # the configuration's viscosity contrast is there
+    bc = [1, 1, 1, 1]
+    A, rhs = S.makeStokesMatrix(nx, grid, etas, etan, rho, bc)
+    x = S.solve(A, rhs)                                           # default rtol / maxit
+    st = A.last_stats
+    xr = oracle.stokes_solve(nx, grid, etas, etan, rho, bc)
+    (vz, vx), p = S.x2vp(x, nx); (rz, rx), rp = oracle.x2vp(xr, nx)
+    ev = np.sqrt((np.sum((vz - rz) ** 2) + np.sum((vx - rx) ** 2)) / (np.sum(rz ** 2) + np.sum(rx ** 2)))
+    assert st["converged"] == 1 and st["rel_residual"] <= S.DEFAULT_RTOL, st
+    assert ev < 1e-6 and relerr(p, rp) < 1e-5, (ev, relerr(p, rp), st)
+    # heat: stock boundary conditions, time step = the diffusive limit of pylamp2.py:339-343
+    dt = 0.67 * (grid[0][1] - grid[0][0]) ** 2 / np.max(2 * kz / (rho * cp))
+    hbc = [0, 1, 0, 1]; hval = [273.0, 0.0, 1623.0, 0.0]
+    Ah, rh = D.makeDiffusionMatrix(nx, grid, gmp, T, [kz, kx], cp, rho, H, hbc, hval, dt)
+    Tn = D.solve(Ah, rh)
+    Tr = oracle.heat_solve(nx, grid, gmp, T, [kz, kx], cp, rho, H, hbc, hval, dt)
+    assert Ah.last_stats["converged"] == 1 and relerr(Tn, Tr) < 1e-6, (relerr(Tn, Tr), Ah.last_stats)
+
+
+def test_config3_2049_67M_tracers(oracle):
+    from pylamp_amd import driver, pylamp_trac as T
+    n = 2049; nx = [n, n]; L = [660e3, 660e3]; dens = 16
+    grid = [np.linspace(0, L[0], n), np.linspace(0, L[1], n)]
+    rng = np.random.default_rng(20260103)
+    tr_x, tr_f = driver.mantle_tracers(nx, L, dens, rng)
+    ntr = tr_x.shape[0]
+    assert ntr == 67174416
+    sim = driver.Simulation(nx, L, tr_x, tr_f, driver.Options())
+    # ---- census of the resident, cell-sorted state = np.bincount of the cell index (pylamp2.py:588-598)
+    def host_census(X):
+        ci = np.minimum((X[:, 0] / (L[0] / (n - 1))).astype(np.int64), n - 2)
+        cj = np.minimum((X[:, 1] / (L[1] / (n - 1))).astype(np.int64), n - 2)
+        return np.bincount(ci * (n - 1) + cj, minlength=(n - 1) * (n - 1)).reshape(n - 1, n - 1)
+    cen = sim.census()
+    assert cen.sum() == ntr and np.array_equal(cen, host_census(tr_x))
+    tmin, tmax = tr_f[:, 3].min(), tr_f[:, 3].max()
+    del tr_f
+    # ---- two resident steps at full size
+    for it in (1, 2):
+        rep = sim.step()
+        assert rep["stokes"]["converged"] == 1 and rep["stokes"]["rel_residual"] <= sim.opt.stokes_rtol, rep
+        assert rep["heat"]["converged"] == 1, rep
+        assert rep["ntrac"] == ntr and rep["ninjected"] == 0                      # tracer count conserved
+        assert np.isfinite(rep["tstep"]) and rep["tstep"] > 0
+    cen2 = sim.census()
+    assert cen2.sum() == ntr
+    for name in ("velz", "velx", "pres", "rho", "etas", "etan", "temp"):
+        f = sim.field(name)
+        assert np.isfinite(f[:-1, :-1]).all(), name
+    # marker averages are convex combinations: node values stay inside the range of the marker values
+    rho = sim.field("rho"); es = sim.field("etas")
+    assert 3300.0 / (3.5e-5 * (tmax + 30 - 1623.0) + 1) - 1 <= rho.min() and rho.max() <= 3300.0 / (3.5e-5 * (tmin - 30 - 1623.0) + 1) + 1
+    assert es.min() >= 1e17 * (1 - 1e-12) and es.max() <= 1e23 * (1 + 1e-12)
+    X, F = sim.tracers()                                                          # upload order
+    assert np.array_equal(F[:, 12], np.arange(ntr, dtype=np.float64))             # identities intact
+    assert X[:, 0].min() > 0 and X[:, 0].max() < L[0] and X[:, 1].min() > 0 and X[:, 1].max() < L[1]
+    assert np.array_equal(cen2, host_census(X))
+    # the velocity field is (discretely) divergence-free: continuity rows of the solution vanish
+    vz = sim.field("velz"); vx = sim.field("velx")
+    div = (vx[:-1, 1:] - vx[:-1, :-1]) / (L[1] / (n - 1)) + (vz[1:, :-1] - vz[:-1, :-1]) / (L[0] / (n - 1))
+    scale = max(np.abs(vz).max(), np.abs(vx).max()) / (L[0] / (n - 1))
+    assert np.abs(div).max() < 1e-6 * scale
+    sim.close()
+    del F
+    # ---- module functions at full size: exactness properties that do not need an oracle
+    # (a) grid2trac LINEAR reproduces a linear field exactly at all 67 M tracers
+    Z, Xg = np.meshgrid(grid[0], grid[1], indexing="ij")
+    lin = 3.0 + 2.0e-6 * Z - 1.5e-6 * Xg
+    out = np.empty((ntr, 1))
+    T.grid2trac(X, out, grid, [lin], nx, method=T.INTERP_METHOD_LINEAR, stopOnError=True)
+    exp = 3.0 + 2.0e-6 * X[:, 0] - 1.5e-6 * X[:, 1]
+    assert np.max(np.abs(out[:, 0] - exp)) < 1e-12 * np.abs(exp).max()
+    del out, exp
+    # (b) trac2grid of a constant is that constant at every node (weights sum to the denominator), and the
+    #     unweighted arithmetic mean of ones is one wherever a node has a tracer: the accumulators add up
+    ones = np.full((ntr, 1), 7.25)
+    gf = [np.zeros(nx)]
+    T.trac2grid(X, ones, None, grid, gf, nx, avgscheme=[T.INTERP_AVG_ARITHW])
+    assert np.allclose(gf[0], 7.25, rtol=1e-13, atol=0)
+    del ones
+    # ---- marker kernels against the oracle on the same grid, 4 M-tracer subset
+    m = 4_200_000
+    sub = np.ascontiguousarray(X[::ntr // m][:m])
+    del X
+    f = np.stack([3300 + 50 * np.sin(sub[:, 0] / 3e4), 1e19 * 10 ** (2 * np.cos(sub[:, 1] / 5e4) ** 2)], axis=1)
+    gf = [np.zeros(nx), np.zeros(nx)]
+    T.trac2grid(sub, f, None, grid, gf, nx, avgscheme=[T.INTERP_AVG_ARITHW, T.INTERP_AVG_GEOMW])
+    ref = oracle.trac2grid(sub, f, grid, nx, [5, 6])
+    for k in range(2):
+        assert np.array_equal(np.isnan(gf[k]), np.isnan(ref[k]))
+        ok = ~np.isnan(ref[k])
+        assert np.max(np.abs(gf[k][ok] - ref[k][ok]) / np.abs(ref[k][ok])) < 1e-11
+    got = np.empty((m, 2))
+    T.grid2trac(sub, got, grid, [vz, vx], nx, method=T.INTERP_METHOD_LINEAR)
+    exp = oracle.grid2trac(sub, grid, [vz, vx], nx)
+    assert relerr(got, exp) < 1e-13
+    # RK4 on the padded cell-centre grid built from the step's own velocity solution (pylamp2.py:491-550)
+    gmp = oracle.gridmp_of(grid)
+    newgrid, vels = oracle.advection_velocity([vz, vx], gmp, nx, [1, 1, 1, 1])
+    dt = 0.67 * (grid[0][1] - grid[0][0]) / max(vz.max(), vx.max())
+    v1, x1 = T.RK(sub, newgrid, vels, nx, dt)
+    v0, x0 = oracle.rk4(sub, newgrid, vels, nx, dt)
+    assert relerr(x1, x0) < 1e-14 and relerr(v1, v0) < 1e-9

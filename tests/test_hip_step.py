@@ -16,9 +16,8 @@ def test_trajectory_vs_reference_driver(name, heat, tmp_path):
     g = golden(name)
     gz, gx = g["gz"], g["gx"]
     nx = [gz.size, gx.size]; L = [gz[-1], gx[-1]]
-    # the mantle fixture is almost hydrostatic (velocities are a response to tracer-sampling noise):
-    # its velocity error sits close to 1e-6 at the default 1e-10, so the test solves one digit deeper
-    opt = driver.Options(do_heatdiff=heat, tdep_rho=heat, tdep_eta=heat, stokes_rtol=1e-11 if heat else 1e-10)
+    # default tolerances: the same ones bench.py times
+    opt = driver.Options(do_heatdiff=heat, tdep_rho=heat, tdep_eta=heat)
     sim = driver.Simulation(nx, L, g["init_tr_x"], g["init_tr_f"], opt)
     for it in range(1, int(g["nsteps"]) + 1):
         rep = sim.step()
