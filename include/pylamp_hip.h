@@ -194,8 +194,9 @@ typedef struct pl_step_config {
     /* Tracer census + injection at the end of the step (pylamp2.py:588-633): cells holding fewer
      * than tracdens_min tracers are refilled to tracdens with tracers at (seeded) random positions
      * whose 12 fields are the plain mean of the tracers already in the cell.  tracdens_min <= 0
-     * disables it.  New IDs continue after the current maximum (unique; the reference re-uses the
-     * maximum once per cell, pylamp2.py:621-622). */
+     * disables it.  IDs follow the reference (pylamp2.py:621-622): the first new ID of every refilled cell repeats
+     * the last ID handed out; inject_unique_ids != 0 continues after the current maximum instead.  Positions come
+     * from a counter-based generator seeded with inject_seed (the reference draws from numpy's global stream). */
     int    tracdens, tracdens_min;
     uint64_t inject_seed;
     /* Free-surface stabilisation (pylamp2.py:71-73,352-355,368-372,387-405): with
@@ -204,6 +205,10 @@ typedef struct pl_step_config {
      * selects the corrected (damping) sign, see pl_stokes_set_coeffs. */
     int    surface_stabilization;
     double surfstab_theta, surfstab_tstep;
+    int    inject_unique_ids;       /* see tracdens above */
+    /* pylamp2.py:41,563-581: with the fence off a tracer at or beyond a wall is deleted (TR__ID = -1 -> np.delete)
+     * instead of being put back EPS inside the wall.  0 = fence on (the reference's default). */
+    int    tracs_fence_disabled;
 } pl_step_config;
 
 typedef struct pl_step_report {
@@ -215,6 +220,7 @@ typedef struct pl_step_report {
     int64_t ntrac;                  /* tracers on this rank after the step (incl. injected) */
     int64_t ninjected;              /* tracers injected on this rank at the end of this step */
     int     stokes_resolves;        /* extra Stokes solves of the surface-stabilisation loop */
+    int64_t nremoved;               /* tracers deleted on this rank at the end of this step (fence off) */
 } pl_step_report;
 
 /* Upload tracer state: tr_x (n,2), tr_f (n,13) AoS rows as in pylamp_const.py:29-42. */

@@ -285,9 +285,15 @@ def gen_grid2trac_rk():
 
 
 # ------------------------------------------------------------------------------------ F8
-def run_driver(tag, repl, nsteps, seed):
-    """exec the stock driver text with in-memory substitutions; collect its snapshots."""
+def run_driver(tag, repl, nsteps, seed, capture_post=False):
+    """exec the stock driver text with in-memory substitutions; collect its snapshots.
+    capture_post: also store the tracer state at the END of every loop pass, i.e. after deletion and injection
+    (pylamp2.py:574-633) -- the stock snapshot holds the state BEFORE injection (prev_tr_x / prev_tr_f)."""
     src = open(os.path.join(REF, "pylamp2.py")).read()
+    if capture_post:
+        hook = "        if IPROC == 0 and output_numpy and ((output_stride > 0"
+        assert hook in src
+        src = src.replace(hook, "        np.savez(output_outdir + '/post.{:06d}.npz'.format(it), tr_x=tr_x, tr_f=tr_f)\n" + hook)
     for a, b in repl:
         assert a in src, a
         src = src.replace(a, b)
@@ -331,6 +337,10 @@ def run_driver(tag, repl, nsteps, seed):
             res["s%d_tr_x" % it] = tc["tr_x"]
             res["s%d_tr_T" % it] = tc["tr_f"][:, TR_TMP]
             res["s%d_tr_v" % it] = tc["tr_v"]
+            if capture_post:
+                res["s%d_tr_id" % it] = tc["tr_f"][:, TR__ID]
+                po = np.load(os.path.join(td, "out", "post.%06d.npz" % it))
+                res["p%d_tr_x" % it] = po["tr_x"]; res["p%d_tr_f" % it] = po["tr_f"]
             if it == 1:
                 res["gz"] = gd["gridz"]; res["gx"] = gd["gridx"]
     save("traj_" + tag, **res)
@@ -357,6 +367,42 @@ def gen_trajectories():
         bcset], 3, 12)
 
 
+def gen_trajectories_census():
+    """Census + injection (pylamp2.py:588-633) and deletion (pylamp2.py:574-581) captured from the reference."""
+    bcset = ("    bcheat = [[]] * 4\n",
+             "    bcheat = [[]] * 4\n    bcstokes = [1, 1, 1, 1]\n")
+    # falling block 41x41, 12 markers/node on average, cells below 9 are refilled to 12 at the end of every step.
+    # (An EMPTY cell would be refilled with NaN-valued tracers -- 0/0 at pylamp2.py:629 -- and the next step's
+    # matrix is singular: seen with 6 markers/node.  At 12 no cell of these runs is empty.)
+    run_driver("inject41", [
+        ("nx    =   [200+1,40+1]", "nx    =   [41,41]"),
+        ("L     =   [1, 0.2] ", "L     =   [660e3, 660e3] "),
+        ("tracdens = 45 ", "tracdens = 12 "),
+        ("tracdens_min = 25 ", "tracdens_min = 9 "),
+        ("choose_model = 5", "choose_model = 2"),
+        bcset], 3, 14, capture_post=True)
+    # mantle model with heat: the injected tracers' temperature / conductivity etc. are cell means too
+    run_driver("inject_mantle25x33", [
+        ("nx    =   [200+1,40+1]", "nx    =   [25,33]"),
+        ("L     =   [1, 0.2] ", "L     =   [660e3, 880e3] "),
+        ("tracdens = 45 ", "tracdens = 14 "),
+        ("tracdens_min = 25 ", "tracdens_min = 10 "),
+        ("choose_model = 5", "choose_model = 1"),
+        bcset], 2, 15, capture_post=True)
+    # fence off: tracers outside the domain get TR__ID = -1 and are deleted.  70 tracers start beyond the low
+    # walls (the reference's marker code handles those through its grid extension; beyond the HIGH walls it
+    # indexes out of bounds, pylamp_trac.py:52)
+    run_driver("delete41", [
+        ("nx    =   [200+1,40+1]", "nx    =   [41,41]"),
+        ("L     =   [1, 0.2] ", "L     =   [660e3, 660e3] "),
+        ("tracdens = 45 ", "tracdens = 8 "),
+        ("tracdens_min = 25 ", "tracdens_min = 0 "),
+        ("tracs_fence_enabled = True", "tracs_fence_enabled = False"),
+        ("choose_model = 5", "choose_model = 2"),
+        ("    tr_x = np.multiply(tr_x, L)\n", "    tr_x = np.multiply(tr_x, L)\n    tr_x[5:45, IZ] = -3000.0\n    tr_x[100:130, IX] = -2500.0\n"),
+        bcset], 2, 16, capture_post=True)
+
+
 def gen_trajectory_surfstab():
     bcset = ("    bcheat = [[]] * 4\n",
              "    bcheat = [[]] * 4\n    bcstokes = [1, 1, 1, 1]\n")
@@ -372,7 +418,7 @@ def gen_trajectory_surfstab():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["op", "solve", "heat", "t2g", "g2t", "traj", "surfstab"]
+    which = sys.argv[1:] or ["op", "solve", "heat", "t2g", "g2t", "traj", "surfstab", "census"]
     if "op" in which: gen_stokes_operator()
     if "solve" in which: gen_stokes_solve()
     if "heat" in which: gen_heat()
@@ -380,3 +426,4 @@ if __name__ == "__main__":
     if "g2t" in which: gen_grid2trac_rk()
     if "traj" in which: gen_trajectories()
     if "surfstab" in which: gen_trajectory_surfstab()
+    if "census" in which: gen_trajectories_census()

@@ -706,14 +706,90 @@ class StepConfig:
         self.bcheat = [BC_FIXTEMP, BC_FIXFLOW, BC_FIXTEMP, BC_FIXFLOW]
         self.bcheatvals = [273.0, 0.0, 1623.0, 0.0]
         self.surface_stabilization = False; self.surfstab_theta = 0.5; self.surfstab_tstep = -1
+        # pylamp2.py:39-42.  tracdens_min = 0 never finds a deficient cell (the stock values are 45 / 25)
+        self.tracdens = 0; self.tracdens_min = 0; self.tracs_fence_enabled = True
         self.__dict__.update(kw)
 
 
+def fence_and_delete(tr_x, tr_f, trac_vel, L, fence_enabled=True):
+    """pylamp2.py:557-581 for the supported (non-CYCLIC, non-FLOWTHRU) walls: tracers at or beyond a wall are put
+    back EPS inside it, or -- fence off -- get TR__ID = -1 and are deleted from all three arrays.
+    Returns (tr_x, tr_f, trac_vel, number removed); tr_x / tr_f are modified in place before the deletion."""
+    for d in range(DIM):
+        idx = tr_x[:, d] <= 0
+        if fence_enabled:
+            tr_x[idx, d] = EPS
+        else:
+            tr_f[idx, TR__ID] = -1
+        idx = tr_x[:, d] >= L[d]
+        if fence_enabled:
+            tr_x[idx, d] = L[d] - EPS
+        else:
+            tr_f[idx, TR__ID] = -1
+    out = tr_f[:, TR__ID] < 0
+    n_out = int(np.sum(out))
+    if n_out:
+        keep = ~out
+        tr_x, tr_f, trac_vel = tr_x[keep], tr_f[keep], trac_vel[keep]
+    return tr_x, tr_f, trac_vel, n_out
+
+
+def census(tr_x, nx, L):
+    """Tracers per cell, pylamp2.py:588-594 (cell = floor((n-1) x / L), counted with np.bincount).
+    Returns (ielem, jelem, counts[(nz-1)*(nx_-1)])."""
+    ielem = np.floor((nx[IZ] - 1) * tr_x[:, IZ] / L[IZ]).astype(int)
+    jelem = np.floor((nx[IX] - 1) * tr_x[:, IX] / L[IX]).astype(int)
+    kelem = ielem * (nx[IX] - 1) + jelem
+    ncell = (nx[IZ] - 1) * (nx[IX] - 1)
+    return ielem, jelem, np.bincount(kelem, minlength=ncell)[:ncell]
+
+
+def inject(tr_x, tr_f, grid, nx, L, tracdens, tracdens_min, rand=None):
+    """Refill of depleted cells, pylamp2.py:595-633.  Cells holding fewer than tracdens_min tracers receive
+    tracdens - count new ones, cell by cell in ascending cell number, appended behind the existing tracers:
+    positions uniformly random inside the cell (np.random.rand(m, DIM), legacy global stream unless `rand` is
+    given), every field except the ID = plain mean of the tracers that were in the cell BEFORE any injection
+    (0/0 = NaN for an empty cell), IDs arange(max(ID), max(ID) + m) with the maximum taken over the array as it
+    stands -- i.e. the first new ID of every cell repeats the last ID handed out (pylamp2.py:621-622).
+    Returns (tr_x, tr_f, info) with info = dict(cells, n_missing, n_injected)."""
+    rand = rand or np.random.rand
+    ielem, jelem, cnt = census(tr_x, nx, L)
+    few = cnt < tracdens_min
+    cells = np.where(few)[0]
+    info = dict(cells=cells, n_missing=tracdens - cnt[few], n_injected=0)
+    if cells.size == 0:
+        return tr_x, tr_f, info
+    ci = cells // (nx[IX] - 1); cj = cells % (nx[IX] - 1)
+    n_missing = info["n_missing"]
+    prev_f = tr_f.copy()
+    new_x, new_f = [], []
+    maxid = np.max(tr_f[:, TR__ID])
+    for k in range(cells.size):
+        m = int(n_missing[k])
+        x = rand(m, DIM)
+        x[:, IX] = x[:, IX] * (grid[IX][cj[k] + 1] - grid[IX][cj[k]]) + grid[IX][cj[k]]
+        x[:, IZ] = x[:, IZ] * (grid[IZ][ci[k] + 1] - grid[IZ][ci[k]]) + grid[IZ][ci[k]]
+        f = np.zeros((m, NFTRAC))
+        f[:, TR__ID] = np.arange(maxid, maxid + m)
+        inel = (ielem == ci[k]) & (jelem == cj[k])
+        with np.errstate(invalid="ignore", divide="ignore"):
+            for q in range(NFTRAC):
+                if q != TR__ID:
+                    f[:, q] = np.sum(prev_f[inel, q]) / np.sum(inel)
+        if m > 0:
+            maxid = max(maxid, f[-1, TR__ID])
+        new_x.append(x); new_f.append(f)
+    info["n_injected"] = int(np.sum(n_missing))
+    return np.concatenate([tr_x] + new_x), np.concatenate([tr_f] + new_f), info
+
+
 def step(state, cfg, it):
-    """One time step of the stock loop (pylamp2.py:273-581), tracer injection excluded.
+    """One time step of the stock loop (pylamp2.py:273-633): everything up to the advection, the fence / deletion
+    (574-581) and the census + injection (588-633; inert while cfg.tracdens_min == 0).
 
     state: dict with nx, L, grid, tr_x (n,2), tr_f (n,13) and, for it>1, newtemp.
-    Returns a dict of the step's grid fields; mutates state['tr_x'], state['tr_f'].
+    Returns a dict of the step's grid fields; replaces state['tr_x'], state['tr_f'] (after injection) and stores
+    the pre-injection arrays the stock snapshot writes as out['snap_tr_x'], out['snap_tr_f'].
     """
     nx, L, grid = state['nx'], state['L'], state['grid']
     nz, nxx = nx
@@ -794,9 +870,10 @@ def step(state, cfg, it):
 
     grids, vels = advection_velocity(newvel, gridmp, nx, cfg.bcstokes)
     trac_vel, xnew = rk4(tr_x, grids, vels, nx, tstep)
-    for d in range(DIM):                       # fence, pylamp2.py:558-572
-        xnew[xnew[:, d] <= 0, d] = EPS
-        xnew[xnew[:, d] >= L[d], d] = L[d] - EPS
-    state['tr_x'] = xnew
-    out.update(tr_v=trac_vel)
+    xnew, tr_f, trac_vel, n_removed = fence_and_delete(xnew, tr_f, trac_vel, L, cfg.tracs_fence_enabled)
+    out.update(tr_v=trac_vel, n_removed=n_removed, snap_tr_x=xnew, snap_tr_f=tr_f)
+    if cfg.tracdens_min > 0:
+        xnew, tr_f, info = inject(xnew, tr_f, grid, nx, L, cfg.tracdens, cfg.tracdens_min, state.get('rand'))
+        out.update(inject=info)
+    state['tr_x'] = xnew; state['tr_f'] = tr_f
     return out

@@ -32,7 +32,7 @@ class StepConfig(C.Structure):
                 ("heat_rtol", C.c_double), ("stokes_maxit", C.c_int), ("heat_maxit", C.c_int),
                 ("length", C.c_double * 2), ("tracdens", C.c_int), ("tracdens_min", C.c_int),
                 ("inject_seed", C.c_uint64), ("surface_stabilization", C.c_int), ("surfstab_theta", C.c_double),
-                ("surfstab_tstep", C.c_double)]
+                ("surfstab_tstep", C.c_double), ("inject_unique_ids", C.c_int), ("tracs_fence_disabled", C.c_int)]
 
 
 class StepReport(C.Structure):
@@ -41,7 +41,7 @@ class StepReport(C.Structure):
                 ("ms_props", C.c_double), ("ms_scatter", C.c_double), ("ms_stokes", C.c_double),
                 ("ms_heat", C.c_double), ("ms_gather", C.c_double), ("ms_advect", C.c_double),
                 ("ms_sort", C.c_double), ("ms_total", C.c_double), ("ntrac", C.c_int64), ("ninjected", C.c_int64),
-                ("stokes_resolves", C.c_int)]
+                ("stokes_resolves", C.c_int), ("nremoved", C.c_int64)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/pylamp_hip.h

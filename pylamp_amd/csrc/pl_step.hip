@@ -36,7 +36,10 @@ struct PlStepState {
     int lo_ext = 0, hi_ext = 0;
     bool sorted = false;                             // tracers are cell-sorted and cell_start is valid
     int* need = nullptr; int* need_off = nullptr;    // injection: per-cell deficit and its exclusive scan
-    double next_id = 0.0;                            // next free TR__ID                      // 1: sort row 0 / last row collect tracers leaving to rank-1 / rank+1
+    int* need_flag = nullptr; int* need_rank = nullptr;   // 1 for a deficient cell, and its exclusive scan (reference ID rule)
+    double max_id = -1.0;                            // current maximum of TR__ID over all ranks
+    bool max_id_valid = false;                       // false after a deletion: recomputed on the device when needed
+    int sort_cells = 0;                              // cells of the current sort grid (the trash bucket follows them)
     std::vector<double> gmz, gmx;                    // midpoint grids (pylamp2.py:92-95)
 };
 
@@ -52,7 +55,7 @@ void pl_step_free(pl_ctx* ctx) {
         if (q) (void)hipFree(q);
     for (double* q : s->f) if (q) (void)hipFree(q);
     for (double* q : s->f2) if (q) (void)hipFree(q);
-    for (int* q : {s->cell, s->dest, s->orig, s->orig2, s->cell_count, s->cell_start, s->block_sums, s->need, s->need_off}) if (q) (void)hipFree(q);
+    for (int* q : {s->cell, s->dest, s->orig, s->orig2, s->cell_count, s->cell_start, s->block_sums, s->need, s->need_off, s->need_flag, s->need_rank}) if (q) (void)hipFree(q);
     delete s;
     ctx->step = nullptr;
 }
@@ -95,14 +98,20 @@ __device__ inline void wave_runs(int c, int lane, int& seg0, int& len) {
     const unsigned long long above = (seg0 == 63) ? 0ull : (heads >> (seg0 + 1));
     len = above ? __ffsll((long long)above) : 64 - seg0;            // lanes in my run
 }
+// del_outside: a tracer at or beyond a wall (pylamp2.py:563-572 with the fence off: TR__ID = -1) goes to the trash
+// bucket behind the last cell; the permutation then leaves the survivors as the first cell_start[ncells] entries.
 __global__ __launch_bounds__(256) void k_cell_count(long long n, const double* __restrict__ tz, const double* __restrict__ tx,
                                                     double z0, double hz, double x0, double hx, const double* __restrict__ zc,
                                                     const double* __restrict__ xc, int ncz, int ncx, int crow0,
-                                                    int gcz, int* __restrict__ cell, int* __restrict__ count) {
+                                                    int gcz, int* __restrict__ cell, int* __restrict__ count,
+                                                    int del_outside, double Lz, double Lx) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int c = -1;                                          // lanes past the end form their own run and add nothing
-    if (t < n) {
+    if (t < n && del_outside && (tz[t] <= 0.0 || tz[t] >= Lz || tx[t] <= 0.0 || tx[t] >= Lx)) {
+        c = ncz * ncx;
+        cell[t] = c;
+    } else if (t < n) {
         int ci, cj;
         if (zc) { double a_; mic_axis_locate(zc, gcz + 1, tz[t], ci, a_); mic_axis_locate(xc, ncx + 1, tx[t], cj, a_); }   // rectilinear node grid
         else { ci = (int)floor((tz[t] - z0) / hz); cj = (int)floor((tx[t] - x0) / hx); }
@@ -193,7 +202,7 @@ __global__ __launch_bounds__(256) void k_permute(long long n, const int* __restr
 
 // ---- census + injection (pylamp2.py:588-633) ---------------------------------------------------
 __global__ __launch_bounds__(256) void k_deficit(int nc, int ncx, int row_lo, int row_hi, const int* __restrict__ start,
-                                                 int dens, int dmin, int* __restrict__ need) {
+                                                 int dens, int dmin, int* __restrict__ need, int* __restrict__ flag) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c > nc) return;
     int v = 0;
@@ -203,6 +212,26 @@ __global__ __launch_bounds__(256) void k_deficit(int nc, int ncx, int row_lo, in
         if (row >= row_lo && row < row_hi && cnt < dmin) v = dens - cnt;
     }
     need[c] = v;                                   // need[nc] = 0 so that the scan yields the total
+    flag[c] = v > 0 ? 1 : 0;
+}
+// block partials of max(v[0..n))
+__global__ __launch_bounds__(256) void k_max1d(long long n, const double* __restrict__ v, double* __restrict__ part) {
+    double m = -INFINITY;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long long)gridDim.x * 256) m = fmax(m, v[t]);
+    __shared__ double sh[4];
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_down(m, o, 64));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+}
+// survivors of a deletion keep the caller's relative order: orig -> rank among the survivors
+__global__ __launch_bounds__(256) void k_mark_alive(long long n, const int* __restrict__ orig, int* __restrict__ alive) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) alive[orig[t]] = 1;
+}
+__global__ __launch_bounds__(256) void k_remap_orig(long long n, int* __restrict__ orig, const int* __restrict__ rank) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) orig[t] = rank[orig[t]];
 }
 __device__ inline double inj_uniform(unsigned long long seed, unsigned a, unsigned b, unsigned c) {
     unsigned long long h = seed ^ (0x9E3779B97F4A7C15ull * (a + 1)) ^ (0xC2B2AE3D27D4EB4Full * (b + 1)) ^ (0x165667B19E3779F9ull * (c + 1));
@@ -212,6 +241,7 @@ __device__ inline double inj_uniform(unsigned long long seed, unsigned a, unsign
 struct InjectArgs {
     int nc, ncx, crow0; long long n;
     const int* start; const int* need; const int* off;
+    const int* rank;                             // deficient cells before this one, or NULL: unique IDs
     double* tz; double* tx; double* f[NFTRAC]; double* vtz; double* vtx;
     double z0, hz, x0, hx; unsigned long long seed; unsigned step; double id0;
     const double* zc; const double* xc;          // rectilinear node grid (NULL: regular)
@@ -236,7 +266,8 @@ __global__ __launch_bounds__(64) void k_inject(InjectArgs a) {
         a.tz[d] = a.zc ? a.zc[ci] + uz * (a.zc[ci + 1] - a.zc[ci]) : a.z0 + (ci + uz) * a.hz;
         a.tx[d] = a.xc ? a.xc[cj] + ux * (a.xc[cj + 1] - a.xc[cj]) : a.x0 + (cj + ux) * a.hx;
         for (int k = 0; k < NFTRAC; k++) a.f[k][d] = mean[k];
-        a.f[TR__ID][d] = a.id0 + a.off[c] + q;
+        // reference rule (pylamp2.py:621-622): the first new ID of every cell repeats the last ID handed out
+        a.f[TR__ID][d] = a.id0 + a.off[c] + q - (a.rank ? a.rank[c] : 0);
         a.vtz[d] = 0.0; a.vtx[d] = 0.0;                             // injected tracers have not been advected yet
     }
 }
@@ -439,7 +470,8 @@ static int ensure_tracers(pl_ctx* ctx, PlStepState* S, long long n) {
 }
 
 static void unpermute(pl_ctx* ctx, PlStepState* S, int na, const double* const* in, double* const* out);
-static int sort_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, double x0, double hx);
+static int sort_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, double x0, double hx, int del_outside = 0,
+                        double Lz = 0.0, double Lx = 0.0, long long* removed = nullptr);
 // Host midpoint grids (pylamp2.py:92-95) and device copies of all coordinate arrays the marker kernels use:
 // gcoords = [ node z (nz) | node x (nx) | padded centres z (nz+1) | padded centres x (nx+1) ]; the centre
 // (midpoint) grids of the staggered targets are the padded ones without their first entry.
@@ -498,7 +530,7 @@ extern "C" int pl_tracers_upload(pl_ctx* ctx, int64_t n, const double* tr_x, con
     double idmax[1] = {-1.0};
     for (int64_t t = 0; t < n; t++) if (tr_f[NFTRAC * t + TR__ID] > idmax[0]) idmax[0] = tr_f[NFTRAC * t + TR__ID];
     PL_TRY(pl_allreduce_host(ctx, idmax, 1, 2));
-    S->next_id = idmax[0] + 1.0;
+    S->max_id = idmax[0]; S->max_id_valid = true;
     // cell-sort (and, on a slab, hand over anything that does not belong here)
     PL_TRY(ensure_coords(ctx, S));
     const int nz = ctx->nz, nx = ctx->nx;
@@ -587,7 +619,9 @@ extern "C" int pl_get_tracer_velocity(pl_ctx* ctx, int64_t n, double* out) {
 // Counting sort of all tracer arrays by node-grid cell; leaves cell_start (ncells+1 ints) valid.
 // On a slab the sort grid has one extra row on each interior side that collects the tracers which
 // left the slab (they end up as contiguous ranges at the two ends of every array).
-static int sort_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, double x0, double hx) {
+// del_outside != 0: tracers at or beyond a wall are removed (fence off, pylamp2.py:563-581); *removed returns their number.
+static int sort_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, double x0, double hx, int del_outside,
+                        double Lz, double Lx, long long* removed) {
     const PlGeom& g = ctx->geom.d;
     const int C = (ctx->nranks > 1) ? (g.nz - 1) / ctx->nranks : g.nz - 1;
     S->lo_ext = (ctx->rank > 0) ? 1 : 0; S->hi_ext = (ctx->rank < ctx->nranks - 1) ? 1 : 0;
@@ -597,21 +631,23 @@ static int sort_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, doubl
     if (n >= (1LL << 31)) return pl_fail(ctx, "sort_tracers: more than 2^31 tracers per GPU");
     if (!S->cell_count || S->ncz != ncz) {
         for (int** q : {&S->cell_count, &S->cell_start, &S->block_sums}) { if (*q) (void)hipFree(*q); *q = nullptr; }
-        const int nb = (nc + 1 + 1023) / 1024;
-        PL_HIP(ctx, hipMalloc((void**)&S->cell_count, (size_t)(nc + 1) * sizeof(int)));
-        PL_HIP(ctx, hipMalloc((void**)&S->cell_start, (size_t)(nc + 1) * sizeof(int)));
+        const int nb = (nc + 2 + 1023) / 1024;
+        PL_HIP(ctx, hipMalloc((void**)&S->cell_count, (size_t)(nc + 2) * sizeof(int)));
+        PL_HIP(ctx, hipMalloc((void**)&S->cell_start, (size_t)(nc + 2) * sizeof(int)));
         PL_HIP(ctx, hipMalloc((void**)&S->block_sums, (size_t)(nb + 1) * sizeof(int)));
         S->ncz = ncz; S->ncx = ncx;
     }
-    PL_HIP(ctx, hipMemsetAsync(S->cell_count, 0, (size_t)(nc + 1) * sizeof(int), ctx->stream));
+    S->sort_cells = nc;
+    // counts: [0, nc) cells, [nc] trash bucket (deleted tracers), [nc + 1] = 0 so that the scan ends with the total
+    PL_HIP(ctx, hipMemsetAsync(S->cell_count, 0, (size_t)(nc + 2) * sizeof(int), ctx->stream));
     if (n > 0)
         hipLaunchKernelGGL(k_cell_count, grid1d(n), dim3(256), 0, ctx->stream, n, S->tz, S->tx, z0, hz, x0, hx, coords_z(ctx, S, 0),
-                           coords_x(ctx, S, 0), ncz, ncx, S->crow0, g.nz - 1, S->cell, S->cell_count);
-    const int m = nc + 1, nb = (m + 1023) / 1024;
+                           coords_x(ctx, S, 0), ncz, ncx, S->crow0, g.nz - 1, S->cell, S->cell_count, del_outside, Lz, Lx);
+    const int m = nc + 2, nb = (m + 1023) / 1024;
     hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(256), 0, ctx->stream, m, S->cell_count, S->cell_start, S->block_sums);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, ctx->stream, nb, S->block_sums);
     hipLaunchKernelGGL(k_scan_add, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, m, S->cell_start, S->block_sums, 0);
-    PL_HIP(ctx, hipMemsetAsync(S->cell_count, 0, (size_t)(nc + 1) * sizeof(int), ctx->stream));   // reused as fill counters
+    PL_HIP(ctx, hipMemsetAsync(S->cell_count, 0, (size_t)(nc + 2) * sizeof(int), ctx->stream));   // reused as fill counters
     if (n > 0) {
         hipLaunchKernelGGL(k_cell_place, grid1d(n), dim3(256), 0, ctx->stream, n, S->cell, S->cell_start, S->cell_count, S->dest);
         // permute positions and the 13 fields
@@ -631,6 +667,30 @@ static int sort_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, doubl
         for (int k = 0; k < NFTRAC; k++) std::swap(S->f[k], S->f2[k]);
     }
     PL_HIP(ctx, hipGetLastError());
+    if (removed) *removed = 0;
+    if (del_outside && n > 0) {
+        int alive_n = 0;
+        PL_HIP(ctx, hipMemcpyAsync(&alive_n, S->cell_start + nc, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (alive_n < n) {
+            // the survivors are the first alive_n entries; renumber `orig` so that downloads keep the caller's
+            // relative order (np.delete keeps it, pylamp2.py:578-580).  cell / dest are free after the sort.
+            PL_HIP(ctx, hipMemsetAsync(S->cell, 0, (size_t)n * sizeof(int), ctx->stream));
+            if (alive_n > 0) hipLaunchKernelGGL(k_mark_alive, grid1d(alive_n), dim3(256), 0, ctx->stream, (long long)alive_n, S->orig, S->cell);
+            const int mm = (int)n, nbb = (mm + 1023) / 1024;
+            int* bs = nullptr;
+            PL_HIP(ctx, hipMalloc((void**)&bs, (size_t)(nbb + 1) * sizeof(int)));
+            hipLaunchKernelGGL(k_scan_block, dim3(nbb), dim3(256), 0, ctx->stream, mm, S->cell, S->dest, bs);
+            hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, ctx->stream, nbb, bs);
+            hipLaunchKernelGGL(k_scan_add, dim3((mm + 255) / 256), dim3(256), 0, ctx->stream, mm, S->dest, bs, 0);
+            if (alive_n > 0) hipLaunchKernelGGL(k_remap_orig, grid1d(alive_n), dim3(256), 0, ctx->stream, (long long)alive_n, S->orig, S->dest);
+            PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            (void)hipFree(bs);
+            if (removed) *removed = n - alive_n;
+            S->n = alive_n;
+            S->max_id_valid = false;
+        }
+    }
     return 0;
 }
 
@@ -683,30 +743,58 @@ static int inject_tracers(pl_ctx* ctx, PlStepState* S, const pl_step_config* cfg
     *ninj = 0;
     const int nc = S->ncz * S->ncx;
     if (!S->need) {
-        PL_HIP(ctx, hipMalloc((void**)&S->need, (size_t)(nc + 1) * sizeof(int)));
-        PL_HIP(ctx, hipMalloc((void**)&S->need_off, (size_t)(nc + 1) * sizeof(int)));
+        for (int** q : {&S->need, &S->need_off, &S->need_flag, &S->need_rank}) PL_HIP(ctx, hipMalloc((void**)q, (size_t)(nc + 1) * sizeof(int)));
     }
     const int m1 = nc + 1, nb = (m1 + 1023) / 1024;
     hipLaunchKernelGGL(k_deficit, dim3((m1 + 255) / 256), dim3(256), 0, ctx->stream, nc, S->ncx, S->lo_ext, S->ncz - S->hi_ext,
-                       S->cell_start, cfg->tracdens, cfg->tracdens_min, S->need);
-    hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(256), 0, ctx->stream, m1, S->need, S->need_off, S->block_sums);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, ctx->stream, nb, S->block_sums);
-    hipLaunchKernelGGL(k_scan_add, dim3((m1 + 255) / 256), dim3(256), 0, ctx->stream, m1, S->need_off, S->block_sums, 0);
-    int m = 0;
+                       S->cell_start, cfg->tracdens, cfg->tracdens_min, S->need, S->need_flag);
+    for (int pass = 0; pass < 2; pass++) {                 // exclusive scans of the deficits and of the deficient-cell flags
+        hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(256), 0, ctx->stream, m1, pass ? S->need_flag : S->need,
+                           pass ? S->need_rank : S->need_off, S->block_sums);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, ctx->stream, nb, S->block_sums);
+        hipLaunchKernelGGL(k_scan_add, dim3((m1 + 255) / 256), dim3(256), 0, ctx->stream, m1, pass ? S->need_rank : S->need_off, S->block_sums, 0);
+    }
+    int m = 0, ndef = 0;
     PL_HIP(ctx, hipMemcpyAsync(&m, S->need_off + nc, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    PL_HIP(ctx, hipMemcpyAsync(&ndef, S->need_rank + nc, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    // globally unique new IDs: rank r takes the block after the ranks before it
-    std::vector<double> cnt((size_t)ctx->nranks, 0.0);
-    cnt[ctx->rank] = m;
+    // new IDs in global cell order: rank r continues after the ranks before it
+    const int R = ctx->nranks;
+    std::vector<double> cnt((size_t)2 * R, 0.0);
+    cnt[2 * ctx->rank] = m; cnt[2 * ctx->rank + 1] = ndef;
     PL_TRY(pl_allreduce_host(ctx, cnt.data(), (long long)cnt.size(), 0));
-    double before = 0.0, total = 0.0;
-    for (int q = 0; q < ctx->nranks; q++) { if (q < ctx->rank) before += cnt[q]; total += cnt[q]; }
-    const double id0 = S->next_id + before;
-    S->next_id += total;
+    double before = 0.0, total = 0.0, def_before = 0.0, def_total = 0.0;
+    for (int q = 0; q < R; q++) {
+        if (q < ctx->rank) { before += cnt[2 * q]; def_before += cnt[2 * q + 1]; }
+        total += cnt[2 * q]; def_total += cnt[2 * q + 1];
+    }
+    if (total == 0.0) return 0;
+    if (!S->max_id_valid) {                                // a deletion may have removed the holder of the maximum
+        double mx[1] = {-1.0};
+        if (S->n > 0) {
+            const int nbm = 256;
+            if (!S->partial || S->hpartial.size() < (size_t)nbm) {
+                if (S->partial) (void)hipFree(S->partial);
+                PL_HIP(ctx, hipMalloc((void**)&S->partial, 3 * 4096 * sizeof(double)));
+                S->hpartial.resize(3 * 4096);
+            }
+            hipLaunchKernelGGL(k_max1d, dim3(nbm), dim3(256), 0, ctx->stream, S->n, S->f[TR__ID], S->partial);
+            PL_HIP(ctx, hipMemcpyAsync(S->hpartial.data(), S->partial, nbm * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            for (int k = 0; k < nbm; k++) mx[0] = std::fmax(mx[0], S->hpartial[k]);
+        }
+        PL_TRY(pl_allreduce_host(ctx, mx, 1, 2));
+        S->max_id = mx[0]; S->max_id_valid = true;
+    }
+    const bool strict = cfg->inject_unique_ids == 0;
+    // strict: IDs start AT the current maximum and every refilled cell repeats one (pylamp2.py:621-622)
+    const double id0 = strict ? S->max_id + before - def_before : S->max_id + 1.0 + before;
+    S->max_id += strict ? total - def_total : total;
     if (m == 0) return 0;
     PL_TRY(grow_tracers(ctx, S, S->n + m, S->n));
     InjectArgs a{};
     a.nc = nc; a.ncx = S->ncx; a.crow0 = S->crow0; a.n = S->n; a.start = S->cell_start; a.need = S->need; a.off = S->need_off;
+    a.rank = strict ? S->need_rank : nullptr;
     a.tz = S->tz; a.tx = S->tx; for (int k = 0; k < NFTRAC; k++) a.f[k] = S->f[k];
     a.vtz = S->vtz; a.vtx = S->vtx;
     a.z0 = z0; a.hz = hz; a.x0 = x0; a.hx = hx; a.seed = cfg->inject_seed; a.step = (unsigned)it; a.id0 = id0;
@@ -980,7 +1068,7 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
     ra.g.pitch = nx + 1; ra.g.off = 0;
     ra.Vz = V; ra.Vx = V + VN; ra.dt = tstep;
     ra.tz_out = S->tz2; ra.tx_out = S->tx2; ra.vz_out = S->vtz; ra.vx_out = S->vtx;
-    ra.fence = 1; ra.eps = PL_EPS; ra.Lz = Lz; ra.Lx = Lx;
+    ra.fence = cfg->tracs_fence_disabled ? 0 : 1; ra.eps = PL_EPS; ra.Lz = Lz; ra.Lx = Lx;
     pl_launch_rk4(ctx, ra);
     PL_HIP(ctx, hipGetLastError());
     std::swap(S->tz, S->tz2); std::swap(S->tx, S->tx2);
@@ -990,7 +1078,11 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
     // ---- 7. cell sort of the advected tracers, slab migration, census + injection --------------------
     t0 = now_ms();
     S->sorted = false;
-    PL_TRY(sort_tracers(ctx, S, z0, hz, x0, hx));
+    {
+        long long removed = 0;
+        PL_TRY(sort_tracers(ctx, S, z0, hz, x0, hx, cfg->tracs_fence_disabled ? 1 : 0, Lz, Lx, &removed));
+        rep->nremoved = removed;
+    }
     PL_TRY(migrate_tracers(ctx, S, z0, hz, x0, hx));
     if (cfg->tracdens_min > 0 && cfg->tracdens > 0) PL_TRY(inject_tracers(ctx, S, cfg, it, z0, hz, x0, hx, &rep->ninjected));
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));

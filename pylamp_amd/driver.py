@@ -37,6 +37,10 @@ class Options:
         self.stokes_rtol, self.stokes_maxit = 1e-10, 400
         self.heat_rtol, self.heat_maxit = 1e-12, 2000
         self.tracdens, self.tracdens_min, self.inject_seed = 0, 0, 12345     # pylamp2.py:39-40; 0 = no injection
+        # False: the reference's ID rule for injected tracers (first new ID of every refilled cell repeats the last one
+        # handed out, pylamp2.py:621-622); True: unique IDs
+        self.inject_unique_ids = False
+        self.tracs_fence_enabled = True                                      # pylamp2.py:41; False: leavers are deleted
         self.surface_stabilization, self.surfstab_theta, self.surfstab_tstep = False, 0.5, -1.0   # pylamp2.py:71-73
         # False: corrected (damping) sign of the stabilisation terms, see pylamp_stokes.makeStokesMatrix
         self.surfstab_strict_reference = True
@@ -191,6 +195,7 @@ class Simulation:
         c.surface_stabilization = int(bool(o.surface_stabilization))
         theta = float(o.surfstab_theta)
         c.surfstab_theta, c.surfstab_tstep = (theta if o.surfstab_strict_reference else -theta), float(o.surfstab_tstep)
+        c.inject_unique_ids = int(bool(o.inject_unique_ids)); c.tracs_fence_disabled = int(not o.tracs_fence_enabled)
         return c
 
     def step(self):
@@ -202,6 +207,7 @@ class Simulation:
         self.ctx.check(self.ctx.lib.pl_step(self.ctx.handle(), C.byref(cfg), self.it, C.byref(rep)))
         self.totaltime += rep.tstep
         self.ntrac = rep.ntrac
+        self.n_before_injection = rep.ntrac - rep.ninjected
         out = {k: getattr(rep, k) for k, _ in rep._fields_ if k not in ("stokes", "heat", "limiter")}
         out["limiter"] = "Ss" if chr(rep.limiter) == "s" else chr(rep.limiter)
         out["stokes"] = rep.stokes.as_dict(); out["heat"] = rep.heat.as_dict()
@@ -220,6 +226,10 @@ class Simulation:
                 return
         else:
             tr_x, tr_f = self.tracers(); tr_v = self.tracer_velocity()
+            # the stock snapshot holds the state BEFORE this step's injection (prev_tr_x / prev_tr_f, pylamp2.py:599-600);
+            # injected tracers are appended behind the resident ones
+            k = getattr(self, "n_before_injection", tr_x.shape[0])
+            tr_x, tr_f, tr_v = tr_x[:k], tr_f[:k], tr_v[:k]
         os.makedirs(outdir, exist_ok=True)
         np.savez(os.path.join(outdir, "griddata.{:06d}.npz".format(self.it)), gridz=self.grid[IZ], gridx=self.grid[IX],
                  velz=velz, velx=velx, pres=pres, rho=rho, temp=temp, tstep=self.it, time=self.totaltime)

@@ -67,6 +67,81 @@ def test_step_vs_oracle_midsize(oracle):
     sim.close()
 
 
+def _cells(X, nx, L):
+    ci = np.floor((nx[0] - 1) * X[:, 0] / L[0]).astype(int); cj = np.floor((nx[1] - 1) * X[:, 1] / L[1]).astype(int)
+    return ci * (nx[1] - 1) + cj
+
+
+@pytest.mark.parametrize("name,heat,dens,dmin", [("traj_inject41", False, 12, 9), ("traj_inject_mantle25x33", True, 14, 10)])
+def test_census_and_injection_vs_reference_driver(name, heat, dens, dmin):
+    """pylamp2.py:588-633 against the stock driver run with tracdens_min > 0 (oracle/gen_golden.py, state captured
+    after the injection).  Everything but the random positions is compared: number injected, which cells are
+    refilled and by how many, append order, the reference's ID rule, the cell-mean fields, the census afterwards.
+    The positions come from a different generator, so every step starts from the reference's post-injection state
+    of the step before (block model; the heat model compares its first step)."""
+    from pylamp_amd import driver
+    g = golden(name)
+    gz, gx = g["gz"], g["gx"]
+    nx = [gz.size, gx.size]; L = [gz[-1], gx[-1]]
+    opt = driver.Options(do_heatdiff=heat, tdep_rho=heat, tdep_eta=heat, tracdens=dens, tracdens_min=dmin)
+    start_x, start_f = g["init_tr_x"], g["init_tr_f"]
+    total = 0
+    for it in range(1, (1 if heat else int(g["nsteps"])) + 1):
+        sim = driver.Simulation(nx, L, start_x, start_f, opt)
+        rep = sim.step()
+        p, q = "s%d_" % it, "p%d_" % it
+        ref_x, ref_f = g[q + "tr_x"], g[q + "tr_f"]
+        n_old = g[p + "tr_x"].shape[0]
+        assert rep["stokes"]["converged"] == 1
+        assert relerr(sim.field("velz"), g[p + "velz"]) < 1e-6 and relerr(sim.field("velx"), g[p + "velx"]) < 1e-6
+        assert rep["ninjected"] == ref_x.shape[0] - n_old and rep["ntrac"] == ref_x.shape[0] and rep["nremoved"] == 0
+        total += rep["ninjected"]
+        X, F = sim.tracers()
+        assert relerr(X[:n_old], ref_x[:n_old]) < 1e-7                           # resident tracers: the advection
+        assert np.allclose(F[:n_old], ref_f[:n_old], rtol=1e-6, atol=0)
+        # injected tracers: appended in the reference's order (ascending cell number), same cells, same IDs
+        assert np.array_equal(_cells(X[n_old:], nx, L), _cells(ref_x[n_old:], nx, L))
+        assert np.array_equal(F[n_old:, 12], ref_f[n_old:, 12])
+        ids = F[n_old:, 12]
+        assert ids.size - np.unique(ids).size == np.unique(_cells(ref_x[n_old:], nx, L)).size - 1   # one repeat per cell
+        cols = [c for c in range(13) if c != 12]
+        assert np.allclose(F[n_old:][:, cols], ref_f[n_old:][:, cols], rtol=1e-6, atol=0, equal_nan=True)
+        cen = sim.census().ravel()
+        assert np.array_equal(cen, np.bincount(_cells(ref_x, nx, L), minlength=cen.size))
+        assert cen.min() >= dmin
+        # the snapshot holds the pre-injection state, like the reference's (pylamp2.py:599-600,648)
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            sim.write_snapshot(td)
+            tc = np.load(os.path.join(td, "tracs.%06d.npz" % sim.it))
+            assert tc["tr_x"].shape[0] == n_old and np.array_equal(tc["tr_f"][:, 12], g[p + "tr_id"])
+        sim.close()
+        start_x, start_f = ref_x, ref_f
+    assert total > 100
+
+
+def test_deletion_vs_reference_driver():
+    """pylamp2.py:563-581 with the fence off: 70 tracers start beyond the low walls, get TR__ID = -1 after the first
+    advection and are deleted; the survivors keep their order.  Two steps against the stock driver."""
+    from pylamp_amd import driver
+    g = golden("traj_delete41")
+    gz, gx = g["gz"], g["gx"]
+    nx = [gz.size, gx.size]; L = [gz[-1], gx[-1]]
+    opt = driver.Options(do_heatdiff=False, tdep_rho=False, tdep_eta=False, tracs_fence_enabled=False)
+    sim = driver.Simulation(nx, L, g["init_tr_x"], g["init_tr_f"], opt)
+    n0 = g["init_tr_x"].shape[0]
+    for it, nrem in ((1, 70), (2, 0)):
+        rep = sim.step()
+        p = "s%d_" % it
+        assert rep["stokes"]["converged"] == 1 and rep["nremoved"] == nrem and rep["ntrac"] == n0 - 70
+        assert relerr(sim.field("velz"), g[p + "velz"]) < 1e-6 and relerr(sim.field("velx"), g[p + "velx"]) < 1e-6
+        X, F = sim.tracers()
+        assert X.shape == g[p + "tr_x"].shape and np.array_equal(F[:, 12], g[p + "tr_id"])       # order kept
+        assert relerr(X, g[p + "tr_x"]) < 1e-7
+        assert relerr(sim.tracer_velocity(), g[p + "tr_v"]) < 1e-5
+    sim.close()
+
+
 @pytest.mark.parametrize("graded", [False, True])
 def test_census_and_injection(graded):
     """Cells that fall below tracdens_min are refilled to tracdens with tracers carrying the cell
@@ -91,7 +166,8 @@ def test_census_and_injection(graded):
     keep = ~patch | first
     tr_x, tr_f = tr_x[keep], tr_f[keep]
     n0 = tr_x.shape[0]
-    opt = driver.Options(do_heatdiff=False, tdep_rho=False, tdep_eta=False, tracdens=8, tracdens_min=3)
+    opt = driver.Options(do_heatdiff=False, tdep_rho=False, tdep_eta=False, tracdens=8, tracdens_min=3,
+                         inject_unique_ids=True)
     sim = driver.Simulation(nx, L, tr_x, tr_f, opt, grid=grid if graded else None)
     rep = sim.step()
     assert rep["ninjected"] > 0 and rep["ntrac"] == n0 + rep["ninjected"]

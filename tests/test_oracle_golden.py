@@ -200,6 +200,68 @@ def test_trajectory_surface_stabilisation(oracle):
         assert relerr(st["tr_x"], g[p + "tr_x"]) < 1e-10
 
 
+@pytest.mark.parametrize("name,heat,dens,dmin,seed", [("traj_inject41", False, 12, 9, 14),
+                                                       ("traj_inject_mantle25x33", True, 14, 10, 15)])
+def test_trajectory_with_census_and_injection(oracle, name, heat, dens, dmin, seed):
+    """pylamp2.py:588-633 pinned to the reference: the stock driver run with tracdens_min > 0 (seeded legacy
+    np.random stream), state captured after the injection of every step.  The oracle, fed the same stream,
+    reproduces it entirely: which cells are refilled, how many tracers each receives, their random positions,
+    the cell-mean fields and the reference's ID rule (first new ID of a cell repeats the last one handed out)."""
+    g = golden(name)
+    gz, gx = g["gz"], g["gx"]
+    nx = [gz.size, gx.size]; L = [gz[-1], gx[-1]]
+    np.random.seed(seed)
+    x0 = np.random.rand(g["init_tr_x"].shape[0], 2)              # the driver's own first draw (pylamp2.py:119)
+    assert np.array_equal(np.multiply(x0, L), g["init_tr_x"])
+    st = dict(nx=nx, L=L, grid=[gz, gx], tr_x=g["init_tr_x"].copy(), tr_f=g["init_tr_f"].copy())
+    cfg = oracle.StepConfig(do_heatdiff=heat, tdep_rho=heat, tdep_eta=heat, tracdens=dens, tracdens_min=dmin)
+    ninj = 0
+    for it in range(1, int(g["nsteps"]) + 1):
+        out = oracle.step(st, cfg, it)
+        p = "s%d_" % it
+        assert relerr(out["velz"], g[p + "velz"]) < 1e-7 and relerr(out["velx"], g[p + "velx"]) < 1e-7
+        assert out["snap_tr_x"].shape == g[p + "tr_x"].shape                      # the snapshot is pre-injection
+        assert relerr(out["snap_tr_x"], g[p + "tr_x"]) < 1e-10
+        assert np.array_equal(out["snap_tr_f"][:, oracle.TR__ID], g[p + "tr_id"])
+        q = "p%d_" % it
+        assert st["tr_x"].shape == g[q + "tr_x"].shape
+        n_old = out["snap_tr_x"].shape[0]
+        assert out["inject"]["n_injected"] == st["tr_x"].shape[0] - n_old
+        ninj += out["inject"]["n_injected"]
+        assert np.array_equal(st["tr_f"][:, oracle.TR__ID], g[q + "tr_f"][:, oracle.TR__ID])
+        assert np.array_equal(st["tr_x"][n_old:], g[q + "tr_x"][n_old:])          # same random stream, same cells
+        assert relerr(st["tr_x"][:n_old], g[q + "tr_x"][:n_old]) < 1e-10
+        assert np.allclose(st["tr_f"], g[q + "tr_f"], rtol=1e-9, atol=0, equal_nan=True)
+        # the census after the refill: no cell below the minimum, refilled cells hold exactly tracdens
+        _, _, cnt = oracle.census(st["tr_x"], nx, L)
+        assert cnt.min() >= dmin and np.all(cnt[out["inject"]["cells"]] == dens)
+        # the ID rule: every refilled cell repeats one ID (pylamp2.py:621-622)
+        ids = st["tr_f"][n_old:, oracle.TR__ID]
+        assert ids.size - np.unique(ids).size == max(out["inject"]["cells"].size - 1, 0)
+    assert ninj > 100
+
+
+def test_trajectory_with_deletion(oracle):
+    """pylamp2.py:574-581 pinned to the reference: fence off, 70 tracers start beyond the low walls, receive
+    TR__ID = -1 after the first advection and are deleted from tr_x / tr_f / trac_vel."""
+    g = golden("traj_delete41")
+    gz, gx = g["gz"], g["gx"]
+    nx = [gz.size, gx.size]; L = [gz[-1], gx[-1]]
+    st = dict(nx=nx, L=L, grid=[gz, gx], tr_x=g["init_tr_x"].copy(), tr_f=g["init_tr_f"].copy())
+    cfg = oracle.StepConfig(do_heatdiff=False, tdep_rho=False, tdep_eta=False, tracs_fence_enabled=False)
+    n0 = st["tr_x"].shape[0]
+    removed = []
+    for it in (1, 2):
+        out = oracle.step(st, cfg, it)
+        removed.append(out["n_removed"])
+        p = "s%d_" % it
+        assert relerr(out["velz"], g[p + "velz"]) < 1e-7 and relerr(out["velx"], g[p + "velx"]) < 1e-7
+        assert st["tr_x"].shape == g[p + "tr_x"].shape and relerr(st["tr_x"], g[p + "tr_x"]) < 1e-10
+        assert np.array_equal(st["tr_f"][:, oracle.TR__ID], g[p + "tr_id"])
+        assert relerr(out["tr_v"], g[p + "tr_v"]) < 1e-6
+    assert removed == [70, 0] and st["tr_x"].shape[0] == n0 - 70
+
+
 def test_rect_search_equals_regular_formula_on_uniform_grids(oracle):
     """the per-axis search mode of the oracle (defined here, the reference has none) must reproduce
     the reference wherever the reference is defined, i.e. on its own uniform-grid fixtures."""
