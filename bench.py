@@ -35,7 +35,9 @@ def build_sim(n, tracdens, seed, device, rank, world, scaling):
         nx = [(n - 1) * world + 1, n]; L = [660e3 * world, 660e3]
     else:
         nx = [n, n]; L = [660e3, 660e3]
-    sim = driver.Simulation(nx, L, options=driver.Options(), device=device)
+    # census + injection inside the timed step, like the reference (pylamp2.py:39-40,588-633; its stock values are
+    # 45 / 25): cells below 9 markers are refilled to 16
+    sim = driver.Simulation(nx, L, options=driver.Options(tracdens=tracdens, tracdens_min=(tracdens * 9) // 16), device=device)
     rng = np.random.default_rng(seed + rank)
     lo, hi = sim.slab()
     per_rank = nx[0] * nx[1] * tracdens // max(world, 1)
@@ -45,43 +47,90 @@ def build_sim(n, tracdens, seed, device, rank, world, scaling):
     return sim
 
 
+def _apply_point(ctx, nodes, reps, traffic):
+    """HIP-event timing of the resident Stokes stencil on this context: the row-scaled variant the Krylov solver
+    launches and the plain operator; algorithmic bytes = 64 B/node (x 24 + etas 8 + etan 8 + y 24)."""
+    ms = C.c_double()
+    out = {}
+    for name, fn in (("scaled", ctx.lib.pl_stokes_apply_scaled_bench), ("plain", ctx.lib.pl_stokes_apply_bench)):
+        vals = []
+        for _ in range(3):
+            ctx.check(fn(ctx.h, reps, C.byref(ms)))
+            vals.append(ms.value)
+        avg = vals[-1]                                  # the LAST average is the reported one, the best is informative
+        ach = 64.0 * nodes / (avg * 1e-3) / 1e9
+        out[name] = {"achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4), "avg_launch_ms": round(avg, 5),
+                     "best_launch_ms": round(min(vals), 5), "traffic": traffic.get(name)}
+    return out
+
+
 def kernel_roofline(sim, reps):
-    """Average duration of the Stokes stencil apply on the resident operator (HIP events)."""
+    """`roofline` of the bench line: the dominant north-star kernel is the matrix-free Stokes stencil.  The figure
+    reported at the top level is the ROW-SCALED variant (k_stokes_apply_v2<R, true>) -- the one BiCGStab launches twice
+    per iteration -- on the bench grid; the plain operator, the 4097^2 point (working set 1.07 GB >> the 256 MiB
+    Infinity Cache, so no replay is cache-served), the measured stream triad of this box and the multigrid smoother
+    follow as sub-objects.  `traffic` = PMC bytes per launch from profiles/traffic.json (tools/make_traffic.py)."""
+    from pylamp_amd import pylamp_stokes as S
     ctx = sim.ctx
     ms = C.c_double()
-    best = None
-    for _ in range(3):
-        ctx.check(ctx.lib.pl_stokes_apply_bench(ctx.h, reps, C.byref(ms)))
-        best = ms.value if best is None else min(best, ms.value)
-    avg_ms = ms.value                       # report the LAST average (not the best) as the measured value
     first, count = ctx.local_rows()
     n = count * sim.nx[1]                   # nodes of this rank's slab (the whole grid on one GPU)
-    alg_bytes = 64.0 * n                    # x 24 + etas 8 + etan 8 + y 24 B per node (SURVEY 8d)
-    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-    traffic = None; tj = {}
+    tj = {}
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tf):
         try:
             tj = json.load(open(tf))
-            traffic = tj.get("k_stokes_apply", {}).get(str(sim.nx[1]) if abs(count - sim.nx[1]) <= 1 else "-")
         except Exception:
-            traffic = None
-    # the kernel with the largest share of the step: one Chebyshev sweep of the finest multigrid level
+            tj = {}
+    whole = abs(count - sim.nx[0]) <= 1
+
+    def tr(kernel, size):
+        return tj.get(kernel, {}).get(str(size)) if whole else None
+    here = _apply_point(ctx, n, reps, {"scaled": tr("k_stokes_apply_scaled", sim.nx[1]), "plain": tr("k_stokes_apply", sim.nx[1])})
+    # measured stream triad (3 x 1 GiB arrays)
+    triad = None
+    try:
+        nt = 1 << 27
+        ctx.check(ctx.lib.pl_stream_triad_bench(ctx.h, nt, 20, C.byref(ms)))
+        triad = 24.0 * nt / (ms.value * 1e-3) / 1e9
+    except Exception:
+        triad = None
+    # the smoother: one Chebyshev sweep of the finest multigrid level (largest share of a step)
     sweep = None
     try:
         ctx.check(ctx.lib.pl_stokes_sweep_bench(ctx.h, reps, C.byref(ms)))
         sb = 80.0 * n                       # v 16 + v_prev 16 + f 16 + etas 8 + etan 8 + write 16 B per node
         sweep = {"kernel": "k_vv_sweep2<0> (Chebyshev sweep, finest level)", "bound": "hbm",
                  "achieved": round(sb / (ms.value * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                 "frac": round(sb / (ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                 "traffic": tj.get("k_vv_sweep2_cheb", {}).get(str(sim.nx[1]) if abs(count - sim.nx[1]) <= 1 else "-"),
+                 "frac": round(sb / (ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": tr("k_vv_sweep2_cheb", sim.nx[1]),
                  "algorithmic_bytes_per_launch": sb, "avg_launch_ms": round(ms.value, 5), "launches_timed": reps}
     except Exception:
         sweep = None
-    return {"kernel": "k_stokes_apply", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 5),
-            "best_launch_ms": round(best, 5), "launches_timed": reps, "smoother": sweep}
+    # the same stencil at 4097^2 on a second context (one GPU only: HBM-honest point)
+    big = None
+    if whole and not os.environ.get("PYLAMP_BENCH_NO_4097"):
+        try:
+            nb = 4097
+            rng = np.random.default_rng(1)
+            g = [np.linspace(0, 660e3, nb), np.linspace(0, 660e3, nb)]
+            es = 1e19 * 10 ** rng.uniform(0, 3, (nb, nb)); en = 1e19 * 10 ** rng.uniform(0, 3, (nb, nb))
+            A, _ = S.makeStokesMatrix([nb, nb], g, es, en, 3300 + rng.uniform(-50, 50, (nb, nb)), [1, 1, 1, 1])
+            big = _apply_point(A._ctx, nb * nb, max(reps // 2, 10), {"scaled": tr("k_stokes_apply_scaled", nb), "plain": tr("k_stokes_apply", nb)})
+            big["algorithmic_bytes_per_launch"] = 64.0 * nb * nb
+            del A
+            from pylamp_amd import _context
+            _context.clear_contexts()
+        except Exception as e:
+            big = {"error": repr(e)}
+    top = here["scaled"]
+    out = {"kernel": "k_stokes_apply_v2<R,true> (row-scaled stencil, the in-solver variant)", "bound": "hbm",
+           "achieved": top["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": top["frac"], "traffic": top["traffic"],
+           "algorithmic_bytes_per_launch": 64.0 * n, "avg_launch_ms": top["avg_launch_ms"], "best_launch_ms": top["best_launch_ms"],
+           "launches_timed": reps, "plain_operator": here["plain"], "at_4097": big,
+           "triad_GBps": None if triad is None else round(triad, 1),
+           "frac_of_triad": None if not triad else round(top["achieved"] / triad, 4),
+           "traffic_commit": tj.get("_commit"), "smoother": sweep}
+    return out
 
 
 def cpu_baseline(n=257, tracdens=16, steps=1):
@@ -127,6 +176,7 @@ def main():
         import torch.distributed as dist
         backend = os.environ.get("PYLAMP_DIST_BACKEND", "nccl")     # "gloo": several ranks sharing one GPU (tests)
         if backend == "nccl":
+            os.environ.setdefault("PYLAMP_RCCL", "1")               # native RCCL transport (self-tested at start-up, falls back)
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -197,6 +247,7 @@ def main():
             "stokes_rel_residual": [float("%.3g" % r["stokes"]["rel_residual"]) for r in timed],
             "stokes_converged": [r["stokes"]["converged"] for r in timed],
             "heat_iterations": [r["heat"]["iterations"] for r in timed],
+            "tracers_injected": [int(r["ninjected"]) for r in timed],
             "roofline": roof,
         }
         if world > 1:       # communication calls of rank 0 per timed step (halo exchanges, all-gathers, device / host all-reduces)

@@ -127,6 +127,10 @@ int  pl_stokes_solve(pl_ctx* ctx, const double* rhs, double* x, int use_x0, doub
 /* Times `reps` back-to-back applies of the device-resident operator on device-resident
  * vectors with HIP events (no host transfers); returns average ms per apply. */
 int  pl_stokes_apply_bench(pl_ctx* ctx, int reps, double* avg_ms);
+/* the same for the row-scaled operator y = D_r A x, the variant the Krylov solver launches */
+int  pl_stokes_apply_scaled_bench(pl_ctx* ctx, int reps, double* avg_ms);
+/* stream triad a = b + s c on three device arrays of n doubles (24 n bytes per launch): measured HBM rate of the box */
+int  pl_stream_triad_bench(pl_ctx* ctx, int64_t n, int reps, double* avg_ms);
 
 /* Diagnostics for component tests of the solver: z = M^-1 r for an UNSCALED residual r in
  * the reference DOF order (builds the multigrid hierarchy for the current coefficients; the
@@ -237,6 +241,12 @@ int  pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_report* rep
 int  pl_get_field(pl_ctx* ctx, const char* name, double* out);
 /* Velocity of the last advection, (n,2) like trac_vel (pylamp2.py:547-555). */
 int  pl_get_tracer_velocity(pl_ctx* ctx, int64_t n, double* out);
+
+/* sizeof / offsetof of the structs above as compiled into the library: out = { sizeof(pl_solve_stats),
+ * sizeof(pl_step_config), sizeof(pl_step_report), offsetof(config.length), offsetof(config.inject_seed),
+ * offsetof(config.tracs_fence_disabled), offsetof(report.ntrac), offsetof(report.nremoved) } -- lets a binding
+ * verify its mirror of the layout (tests/test_cabi.py). */
+int  pl_abi_layout(size_t out[8]);
 
 #ifdef __cplusplus
 }

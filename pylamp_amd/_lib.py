@@ -50,6 +50,7 @@ SIGNATURES = {
     "pl_destroy": (None, [C.c_void_p]),
     "pl_last_error": (C.c_char_p, [C.c_void_p]),
     "pl_sync": (C.c_int, [C.c_void_p]),
+    "pl_abi_layout": (C.c_int, [C.POINTER(C.c_size_t)]),
     "pl_device_info": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, c_int_p, C.POINTER(C.c_size_t)]),
     "pl_set_comm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "pl_local_rows": (C.c_int, [C.c_void_p, c_int_p, c_int_p]),
@@ -68,6 +69,8 @@ SIGNATURES = {
     "pl_stokes_solve": (C.c_int, [C.c_void_p, c_double_p, c_double_p, C.c_int, C.c_double, C.c_int,
                                   C.POINTER(SolveStats)]),
     "pl_stokes_apply_bench": (C.c_int, [C.c_void_p, C.c_int, c_double_p]),
+    "pl_stokes_apply_scaled_bench": (C.c_int, [C.c_void_p, C.c_int, c_double_p]),
+    "pl_stream_triad_bench": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, c_double_p]),
     "pl_stokes_precond_apply": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     "pl_stokes_mg_info": (C.c_int, [C.c_void_p, c_int_p, c_double_p, C.c_int]),
     "pl_stokes_sweep_bench": (C.c_int, [C.c_void_p, C.c_int, c_double_p]),

@@ -2,6 +2,7 @@
 #include "pl_internal.h"
 #include <cmath>
 #include <cstdlib>
+#include <cstddef>
 
 thread_local std::string pl_tls_error;
 
@@ -210,6 +211,15 @@ extern "C" void pl_destroy(pl_ctx* ctx) {
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+// sizes and a few field offsets of the ABI structs as THIS build sees them (the ctypes mirror is checked against it)
+extern "C" int pl_abi_layout(size_t out[8]) {
+    out[0] = sizeof(pl_solve_stats); out[1] = sizeof(pl_step_config); out[2] = sizeof(pl_step_report);
+    out[3] = offsetof(pl_step_config, length); out[4] = offsetof(pl_step_config, inject_seed);
+    out[5] = offsetof(pl_step_config, tracs_fence_disabled); out[6] = offsetof(pl_step_report, ntrac);
+    out[7] = offsetof(pl_step_report, nremoved);
+    return 0;
 }
 
 extern "C" int pl_sync(pl_ctx* ctx) {

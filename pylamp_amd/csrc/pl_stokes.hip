@@ -483,7 +483,7 @@ __global__ void k_fill_pseudo(double* __restrict__ v, long long n, unsigned seed
     }
 }
 
-extern "C" int pl_stokes_apply_bench(pl_ctx* ctx, int reps, double* avg_ms) {
+static int apply_bench(pl_ctx* ctx, int scaled, int reps, double* avg_ms) {
     if (!ctx->sop_ready) return pl_fail(ctx, "stokes operator not set");
     if (reps < 1) reps = 1;
     PL_HIP(ctx, hipSetDevice(ctx->device));
@@ -492,9 +492,44 @@ extern "C" int pl_stokes_apply_bench(pl_ctx* ctx, int reps, double* avg_ms) {
     double *dx, *dy;
     PL_TRY(pl_buf(ctx, "api_x", vb, &dx)); PL_TRY(pl_buf(ctx, "api_y", vb, &dy));
     hipLaunchKernelGGL(k_fill_pseudo, dim3(2048), dim3(256), 0, ctx->stream, dx, 3 * g.plane, 12345u);
-    pl_launch_stokes_apply(ctx, ctx->sop, dx, dy);      // warm-up
+    PlStokesOp op = ctx->sop; op.scaled = scaled ? 1 : 0;
+    pl_launch_stokes_apply(ctx, op, dx, dy);      // warm-up
     PL_TRY(pl_timer_start(ctx));
-    for (int r = 0; r < reps; r++) pl_launch_stokes_apply(ctx, ctx->sop, dx, dy);
+    for (int r = 0; r < reps; r++) pl_launch_stokes_apply(ctx, op, dx, dy);
+    double ms = 0;
+    PL_TRY(pl_timer_stop_ms(ctx, &ms));
+    PL_HIP(ctx, hipGetLastError());
+    if (avg_ms) *avg_ms = ms / reps;
+    return 0;
+}
+extern "C" int pl_stokes_apply_bench(pl_ctx* ctx, int reps, double* avg_ms) { return apply_bench(ctx, 0, reps, avg_ms); }
+// the row-scaled variant y = D_r A x, the one the Krylov solver launches
+extern "C" int pl_stokes_apply_scaled_bench(pl_ctx* ctx, int reps, double* avg_ms) { return apply_bench(ctx, 1, reps, avg_ms); }
+
+// Stream triad a = b + s c on three arrays of n doubles (24 n bytes per launch, 16 B per lane): the measured HBM rate of
+// this box, against which the roofline fractions are reported next to the datasheet peak.
+__global__ __launch_bounds__(256) void k_triad(long long n2, double2* __restrict__ a, const double2* __restrict__ b,
+                                               const double2* __restrict__ c, double s) {
+    long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; k < n2; k += (long long)gridDim.x * blockDim.x) {
+        const double2 u = b[k], v = c[k];
+        a[k] = make_double2(u.x + s * v.x, u.y + s * v.y);
+    }
+}
+extern "C" int pl_stream_triad_bench(pl_ctx* ctx, int64_t n, int reps, double* avg_ms) {
+    if (n < 1024 || reps < 1) return pl_fail(ctx, "pl_stream_triad_bench: bad argument");
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    n &= ~(int64_t)1;
+    double* buf;
+    PL_TRY(pl_buf(ctx, "triad", (size_t)3 * n * sizeof(double), &buf, false));
+    hipLaunchKernelGGL(k_fill_pseudo, dim3(2048), dim3(256), 0, ctx->stream, buf, 3 * n, 777u);
+    auto launch = [&]() {
+        hipLaunchKernelGGL(k_triad, dim3(8192), dim3(256), 0, ctx->stream, (long long)(n / 2), (double2*)buf, (const double2*)(buf + n),
+                           (const double2*)(buf + 2 * n), 0.5);
+    };
+    launch();
+    PL_TRY(pl_timer_start(ctx));
+    for (int r = 0; r < reps; r++) launch();
     double ms = 0;
     PL_TRY(pl_timer_stop_ms(ctx, &ms));
     PL_HIP(ctx, hipGetLastError());

@@ -1,0 +1,69 @@
+"""profiles/traffic.json + a per-kernel summary CSV from two rocprofv3 PMC passes over tools/pmc_run.py:
+
+    python tools/make_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <round-tag>
+
+FETCH_SIZE / WRITE_SIZE are reported in KiB per dispatch.  On gfx950 FETCH_SIZE counts a wide coalesced read at half
+its bytes (MI355X_MICROARCH.md, HBM section): it is doubled here, and the factor is CHECKED on the stream triad of the
+same run (2 GiB read, 1 GiB written per launch).  Kernels are keyed by name and by the grid side derived from the launch
+size, bytes per launch = median over the dispatches of that key.  The commit of the build is recorded."""
+import csv, json, os, re, subprocess, sys, collections
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+fetch_csv, write_csv, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+
+
+def load(path, counter):
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        name = re.sub(r"^void ", "", r["Kernel_Name"]).split("(")[0].strip()
+        d[(name, int(r["Grid_Size"]))].append(float(r["Counter_Value"]) * 1024.0)
+    return {k: float(np.median(v)) for k, v in d.items()}, {k: len(v) for k, v in d.items()}
+
+
+F, nF = load(fetch_csv, "FETCH_SIZE")
+W, nW = load(write_csv, "WRITE_SIZE")
+# calibration on the triad
+tri = [k for k in F if k[0].startswith("k_triad")]
+calib = None
+if tri:
+    k = tri[0]
+    calib = {"fetch_raw_bytes": F[k], "expected_read_bytes": 2.0 * (1 << 30), "fetch_factor": 2.0 * (1 << 30) / F[k],
+             "write_bytes": W.get(k), "expected_write_bytes": 1.0 * (1 << 30)}
+factor = 2.0
+
+
+def side(name, grid):
+    """grid side n for the 2-columns-per-lane kernels: launches are ((n+127)/128 * 64) x rows threads"""
+    for n in (2049, 4097, 1025, 513):
+        gx = (n + 127) // 128 * 64
+        if grid % gx == 0 and abs(grid // gx - n) <= 16:
+            return n
+    return None
+
+
+out = {"_provenance": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on tools/pmc_run.py, MI355X, %s; FETCH_SIZE "
+                      "doubled per MI355X_MICROARCH.md; bytes per launch (median over dispatches), Infinity-Cache hits included" % tag,
+       "_commit": subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip(),
+       "_triad_calibration": calib}
+names = {"k_stokes_apply_v2<4, true>": "k_stokes_apply_scaled", "k_stokes_apply_v2<16, true>": "k_stokes_apply_scaled",
+         "k_stokes_apply_v2<4, false>": "k_stokes_apply", "k_stokes_apply_v2<16, false>": "k_stokes_apply",
+         "k_vv_sweep2<0>": "k_vv_sweep2_cheb", "k_vv_sweep2<1>": "k_vv_sweep2_residual", "k_prec_stage1_v2": "k_prec_stage1_v2",
+         "k_vv_first2": "k_vv_first2"}
+rows = []
+for (name, grid), fb in sorted(F.items()):
+    wb = W.get((name, grid), 0.0)
+    rows.append((name, grid, nF[(name, grid)], fb * factor, wb))
+    key = names.get(name)
+    n = side(name, grid)
+    if key and n:
+        out.setdefault(key, {})[str(n)] = int(round(fb * factor + wb))
+        out.setdefault(key + "_split", {})[str(n)] = {"fetch": int(round(fb * factor)), "write": int(round(wb))}
+json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+with open(os.path.join(ROOT, "profiles", "%s_pmc_summary.csv" % tag), "w") as f:
+    f.write("kernel,grid_size,dispatches,fetch_bytes_x2,write_bytes\n")
+    for r in rows:
+        f.write("%s,%d,%d,%.0f,%.0f\n" % (r[0].replace(",", ";"), r[1], r[2], r[3], r[4]))
+print(json.dumps(out, indent=1))
