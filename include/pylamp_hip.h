@@ -59,36 +59,45 @@ const char* pl_last_error(const pl_ctx* ctx);   /* ctx may be NULL: error of a f
 int  pl_sync(pl_ctx* ctx);                      /* hipStreamSynchronize on the context stream */
 int  pl_device_info(pl_ctx* ctx, char* name, size_t name_len, int* cu_count, size_t* hbm_bytes);
 
-/* ---- multi-GPU: one context per rank, 1-D slab decomposition of the node ROWS (z) -------------
+/* ---- multi-GPU: one context per rank, 2-D block decomposition of the node grid ---------------------------------
  * The reference only strides tracers over MPI ranks and replicates every grid array
- * (pylamp2.py:30-32,445-455,550-555); here the grid itself is decomposed.  Rank r owns node rows
- * [r*C, (r+1)*C) with C = (nz-1)/nranks (the last rank also owns row nz-1); (nz-1) must be
- * divisible by nranks*2^k for the k distributed multigrid levels.  Communication is delegated to
- * the host program (torch.distributed over RCCL in pylamp_amd/parallel.py) through this table;
- * every callback returns 0 on success and must have completed when it returns.
- * Device pointers are plain HIP allocations of this context's device. */
+ * (pylamp2.py:30-32,445-455,550-555); here the grid itself is decomposed into Pz x Px blocks (1x2, 2x2, 2x4 ...).
+ * Rank r = pz * Px + px owns node rows [pz*Cz, (pz+1)*Cz) and columns [px*Cx, (px+1)*Cx), Cz = (nz-1)/Pz,
+ * Cx = (nx-1)/Px (the last block of an axis also owns the last node row / column); (nz-1) and (nx-1) must be
+ * divisible by Pz resp. Px, with even quotients >= 8.  Every plane carries a halo ring filled from the (up to 8)
+ * neighbour blocks, corners included (the momentum stencils reach (i-1,j+1) and (i+1,j-1)).
+ * Transports: (a) direct RCCL calls on the context stream (opt-in, PYLAMP_RCCL=1, self-tested at start-up);
+ * (b) this callback table into the host program (torch.distributed in pylamp_amd/parallel.py); (c) an in-process
+ * group of "virtual ranks" sharing one GPU, one host thread per context (pl_local_group_*; tests and rehearsals).
+ * Every callback returns 0 on success and must have completed when it returns.  Device pointers are plain HIP
+ * allocations of this context's device. */
 typedef struct pl_comm_ops {
-    /* Neighbour exchange of nseg segments of `count` doubles, segment k at base + k*stride:
-     * send send_lo[] to rank-1 and receive recv_lo[] from it; send send_hi[] to rank+1 and receive
-     * recv_hi[] from it.  A missing neighbour (rank 0 / last rank) is skipped. add != 0: the
-     * received data is ADDED to recv (reverse halo of scatter accumulators). */
-    int (*exchange)(void* user, const double* send_lo, double* recv_lo, const double* send_hi, double* recv_hi,
-                    int64_t count, int nseg, int64_t stride, int add);
+    /* nmsg point-to-point messages: message k sends nsend[k] doubles at send[k] to rank peer[k] and receives nrecv[k]
+     * doubles into recv[k] from it (either count may be 0).  Messages between the same pair of ranks are matched in
+     * list order; both sides list them in the same order. */
+    int (*sendrecv)(void* user, int nmsg, const int* peer, const double* const* send, const int64_t* nsend,
+                    double* const* recv, const int64_t* nrecv);
     /* In-place all-reduce of n doubles in HOST memory; op: 0 sum, 1 min, 2 max. */
     int (*allreduce_host)(void* user, double* buf, int64_t n, int op);
-    /* All-gather of nseg segments: rank r contributes count doubles at recv + r*count (+ k*stride). */
-    int (*allgather)(void* user, double* recv, int64_t count, int nseg, int64_t stride);
-    /* Variable-size neighbour exchange of tracer columns: send n_lo (n_hi) doubles of each of ncol
-     * columns starting at send_lo[k] (send_hi[k]); received columns are appended at recv[k];
-     * *got returns the number of doubles received per column (from both neighbours together). */
-    int (*exchange_var)(void* user, double* const* send_lo, int64_t n_lo, double* const* send_hi, int64_t n_hi,
-                        double* const* recv, int64_t recv_capacity, int ncol, int64_t* got);
+    /* All-gather: every rank contributes count doubles at send; recv receives nranks*count (rank r at r*count). */
+    int (*allgather)(void* user, const double* send, double* recv, int64_t count);
     void* user;
 } pl_comm_ops;
-int  pl_set_comm(pl_ctx* ctx, int rank, int nranks, const pl_comm_ops* ops);   /* right after pl_create */
+/* Right after pl_create.  Pz * Px must equal nranks; pl_set_comm chooses the layout itself: PYLAMP_DECOMP="PzxPx",
+ * otherwise the most square one with Px >= Pz (2 -> 1x2, 4 -> 2x2, 8 -> 2x4). */
+int  pl_set_comm(pl_ctx* ctx, int rank, int nranks, const pl_comm_ops* ops);
+int  pl_set_comm_2d(pl_ctx* ctx, int rank, int Pz, int Px, const pl_comm_ops* ops);
 int  pl_local_rows(pl_ctx* ctx, int* first_row, int* n_rows);
-/* *native = 1 when halo exchange / all-gather run as direct RCCL calls on the context stream
- * (dlopen'ed librccl, self-tested at pl_set_comm), 0 when they go through the callback table.
+int  pl_local_block(pl_ctx* ctx, int* first_row, int* n_rows, int* first_col, int* n_cols, int* Pz, int* Px);
+/* In-process group of virtual ranks: create one group, then one context per rank (same or different devices), attach
+ * each with pl_set_comm_local and drive every context from its OWN host thread (the calls are collective and block
+ * until all ranks of the group have entered them). */
+typedef struct pl_local_group pl_local_group;
+int  pl_local_group_create(pl_local_group** out, int nranks);
+void pl_local_group_destroy(pl_local_group* g);
+int  pl_set_comm_local(pl_ctx* ctx, pl_local_group* g, int rank, int Pz, int Px);
+/* *native = 1 when the exchanges run as direct RCCL calls on the context stream (dlopen'ed librccl, self-tested at
+ * pl_set_comm), 2 for the in-process group, 0 when they go through the callback table.
  * The native path is opt-in: PYLAMP_RCCL=1 (bench.py sets it under the nccl backend). */
 int  pl_comm_info(pl_ctx* ctx, int* rank, int* nranks, int* native);
 /* Cumulative numbers of communication calls of this context: out[0] neighbour (halo) exchanges, [1] all-gathers,

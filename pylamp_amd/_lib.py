@@ -53,7 +53,12 @@ SIGNATURES = {
     "pl_abi_layout": (C.c_int, [C.POINTER(C.c_size_t)]),
     "pl_device_info": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, c_int_p, C.POINTER(C.c_size_t)]),
     "pl_set_comm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "pl_set_comm_2d": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pl_local_rows": (C.c_int, [C.c_void_p, c_int_p, c_int_p]),
+    "pl_local_block": (C.c_int, [C.c_void_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p]),
+    "pl_local_group_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "pl_local_group_destroy": (None, [C.c_void_p]),
+    "pl_set_comm_local": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "pl_comm_info": (C.c_int, [C.c_void_p, c_int_p, c_int_p, c_int_p]),
     "pl_comm_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
     "pl_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

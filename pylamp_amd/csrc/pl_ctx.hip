@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstddef>
+#include <algorithm>
 
 thread_local std::string pl_tls_error;
 
@@ -55,8 +56,8 @@ int pl_geom_build(pl_ctx* ctx, PlGeomHost& gh, int nz, int nx, const double* zc,
     gh.xc.assign(xc, xc + nx);
     PlGeom& g = gh.d;
     g.nz = nz; g.nx = nx; g.lnz = nz; g.lnx = nx; g.gi0 = 0; g.gj0 = 0;
-    g.pitch = ((PL_PADL + nx + 1 + 15) / 16) * 16;
-    g.plane = (long long)(nz + 2) * g.pitch;
+    g.pitch = ((PL_PADL + nx + PL_RING + 15) / 16) * 16;
+    g.plane = (long long)(nz + 2 * PL_RING) * g.pitch;
     // tables indexed by global index + 1, length n+3 each
     const int T0 = PL_TOFF;
     size_t lz = ((size_t)nz + 2 * T0 + 2 + 1) & ~(size_t)1, lx = ((size_t)nx + 2 * T0 + 2 + 1) & ~(size_t)1;   // even lengths
@@ -82,20 +83,11 @@ int pl_geom_build(pl_ctx* ctx, PlGeomHost& gh, int nz, int nx, const double* zc,
     return 0;
 }
 
-void pl_geom_set_rows(PlGeomHost& gh, int gi0, int lnz) {
-    gh.d.gi0 = gi0; gh.d.lnz = lnz;
-    gh.d.plane = (long long)(lnz + 2) * gh.d.pitch;
-}
-
-int pl_halo_rows(pl_ctx* ctx, const PlGeom& g, double* planes, int nplanes, long long plane_stride, bool add) {
-    if (ctx->nranks <= 1) return 0;
-    const long long p = g.pitch;
-    if (!add)   // forward: my first/last owned rows -> neighbours' ring rows
-        return pl_comm_exchange(ctx, planes + p, planes, planes + (long long)g.lnz * p, planes + (long long)(g.lnz + 1) * p,
-                                p, nplanes, plane_stride, 0);
-    // reverse: my ring rows are added to the neighbours' owned boundary rows
-    return pl_comm_exchange(ctx, planes, planes + p, planes + (long long)(g.lnz + 1) * p, planes + (long long)g.lnz * p, p,
-                            nplanes, plane_stride, 1);
+void pl_geom_set_block(PlGeomHost& gh, int gi0, int lnz, int gj0, int lnx) {
+    PlGeom& g = gh.d;
+    g.gi0 = gi0; g.lnz = lnz; g.gj0 = gj0; g.lnx = lnx;
+    g.pitch = ((PL_PADL + lnx + PL_RING + 15) / 16) * 16;
+    g.plane = (long long)(lnz + 2 * PL_RING) * g.pitch;
 }
 
 int pl_allreduce_host(pl_ctx* ctx, double* buf, long long n, int op) {
@@ -105,23 +97,57 @@ int pl_allreduce_host(pl_ctx* ctx, double* buf, long long n, int op) {
     return 0;
 }
 
-extern "C" int pl_set_comm(pl_ctx* ctx, int rank, int nranks, const pl_comm_ops* ops) {
-    if (!ops || nranks < 1 || rank < 0 || rank >= nranks) return pl_fail(ctx, "pl_set_comm: bad argument");
+// block of this rank; the checks every transport shares
+static int set_layout(pl_ctx* ctx, int rank, int Pz, int Px) {
+    const int nranks = Pz * Px;
+    if (Pz < 1 || Px < 1 || rank < 0 || rank >= nranks) return pl_fail(ctx, "pl_set_comm: bad rank / layout");
     if (!ctx->bufs.empty() || ctx->krylov || ctx->step) return pl_fail(ctx, "pl_set_comm must be called right after pl_create");
-    if (nranks == 1) {
-        ctx->rank = 0; ctx->nranks = 1;
+    ctx->rank = rank; ctx->nranks = nranks; ctx->Pz = Pz; ctx->Px = Px; ctx->pz = rank / Px; ctx->px = rank % Px;
+    if (nranks == 1) return 0;
+    if ((ctx->nz - 1) % Pz || (ctx->nx - 1) % Px)
+        return pl_fail(ctx, "pl_set_comm: (nz-1) and (nx-1) must be divisible by the number of blocks along z resp. x");
+    const int Cz = (ctx->nz - 1) / Pz, Cx = (ctx->nx - 1) / Px;
+    if ((Pz > 1 && (Cz < 8 || (Cz % 2))) || (Px > 1 && (Cx < 8 || (Cx % 2))))
+        return pl_fail(ctx, "pl_set_comm: need an even number (>= 8) of node rows / columns per block");
+    int i0, ni, j0, nj;
+    pl_block_1d(ctx->nz, Pz, ctx->pz, &i0, &ni); pl_block_1d(ctx->nx, Px, ctx->px, &j0, &nj);
+    pl_geom_set_block(ctx->geom, i0, ni, j0, nj);
+    return 0;
+}
+
+static void choose_layout(int nranks, int* Pz, int* Px) {
+    *Pz = 1; *Px = nranks;
+    if (const char* e = getenv("PYLAMP_DECOMP")) {
+        int a = 0, b = 0;
+        if (sscanf(e, "%dx%d", &a, &b) == 2 && a >= 1 && b >= 1 && a * b == nranks) { *Pz = a; *Px = b; return; }
+    }
+    for (int a = 1; a * a <= nranks; a++) if (nranks % a == 0) { *Pz = a; *Px = nranks / a; }     // most square, Px >= Pz
+}
+
+extern "C" int pl_set_comm_2d(pl_ctx* ctx, int rank, int Pz, int Px, const pl_comm_ops* ops) {
+    if (!ops) return pl_fail(ctx, "pl_set_comm: bad argument");
+    PL_TRY(set_layout(ctx, rank, Pz, Px));
+    if (ctx->nranks == 1) {
         if (getenv("PYLAMP_RCCL_SELFTEST")) return pl_comm_native_init(ctx);   // single-rank API check (tests)
         return 0;
     }
-    if (!ops->exchange || !ops->allreduce_host || !ops->allgather || !ops->exchange_var)
-        return pl_fail(ctx, "pl_set_comm: incomplete callback table");
-    const int cells = ctx->nz - 1;
-    if (cells % nranks) return pl_fail(ctx, "pl_set_comm: (nz-1) must be divisible by the number of ranks");
-    const int C = cells / nranks;
-    if (C < 8 || (C % 2)) return pl_fail(ctx, "pl_set_comm: need an even number (>= 8) of node rows per rank");
-    ctx->rank = rank; ctx->nranks = nranks; ctx->comm = *ops;
-    pl_geom_set_rows(ctx->geom, rank * C, (rank == nranks - 1) ? C + 1 : C);
-    return pl_comm_native_init(ctx);      // RCCL directly on the context stream when every rank can
+    if (!ops->sendrecv || !ops->allreduce_host || !ops->allgather) return pl_fail(ctx, "pl_set_comm: incomplete callback table");
+    ctx->comm = *ops;
+    return pl_comm_native_init(ctx);      // RCCL directly on the context stream when asked for and every rank can
+}
+
+extern "C" int pl_set_comm(pl_ctx* ctx, int rank, int nranks, const pl_comm_ops* ops) {
+    if (nranks < 1) return pl_fail(ctx, "pl_set_comm: bad argument");
+    int Pz, Px;
+    choose_layout(nranks, &Pz, &Px);
+    return pl_set_comm_2d(ctx, rank, Pz, Px, ops);
+}
+
+int pl_local_attach(pl_ctx* ctx, pl_local_group* g, int rank);       // pl_comm.hip
+extern "C" int pl_set_comm_local(pl_ctx* ctx, pl_local_group* g, int rank, int Pz, int Px) {
+    if (!g) return pl_fail(ctx, "pl_set_comm_local: no group");
+    PL_TRY(set_layout(ctx, rank, Pz, Px));
+    return pl_local_attach(ctx, g, rank);
 }
 
 // cumulative counts of the communication calls issued by this context (reset = 1 clears them afterwards)
@@ -140,6 +166,16 @@ extern "C" int pl_comm_info(pl_ctx* ctx, int* rank, int* nranks, int* native) {
 extern "C" int pl_local_rows(pl_ctx* ctx, int* first_row, int* n_rows) {
     if (first_row) *first_row = ctx->geom.d.gi0;
     if (n_rows) *n_rows = ctx->geom.d.lnz;
+    return 0;
+}
+extern "C" int pl_local_block(pl_ctx* ctx, int* first_row, int* n_rows, int* first_col, int* n_cols, int* Pz, int* Px) {
+    const PlGeom& g = ctx->geom.d;
+    if (first_row) *first_row = g.gi0;
+    if (n_rows) *n_rows = g.lnz;
+    if (first_col) *first_col = g.gj0;
+    if (n_cols) *n_cols = g.lnx;
+    if (Pz) *Pz = ctx->Pz;
+    if (Px) *Px = ctx->Px;
     return 0;
 }
 
@@ -201,6 +237,7 @@ extern "C" void pl_destroy(pl_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     pl_comm_native_free(ctx);
+    pl_local_detach(ctx);
     pl_step_free(ctx);
     pl_mic_free(ctx);
     pl_solver_free(ctx);
@@ -251,25 +288,26 @@ extern "C" int pl_timer_stop_ms(pl_ctx* ctx, double* ms) {
 }
 
 // ---- plane / vector transfers ---------------------------------------------------------------
-// host is the GLOBAL (nz,nx) array on every rank; the local rows plus the neighbouring ring rows
-// (when they exist) are taken from it, so coefficient planes need no halo exchange.
+// host is the GLOBAL (nz,nx) array on every rank; the local block plus the neighbouring halo (PL_RING deep, clipped
+// at the domain boundary) is taken from it, so coefficient planes need no halo exchange.
 int pl_plane_upload(pl_ctx* ctx, const PlGeom& g, const double* host, double* dplane) {
-    const int r0 = (g.gi0 > 0) ? -1 : 0, r1 = (g.gi0 + g.lnz < g.nz) ? g.lnz + 1 : g.lnz;
-    PL_HIP(ctx, hipMemcpy2DAsync(dplane + pl_idx(g, r0, 0), (size_t)g.pitch * sizeof(double),
-                                 host + (size_t)(g.gi0 + r0) * g.lnx, (size_t)g.lnx * sizeof(double),
-                                 (size_t)g.lnx * sizeof(double), r1 - r0, hipMemcpyHostToDevice, ctx->stream));
+    const int r0 = -std::min(PL_RING, g.gi0), r1 = g.lnz + std::min(PL_RING, g.nz - (g.gi0 + g.lnz));
+    const int c0 = -std::min(PL_RING, g.gj0), c1 = g.lnx + std::min(PL_RING, g.nx - (g.gj0 + g.lnx));
+    PL_HIP(ctx, hipMemcpy2DAsync(dplane + pl_idx(g, r0, c0), (size_t)g.pitch * sizeof(double),
+                                 host + (size_t)(g.gi0 + r0) * g.nx + (g.gj0 + c0), (size_t)g.nx * sizeof(double),
+                                 (size_t)(c1 - c0) * sizeof(double), r1 - r0, hipMemcpyHostToDevice, ctx->stream));
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));   // host buffer may be reused by the caller
     return 0;
 }
 
-// every rank receives the complete GLOBAL (nz,nx) array (own rows + zero elsewhere, summed over ranks)
+// every rank receives the complete GLOBAL (nz,nx) array (own block + zero elsewhere, summed over ranks)
 int pl_plane_download(pl_ctx* ctx, const PlGeom& g, const double* dplane, double* host) {
-    if (ctx->nranks > 1) memset(host, 0, (size_t)g.nz * g.lnx * sizeof(double));
-    PL_HIP(ctx, hipMemcpy2DAsync(host + (size_t)g.gi0 * g.lnx, (size_t)g.lnx * sizeof(double), dplane + pl_idx(g, 0, 0),
+    if (ctx->nranks > 1) memset(host, 0, (size_t)g.nz * g.nx * sizeof(double));
+    PL_HIP(ctx, hipMemcpy2DAsync(host + (size_t)g.gi0 * g.nx + g.gj0, (size_t)g.nx * sizeof(double), dplane + pl_idx(g, 0, 0),
                                  (size_t)g.pitch * sizeof(double), (size_t)g.lnx * sizeof(double), g.lnz,
                                  hipMemcpyDeviceToHost, ctx->stream));
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return pl_allreduce_host(ctx, host, (long long)g.nz * g.lnx, 0);
+    return pl_allreduce_host(ctx, host, (long long)g.nz * g.nx, 0);
 }
 
 // interleaved (node-major, 3 per node) <-> 3 planes
@@ -294,7 +332,9 @@ static dim3 grid2d(const PlGeom& g) { return dim3((g.lnx + 63) / 64, (g.lnz + 3)
 int pl_vec3_upload(pl_ctx* ctx, const PlGeom& g, const double* host, double* dvec) {
     size_t bytes = (size_t)3 * g.lnz * g.lnx * sizeof(double);
     PL_TRY(pl_stage(ctx, bytes));
-    PL_HIP(ctx, hipMemcpyAsync(ctx->stage, host + (size_t)3 * g.gi0 * g.lnx, bytes, hipMemcpyHostToDevice, ctx->stream));
+    PL_HIP(ctx, hipMemcpy2DAsync(ctx->stage, (size_t)3 * g.lnx * sizeof(double), host + ((size_t)g.gi0 * g.nx + g.gj0) * 3,
+                                 (size_t)3 * g.nx * sizeof(double), (size_t)3 * g.lnx * sizeof(double), g.lnz,
+                                 hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_deinterleave3, grid2d(g), dim3(64, 4), 0, ctx->stream, g, ctx->stage, dvec);
     PL_HIP(ctx, hipGetLastError());
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -306,8 +346,10 @@ int pl_vec3_download(pl_ctx* ctx, const PlGeom& g, const double* dvec, double* h
     PL_TRY(pl_stage(ctx, bytes));
     hipLaunchKernelGGL(k_interleave3, grid2d(g), dim3(64, 4), 0, ctx->stream, g, dvec, ctx->stage);
     PL_HIP(ctx, hipGetLastError());
-    if (ctx->nranks > 1) memset(host, 0, (size_t)3 * g.nz * g.lnx * sizeof(double));
-    PL_HIP(ctx, hipMemcpyAsync(host + (size_t)3 * g.gi0 * g.lnx, ctx->stage, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->nranks > 1) memset(host, 0, (size_t)3 * g.nz * g.nx * sizeof(double));
+    PL_HIP(ctx, hipMemcpy2DAsync(host + ((size_t)g.gi0 * g.nx + g.gj0) * 3, (size_t)3 * g.nx * sizeof(double), ctx->stage,
+                                 (size_t)3 * g.lnx * sizeof(double), (size_t)3 * g.lnx * sizeof(double), g.lnz,
+                                 hipMemcpyDeviceToHost, ctx->stream));
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return pl_allreduce_host(ctx, host, (long long)3 * g.nz * g.lnx, 0);
+    return pl_allreduce_host(ctx, host, (long long)3 * g.nz * g.nx, 0);
 }

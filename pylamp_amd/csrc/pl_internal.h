@@ -11,18 +11,21 @@
 #include "../../include/pylamp_hip.h"
 
 #define PL_PADL 16           // doubles of left padding: interior column 0 is 128-B aligned
+#define PL_RING 6            // halo depth every plane carries: rows above/below and columns right of the local block
+                             // (the left padding holds the halo columns there); deep enough for a smoothing
+                             // sequence of a distributed multigrid level to run on ONE exchange
 #define PL_WAVE 64
 #define PL_TOFF 2            // 1-D tables are indexed by global node index + PL_TOFF (even: pairs are 16-B aligned)
 
 // ---- device-side view of one grid block (fine grid or a multigrid level) -------------
 // Local block of lnz x lnx nodes whose node (0,0) is global node (gi0,gj0); every 2-D
-// plane carries a one-node ring (halo for neighbour ranks, unused at global walls).
+// plane carries a ring of PL_RING nodes (halo for neighbour ranks, unused at global walls).
 struct PlGeom {
     int nz, nx;              // global node counts
     int lnz, lnx;            // local block
     int gi0, gj0;            // global index of local node (0,0)
     int pitch;               // doubles per row
-    long long plane;         // doubles per plane = (lnz+2)*pitch
+    long long plane;         // doubles per plane = (lnz + 2 PL_RING) * pitch
     // 1-D tables indexed by GLOBAL node index + PL_TOFF, zero padded on both sides, 16-B aligned:
     const double* zc; const double* xc;
     const double* rdz; const double* rdx;   // rdz[i] = 1/(z[i+1]-z[i])
@@ -30,7 +33,7 @@ struct PlGeom {
 };
 
 __host__ __device__ inline long long pl_idx(const PlGeom& g, int li, int lj) {
-    return (long long)(li + 1) * g.pitch + (lj + PL_PADL);
+    return (long long)(li + PL_RING) * g.pitch + (lj + PL_PADL);
 }
 
 struct PlStokesOp {
@@ -78,11 +81,13 @@ struct pl_ctx {
     PlHeatOp hop{}; bool hop_ready = false; double heat_bcvalue[4] = {0, 0, 0, 0};
     int mic_search = 0;          // host-API gathers locate cells by per-axis search (pl_mic_set_search)
     std::vector<double> zmp, xmp;
-    // multi-GPU (row slabs): rank r owns node rows [row0, row0 + geom.d.lnz)
-    int rank = 0, nranks = 1;
+    // multi-GPU: Pz x Px blocks of the node grid; rank = pz * Px + px owns node rows [gi0, gi0 + lnz) and columns
+    // [gj0, gj0 + lnx) of geom.d (the last block of an axis also owns the last node row / column)
+    int rank = 0, nranks = 1, Pz = 1, Px = 1, pz = 0, px = 0;
     long long comm_calls[4] = {0, 0, 0, 0};     // neighbour exchanges, all-gathers, device all-reduces, host all-reduces (pl_comm_stats)
     pl_comm_ops comm{};
     void* nccl = nullptr;     // pl_comm.hip: native RCCL transport (optional)
+    void* local = nullptr;    // pl_comm.hip: in-process group of virtual ranks (pl_local_group_*)
     // opaque extension slots owned by other translation units
     void* krylov = nullptr;   // pl_solver.hip
     void* mic = nullptr;      // pl_mic.hip
@@ -151,19 +156,30 @@ int pl_fail(pl_ctx* ctx, const std::string& msg);
 int pl_buf(pl_ctx* ctx, const char* name, size_t bytes, double** out, bool zero = true);
 int pl_stage(pl_ctx* ctx, size_t bytes);
 int pl_geom_build(pl_ctx* ctx, PlGeomHost& gh, int nz, int nx, const double* zc, const double* xc);
-// restrict the geometry to the row slab [gi0, gi0+lnz)
-void pl_geom_set_rows(PlGeomHost& gh, int gi0, int lnz);
-// halo exchange of the ring rows of nplanes planes (no-op on one rank); add: reverse (accumulating) halo
-int pl_halo_rows(pl_ctx* ctx, const PlGeom& g, double* planes, int nplanes, long long plane_stride, bool add = false);
+// restrict the geometry to the block rows [gi0, gi0+lnz) x columns [gj0, gj0+lnx)
+void pl_geom_set_block(PlGeomHost& gh, int gi0, int lnz, int gj0, int lnx);
+inline bool pl_geom_is_dist(const PlGeom& g) { return g.lnz != g.nz || g.lnx != g.nx; }
+// block of rank (pz, px) on a grid of n nodes along one axis split into P parts: first node, node count
+inline void pl_block_1d(int n, int P, int p, int* first, int* count) {
+    const int C = (n - 1) / P;
+    *first = p * C; *count = (p == P - 1) ? C + 1 : C;
+}
+// Halo exchange with the (up to 8) neighbour blocks, `depth` <= PL_RING nodes deep, of nplanes planes (no-op on one
+// rank).  add: reverse (accumulating) halo - the ring contributions are ADDED to the neighbours' owned boundary nodes.
+int pl_halo(pl_ctx* ctx, const PlGeom& g, double* planes, int nplanes, long long plane_stride, int depth = 1, bool add = false);
+// the same for any dense 2-D layout: `origin` points at the owned node (0,0) of plane 0
+int pl_halo_generic(pl_ctx* ctx, int lnz, int lnx, double* origin, long long pitch, int nplanes, long long plane_stride,
+                    int depth, bool add);
+// Replicated planes (lnz = nz, lnx = nx on every rank) of which each rank has computed its own block: gather all blocks
+int pl_gather_blocks(pl_ctx* ctx, const PlGeom& grepl, double* planes, int nplanes, long long plane_stride);
 int pl_allreduce_host(pl_ctx* ctx, double* buf, long long n, int op);
-// neighbour exchange / all-gather / tracer migration: native RCCL on the context stream when available,
-// otherwise the host callback table (pl_comm.hip)
-int pl_comm_exchange(pl_ctx* ctx, const double* send_lo, double* recv_lo, const double* send_hi, double* recv_hi,
-                     long long count, int nseg, long long stride, int add);
-int pl_comm_allgather(pl_ctx* ctx, double* recv, long long count, int nseg, long long stride);
-int pl_comm_exchange_var(pl_ctx* ctx, double* const* send_lo, long long n_lo, double* const* send_hi, long long n_hi,
-                         double* const* recv, long long cap, int ncol, long long* got);
+// point-to-point messages between ranks (device buffers), matched per peer in list order; stream-ordered on the native
+// RCCL transport, otherwise through the in-process group or the host callback table (pl_comm.hip)
+struct PlMsg { int peer; const double* send; long long nsend; double* recv; long long nrecv; };
+int pl_comm_sendrecv(pl_ctx* ctx, const PlMsg* msgs, int nmsg);
+int pl_comm_allgather(pl_ctx* ctx, const double* send, double* recv, long long count);
 int pl_comm_native_init(pl_ctx* ctx);
+void pl_local_detach(pl_ctx* ctx);
 void pl_comm_native_free(pl_ctx* ctx);
 int pl_comm_native_enabled(pl_ctx* ctx);
 int pl_comm_allreduce_dev(pl_ctx* ctx, double* dev, int n);

@@ -1,6 +1,9 @@
 """profiles/traffic.json + a per-kernel summary CSV from two rocprofv3 PMC passes over tools/pmc_run.py:
 
-    python tools/make_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <round-tag>
+    python tools/make_traffic.py <fetch pass: counter_collection.csv or results.db> <write pass: same> <round-tag> [kernel-trace results.db]
+
+(rocprofv3 of ROCm 7.2 writes a rocpd SQLite database by default; `--output-format csv` gives the CSV.  With a fourth
+argument the kernel statistics of a `--kernel-trace --stats` run are written to profiles/<tag>_kernel_stats.csv.)
 
 FETCH_SIZE / WRITE_SIZE are reported in KiB per dispatch.  On gfx950 FETCH_SIZE counts a wide coalesced read at half
 its bytes (MI355X_MICROARCH.md, HBM section): it is doubled here, and the factor is CHECKED on the stream triad of the
@@ -13,13 +16,23 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 fetch_csv, write_csv, tag = sys.argv[1], sys.argv[2], sys.argv[3]
 
 
+def rows_of(path, counter):
+    if path.endswith(".db"):
+        import sqlite3
+        cur = sqlite3.connect(path).cursor()
+        for name, grid, val in cur.execute("select kernel_name, grid_size, value from counters_collection where counter_name = ?", (counter,)):
+            yield name, int(grid), float(val)
+    else:
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] == counter:
+                yield r["Kernel_Name"], int(r["Grid_Size"]), float(r["Counter_Value"])
+
+
 def load(path, counter):
     d = collections.defaultdict(list)
-    for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] != counter:
-            continue
-        name = re.sub(r"^void ", "", r["Kernel_Name"]).split("(")[0].strip()
-        d[(name, int(r["Grid_Size"]))].append(float(r["Counter_Value"]) * 1024.0)
+    for kname, grid, val in rows_of(path, counter):
+        name = re.sub(r"^void ", "", kname).split("(")[0].strip()
+        d[(name, grid)].append(val * 1024.0)
     return {k: float(np.median(v)) for k, v in d.items()}, {k: len(v) for k, v in d.items()}
 
 
@@ -66,4 +79,11 @@ with open(os.path.join(ROOT, "profiles", "%s_pmc_summary.csv" % tag), "w") as f:
     f.write("kernel,grid_size,dispatches,fetch_bytes_x2,write_bytes\n")
     for r in rows:
         f.write("%s,%d,%d,%.0f,%.0f\n" % (r[0].replace(",", ";"), r[1], r[2], r[3], r[4]))
+if len(sys.argv) > 4:
+    import sqlite3
+    cur = sqlite3.connect(sys.argv[4]).cursor()
+    with open(os.path.join(ROOT, "profiles", "%s_kernel_stats.csv" % tag), "w") as f:
+        f.write("kernel,calls,total_us,average_us,percent\n")
+        for name, calls, tot, avg, pct in cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
+            f.write('"%s",%d,%.1f,%.3f,%.2f\n' % (name, calls, tot, avg, pct))
 print(json.dumps(out, indent=1))
