@@ -10,7 +10,7 @@ from . import _lib
 
 
 class Context:
-    def __init__(self, nx, grid, device=None):
+    def __init__(self, nx, grid, device=None, attach_dist=True):
         lib = _lib.load()
         self.lib = lib
         self.nz, self.nx = int(nx[0]), int(nx[1])
@@ -36,10 +36,10 @@ class Context:
         self.heat_gen = 0
         self.comm = None
         self.rank, self.nranks = 0, 1
-        # under torch.distributed (torchrun) every rank owns a row slab of the grid
+        # under torch.distributed (torchrun) every rank owns a block of the grid
         try:
             import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and not os.environ.get("PYLAMP_NO_DIST"):
+            if attach_dist and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and not os.environ.get("PYLAMP_NO_DIST"):
                 from .parallel import Comm
                 Comm(self)
                 self.rank, self.nranks = self.comm.rank, self.comm.size
@@ -64,10 +64,20 @@ class Context:
         _lib.check(self.h, rc)
 
     def local_rows(self):
-        import ctypes as C_
-        a = C_.c_int(); b = C_.c_int()
-        self.check(self.lib.pl_local_rows(self.h, C_.byref(a), C_.byref(b)))
+        a = C.c_int(); b = C.c_int()
+        self.check(self.lib.pl_local_rows(self.handle(), C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def local_block(self):
+        """(first_row, n_rows, first_col, n_cols, Pz, Px) of the node block this rank owns."""
+        v = [C.c_int() for _ in range(6)]
+        self.check(self.lib.pl_local_block(self.handle(), *[C.byref(x) for x in v]))
+        return tuple(x.value for x in v)
+
+    def attach_local(self, group, rank, Pz, Px):
+        """Join an in-process group of virtual ranks (pl_local_group_create) as `rank` of a Pz x Px layout."""
+        self.check(self.lib.pl_set_comm_local(self.handle(), group, int(rank), int(Pz), int(Px)))
+        self.rank, self.nranks = int(rank), int(Pz) * int(Px)
 
     def close(self):
         if self.h is not None:

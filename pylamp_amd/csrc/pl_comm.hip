@@ -1,18 +1,29 @@
-// Communication dispatch for the row-slab decomposition.
+// Communication layer of the 2-D block decomposition (Pz x Px blocks of the node grid).
 //
-// Fast path: RCCL called directly on the context's HIP stream (ncclSend/ncclRecv groups for the
-// halo rows over the direct xGMI links, ncclAllGather for the replicated coarse level and the
-// advection velocity).  Everything is stream-ordered: no host synchronisation per exchange.
-// librccl is dlopen'ed at pl_set_comm time (soname librccl.so.1 - the copy torch already loaded
-// when torch is in the process); the unique id travels through the host callback table.
-// An init-time self-test (ring exchange + all-gather against known values) decides collectively
-// whether the native path is used; otherwise every call falls back to the callback table
-// (pylamp_amd/parallel.py: torch.distributed), which is the path the multi-rank tests exercise
-// on a single GPU.
+// Primitives everything else is built from:
+//   pl_comm_sendrecv   point-to-point messages between neighbour ranks (device buffers)
+//   pl_comm_allgather  equal-sized contributions of all ranks
+//   pl_comm_allreduce_dev / pl_allreduce_host   Krylov dot products, time-step reductions
+// and on top of them
+//   pl_halo / pl_halo_generic   halo exchange with the (up to 8) neighbour blocks, corners included, any depth up to
+//                               PL_RING: ONE pack kernel, one message per neighbour, ONE unpack kernel
+//   pl_gather_blocks            a replicated multigrid level assembled from the blocks the ranks computed
+//
+// Three transports behind the primitives:
+//   (a) RCCL called directly on the context's HIP stream (ncclSend/ncclRecv groups over the direct xGMI links,
+//       ncclAllGather, ncclAllReduce): stream-ordered, no host synchronisation per exchange.  librccl is dlopen'ed at
+//       pl_set_comm time; opt-in (PYLAMP_RCCL=1) and self-tested collectively before it is used;
+//   (b) the host callback table (pylamp_amd/parallel.py: torch.distributed, gloo staging or nccl tensors);
+//   (c) an in-process group of virtual ranks (pl_local_group_*): every rank is a context driven by its own host
+//       thread, messages are device-to-device copies between the contexts' buffers.  This is how a 2 x 4 layout is
+//       rehearsed on ONE GPU; the pack / unpack kernels and all neighbour logic are the ones (a) uses.
 #include "pl_internal.h"
 #include <dlfcn.h>
+#include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cstdlib>
+#include <mutex>
 #include <thread>
 
 typedef struct { char internal[128]; } pl_ncclUniqueId;
@@ -38,15 +49,299 @@ struct PlNccl {
 
 static PlNccl* nccl_of(pl_ctx* ctx) { return (PlNccl*)ctx->nccl; }
 
-__global__ void k_comm_add(long long n, double* __restrict__ d, const double* __restrict__ s) {
-    long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; k < n; k += (long long)gridDim.x * blockDim.x) d[k] += s[k];
+// ---- in-process group of virtual ranks ------------------------------------------------------------------------
+struct pl_local_group {
+    int n = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    long long gen = 0;
+    std::vector<pl_ctx*> ctx;
+    std::vector<const PlMsg*> msgs; std::vector<int> nmsg;
+    std::vector<const void*> ptr;
+    void barrier() {
+        std::unique_lock<std::mutex> lk(m);
+        const long long g = gen;
+        if (++arrived == n) { arrived = 0; gen++; cv.notify_all(); }
+        else cv.wait(lk, [&] { return gen != g; });
+    }
+};
+
+extern "C" int pl_local_group_create(pl_local_group** out, int nranks) {
+    if (!out || nranks < 1) return 1;
+    pl_local_group* g = new pl_local_group();
+    g->n = nranks; g->ctx.assign(nranks, nullptr); g->msgs.assign(nranks, nullptr); g->nmsg.assign(nranks, 0); g->ptr.assign(nranks, nullptr);
+    *out = g;
+    return 0;
 }
-__global__ void k_comm_fill(long long n, double* __restrict__ d, double v) {
-    long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; k < n; k += (long long)gridDim.x * blockDim.x) d[k] = v;
+extern "C" void pl_local_group_destroy(pl_local_group* g) { delete g; }
+
+int pl_local_attach(pl_ctx* ctx, pl_local_group* g, int rank) {
+    if (rank < 0 || rank >= g->n || g->n != ctx->nranks) return pl_fail(ctx, "pl_set_comm_local: rank / group size mismatch");
+    g->ctx[rank] = ctx;
+    ctx->local = g;
+    return 0;
+}
+void pl_local_detach(pl_ctx* ctx) { ctx->local = nullptr; }
+static pl_local_group* local_of(pl_ctx* ctx) { return (pl_local_group*)ctx->local; }
+
+static int local_sendrecv(pl_ctx* ctx, const PlMsg* msgs, int nmsg) {
+    pl_local_group* G = local_of(ctx);
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));              // my send buffers are complete
+    G->msgs[ctx->rank] = msgs; G->nmsg[ctx->rank] = nmsg;
+    G->barrier();
+    int rc = 0;
+    for (int k = 0; k < nmsg && !rc; k++) {
+        if (msgs[k].nrecv <= 0) continue;
+        const int p = msgs[k].peer;
+        int ord = 0;                                             // k is my ord-th message with this peer
+        for (int q = 0; q < k; q++) if (msgs[q].peer == p) ord++;
+        const PlMsg* pm = G->msgs[p]; const PlMsg* hit = nullptr;
+        for (int q = 0, seen = 0; q < G->nmsg[p]; q++)
+            if (pm[q].peer == ctx->rank) { if (seen == ord) { hit = &pm[q]; break; } seen++; }
+        if (!hit || hit->nsend != msgs[k].nrecv) { rc = pl_fail(ctx, "in-process transport: unmatched message"); break; }
+        if (hipMemcpyAsync(msgs[k].recv, hit->send, (size_t)msgs[k].nrecv * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+            rc = pl_fail(ctx, "in-process transport: device copy failed");
+    }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = pl_fail(ctx, "in-process transport: synchronisation failed");
+    G->barrier();                                                // everybody has read: send buffers may be reused
+    return rc;
 }
 
+static int local_allreduce_host(pl_ctx* ctx, double* buf, long long n, int op) {
+    pl_local_group* G = local_of(ctx);
+    G->ptr[ctx->rank] = buf;
+    G->barrier();
+    std::vector<double> tmp((size_t)n);
+    for (long long k = 0; k < n; k++) {
+        double a = ((const double*)G->ptr[0])[k];
+        for (int r = 1; r < G->n; r++) {                        // fixed rank order: every rank gets the same bits
+            const double b = ((const double*)G->ptr[r])[k];
+            a = (op == 0) ? a + b : (op == 1 ? std::min(a, b) : std::max(a, b));
+        }
+        tmp[(size_t)k] = a;
+    }
+    G->barrier();
+    memcpy(buf, tmp.data(), (size_t)n * sizeof(double));
+    return 0;
+}
+
+static int local_allgather(pl_ctx* ctx, const double* send, double* recv, long long count) {
+    pl_local_group* G = local_of(ctx);
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    G->ptr[ctx->rank] = send;
+    G->barrier();
+    int rc = 0;
+    for (int r = 0; r < G->n && !rc; r++)
+        if (hipMemcpyAsync(recv + (long long)r * count, G->ptr[r], (size_t)count * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+            rc = pl_fail(ctx, "in-process transport: device copy failed");
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = pl_fail(ctx, "in-process transport: synchronisation failed");
+    G->barrier();
+    return rc;
+}
+
+// ---- dispatch ---------------------------------------------------------------------------------------------------
+int pl_comm_sendrecv(pl_ctx* ctx, const PlMsg* msgs, int nmsg) {
+    if (ctx->nranks <= 1) return 0;
+    PlNccl* N = nccl_of(ctx);
+    if (N && N->ok) {
+        int rc = N->GroupStart();
+        for (int k = 0; k < nmsg && !rc; k++) {
+            if (msgs[k].nsend > 0) rc |= N->Send(msgs[k].send, (size_t)msgs[k].nsend, PL_NCCL_DOUBLE, msgs[k].peer, N->comm, ctx->stream);
+            if (msgs[k].nrecv > 0) rc |= N->Recv(msgs[k].recv, (size_t)msgs[k].nrecv, PL_NCCL_DOUBLE, msgs[k].peer, N->comm, ctx->stream);
+        }
+        rc |= N->GroupEnd();
+        if (rc) return pl_fail(ctx, "RCCL send/recv group failed");
+        return 0;
+    }
+    if (ctx->local) return local_sendrecv(ctx, msgs, nmsg);
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<int> peer((size_t)nmsg); std::vector<const double*> sp((size_t)nmsg); std::vector<double*> rp((size_t)nmsg);
+    std::vector<int64_t> ns((size_t)nmsg), nr((size_t)nmsg);
+    for (int k = 0; k < nmsg; k++) { peer[k] = msgs[k].peer; sp[k] = msgs[k].send; rp[k] = msgs[k].recv; ns[k] = msgs[k].nsend; nr[k] = msgs[k].nrecv; }
+    if (ctx->comm.sendrecv(ctx->comm.user, nmsg, peer.data(), sp.data(), ns.data(), rp.data(), nr.data()))
+        return pl_fail(ctx, "communication callback 'sendrecv' failed");
+    return 0;
+}
+
+int pl_comm_allgather(pl_ctx* ctx, const double* send, double* recv, long long count) {
+    if (ctx->nranks <= 1) return 0;
+    ctx->comm_calls[1]++;
+    PlNccl* N = nccl_of(ctx);
+    if (N && N->ok) {
+        if (N->AllGather(send, recv, (size_t)count, PL_NCCL_DOUBLE, N->comm, ctx->stream)) return pl_fail(ctx, "RCCL all-gather failed");
+        return 0;
+    }
+    if (ctx->local) return local_allgather(ctx, send, recv, count);
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->comm.allgather(ctx->comm.user, send, recv, count)) return pl_fail(ctx, "communication callback 'allgather' failed");
+    return 0;
+}
+
+int pl_allreduce_host(pl_ctx* ctx, double* buf, long long n, int op) {
+    if (ctx->nranks <= 1) return 0;
+    ctx->comm_calls[3]++;
+    if (ctx->local) return local_allreduce_host(ctx, buf, n, op);
+    if (ctx->comm.allreduce_host(ctx->comm.user, buf, n, op)) return pl_fail(ctx, "communication callback 'allreduce_host' failed");
+    return 0;
+}
+
+// in-place sum all-reduce of n (<= 16) doubles in DEVICE memory: stream-ordered on the native transport, through the
+// host otherwise
+int pl_comm_allreduce_dev(pl_ctx* ctx, double* dev, int n) {
+    if (ctx->nranks <= 1) return 0;
+    ctx->comm_calls[2]++;
+    PlNccl* N = nccl_of(ctx);
+    if (N && N->ok) {
+        if (N->AllReduce(dev, dev, (size_t)n, PL_NCCL_DOUBLE, PL_NCCL_SUM, N->comm, ctx->stream)) return pl_fail(ctx, "RCCL all-reduce failed");
+        return 0;
+    }
+    double h[16];
+    if (n > 16) return pl_fail(ctx, "pl_comm_allreduce_dev: at most 16 values");
+    PL_HIP(ctx, hipMemcpyAsync(h, dev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->comm_calls[3]--;                                        // counted as ONE (device) all-reduce
+    PL_TRY(pl_allreduce_host(ctx, h, n, 0));
+    PL_HIP(ctx, hipMemcpyAsync(dev, h, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int pl_comm_native_enabled(pl_ctx* ctx) { PlNccl* N = nccl_of(ctx); return (N && N->ok) ? 1 : 0; }
+
+extern "C" int pl_comm_info(pl_ctx* ctx, int* rank, int* nranks, int* native) {
+    if (rank) *rank = ctx->rank;
+    if (nranks) *nranks = ctx->nranks;
+    if (native) *native = pl_comm_native_enabled(ctx) ? 1 : (ctx->local ? 2 : 0);
+    return 0;
+}
+
+// ---- halo exchange --------------------------------------------------------------------------------------------------
+// Regions are rectangles in LOCAL node coordinates (owned node (0,0) = origin); a segment holds the region of every
+// plane, plane after plane.
+struct HaloDesc {
+    int n;
+    int r0[8], nr[8], c0[8], nc[8];
+    long long off[9];                 // element offset of segment k in the buffer; off[n] = total
+};
+
+__device__ inline void halo_locate(const HaloDesc& d, long long t, int& k, int& q, int& i, int& j) {
+    k = 0;
+#pragma unroll
+    for (int s = 1; s < 8; s++) if (s < d.n && t >= d.off[s]) k = s;
+    const long long local = t - d.off[k];
+    const long long per = (long long)d.nr[k] * d.nc[k];
+    q = (int)(local / per);
+    const int e = (int)(local % per);
+    i = d.r0[k] + e / d.nc[k]; j = d.c0[k] + e % d.nc[k];
+}
+__global__ __launch_bounds__(256) void k_halo_pack(HaloDesc d, const double* __restrict__ origin, long long pitch,
+                                                   long long stride, double* __restrict__ buf) {
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < d.off[d.n]; t += (long long)gridDim.x * 256) {
+        int k, q, i, j;
+        halo_locate(d, t, k, q, i, j);
+        buf[t] = origin[q * stride + (long long)i * pitch + j];
+    }
+}
+__global__ __launch_bounds__(256) void k_halo_unpack(HaloDesc d, double* __restrict__ origin, long long pitch,
+                                                     long long stride, const double* __restrict__ buf, int add) {
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < d.off[d.n]; t += (long long)gridDim.x * 256) {
+        int k, q, i, j;
+        halo_locate(d, t, k, q, i, j);
+        double* p = origin + q * stride + (long long)i * pitch + j;
+        *p = add ? *p + buf[t] : buf[t];
+    }
+}
+
+static const int DZ[8] = {-1, 1, 0, 0, -1, -1, 1, 1}, DX[8] = {0, 0, -1, 1, -1, 1, -1, 1};
+
+int pl_halo_generic(pl_ctx* ctx, int lnz, int lnx, double* origin, long long pitch, int nplanes, long long stride, int depth, bool add) {
+    if (ctx->nranks <= 1) return 0;
+    if (depth < 1 || depth > PL_RING || depth > lnz || depth > lnx) return pl_fail(ctx, "pl_halo: bad depth");
+    ctx->comm_calls[0]++;
+    HaloDesc S{}, R{};
+    int peers[8];
+    long long off = 0;
+    int n = 0;
+    for (int k = 0; k < 8; k++) {
+        const int qz = ctx->pz + DZ[k], qx = ctx->px + DX[k];
+        if (qz < 0 || qz >= ctx->Pz || qx < 0 || qx >= ctx->Px) continue;
+        // owned boundary strip facing the neighbour, and the ring strip beyond it
+        const int or0 = DZ[k] < 0 ? 0 : (DZ[k] > 0 ? lnz - depth : 0), onr = DZ[k] ? depth : lnz;
+        const int oc0 = DX[k] < 0 ? 0 : (DX[k] > 0 ? lnx - depth : 0), onc = DX[k] ? depth : lnx;
+        const int rr0 = DZ[k] < 0 ? -depth : (DZ[k] > 0 ? lnz : 0), rc0 = DX[k] < 0 ? -depth : (DX[k] > 0 ? lnx : 0);
+        // forward: owned strip -> neighbour's ring; reverse (add): my ring -> neighbour's owned strip
+        S.r0[n] = add ? rr0 : or0; S.c0[n] = add ? rc0 : oc0; S.nr[n] = onr; S.nc[n] = onc;
+        R.r0[n] = add ? or0 : rr0; R.c0[n] = add ? oc0 : rc0; R.nr[n] = onr; R.nc[n] = onc;
+        S.off[n] = R.off[n] = off;
+        off += (long long)nplanes * onr * onc;
+        peers[n++] = qz * ctx->Px + qx;
+    }
+    S.n = R.n = n; S.off[n] = R.off[n] = off;
+    if (n == 0) return 0;
+    double *sb, *rb;
+    PL_TRY(pl_buf(ctx, "halo_send", (size_t)off * sizeof(double), &sb, false));
+    PL_TRY(pl_buf(ctx, "halo_recv", (size_t)off * sizeof(double), &rb, false));
+    const unsigned nb = (unsigned)std::min<long long>((off + 255) / 256, 1024);
+    hipLaunchKernelGGL(k_halo_pack, dim3(nb), dim3(256), 0, ctx->stream, S, (const double*)origin, pitch, stride, sb);
+    PlMsg msgs[8];
+    for (int k = 0; k < n; k++) {
+        const long long cnt = S.off[k + 1] - S.off[k];
+        msgs[k] = PlMsg{peers[k], sb + S.off[k], cnt, rb + R.off[k], cnt};
+    }
+    PL_TRY(pl_comm_sendrecv(ctx, msgs, n));
+    hipLaunchKernelGGL(k_halo_unpack, dim3(nb), dim3(256), 0, ctx->stream, R, origin, pitch, stride, (const double*)rb, add ? 1 : 0);
+    PL_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int pl_halo(pl_ctx* ctx, const PlGeom& g, double* planes, int nplanes, long long plane_stride, int depth, bool add) {
+    if (ctx->nranks <= 1) return 0;
+    return pl_halo_generic(ctx, g.lnz, g.lnx, planes + pl_idx(g, 0, 0), g.pitch, nplanes, plane_stride, depth, add);
+}
+
+// ---- replicated level from per-rank blocks ------------------------------------------------------------------------
+struct GatherDesc { int Pz, Px, nz, nx, maxblk, nplanes; };
+__device__ inline void gather_block(const GatherDesc& d, int r, int& i0, int& ni, int& j0, int& nj) {
+    const int pz = r / d.Px, px = r % d.Px, Cz = (d.nz - 1) / d.Pz, Cx = (d.nx - 1) / d.Px;
+    i0 = pz * Cz; ni = (pz == d.Pz - 1) ? Cz + 1 : Cz; j0 = px * Cx; nj = (px == d.Px - 1) ? Cx + 1 : Cx;
+}
+// buf layout: rank-major, then plane, then the block row-major (padded to maxblk)
+__global__ __launch_bounds__(256) void k_blocks_copy(GatherDesc d, int rank_lo, int rank_hi, double* __restrict__ origin, long long pitch,
+                                                     long long stride, double* __restrict__ buf, int to_buf) {
+    const long long per = (long long)d.nplanes * d.maxblk, total = (long long)(rank_hi - rank_lo) * per;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        const int r = rank_lo + (int)(t / per);
+        const long long l = t % per;
+        const int q = (int)(l / d.maxblk), e = (int)(l % d.maxblk);
+        int i0, ni, j0, nj;
+        gather_block(d, r, i0, ni, j0, nj);
+        if (e >= ni * nj) continue;
+        double* p = origin + q * stride + (long long)(i0 + e / nj) * pitch + (j0 + e % nj);
+        double* b = buf + (to_buf ? l : t);                      // the send buffer holds one rank's share only
+        if (to_buf) *b = *p; else *p = *b;
+    }
+}
+
+int pl_gather_blocks(pl_ctx* ctx, const PlGeom& g, double* planes, int nplanes, long long stride) {
+    if (ctx->nranks <= 1) return 0;
+    if ((g.nz - 1) % ctx->Pz || (g.nx - 1) % ctx->Px) return pl_fail(ctx, "pl_gather_blocks: level not divisible into blocks");
+    GatherDesc d{ctx->Pz, ctx->Px, g.nz, g.nx, 0, nplanes};
+    d.maxblk = ((g.nz - 1) / ctx->Pz + 1) * ((g.nx - 1) / ctx->Px + 1);
+    const long long per = (long long)nplanes * d.maxblk;
+    double *sb, *rb;
+    PL_TRY(pl_buf(ctx, "gather_send", (size_t)per * sizeof(double), &sb, true));
+    PL_TRY(pl_buf(ctx, "gather_recv", (size_t)per * ctx->nranks * sizeof(double), &rb, false));
+    double* origin = planes + pl_idx(g, -g.gi0, -g.gj0);        // global node (0,0)
+    const unsigned nb1 = (unsigned)std::min<long long>((per + 255) / 256, 1024), nbR = (unsigned)std::min<long long>((per * ctx->nranks + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_blocks_copy, dim3(nb1), dim3(256), 0, ctx->stream, d, ctx->rank, ctx->rank + 1, origin, (long long)g.pitch, stride, sb, 1);
+    PL_TRY(pl_comm_allgather(ctx, sb, rb, per));
+    hipLaunchKernelGGL(k_blocks_copy, dim3(nbR), dim3(256), 0, ctx->stream, d, 0, ctx->nranks, origin, (long long)g.pitch, stride, rb, 0);
+    PL_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+// ---- native transport set-up ---------------------------------------------------------------------------------------
 void pl_comm_native_free(pl_ctx* ctx) {
     PlNccl* N = nccl_of(ctx);
     if (!N) return;
@@ -56,109 +351,11 @@ void pl_comm_native_free(pl_ctx* ctx) {
     ctx->nccl = nullptr;
 }
 
-// ---- native primitives ---------------------------------------------------------------------------
-static int native_exchange(pl_ctx* ctx, const double* send_lo, double* recv_lo, const double* send_hi, double* recv_hi,
-                           long long count, int nseg, long long stride, int add) {
-    PlNccl* N = nccl_of(ctx);
-    const int lo = ctx->rank - 1, hi = ctx->rank + 1;
-    const bool has_lo = lo >= 0, has_hi = hi < ctx->nranks;
-    double* tmp = nullptr;
-    if (add) PL_TRY(pl_buf(ctx, "nccl_tmp", (size_t)2 * nseg * count * sizeof(double), &tmp, false));
-    int rc = N->GroupStart();
-    for (int k = 0; k < nseg && !rc; k++) {
-        const long long o = (long long)k * stride;
-        if (has_lo) {
-            rc |= N->Send(send_lo + o, (size_t)count, PL_NCCL_DOUBLE, lo, N->comm, ctx->stream);
-            rc |= N->Recv(add ? tmp + (long long)k * count : recv_lo + o, (size_t)count, PL_NCCL_DOUBLE, lo, N->comm, ctx->stream);
-        }
-        if (has_hi) {
-            rc |= N->Send(send_hi + o, (size_t)count, PL_NCCL_DOUBLE, hi, N->comm, ctx->stream);
-            rc |= N->Recv(add ? tmp + (long long)(nseg + k) * count : recv_hi + o, (size_t)count, PL_NCCL_DOUBLE, hi, N->comm, ctx->stream);
-        }
-    }
-    rc |= N->GroupEnd();
-    if (rc) return pl_fail(ctx, "RCCL neighbour exchange failed");
-    if (add) {
-        const unsigned nb = (unsigned)((count + 255) / 256 > 1024 ? 1024 : (count + 255) / 256);
-        for (int k = 0; k < nseg; k++) {
-            if (has_lo) hipLaunchKernelGGL(k_comm_add, dim3(nb), dim3(256), 0, ctx->stream, count, recv_lo + (long long)k * stride, tmp + (long long)k * count);
-            if (has_hi) hipLaunchKernelGGL(k_comm_add, dim3(nb), dim3(256), 0, ctx->stream, count, recv_hi + (long long)k * stride, tmp + (long long)(nseg + k) * count);
-        }
-    }
-    return 0;
+__global__ void k_comm_fill(long long n, double* __restrict__ d, double v) {
+    long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; k < n; k += (long long)gridDim.x * blockDim.x) d[k] = v;
 }
 
-static int native_allgather(pl_ctx* ctx, double* recv, long long count, int nseg, long long stride) {
-    PlNccl* N = nccl_of(ctx);
-    int rc = 0;
-    for (int k = 0; k < nseg && !rc; k++) {
-        double* base = recv + (long long)k * stride;
-        rc = N->AllGather(base + (long long)ctx->rank * count, base, (size_t)count, PL_NCCL_DOUBLE, N->comm, ctx->stream);
-    }
-    if (rc) return pl_fail(ctx, "RCCL all-gather failed");
-    return 0;
-}
-
-// ---- public dispatch -------------------------------------------------------------------------------
-int pl_comm_exchange(pl_ctx* ctx, const double* send_lo, double* recv_lo, const double* send_hi, double* recv_hi,
-                     long long count, int nseg, long long stride, int add) {
-    if (ctx->nranks <= 1) return 0;
-    ctx->comm_calls[0]++;
-    PlNccl* N = nccl_of(ctx);
-    if (N && N->ok) return native_exchange(ctx, send_lo, recv_lo, send_hi, recv_hi, count, nseg, stride, add);
-    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->comm.exchange(ctx->comm.user, send_lo, recv_lo, send_hi, recv_hi, count, nseg, stride, add))
-        return pl_fail(ctx, "communication callback 'exchange' failed");
-    return 0;
-}
-
-int pl_comm_allgather(pl_ctx* ctx, double* recv, long long count, int nseg, long long stride) {
-    if (ctx->nranks <= 1) return 0;
-    ctx->comm_calls[1]++;
-    PlNccl* N = nccl_of(ctx);
-    if (N && N->ok) return native_allgather(ctx, recv, count, nseg, stride);
-    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->comm.allgather(ctx->comm.user, recv, count, nseg, stride))
-        return pl_fail(ctx, "communication callback 'allgather' failed");
-    return 0;
-}
-
-// variable-size neighbour exchange of tracer columns; counts always travel through the host table
-int pl_comm_exchange_var(pl_ctx* ctx, double* const* send_lo, long long n_lo, double* const* send_hi, long long n_hi,
-                         double* const* recv, long long cap, int ncol, long long* got) {
-    *got = 0;
-    if (ctx->nranks <= 1) return 0;
-    PlNccl* N = nccl_of(ctx);
-    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (!(N && N->ok)) {
-        int64_t g = 0;
-        if (ctx->comm.exchange_var(ctx->comm.user, send_lo, n_lo, send_hi, n_hi, recv, cap, ncol, &g))
-            return pl_fail(ctx, "communication callback 'exchange_var' failed (tracer migration)");
-        *got = g;
-        return 0;
-    }
-    // what do my neighbours send me?  slot r*2 = count rank r sends down (to r-1), r*2+1 = up (to r+1)
-    std::vector<double> c((size_t)2 * ctx->nranks, 0.0);
-    c[2 * ctx->rank] = (double)n_lo; c[2 * ctx->rank + 1] = (double)n_hi;
-    PL_TRY(pl_allreduce_host(ctx, c.data(), (long long)c.size(), 0));
-    const int lo = ctx->rank - 1, hi = ctx->rank + 1;
-    const long long m_lo = lo >= 0 ? (long long)c[2 * lo + 1] : 0, m_hi = hi < ctx->nranks ? (long long)c[2 * hi] : 0;
-    if (m_lo + m_hi > cap) return pl_fail(ctx, "tracer migration exceeds the receive capacity");
-    int rc = N->GroupStart();
-    for (int k = 0; k < ncol && !rc; k++) {
-        if (lo >= 0 && n_lo) rc |= N->Send(send_lo[k], (size_t)n_lo, PL_NCCL_DOUBLE, lo, N->comm, ctx->stream);
-        if (hi < ctx->nranks && n_hi) rc |= N->Send(send_hi[k], (size_t)n_hi, PL_NCCL_DOUBLE, hi, N->comm, ctx->stream);
-        if (m_lo) rc |= N->Recv(recv[k], (size_t)m_lo, PL_NCCL_DOUBLE, lo, N->comm, ctx->stream);
-        if (m_hi) rc |= N->Recv(recv[k] + m_lo, (size_t)m_hi, PL_NCCL_DOUBLE, hi, N->comm, ctx->stream);
-    }
-    rc |= N->GroupEnd();
-    if (rc) return pl_fail(ctx, "RCCL tracer migration failed");
-    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    *got = m_lo + m_hi;
-    return 0;
-}
-
-// ---- set-up -------------------------------------------------------------------------------------------
 #define PL_SYM(field, name) \
     N->field = (decltype(N->field))dlsym(N->lib, name); \
     if (!N->field) good = false;
@@ -184,7 +381,7 @@ int pl_comm_native_init(pl_ctx* ctx) {
         PL_SYM(GroupStart, "ncclGroupStart") PL_SYM(GroupEnd, "ncclGroupEnd")
         N->CommAbort = (decltype(N->CommAbort))dlsym(N->lib, "ncclCommAbort");      // optional
     }
-    // 1. does every rank have the library?
+    // 1. does every rank want it and have the library?
     double flag[1] = {good ? 1.0 : 0.0};
     PL_TRY(pl_allreduce_host(ctx, flag, 1, 1));
     if (flag[0] < 0.5) return 0;
@@ -202,11 +399,12 @@ int pl_comm_native_init(pl_ctx* ctx) {
     flag[0] = (rc == 0) ? 1.0 : 0.0;
     PL_TRY(pl_allreduce_host(ctx, flag, 1, 1));
     if (flag[0] < 0.5) { N->comm = nullptr; return 0; }
-    // 3. self-test: ring exchange (forward and accumulating) and all-gather against known values
+    // 3. self-test: ring send/recv in both directions, all-gather and all-reduce against known values
     N->ok = true;
     const long long cnt = 64; const int R = ctx->nranks, r = ctx->rank;
+    const long long total = 4 * cnt + (long long)R * cnt + 2;
     double* t = nullptr;
-    bool pass = pl_buf(ctx, "nccl_selftest", (size_t)(6 * cnt + R * cnt + 2) * sizeof(double), &t, true) == 0;
+    bool pass = pl_buf(ctx, "nccl_selftest", (size_t)total * sizeof(double), &t, true) == 0;
     // The self-test runs on a stream of its own and is given 60 s: a transport that hangs must not take the solver
     // stream (and the whole job) with it - the communicator is aborted and the callback table is used instead.
     hipStream_t main_stream = ctx->stream, test_stream = nullptr;
@@ -214,18 +412,21 @@ int pl_comm_native_init(pl_ctx* ctx) {
     if (pass) { (void)hipStreamSynchronize(main_stream); ctx->stream = test_stream; }
     bool hung = false;
     std::vector<double>& h = N->selftest_host;
-    h.assign((size_t)(6 * cnt + R * cnt + 2), 0.0);
+    h.assign((size_t)total, 0.0);
     if (pass) {
-        // layout: [recv_lo | own_first | own_last | recv_hi | acc_lo | acc_hi | gather(R*cnt) | all-reduce(2)]
-        hipLaunchKernelGGL(k_comm_fill, dim3(1), dim3(64), 0, ctx->stream, 2, t + 6 * cnt + (long long)R * cnt, 1.0 + r);
+        // layout: [recv_from_prev | send_to_prev | send_to_next | recv_from_next | gather(R*cnt) | all-reduce(2)]
         hipLaunchKernelGGL(k_comm_fill, dim3(1), dim3(64), 0, ctx->stream, cnt, t + cnt, 100.0 + r);
         hipLaunchKernelGGL(k_comm_fill, dim3(1), dim3(64), 0, ctx->stream, cnt, t + 2 * cnt, 200.0 + r);
-        hipLaunchKernelGGL(k_comm_fill, dim3(1), dim3(64), 0, ctx->stream, 2 * cnt, t + 4 * cnt, 1.0);
-        hipLaunchKernelGGL(k_comm_fill, dim3(1), dim3(64), 0, ctx->stream, cnt, t + 6 * cnt + (long long)r * cnt, 300.0 + r);
-        pass = native_exchange(ctx, t + cnt, t, t + 2 * cnt, t + 3 * cnt, cnt, 1, 0, 0) == 0 &&
-               native_exchange(ctx, t + cnt, t + 4 * cnt, t + 2 * cnt, t + 5 * cnt, cnt, 1, 0, 1) == 0 &&
-               native_allgather(ctx, t + 6 * cnt, cnt, 1, 0) == 0 &&
-               pl_comm_allreduce_dev(ctx, t + 6 * cnt + (long long)R * cnt, 2) == 0 &&
+        hipLaunchKernelGGL(k_comm_fill, dim3(1), dim3(64), 0, ctx->stream, 2, t + 4 * cnt + (long long)R * cnt, 1.0 + r);
+        double* mine = nullptr;
+        pass = pl_buf(ctx, "nccl_selftest_mine", (size_t)cnt * sizeof(double), &mine, false) == 0;
+        if (pass) hipLaunchKernelGGL(k_comm_fill, dim3(1), dim3(64), 0, ctx->stream, cnt, mine, 300.0 + r);
+        PlMsg m[2]; int nm = 0;
+        if (r > 0) m[nm++] = PlMsg{r - 1, t + cnt, cnt, t, cnt};
+        if (r < R - 1) m[nm++] = PlMsg{r + 1, t + 2 * cnt, cnt, t + 3 * cnt, cnt};
+        pass = pass && (nm == 0 || pl_comm_sendrecv(ctx, m, nm) == 0) &&
+               N->AllGather(mine, t + 4 * cnt, (size_t)cnt, PL_NCCL_DOUBLE, N->comm, ctx->stream) == 0 &&
+               N->AllReduce(t + 4 * cnt + (long long)R * cnt, t + 4 * cnt + (long long)R * cnt, 2, PL_NCCL_DOUBLE, PL_NCCL_SUM, N->comm, ctx->stream) == 0 &&
                hipMemcpyAsync(h.data(), t, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
         if (pass) {
             const auto t0 = std::chrono::steady_clock::now();
@@ -245,12 +446,12 @@ int pl_comm_native_init(pl_ctx* ctx) {
     if (test_stream && !hung) (void)hipStreamDestroy(test_stream);       // a hung stream is abandoned
     if (pass) {
         for (long long k = 0; k < cnt && pass; k++) {
-            if (r > 0 && (h[k] != 200.0 + (r - 1) || h[4 * cnt + k] != 1.0 + 200.0 + (r - 1))) pass = false;
-            if (r < R - 1 && (h[3 * cnt + k] != 100.0 + (r + 1) || h[5 * cnt + k] != 1.0 + 100.0 + (r + 1))) pass = false;
-            for (int q = 0; q < R && pass; q++) if (h[6 * cnt + (long long)q * cnt + k] != 300.0 + q) pass = false;
+            if (r > 0 && h[k] != 200.0 + (r - 1)) pass = false;
+            if (r < R - 1 && h[3 * cnt + k] != 100.0 + (r + 1)) pass = false;
+            for (int q = 0; q < R && pass; q++) if (h[4 * cnt + (long long)q * cnt + k] != 300.0 + q) pass = false;
         }
-        const double want = 0.5 * R * (R + 1);                     // sum over ranks of (1 + r)
-        if (h[6 * cnt + (long long)R * cnt] != want || h[6 * cnt + (long long)R * cnt + 1] != want) pass = false;
+        const double want_sum = 0.5 * R * (R + 1);                 // sum over ranks of (1 + r)
+        if (h[4 * cnt + (long long)R * cnt] != want_sum || h[4 * cnt + (long long)R * cnt + 1] != want_sum) pass = false;
     }
     flag[0] = pass ? 1.0 : 0.0;
     PL_TRY(pl_allreduce_host(ctx, flag, 1, 1));
@@ -261,15 +462,3 @@ int pl_comm_native_init(pl_ctx* ctx) {
     }
     return 0;
 }
-
-// in-place sum all-reduce of n doubles in DEVICE memory on the context stream (native path only)
-int pl_comm_allreduce_dev(pl_ctx* ctx, double* dev, int n) {
-    PlNccl* N = nccl_of(ctx);
-    if (!(N && N->ok)) return 1;
-    ctx->comm_calls[2]++;
-    if (N->AllReduce(dev, dev, (size_t)n, PL_NCCL_DOUBLE, PL_NCCL_SUM, N->comm, ctx->stream))
-        return pl_fail(ctx, "RCCL all-reduce failed");
-    return 0;
-}
-
-int pl_comm_native_enabled(pl_ctx* ctx) { PlNccl* N = nccl_of(ctx); return (N && N->ok) ? 1 : 0; }

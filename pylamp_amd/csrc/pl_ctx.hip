@@ -90,13 +90,6 @@ void pl_geom_set_block(PlGeomHost& gh, int gi0, int lnz, int gj0, int lnx) {
     g.plane = (long long)(lnz + 2 * PL_RING) * g.pitch;
 }
 
-int pl_allreduce_host(pl_ctx* ctx, double* buf, long long n, int op) {
-    if (ctx->nranks <= 1) return 0;
-    ctx->comm_calls[3]++;
-    if (ctx->comm.allreduce_host(ctx->comm.user, buf, n, op)) return pl_fail(ctx, "communication callback 'allreduce_host' failed");
-    return 0;
-}
-
 // block of this rank; the checks every transport shares
 static int set_layout(pl_ctx* ctx, int rank, int Pz, int Px) {
     const int nranks = Pz * Px;
@@ -153,13 +146,6 @@ extern "C" int pl_set_comm_local(pl_ctx* ctx, pl_local_group* g, int rank, int P
 // cumulative counts of the communication calls issued by this context (reset = 1 clears them afterwards)
 extern "C" int pl_comm_stats(pl_ctx* ctx, int64_t out[4], int reset) {
     for (int k = 0; k < 4; k++) { if (out) out[k] = ctx->comm_calls[k]; if (reset) ctx->comm_calls[k] = 0; }
-    return 0;
-}
-
-extern "C" int pl_comm_info(pl_ctx* ctx, int* rank, int* nranks, int* native) {
-    if (rank) *rank = ctx->rank;
-    if (nranks) *nranks = ctx->nranks;
-    if (native) *native = pl_comm_native_enabled(ctx);
     return 0;
 }
 

@@ -17,15 +17,16 @@ struct PlScatterArgs {
     // rectilinear target node set: coordinates of the nz / nx nodes; NULL = regular (z0, hz, x0, hx)
     const double* zc; const double* xc;
     int nz, nx;
-    // dense accumulators of nrows x nx doubles; accumulator row 0 is GLOBAL node row `row0`
-    // (single rank / host API: row0 = 0, nrows = nz; slab: row0 = gi0-1, nrows = lnz+2)
-    int row0, nrows;
+    // dense accumulators of nrows x ncols doubles; accumulator element (0,0) is GLOBAL node (row0, col0)
+    // (host API: row0 = col0 = 0, nrows = nz, ncols = nx; resident block: row0 = gi0-1, nrows = lnz+2, col0 = gj0-1,
+    // ncols = lnx+2 -- one ring of nodes that belong to the neighbour blocks)
+    int row0, nrows, col0, ncols;
     double* wsum; double* cnt;
     double* acc[PL_MAX_SCATTER_FIELDS];
     // cell-sorted tracers (optional): tracers of sort cell (ci,cj) are [cell_start[ci*ncx+cj],
     // cell_start[ci*ncx+cj+1]); the sort grid has ncz x ncx cells.  NULL -> unsorted path.
     const int* cell_start; int ncz, ncx;
-    int crow0;                  // global cell row of sort row 0
+    int crow0, ccol0;           // global cell row / column of sort cell (0,0)
 };
 
 // tile of sort cells handled by one workgroup of the LDS-binned scatter
@@ -39,6 +40,9 @@ struct PlGatherGrid {
     double sz, sx;              // (nz-1)/Lz, (nx-1)/Lx (filled by the launch wrappers)
     int rect;                   // 1: cells located by per-axis search in gz/gx (non-uniform grids), 0: the reference's regular formula
     long long pitch, off;       // field element (i,j) is F[off + i*pitch + j] (dense: pitch = nx, off = 0)
+    // cells [ie_lo, ie_hi] x [je_lo, je_hi] are held in memory (a rank's window of the field; all zero: the whole
+    // grid).  A lookup outside is clamped into the window and counted in *n_outside_window by the kernels that have it.
+    int ie_lo, ie_hi, je_lo, je_hi;
 };
 
 struct PlGatherArgs {
@@ -62,6 +66,7 @@ struct PlRk4Args {
     double dt;
     double* tz_out; double* tx_out; double* vz_out; double* vx_out;
     int fence; double eps, Lz, Lx;                 // optional fence of pylamp2.py:563-570
+    unsigned long long* n_outside_window;          // stage positions whose cell lies outside the local window (or NULL)
 };
 
 // Cell index and in-cell coordinate on a rectilinear axis c[0..n-1] (largest ie with c[ie] <= z; a marker exactly
@@ -83,9 +88,9 @@ __device__ inline void mic_axis_locate(const double* __restrict__ c, int n, doub
     ie = lo; a = (z - c[lo]) / (c[lo + 1] - c[lo]);
 }
 
-// slab != NULL: accumulators carry one ring row on each side; they are summed across ranks
-// (reverse halo), only the owned rows are finalised into the ring planes `out`, whose ring rows are
-// then filled by a forward halo exchange.
+// slab != NULL (the rank's block): accumulators carry one ring of nodes; they are summed across ranks
+// (reverse halo with the 8 neighbour blocks), only the owned nodes are finalised into the ring planes `out`,
+// whose halo is then filled by a forward exchange.
 int pl_scatter_device(pl_ctx* ctx, PlScatterArgs& a, double* const* out, long long out_pitch, long long out_off,
                       const PlGeom* slab = nullptr);
 void pl_launch_gather(pl_ctx* ctx, const PlGatherArgs& a);

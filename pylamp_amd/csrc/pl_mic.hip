@@ -75,8 +75,8 @@ __global__ __launch_bounds__(256) void k_scatter_atomic(PlScatterArgs a) {
     for (int cnr = 0; cnr < 4; cnr++) {
         const int ni = ie + (cnr & 1), nj = je + (cnr >> 1);
         if (ni < 0 || ni >= a.nz || nj < 0 || nj >= a.nx) continue;
-        if (ni < a.row0 || ni >= a.row0 + a.nrows) continue;
-        const long long o = (long long)(ni - a.row0) * a.nx + nj;
+        if (ni < a.row0 || ni >= a.row0 + a.nrows || nj < a.col0 || nj >= a.col0 + a.ncols) continue;
+        const long long o = (long long)(ni - a.row0) * a.ncols + (nj - a.col0);
         if (a.wsum) mic_atomic_add(a.wsum + o, w[cnr]);
         if (a.cnt) mic_atomic_add(a.cnt + o, 1.0);
         for (int k = 0; k < a.nf; k++)
@@ -150,11 +150,12 @@ __global__ __launch_bounds__(256) void k_scatter_binned(PlScatterArgs a, int til
 #pragma unroll
             for (int cnr = 0; cnr < 4; cnr++) {
                 const int ni = ie + (cnr & 1), nj = je + (cnr >> 1);
-                const bool ok = valid && ni >= 0 && ni < a.nz && nj >= 0 && nj < a.nx && ni >= a.row0 && ni < a.row0 + a.nrows;
-                const int li = ni - ni0, lj = nj - (cj0 - 1);
+                const bool ok = valid && ni >= 0 && ni < a.nz && nj >= 0 && nj < a.nx && ni >= a.row0 && ni < a.row0 + a.nrows &&
+                                nj >= a.col0 && nj < a.col0 + a.ncols;
+                const int li = ni - ni0, lj = nj - (a.ccol0 + cj0 - 1);
                 const bool in_win = li >= 0 && li < H && lj >= 0 && lj < W;
                 const int o = li * W + lj;
-                const long long go = (long long)(ni - a.row0) * a.nx + nj;
+                const long long go = (long long)(ni - a.row0) * a.ncols + (nj - a.col0);
                 for (int q = 0; q < nacc; q++) {
                     if (q == 0 && !a.wsum) continue;                              // wave-uniform
                     if (q == 1 && !a.cnt) continue;
@@ -171,10 +172,10 @@ __global__ __launch_bounds__(256) void k_scatter_binned(PlScatterArgs a, int til
     }
     __syncthreads();
     for (int o = tid; o < WH; o += 256) {
-        const int ni = ni0 + o / W, nj = cj0 - 1 + o % W;
+        const int ni = ni0 + o / W, nj = a.ccol0 + cj0 - 1 + o % W;
         if (ni < 0 || ni >= a.nz || nj < 0 || nj >= a.nx) continue;
-        if (ni < a.row0 || ni >= a.row0 + a.nrows) continue;
-        const long long go = (long long)(ni - a.row0) * a.nx + nj;
+        if (ni < a.row0 || ni >= a.row0 + a.nrows || nj < a.col0 || nj >= a.col0 + a.ncols) continue;
+        const long long go = (long long)(ni - a.row0) * a.ncols + (nj - a.col0);
         if (a.wsum) { const double v = lds[o]; if (v != 0.0) mic_atomic_add(a.wsum + go, v); }
         if (a.cnt) { const double v = lds[WH + o]; if (v != 0.0) mic_atomic_add(a.cnt + go, v); }
         for (int k = 0; k < a.nf; k++) { const double v = lds[(2 + k) * WH + o]; if (v != 0.0) mic_atomic_add(a.acc[k] + go, v); }
@@ -182,13 +183,14 @@ __global__ __launch_bounds__(256) void k_scatter_binned(PlScatterArgs a, int til
 }
 
 // out = g^-1(acc / den), written into a ring/pitch plane or a dense (nz,nx) array
+// acc / den point at the accumulator element of output node (0,0); acc_pitch = accumulator columns
 __global__ __launch_bounds__(256) void k_scatter_finalize(int nz, int nx, const double* __restrict__ acc,
-                                                          const double* __restrict__ den, int scheme,
+                                                          const double* __restrict__ den, long long acc_pitch, int scheme,
                                                           double* __restrict__ out, long long out_pitch,
                                                           long long out_off) {
     const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
     if (j >= nx || i >= nz) return;
-    const long long o = (long long)i * nx + j;
+    const long long o = (long long)i * acc_pitch + j;
     double s = acc[o];
     const double d = den[o];
     double r;
@@ -210,9 +212,9 @@ int pl_scatter_device(pl_ctx* ctx, PlScatterArgs& a, double* const* out, long lo
         if (s & PL_AVG_WEIGHTED) has_w = true; else has_c = true;
     }
     a.rhz = 1.0 / a.hz; a.rhx = 1.0 / a.hx;
-    if (slab) { a.row0 = slab->gi0 - 1; a.nrows = slab->lnz + 2; }
-    else { a.row0 = 0; a.nrows = a.nz; }
-    size_t N = (size_t)a.nrows * a.nx;
+    if (slab) { a.row0 = slab->gi0 - 1; a.nrows = slab->lnz + 2; a.col0 = slab->gj0 - 1; a.ncols = slab->lnx + 2; }
+    else { a.row0 = 0; a.nrows = a.nz; a.col0 = 0; a.ncols = a.nx; }
+    size_t N = (size_t)a.nrows * a.ncols;
     double* accbuf;
     PL_TRY(pl_buf(ctx, "scatter_acc", (size_t)(a.nf + 2) * N * sizeof(double), &accbuf, false));
     PL_HIP(ctx, hipMemsetAsync(accbuf, 0, (size_t)(a.nf + 2) * N * sizeof(double), ctx->stream));
@@ -228,32 +230,39 @@ int pl_scatter_device(pl_ctx* ctx, PlScatterArgs& a, double* const* out, long lo
         hipLaunchKernelGGL(k_scatter_atomic, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, ctx->stream, a);
         PL_HIP(ctx, hipGetLastError());
     }
-    int frows = a.nrows; const double* fbase = accbuf;
+    int frows = a.nrows, fcols = a.ncols; const double* fbase = accbuf;
     if (slab) {
-        if (ctx->nranks > 1) {
-            // reverse halo: my ring rows are added to the neighbours' first / last owned rows
-            const long long nx = a.nx;
-            PL_TRY(pl_comm_exchange(ctx, accbuf, accbuf + nx, accbuf + (long long)(slab->lnz + 1) * nx,
-                                    accbuf + (long long)slab->lnz * nx, nx, a.nf + 2, (long long)N, 1));
-        }
-        frows = slab->lnz; fbase = accbuf + a.nx;           // owned rows only
+        // reverse halo: what I accumulated for nodes of the neighbour blocks is added to their accumulators
+        if (ctx->nranks > 1)
+            PL_TRY(pl_halo_generic(ctx, slab->lnz, slab->lnx, accbuf + a.ncols + 1, a.ncols, a.nf + 2, (long long)N, 1, true));
+        frows = slab->lnz; fcols = slab->lnx; fbase = accbuf + a.ncols + 1;           // owned nodes only
     }
-    dim3 g2((a.nx + 63) / 64, (frows + 3) / 4);
+    dim3 g2((fcols + 63) / 64, (frows + 3) / 4);
     for (int k = 0; k < a.nf; k++) {
         const double* den = (a.scheme[k] & PL_AVG_WEIGHTED) ? fbase : fbase + N;
-        hipLaunchKernelGGL(k_scatter_finalize, g2, dim3(64, 4), 0, ctx->stream, frows, a.nx, fbase + (size_t)(2 + k) * N, den,
-                           a.scheme[k], out[k], out_pitch, out_off);
+        hipLaunchKernelGGL(k_scatter_finalize, g2, dim3(64, 4), 0, ctx->stream, frows, fcols, fbase + (size_t)(2 + k) * N, den,
+                           (long long)a.ncols, a.scheme[k], out[k], out_pitch, out_off);
     }
     PL_HIP(ctx, hipGetLastError());
     if (slab && ctx->nranks > 1)
-        for (int k = 0; k < a.nf; k++) PL_TRY(pl_halo_rows(ctx, *slab, out[k], 1, slab->plane));
+        for (int k = 0; k < a.nf; k++) PL_TRY(pl_halo(ctx, *slab, out[k], 1, slab->plane, 2));
     return 0;
 }
 
 // ---------------------------------------------------------------------------------------
 // Gather (grid2trac) and RK4
 // ---------------------------------------------------------------------------------------
-struct CellLoc { int ie, je; bool bad; double a, b; };
+struct CellLoc { int ie, je; bool bad, oow; double a, b; };
+
+// keep the cell inside the window of the field this rank holds (no-op for a whole grid: all bounds zero)
+__device__ inline void mic_window(const PlGatherGrid& g, CellLoc& c) {
+    c.oow = false;
+    if (g.ie_hi | g.je_hi) {
+        const int i2 = min(max(c.ie, g.ie_lo), g.ie_hi), j2 = min(max(c.je, g.je_lo), g.je_hi);
+        c.oow = !c.bad && (i2 != c.ie || j2 != c.je);
+        c.ie = i2; c.je = j2;
+    }
+}
 
 // Cell lookup + normalised in-cell coordinates exactly as pylamp_trac.py:42-52,63-75,89-90.
 // A cell index equal to n-1 passes the reference's range test but then indexes one past
@@ -265,6 +274,7 @@ __device__ inline CellLoc mic_locate(const PlGatherGrid& g, double z, double x) 
         c.ie = 0; c.je = 0; c.a = 0.0; c.b = 0.0;
         if (!c.bad) { mic_axis_locate(g.gz, g.nz, z, c.ie, c.a); mic_axis_locate(g.gx, g.nx, x, c.je, c.b); }
         else { c.a = (z - g.gz[0]) / (g.gz[1] - g.gz[0]); c.b = (x - g.gx[0]) / (g.gx[1] - g.gx[0]); }   // cell (0,0), as the strict path
+        mic_window(g, c);
         return c;
     }
     const double fi = floor((z - g.zmin) * g.sz);          // the reference divides, (nz-1)(z-zmin)/Lz: same cell except within
@@ -272,6 +282,7 @@ __device__ inline CellLoc mic_locate(const PlGatherGrid& g, double z, double x) 
     c.bad = !(fi >= 0.0 && fi <= (double)(g.nz - 2) && fj >= 0.0 && fj <= (double)(g.nx - 2));
     c.ie = c.bad ? 0 : (int)fi;
     c.je = c.bad ? 0 : (int)fj;
+    mic_window(g, c);
     const double dz0 = z - g.gz[c.ie], dz1 = g.gz[c.ie + 1] - z;
     const double dx0 = x - g.gx[c.je], dx1 = g.gx[c.je + 1] - x;
     c.a = dz0 / (dz0 + dz1);
@@ -288,7 +299,7 @@ __device__ inline double mic_bilinear(const double* __restrict__ F, const PlGath
 // divergence-conserving velocity interpolation (pylamp_trac.py:98-154)
 __device__ inline void mic_veldiv(const PlGatherGrid& g, const double* __restrict__ Vz,
                                   const double* __restrict__ Vx, double z, double x, double defval, double& uz,
-                                  double& ux, bool& bad) {
+                                  double& ux, bool& bad, bool& oow) {
     const CellLoc c = mic_locate(g, z, x);
     const long long o = g.off + (long long)c.ie * g.pitch + c.je;
     const double hz = g.gz[c.ie + 1] - g.gz[c.ie], hx = g.gx[c.je + 1] - g.gx[c.je];
@@ -303,6 +314,7 @@ __device__ inline void mic_veldiv(const PlGatherGrid& g, const double* __restric
     // out-of-grid tracer; vz keeps the value extrapolated from cell (0,0).
     if (c.bad) ux = defval;
     bad = c.bad;
+    oow = oow || c.oow;
 }
 
 __global__ __launch_bounds__(256) void k_gather(PlGatherArgs a) {
@@ -327,8 +339,8 @@ __global__ __launch_bounds__(256) void k_gather(PlGatherArgs a) {
         }
         if (c.bad) atomicAdd(a.n_outside, 1ull);
     } else {
-        double uz, ux; bool bad;
-        mic_veldiv(a.g, a.fields[0], a.fields[1], z, x, a.defval, uz, ux, bad);
+        double uz, ux; bool bad, oow = false;
+        mic_veldiv(a.g, a.fields[0], a.fields[1], z, x, a.defval, uz, ux, bad, oow);
         a.out[0][t] = uz; a.out[1][t] = ux;
         if (bad) atomicAdd(a.n_outside, 1ull);
     }
@@ -340,11 +352,12 @@ __global__ __launch_bounds__(256) void k_rk4(PlRk4Args a) {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= a.n) return;
     const double z = a.tz[t], x = a.tx[t], dt = a.dt;
-    double k1z, k1x, k2z, k2x, k3z, k3x, k4z, k4x; bool bad;
-    mic_veldiv(a.g, a.Vz, a.Vx, z, x, 0.0, k1z, k1x, bad);
-    mic_veldiv(a.g, a.Vz, a.Vx, z + 0.5 * dt * k1z, x + 0.5 * dt * k1x, 0.0, k2z, k2x, bad);
-    mic_veldiv(a.g, a.Vz, a.Vx, z + 0.5 * dt * k2z, x + 0.5 * dt * k2x, 0.0, k3z, k3x, bad);
-    mic_veldiv(a.g, a.Vz, a.Vx, z + dt * k3z, x + dt * k3x, 0.0, k4z, k4x, bad);
+    double k1z, k1x, k2z, k2x, k3z, k3x, k4z, k4x; bool bad, oow = false;
+    mic_veldiv(a.g, a.Vz, a.Vx, z, x, 0.0, k1z, k1x, bad, oow);
+    mic_veldiv(a.g, a.Vz, a.Vx, z + 0.5 * dt * k1z, x + 0.5 * dt * k1x, 0.0, k2z, k2x, bad, oow);
+    mic_veldiv(a.g, a.Vz, a.Vx, z + 0.5 * dt * k2z, x + 0.5 * dt * k2x, 0.0, k3z, k3x, bad, oow);
+    mic_veldiv(a.g, a.Vz, a.Vx, z + dt * k3z, x + dt * k3x, 0.0, k4z, k4x, bad, oow);
+    if (oow && a.n_outside_window) atomicAdd(a.n_outside_window, 1ull);
     const double zn = z + (1.0 / 6.0) * dt * (k1z + k2z + k3z + k4z);
     const double xn = x + (1.0 / 6.0) * dt * (k1x + k2x + k3x + k4x);
     a.vz_out[t] = (zn - z) / dt; a.vx_out[t] = (xn - x) / dt;

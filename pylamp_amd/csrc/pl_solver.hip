@@ -908,7 +908,7 @@ __global__ __launch_bounds__(64) void k_hydro_chunk(PlStokesOp op, double* __res
     double* P = x + 2 * g.plane;
     const double* r = op.rho;
     const int l0 = ch * PL_HYDRO_CHUNK, l1 = min(l0 + PL_HYDRO_CHUNK, g.lnz);
-    const int jn = (lj + 1 < g.nx) ? 1 : 0;
+    const int jn = (g.gj0 + lj + 1 < g.nx) ? 1 : 0;
     double acc = 0.0;
     for (int li = l0; li < l1; li++) {
         const int i = g.gi0 + li;
@@ -939,7 +939,7 @@ __global__ __launch_bounds__(256) void k_hydrostatic_apply_shift(PlStokesOp op, 
     const PlGeom& g = op.g;
     double* P = x + 2 * g.plane;
     x[c] = 0.0; x[c + g.plane] = 0.0;
-    P[c] = (i >= g.nz - 1 || j >= g.nx - 1) ? 0.0 : P[c] + prefix[j] - pa;
+    P[c] = (i >= g.nz - 1 || j >= g.nx - 1) ? 0.0 : P[c] + prefix[lj] - pa;
 }
 
 // =========================================================================================
@@ -949,7 +949,7 @@ struct MgLevel {
     PlGeomHost gh;
     bool dist = false;          // rows decomposed over the ranks (halo exchanges needed)
     PlGeom win{};               // first tail level only: this rank's row window of the GLOBAL arrays
-    int win_rows0 = 0;
+    long long win_shift = 0;     // element offset of the window's node (0,0) inside the replicated planes
     PlVvOp op{};
     double* etas = nullptr; double* etan = nullptr; bool own_visc = false;
     double *rho = nullptr, *szz = nullptr, *szx = nullptr;     // free-surface stabilisation (allocated on first use)
@@ -1092,7 +1092,7 @@ static int dots(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const double*
     if (a && c) hipLaunchKernelGGL((k_dot2<true, true>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 8);
     else if (a) hipLaunchKernelGGL((k_dot2<true, false>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 8);
     else hipLaunchKernelGGL((k_dot2<false, true>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 8);
-    if (ctx->nranks > 1 && g.lnz != g.nz && pl_comm_native_enabled(ctx)) {
+    if (ctx->nranks > 1 && pl_geom_is_dist(g) && pl_comm_native_enabled(ctx)) {
         // slab + native RCCL: reduce on the device, all-reduce 2 doubles over xGMI, one 16-byte copy back
         hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, nb, S->scal + 8, S->scal);
         PL_TRY(pl_comm_allreduce_dev(ctx, S->scal, 2));
@@ -1106,13 +1106,13 @@ static int dots(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const double*
     double s0 = 0.0, s1 = 0.0;
     for (int k = 0; k < nb; k++) { s0 += S->hpart[2 * k]; s1 += S->hpart[2 * k + 1]; }
     out2[0] = s0; out2[1] = s1;
-    if (ctx->nranks > 1 && g.lnz != g.nz) PL_TRY(pl_allreduce_host(ctx, out2, 2, 0));
+    if (ctx->nranks > 1 && pl_geom_is_dist(g)) PL_TRY(pl_allreduce_host(ctx, out2, 2, 0));
     return 0;
 }
 
 // the device-scalar path needs the global sums on the device: one rank, or the native (stream-ordered) all-reduce
 static bool dots_on_device(pl_ctx* ctx, const PlGeom& g) {
-    return ctx->nranks == 1 || g.lnz == g.nz || pl_comm_native_enabled(ctx);
+    return ctx->nranks == 1 || !pl_geom_is_dist(g) || pl_comm_native_enabled(ctx);
 }
 // sums of the two dot products into S->scal[0..1], no host synchronisation
 // mode 1 / 2: alpha resp. omega are derived in the same pass (see k_sum_partials); with several ranks the sums
@@ -1124,7 +1124,7 @@ static int dots_dev(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const dou
     if (a && c) hipLaunchKernelGGL((k_dot2<true, true>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 8);
     else if (a) hipLaunchKernelGGL((k_dot2<true, false>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 8);
     else hipLaunchKernelGGL((k_dot2<false, true>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 8);
-    const bool reduce = ctx->nranks > 1 && g.lnz != g.nz;
+    const bool reduce = ctx->nranks > 1 && pl_geom_is_dist(g);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, nb, S->scal + 8, S->scal, reduce ? 0 : mode, rho_new);
     if (reduce) {
         PL_TRY(pl_comm_allreduce_dev(ctx, S->scal, 2));
@@ -1148,16 +1148,6 @@ static void level_flags(MgLevel* L, const PlStokesOp& sop, bool finest) {
     // NOSLIP extrapolation rows (pylamp_stokes.py:165-166,204-205): a0 v_s + a1 v_m = 0
     o.s0 = ns0 ? (1.0 / (z[2] - z[0])) / (1.0 / (z[2] - z[0]) + 1.0 / (z[1] - z[0])) : 1.0;
     o.sL = nsL ? (1.0 / (z[nz - 1] - z[nz - 3])) / (1.0 / (z[nz - 1] - z[nz - 3]) + 1.0 / (z[nz - 1] - z[nz - 2])) : 1.0;
-}
-
-// copy the last global node row of a replicated plane from the last rank to everybody
-static int share_last_row(pl_ctx* ctx, const PlGeom& gg, double* plane) {
-    std::vector<double> row((size_t)gg.pitch, 0.0);
-    double* p = plane + (long long)(gg.nz) * gg.pitch;          // row index nz-1 -> plane row nz
-    if (ctx->rank == ctx->nranks - 1) PL_HIP(ctx, hipMemcpy(row.data(), p, row.size() * sizeof(double), hipMemcpyDeviceToHost));
-    PL_TRY(pl_allreduce_host(ctx, row.data(), (long long)row.size(), 0));
-    PL_HIP(ctx, hipMemcpy(p, row.data(), row.size() * sizeof(double), hipMemcpyHostToDevice));
-    return 0;
 }
 
 static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
@@ -1203,16 +1193,20 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
             if (pl_geom_build(ctx, L->gh, nz, nx, zc.data(), xc.data())) { delete L; return 1; }
             if (S->repl_start < 0 && l > 0 && (long long)nz * nx <= S->repl_max_nodes) S->repl_start = l;
             if (R > 1 && S->repl_start < 0) {                     // distributed level
-                const int C = (nz - 1) / R;
-                if ((nz - 1) % R || C < 2) { delete L; return pl_fail(ctx, "multigrid: (nz-1) must be divisible by the number of ranks, with at least 2 node rows each"); }
+                const int Cz = (nz - 1) / ctx->Pz, Cx = (nx - 1) / ctx->Px;
+                if ((nz - 1) % ctx->Pz || (nx - 1) % ctx->Px || (ctx->Pz > 1 && Cz < 2) || (ctx->Px > 1 && Cx < 2)) {
+                    delete L; return pl_fail(ctx, "multigrid: the level cannot be divided into the rank blocks (at least 2 node rows / columns each)");
+                }
                 L->dist = true;
-                pl_geom_set_rows(L->gh, ctx->rank * C, (ctx->rank == R - 1) ? C + 1 : C);
+                int i0, ni, j0, nj;
+                pl_block_1d(nz, ctx->Pz, ctx->pz, &i0, &ni); pl_block_1d(nx, ctx->Px, ctx->px, &j0, &nj);
+                pl_geom_set_block(L->gh, i0, ni, j0, nj);
             }
-            if (R > 1 && l == S->repl_start) {                    // window of the replicated arrays
-                const int C = (nz - 1) / R;
-                if ((nz - 1) % R || C < 1) { delete L; return pl_fail(ctx, "multigrid: coarse grid smaller than the number of ranks"); }
-                L->win = L->gh.d; L->win.gi0 = ctx->rank * C; L->win.lnz = (ctx->rank == R - 1) ? C + 1 : C;
-                L->win_rows0 = ctx->rank * C;
+            if (R > 1 && l == S->repl_start) {                    // this rank's window of the replicated arrays
+                if ((nz - 1) % ctx->Pz || (nx - 1) % ctx->Px) { delete L; return pl_fail(ctx, "multigrid: coarse grid smaller than the number of ranks"); }
+                L->win = L->gh.d;
+                pl_block_1d(nz, ctx->Pz, ctx->pz, &L->win.gi0, &L->win.lnz); pl_block_1d(nx, ctx->Px, ctx->px, &L->win.gj0, &L->win.lnx);
+                L->win_shift = (long long)L->win.gi0 * L->gh.d.pitch + L->win.gj0;
             }
             size_t vb = (size_t)2 * L->gh.d.plane * sizeof(double), pb = (size_t)L->gh.d.plane * sizeof(double);
             if (l > 0) {
@@ -1223,9 +1217,9 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
             PL_TRY(dmalloc0(ctx, &L->f, vb)); PL_TRY(dmalloc0(ctx, &L->r, vb));
             S->levels.push_back(L);
             if ((nz - 1) % 2 || (nx - 1) % 2 || (nz - 1) / 2 < S->min_cells || (nx - 1) / 2 < S->min_cells) break;
-            // slabs with an odd number of rows cannot be halved rank by rank: this level stays the coarsest one
-            // (a distributed coarsest level is smoothed with a halo exchange per sweep - slow, but correct)
-            if (L->dist && (((nz - 1) / R) % 2)) break;
+            // blocks with an odd number of rows / columns cannot be halved rank by rank: this level stays the coarsest
+            // one (a distributed coarsest level is smoothed with a halo exchange per sweep - slow, but correct)
+            if (L->dist && ((ctx->Pz > 1 && (((nz - 1) / ctx->Pz) % 2)) || (ctx->Px > 1 && (((nx - 1) / ctx->Px) % 2)))) break;
             std::vector<double> z2, x2;
             for (int i = 0; i < nz; i += 2) z2.push_back(zc[i]);
             for (int j = 0; j < nx; j += 2) x2.push_back(xc[j]);
@@ -1240,20 +1234,16 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
         if (l > 0) {
             MgLevel* F = S->levels[l - 1];
             if (F->dist) {       // fine viscosity rings must be valid for the [1 2 1] stencil
-                PL_TRY(pl_halo_rows(ctx, F->gh.d, F->etas, 1, F->gh.d.plane));
-                PL_TRY(pl_halo_rows(ctx, F->gh.d, F->etan, 1, F->gh.d.plane));
+                PL_TRY(pl_halo(ctx, F->gh.d, F->etas, 1, F->gh.d.plane, 2));
+                PL_TRY(pl_halo(ctx, F->gh.d, F->etan, 1, F->gh.d.plane, 2));
             }
             if (R > 1 && (int)l == S->repl_start) {
-                // my rows of the replicated arrays, then all-gather (+ the last node row)
-                const long long sh = (long long)L->win_rows0 * L->gh.d.pitch;
+                // my block of the replicated arrays, then gather everybody's
+                const long long sh = L->win_shift;
                 hipLaunchKernelGGL(k_coarsen_visc, grid2d(L->win), dim3(64, 4), 0, ctx->stream, F->gh.d, F->etas, F->etan,
                                    L->win, L->etas + sh, L->etan + sh);
-                const long long cnt = (long long)((L->gh.d.nz - 1) / R) * L->gh.d.pitch;
-                PL_TRY(pl_comm_allgather(ctx, L->etas + L->gh.d.pitch, cnt, 1, 0));
-                PL_TRY(pl_comm_allgather(ctx, L->etan + L->gh.d.pitch, cnt, 1, 0));
-                PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                PL_TRY(share_last_row(ctx, L->gh.d, L->etas));
-                PL_TRY(share_last_row(ctx, L->gh.d, L->etan));
+                PL_TRY(pl_gather_blocks(ctx, L->gh.d, L->etas, 1, L->gh.d.plane));
+                PL_TRY(pl_gather_blocks(ctx, L->gh.d, L->etan, 1, L->gh.d.plane));
             } else {
                 hipLaunchKernelGGL(k_coarsen_visc, grid2d(L->gh.d), dim3(64, 4), 0, ctx->stream, F->gh.d, F->etas, F->etan,
                                    L->gh.d, L->etas, L->etan);
@@ -1277,21 +1267,18 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
             }
             if (l == 0) { L->rho = (double*)sop.rho; continue; }
             MgLevel* F = S->levels[l - 1];
-            if (F->dist && l > 1) PL_TRY(pl_halo_rows(ctx, F->gh.d, F->rho, 1, F->gh.d.plane));
+            if (F->dist) PL_TRY(pl_halo(ctx, F->gh.d, F->rho, 1, F->gh.d.plane, 2));
             if (R > 1 && (int)l == S->repl_start) {
-                const long long sh = (long long)L->win_rows0 * L->gh.d.pitch;
+                const long long sh = L->win_shift;
                 hipLaunchKernelGGL(k_coarsen_node, grid2d(L->win), dim3(64, 4), 0, ctx->stream, F->gh.d, F->rho, L->win, L->rho + sh);
-                const long long cnt = (long long)((L->gh.d.nz - 1) / R) * L->gh.d.pitch;
-                PL_TRY(pl_comm_allgather(ctx, L->rho + L->gh.d.pitch, cnt, 1, 0));
-                PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                PL_TRY(share_last_row(ctx, L->gh.d, L->rho));
+                PL_TRY(pl_gather_blocks(ctx, L->gh.d, L->rho, 1, L->gh.d.plane));
             } else {
                 hipLaunchKernelGGL(k_coarsen_node, grid2d(L->gh.d), dim3(64, 4), 0, ctx->stream, F->gh.d, F->rho, L->gh.d, L->rho);
             }
         }
         for (size_t l = 0; l < S->levels.size(); l++) {
             MgLevel* L = S->levels[l];
-            if (L->dist && l > 0) PL_TRY(pl_halo_rows(ctx, L->gh.d, L->rho, 1, L->gh.d.plane));
+            if (L->dist) PL_TRY(pl_halo(ctx, L->gh.d, L->rho, 1, L->gh.d.plane, 2));
             hipLaunchKernelGGL(k_stab_coeffs, grid2d(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, L->rho, coef, L->szz, L->szx);
             L->op.szz = L->szz; L->op.szx = L->szx;
         }
@@ -1312,7 +1299,7 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
             // warm restart: at least power_its_warm iterations, then stop once the estimate moves by < 1 %
             if (warm && it >= S->power_its_warm && std::fabs(lam - lam_prev) < 0.01 * lam) break;
             lam_prev = lam;
-            if (L->dist) PL_TRY(pl_halo_rows(ctx, g, L->v[0], 2, g.plane));
+            if (L->dist) PL_TRY(pl_halo(ctx, g, L->v[0], 2, g.plane));
             hipLaunchKernelGGL(k_vv_dinv_apply, grid2d(g), dim3(64, 4), 0, ctx->stream, L->op, L->v[0], L->v[1]);
             PL_TRY(dots(ctx, S, g, 2, L->v[1], L->v[1], L->v[0], L->v[0], nn));
             if (!(nn[1] > 0.0) || !(nn[0] > 0.0)) break;
@@ -1328,7 +1315,9 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
 }
 
 // PYLAMP_VV_VEC=0 selects the scalar one-column-per-lane sweep kernels (kept as the cross-check)
-static const bool g_vv_vec = [] { const char* e = getenv("PYLAMP_VV_VEC"); return !(e && e[0] == '0'); }();
+static const bool g_vv_vec_env = [] { const char* e = getenv("PYLAMP_VV_VEC"); return !(e && e[0] == '0'); }();
+// the two-columns-per-lane kernels load the x tables as aligned pairs: the block's first global column must be even
+#define g_vv_vec (g_vv_vec_env && !(L->gh.d.gj0 & 1))
 
 // ---- smoothing and V-cycle ----------------------------------------------------------------
 // nsweep Chebyshev-Jacobi sweeps on level L; buf[0] is the current iterate on entry and on exit
@@ -1342,7 +1331,7 @@ static void smooth(pl_ctx* ctx, MgLevel* L, double* buf[3], const double* f, int
         if (k == 0) { c1 = 0.0; c2 = 1.0 / theta; }
         else { const double rho = 1.0 / (2.0 * sigma - rho_old); c1 = rho * rho_old; c2 = 2.0 * rho / delta; rho_old = rho; }
         if (L->dist && !(k == 0 && (zero_guess || first_halo_valid)) && (halo == 2 || (halo == 1 && k == 0)))
-            (void)pl_halo_rows(ctx, L->gh.d, buf[0], 2, L->gh.d.plane);
+            (void)pl_halo(ctx, L->gh.d, buf[0], 2, L->gh.d.plane);
         double* dst = (final_out && k == nsweep - 1) ? final_out : buf[2];
         if (k == 0 && zero_guess) {        // buf[0] is NOT read (and need not be zeroed)
             if (g_vv_vec) hipLaunchKernelGGL(k_vv_first2, pl_grid_rows2(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, f, dst, c2);
@@ -1408,36 +1397,36 @@ static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const double* f, double**
     const int hp = S->mg_halo;
     const int npre = (l == 0 && S->nu0_pre > 0) ? S->nu0_pre : S->nu_pre, npost = (l == 0 && S->nu0_post > 0) ? S->nu0_post : S->nu_post;
     smooth(ctx, L, buf, f, npre, S->cheb_ratio, nullptr, true, hp);
-    if (L->dist && hp >= 1) (void)pl_halo_rows(ctx, g, buf[0], 2, g.plane);
+    if (L->dist && hp >= 1) (void)pl_halo(ctx, g, buf[0], 2, g.plane);
     if (g_vv_vec)
         hipLaunchKernelGGL(k_vv_sweep2<1>, pl_grid_rows2(g), dim3(64, 4), 0, ctx->stream, L->op, buf[0], (const double*)nullptr, f,
                            L->r, 0.0, 0.0);
     else
         hipLaunchKernelGGL(k_vv_residual, pl_grid_rows(g), dim3(64, 4), 0, ctx->stream, L->op, buf[0], f, L->r, pl_row_iters(g));
-    if (L->dist && hp >= 1) (void)pl_halo_rows(ctx, g, L->r, 2, g.plane);
+    if (L->dist && hp >= 1) (void)pl_halo(ctx, g, L->r, 2, g.plane, 2);
     MgLevel* C = S->levels[l + 1];
     if (L->dist && !C->dist) {
-        // restrict my rows into the replicated coarse rhs, then all-gather it
+        // restrict my block of the replicated coarse rhs, then gather everybody's
         PlVvOp wop = C->op; wop.g = C->win;
-        const long long sh = (long long)C->win_rows0 * C->gh.d.pitch;
+        const long long sh = C->win_shift;
         hipLaunchKernelGGL(k_vv_restrict, grid2d(C->win), dim3(64, 4), 0, ctx->stream, g, wop, L->r, C->f + sh);
-        const long long cnt = (long long)((C->gh.d.nz - 1) / ctx->nranks) * C->gh.d.pitch;
-        (void)pl_comm_allgather(ctx, C->f + C->gh.d.pitch, cnt, 2, C->gh.d.plane);
+        (void)pl_gather_blocks(ctx, C->gh.d, C->f, 2, C->gh.d.plane);
     } else {
         hipLaunchKernelGGL(k_vv_restrict, grid2d(C->gh.d), dim3(64, 4), 0, ctx->stream, g, C->op, L->r, C->f);
     }
     double* ec = nullptr;
     vcycle(ctx, S, l + 1, C->f, &ec);
-    if (C->dist && hp >= 1) (void)pl_halo_rows(ctx, C->gh.d, ec, 2, C->gh.d.plane);
+    if (C->dist && hp >= 1) (void)pl_halo(ctx, C->gh.d, ec, 2, C->gh.d.plane, 2);
     // On a distributed level the correction is also prolonged into the two halo rows (their coarse neighbours are in
     // the coarse halo / the replicated coarse array, and the halo of the pre-smoothed iterate is still valid from the
     // residual): the first post-smoothing sweep then needs no exchange of its own.
     const bool ext = L->dist && hp == 2;
-    const int lo = (ext && ctx->rank > 0) ? 1 : 0, hi = (ext && ctx->rank < ctx->nranks - 1) ? 1 : 0;
+    const int lo = (ext && ctx->pz > 0) ? 1 : 0, hi = (ext && ctx->pz < ctx->Pz - 1) ? 1 : 0;
+    const int we = (ext && ctx->px > 0) ? 1 : 0, ea = (ext && ctx->px < ctx->Px - 1) ? 1 : 0;
     PlVvOp ope = L->op;
-    ope.g.gi0 -= lo; ope.g.lnz += lo + hi;
-    hipLaunchKernelGGL(k_vv_prolong_add, grid2d(ope.g), dim3(64, 4), 0, ctx->stream, ope, C->gh.d, ec, buf[0] - (long long)lo * g.pitch,
-                       buf[2] - (long long)lo * g.pitch);
+    ope.g.gi0 -= lo; ope.g.lnz += lo + hi; ope.g.gj0 -= we; ope.g.lnx += we + ea;
+    const long long esh = (long long)lo * g.pitch + we;
+    hipLaunchKernelGGL(k_vv_prolong_add, grid2d(ope.g), dim3(64, 4), 0, ctx->stream, ope, C->gh.d, ec, buf[0] - esh, buf[2] - esh);
     std::swap(buf[0], buf[2]);
     smooth(ctx, L, buf, f, npost, S->cheb_ratio, final_out, false, hp, ext);
     *out = buf[0];
@@ -1448,8 +1437,8 @@ static int stokes_precond(pl_ctx* ctx, PlSolver* S, const double* rs, double* z)
     const PlStokesOp& op = ctx->sop;
     MgLevel* L0 = S->levels[0];
     const PlGeom& g = op.g;
-    if (L0->dist) PL_TRY(pl_halo_rows(ctx, g, (double*)rs + 2 * g.plane, 1, g.plane));      // rs_p row above
-    if (g_vv_vec && (g.plane % 2) == 0)
+    if (L0->dist) PL_TRY(pl_halo(ctx, g, (double*)rs + 2 * g.plane, 1, g.plane));      // rs_p row above / column to the left
+    if (g_vv_vec_env && !(g.gj0 & 1) && (g.plane % 2) == 0)
         hipLaunchKernelGGL(k_prec_stage1_v2, pl_grid_rows2(g), dim3(64, 4), 0, ctx->stream, op, L0->op, rs, z, L0->f);
     else
         hipLaunchKernelGGL(k_prec_stage1, pl_grid_rows(g), dim3(64, 4), 0, ctx->stream, op, L0->op, rs, z, L0->f, pl_row_iters(g));
@@ -1619,7 +1608,7 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
     PlStokesOp sop_scaled = sop; sop_scaled.scaled = 1;
     S->napply = 0; S->nprec = 0;
     VecOp A = [&](const double* in, double* out) -> int {
-        PL_TRY(pl_halo_rows(ctx, g, (double*)in, 3, g.plane));
+        PL_TRY(pl_halo(ctx, g, (double*)in, 3, g.plane));
         pl_launch_stokes_apply(ctx, sop_scaled, in, out);      // y = D_r A x in one pass
         S->napply++;
         return 0;
@@ -1644,23 +1633,23 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
             hipLaunchKernelGGL(k_hydro_chunk_scan, dim3((g.lnx + 63) / 64), dim3(64), 0, ctx->stream, g, nch, ctot, coltot);
             hipLaunchKernelGGL(k_hydro_add, grid2d(g), dim3(64, 4), 0, ctx->stream, g, S->y, ctot);
         }
-        // prefix over the slabs above + anchor value, through the host
-        const int R = ctx->nranks;
-        std::vector<double> hb((size_t)R * g.lnx + 1, 0.0);
-        PL_HIP(ctx, hipMemcpyAsync(hb.data() + (size_t)ctx->rank * g.lnx, coltot, (size_t)g.lnx * sizeof(double),
+        // prefix over the blocks above (same block column) + anchor value, through the host
+        const int Pz = ctx->Pz, NX = g.nx;
+        std::vector<double> hb((size_t)Pz * NX + 1, 0.0);
+        PL_HIP(ctx, hipMemcpyAsync(hb.data() + (size_t)ctx->pz * NX + g.gj0, coltot, (size_t)g.lnx * sizeof(double),
                                    hipMemcpyDeviceToHost, ctx->stream));
-        const bool own_anchor = sop.anchor_i >= g.gi0 && sop.anchor_i < g.gi0 + g.lnz;
+        const bool own_anchor = sop.anchor_i >= g.gi0 && sop.anchor_i < g.gi0 + g.lnz && sop.anchor_j >= g.gj0 && sop.anchor_j < g.gj0 + g.lnx;
         if (own_anchor)
-            PL_HIP(ctx, hipMemcpyAsync(&hb[(size_t)R * g.lnx], S->y + 2 * g.plane + pl_idx(g, sop.anchor_i - g.gi0, sop.anchor_j),
+            PL_HIP(ctx, hipMemcpyAsync(&hb[(size_t)Pz * NX], S->y + 2 * g.plane + pl_idx(g, sop.anchor_i - g.gi0, sop.anchor_j - g.gj0),
                                        sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
         PL_TRY(pl_allreduce_host(ctx, hb.data(), (long long)hb.size(), 0));
         std::vector<double> pre((size_t)g.lnx, 0.0);
-        for (int q = 0; q < ctx->rank; q++) for (int jj = 0; jj < g.lnx; jj++) pre[jj] += hb[(size_t)q * g.lnx + jj];
-        double pa = hb[(size_t)R * g.lnx];
-        if (R > 1) {      // the anchor value was taken before the prefix of its own slab was added
-            int owner = 0; while ((owner + 1) * ((g.nz - 1) / R) <= sop.anchor_i && owner + 1 < R) owner++;
-            for (int q = 0; q < owner; q++) pa += hb[(size_t)q * g.lnx + sop.anchor_j];
+        for (int q = 0; q < ctx->pz; q++) for (int jj = 0; jj < g.lnx; jj++) pre[jj] += hb[(size_t)q * NX + g.gj0 + jj];
+        double pa = hb[(size_t)Pz * NX];
+        if (ctx->nranks > 1) {      // the anchor value was taken before the prefix of its own block was added
+            int owner = 0; while ((owner + 1) * ((g.nz - 1) / Pz) <= sop.anchor_i && owner + 1 < Pz) owner++;
+            for (int q = 0; q < owner; q++) pa += hb[(size_t)q * NX + sop.anchor_j];
         }
         PL_HIP(ctx, hipMemcpyAsync(prefix, pre.data(), (size_t)g.lnx * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(k_hydrostatic_apply_shift, grid2d(g), dim3(64, 4), 0, ctx->stream, sop, S->y, prefix, pa);
@@ -1791,7 +1780,7 @@ int pl_heat_solve_device(pl_ctx* ctx, const double* b_dev, double rtol, int maxi
     PlHeatOp hop = ctx->hop;
     S->napply = 0;
     VecOp A = [&](const double* in, double* out) -> int {
-        PL_TRY(pl_halo_rows(ctx, g, (double*)in, 1, g.plane));
+        PL_TRY(pl_halo(ctx, g, (double*)in, 1, g.plane));
         pl_launch_heat_apply(ctx, hop, in, out, true);          // D^-1 A in one pass
         S->napply++;
         return 0;

@@ -6,6 +6,7 @@
 // Not included: tracer deletion (pylamp2.py:574-581) - it cannot trigger with the supported walls.
 #include "pl_internal.h"
 #include "pl_mic.h"
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <limits>
@@ -31,12 +32,12 @@ struct PlStepState {
     int* cell = nullptr; int* dest = nullptr;        // per tracer: sort cell, destination slot
     int* orig = nullptr; int* orig2 = nullptr;       // caller's index of the tracer now stored at slot t
     int* cell_count = nullptr; int* cell_start = nullptr; int* block_sums = nullptr;
-    int ncz = 0, ncx = 0;                            // sort grid (rows incl. the leaver rows of a slab)
-    int crow0 = 0;                                   // global cell row of sort row 0
-    int lo_ext = 0, hi_ext = 0;
+    int ncz = 0, ncx = 0;                            // sort grid = the cells of this rank's block
+    int crow0 = 0, ccol0 = 0;                        // global cell row / column of sort cell (0,0)
     bool sorted = false;                             // tracers are cell-sorted and cell_start is valid
     int* need = nullptr; int* need_off = nullptr;    // injection: per-cell deficit and its exclusive scan
     int* need_flag = nullptr; int* need_rank = nullptr;   // 1 for a deficient cell, and its exclusive scan (reference ID rule)
+    int* cell_res = nullptr;                         // residents per cell (census) while the sort makes room for new tracers
     double max_id = -1.0;                            // current maximum of TR__ID over all ranks
     bool max_id_valid = false;                       // false after a deletion: recomputed on the device when needed
     int sort_cells = 0;                              // cells of the current sort grid (the trash bucket follows them)
@@ -55,13 +56,13 @@ void pl_step_free(pl_ctx* ctx) {
         if (q) (void)hipFree(q);
     for (double* q : s->f) if (q) (void)hipFree(q);
     for (double* q : s->f2) if (q) (void)hipFree(q);
-    for (int* q : {s->cell, s->dest, s->orig, s->orig2, s->cell_count, s->cell_start, s->block_sums, s->need, s->need_off, s->need_flag, s->need_rank}) if (q) (void)hipFree(q);
+    for (int* q : {s->cell, s->dest, s->orig, s->orig2, s->cell_count, s->cell_start, s->block_sums, s->need, s->need_off, s->need_flag, s->need_rank, s->cell_res}) if (q) (void)hipFree(q);
     delete s;
     ctx->step = nullptr;
 }
 
 static dim3 grid2d(const PlGeom& g) { return dim3((g.lnx + 63) / 64, (g.lnz + 3) / 4); }
-static dim3 grid1d(long long n) { return dim3((unsigned)((n + 255) / 256)); }
+static dim3 grid1d(long long n) { return dim3((unsigned)std::max<long long>((n + 255) / 256, 1)); }      // n = 0: one idle block
 
 // ---- kernels --------------------------------------------------------------------------------
 // AoS rows of the reference (tr_x (n,2), tr_f (n,13)) <-> SoA columns
@@ -98,26 +99,31 @@ __device__ inline void wave_runs(int c, int lane, int& seg0, int& len) {
     const unsigned long long above = (seg0 == 63) ? 0ull : (heads >> (seg0 + 1));
     len = above ? __ffsll((long long)above) : 64 - seg0;            // lanes in my run
 }
-// del_outside: a tracer at or beyond a wall (pylamp2.py:563-572 with the fence off: TR__ID = -1) goes to the trash
-// bucket behind the last cell; the permutation then leaves the survivors as the first cell_start[ncells] entries.
+// Sort key of a tracer: the cell of this rank's block it lies in, [0, ncz*ncx); or, behind the cells, one of 8 LEAVER
+// buckets (the neighbour block it has moved into; order N S W E NW NE SW SE as in pl_comm.hip); or the trash bucket
+// behind those -- del_outside: a tracer at or beyond a wall (pylamp2.py:563-572 with the fence off: TR__ID = -1).
+// After the permutation the stayers are the first cell_start[nc] entries, then the leavers per neighbour.
 __global__ __launch_bounds__(256) void k_cell_count(long long n, const double* __restrict__ tz, const double* __restrict__ tx,
                                                     double z0, double hz, double x0, double hx, const double* __restrict__ zc,
-                                                    const double* __restrict__ xc, int ncz, int ncx, int crow0,
-                                                    int gcz, int* __restrict__ cell, int* __restrict__ count,
+                                                    const double* __restrict__ xc, int ncz, int ncx, int crow0, int ccol0,
+                                                    int gcz, int gcx, int* __restrict__ cell, int* __restrict__ count,
                                                     int del_outside, double Lz, double Lx) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
+    const int nc = ncz * ncx;
     int c = -1;                                          // lanes past the end form their own run and add nothing
     if (t < n && del_outside && (tz[t] <= 0.0 || tz[t] >= Lz || tx[t] <= 0.0 || tx[t] >= Lx)) {
-        c = ncz * ncx;
+        c = nc + 8;
         cell[t] = c;
     } else if (t < n) {
         int ci, cj;
-        if (zc) { double a_; mic_axis_locate(zc, gcz + 1, tz[t], ci, a_); mic_axis_locate(xc, ncx + 1, tx[t], cj, a_); }   // rectilinear node grid
+        if (zc) { double a_; mic_axis_locate(zc, gcz + 1, tz[t], ci, a_); mic_axis_locate(xc, gcx + 1, tx[t], cj, a_); }   // rectilinear node grid
         else { ci = (int)floor((tz[t] - z0) / hz); cj = (int)floor((tx[t] - x0) / hx); }
-        ci = min(max(ci, 0), gcz - 1) - crow0;              // global cell row (clamped to the domain) -> sort row
-        ci = min(max(ci, 0), ncz - 1); cj = min(max(cj, 0), ncx - 1);
-        c = ci * ncx + cj;
+        ci = min(max(ci, 0), gcz - 1) - crow0;              // global cell (clamped to the domain) -> block cell
+        cj = min(max(cj, 0), gcx - 1) - ccol0;
+        const int dz = ci < 0 ? -1 : (ci >= ncz ? 1 : 0), dx = cj < 0 ? -1 : (cj >= ncx ? 1 : 0);
+        if (dz == 0 && dx == 0) c = ci * ncx + cj;
+        else c = nc + (dx == 0 ? (dz < 0 ? 0 : 1) : (dz == 0 ? (dx < 0 ? 2 : 3) : (dz < 0 ? (dx < 0 ? 4 : 5) : (dx < 0 ? 6 : 7))));
         cell[t] = c;
     }
     int seg0, len;
@@ -238,40 +244,6 @@ __device__ inline double inj_uniform(unsigned long long seed, unsigned a, unsign
     h ^= h >> 33; h *= 0xff51afd7ed558ccdull; h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ull; h ^= h >> 33;
     return (double)(h >> 11) * (1.0 / 9007199254740992.0);          // [0,1)
 }
-struct InjectArgs {
-    int nc, ncx, crow0; long long n;
-    const int* start; const int* need; const int* off;
-    const int* rank;                             // deficient cells before this one, or NULL: unique IDs
-    double* tz; double* tx; double* f[NFTRAC]; double* vtz; double* vtx;
-    double z0, hz, x0, hx; unsigned long long seed; unsigned step; double id0;
-    const double* zc; const double* xc;          // rectilinear node grid (NULL: regular)
-};
-// one thread per deficient cell: field means of the resident tracers, then the new tracers
-__global__ __launch_bounds__(64) void k_inject(InjectArgs a) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= a.nc) return;
-    const int m = a.need[c];
-    if (m <= 0) return;
-    const int t0 = a.start[c], t1 = a.start[c + 1];
-    const int ci = c / a.ncx + a.crow0, cj = c % a.ncx;            // global cell
-    double mean[NFTRAC];
-    for (int k = 0; k < NFTRAC; k++) {
-        double sum = 0.0;
-        for (int t = t0; t < t1; t++) sum += a.f[k][t];
-        mean[k] = sum / (double)(t1 - t0);                          // 0/0 = NaN for an empty cell, like the reference
-    }
-    for (int q = 0; q < m; q++) {
-        const long long d = a.n + a.off[c] + q;
-        const double uz = inj_uniform(a.seed, (unsigned)c, (unsigned)q, 2 * a.step), ux = inj_uniform(a.seed, (unsigned)c, (unsigned)q, 2 * a.step + 1);
-        a.tz[d] = a.zc ? a.zc[ci] + uz * (a.zc[ci + 1] - a.zc[ci]) : a.z0 + (ci + uz) * a.hz;
-        a.tx[d] = a.xc ? a.xc[cj] + ux * (a.xc[cj + 1] - a.xc[cj]) : a.x0 + (cj + ux) * a.hx;
-        for (int k = 0; k < NFTRAC; k++) a.f[k][d] = mean[k];
-        // reference rule (pylamp2.py:621-622): the first new ID of every cell repeats the last ID handed out
-        a.f[TR__ID][d] = a.id0 + a.off[c] + q - (a.rank ? a.rank[c] : 0);
-        a.vtz[d] = 0.0; a.vtx[d] = 0.0;                             // injected tracers have not been advected yet
-    }
-}
-
 // pylamp2.py:291-303
 __global__ __launch_bounds__(256) void k_property_update(long long n, const double* __restrict__ T,
                                                          const double* __restrict__ rh0, const double* __restrict__ alp,
@@ -335,19 +307,22 @@ __global__ __launch_bounds__(256) void k_plane_sub(PlGeom g, const double* __res
 }
 
 // Cell-centred advection velocities on the padded (nz+1, nx+1) grid with the ghost ring
-// filled per wall BC in source order z0, x0, zL, xL (pylamp2.py:491-545).  Dense output.
+// filled per wall BC in source order z0, x0, zL, xL (pylamp2.py:491-545).  Every rank computes the window
+// [I0, I0+nr) x [J0, J0+nc) of it that the RK4 stages of its own tracers can reach, from its velocity planes and
+// their halo (no all-gather).  Dense output of the window.
 __global__ __launch_bounds__(256) void k_advection_velocity(PlGeom g, const double* __restrict__ vz,
                                                             const double* __restrict__ vx, int fs_z0, int fs_x0,
-                                                            int fs_zL, int fs_xL, double* __restrict__ Vz,
-                                                            double* __restrict__ Vx) {
-    const int J = blockIdx.x * 64 + threadIdx.x, I = blockIdx.y * 4 + threadIdx.y;
+                                                            int fs_zL, int fs_xL, int I0, int J0, int nr, int nc,
+                                                            double* __restrict__ Vz, double* __restrict__ Vx) {
+    const int wj = blockIdx.x * 64 + threadIdx.x, wi = blockIdx.y * 4 + threadIdx.y;
     const int nz = g.nz, nx = g.nx;
-    if (J > nx || I > nz) return;
+    if (wj >= nc || wi >= nr) return;
+    const int I = I0 + wi, J = J0 + wj;
     // value of the un-filled array at (I,J): interior = centre average, ring = 0
     auto raw = [&](int a, int b, double& oz, double& ox) {
         oz = 0.0; ox = 0.0;
         if (a >= 1 && a <= nz - 1 && b >= 1 && b <= nx - 1) {
-            const long long o = pl_idx(g, a - 1, b - 1);
+            const long long o = pl_idx(g, a - 1 - g.gi0, b - 1 - g.gj0);
             oz = 0.5 * (vz[o + g.pitch] + vz[o]);
             ox = 0.5 * (vx[o + 1] + vx[o]);
         }
@@ -367,7 +342,7 @@ __global__ __launch_bounds__(256) void k_advection_velocity(PlGeom g, const doub
     // zL fill of row nz reads row nz-1 INCLUDING its x0/xL ring columns as they stood after the
     // x0 fill but before the xL fill; the chase above handles every combination because each
     // step moves strictly inward and an inner node is never a ring node of an earlier fill.
-    const long long o = (long long)I * (nx + 1) + J;
+    const long long o = (long long)wi * nc + wj;
     Vz[o] = sz * oz; Vx[o] = sx * ox;
 }
 
@@ -437,14 +412,16 @@ static int grow_tracers(pl_ctx* ctx, PlStepState* S, long long n, long long keep
     for (int k = 0; k < NFTRAC; k++) { PL_TRY(regrow(&S->f[k], true)); PL_TRY(regrow(&S->f2[k], false)); }
     PL_TRY(regrow(&S->vtz, true)); PL_TRY(regrow(&S->vtx, true));
     for (double** q : {&S->tz2, &S->tx2, &S->tmp[0], &S->tmp[1], &S->tmp[2]}) PL_TRY(regrow(q, false));
-    for (int** q : {&S->cell, &S->dest, &S->orig2}) {
+    for (int** q : {&S->dest, &S->orig2}) {
         if (*q) (void)hipFree(*q);
         PL_HIP(ctx, hipMalloc((void**)q, (size_t)cap * sizeof(int)));
     }
-    { int* q = nullptr; PL_HIP(ctx, hipMalloc((void**)&q, (size_t)cap * sizeof(int)));
-      if (S->orig && keep > 0) PL_HIP(ctx, hipMemcpy(q, S->orig, (size_t)keep * sizeof(int), hipMemcpyDeviceToDevice));
-      if (S->orig) (void)hipFree(S->orig);
-      S->orig = q; }
+    for (int** pq : {&S->orig, &S->cell}) {        // the sort keys of a sort in progress are kept as well
+        int* q = nullptr; PL_HIP(ctx, hipMalloc((void**)&q, (size_t)cap * sizeof(int)));
+        if (*pq && keep > 0) PL_HIP(ctx, hipMemcpy(q, *pq, (size_t)keep * sizeof(int), hipMemcpyDeviceToDevice));
+        if (*pq) (void)hipFree(*pq);
+        *pq = q;
+    }
     S->cap = cap;
     return 0;
 }
@@ -470,8 +447,11 @@ static int ensure_tracers(pl_ctx* ctx, PlStepState* S, long long n) {
 }
 
 static void unpermute(pl_ctx* ctx, PlStepState* S, int na, const double* const* in, double* const* out);
-static int sort_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, double x0, double hx, int del_outside = 0,
-                        double Lz = 0.0, double Lx = 0.0, long long* removed = nullptr);
+struct SortOpts {
+    int del_outside = 0; double Lz = 0.0, Lx = 0.0; long long* removed = nullptr;     // fence off: delete leavers of the domain
+    const pl_step_config* inject = nullptr; int it = 0; int64_t* ninjected = nullptr;  // census + refill fused into the sort
+};
+static int sort_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, double x0, double hx, const SortOpts& o = SortOpts());
 // Host midpoint grids (pylamp2.py:92-95) and device copies of all coordinate arrays the marker kernels use:
 // gcoords = [ node z (nz) | node x (nx) | padded centres z (nz+1) | padded centres x (nx+1) ]; the centre
 // (midpoint) grids of the staggered targets are the padded ones without their first entry.
@@ -503,7 +483,7 @@ static const double* coords_x(pl_ctx* ctx, PlStepState* S, int stag) {
     if (ctx->geom.uniform) return nullptr;
     return stag ? S->gcoords + ctx->nz + ctx->nx + (ctx->nz + 1) + 1 : S->gcoords + ctx->nz;
 }
-static int migrate_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, double x0, double hx);
+static int migrate_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, double x0, double hx, const SortOpts& o = SortOpts());
 
 extern "C" int pl_tracers_upload(pl_ctx* ctx, int64_t n, const double* tr_x, const double* tr_f) {
     if (n < 0 || !tr_x || !tr_f) return pl_fail(ctx, "pl_tracers_upload: bad argument");
@@ -580,18 +560,17 @@ extern "C" int pl_tracers_count(pl_ctx* ctx, int64_t* n) {
 }
 
 // Per-cell tracer counts of the resident (cell-sorted) state: the census of pylamp2.py:588-598 (np.bincount of the
-// cell index), for this rank's owned cells, row-major (rows x (nx-1)).
+// cell index), for the cells of this rank's block, row-major (n_cell_rows x n_cell_cols).
 extern "C" int pl_tracers_census(pl_ctx* ctx, int64_t ncells, int32_t* counts, int* first_cell_row, int* n_cell_rows) {
     PlStepState* S = state_of(ctx);
     if (!S->sorted || !S->cell_start) return pl_fail(ctx, "pl_tracers_census: no cell-sorted tracers resident");
-    const int rows = S->ncz - S->lo_ext - S->hi_ext;
-    if (first_cell_row) *first_cell_row = S->crow0 + S->lo_ext;
-    if (n_cell_rows) *n_cell_rows = rows;
+    if (first_cell_row) *first_cell_row = S->crow0;
+    if (n_cell_rows) *n_cell_rows = S->ncz;
     if (!counts) return 0;
-    if (ncells != (int64_t)rows * S->ncx) return pl_fail(ctx, "pl_tracers_census: ncells does not match the owned cells");
+    if (ncells != (int64_t)S->ncz * S->ncx) return pl_fail(ctx, "pl_tracers_census: ncells does not match the owned cells");
     PL_HIP(ctx, hipSetDevice(ctx->device));
     std::vector<int> st((size_t)ncells + 1);
-    PL_HIP(ctx, hipMemcpyAsync(st.data(), S->cell_start + (size_t)S->lo_ext * S->ncx, st.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    PL_HIP(ctx, hipMemcpyAsync(st.data(), S->cell_start, st.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int64_t c = 0; c < ncells; c++) counts[c] = st[c + 1] - st[c];
     return 0;
@@ -616,41 +595,149 @@ extern "C" int pl_get_tracer_velocity(pl_ctx* ctx, int64_t n, double* out) {
     return 0;
 }
 
-// Counting sort of all tracer arrays by node-grid cell; leaves cell_start (ncells+1 ints) valid.
-// On a slab the sort grid has one extra row on each interior side that collects the tracers which
-// left the slab (they end up as contiguous ranges at the two ends of every array).
-// del_outside != 0: tracers at or beyond a wall are removed (fence off, pylamp2.py:563-581); *removed returns their number.
-static int sort_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, double x0, double hx, int del_outside,
-                        double Lz, double Lx, long long* removed) {
+// new tracers of the deficient cells, written straight into their sorted slots (behind the residents of the cell)
+struct InjectSorted {
+    int nc, ncx, crow0, ccol0;
+    const int* start;            // cell_start of the sorted arrays INCLUDING the new tracers
+    const int* count;            // residents per cell
+    const int* need; const int* off; const int* rank;     // deficit, its exclusive scan, deficient cells before (or NULL)
+    double* tz; double* tx; double* f[NFTRAC]; double* vtz; double* vtx; int* orig;
+    double z0, hz, x0, hx; unsigned long long seed; unsigned step; double id0; int n_old;
+    const double* zc; const double* xc;
+};
+__global__ __launch_bounds__(64) void k_inject_sorted(InjectSorted a) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= a.nc) return;
+    const int m = a.need[c];
+    if (m <= 0) return;
+    const int t0 = a.start[c], t1 = t0 + a.count[c];
+    const int ci = c / a.ncx + a.crow0, cj = c % a.ncx + a.ccol0;   // global cell
+    double mean[NFTRAC];
+    for (int k = 0; k < NFTRAC; k++) {
+        double sum = 0.0;
+        for (int t = t0; t < t1; t++) sum += a.f[k][t];
+        mean[k] = sum / (double)(t1 - t0);                          // 0/0 = NaN for an empty cell, like the reference
+    }
+    for (int q = 0; q < m; q++) {
+        const int d = t1 + q;
+        const unsigned gc = (unsigned)(ci * 65536 + cj);            // the stream depends on the GLOBAL cell: same on any layout
+        const double uz = inj_uniform(a.seed, gc, (unsigned)q, 2 * a.step), ux = inj_uniform(a.seed, gc, (unsigned)q, 2 * a.step + 1);
+        a.tz[d] = a.zc ? a.zc[ci] + uz * (a.zc[ci + 1] - a.zc[ci]) : a.z0 + (ci + uz) * a.hz;
+        a.tx[d] = a.xc ? a.xc[cj] + ux * (a.xc[cj + 1] - a.xc[cj]) : a.x0 + (cj + ux) * a.hx;
+        for (int k = 0; k < NFTRAC; k++) a.f[k][d] = mean[k];
+        // reference rule (pylamp2.py:621-622): the first new ID of every cell repeats the last ID handed out
+        a.f[TR__ID][d] = a.id0 + a.off[c] + q - (a.rank ? a.rank[c] : 0);
+        a.vtz[d] = 0.0; a.vtx[d] = 0.0;                             // injected tracers have not been advected yet
+        a.orig[d] = a.n_old + a.off[c] + q;                         // appended behind the residents in the caller's order
+    }
+}
+// total[c] = count[c] + need[c] for the cells, count[c] for the buckets behind them
+__global__ __launch_bounds__(256) void k_add_need(int nc, int m, const int* __restrict__ count, const int* __restrict__ need, int* __restrict__ total) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < m) total[c] = count[c] + (c < nc ? need[c] : 0);
+}
+
+static int scan_ints(pl_ctx* ctx, PlStepState* S, int m, const int* in, int* out) {
+    const int nb = (m + 1023) / 1024;
+    hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(256), 0, ctx->stream, m, in, out, S->block_sums);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, ctx->stream, nb, S->block_sums);
+    hipLaunchKernelGGL(k_scan_add, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, m, out, S->block_sums, 0);
+    return 0;
+}
+
+// Counting sort of all tracer arrays by the cells of this rank's block; leaves cell_start valid:
+//   [0, nc] cells (cell_start[nc] = number of stayers), [nc, nc+8] the leaver buckets per neighbour block,
+//   [nc+8] the trash bucket (deleted tracers), [nc+9] = all.
+// o.del_outside: tracers at or beyond a wall are removed (fence off, pylamp2.py:563-581).
+// o.inject: census + refill (pylamp2.py:588-633) in the SAME pass -- the deficits follow from the counts, the
+// permutation leaves room for the new tracers behind the residents of their cell, and they are written straight
+// into their sorted slots (no second sort: re-sorting 67 M tracers for a few thousand new ones took 4.4 ms).
+static int sort_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, double x0, double hx, const SortOpts& o) {
     const PlGeom& g = ctx->geom.d;
-    const int C = (ctx->nranks > 1) ? (g.nz - 1) / ctx->nranks : g.nz - 1;
-    S->lo_ext = (ctx->rank > 0) ? 1 : 0; S->hi_ext = (ctx->rank < ctx->nranks - 1) ? 1 : 0;
-    const int ncz = C + S->lo_ext + S->hi_ext, ncx = ctx->nx - 1, nc = ncz * ncx;
-    S->crow0 = g.gi0 - S->lo_ext;
-    const long long n = S->n;
+    const int ncz = (g.gi0 + g.lnz >= g.nz) ? g.lnz - 1 : g.lnz;        // cells of the block = its nodes (the last block owns one more node)
+    const int ncx = (g.gj0 + g.lnx >= g.nx) ? g.lnx - 1 : g.lnx;
+    const int nc = ncz * ncx, m = nc + 10;
+    S->crow0 = g.gi0; S->ccol0 = g.gj0;
+    long long n = S->n;
     if (n >= (1LL << 31)) return pl_fail(ctx, "sort_tracers: more than 2^31 tracers per GPU");
-    if (!S->cell_count || S->ncz != ncz) {
-        for (int** q : {&S->cell_count, &S->cell_start, &S->block_sums}) { if (*q) (void)hipFree(*q); *q = nullptr; }
-        const int nb = (nc + 2 + 1023) / 1024;
-        PL_HIP(ctx, hipMalloc((void**)&S->cell_count, (size_t)(nc + 2) * sizeof(int)));
-        PL_HIP(ctx, hipMalloc((void**)&S->cell_start, (size_t)(nc + 2) * sizeof(int)));
+    if (!S->cell_count || S->ncz != ncz || S->ncx != ncx) {
+        for (int** q : {&S->cell_count, &S->cell_start, &S->block_sums, &S->need, &S->need_off, &S->need_flag, &S->need_rank, &S->cell_res}) {
+            if (*q) (void)hipFree(*q);
+            *q = nullptr;
+        }
+        const int nb = (m + 1023) / 1024;
+        for (int** q : {&S->cell_count, &S->cell_start, &S->need, &S->need_off, &S->need_flag, &S->need_rank, &S->cell_res})
+            PL_HIP(ctx, hipMalloc((void**)q, (size_t)m * sizeof(int)));
         PL_HIP(ctx, hipMalloc((void**)&S->block_sums, (size_t)(nb + 1) * sizeof(int)));
         S->ncz = ncz; S->ncx = ncx;
     }
     S->sort_cells = nc;
-    // counts: [0, nc) cells, [nc] trash bucket (deleted tracers), [nc + 1] = 0 so that the scan ends with the total
-    PL_HIP(ctx, hipMemsetAsync(S->cell_count, 0, (size_t)(nc + 2) * sizeof(int), ctx->stream));
-    if (n > 0)
-        hipLaunchKernelGGL(k_cell_count, grid1d(n), dim3(256), 0, ctx->stream, n, S->tz, S->tx, z0, hz, x0, hx, coords_z(ctx, S, 0),
-                           coords_x(ctx, S, 0), ncz, ncx, S->crow0, g.nz - 1, S->cell, S->cell_count, del_outside, Lz, Lx);
-    const int m = nc + 2, nb = (m + 1023) / 1024;
-    hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(256), 0, ctx->stream, m, S->cell_count, S->cell_start, S->block_sums);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, ctx->stream, nb, S->block_sums);
-    hipLaunchKernelGGL(k_scan_add, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, m, S->cell_start, S->block_sums, 0);
-    PL_HIP(ctx, hipMemsetAsync(S->cell_count, 0, (size_t)(nc + 2) * sizeof(int), ctx->stream));   // reused as fill counters
+    PL_HIP(ctx, hipMemsetAsync(S->cell_count, 0, (size_t)m * sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_cell_count, grid1d(n), dim3(256), 0, ctx->stream, n, S->tz, S->tx, z0, hz, x0, hx, coords_z(ctx, S, 0),
+                       coords_x(ctx, S, 0), ncz, ncx, S->crow0, S->ccol0, g.nz - 1, g.nx - 1, S->cell, S->cell_count, o.del_outside, o.Lz, o.Lx);
+    // ---- census + deficits (the counts ARE the census)
+    long long ninj = 0; int ndef = 0;
+    double id0 = 0.0; bool strict = false;
+    const bool inj = o.inject && o.inject->tracdens_min > 0 && o.inject->tracdens > 0;
+    if (inj) {
+        const pl_step_config* cfg = o.inject;
+        // resident counts of the cells as the deficit kernel expects them (start[c+1]-start[c]): scan the counts first
+        scan_ints(ctx, S, m, S->cell_count, S->cell_res);
+        hipLaunchKernelGGL(k_deficit, dim3((nc + 1 + 255) / 256), dim3(256), 0, ctx->stream, nc, ncx, 0, ncz, S->cell_res, cfg->tracdens,
+                           cfg->tracdens_min, S->need, S->need_flag);
+        scan_ints(ctx, S, nc + 1, S->need, S->need_off);
+        scan_ints(ctx, S, nc + 1, S->need_flag, S->need_rank);
+        int h2[2] = {0, 0};
+        PL_HIP(ctx, hipMemcpyAsync(&h2[0], S->need_off + nc, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        PL_HIP(ctx, hipMemcpyAsync(&h2[1], S->need_rank + nc, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ninj = h2[0]; ndef = h2[1];
+        // new IDs in global (rank-major) cell order: rank r continues after the ranks before it
+        const int R = ctx->nranks;
+        std::vector<double> cnt((size_t)2 * R, 0.0);
+        cnt[2 * ctx->rank] = (double)ninj; cnt[2 * ctx->rank + 1] = ndef;
+        PL_TRY(pl_allreduce_host(ctx, cnt.data(), (long long)cnt.size(), 0));
+        double before = 0.0, total = 0.0, def_before = 0.0, def_total = 0.0;
+        for (int q = 0; q < R; q++) {
+            if (q < ctx->rank) { before += cnt[2 * q]; def_before += cnt[2 * q + 1]; }
+            total += cnt[2 * q]; def_total += cnt[2 * q + 1];
+        }
+        if (total > 0.0) {
+            if (!S->max_id_valid) {                                // a deletion may have removed the holder of the maximum
+                double mx[1] = {-1.0};
+                if (n > 0) {
+                    const int nbm = 256;
+                    if (!S->partial || S->hpartial.size() < (size_t)3 * 4096) {
+                        if (S->partial) (void)hipFree(S->partial);
+                        PL_HIP(ctx, hipMalloc((void**)&S->partial, 3 * 4096 * sizeof(double)));
+                        S->hpartial.resize(3 * 4096);
+                    }
+                    hipLaunchKernelGGL(k_max1d, dim3(nbm), dim3(256), 0, ctx->stream, n, S->f[TR__ID], S->partial);
+                    PL_HIP(ctx, hipMemcpyAsync(S->hpartial.data(), S->partial, nbm * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+                    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                    for (int k = 0; k < nbm; k++) mx[0] = std::fmax(mx[0], S->hpartial[k]);
+                }
+                PL_TRY(pl_allreduce_host(ctx, mx, 1, 2));
+                S->max_id = mx[0]; S->max_id_valid = true;
+            }
+            strict = cfg->inject_unique_ids == 0;
+            // strict: IDs start AT the current maximum and every refilled cell repeats one (pylamp2.py:621-622)
+            id0 = strict ? S->max_id + before - def_before : S->max_id + 1.0 + before;
+            S->max_id += strict ? total - def_total : total;
+        }
+        if (ninj > 0) PL_TRY(grow_tracers(ctx, S, n + ninj, n));
+    }
+    // ---- offsets of the sorted arrays: residents (+ room for the new tracers of a cell right behind them)
+    if (ninj > 0) {
+        hipLaunchKernelGGL(k_add_need, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, nc, m, S->cell_count, S->need, S->cell_res);
+        scan_ints(ctx, S, m, S->cell_res, S->cell_start);
+        PL_HIP(ctx, hipMemcpyAsync(S->cell_res, S->cell_count, (size_t)m * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));   // residents per cell
+    } else {
+        scan_ints(ctx, S, m, S->cell_count, S->cell_start);
+    }
+    PL_HIP(ctx, hipMemsetAsync(S->cell_count, 0, (size_t)m * sizeof(int), ctx->stream));   // reused as fill counters
     if (n > 0) {
         hipLaunchKernelGGL(k_cell_place, grid1d(n), dim3(256), 0, ctx->stream, n, S->cell, S->cell_start, S->cell_count, S->dest);
-        // permute positions and the 13 fields
         // positions, the 13 fields and the velocities of the last advection travel together
         const double* src[17]; double* dst[17];
         src[0] = S->tz; dst[0] = S->tz2; src[1] = S->tx; dst[1] = S->tx2;
@@ -666,27 +753,40 @@ static int sort_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, doubl
         std::swap(S->vtz, S->tmp[0]); std::swap(S->vtx, S->tmp[1]);
         for (int k = 0; k < NFTRAC; k++) std::swap(S->f[k], S->f2[k]);
     }
+    if (ninj > 0) {
+        InjectSorted a{};
+        a.nc = nc; a.ncx = ncx; a.crow0 = S->crow0; a.ccol0 = S->ccol0; a.start = S->cell_start; a.count = S->cell_res;
+        a.need = S->need; a.off = S->need_off; a.rank = strict ? S->need_rank : nullptr;
+        a.tz = S->tz; a.tx = S->tx; for (int k = 0; k < NFTRAC; k++) a.f[k] = S->f[k];
+        a.vtz = S->vtz; a.vtx = S->vtx; a.orig = S->orig;
+        a.z0 = z0; a.hz = hz; a.x0 = x0; a.hx = hx; a.seed = o.inject->inject_seed; a.step = (unsigned)o.it; a.id0 = id0; a.n_old = (int)n;
+        a.zc = coords_z(ctx, S, 0); a.xc = coords_x(ctx, S, 0);
+        hipLaunchKernelGGL(k_inject_sorted, dim3((nc + 63) / 64), dim3(64), 0, ctx->stream, a);
+        S->n = n + ninj;
+    }
+    if (o.ninjected) *o.ninjected = ninj;
     PL_HIP(ctx, hipGetLastError());
-    if (removed) *removed = 0;
-    if (del_outside && n > 0) {
-        int alive_n = 0;
-        PL_HIP(ctx, hipMemcpyAsync(&alive_n, S->cell_start + nc, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    if (o.removed) *o.removed = 0;
+    if (o.del_outside && n > 0) {
+        int h[2] = {0, 0};
+        PL_HIP(ctx, hipMemcpyAsync(h, S->cell_start + nc + 8, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (alive_n < n) {
+        const int alive_n = h[0], all_n = h[1];
+        if (alive_n < all_n) {
             // the survivors are the first alive_n entries; renumber `orig` so that downloads keep the caller's
             // relative order (np.delete keeps it, pylamp2.py:578-580).  cell / dest are free after the sort.
-            PL_HIP(ctx, hipMemsetAsync(S->cell, 0, (size_t)n * sizeof(int), ctx->stream));
+            PL_HIP(ctx, hipMemsetAsync(S->cell, 0, (size_t)all_n * sizeof(int), ctx->stream));
             if (alive_n > 0) hipLaunchKernelGGL(k_mark_alive, grid1d(alive_n), dim3(256), 0, ctx->stream, (long long)alive_n, S->orig, S->cell);
-            const int mm = (int)n, nbb = (mm + 1023) / 1024;
+            const int nbb = (all_n + 1023) / 1024;
             int* bs = nullptr;
             PL_HIP(ctx, hipMalloc((void**)&bs, (size_t)(nbb + 1) * sizeof(int)));
-            hipLaunchKernelGGL(k_scan_block, dim3(nbb), dim3(256), 0, ctx->stream, mm, S->cell, S->dest, bs);
+            hipLaunchKernelGGL(k_scan_block, dim3(nbb), dim3(256), 0, ctx->stream, all_n, S->cell, S->dest, bs);
             hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, ctx->stream, nbb, bs);
-            hipLaunchKernelGGL(k_scan_add, dim3((mm + 255) / 256), dim3(256), 0, ctx->stream, mm, S->dest, bs, 0);
+            hipLaunchKernelGGL(k_scan_add, dim3((all_n + 255) / 256), dim3(256), 0, ctx->stream, all_n, S->dest, bs, 0);
             if (alive_n > 0) hipLaunchKernelGGL(k_remap_orig, grid1d(alive_n), dim3(256), 0, ctx->stream, (long long)alive_n, S->orig, S->dest);
             PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
             (void)hipFree(bs);
-            if (removed) *removed = n - alive_n;
+            if (o.removed) *o.removed = all_n - alive_n;
             S->n = alive_n;
             S->max_id_valid = false;
         }
@@ -694,38 +794,50 @@ static int sort_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, doubl
     return 0;
 }
 
-// Slab only: send the tracers in the two leaver rows to the neighbour ranks, append what arrives,
-// then sort again.  (Tracers move less than a cell per step, so rank +-1 is always the destination;
-// one that jumps further is simply forwarded again at the next step.)
-static int migrate_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, double x0, double hx) {
+// Several ranks: send the tracers in the 8 leaver buckets to the neighbour blocks, append what arrives, then sort
+// again.  (Tracers move less than a cell per step, so a neighbour block is always the destination; one that jumps
+// further is simply forwarded again at the next step.)  The arrays grow when the arrivals do not fit.
+// The census + refill of o.inject happens in the final sort, when every tracer is on its owner.
+static int migrate_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, double x0, double hx, const SortOpts& o) {
     if (ctx->nranks <= 1) return 0;
-    const int ncx = S->ncx;
-    int h[2] = {0, 0};
-    PL_HIP(ctx, hipMemcpyAsync(&h[0], S->cell_start + (size_t)S->lo_ext * ncx, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    PL_HIP(ctx, hipMemcpyAsync(&h[1], S->cell_start + (size_t)(S->ncz - S->hi_ext) * ncx, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    static const int DZ[8] = {-1, 1, 0, 0, -1, -1, 1, 1}, DX[8] = {0, 0, -1, 1, -1, 1, -1, 1}, OPP[8] = {1, 0, 3, 2, 7, 6, 5, 4};
+    const int nc = S->sort_cells, R = ctx->nranks;
+    int h[10];
+    PL_HIP(ctx, hipMemcpyAsync(h, S->cell_start + nc, 10 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const long long n = S->n;
-    const long long n_lo = S->lo_ext ? h[0] : 0, hi_begin = S->hi_ext ? h[1] : n, n_hi = n - hi_begin, stay = hi_begin - n_lo;
+    const long long stay = h[0];
+    // who sends how many to whom: slot [r*8 + k] = tracers rank r sends towards direction k
+    std::vector<double> cnt((size_t)8 * R, 0.0);
+    for (int k = 0; k < 8; k++) cnt[(size_t)8 * ctx->rank + k] = (double)(h[k + 1] - h[k]);
+    PL_TRY(pl_allreduce_host(ctx, cnt.data(), (long long)cnt.size(), 0));
+    int peer[8]; long long nsend[8], nrecv[8], roff[8]; long long incoming = 0;
+    for (int k = 0; k < 8; k++) {
+        const int qz = ctx->pz + DZ[k], qx = ctx->px + DX[k];
+        peer[k] = (qz < 0 || qz >= ctx->Pz || qx < 0 || qx >= ctx->Px) ? -1 : qz * ctx->Px + qx;
+        nsend[k] = h[k + 1] - h[k];
+        nrecv[k] = peer[k] < 0 ? 0 : (long long)cnt[(size_t)8 * peer[k] + OPP[k]];
+        if (peer[k] < 0 && nsend[k] > 0) return pl_fail(ctx, "migrate_tracers: a tracer left through a domain wall (internal error)");
+        roff[k] = incoming; incoming += nrecv[k];
+    }
+    const long long n_all = S->n;
+    PL_TRY(grow_tracers(ctx, S, std::max(stay + incoming, n_all), n_all));    // collective decision: every rank knows its own need
     const int NC = 17;
     double* cols[NC]; double* spare[NC];
     cols[0] = S->tz; cols[1] = S->tx; spare[0] = S->tz2; spare[1] = S->tx2;
     for (int k = 0; k < NFTRAC; k++) { cols[2 + k] = S->f[k]; spare[2 + k] = S->f2[k]; }
     cols[15] = S->vtz; spare[15] = S->tmp[0]; cols[16] = S->vtx; spare[16] = S->tmp[1];
-    double *slo[NC], *shi[NC], *rcv[NC];
-    for (int k = 0; k < NC; k++) {
-        // stayers first into the spare buffers, arrivals appended behind them
-        PL_HIP(ctx, hipMemcpyAsync(spare[k], cols[k] + n_lo, (size_t)stay * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-        slo[k] = cols[k]; shi[k] = cols[k] + hi_begin; rcv[k] = spare[k] + stay;
+    std::vector<PlMsg> msgs;
+    for (int k = 0; k < 8; k++) {
+        if (peer[k] < 0 || (nsend[k] == 0 && nrecv[k] == 0)) continue;
+        for (int c = 0; c < NC; c++) msgs.push_back(PlMsg{peer[k], cols[c] + h[k], nsend[k], spare[c] + roff[k], nrecv[k]});
     }
-    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    long long got = 0;
-    PL_TRY(pl_comm_exchange_var(ctx, slo, n_lo, shi, n_hi, rcv, S->cap - stay, NC, &got));
-    std::swap(S->tz, S->tz2); std::swap(S->tx, S->tx2);
-    std::swap(S->vtz, S->tmp[0]); std::swap(S->vtx, S->tmp[1]);
-    for (int k = 0; k < NFTRAC; k++) std::swap(S->f[k], S->f2[k]);
-    S->n = stay + got;
-    if (S->n > 0) hipLaunchKernelGGL(k_iota, grid1d(S->n), dim3(256), 0, ctx->stream, S->n, S->orig);
-    return sort_tracers(ctx, S, z0, hz, x0, hx);
+    PL_TRY(pl_comm_sendrecv(ctx, msgs.data(), (int)msgs.size()));
+    if (incoming > 0)
+        for (int c = 0; c < NC; c++)
+            PL_HIP(ctx, hipMemcpyAsync(cols[c] + stay, spare[c], (size_t)incoming * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    S->n = stay + incoming;
+    hipLaunchKernelGGL(k_iota, grid1d(S->n), dim3(256), 0, ctx->stream, S->n, S->orig, 0);
+    return sort_tracers(ctx, S, z0, hz, x0, hx, o);
 }
 
 // un-permute resident arrays into the spare buffers so that downloads come out in the caller's order
@@ -735,76 +847,6 @@ static void unpermute(pl_ctx* ctx, PlStepState* S, int na, const double* const* 
         for (int k = 0; k < pa.na; k++) { pa.in[k] = in[k0 + k]; pa.out[k] = out[k0 + k]; }
         hipLaunchKernelGGL(k_permute, grid1d(S->n), dim3(256), 0, ctx->stream, S->n, S->orig, pa);
     }
-}
-
-// census of the sorted tracers and refill of depleted cells (end of step; pylamp2.py:588-633)
-static int inject_tracers(pl_ctx* ctx, PlStepState* S, const pl_step_config* cfg, int it, double z0, double hz, double x0,
-                          double hx, int64_t* ninj) {
-    *ninj = 0;
-    const int nc = S->ncz * S->ncx;
-    if (!S->need) {
-        for (int** q : {&S->need, &S->need_off, &S->need_flag, &S->need_rank}) PL_HIP(ctx, hipMalloc((void**)q, (size_t)(nc + 1) * sizeof(int)));
-    }
-    const int m1 = nc + 1, nb = (m1 + 1023) / 1024;
-    hipLaunchKernelGGL(k_deficit, dim3((m1 + 255) / 256), dim3(256), 0, ctx->stream, nc, S->ncx, S->lo_ext, S->ncz - S->hi_ext,
-                       S->cell_start, cfg->tracdens, cfg->tracdens_min, S->need, S->need_flag);
-    for (int pass = 0; pass < 2; pass++) {                 // exclusive scans of the deficits and of the deficient-cell flags
-        hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(256), 0, ctx->stream, m1, pass ? S->need_flag : S->need,
-                           pass ? S->need_rank : S->need_off, S->block_sums);
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, ctx->stream, nb, S->block_sums);
-        hipLaunchKernelGGL(k_scan_add, dim3((m1 + 255) / 256), dim3(256), 0, ctx->stream, m1, pass ? S->need_rank : S->need_off, S->block_sums, 0);
-    }
-    int m = 0, ndef = 0;
-    PL_HIP(ctx, hipMemcpyAsync(&m, S->need_off + nc, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    PL_HIP(ctx, hipMemcpyAsync(&ndef, S->need_rank + nc, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    // new IDs in global cell order: rank r continues after the ranks before it
-    const int R = ctx->nranks;
-    std::vector<double> cnt((size_t)2 * R, 0.0);
-    cnt[2 * ctx->rank] = m; cnt[2 * ctx->rank + 1] = ndef;
-    PL_TRY(pl_allreduce_host(ctx, cnt.data(), (long long)cnt.size(), 0));
-    double before = 0.0, total = 0.0, def_before = 0.0, def_total = 0.0;
-    for (int q = 0; q < R; q++) {
-        if (q < ctx->rank) { before += cnt[2 * q]; def_before += cnt[2 * q + 1]; }
-        total += cnt[2 * q]; def_total += cnt[2 * q + 1];
-    }
-    if (total == 0.0) return 0;
-    if (!S->max_id_valid) {                                // a deletion may have removed the holder of the maximum
-        double mx[1] = {-1.0};
-        if (S->n > 0) {
-            const int nbm = 256;
-            if (!S->partial || S->hpartial.size() < (size_t)nbm) {
-                if (S->partial) (void)hipFree(S->partial);
-                PL_HIP(ctx, hipMalloc((void**)&S->partial, 3 * 4096 * sizeof(double)));
-                S->hpartial.resize(3 * 4096);
-            }
-            hipLaunchKernelGGL(k_max1d, dim3(nbm), dim3(256), 0, ctx->stream, S->n, S->f[TR__ID], S->partial);
-            PL_HIP(ctx, hipMemcpyAsync(S->hpartial.data(), S->partial, nbm * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-            PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            for (int k = 0; k < nbm; k++) mx[0] = std::fmax(mx[0], S->hpartial[k]);
-        }
-        PL_TRY(pl_allreduce_host(ctx, mx, 1, 2));
-        S->max_id = mx[0]; S->max_id_valid = true;
-    }
-    const bool strict = cfg->inject_unique_ids == 0;
-    // strict: IDs start AT the current maximum and every refilled cell repeats one (pylamp2.py:621-622)
-    const double id0 = strict ? S->max_id + before - def_before : S->max_id + 1.0 + before;
-    S->max_id += strict ? total - def_total : total;
-    if (m == 0) return 0;
-    PL_TRY(grow_tracers(ctx, S, S->n + m, S->n));
-    InjectArgs a{};
-    a.nc = nc; a.ncx = S->ncx; a.crow0 = S->crow0; a.n = S->n; a.start = S->cell_start; a.need = S->need; a.off = S->need_off;
-    a.rank = strict ? S->need_rank : nullptr;
-    a.tz = S->tz; a.tx = S->tx; for (int k = 0; k < NFTRAC; k++) a.f[k] = S->f[k];
-    a.vtz = S->vtz; a.vtx = S->vtx;
-    a.z0 = z0; a.hz = hz; a.x0 = x0; a.hx = hx; a.seed = cfg->inject_seed; a.step = (unsigned)it; a.id0 = id0;
-    a.zc = coords_z(ctx, S, 0); a.xc = coords_x(ctx, S, 0);
-    hipLaunchKernelGGL(k_inject, dim3((nc + 63) / 64), dim3(64), 0, ctx->stream, a);
-    hipLaunchKernelGGL(k_iota, grid1d(m), dim3(256), 0, ctx->stream, (long long)m, S->orig + S->n, (int)S->n);
-    PL_HIP(ctx, hipGetLastError());
-    S->n += m;
-    *ninj = m;
-    return sort_tracers(ctx, S, z0, hz, x0, hx);
 }
 
 static double now_ms() {
@@ -820,7 +862,7 @@ static int scatter_to_planes(pl_ctx* ctx, PlStepState* S, int nf, const int* fid
     for (int k = 0; k < nf; k++) { a.f[k] = fidx[k] >= 0 ? S->f[fidx[k]] : S->tmp[-fidx[k] - 1]; a.scheme[k] = schemes[k]; }
     a.z0 = z0; a.hz = hz; a.x0 = x0; a.hx = hx; a.nz = g.nz; a.nx = g.nx;
     a.zc = coords_z(ctx, S, stag_z); a.xc = coords_x(ctx, S, stag_x);
-    a.cell_start = S->cell_start; a.ncz = S->ncz; a.ncx = S->ncx; a.crow0 = S->crow0;     // cell-sorted (sort_tracers)
+    a.cell_start = S->cell_start; a.ncz = S->ncz; a.ncx = S->ncx; a.crow0 = S->crow0; a.ccol0 = S->ccol0;     // cell-sorted (sort_tracers)
     return pl_scatter_device(ctx, a, planes, g.pitch, pl_idx(g, 0, 0), &g);
 }
 
@@ -829,6 +871,7 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
     PL_HIP(ctx, hipSetDevice(ctx->device));
     PlStepState* S = state_of(ctx);
     if (S->n <= 0 && ctx->nranks == 1) return pl_fail(ctx, "pl_step: no tracers resident (call pl_tracers_upload)");
+    if (!S->cell_start) return pl_fail(ctx, "pl_step: no tracers uploaded on this rank (every rank calls pl_tracers_upload, with n = 0 if need be)");
     PL_TRY(ensure_coords(ctx, S));
     PL_TRY(pl_stokes_check_bc(ctx, cfg->bcstokes));
     if (cfg->do_heatdiff) PL_TRY(pl_heat_check_bc(ctx, cfg->bcheat));
@@ -977,7 +1020,7 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
                                     cfg->heat_maxit > 0 ? cfg->heat_maxit : 2000, &rep->heat, &xs));
         PL_HIP(ctx, hipMemcpyAsync(p_newT, xs, pb, hipMemcpyDeviceToDevice, ctx->stream));
         PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        PL_TRY(pl_halo_rows(ctx, g, p_newT, 1, g.plane));
+        PL_TRY(pl_halo(ctx, g, p_newT, 1, g.plane));
         rep->ms_heat = now_ms() - t0;
 
         // temperature to tracers
@@ -992,13 +1035,13 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
         ga.g.zmin = ctx->geom.zc[0]; ga.g.xmin = ctx->geom.xc[0];
         ga.g.Lz = ctx->geom.zc[nz - 1] - ctx->geom.zc[0]; ga.g.Lx = ctx->geom.xc[nx - 1] - ctx->geom.xc[0];
         ga.g.rect = ctx->geom.uniform ? 0 : 1;
-        ga.g.pitch = g.pitch; ga.g.off = pl_idx(g, -g.gi0, 0);      // field row index is GLOBAL
+        ga.g.pitch = g.pitch; ga.g.off = pl_idx(g, -g.gi0, -g.gj0);      // field indices are GLOBAL
         if (it == 1 || !S->have_newtemp) {
             ga.fields[0] = p_newT; ga.out[0] = S->f[TR_TMP];
             pl_launch_gather(ctx, ga);
         } else {
             hipLaunchKernelGGL(k_plane_sub, grid2d(g), dim3(64, 4), 0, ctx->stream, g, p_newT, p_T, p_dT);
-            PL_TRY(pl_halo_rows(ctx, g, p_dT, 1, g.plane));
+            PL_TRY(pl_halo(ctx, g, p_dT, 1, g.plane));
             ga.fields[0] = p_dT; ga.out[0] = S->tmp[0];
             pl_launch_gather(ctx, ga);
             const double inv2 = (2.0 / dx) * (2.0 / dx) + (2.0 / dz) * (2.0 / dz);
@@ -1024,38 +1067,20 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
 
     // ---- 6. advection (pylamp2.py:484-572) ------------------------------------------------------------
     t0 = now_ms();
+    // window of the padded centre grid the RK4 stages of this rank's tracers can reach: a tracer moves less than a cell
+    // per stage (the time step is CFL-limited, pylamp2.py:364), so cells [gi0-1, gi0+lnz+1] of the padded grid, i.e.
+    // its nodes I in [gi0-1, gi0+lnz+2], computed from the velocity planes with a halo 3 nodes deep -- no all-gather.
+    const int I0 = std::max(g.gi0 - 1, 0), I1 = std::min(g.gi0 + g.lnz + 2, nz), J0 = std::max(g.gj0 - 1, 0), J1 = std::min(g.gj0 + g.lnx + 2, nx);
+    const int nVr = I1 - I0 + 1, nVc = J1 - J0 + 1;
+    const size_t VN = (size_t)nVr * nVc;
     double* V;
-    const size_t VN = (size_t)(nz + 1) * (nx + 1);
     PL_TRY(pl_buf(ctx, "advect_vel", 2 * VN * sizeof(double), &V, false));
-    PlGeom gfull = g;                       // the advection velocity grid is replicated on every rank
-    const double* a_vz = p_vz; const double* a_vx = p_vx;
-    if (ctx->nranks > 1) {
-        gfull.gi0 = 0; gfull.lnz = nz; gfull.plane = (long long)(nz + 2) * g.pitch;
-        double* full;
-        PL_TRY(pl_buf(ctx, "vel_full", (size_t)2 * gfull.plane * sizeof(double), &full));
-        const long long C = (nz - 1) / ctx->nranks, cnt = C * g.pitch;
-        for (int q = 0; q < 2; q++)
-            PL_HIP(ctx, hipMemcpyAsync(full + q * gfull.plane + (long long)(1 + g.gi0) * g.pitch, (q ? p_vx : p_vz) + g.pitch,
-                                       (size_t)g.lnz * g.pitch * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-        PL_TRY(pl_comm_allgather(ctx, full + g.pitch, cnt, 2, gfull.plane));
-        PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        // the last node row (a wall / ghost row) lives on the last rank only
-        std::vector<double> row((size_t)2 * g.pitch, 0.0);
-        if (ctx->rank == ctx->nranks - 1)
-            for (int q = 0; q < 2; q++)
-                PL_HIP(ctx, hipMemcpy(row.data() + (size_t)q * g.pitch, full + q * gfull.plane + (long long)nz * g.pitch,
-                                      (size_t)g.pitch * sizeof(double), hipMemcpyDeviceToHost));
-        PL_TRY(pl_allreduce_host(ctx, row.data(), (long long)row.size(), 0));
-        for (int q = 0; q < 2; q++)
-            PL_HIP(ctx, hipMemcpy(full + q * gfull.plane + (long long)nz * g.pitch, row.data() + (size_t)q * g.pitch,
-                                  (size_t)g.pitch * sizeof(double), hipMemcpyHostToDevice));
-        a_vz = full; a_vx = full + gfull.plane;
-    }
+    PL_TRY(pl_halo(ctx, g, xsol, 2, g.plane, 3));
     {
-        dim3 gr((nx + 1 + 63) / 64, (nz + 1 + 3) / 4);
-        hipLaunchKernelGGL(k_advection_velocity, gr, dim3(64, 4), 0, ctx->stream, gfull, a_vz, a_vx,
+        dim3 gr((nVc + 63) / 64, (nVr + 3) / 4);
+        hipLaunchKernelGGL(k_advection_velocity, gr, dim3(64, 4), 0, ctx->stream, g, (const double*)p_vz, (const double*)p_vx,
                            (cfg->bcstokes[0] & PL_BC_FREESLIP) ? 1 : 0, (cfg->bcstokes[1] & PL_BC_FREESLIP) ? 1 : 0,
-                           (cfg->bcstokes[2] & PL_BC_FREESLIP) ? 1 : 0, (cfg->bcstokes[3] & PL_BC_FREESLIP) ? 1 : 0, V, V + VN);
+                           (cfg->bcstokes[2] & PL_BC_FREESLIP) ? 1 : 0, (cfg->bcstokes[3] & PL_BC_FREESLIP) ? 1 : 0, I0, J0, nVr, nVc, V, V + VN);
     }
     PlRk4Args ra{};
     ra.n = n; ra.tz = S->tz; ra.tx = S->tx;
@@ -1065,14 +1090,29 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
         ra.g.zmin = gz0; ra.g.xmin = gx0; ra.g.Lz = S->gmz[nz - 1] - gz0; ra.g.Lx = S->gmx[nx - 1] - gx0;
     }
     ra.g.rect = ctx->geom.uniform ? 0 : 1;
-    ra.g.pitch = nx + 1; ra.g.off = 0;
+    ra.g.pitch = nVc; ra.g.off = -((long long)I0 * nVc + J0);      // cell indices are GLOBAL
+    ra.g.ie_lo = I0; ra.g.ie_hi = I1 - 1; ra.g.je_lo = J0; ra.g.je_hi = J1 - 1;      // cells held locally
     ra.Vz = V; ra.Vx = V + VN; ra.dt = tstep;
     ra.tz_out = S->tz2; ra.tx_out = S->tx2; ra.vz_out = S->vtz; ra.vx_out = S->vtx;
     ra.fence = cfg->tracs_fence_disabled ? 0 : 1; ra.eps = PL_EPS; ra.Lz = Lz; ra.Lx = Lx;
+    double* oowc = nullptr;
+    if (ctx->nranks > 1) {
+        PL_TRY(pl_buf(ctx, "rk4_counter", 64, &oowc, false));
+        PL_HIP(ctx, hipMemsetAsync(oowc, 0, 64, ctx->stream));
+        ra.n_outside_window = (unsigned long long*)oowc;
+    }
     pl_launch_rk4(ctx, ra);
     PL_HIP(ctx, hipGetLastError());
     std::swap(S->tz, S->tz2); std::swap(S->tx, S->tx2);
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->nranks > 1) {      // collective: a stage that left the local velocity window means the step was not CFL-limited
+        unsigned long long no = 0;
+        PL_HIP(ctx, hipMemcpy(&no, oowc, sizeof(no), hipMemcpyDeviceToHost));
+        double v[1] = {(double)no};
+        PL_TRY(pl_allreduce_host(ctx, v, 1, 0));
+        if (v[0] > 0) return pl_fail(ctx, "pl_step: a tracer moved by more than one cell in an RK4 stage (time step not CFL-limited); the "
+                                          "block decomposition holds the advection velocity one cell around each block only");
+    }
     rep->ms_advect = now_ms() - t0;
 
     // ---- 7. cell sort of the advected tracers, slab migration, census + injection --------------------
@@ -1080,11 +1120,13 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
     S->sorted = false;
     {
         long long removed = 0;
-        PL_TRY(sort_tracers(ctx, S, z0, hz, x0, hx, cfg->tracs_fence_disabled ? 1 : 0, Lz, Lx, &removed));
+        SortOpts so; so.del_outside = cfg->tracs_fence_disabled ? 1 : 0; so.Lz = Lz; so.Lx = Lx; so.removed = &removed;
+        SortOpts si; si.inject = cfg; si.it = it; si.ninjected = &rep->ninjected;
+        if (ctx->nranks == 1) { so.inject = si.inject; so.it = it; so.ninjected = si.ninjected; }     // one pass does it all
+        PL_TRY(sort_tracers(ctx, S, z0, hz, x0, hx, so));
         rep->nremoved = removed;
+        PL_TRY(migrate_tracers(ctx, S, z0, hz, x0, hx, si));          // several ranks: the refill follows the migration
     }
-    PL_TRY(migrate_tracers(ctx, S, z0, hz, x0, hx));
-    if (cfg->tracdens_min > 0 && cfg->tracdens > 0) PL_TRY(inject_tracers(ctx, S, cfg, it, z0, hz, x0, hx, &rep->ninjected));
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     S->sorted = true;
     rep->ms_sort = now_ms() - t0;

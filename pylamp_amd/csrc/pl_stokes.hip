@@ -26,7 +26,7 @@ __device__ inline void stokes_apply_node(const PlStokesOp& op, const double* __r
     const int p = g.pitch;
     // 32-bit element offsets from wave-uniform base pointers: lets the compiler use the
     // SGPR-base + VGPR-offset addressing mode instead of a 64-bit address per neighbour
-    const int c = (li + 1) * p + (lj + PL_PADL);
+    const int c = (li + PL_RING) * p + (lj + PL_PADL);
     const double* __restrict__ vz = x;
     const double* __restrict__ vx = x + g.plane;
     const double* __restrict__ P = x + 2 * g.plane;
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(64 * ROWS) void k_stokes_apply_v2(PlStokesOp op, co
     const bool active = lj0 < g.lnx;                        // lanes beyond the row take part in shuffles only
     const bool has_right = (lj0 + 2) < g.lnx;               // the lane to the right holds real columns
     const int p = g.pitch;
-    const int c = (li + 1) * p + PL_PADL + lj0;             // element offset of column A (16-B aligned)
+    const int c = (li + PL_RING) * p + PL_PADL + lj0;             // element offset of column A (16-B aligned)
     const double* __restrict__ vz = x;
     const double* __restrict__ vx = x + g.plane;
     const double* __restrict__ P = x + 2 * g.plane;
@@ -353,7 +353,7 @@ void pl_launch_stokes_apply(pl_ctx* ctx, const PlStokesOp& op, const double* x, 
     // were never the limit, the barrier is one.
     // PYLAMP_VV_VEC=0 selects the scalar one-column-per-lane kernel (cross-check of the vectorised one, like the multigrid kernels)
     static const bool vec = [] { const char* e = getenv("PYLAMP_VV_VEC"); return !(e && e[0] == '0'); }();
-    if (vec && (op.g.plane % 2) == 0) {           // double2 accesses need even plane strides (pitch is a multiple of 16)
+    if (vec && (op.g.plane % 2) == 0 && !(op.g.gj0 & 1)) {     // double2 accesses need even plane strides (pitch is a multiple of 16) and an even first column
         const int gx = (op.g.lnx + 127) / 128;
 #define PL_APPLY_LAUNCH(KERNEL, ROWS)                                                                                   \
         do {                                                                                                            \
@@ -455,7 +455,7 @@ extern "C" int pl_stokes_apply(pl_ctx* ctx, const double* x, double* y) {
     double *dx, *dy;
     PL_TRY(pl_buf(ctx, "api_x", vb, &dx)); PL_TRY(pl_buf(ctx, "api_y", vb, &dy));
     PL_TRY(pl_vec3_upload(ctx, g, x, dx));
-    PL_TRY(pl_halo_rows(ctx, g, dx, 3, g.plane));
+    PL_TRY(pl_halo(ctx, g, dx, 3, g.plane));
     pl_launch_stokes_apply(ctx, ctx->sop, dx, dy);
     PL_HIP(ctx, hipGetLastError());
     PL_TRY(pl_vec3_download(ctx, g, dy, y));

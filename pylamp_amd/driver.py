@@ -62,17 +62,18 @@ def falling_block_tracers(nx, L, tracdens, rng):
     return tr_x, tr_f
 
 
-def mantle_tracers(nx, L, tracdens, rng, perturb=20.0, zrange=None, id0=0):
+def mantle_tracers(nx, L, tracdens, rng, perturb=20.0, zrange=None, id0=0, xrange=None):
     """Model-1-like T-dependent mantle (values of pylamp2.py:146-154) with a conductive
     initial temperature plus a sinusoidal perturbation.
-    zrange=(lo, hi) draws only this slab's share of the tracers (multi-GPU benchmark set-up)."""
+    zrange=(lo, hi) / xrange=(lo, hi) draw only this block's share of the tracers (multi-GPU benchmark set-up)."""
     n = int(np.prod(nx)) * tracdens
-    if zrange is None:
+    if zrange is None and xrange is None:
         tr_x = rng.random((n, DIM)) * np.array(L)
     else:
-        lo, hi = max(zrange[0], 0.0), min(zrange[1], L[IZ])
-        n = int(round(n * (hi - lo) / L[IZ]))
-        tr_x = rng.random((n, DIM)) * np.array([hi - lo, L[IX]]) + np.array([lo, 0.0])
+        zlo, zhi = (0.0, L[IZ]) if zrange is None else (max(zrange[0], 0.0), min(zrange[1], L[IZ]))
+        xlo, xhi = (0.0, L[IX]) if xrange is None else (max(xrange[0], 0.0), min(xrange[1], L[IX]))
+        n = int(round(n * (zhi - zlo) / L[IZ] * (xhi - xlo) / L[IX]))
+        tr_x = rng.random((n, DIM)) * np.array([zhi - zlo, xhi - xlo]) + np.array([zlo, xlo])
     tr_f = np.zeros((n, NFTRAC))
     tr_f[:, TR__ID] = np.arange(n) + id0
     tr_f[:, TR_RH0] = 3300; tr_f[:, TR_ALP] = 3.5e-5; tr_f[:, TR_MAT] = 2; tr_f[:, TR_ET0] = 1e20
@@ -83,7 +84,7 @@ def mantle_tracers(nx, L, tracdens, rng, perturb=20.0, zrange=None, id0=0):
 
 
 class Simulation:
-    def __init__(self, nx, L, tr_x=None, tr_f=None, options=None, device=None, grid=None):
+    def __init__(self, nx, L, tr_x=None, tr_f=None, options=None, device=None, grid=None, local=None):
         """grid: optional [z, x] node coordinates from 0 to L (rectilinear, strictly increasing).  The stock
         driver only builds regular grids (pylamp2.py:90); a non-uniform one makes the marker kernels locate
         cells by per-axis search."""
@@ -99,7 +100,10 @@ class Simulation:
                 if abs(self.grid[i][0]) > 0 or abs(self.grid[i][-1] - self.L[i]) > 1e-12 * self.L[i]:
                     raise Exception("grid: coordinates must run from 0 to L")
         self.opt = options or Options()
-        self.ctx = Context(self.nx, self.grid, device=device)
+        # local = (group, rank, Pz, Px): a virtual rank of an in-process group (VirtualCluster) instead of torch.distributed
+        self.ctx = Context(self.nx, self.grid, device=device, attach_dist=local is None)
+        if local is not None:
+            self.ctx.attach_local(*local)
         self.it = 0
         self.totaltime = 0.0
         self.last = None
@@ -108,25 +112,31 @@ class Simulation:
             self.upload(tr_x, tr_f)
 
     # -- tracer state -------------------------------------------------------------------------
-    def slab(self):
-        """z-interval [lo, hi) of the node rows this rank owns (whole domain on one rank)."""
+    def block(self):
+        """[zlo, zhi) x [xlo, xhi) of the node block this rank owns (the whole plane on one rank; blocks at a domain
+        wall extend to infinity so that every tracer has exactly one owner)."""
         if self.ctx.nranks == 1:
-            return -np.inf, np.inf
-        first, _ = self.ctx.local_rows()
-        c = (self.nx[0] - 1) // self.ctx.nranks
-        lo = -np.inf if self.ctx.rank == 0 else self.grid[IZ][first]
-        hi = np.inf if self.ctx.rank == self.ctx.nranks - 1 else self.grid[IZ][first + c]
-        return lo, hi
+            return (-np.inf, np.inf), (-np.inf, np.inf)
+        i0, ni, j0, nj, Pz, Px = self.ctx.local_block()
+        pz, px = self.ctx.rank // Px, self.ctx.rank % Px
+        cz, cx = (self.nx[0] - 1) // Pz, (self.nx[1] - 1) // Px
+        zr = (-np.inf if pz == 0 else self.grid[IZ][i0], np.inf if pz == Pz - 1 else self.grid[IZ][i0 + cz])
+        xr = (-np.inf if px == 0 else self.grid[IX][j0], np.inf if px == Px - 1 else self.grid[IX][j0 + cx])
+        return zr, xr
+
+    def slab(self):
+        """z-interval of this rank's block (kept for callers that only split rows)."""
+        return self.block()[0]
 
     def upload(self, tr_x, tr_f):
-        """Upload tracers; under torch.distributed every rank passes the full (or any superset of
-        its) tracer set and keeps the ones inside its row slab."""
+        """Upload tracers; under several ranks every rank passes the full (or any superset of its) tracer set and keeps
+        the ones inside its block."""
         tr_x = _lib.f64(tr_x); tr_f = _lib.f64(tr_f)
         if tr_x.shape[1] != DIM or tr_f.shape != (tr_x.shape[0], NFTRAC):
             raise Exception("tracer arrays must be (n,2) and (n,13)")
-        lo, hi = self.slab()
         if self.ctx.nranks > 1:
-            keep = (tr_x[:, IZ] >= lo) & (tr_x[:, IZ] < hi)
+            (zlo, zhi), (xlo, xhi) = self.block()
+            keep = (tr_x[:, IZ] >= zlo) & (tr_x[:, IZ] < zhi) & (tr_x[:, IX] >= xlo) & (tr_x[:, IX] < xhi)
             tr_x = np.ascontiguousarray(tr_x[keep]); tr_f = np.ascontiguousarray(tr_f[keep])
         self.ntrac = tr_x.shape[0]
         self.ctx.check(self.ctx.lib.pl_tracers_upload(self.ctx.handle(), self.ntrac, _lib.dptr(tr_x), _lib.dptr(tr_f)))
@@ -157,10 +167,12 @@ class Simulation:
         return tr_x[o], tr_f[o], v[o]
 
     def census(self):
-        """Tracers per cell of this rank's owned cells, shape (rows, nx-1) (pylamp2.py:588-598)."""
+        """Tracers per cell of this rank's block, shape (cell rows, cell columns) (pylamp2.py:588-598)."""
         r0 = C.c_int(); nr = C.c_int()
         self.ctx.check(self.ctx.lib.pl_tracers_census(self.ctx.handle(), 0, None, C.byref(r0), C.byref(nr)))
-        cnt = np.empty((nr.value, self.nx[1] - 1), dtype=np.int32)
+        _, _, j0, nj, _, _ = self.ctx.local_block()
+        ncx = nj - 1 if j0 + nj >= self.nx[1] else nj
+        cnt = np.empty((nr.value, ncx), dtype=np.int32)
         self.ctx.check(self.ctx.lib.pl_tracers_census(self.ctx.handle(), cnt.size, cnt.ctypes.data_as(C.POINTER(C.c_int32)),
                                                       C.byref(r0), C.byref(nr)))
         return cnt
@@ -238,6 +250,57 @@ class Simulation:
 
     def close(self):
         self.ctx.close()
+
+
+class VirtualCluster:
+    """Pz x Px virtual ranks in ONE process, each a Simulation with its own device context and host thread, joined by
+    the library's in-process transport (pl_local_group_*).  The grid is decomposed exactly as on Pz*Px GPUs -- the same
+    pack / unpack kernels, halo logic, replicated multigrid levels and 8-neighbour tracer migration -- only the
+    messages are device-to-device copies.  This is how the 2 x 4 layout is rehearsed on a single GPU."""
+
+    def __init__(self, nx, L, Pz, Px, tr_x, tr_f, options=None, device=None, grid=None):
+        import concurrent.futures
+        lib = _lib.load()
+        self.Pz, self.Px, self.size = int(Pz), int(Px), int(Pz) * int(Px)
+        g = C.c_void_p()
+        if lib.pl_local_group_create(C.byref(g), self.size) != 0:
+            raise Exception("pl_local_group_create failed")
+        self.group, self.lib = g, lib
+        self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=self.size)
+        self.sims = [Simulation(nx, L, options=options, device=device, grid=grid, local=(g, r, Pz, Px)) for r in range(self.size)]
+        self.all(lambda s: s.upload(tr_x, tr_f))
+
+    def all(self, fn, timeout=900):
+        """fn(sim) on every rank at once (the calls are collective); returns the list of results in rank order."""
+        futs = [self.pool.submit(fn, s) for s in self.sims]
+        return [f.result(timeout=timeout) for f in futs]
+
+    def step(self):
+        return self.all(lambda s: s.step())
+
+    def field(self, name):
+        return self.all(lambda s: s.field(name))[0]          # every rank receives the assembled global array
+
+    def tracers(self):
+        """All tracers of all ranks, ordered by TR__ID."""
+        parts = self.all(lambda s: s.tracers() + (s.tracer_velocity(),))
+        tr_x = np.concatenate([p[0] for p in parts]); tr_f = np.concatenate([p[1] for p in parts]); v = np.concatenate([p[2] for p in parts])
+        o = np.argsort(tr_f[:, TR__ID], kind="stable")
+        return tr_x[o], tr_f[o], v[o]
+
+    def comm_stats(self, reset=False):
+        out = []
+        for s in self.sims:
+            cc = (C.c_int64 * 4)()
+            s.ctx.check(self.lib.pl_comm_stats(s.ctx.handle(), cc, 1 if reset else 0))
+            out.append([int(v) for v in cc])
+        return out
+
+    def close(self):
+        for s in self.sims:
+            s.close()
+        self.pool.shutdown(wait=False)
+        self.lib.pl_local_group_destroy(self.group)
 
 
 def run(nx, L, model="block", tracdens=4, steps=5, seed=0, outdir=None, options=None):

@@ -1,7 +1,7 @@
 """Multi-GPU communication layer: one process per GPU, torch.distributed.
 
-The C library decomposes the grid into row slabs and calls back into this module for every
-exchange (include/pylamp_hip.h, pl_comm_ops).  Two transports:
+The C library decomposes the grid into Pz x Px blocks and calls back into this module for every
+message group (include/pylamp_hip.h, pl_comm_ops).  Two transports:
 
   * backend "nccl" (= RCCL over xGMI on a real node): device pointers of the library are
     wrapped zero-copy as torch tensors (__cuda_array_interface__) and moved with
@@ -18,17 +18,14 @@ import numpy as np
 
 from . import _lib
 
-_EXCHANGE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
-                        C.c_int64, C.c_int)
+_SENDRECV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                        C.POINTER(C.c_void_p), C.POINTER(C.c_int64))
 _ALLREDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.c_int)
-_ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64)
-_EXCHANGE_VAR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.c_int64, C.POINTER(C.c_void_p), C.c_int64,
-                            C.POINTER(C.c_void_p), C.c_int64, C.c_int, C.POINTER(C.c_int64))
+_ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
 
 
 class CommOps(C.Structure):
-    _fields_ = [("exchange", _EXCHANGE), ("allreduce_host", _ALLREDUCE), ("allgather", _ALLGATHER),
-                ("exchange_var", _EXCHANGE_VAR), ("user", C.c_void_p)]
+    _fields_ = [("sendrecv", _SENDRECV), ("allreduce_host", _ALLREDUCE), ("allgather", _ALLGATHER), ("user", C.c_void_p)]
 
 
 class _DevView:
@@ -39,13 +36,39 @@ class _DevView:
                                          "version": 3, "strides": None}
 
 
-def slab_rows(nz, rank, size):
-    """Node rows [first, first+n) owned by `rank` (mirrors pl_set_comm)."""
-    cells = nz - 1
-    if cells % size:
-        raise Exception("(nz-1) must be divisible by the number of ranks")
-    c = cells // size
-    return rank * c, (c + 1 if rank == size - 1 else c)
+def choose_layout(size):
+    """Pz x Px with Px >= Pz, most square (2 -> 1x2, 4 -> 2x2, 8 -> 2x4); PYLAMP_DECOMP="PzxPx" overrides.  Mirrors
+    pl_set_comm."""
+    import os
+    e = os.environ.get("PYLAMP_DECOMP")
+    if e:
+        try:
+            a, b = (int(v) for v in e.lower().split("x"))
+            if a >= 1 and b >= 1 and a * b == size:
+                return a, b
+        except ValueError:
+            pass
+    pz = 1
+    for a in range(1, int(size ** 0.5) + 1):
+        if size % a == 0:
+            pz = a
+    return pz, size // pz
+
+
+def block_1d(n, P, p):
+    """Nodes [first, first+count) of part p when n nodes (n-1 cells) are split into P parts (mirrors pl_block_1d)."""
+    cells = n - 1
+    if cells % P:
+        raise Exception("(n-1) must be divisible by the number of blocks along the axis")
+    c = cells // P
+    return p * c, (c + 1 if p == P - 1 else c)
+
+
+def block_of(nx, rank, Pz, Px):
+    """(first_row, n_rows, first_col, n_cols) of rank = pz * Px + px."""
+    i0, ni = block_1d(nx[0], Pz, rank // Px)
+    j0, nj = block_1d(nx[1], Px, rank % Px)
+    return i0, ni, j0, nj
 
 
 class Comm:
@@ -64,14 +87,13 @@ class Comm:
         self.host_group = group if self.backend == "gloo" else dist.new_group(backend="gloo")
         self.stage_group = self.host_group
         self.errors = []
-        self._ops = CommOps(_EXCHANGE(self._exchange), _ALLREDUCE(self._allreduce_host), _ALLGATHER(self._allgather),
-                            _EXCHANGE_VAR(self._exchange_var), None)
+        self._ops = CommOps(_SENDRECV(self._sendrecv), _ALLREDUCE(self._allreduce_host), _ALLGATHER(self._allgather), None)
         if not self.device_mode:
             os.environ["PYLAMP_RCCL"] = "0"      # direct RCCL needs one GPU per rank (nccl backend)
         ctx.check(ctx.lib.pl_set_comm(ctx.handle(), self.rank, self.size, C.byref(self._ops)))
         nat = C.c_int(0)
         ctx.check(ctx.lib.pl_comm_info(ctx.handle(), None, None, C.byref(nat)))
-        self.native = bool(nat.value)
+        self.native = nat.value == 1
         ctx.comm = self          # keep the callbacks alive as long as the context
 
     # ---- helpers ------------------------------------------------------------------------------
@@ -117,62 +139,47 @@ class Comm:
             self.device_mode = False
         self._agreed = True
 
-    # ---- neighbour exchange ------------------------------------------------------------------------
-    def _exchange(self, user, send_lo, recv_lo, send_hi, recv_hi, count, nseg, stride, add):
-        return self._guard(self._exchange_impl, send_lo, recv_lo, send_hi, recv_hi, count, nseg, stride, add)
+    # ---- point-to-point messages (halo exchange, tracer migration) ---------------------------------------------
+    def _sendrecv(self, user, nmsg, peer, send, nsend, recv, nrecv):
+        return self._guard(self._sendrecv_impl, nmsg, peer, send, nsend, recv, nrecv)
 
-    def _exchange_impl(self, send_lo, recv_lo, send_hi, recv_hi, count, nseg, stride, add):
+    def _sendrecv_impl(self, nmsg, peer, send, nsend, recv, nrecv):
         dist, torch = self.dist, self.torch
         self._agree_device_mode()
-        lo, hi = self.rank - 1, self.rank + 1
-        has_lo, has_hi = lo >= 0, hi < self.size
-        B = 8
+        msgs = [(int(peer[k]), send[k], int(nsend[k]), recv[k], int(nrecv[k])) for k in range(nmsg)]
         if self.device_mode:
-            ops, post = [], []
-            for k in range(nseg):
-                o = k * stride * B
-                if has_lo:
-                    ops.append(dist.P2POp(dist.isend, self._dev(send_lo + o, count), lo, self.group))
-                    if add:
-                        t = torch.empty(count, dtype=torch.float64, device="cuda")
-                        ops.append(dist.P2POp(dist.irecv, t, lo, self.group)); post.append((recv_lo + o, t))
-                    else:
-                        ops.append(dist.P2POp(dist.irecv, self._dev(recv_lo + o, count), lo, self.group))
-                if has_hi:
-                    ops.append(dist.P2POp(dist.isend, self._dev(send_hi + o, count), hi, self.group))
-                    if add:
-                        t = torch.empty(count, dtype=torch.float64, device="cuda")
-                        ops.append(dist.P2POp(dist.irecv, t, hi, self.group)); post.append((recv_hi + o, t))
-                    else:
-                        ops.append(dist.P2POp(dist.irecv, self._dev(recv_hi + o, count), hi, self.group))
+            ops = []
+            for p, sp, ns, rp, nr in msgs:           # both sides list their messages with a peer in the same order
+                if ns:
+                    ops.append(dist.P2POp(dist.isend, self._dev(sp, ns), p, self.group))
+                if nr:
+                    ops.append(dist.P2POp(dist.irecv, self._dev(rp, nr), p, self.group))
             if ops:
                 for w in dist.batch_isend_irecv(ops):
                     w.wait()
-            for ptr, t in post:
-                self._dev(ptr, count).add_(t)
             torch.cuda.synchronize()
             return
-        # gloo: stage through the host; pack all segments of one direction into one message
-        def pack(base):
-            return np.concatenate([self._d2h(base + k * stride * B, count) for k in range(nseg)])
-        reqs, rl, rh = [], None, None
-        if has_lo:
-            sl = torch.from_numpy(pack(send_lo)); rl = torch.empty(nseg * count, dtype=torch.float64)
-            reqs += [dist.isend(sl, lo, self.stage_group), dist.irecv(rl, lo, self.stage_group)]
-        if has_hi:
-            sh = torch.from_numpy(pack(send_hi)); rh = torch.empty(nseg * count, dtype=torch.float64)
-            reqs += [dist.isend(sh, hi, self.stage_group), dist.irecv(rh, hi, self.stage_group)]
+        # gloo: stage through the host; all messages to one peer travel as ONE message (in list order)
+        peers = sorted(set(m[0] for m in msgs))
+        reqs, bufs = [], {}
+        for p in peers:
+            mine = [m for m in msgs if m[0] == p]
+            out = [self._d2h(sp, ns) for _, sp, ns, _, _ in mine if ns]
+            n_in = sum(nr for _, _, _, _, nr in mine)
+            if out:
+                reqs.append(dist.isend(torch.from_numpy(np.concatenate(out)), p, self.stage_group))
+            if n_in:
+                bufs[p] = torch.empty(n_in, dtype=torch.float64)
+                reqs.append(dist.irecv(bufs[p], p, self.stage_group))
         for r in reqs:
             r.wait()
-        for base, buf in ((recv_lo, rl), (recv_hi, rh)):
-            if buf is None:
+        for p in peers:
+            if p not in bufs:
                 continue
-            a = buf.numpy()
-            for k in range(nseg):
-                seg = a[k * count:(k + 1) * count]
-                if add:
-                    seg = seg + self._d2h(base + k * stride * B, count)
-                self._h2d(base + k * stride * B, seg)
+            a = bufs[p].numpy(); o = 0
+            for _, _, _, rp, nr in [m for m in msgs if m[0] == p]:
+                if nr:
+                    self._h2d(rp, a[o:o + nr]); o += nr
 
     # ---- host all-reduce ------------------------------------------------------------------------------
     def _allreduce_host(self, user, buf, n, op):
@@ -184,85 +191,19 @@ class Comm:
         rop = {0: self.dist.ReduceOp.SUM, 1: self.dist.ReduceOp.MIN, 2: self.dist.ReduceOp.MAX}[int(op)]
         self.dist.all_reduce(t, op=rop, group=self.host_group)
 
-    # ---- all-gather (in place: rank r owns recv[r*count : (r+1)*count] of every segment) ----------------
-    def _allgather(self, user, recv, count, nseg, stride):
-        return self._guard(self._allgather_impl, recv, count, nseg, stride)
+    # ---- all-gather: every rank contributes `count` doubles, recv holds size*count ---------------------------------
+    def _allgather(self, user, send, recv, count):
+        return self._guard(self._allgather_impl, send, recv, count)
 
-    def _allgather_impl(self, recv, count, nseg, stride):
+    def _allgather_impl(self, send, recv, count):
         dist, torch = self.dist, self.torch
         self._agree_device_mode()
-        B = 8
-        for k in range(nseg):
-            base = recv + k * stride * B
-            if self.device_mode:
-                full = self._dev(base, count * self.size)
-                mine = full[self.rank * count:(self.rank + 1) * count].clone()
-                dist.all_gather_into_tensor(full, mine, group=self.group)
-            else:
-                mine = torch.from_numpy(self._d2h(base + self.rank * count * B, count))
-                out = [torch.empty(count, dtype=torch.float64) for _ in range(self.size)]
-                dist.all_gather(out, mine, group=self.stage_group)
-                self._h2d(base, np.concatenate([o.numpy() for o in out]))
+        count = int(count)
         if self.device_mode:
-            torch.cuda.synchronize()
-
-    # ---- variable-size neighbour exchange of tracer columns ----------------------------------------------
-    def _exchange_var(self, user, send_lo, n_lo, send_hi, n_hi, recv, cap, ncol, got):
-        return self._guard(self._exchange_var_impl, send_lo, n_lo, send_hi, n_hi, recv, cap, ncol, got)
-
-    def _exchange_var_impl(self, send_lo, n_lo, send_hi, n_hi, recv, cap, ncol, got):
-        dist, torch = self.dist, self.torch
-        self._agree_device_mode()
-        lo, hi = self.rank - 1, self.rank + 1
-        has_lo, has_hi = lo >= 0, hi < self.size
-        # 1. counts (host, gloo)
-        cnt_from_lo = torch.zeros(1, dtype=torch.int64); cnt_from_hi = torch.zeros(1, dtype=torch.int64)
-        reqs = []
-        if has_lo:
-            reqs += [dist.isend(torch.tensor([int(n_lo)], dtype=torch.int64), lo, self.host_group),
-                     dist.irecv(cnt_from_lo, lo, self.host_group)]
-        if has_hi:
-            reqs += [dist.isend(torch.tensor([int(n_hi)], dtype=torch.int64), hi, self.host_group),
-                     dist.irecv(cnt_from_hi, hi, self.host_group)]
-        for r in reqs:
-            r.wait()
-        m_lo, m_hi = int(cnt_from_lo.item()), int(cnt_from_hi.item())
-        if m_lo + m_hi > cap:
-            raise Exception("tracer migration exceeds the receive capacity")
-        got[0] = m_lo + m_hi
-        B = 8
-        # 2. payload, column by column (all columns of one direction in one message under gloo)
-        if self.device_mode:
-            ops = []
-            for k in range(ncol):
-                if has_lo and n_lo:
-                    ops.append(dist.P2POp(dist.isend, self._dev(send_lo[k], n_lo), lo, self.group))
-                if has_hi and n_hi:
-                    ops.append(dist.P2POp(dist.isend, self._dev(send_hi[k], n_hi), hi, self.group))
-                if m_lo:
-                    ops.append(dist.P2POp(dist.irecv, self._dev(recv[k], m_lo), lo, self.group))
-                if m_hi:
-                    ops.append(dist.P2POp(dist.irecv, self._dev(recv[k] + m_lo * B, m_hi), hi, self.group))
-            if ops:
-                for w in dist.batch_isend_irecv(ops):
-                    w.wait()
+            dist.all_gather_into_tensor(self._dev(recv, count * self.size), self._dev(send, count), group=self.group)
             torch.cuda.synchronize()
             return
-        reqs, rl, rh = [], None, None
-        if has_lo and n_lo:
-            reqs.append(dist.isend(torch.from_numpy(np.concatenate([self._d2h(send_lo[k], n_lo) for k in range(ncol)])),
-                                   lo, self.stage_group))
-        if has_hi and n_hi:
-            reqs.append(dist.isend(torch.from_numpy(np.concatenate([self._d2h(send_hi[k], n_hi) for k in range(ncol)])),
-                                   hi, self.stage_group))
-        if m_lo:
-            rl = torch.empty(ncol * m_lo, dtype=torch.float64); reqs.append(dist.irecv(rl, lo, self.stage_group))
-        if m_hi:
-            rh = torch.empty(ncol * m_hi, dtype=torch.float64); reqs.append(dist.irecv(rh, hi, self.stage_group))
-        for r in reqs:
-            r.wait()
-        for k in range(ncol):
-            if m_lo:
-                self._h2d(recv[k], rl.numpy()[k * m_lo:(k + 1) * m_lo])
-            if m_hi:
-                self._h2d(recv[k] + m_lo * B, rh.numpy()[k * m_hi:(k + 1) * m_hi])
+        mine = torch.from_numpy(self._d2h(send, count))
+        out = [torch.empty(count, dtype=torch.float64) for _ in range(self.size)]
+        dist.all_gather(out, mine, group=self.stage_group)
+        self._h2d(recv, np.concatenate([o.numpy() for o in out]))

@@ -18,12 +18,18 @@ def test_comm_layer_gloo(nproc):
     assert r.returncode == 0 and "PASS comm cpu" in r.stdout, (r.stdout + r.stderr)[-3000:]
 
 
-def test_slab_partition():
-    from pylamp_amd.parallel import slab_rows
-    for nz, size in ((2049, 1), (2049, 2), (2049, 4), (2049, 8), (4097, 8), (129, 4)):
-        rows = [slab_rows(nz, r, size) for r in range(size)]
-        assert rows[0][0] == 0 and sum(n for _, n in rows) == nz
-        for (a, n), (b, _) in zip(rows[:-1], rows[1:]):
-            assert a + n == b and n % 2 == 0
+def test_block_partition():
+    from pylamp_amd.parallel import block_of, block_1d, choose_layout
+    for n, P in ((2049, 1), (2049, 2), (2049, 4), (2049, 8), (4097, 8), (129, 4)):
+        parts = [block_1d(n, P, p) for p in range(P)]
+        assert parts[0][0] == 0 and sum(c for _, c in parts) == n
+        for (a, c), (b, _) in zip(parts[:-1], parts[1:]):
+            assert a + c == b and c % 2 == 0
     with pytest.raises(Exception):
-        slab_rows(2050, 0, 4)
+        block_1d(2050, 4, 0)
+    assert choose_layout(1) == (1, 1) and choose_layout(2) == (1, 2) and choose_layout(4) == (2, 2) and choose_layout(8) == (2, 4)
+    owned = set()
+    for r in range(8):
+        i0, ni, j0, nj = block_of([4097, 4097], r, 2, 4)
+        owned |= {(i, j) for i in (i0, i0 + ni - 1) for j in (j0, j0 + nj - 1)}
+    assert (0, 0) in owned and (4096, 4096) in owned
