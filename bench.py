@@ -27,21 +27,24 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~
 
 def build_sim(n, tracdens, seed, device, rank, world, scaling):
     """strong (default, what BASELINE.json's metric names: the 2048^2-cell problem at 1/2/4/8 GPUs): the SAME n x n
-    grid for every N, split into N row slabs.  weak (--scaling weak): every GPU holds one (n-1) x (n-1)-cell slab of a
-    ((n-1) N + 1) x n grid over a domain N times as deep (square cells).  Every rank draws the tracers of its own
-    slab; N = 1 is BASELINE's config 3 either way."""
+    grid for every N, split into Pz x Px blocks (1x2, 2x2, 2x4).  weak (--scaling weak): every GPU holds one
+    (n-1) x (n-1)-cell block of a ((n-1) Pz + 1) x ((n-1) Px + 1) grid over a correspondingly larger domain (square
+    cells).  Every rank draws the tracers of its own block; N = 1 is BASELINE's config 3 either way."""
     from pylamp_amd import driver
+    from pylamp_amd.parallel import choose_layout
+    Pz, Px = choose_layout(world)
     if scaling == "weak":
-        nx = [(n - 1) * world + 1, n]; L = [660e3 * world, 660e3]
+        nx = [(n - 1) * Pz + 1, (n - 1) * Px + 1]; L = [660e3 * Pz, 660e3 * Px]
     else:
         nx = [n, n]; L = [660e3, 660e3]
     # census + injection inside the timed step, like the reference (pylamp2.py:39-40,588-633; its stock values are
     # 45 / 25): cells below 9 markers are refilled to 16
     sim = driver.Simulation(nx, L, options=driver.Options(tracdens=tracdens, tracdens_min=(tracdens * 9) // 16), device=device)
     rng = np.random.default_rng(seed + rank)
-    lo, hi = sim.slab()
+    zr, xr = sim.block()
     per_rank = nx[0] * nx[1] * tracdens // max(world, 1)
-    tr_x, tr_f = driver.mantle_tracers(nx, L, tracdens, rng, zrange=None if world == 1 else (lo, hi), id0=rank * per_rank)
+    tr_x, tr_f = driver.mantle_tracers(nx, L, tracdens, rng, zrange=None if world == 1 else zr, xrange=None if world == 1 else xr,
+                                       id0=rank * per_rank)
     sim.upload(tr_x, tr_f)
     del tr_x, tr_f
     return sim
@@ -217,7 +220,7 @@ def main():
 
     cells = (sim.nx[0] - 1) * (sim.nx[1] - 1)
     ms_per_step = 1e3 * elapsed / args.steps
-    # N > 1: ONE global problem of N row slabs (halo exchange + all-reduce over RCCL); value = global cells * steps / time
+    # N > 1: ONE global problem of Pz x Px blocks (halo exchange + all-reduce over RCCL); value = global cells * steps / time
     # (strong scaling: the global problem is fixed; weak: it grows with N).
     value = cells * args.steps / elapsed
     ntrac_global = sim.ntrac
@@ -237,8 +240,8 @@ def main():
             "config": {"workload": "2D %dx%d nodes (%dx%d cells), %d markers/node (%d tracers), T-dependent mantle "
                                    "model, heat + subgrid diffusion on, all free-slip, full time step" %
                                    (sim.nx[0], sim.nx[1], sim.nx[0] - 1, sim.nx[1] - 1, args.tracdens, ntrac_global),
-                       "parallelism": "1 GPU" if world == 1 else "%d row slabs (%d x 1 domain decomposition), halo exchange + all-reduce, transport: %s" %
-                                      (world, world, "direct RCCL on the solver stream" if (sim.ctx.comm is not None and sim.ctx.comm.native)
+                       "parallelism": "1 GPU" if world == 1 else "%d x %d blocks of the node grid (8-neighbour halo exchange with corners + all-reduce), transport: %s" %
+                                      (sim.ctx.local_block()[4], sim.ctx.local_block()[5], "direct RCCL on the solver stream" if (sim.ctx.comm is not None and sim.ctx.comm.native)
                                        else "torch.distributed (%s)" % (dist.get_backend() if dist is not None else "-")),
                        "stokes_rtol": sim.opt.stokes_rtol, "heat_rtol": sim.opt.heat_rtol},
             "time_steps_per_s": round(args.steps / elapsed, 4),

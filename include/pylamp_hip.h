@@ -95,6 +95,7 @@ int  pl_local_block(pl_ctx* ctx, int* first_row, int* n_rows, int* first_col, in
 typedef struct pl_local_group pl_local_group;
 int  pl_local_group_create(pl_local_group** out, int nranks);
 void pl_local_group_destroy(pl_local_group* g);
+void pl_local_group_abort(pl_local_group* g);    /* a rank's driver thread failed: every collective call of the group returns an error */
 int  pl_set_comm_local(pl_ctx* ctx, pl_local_group* g, int rank, int Pz, int Px);
 /* *native = 1 when the exchanges run as direct RCCL calls on the context stream (dlopen'ed librccl, self-tested at
  * pl_set_comm), 2 for the in-process group, 0 when they go through the callback table.

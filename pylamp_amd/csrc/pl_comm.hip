@@ -59,11 +59,15 @@ struct pl_local_group {
     std::vector<pl_ctx*> ctx;
     std::vector<const PlMsg*> msgs; std::vector<int> nmsg;
     std::vector<const void*> ptr;
-    void barrier() {
+    bool failed = false;         // a rank gave up (error on its side, or a barrier timed out): every later barrier fails at once
+    // false: the group has failed -- some rank did not arrive (it raised an error before the collective call)
+    bool barrier() {
         std::unique_lock<std::mutex> lk(m);
+        if (failed) return false;
         const long long g = gen;
-        if (++arrived == n) { arrived = 0; gen++; cv.notify_all(); }
-        else cv.wait(lk, [&] { return gen != g; });
+        if (++arrived == n) { arrived = 0; gen++; cv.notify_all(); return true; }
+        if (!cv.wait_for(lk, std::chrono::seconds(300), [&] { return gen != g || failed; })) { failed = true; cv.notify_all(); }
+        return !failed;
     }
 };
 
@@ -75,6 +79,13 @@ extern "C" int pl_local_group_create(pl_local_group** out, int nranks) {
     return 0;
 }
 extern "C" void pl_local_group_destroy(pl_local_group* g) { delete g; }
+// wake every rank waiting in a collective call with an error (a rank's driver thread has failed)
+extern "C" void pl_local_group_abort(pl_local_group* g) {
+    if (!g) return;
+    std::unique_lock<std::mutex> lk(g->m);
+    g->failed = true;
+    g->cv.notify_all();
+}
 
 int pl_local_attach(pl_ctx* ctx, pl_local_group* g, int rank) {
     if (rank < 0 || rank >= g->n || g->n != ctx->nranks) return pl_fail(ctx, "pl_set_comm_local: rank / group size mismatch");
@@ -89,7 +100,7 @@ static int local_sendrecv(pl_ctx* ctx, const PlMsg* msgs, int nmsg) {
     pl_local_group* G = local_of(ctx);
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));              // my send buffers are complete
     G->msgs[ctx->rank] = msgs; G->nmsg[ctx->rank] = nmsg;
-    G->barrier();
+    if (!G->barrier()) return pl_fail(ctx, "in-process transport: another rank failed or did not arrive");
     int rc = 0;
     for (int k = 0; k < nmsg && !rc; k++) {
         if (msgs[k].nrecv <= 0) continue;
@@ -104,14 +115,15 @@ static int local_sendrecv(pl_ctx* ctx, const PlMsg* msgs, int nmsg) {
             rc = pl_fail(ctx, "in-process transport: device copy failed");
     }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = pl_fail(ctx, "in-process transport: synchronisation failed");
-    G->barrier();                                                // everybody has read: send buffers may be reused
+    if (rc) pl_local_group_abort(G);
+    if (!G->barrier() && !rc) rc = pl_fail(ctx, "in-process transport: another rank failed or did not arrive");   // everybody has read: send buffers may be reused
     return rc;
 }
 
 static int local_allreduce_host(pl_ctx* ctx, double* buf, long long n, int op) {
     pl_local_group* G = local_of(ctx);
     G->ptr[ctx->rank] = buf;
-    G->barrier();
+    if (!G->barrier()) return pl_fail(ctx, "in-process transport: another rank failed or did not arrive");
     std::vector<double> tmp((size_t)n);
     for (long long k = 0; k < n; k++) {
         double a = ((const double*)G->ptr[0])[k];
@@ -121,7 +133,7 @@ static int local_allreduce_host(pl_ctx* ctx, double* buf, long long n, int op) {
         }
         tmp[(size_t)k] = a;
     }
-    G->barrier();
+    if (!G->barrier()) return pl_fail(ctx, "in-process transport: another rank failed or did not arrive");
     memcpy(buf, tmp.data(), (size_t)n * sizeof(double));
     return 0;
 }
@@ -130,13 +142,14 @@ static int local_allgather(pl_ctx* ctx, const double* send, double* recv, long l
     pl_local_group* G = local_of(ctx);
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     G->ptr[ctx->rank] = send;
-    G->barrier();
+    if (!G->barrier()) return pl_fail(ctx, "in-process transport: another rank failed or did not arrive");
     int rc = 0;
     for (int r = 0; r < G->n && !rc; r++)
         if (hipMemcpyAsync(recv + (long long)r * count, G->ptr[r], (size_t)count * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
             rc = pl_fail(ctx, "in-process transport: device copy failed");
     if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = pl_fail(ctx, "in-process transport: synchronisation failed");
-    G->barrier();
+    if (rc) pl_local_group_abort(G);
+    if (!G->barrier() && !rc) rc = pl_fail(ctx, "in-process transport: another rank failed or did not arrive");
     return rc;
 }
 
@@ -249,7 +262,8 @@ __global__ __launch_bounds__(256) void k_halo_unpack(HaloDesc d, double* __restr
         int k, q, i, j;
         halo_locate(d, t, k, q, i, j);
         double* p = origin + q * stride + (long long)i * pitch + j;
-        *p = add ? *p + buf[t] : buf[t];
+        // reverse halo: the owned strips facing N, W and NW overlap in the corner node -> three segments add to it
+        if (add) unsafeAtomicAdd(p, buf[t]); else *p = buf[t];
     }
 }
 

@@ -369,7 +369,8 @@ __global__ __launch_bounds__(256) void k_vv_first2(PlVvOp op, const double* __re
     const int c = (int)pl_idx(g, li, lj0);
     const int i = g.gi0 + li, j0 = g.gj0 + lj0;
     const int jw = g.gj0 + blockIdx.x * 128;
-    if (i <= 0 || i >= nz - 2 || jw < 1 || jw + 127 > nx - 3 || op.szz) {     // walls, slaves, stabilised rows (wave-uniform)
+    // walls, slaves, stabilised rows, or a wave that sticks out of the block (wave-uniform)
+    if (i <= 0 || i >= nz - 2 || jw < 1 || jw + 127 > nx - 3 || op.szz || blockIdx.x * 128 + 127 >= g.lnx) {
         if (!active) return;
         for (int q = 0; q < 2 && lj0 + q < g.lnx; q++) cheb_first_node(op, f, out, c2, i, j0 + q, c + q);
         return;
@@ -828,7 +829,7 @@ __global__ __launch_bounds__(256) void k_prec_stage1_v2(PlStokesOp op, PlVvOp vo
     const int i = g.gi0 + li;
     const int jw = g.gj0 + blockIdx.x * 128;
     const bool anchor_near = (op.anchor_i == i || op.anchor_i == i - 1) && op.anchor_j >= jw - 1 && op.anchor_j <= jw + 127;
-    if (i < 1 || i > nz - 3 || jw < 1 || jw + 127 > nx - 3 || anchor_near) {
+    if (i < 1 || i > nz - 3 || jw < 1 || jw + 127 > nx - 3 || anchor_near || blockIdx.x * 128 + 127 >= g.lnx) {     // (or the wave sticks out of the block)
         for (int q = 0; q < 2 && lj0 + q < g.lnx; q++) stage1_node(op, vop, rs, z, f, li, lj0 + q);
         return;
     }

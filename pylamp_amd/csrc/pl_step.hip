@@ -791,6 +791,11 @@ static int sort_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, doubl
             S->max_id_valid = false;
         }
     }
+    if (o.del_outside && ctx->nranks > 1) {        // collective: a deletion anywhere invalidates the cached maximum ID everywhere
+        double v[1] = {S->max_id_valid ? 0.0 : 1.0};
+        PL_TRY(pl_allreduce_host(ctx, v, 1, 2));
+        if (v[0] > 0.0) S->max_id_valid = false;
+    }
     return 0;
 }
 

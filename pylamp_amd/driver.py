@@ -272,8 +272,13 @@ class VirtualCluster:
 
     def all(self, fn, timeout=900):
         """fn(sim) on every rank at once (the calls are collective); returns the list of results in rank order."""
+        import concurrent.futures as cf
         futs = [self.pool.submit(fn, s) for s in self.sims]
-        return [f.result(timeout=timeout) for f in futs]
+        done, pending = cf.wait(futs, timeout=timeout, return_when=cf.FIRST_EXCEPTION)
+        if pending:                      # a rank raised (or the time is up): release the others from their collective calls
+            self.lib.pl_local_group_abort(self.group)
+            cf.wait(futs, timeout=60)
+        return [f.result(timeout=1) for f in futs]
 
     def step(self):
         return self.all(lambda s: s.step())

@@ -88,7 +88,8 @@ def test_blocks_injection_deletion_and_graded_grid(oracle):
     vc = driver.VirtualCluster(nx, L, 2, 2, tr_x, tr_f, opt)
     for it in range(2):
         reps = vc.step()
-        assert sum(r["ninjected"] for r in reps) == ref["reps"][it]["ninjected"] > 0
+        assert sum(r["ninjected"] for r in reps) == ref["reps"][it]["ninjected"]
+        assert it > 0 or ref["reps"][it]["ninjected"] > 1000
         assert sum(r["nremoved"] for r in reps) == ref["reps"][it]["nremoved"]
         assert sum(r["ntrac"] for r in reps) == ref["reps"][it]["ntrac"]
     assert ref["reps"][0]["nremoved"] == 93
