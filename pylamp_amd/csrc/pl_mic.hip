@@ -5,6 +5,7 @@
 #include "pl_internal.h"
 #include "pl_mic.h"
 #include <cmath>
+#include <algorithm>
 
 // ---------------------------------------------------------------------------------------
 // AoS <-> SoA
@@ -245,7 +246,8 @@ int pl_scatter_device(pl_ctx* ctx, PlScatterArgs& a, double* const* out, long lo
     }
     PL_HIP(ctx, hipGetLastError());
     if (slab && ctx->nranks > 1)
-        for (int k = 0; k < a.nf; k++) PL_TRY(pl_halo(ctx, *slab, out[k], 1, slab->plane, 2));
+        for (int k = 0; k < a.nf; k++)      // full depth: the solver's kernels also run on the block extended into the halo
+            PL_TRY(pl_halo(ctx, *slab, out[k], 1, slab->plane, std::min(PL_RING, std::min(slab->lnz, slab->lnx))));
     return 0;
 }
 

@@ -986,6 +986,7 @@ struct PlSolver {
     // transfer (identical numerics to one rank); 1 = once per level and direction; 0 = none (slab-local
     // smoothing with frozen zero halos; only the replicated coarse tail couples the slabs)
     int mg_halo = 2;
+    bool deep = true;            // PYLAMP_MG_DEEP=0: distributed levels exchange before every sweep instead of once per smoothing sequence
     int tail_nu_pre = -1, tail_nu_post = -1;        // smoothing sweeps on the replicated tail levels (-1: same as nu)
     double cheb_ratio = 6.0, lmax_safety = 1.1;     // smoothing window [lmax/ratio, lmax]; lmax = safety * power-iteration estimate
     // heat work vectors (1 plane each)
@@ -1006,6 +1007,7 @@ static PlSolver* solver_of(pl_ctx* ctx) {
         if (const char* e = getenv("PYLAMP_MG_REPL_NODES")) { long long v = atoll(e); if (v >= 25) S->repl_max_nodes = v; }
         if (const char* e = getenv("PYLAMP_MG_TAIL_NODES")) { long long v = atoll(e); if (v >= 25 && v <= PL_TAIL_MAX_NODES) S->tail_knob = v; }
         if (const char* e = getenv("PYLAMP_MG_HALO")) S->mg_halo = atoi(e);
+        if (const char* e = getenv("PYLAMP_MG_DEEP")) S->deep = atoi(e) != 0;
         if (const char* e = getenv("PYLAMP_MG_TAIL_NU")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a + b > 0) { S->tail_nu_pre = a; S->tail_nu_post = b; } }
         if (const char* e = getenv("PYLAMP_MG_RATIO")) { double v = atof(e); if (v > 1.5) { S->cheb_ratio = v; S->ratio_knob = true; } }
         if (const char* e = getenv("PYLAMP_MG_ANISO")) S->aniso_auto = atoi(e) != 0;
@@ -1234,9 +1236,11 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
         MgLevel* L = S->levels[l];
         if (l > 0) {
             MgLevel* F = S->levels[l - 1];
-            if (F->dist) {       // fine viscosity rings must be valid for the [1 2 1] stencil
-                PL_TRY(pl_halo(ctx, F->gh.d, F->etas, 1, F->gh.d.plane, 2));
-                PL_TRY(pl_halo(ctx, F->gh.d, F->etan, 1, F->gh.d.plane, 2));
+            if (F->dist && l > 1) {       // fine viscosity halos: the [1 2 1] stencil here, and the smoothing kernels that run on
+                                          // the block extended into the halo (level 0 arrives with its halo filled: scatter / upload)
+                const int dep = std::min(PL_RING, std::min(F->gh.d.lnz, F->gh.d.lnx));
+                PL_TRY(pl_halo(ctx, F->gh.d, F->etas, 1, F->gh.d.plane, dep));
+                PL_TRY(pl_halo(ctx, F->gh.d, F->etan, 1, F->gh.d.plane, dep));
             }
             if (R > 1 && (int)l == S->repl_start) {
                 // my block of the replicated arrays, then gather everybody's
@@ -1251,9 +1255,13 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
             }
         }
         level_flags(L, sop, l == 0);
-        if (R > 1 && (int)l == S->repl_start) {           // window view shares flags and pointers (shifted)
-            const PlGeom w = L->win;
-            (void)w;
+    }
+    {   // a distributed coarsest level never is the "fine" level of the loop above: its halo is filled here
+        MgLevel* L = S->levels.back();
+        if (L->dist && S->levels.size() > 1) {
+            const int dep = std::min(PL_RING, std::min(L->gh.d.lnz, L->gh.d.lnx));
+            PL_TRY(pl_halo(ctx, L->gh.d, L->etas, 1, L->gh.d.plane, dep));
+            PL_TRY(pl_halo(ctx, L->gh.d, L->etan, 1, L->gh.d.plane, dep));
         }
     }
     if (sop.surfstab && sop.ss != 0.0 && sop.gz != 0.0) {
@@ -1281,6 +1289,11 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
             MgLevel* L = S->levels[l];
             if (L->dist) PL_TRY(pl_halo(ctx, L->gh.d, L->rho, 1, L->gh.d.plane, 2));
             hipLaunchKernelGGL(k_stab_coeffs, grid2d(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, L->rho, coef, L->szz, L->szx);
+            if (L->dist) {
+                const int dep = std::min(PL_RING, std::min(L->gh.d.lnz, L->gh.d.lnx));
+                PL_TRY(pl_halo(ctx, L->gh.d, L->szz, 1, L->gh.d.plane, dep));
+                PL_TRY(pl_halo(ctx, L->gh.d, L->szx, 1, L->gh.d.plane, dep));
+            }
             L->op.szz = L->szz; L->op.szx = L->szx;
         }
     }
@@ -1321,9 +1334,36 @@ static const bool g_vv_vec_env = [] { const char* e = getenv("PYLAMP_VV_VEC"); r
 #define g_vv_vec (g_vv_vec_env && !(L->gh.d.gj0 & 1))
 
 // ---- smoothing and V-cycle ----------------------------------------------------------------
-// nsweep Chebyshev-Jacobi sweeps on level L; buf[0] is the current iterate on entry and on exit
+// Deep halos (distributed levels): a kernel launched on the block EXTENDED by e nodes into the halo computes there
+// exactly what the neighbour computes for its own nodes (same inputs, same arithmetic), so a sequence of nu sweeps
+// needs ONE exchange -- of its right-hand side, nu+... nodes deep -- instead of one per sweep: sweep k runs on the
+// block extended by e_k, e shrinking by one per sweep.  The view below is the level's operator on the extended
+// block; every pointer handed to a kernel is shifted back by `sh` so that local node (0,0) of the view lands on
+// global node (gi0-a, gj0-c).  The extension is clipped at the domain walls; towards -x it is rounded up to an even
+// number (aligned double2 accesses of the two-columns-per-lane kernels) -- the extra column is computed from data
+// one node beyond the valid depth, i.e. garbage that no needed node ever reads.
+struct ExtView { PlVvOp op; long long sh; };
+static ExtView ext_view(pl_ctx* ctx, const MgLevel* L, int e) {
+    ExtView v; v.op = L->op; v.sh = 0;
+    if (e <= 0 || !L->dist) return v;
+    const PlGeom& g = L->gh.d;
+    const int a = ctx->pz > 0 ? e : 0, b = ctx->pz < ctx->Pz - 1 ? e : 0;
+    const int c = ctx->px > 0 ? ((e + 1) & ~1) : 0, d = ctx->px < ctx->Px - 1 ? e : 0;
+    v.op.g.gi0 -= a; v.op.g.lnz += a + b; v.op.g.gj0 -= c; v.op.g.lnx += c + d;
+    v.sh = (long long)a * g.pitch + c;
+    v.op.etas -= v.sh; v.op.etan -= v.sh;
+    if (v.op.szz) { v.op.szz -= v.sh; v.op.szx -= v.sh; }
+    return v;
+}
+// deepest halo a level can exchange / compute on
+static int level_max_depth(const MgLevel* L) { return std::min(PL_RING - 1, std::min(L->gh.d.lnz, L->gh.d.lnx)); }
+
+// nsweep Chebyshev-Jacobi sweeps on level L; buf[0] is the current iterate on entry and on exit.
+// ext_first >= 0 (deep mode): sweep k runs on the block extended by ext_first - k nodes, no exchanges in here;
+// ext_first < 0: one halo exchange before every sweep that needs one (halo policy `halo`).
 static void smooth(pl_ctx* ctx, MgLevel* L, double* buf[3], const double* f, int nsweep, double ratio,
-                   double* final_out = nullptr, bool zero_guess = false, int halo = 2, bool first_halo_valid = false) {
+                   double* final_out = nullptr, bool zero_guess = false, int halo = 2, bool first_halo_valid = false,
+                   int ext_first = -1) {
     const double lmax = L->lmax, lmin = lmax / ratio;
     const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
     double rho_old = 1.0 / sigma;
@@ -1331,23 +1371,25 @@ static void smooth(pl_ctx* ctx, MgLevel* L, double* buf[3], const double* f, int
         double c1, c2;
         if (k == 0) { c1 = 0.0; c2 = 1.0 / theta; }
         else { const double rho = 1.0 / (2.0 * sigma - rho_old); c1 = rho * rho_old; c2 = 2.0 * rho / delta; rho_old = rho; }
-        if (L->dist && !(k == 0 && (zero_guess || first_halo_valid)) && (halo == 2 || (halo == 1 && k == 0)))
+        if (ext_first < 0 && L->dist && !(k == 0 && (zero_guess || first_halo_valid)) && (halo == 2 || (halo == 1 && k == 0)))
             (void)pl_halo(ctx, L->gh.d, buf[0], 2, L->gh.d.plane);
+        const ExtView V = ext_view(ctx, L, ext_first < 0 ? 0 : std::max(ext_first - k, 0));
+        const long long sh = V.sh;
         double* dst = (final_out && k == nsweep - 1) ? final_out : buf[2];
         if (k == 0 && zero_guess) {        // buf[0] is NOT read (and need not be zeroed)
-            if (g_vv_vec) hipLaunchKernelGGL(k_vv_first2, pl_grid_rows2(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, f, dst, c2);
-            else hipLaunchKernelGGL(k_vv_cheb_first, pl_grid_rows(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, f, dst, c2,
-                                    pl_row_iters(L->gh.d));
+            if (g_vv_vec) hipLaunchKernelGGL(k_vv_first2, pl_grid_rows2(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, f - sh, dst - sh, c2);
+            else hipLaunchKernelGGL(k_vv_cheb_first, pl_grid_rows(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, f - sh, dst - sh, c2,
+                                    pl_row_iters(V.op.g));
         }
         else
         {
-            const double* prev = (k == 1 && zero_guess) ? (const double*)nullptr : buf[1];
+            const double* prev = (k == 1 && zero_guess) ? (const double*)nullptr : buf[1] - sh;
             if (g_vv_vec)
-                hipLaunchKernelGGL(k_vv_sweep2<0>, pl_grid_rows2(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, buf[0], prev, f, dst,
-                                   c1, c2);
+                hipLaunchKernelGGL(k_vv_sweep2<0>, pl_grid_rows2(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, (const double*)(buf[0] - sh), prev,
+                                   f - sh, dst - sh, c1, c2);
             else
-                hipLaunchKernelGGL(k_vv_cheb, pl_grid_rows(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, buf[0], prev, f, dst, c1,
-                                   c2, pl_row_iters(L->gh.d));
+                hipLaunchKernelGGL(k_vv_cheb, pl_grid_rows(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, (const double*)(buf[0] - sh), prev, f - sh,
+                                   dst - sh, c1, c2, pl_row_iters(V.op.g));
         }
         if (dst != buf[2]) { buf[1] = buf[0]; buf[0] = dst; }
         else { double* nxt = buf[2]; buf[2] = buf[1]; buf[1] = buf[0]; buf[0] = nxt; }    // (cur, prev, free)
@@ -1365,9 +1407,29 @@ static int coarsest_sweeps(const PlSolver* S, const PlGeom& g) {
     return n;
 }
 
+// smoothing counts of level l
+static void level_nu(const PlSolver* S, size_t l, int& npre, int& npost) {
+    npre = (l == 0 && S->nu0_pre > 0) ? S->nu0_pre : S->nu_pre;
+    npost = (l == 0 && S->nu0_post > 0) ? S->nu0_post : S->nu_post;
+}
+// Deep-halo plan of a distributed level: the pre-smoothed iterate is needed e_last nodes into the halo (1 for the
+// residual whose restriction reaches one fine node beyond the block, + the post-smoothing sequence that starts from
+// it), hence the right-hand side e_last + npre - 1 nodes deep.  Returns false when the block is too small for that
+// (or PYLAMP_MG_DEEP=0): the level then exchanges before every sweep.
+static bool level_deep_plan(const PlSolver* S, const MgLevel* L, size_t l, int& e_last, int& f_depth) {
+    int npre, npost;
+    level_nu(S, l, npre, npost);
+    e_last = std::max(2, npost);
+    f_depth = e_last + std::max(npre, 1) - 1;
+    if (!L->dist || !S->deep || l + 1 == S->levels.size() || npre < 1) return false;
+    return f_depth + 1 <= level_max_depth(L);
+}
+
 // solves A_vv e = f(level l) approximately; result in *out (one of the level's v buffers)
 // final_out (level 0 only): the last post-smoothing sweep writes its result there (zero-copy into z)
-static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const double* f, double** out, double* final_out = nullptr) {
+// f_valid_depth: how deep into the halo the caller has already made f valid (level 0: stage 1 computes it there)
+static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const double* f, double** out, double* final_out = nullptr,
+                   int f_valid_depth = 0) {
     MgLevel* L = S->levels[l];
     const PlGeom& g = L->gh.d;
     if (S->use_tail && l > 0 && (long long)g.nz * g.nx <= S->tail_max_nodes &&
@@ -1396,16 +1458,32 @@ static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const double* f, double**
         return;
     }
     const int hp = S->mg_halo;
-    const int npre = (l == 0 && S->nu0_pre > 0) ? S->nu0_pre : S->nu_pre, npost = (l == 0 && S->nu0_post > 0) ? S->nu0_post : S->nu_post;
-    smooth(ctx, L, buf, f, npre, S->cheb_ratio, nullptr, true, hp);
-    if (L->dist && hp >= 1) (void)pl_halo(ctx, g, buf[0], 2, g.plane);
-    if (g_vv_vec)
-        hipLaunchKernelGGL(k_vv_sweep2<1>, pl_grid_rows2(g), dim3(64, 4), 0, ctx->stream, L->op, buf[0], (const double*)nullptr, f,
-                           L->r, 0.0, 0.0);
-    else
-        hipLaunchKernelGGL(k_vv_residual, pl_grid_rows(g), dim3(64, 4), 0, ctx->stream, L->op, buf[0], f, L->r, pl_row_iters(g));
-    if (L->dist && hp >= 1) (void)pl_halo(ctx, g, L->r, 2, g.plane, 2);
+    int npre, npost, e_last, f_depth;
+    level_nu(S, l, npre, npost);
+    const bool deep = level_deep_plan(S, L, l, e_last, f_depth);
     MgLevel* C = S->levels[l + 1];
+    if (deep) {
+        // ---- ONE exchange on the way down: the right-hand side, deep enough for the whole pre-smoothing sequence,
+        //      the residual and (later) the post-smoothing sequence
+        if (f_valid_depth < f_depth) (void)pl_halo(ctx, g, (double*)f, 2, g.plane, f_depth);
+        smooth(ctx, L, buf, f, npre, S->cheb_ratio, nullptr, true, hp, false, e_last + npre - 1);      // iterate valid e_last deep
+        const ExtView V = ext_view(ctx, L, e_last - 1);
+        if (g_vv_vec)
+            hipLaunchKernelGGL(k_vv_sweep2<1>, pl_grid_rows2(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, (const double*)(buf[0] - V.sh),
+                               (const double*)nullptr, f - V.sh, L->r - V.sh, 0.0, 0.0);
+        else
+            hipLaunchKernelGGL(k_vv_residual, pl_grid_rows(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, (const double*)(buf[0] - V.sh), f - V.sh,
+                               L->r - V.sh, pl_row_iters(V.op.g));
+    } else {
+        smooth(ctx, L, buf, f, npre, S->cheb_ratio, nullptr, true, hp);
+        if (L->dist && hp >= 1) (void)pl_halo(ctx, g, buf[0], 2, g.plane);
+        if (g_vv_vec)
+            hipLaunchKernelGGL(k_vv_sweep2<1>, pl_grid_rows2(g), dim3(64, 4), 0, ctx->stream, L->op, buf[0], (const double*)nullptr, f,
+                               L->r, 0.0, 0.0);
+        else
+            hipLaunchKernelGGL(k_vv_residual, pl_grid_rows(g), dim3(64, 4), 0, ctx->stream, L->op, buf[0], f, L->r, pl_row_iters(g));
+        if (L->dist && hp >= 1) (void)pl_halo(ctx, g, L->r, 2, g.plane, 2);
+    }
     if (L->dist && !C->dist) {
         // restrict my block of the replicated coarse rhs, then gather everybody's
         PlVvOp wop = C->op; wop.g = C->win;
@@ -1417,35 +1495,51 @@ static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const double* f, double**
     }
     double* ec = nullptr;
     vcycle(ctx, S, l + 1, C->f, &ec);
-    if (C->dist && hp >= 1) (void)pl_halo(ctx, C->gh.d, ec, 2, C->gh.d.plane, 2);
-    // On a distributed level the correction is also prolonged into the two halo rows (their coarse neighbours are in
-    // the coarse halo / the replicated coarse array, and the halo of the pre-smoothed iterate is still valid from the
-    // residual): the first post-smoothing sweep then needs no exchange of its own.
-    const bool ext = L->dist && hp == 2;
-    const int lo = (ext && ctx->pz > 0) ? 1 : 0, hi = (ext && ctx->pz < ctx->Pz - 1) ? 1 : 0;
-    const int we = (ext && ctx->px > 0) ? 1 : 0, ea = (ext && ctx->px < ctx->Px - 1) ? 1 : 0;
-    PlVvOp ope = L->op;
-    ope.g.gi0 -= lo; ope.g.lnz += lo + hi; ope.g.gj0 -= we; ope.g.lnx += we + ea;
-    const long long esh = (long long)lo * g.pitch + we;
-    hipLaunchKernelGGL(k_vv_prolong_add, grid2d(ope.g), dim3(64, 4), 0, ctx->stream, ope, C->gh.d, ec, buf[0] - esh, buf[2] - esh);
+    // ---- way up.  The correction is prolonged into the halo as well -- `pe` nodes deep -- so that the post-smoothing
+    // sequence needs no exchange of its own; the coarse correction must then be known (pe+1)/2 + 1 coarse nodes deep
+    // (ONE exchange, none when the coarse level is replicated).
+    const int pe = deep ? npost : ((L->dist && hp == 2) ? 1 : 0);
+    if (C->dist && (deep || hp >= 1))
+        (void)pl_halo(ctx, C->gh.d, ec, 2, C->gh.d.plane, std::min(std::max((pe + 1) / 2 + 1, 2), std::min(PL_RING, std::min(C->gh.d.lnz, C->gh.d.lnx))));
+    {
+        ExtView V = ext_view(ctx, L, pe);
+        if (!deep && pe == 1) {            // legacy extension by exactly one node (no rounding: the prolongation kernel is scalar)
+            V.op = L->op;
+            const int lo = ctx->pz > 0 ? 1 : 0, hi = ctx->pz < ctx->Pz - 1 ? 1 : 0, we = ctx->px > 0 ? 1 : 0, ea = ctx->px < ctx->Px - 1 ? 1 : 0;
+            V.op.g.gi0 -= lo; V.op.g.lnz += lo + hi; V.op.g.gj0 -= we; V.op.g.lnx += we + ea;
+            V.sh = (long long)lo * g.pitch + we;
+        }
+        hipLaunchKernelGGL(k_vv_prolong_add, grid2d(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, C->gh.d, ec, buf[0] - V.sh, buf[2] - V.sh);
+    }
     std::swap(buf[0], buf[2]);
-    smooth(ctx, L, buf, f, npost, S->cheb_ratio, final_out, false, hp, ext);
+    if (deep) smooth(ctx, L, buf, f, npost, S->cheb_ratio, final_out, false, hp, true, npost - 1);
+    else smooth(ctx, L, buf, f, npost, S->cheb_ratio, final_out, false, hp, pe == 1);
     *out = buf[0];
 }
 
 // z = M^-1 rs   (rs: scaled residual, 3 planes)
 static int stokes_precond(pl_ctx* ctx, PlSolver* S, const double* rs, double* z) {
-    const PlStokesOp& op = ctx->sop;
+    PlStokesOp op = ctx->sop;
     MgLevel* L0 = S->levels[0];
-    const PlGeom& g = op.g;
-    if (L0->dist) PL_TRY(pl_halo(ctx, g, (double*)rs + 2 * g.plane, 1, g.plane));      // rs_p row above / column to the left
-    if (g_vv_vec_env && !(g.gj0 & 1) && (g.plane % 2) == 0)
-        hipLaunchKernelGGL(k_prec_stage1_v2, pl_grid_rows2(g), dim3(64, 4), 0, ctx->stream, op, L0->op, rs, z, L0->f);
+    MgLevel* L = L0;                                  // (g_vv_vec looks at L)
+    const PlGeom& g = ctx->sop.g;
+    int e_last = 0, f_depth = 0;
+    const bool deep = level_deep_plan(S, L0, 0, e_last, f_depth);
+    ExtView V = ext_view(ctx, L0, deep ? f_depth : 0);
+    if (L0->dist) {
+        // stage 1 reads the pressure residual one node up / left; in deep mode it is evaluated f_depth nodes into the halo,
+        // which makes the velocity right-hand side of level 0 valid there without an exchange of its own
+        if (deep) PL_TRY(pl_halo(ctx, g, (double*)rs, 3, g.plane, f_depth + 1));
+        else PL_TRY(pl_halo(ctx, g, (double*)rs + 2 * g.plane, 1, g.plane));
+    }
+    op.g = V.op.g; op.etas -= V.sh; op.etan -= V.sh; if (op.rho) op.rho -= V.sh;
+    if (g_vv_vec && (g.plane % 2) == 0)
+        hipLaunchKernelGGL(k_prec_stage1_v2, pl_grid_rows2(op.g), dim3(64, 4), 0, ctx->stream, op, V.op, rs - V.sh, z - V.sh, L0->f - V.sh);
     else
-        hipLaunchKernelGGL(k_prec_stage1, pl_grid_rows(g), dim3(64, 4), 0, ctx->stream, op, L0->op, rs, z, L0->f, pl_row_iters(g));
+        hipLaunchKernelGGL(k_prec_stage1, pl_grid_rows(op.g), dim3(64, 4), 0, ctx->stream, op, V.op, rs - V.sh, z - V.sh, L0->f - V.sh, pl_row_iters(op.g));
     double* e = nullptr;
     const bool direct = S->levels.size() > 1 && S->nu_post > 0;     // last sweep writes into z
-    vcycle(ctx, S, 0, L0->f, &e, direct ? z : nullptr);
+    vcycle(ctx, S, 0, L0->f, &e, direct ? z : nullptr, deep ? f_depth : 0);
     if (e != z) hipLaunchKernelGGL(k_copy_vel, grid2d(g), dim3(64, 4), 0, ctx->stream, g, e, z);
     PL_HIP(ctx, hipGetLastError());
     S->nprec++;

@@ -1,0 +1,44 @@
+"""Rehearsal of the Pz x Px block decomposition on ONE GPU with virtual ranks (driver.VirtualCluster): communication
+calls per time step / per BiCGStab iteration / per preconditioner application, and agreement with the one-rank run.
+
+    python tools/rehearse_blocks.py [n=2049] [Pz=2] [Px=4] [markers/node=4] [steps=2]
+
+Timings mean nothing here (8 contexts share one GPU and the in-process transport synchronises on the host); the
+COUNTS are those of the multi-GPU run."""
+import sys, os, json
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import numpy as np
+from pylamp_amd import driver
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2049
+Pz = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+Px = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+dens = int(sys.argv[4]) if len(sys.argv) > 4 else 4
+steps = int(sys.argv[5]) if len(sys.argv) > 5 else 2
+nx = [n, n]; L = [660e3, 660e3]
+rng = np.random.default_rng(20260103)
+tr_x, tr_f = driver.mantle_tracers(nx, L, dens, rng)
+opt = driver.Options()
+ref = None
+if os.environ.get("REHEARSE_REF", "1") != "0":
+    sim = driver.Simulation(nx, L, tr_x, tr_f, opt)
+    reps1 = [sim.step() for _ in range(steps)]
+    ref = dict(velz=sim.field("velz"), temp=sim.field("temp"), its=[r["stokes"]["iterations"] for r in reps1])
+    sim.close()
+vc = driver.VirtualCluster(nx, L, Pz, Px, tr_x, tr_f, opt)
+out = []
+for it in range(steps):
+    vc.comm_stats(reset=True)
+    reps = vc.step()
+    st = vc.comm_stats()
+    r0 = reps[0]
+    its = r0["stokes"]["iterations"]; nprec = r0["stokes"]["precond_applies"]; napply = r0["stokes"]["operator_applies"]
+    ex = max(s[0] for s in st); ag = max(s[1] for s in st); ard = max(s[2] for s in st); arh = max(s[3] for s in st)
+    out.append(dict(step=it + 1, stokes_iterations=its, precond_applies=nprec, operator_applies=napply, heat_iterations=r0["heat"]["iterations"],
+                    halo_exchanges=ex, allgathers=ag, device_allreduces=ard, host_allreduces=arh,
+                    converged=[r["stokes"]["converged"] for r in reps]))
+    print(json.dumps(out[-1]), flush=True)
+if ref is not None:
+    e = np.linalg.norm(vc.field("velz") - ref["velz"]) / np.linalg.norm(ref["velz"])
+    print("one-rank iterations", ref["its"], "velz rel diff", e, "temp rel diff", np.linalg.norm(vc.field("temp") - ref["temp"]) / np.linalg.norm(ref["temp"]))
+vc.close()
