@@ -679,6 +679,68 @@ __global__ __launch_bounds__(256) void k_dot2(PlGeom g, int nplanes, const doubl
     }
 }
 
+// The five sums BiCGStab needs at its second reduction point, in ONE pass over t, s and r~:
+//   part[5b..] = (t.s, t.t, r~.s, r~.t, s.s)
+// from which omega = ts/tt and -- algebraically, r = s - omega t -- rho' = r~.r = r~.s - omega r~.t and
+// |r|^2 = s.s - 2 omega t.s + omega^2 t.t follow without another pass over r (and without a third all-reduce).
+__global__ __launch_bounds__(256) void k_dot5(PlGeom g, int nplanes, const double* __restrict__ t, const double* __restrict__ sv,
+                                              const double* __restrict__ rt, double* __restrict__ part) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0;
+    const long long rows = (long long)g.lnz * nplanes;
+    const int npair = g.lnx >> 1;
+    for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
+        const int q = (int)(r / g.lnz), li = (int)(r % g.lnz);
+        const long long base = pl_idx(g, li, 0) + q * g.plane;
+#pragma unroll 2
+        for (int k = threadIdx.x; k < npair; k += 256) {
+            const long long o = base + 2 * k;
+            const double2 T = *reinterpret_cast<const double2*>(t + o), Sv = *reinterpret_cast<const double2*>(sv + o),
+                          Rt = *reinterpret_cast<const double2*>(rt + o);
+            a0 += T.x * Sv.x + T.y * Sv.y; a1 += T.x * T.x + T.y * T.y; a2 += Rt.x * Sv.x + Rt.y * Sv.y;
+            a3 += Rt.x * T.x + Rt.y * T.y; a4 += Sv.x * Sv.x + Sv.y * Sv.y;
+        }
+        if ((g.lnx & 1) && threadIdx.x == 0) {
+            const long long o = base + g.lnx - 1;
+            a0 += t[o] * sv[o]; a1 += t[o] * t[o]; a2 += rt[o] * sv[o]; a3 += rt[o] * t[o]; a4 += sv[o] * sv[o];
+        }
+    }
+    __shared__ double sh[5][4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a0 += __shfl_down(a0, o, 64); a1 += __shfl_down(a1, o, 64); a2 += __shfl_down(a2, o, 64);
+        a3 += __shfl_down(a3, o, 64); a4 += __shfl_down(a4, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; sh[0][w] = a0; sh[1][w] = a1; sh[2][w] = a2; sh[3][w] = a3; sh[4][w] = a4; }
+    __syncthreads();
+    if (threadIdx.x < 5) part[5 * blockIdx.x + threadIdx.x] = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
+}
+// sums of the k_dot5 partials -> out[8..12]; derive = 1: also omega -> out[3], rho' -> out[5], |r|^2 -> out[6]
+__device__ inline void bicg_derive(double* __restrict__ out) {
+    const double ts = out[8], tt = out[9], rts = out[10], rtt = out[11], ss = out[12];
+    const double om = (tt > 0.0) ? ts / tt : 0.0;       // t = 0: s is already the residual
+    out[3] = om; out[5] = rts - om * rtt;
+    const double rr = ss - 2.0 * om * ts + om * om * tt;
+    out[6] = rr > 0.0 ? rr : 0.0;
+}
+__global__ __launch_bounds__(256) void k_sum_partials5(int nb, const double* __restrict__ part, double* __restrict__ out, int derive) {
+    __shared__ double sh[5][4];
+    double a[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int k = threadIdx.x; k < nb; k += 256)
+#pragma unroll
+        for (int q = 0; q < 5; q++) a[q] += part[5 * k + q];
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+        for (int o = 32; o > 0; o >>= 1) a[q] += __shfl_down(a[q], o, 64);
+        if ((threadIdx.x & 63) == 0) sh[q][threadIdx.x >> 6] = a[q];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int q = 0; q < 5; q++) out[8 + q] = sh[q][0] + sh[q][1] + sh[q][2] + sh[q][3];
+        if (derive) bicg_derive(out);
+    }
+}
+__global__ void k_bicg_derive(double* __restrict__ out) { bicg_derive(out); }
+
 // p = r + beta (p - omega v)
 __global__ void k_p_update(long long n, double* __restrict__ p, const double* __restrict__ r,
                            const double* __restrict__ v, double beta, double omega) {
@@ -971,7 +1033,7 @@ struct PlSolver {
     // BiCGStab work vectors (3 planes each)
     double *r = nullptr, *rt = nullptr, *p = nullptr, *v = nullptr, *s = nullptr, *t = nullptr, *y = nullptr,
            *z = nullptr, *b = nullptr, *x = nullptr, *xb = nullptr, *dx = nullptr, *r0 = nullptr;
-    double* scal = nullptr;     // device scalars [0..8) + dot partials [8..8+2*DOT_BLOCKS)
+    double* scal = nullptr;     // device scalars [0..16) + dot partials [16..16+5*DOT_BLOCKS)
     double* hpart = nullptr;    // pinned host copy of the dot partials
     int nu_pre = 2, nu_post = 2, coarse_sweeps = 12;
     int nu0_pre = -1, nu0_post = -1;                    // finest level only (PYLAMP_MG_NU0), -1: as the other levels
@@ -1092,19 +1154,19 @@ static int dots(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const double*
                 const double* d, double* out2) {
     long long rows = (long long)g.lnz * np;
     const int nb = (int)(rows < DOT_BLOCKS ? rows : DOT_BLOCKS);
-    if (a && c) hipLaunchKernelGGL((k_dot2<true, true>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 8);
-    else if (a) hipLaunchKernelGGL((k_dot2<true, false>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 8);
-    else hipLaunchKernelGGL((k_dot2<false, true>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 8);
+    if (a && c) hipLaunchKernelGGL((k_dot2<true, true>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 16);
+    else if (a) hipLaunchKernelGGL((k_dot2<true, false>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 16);
+    else hipLaunchKernelGGL((k_dot2<false, true>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 16);
     if (ctx->nranks > 1 && pl_geom_is_dist(g) && pl_comm_native_enabled(ctx)) {
         // slab + native RCCL: reduce on the device, all-reduce 2 doubles over xGMI, one 16-byte copy back
-        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, nb, S->scal + 8, S->scal);
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, nb, S->scal + 16, S->scal);
         PL_TRY(pl_comm_allreduce_dev(ctx, S->scal, 2));
         PL_HIP(ctx, hipMemcpyAsync(S->hpart, S->scal, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
         out2[0] = S->hpart[0]; out2[1] = S->hpart[1];
         return 0;
     }
-    PL_HIP(ctx, hipMemcpyAsync(S->hpart, S->scal + 8, (size_t)2 * nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PL_HIP(ctx, hipMemcpyAsync(S->hpart, S->scal + 16, (size_t)2 * nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     double s0 = 0.0, s1 = 0.0;
     for (int k = 0; k < nb; k++) { s0 += S->hpart[2 * k]; s1 += S->hpart[2 * k + 1]; }
@@ -1115,7 +1177,21 @@ static int dots(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const double*
 
 // the device-scalar path needs the global sums on the device: one rank, or the native (stream-ordered) all-reduce
 static bool dots_on_device(pl_ctx* ctx, const PlGeom& g) {
-    return ctx->nranks == 1 || !pl_geom_is_dist(g) || pl_comm_native_enabled(ctx);
+    (void)ctx; (void)g;
+    return true;       // pl_comm_allreduce_dev stages through the host on the non-native transports
+}
+// second reduction point of BiCGStab: omega -> scal[3], rho' -> scal[5], |r|^2 -> scal[6] (ONE all-reduce of 5 doubles)
+static int dots5_dev(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const double* t, const double* sv, const double* rt) {
+    long long rows = (long long)g.lnz * np;
+    const int nb = (int)(rows < DOT_BLOCKS ? rows : DOT_BLOCKS);
+    hipLaunchKernelGGL(k_dot5, dim3(nb), dim3(256), 0, ctx->stream, g, np, t, sv, rt, S->scal + 16);
+    const bool reduce = ctx->nranks > 1 && pl_geom_is_dist(g);
+    hipLaunchKernelGGL(k_sum_partials5, dim3(1), dim3(256), 0, ctx->stream, nb, S->scal + 16, S->scal, reduce ? 0 : 1);
+    if (reduce) {
+        PL_TRY(pl_comm_allreduce_dev(ctx, S->scal + 8, 5));
+        hipLaunchKernelGGL(k_bicg_derive, dim3(1), dim3(1), 0, ctx->stream, S->scal);
+    }
+    return 0;
 }
 // sums of the two dot products into S->scal[0..1], no host synchronisation
 // mode 1 / 2: alpha resp. omega are derived in the same pass (see k_sum_partials); with several ranks the sums
@@ -1124,11 +1200,11 @@ static int dots_dev(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const dou
                     const double* d, int mode, double rho_new) {
     long long rows = (long long)g.lnz * np;
     const int nb = (int)(rows < DOT_BLOCKS ? rows : DOT_BLOCKS);
-    if (a && c) hipLaunchKernelGGL((k_dot2<true, true>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 8);
-    else if (a) hipLaunchKernelGGL((k_dot2<true, false>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 8);
-    else hipLaunchKernelGGL((k_dot2<false, true>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 8);
+    if (a && c) hipLaunchKernelGGL((k_dot2<true, true>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 16);
+    else if (a) hipLaunchKernelGGL((k_dot2<true, false>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 16);
+    else hipLaunchKernelGGL((k_dot2<false, true>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 16);
     const bool reduce = ctx->nranks > 1 && pl_geom_is_dist(g);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, nb, S->scal + 8, S->scal, reduce ? 0 : mode, rho_new);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, nb, S->scal + 16, S->scal, reduce ? 0 : mode, rho_new);
     if (reduce) {
         PL_TRY(pl_comm_allreduce_dev(ctx, S->scal, 2));
         if (mode == 1) hipLaunchKernelGGL(k_scalar_alpha, dim3(1), dim3(1), 0, ctx->stream, S->scal, rho_new);
@@ -1355,9 +1431,6 @@ static ExtView ext_view(pl_ctx* ctx, const MgLevel* L, int e) {
     if (v.op.szz) { v.op.szz -= v.sh; v.op.szx -= v.sh; }
     return v;
 }
-// deepest halo a level can exchange / compute on
-static int level_max_depth(const MgLevel* L) { return std::min(PL_RING - 1, std::min(L->gh.d.lnz, L->gh.d.lnx)); }
-
 // nsweep Chebyshev-Jacobi sweeps on level L; buf[0] is the current iterate on entry and on exit.
 // ext_first >= 0 (deep mode): sweep k runs on the block extended by ext_first - k nodes, no exchanges in here;
 // ext_first < 0: one halo exchange before every sweep that needs one (halo policy `halo`).
@@ -1422,7 +1495,9 @@ static bool level_deep_plan(const PlSolver* S, const MgLevel* L, size_t l, int& 
     e_last = std::max(2, npost);
     f_depth = e_last + std::max(npre, 1) - 1;
     if (!L->dist || !S->deep || l + 1 == S->levels.size() || npre < 1) return false;
-    return f_depth + 1 <= level_max_depth(L);
+    // kernels on the block extended by f_depth read coefficients one node further: f_depth + 1 <= PL_RING; the exchanges
+    // (f_depth deep; f_depth + 1 for the residual vector of level 0) must fit into the block
+    return f_depth <= PL_RING - 1 && f_depth + 1 <= std::min(L->gh.d.lnz, L->gh.d.lnx);
 }
 
 // solves A_vv e = f(level l) approximately; result in *out (one of the level's v buffers)
@@ -1621,13 +1696,13 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
                 hipLaunchKernelGGL(k_s_update_dev, grid1d(n), dim3(256), 0, ctx->stream, n, w.s, w.r, w.v, S->scal);
                 if (M) { PL_TRY((*M)(w.s, w.z)); zv = w.z; }
                 PL_TRY(A(zv, w.t));
-                PL_TRY(dots_dev(ctx, S, g, np, w.t, w.s, w.t, w.t, 2, 0.0));
+                PL_TRY(dots5_dev(ctx, S, g, np, w.t, w.s, w.rt));            // omega, rho' and |r|^2 from ONE reduction
                 hipLaunchKernelGGL(k_xr_update_dev, grid1d(n), dim3(256), 0, ctx->stream, n, dx, yv, zv, w.r, w.s, w.t, S->scal);
-                PL_HIP(ctx, hipMemcpyAsync(S->hpart + 2 * DOT_BLOCKS, S->scal + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+                PL_HIP(ctx, hipMemcpyAsync(S->hpart + 5 * DOT_BLOCKS, S->scal + 2, 5 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+                PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 rho = rho_new;
-                PL_TRY(dots(ctx, S, g, np, w.rt, w.r, w.r, w.r, d2));       // synchronises: alpha, omega have arrived too
-                alpha = S->hpart[2 * DOT_BLOCKS]; omega = S->hpart[2 * DOT_BLOCKS + 1];
-                rho_new = d2[0]; rnorm = std::sqrt(d2[1]);
+                alpha = S->hpart[5 * DOT_BLOCKS]; omega = S->hpart[5 * DOT_BLOCKS + 1];
+                rho_new = S->hpart[5 * DOT_BLOCKS + 3]; rnorm = std::sqrt(S->hpart[5 * DOT_BLOCKS + 4]);
                 if (!std::isfinite(alpha)) { broke = true; break; }
             } else {
                 PL_TRY(dots(ctx, S, g, np, w.rt, w.v, nullptr, nullptr, d2));
@@ -1685,8 +1760,8 @@ static int stokes_alloc(pl_ctx* ctx, PlSolver* S) {
     for (double** q : {&S->r, &S->rt, &S->p, &S->v, &S->s, &S->t, &S->y, &S->z, &S->b, &S->x, &S->xb, &S->dx, &S->r0})
         PL_TRY(dmalloc0(ctx, q, vb));
     if (!S->scal) {
-        PL_TRY(dmalloc0(ctx, &S->scal, (8 + 2 * DOT_BLOCKS) * sizeof(double)));
-        PL_HIP(ctx, hipHostMalloc((void**)&S->hpart, (2 * DOT_BLOCKS + 8) * sizeof(double)));
+        PL_TRY(dmalloc0(ctx, &S->scal, (16 + 5 * DOT_BLOCKS) * sizeof(double)));
+        PL_HIP(ctx, hipHostMalloc((void**)&S->hpart, (5 * DOT_BLOCKS + 16) * sizeof(double)));
     }
     return 0;
 }
@@ -1868,8 +1943,8 @@ int pl_heat_solve_device(pl_ctx* ctx, const double* b_dev, double rtol, int maxi
     size_t pb = (size_t)g.plane * sizeof(double);
     for (int k = 0; k < 11; k++) if (!S->h[k]) PL_TRY(dmalloc0(ctx, &S->h[k], pb));
     if (!S->scal) {
-        PL_TRY(dmalloc0(ctx, &S->scal, (8 + 2 * DOT_BLOCKS) * sizeof(double)));
-        PL_HIP(ctx, hipHostMalloc((void**)&S->hpart, (2 * DOT_BLOCKS + 8) * sizeof(double)));
+        PL_TRY(dmalloc0(ctx, &S->scal, (16 + 5 * DOT_BLOCKS) * sizeof(double)));
+        PL_HIP(ctx, hipHostMalloc((void**)&S->hpart, (5 * DOT_BLOCKS + 16) * sizeof(double)));
     }
     PL_TRY(pl_timer_start(ctx));
     PlHeatOp hop = ctx->hop;

@@ -121,3 +121,31 @@ def test_blocks_injection_deletion_and_graded_grid(oracle):
         X, F, V = vc.tracers()
         assert relerr(X, st["tr_x"]) < 1e-7 and relerr(F[:, 3], st["tr_f"][:, 3]) < 1e-6
     vc.close()
+
+
+def test_blocks_communication_budget(monkeypatch):
+    """Three distributed multigrid levels on 2 x 4 blocks (replication threshold lowered so that a 257 x 513 grid has
+    them): with deep halos a preconditioner application costs at most 8 neighbour exchanges (one per smoothing sequence
+    of a level instead of one per sweep) and a BiCGStab iteration two all-reduces; the exchange-per-sweep mode
+    (PYLAMP_MG_DEEP=0) gives the same iterates at several times the exchanges."""
+    from pylamp_amd import driver
+    nx = [257, 513]; L = [660e3, 1320e3]
+    tr_x, tr_f = driver.mantle_tracers(nx, L, 12, np.random.default_rng(6), perturb=60.0)
+    res = {}
+    for deep in ("1", "0"):
+        monkeypatch.setenv("PYLAMP_MG_REPL_NODES", "3000")
+        monkeypatch.setenv("PYLAMP_MG_DEEP", deep)
+        vc = driver.VirtualCluster(nx, L, 2, 4, tr_x, tr_f, driver.Options(do_heatdiff=False, tdep_rho=True, tdep_eta=True))
+        vc.comm_stats(reset=True)
+        rep = vc.step()[0]
+        st = np.array(vc.comm_stats()).max(axis=0)
+        res[deep] = dict(velz=vc.field("velz"), its=rep["stokes"]["iterations"], nprec=rep["stokes"]["precond_applies"],
+                         napply=rep["stokes"]["operator_applies"], exchanges=int(st[0]), allreduces=int(st[2] + st[3]))
+        assert rep["stokes"]["converged"] == 1
+        vc.close()
+    d, l = res["1"], res["0"]
+    other = 80                                   # set-up (coefficient halos, power iterations), scatter, advection
+    assert d["exchanges"] <= 8 * d["nprec"] + d["napply"] + other, d
+    assert d["allreduces"] <= 2 * d["its"] + other, d
+    assert l["exchanges"] > 2.0 * d["exchanges"], (d, l)
+    assert relerr(d["velz"], l["velz"]) < 1e-7
