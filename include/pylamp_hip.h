@@ -252,6 +252,36 @@ int  pl_get_field(pl_ctx* ctx, const char* name, double* out);
 /* Velocity of the last advection, (n,2) like trac_vel (pylamp2.py:547-555). */
 int  pl_get_tracer_velocity(pl_ctx* ctx, int64_t n, double* out);
 
+/* ---- 3-D staggered Stokes + heat (BASELINE config 5) ----------------------------------------------------------------
+ * PARITY UNPINNED: the reference implements DIM = 2 only (pylamp_const.py:6; pylamp_stokes.py:30-35 prints "NOT
+ * IMPLEMENTED" for dim != 2).  It fixes the intent -- axis order z, x, y (pylamp_const.py:9-13), arrays (nz, nx, ny),
+ * IP = DIM, DOF order iz*nx*ny*4 + ix*ny*4 + iy*4 + ieq (pylamp_stokes.py:24) -- and these entry points extend the 2-D
+ * rows (pylamp_stokes.py:376-518, pylamp_diff.py:99-179) dimension by dimension: a y-invariant extrusion reproduces the
+ * 2-D operator and solution on every y-slice.  Host arrays are C-order (nz, nx, ny) doubles; Stokes vectors are
+ * (nz, nx, ny, 4) with components (vz, vx, vy, P).  All walls free-slip; heat walls FIXTEMP / FIXFLOW in the order
+ * [z0, x0, y0, zL, xL, yL].  The shear viscosity is given at the NODES and averaged onto the edges. */
+typedef struct pl3_ctx pl3_ctx;
+int  pl3_create(pl3_ctx** out, int device, int nz, int nx, int ny, const double* zc, const double* xc, const double* yc);
+void pl3_destroy(pl3_ctx* ctx);
+const char* pl3_last_error(const pl3_ctx* ctx);
+/* grav = G[3] (NULL: (9.81, 0, 0), pylamp_const.py:21); Kcont = 3 min(eta) / sum(avgd), Kbond = 9 min(eta) / sum(avgd)^2 */
+int  pl3_stokes_set_coeffs(pl3_ctx* ctx, const double* etas, const double* etan, const double* rho, const double grav[3]);
+/* slaved != 0 (default): the reference's wall rows extended to 3-D (outermost in-domain tangential velocities slaved to their
+ * inner neighbours, pylamp_stokes.py:170-175 ...: first-order accurate at the walls); 0: natural mirror rows (second order) */
+int  pl3_stokes_set_wall_rows(pl3_ctx* ctx, int slaved);
+int  pl3_stokes_get_scaling(pl3_ctx* ctx, double* kcont, double* kbond);
+int  pl3_stokes_apply(pl3_ctx* ctx, const double* x, double* y);
+int  pl3_stokes_rhs(pl3_ctx* ctx, double* rhs);
+int  pl3_stokes_solve(pl3_ctx* ctx, const double* rhs, double* x, int use_x0, double rtol, int maxit, pl_solve_stats* stats);
+int  pl3_stokes_apply_bench(pl3_ctx* ctx, int scaled, int reps, double* avg_ms);     /* 80 B/node algorithmic */
+int  pl3_stokes_mg_info(pl3_ctx* ctx, int* nlevels, double* lmax, int max_levels);
+int  pl3_heat_set_coeffs(pl3_ctx* ctx, const double* zmp, const double* xmp, const double* ymp, const double* T, const double* kz,
+                         const double* kx, const double* ky, const double* cp, const double* rho, const double* H, const int bc[6],
+                         const double bcvalue[6], double tstep);
+int  pl3_heat_apply(pl3_ctx* ctx, const double* x, double* y);
+int  pl3_heat_rhs(pl3_ctx* ctx, double* rhs);
+int  pl3_heat_solve(pl3_ctx* ctx, const double* rhs /* NULL: the operator's own */, double* x, double rtol, int maxit, pl_solve_stats* stats);
+
 /* sizeof / offsetof of the structs above as compiled into the library: out = { sizeof(pl_solve_stats),
  * sizeof(pl_step_config), sizeof(pl_step_report), offsetof(config.length), offsetof(config.inject_seed),
  * offsetof(config.tracs_fence_disabled), offsetof(report.ntrac), offsetof(report.nremoved) } -- lets a binding

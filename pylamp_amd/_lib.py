@@ -51,6 +51,21 @@ SIGNATURES = {
     "pl_last_error": (C.c_char_p, [C.c_void_p]),
     "pl_sync": (C.c_int, [C.c_void_p]),
     "pl_abi_layout": (C.c_int, [C.POINTER(C.c_size_t)]),
+    "pl3_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p]),
+    "pl3_destroy": (None, [C.c_void_p]),
+    "pl3_last_error": (C.c_char_p, [C.c_void_p]),
+    "pl3_stokes_set_coeffs": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p]),
+    "pl3_stokes_set_wall_rows": (C.c_int, [C.c_void_p, C.c_int]),
+    "pl3_stokes_get_scaling": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
+    "pl3_stokes_apply": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
+    "pl3_stokes_rhs": (C.c_int, [C.c_void_p, c_double_p]),
+    "pl3_stokes_solve": (C.c_int, [C.c_void_p, c_double_p, c_double_p, C.c_int, C.c_double, C.c_int, C.POINTER(SolveStats)]),
+    "pl3_stokes_apply_bench": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p]),
+    "pl3_stokes_mg_info": (C.c_int, [C.c_void_p, c_int_p, c_double_p, C.c_int]),
+    "pl3_heat_set_coeffs": (C.c_int, [C.c_void_p] + [c_double_p] * 10 + [c_int_p, c_double_p, C.c_double]),
+    "pl3_heat_apply": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
+    "pl3_heat_rhs": (C.c_int, [C.c_void_p, c_double_p]),
+    "pl3_heat_solve": (C.c_int, [C.c_void_p, c_double_p, c_double_p, C.c_double, C.c_int, C.POINTER(SolveStats)]),
     "pl_device_info": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, c_int_p, C.POINTER(C.c_size_t)]),
     "pl_set_comm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "pl_set_comm_2d": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -1,0 +1,1078 @@
+// 3-D staggered Stokes + heat (BASELINE config 5).  PARITY UNPINNED: the reference implements 2-D only
+// (pylamp_const.py:6 "DIM = 2  # 2 or 3, currently only 2 implemented"; pylamp_stokes.py:30-35 prints
+// "NOT IMPLEMENTED" for dim != 2).  What it does fix is the intent: axis order z, x, y (pylamp_const.py:9-13), arrays
+// (nz, nx, ny), pressure as equation IP = DIM = 3, DOF order iz*nx*ny*4 + ix*ny*4 + iy*4 + ieq (pylamp_stokes.py:24).
+// This file extends the 2-D rows of pylamp_stokes.py:376-518 and pylamp_diff.py:157-179 dimension by dimension
+//  so that a y-invariant extrusion of a 2-D problem reproduces the 2-D operator and solution on every
+// y-slice (tests/test_hip_3d.py), and is otherwise validated by manufactured solutions and true residuals.
+//
+// Staggering: vz at (z_i, x_j+1/2, y_k+1/2), vx at (z_i+1/2, x_j, y_k+1/2), vy at (z_i+1/2, x_j+1/2, y_k), P and the
+// normal viscosity eta_n at cell centres, the shear viscosity eta_s ONCE at the nodes (z_i, x_j, y_k) and averaged on
+// the fly onto the edge a term needs (the 80 B/node layout of SURVEY 8d: x 32 + y 32 + eta_n 8 + eta_s 8).
+// One velocity component's row is the same expression under a cyclic permutation of the axes: the kernels are
+// templated on the component.  Solver: the 2-D design (pl_solver.hip) in 3-D -- row-scaled BiCGStab, block-triangular
+// preconditioner [[A_vv, A_vp],[0, S^]] with one geometric-multigrid V-cycle (Chebyshev-Jacobi smoothing, rediscretised
+// coarse operators with natural wall rows, arithmetic viscosity coarsening) for A_vv.  One GPU per problem.
+#include "pl_internal.h"
+#include <algorithm>
+#include <cmath>
+#include <functional>
+
+#define P3_PAD 16                    // left padding of a y-line: node k = 0 is 128-B aligned
+#define TB(tab, k) (tab)[(k) + PL_TOFF]
+
+struct G3 {
+    int n[3];                        // nz, nx, ny
+    long long s[3];                  // element strides of z, x, y
+    long long vol;                   // elements per scalar array (incl. one ring of nodes in z and x, padding in y)
+    const double* rd[3];             // 1/(c[i+1]-c[i])      per axis, zero padded, index + PL_TOFF
+    const double* rD[3];             // 1/(c[i+1]-c[i-1])
+};
+__host__ __device__ inline long long i3(const G3& g, int i, int j, int k) {
+    return (long long)(i + 1) * g.s[0] + (long long)(j + 1) * g.s[1] + (k + P3_PAD);
+}
+
+struct Op3 {
+    G3 g;
+    const double* es; const double* en; const double* rho;
+    double Kc, Kb, iKc;
+    int slave;                       // 1: the reference's slaved outermost in-domain tangential rows (finest level); 0: natural rows
+    double grav[3];
+    int anchor[3];
+};
+
+enum { C3_ZERO = 0, C3_INT = 1, C3_SLAVE = 2 };
+
+// class of the row of velocity component D at node idx; slaves get the offset to their (interior) master
+template <int D> __device__ inline int cls3(const Op3& op, const int* idx, long long& moff) {
+    constexpr int E = (D + 1) % 3, F = (D + 2) % 3;
+    const int* n = op.g.n;
+    moff = 0;
+    if (idx[D] <= 0 || idx[D] >= n[D] - 1 || idx[E] >= n[E] - 1 || idx[F] >= n[F] - 1) return C3_ZERO;
+    if (op.slave) {
+        if (idx[E] == 0) moff += op.g.s[E]; else if (idx[E] == n[E] - 2) moff -= op.g.s[E];
+        if (idx[F] == 0) moff += op.g.s[F]; else if (idx[F] == n[F] - 2) moff -= op.g.s[F];
+        if (moff != 0) return C3_SLAVE;
+    }
+    return C3_INT;
+}
+
+// (A_vv v)_D without the pressure term and the sum `dg` of the four..six own-component coefficients at element c.
+// Zero-padded tables make the mirror terms of natural wall rows vanish (rD[0] = rD[n-1] = 0).
+template <int D> __device__ inline void row3(const Op3& op, const double* const* __restrict__ v, long long c, const int* idx,
+                                              double& Av, double& dg) {
+    constexpr int E = (D + 1) % 3, F = (D + 2) % 3;
+    const G3& g = op.g;
+    const long long sd = g.s[D], se = g.s[E], sf = g.s[F];
+    const double* __restrict__ u = v[D];
+    const double* __restrict__ es = op.es;
+    const double rd_d = TB(g.rd[D], idx[D]), rd_dm = TB(g.rd[D], idx[D] - 1), rD_d = TB(g.rD[D], idx[D]);
+    const double u0 = u[c];
+    const double cN = 4.0 * op.en[c] * rd_d * rD_d, cS = 4.0 * op.en[c - sd] * rd_dm * rD_d;
+    double a = cN * (u[c + sd] - u0) - cS * (u0 - u[c - sd]);
+    double d = cN + cS;
+    {   // tangential axis E: the edge viscosities are node values averaged along F
+        const double rd_e = TB(g.rd[E], idx[E]), rD_e = TB(g.rD[E], idx[E]), rD_ep = TB(g.rD[E], idx[E] + 1);
+        const double ep = 0.5 * (es[c + se] + es[c + se + sf]), em = 0.5 * (es[c] + es[c + sf]);
+        const double cE = 2.0 * ep * rD_ep * rd_e, cW = 2.0 * em * rD_e * rd_e;
+        const double* __restrict__ w = v[E];
+        a += cE * (u[c + se] - u0) - cW * (u0 - u[c - se]) + (2.0 * ep * rD_d * rd_e) * (w[c + se] - w[c + se - sd]) -
+             (2.0 * em * rD_d * rd_e) * (w[c] - w[c - sd]);
+        d += cE + cW;
+    }
+    {   // tangential axis F: averaged along E
+        const double rd_f = TB(g.rd[F], idx[F]), rD_f = TB(g.rD[F], idx[F]), rD_fp = TB(g.rD[F], idx[F] + 1);
+        const double ep = 0.5 * (es[c + sf] + es[c + sf + se]), em = 0.5 * (es[c] + es[c + se]);
+        const double cE = 2.0 * ep * rD_fp * rd_f, cW = 2.0 * em * rD_f * rd_f;
+        const double* __restrict__ w = v[F];
+        a += cE * (u[c + sf] - u0) - cW * (u0 - u[c - sf]) + (2.0 * ep * rD_d * rd_f) * (w[c + sf] - w[c + sf - sd]) -
+             (2.0 * em * rD_d * rd_f) * (w[c] - w[c - sd]);
+        d += cE + cW;
+    }
+    Av = a; dg = d;
+}
+// diagonal sum only
+template <int D> __device__ inline double diag3(const Op3& op, long long c, const int* idx) {
+    constexpr int E = (D + 1) % 3, F = (D + 2) % 3;
+    const G3& g = op.g;
+    const long long sd = g.s[D], se = g.s[E], sf = g.s[F];
+    const double* __restrict__ es = op.es;
+    const double rD_d = TB(g.rD[D], idx[D]);
+    double d = 4.0 * op.en[c] * TB(g.rd[D], idx[D]) * rD_d + 4.0 * op.en[c - sd] * TB(g.rd[D], idx[D] - 1) * rD_d;
+    const double rd_e = TB(g.rd[E], idx[E]), rd_f = TB(g.rd[F], idx[F]);
+    d += (es[c + se] + es[c + se + sf]) * TB(g.rD[E], idx[E] + 1) * rd_e + (es[c] + es[c + sf]) * TB(g.rD[E], idx[E]) * rd_e;
+    d += (es[c + sf] + es[c + sf + se]) * TB(g.rD[F], idx[F] + 1) * rd_f + (es[c] + es[c + se]) * TB(g.rD[F], idx[F]) * rd_f;
+    return d;
+}
+
+#define K3_PROLOGUE(g)                                                                          \
+    const int k = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, i = blockIdx.z; \
+    if (k >= (g).n[2] || j >= (g).n[1]) return;                                                 \
+    const long long c = i3((g), i, j, k);                                                       \
+    const int idx[3] = {i, j, k};                                                               \
+    (void)idx;
+static dim3 grid3(const G3& g) { return dim3((g.n[2] + 63) / 64, (g.n[1] + 3) / 4, g.n[0]); }
+
+// ---- full Stokes operator --------------------------------------------------------------------------------------
+struct V4 { const double* p[4]; };
+struct W4 { double* p[4]; };
+struct V3 { const double* p[3]; };
+struct W3 { double* p[3]; };
+
+// pressure row class: 0 ghost/anchor (Kc P), 1 continuity, 2 symmetry with the neighbour at offset moff (Kb (P_nb - P))
+__device__ inline int cls3_p(const Op3& op, const int* idx, long long& moff) {
+    const int* n = op.g.n;
+    moff = 0;
+    if (idx[0] >= n[0] - 1 || idx[1] >= n[1] - 1 || idx[2] >= n[2] - 1) return 0;
+    if (idx[0] == op.anchor[0] && idx[1] == op.anchor[1] && idx[2] == op.anchor[2]) return 0;
+    // with natural wall rows every pressure cell appears in a momentum row: no symmetry rows
+    if (!op.slave) return 1;
+    const bool bz = idx[0] == 0 || idx[0] == n[0] - 2, bx = idx[1] == 0 || idx[1] == n[1] - 2, by = idx[2] == 0 || idx[2] == n[2] - 2;
+    if (bz && bx) { moff = idx[1] == 0 ? op.g.s[1] : -op.g.s[1]; return 2; }            // the 2-D corner rule (pylamp_stokes.py:358-369)
+    if (by && (bz || bx)) { moff = idx[2] == 0 ? op.g.s[2] : -op.g.s[2]; return 2; }     // remaining cube edges: inward along y
+    return 1;
+}
+
+template <int D> __device__ inline double apply_vel3(const Op3& op, const double* const* v, const double* __restrict__ P, long long c,
+                                                     const int* idx, bool scaled) {
+    long long moff;
+    const int cl = cls3<D>(op, idx, moff);
+    const double u0 = v[D][c];
+    if (cl == C3_ZERO) return scaled ? u0 : op.Kc * u0;
+    if (cl == C3_SLAVE) {
+        // the matrix row couples to the neighbour along the FIRST boundary axis (E before F), pylamp_stokes.py:170-175
+        constexpr int E = (D + 1) % 3, F = (D + 2) % 3;
+        const int* n = op.g.n;
+        long long nb;
+        if (idx[E] == 0) nb = op.g.s[E]; else if (idx[E] == n[E] - 2) nb = -op.g.s[E];
+        else nb = (idx[F] == 0) ? op.g.s[F] : -op.g.s[F];
+        const double y = u0 - v[D][c + nb];
+        return scaled ? y : op.Kc * y;
+    }
+    double Av, dg;
+    row3<D>(op, v, c, idx, Av, dg);
+    Av -= 2.0 * op.Kc * TB(op.g.rD[D], idx[D]) * (P[c] - P[c - op.g.s[D]]);
+    return scaled ? Av / dg : Av;
+}
+
+template <bool SCALED> __global__ __launch_bounds__(256) void k3_apply(Op3 op, V4 x, W4 y) {
+    K3_PROLOGUE(op.g)
+    const double* v[3] = {x.p[0], x.p[1], x.p[2]};
+    const double* __restrict__ P = x.p[3];
+    y.p[0][c] = apply_vel3<0>(op, v, P, c, idx, SCALED);
+    y.p[1][c] = apply_vel3<1>(op, v, P, c, idx, SCALED);
+    y.p[2][c] = apply_vel3<2>(op, v, P, c, idx, SCALED);
+    long long moff;
+    const int cl = cls3_p(op, idx, moff);
+    double yp;
+    if (cl == 0) yp = SCALED ? P[c] : op.Kc * P[c];
+    else if (cl == 2) yp = SCALED ? (P[c + moff] - P[c]) : op.Kb * (P[c + moff] - P[c]);
+    else {
+        const G3& g = op.g;
+        const double rz = TB(g.rd[0], i), rx = TB(g.rd[1], j), ry = TB(g.rd[2], k);
+        const double div = (v[0][c + g.s[0]] - v[0][c]) * rz + (v[1][c + g.s[1]] - v[1][c]) * rx + (v[2][c + g.s[2]] - v[2][c]) * ry;
+        yp = SCALED ? div / (rz + rx + ry) : op.Kc * div;
+    }
+    y.p[3][c] = yp;
+}
+
+// rhs (pylamp_stokes.py:429,490 extended: density averaged onto the face), optionally row-scaled like k3_apply<true>
+template <int D> __device__ inline double rhs_vel3(const Op3& op, long long c, const int* idx, bool scaled) {
+    constexpr int E = (D + 1) % 3, F = (D + 2) % 3;
+    long long moff;
+    if (cls3<D>(op, idx, moff) != C3_INT || op.grav[D] == 0.0) return 0.0;
+    const double* r = op.rho;
+    const long long se = op.g.s[E], sf = op.g.s[F];
+    const double b = -0.25 * ((r[c] + r[c + se]) + (r[c + sf] + r[c + se + sf])) * op.grav[D];
+    return scaled ? b / diag3<D>(op, c, idx) : b;
+}
+__global__ __launch_bounds__(256) void k3_rhs(Op3 op, W4 b, int scaled) {
+    K3_PROLOGUE(op.g)
+    b.p[0][c] = rhs_vel3<0>(op, c, idx, scaled);
+    b.p[1][c] = rhs_vel3<1>(op, c, idx, scaled);
+    b.p[2][c] = rhs_vel3<2>(op, c, idx, scaled);
+    b.p[3][c] = 0.0;
+}
+// b *= D_r (a user-supplied right-hand side)
+__global__ __launch_bounds__(256) void k3_scale_rows(Op3 op, W4 b) {
+    K3_PROLOGUE(op.g)
+    long long moff;
+    b.p[0][c] *= (cls3<0>(op, idx, moff) == C3_INT) ? 1.0 / diag3<0>(op, c, idx) : op.iKc;
+    b.p[1][c] *= (cls3<1>(op, idx, moff) == C3_INT) ? 1.0 / diag3<1>(op, c, idx) : op.iKc;
+    b.p[2][c] *= (cls3<2>(op, idx, moff) == C3_INT) ? 1.0 / diag3<2>(op, c, idx) : op.iKc;
+    const int cl = cls3_p(op, idx, moff);
+    const G3& g = op.g;
+    b.p[3][c] *= cl == 0 ? op.iKc : (cl == 2 ? 1.0 / op.Kb : op.iKc / (TB(g.rd[0], i) + TB(g.rd[1], j) + TB(g.rd[2], k)));
+}
+
+// ---- preconditioner pieces ---------------------------------------------------------------------------------------
+// z_p = S^-1 r_p from the SCALED residual (continuity rows: r eta_n / Kc^2 -> rs (sum rd) eta_n / Kc; ghost / anchor: rs;
+// symmetry rows: P = P_nb - rs)
+__device__ inline double prec_p3(const Op3& op, const double* __restrict__ rp, long long c, const int* idx) {
+    long long moff;
+    const int cl = cls3_p(op, idx, moff);
+    const G3& g = op.g;
+    if (cl == 0) return rp[c];
+    if (cl == 1) return rp[c] * (TB(g.rd[0], idx[0]) + TB(g.rd[1], idx[1]) + TB(g.rd[2], idx[2])) * op.en[c] * op.iKc;
+    // symmetry: value of the neighbour (one or two steps of the chain end on a continuity cell) minus the own residual
+    int id2[3] = {idx[0], idx[1], idx[2]};
+    long long c2 = c; double acc = 0.0;
+    for (int hop = 0; hop < 3; hop++) {
+        long long m2;
+        const int cl2 = cls3_p(op, id2, m2);
+        if (cl2 != 2) break;
+        acc -= rp[c2];
+        const int ax = (m2 == op.g.s[1] || m2 == -op.g.s[1]) ? 1 : 2;
+        id2[ax] += (m2 > 0) ? 1 : -1; c2 += m2;
+    }
+    long long m3;
+    const int cl3 = cls3_p(op, id2, m3);
+    const double base = cl3 == 1 ? rp[c2] * (TB(g.rd[0], id2[0]) + TB(g.rd[1], id2[1]) + TB(g.rd[2], id2[2])) * op.en[c2] * op.iKc : rp[c2];
+    return base + acc;
+}
+template <int D> __device__ inline double stage1_vel3(const Op3& op, const double* __restrict__ rs, const double* __restrict__ rp, long long c,
+                                                      const int* idx, double zp_c) {
+    long long moff;
+    if (cls3<D>(op, idx, moff) != C3_INT) return 0.0;
+    int idm[3] = {idx[0], idx[1], idx[2]}; idm[D] -= 1;
+    return rs[c] * diag3<D>(op, c, idx) + 2.0 * op.Kc * TB(op.g.rD[D], idx[D]) * (zp_c - prec_p3(op, rp, c - op.g.s[D], idm));
+}
+// z_p = S^-1 r_p and f = r_v - A_vp z_p on the interior momentum rows (unscaled), 0 elsewhere
+__global__ __launch_bounds__(256) void k3_stage1(Op3 op, V4 rs, double* __restrict__ zp, W3 f) {
+    K3_PROLOGUE(op.g)
+    const double z0 = prec_p3(op, rs.p[3], c, idx);
+    zp[c] = z0;
+    f.p[0][c] = stage1_vel3<0>(op, rs.p[0], rs.p[3], c, idx, z0);
+    f.p[1][c] = stage1_vel3<1>(op, rs.p[1], rs.p[3], c, idx, z0);
+    f.p[2][c] = stage1_vel3<2>(op, rs.p[2], rs.p[3], c, idx, z0);
+}
+
+// one Chebyshev-Jacobi sweep  v_next = v + c1 (v - v_prev) + c2 D^-1 (f - A v)  with the constraint rows closed in the same
+// pass (a slave evaluates its master's update).  zero != 0: v = 0 is implied and not read.
+template <int D> __device__ inline double cheb3(const Op3& op, const double* const* v, const double* __restrict__ vprev,
+                                                const double* __restrict__ f, double c1, double c2, long long c, const int* idx, int zero) {
+    constexpr int E = (D + 1) % 3, F = (D + 2) % 3;
+    long long moff;
+    const int cl = cls3<D>(op, idx, moff);
+    if (cl == C3_ZERO) return 0.0;
+    const long long cm = c + moff;
+    int im[3] = {idx[0], idx[1], idx[2]};
+    if (cl == C3_SLAVE) {
+        if (idx[E] == 0) im[E] = 1; else if (idx[E] == op.g.n[E] - 2) im[E] = op.g.n[E] - 3;
+        if (idx[F] == 0) im[F] = 1; else if (idx[F] == op.g.n[F] - 2) im[F] = op.g.n[F] - 3;
+    }
+    if (zero) return (-c2 * f[cm]) / diag3<D>(op, cm, im);
+    double Av, dg;
+    row3<D>(op, v, cm, im, Av, dg);
+    const double v0 = v[D][cm];
+    const double mom = (c1 != 0.0) ? c1 * (v0 - (vprev ? vprev[cm] : 0.0)) : 0.0;
+    return v0 + mom + (c2 * (Av - f[cm])) / dg;                                  // D = -dg
+}
+__global__ __launch_bounds__(256) void k3_cheb(Op3 op, V3 vcur, V3 vprev, V3 f, W3 vnext, double c1, double c2, int zero) {
+    K3_PROLOGUE(op.g)
+    const double* v[3] = {vcur.p[0], vcur.p[1], vcur.p[2]};
+    vnext.p[0][c] = cheb3<0>(op, v, vprev.p[0], f.p[0], c1, c2, c, idx, zero);
+    vnext.p[1][c] = cheb3<1>(op, v, vprev.p[1], f.p[1], c1, c2, c, idx, zero);
+    vnext.p[2][c] = cheb3<2>(op, v, vprev.p[2], f.p[2], c1, c2, c, idx, zero);
+}
+// mode 0: r = f - A v on interior rows (0 elsewhere); mode 1: y = D^-1 A v with closure (power iteration)
+template <int D> __device__ inline double resid3(const Op3& op, const double* const* v, const double* __restrict__ f, long long c,
+                                                 const int* idx, int mode) {
+    constexpr int E = (D + 1) % 3, F = (D + 2) % 3;
+    long long moff;
+    const int cl = cls3<D>(op, idx, moff);
+    if (cl == C3_ZERO || (mode == 0 && cl != C3_INT)) return 0.0;
+    const long long cm = c + moff;
+    int im[3] = {idx[0], idx[1], idx[2]};
+    if (cl == C3_SLAVE) {
+        if (idx[E] == 0) im[E] = 1; else if (idx[E] == op.g.n[E] - 2) im[E] = op.g.n[E] - 3;
+        if (idx[F] == 0) im[F] = 1; else if (idx[F] == op.g.n[F] - 2) im[F] = op.g.n[F] - 3;
+    }
+    double Av, dg;
+    row3<D>(op, v, cm, im, Av, dg);
+    return mode == 0 ? f[c] - Av : Av / dg;
+}
+__global__ __launch_bounds__(256) void k3_resid(Op3 op, V3 vv, V3 f, W3 r, int mode) {
+    K3_PROLOGUE(op.g)
+    const double* v[3] = {vv.p[0], vv.p[1], vv.p[2]};
+    r.p[0][c] = resid3<0>(op, v, f.p[0], c, idx, mode);
+    r.p[1][c] = resid3<1>(op, v, f.p[1], c, idx, mode);
+    r.p[2][c] = resid3<2>(op, v, f.p[2], c, idx, mode);
+}
+
+// full-weighting restriction: vertex-centred [1/4 1/2 1/4] along the component's own axis, cell-centred [1/8 3/8 3/8 1/8]
+// along the other two (uniform-grid weights)
+template <int D> __device__ inline double restrict3(const G3& gf, const Op3& opc, const double* __restrict__ rf, const int* idx) {
+    constexpr int E = (D + 1) % 3, F = (D + 2) % 3;
+    long long moff;
+    if (cls3<D>(opc, idx, moff) != C3_INT) return 0.0;
+    const long long b = i3(gf, 2 * idx[0], 2 * idx[1], 2 * idx[2]);
+    const double wv[3] = {0.25, 0.5, 0.25}, wc[4] = {0.125, 0.375, 0.375, 0.125};
+    double acc = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        double s1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            double s2 = 0.0;
+#pragma unroll
+            for (int p = 0; p < 4; p++) s2 += wc[p] * rf[b + (a - 1) * gf.s[D] + (q - 1) * gf.s[E] + (p - 1) * gf.s[F]];
+            s1 += wc[q] * s2;
+        }
+        acc += wv[a] * s1;
+    }
+    return acc;
+}
+__global__ __launch_bounds__(256) void k3_restrict(G3 gf, Op3 opc, V3 rf, W3 fc) {
+    K3_PROLOGUE(opc.g)
+    fc.p[0][c] = restrict3<0>(gf, opc, rf.p[0], idx);
+    fc.p[1][c] = restrict3<1>(gf, opc, rf.p[1], idx);
+    fc.p[2][c] = restrict3<2>(gf, opc, rf.p[2], idx);
+}
+// (P e)_D at a fine node: linear along the own axis, 3/4-1/4 (clamped) along the other two
+template <int D> __device__ inline double prolong3_at(const G3& gc, const double* __restrict__ e, const int* idx) {
+    constexpr int E = (D + 1) % 3, F = (D + 2) % 3;
+    const int d0 = idx[D] >> 1, d1 = (idx[D] + 1) >> 1;
+    int en_ = idx[E] >> 1, eo = (idx[E] & 1) ? en_ + 1 : en_ - 1;
+    int fn = idx[F] >> 1, fo = (idx[F] & 1) ? fn + 1 : fn - 1;
+    const int emax = gc.n[E] - 2, fmax = gc.n[F] - 2;
+    en_ = min(max(en_, 0), emax); eo = min(max(eo, 0), emax); fn = min(max(fn, 0), fmax); fo = min(max(fo, 0), fmax);
+    auto at = [&](int a, int b_, int c_) {
+        int id[3]; id[D] = a; id[E] = b_; id[F] = c_;
+        return e[i3(gc, id[0], id[1], id[2])];
+    };
+    auto lin = [&](int b_, int c_) { return 0.5 * (at(d0, b_, c_) + at(d1, b_, c_)); };
+    return 0.75 * (0.75 * lin(en_, fn) + 0.25 * lin(en_, fo)) + 0.25 * (0.75 * lin(eo, fn) + 0.25 * lin(eo, fo));
+}
+template <int D> __device__ inline double prolong3(const Op3& opf, const G3& gc, const double* __restrict__ e, const double* __restrict__ vin,
+                                                   long long c, const int* idx) {
+    constexpr int E = (D + 1) % 3, F = (D + 2) % 3;
+    long long moff;
+    const int cl = cls3<D>(opf, idx, moff);
+    if (cl == C3_ZERO) return 0.0;
+    int im[3] = {idx[0], idx[1], idx[2]};
+    if (cl == C3_SLAVE) {
+        if (idx[E] == 0) im[E] = 1; else if (idx[E] == opf.g.n[E] - 2) im[E] = opf.g.n[E] - 3;
+        if (idx[F] == 0) im[F] = 1; else if (idx[F] == opf.g.n[F] - 2) im[F] = opf.g.n[F] - 3;
+    }
+    return vin[c + moff] + prolong3_at<D>(gc, e, im);
+}
+__global__ __launch_bounds__(256) void k3_prolong_add(Op3 opf, G3 gc, V3 ec, V3 vin, W3 vout) {
+    K3_PROLOGUE(opf.g)
+    vout.p[0][c] = prolong3<0>(opf, gc, ec.p[0], vin.p[0], c, idx);
+    vout.p[1][c] = prolong3<1>(opf, gc, ec.p[1], vin.p[1], c, idx);
+    vout.p[2][c] = prolong3<2>(opf, gc, ec.p[2], vin.p[2], c, idx);
+}
+// arithmetic viscosity coarsening: nodes by [1 2 1]^3 / 64 (edge-clamped), centres by the mean of the 8 covered fine cells
+__global__ __launch_bounds__(256) void k3_coarsen(G3 gf, const double* __restrict__ esf, const double* __restrict__ enf, G3 gc,
+                                                  double* __restrict__ esc, double* __restrict__ enc) {
+    K3_PROLOGUE(gc)
+    double acc = 0.0;
+    for (int a = -1; a <= 1; a++)
+        for (int q = -1; q <= 1; q++)
+            for (int p = -1; p <= 1; p++) {
+                const int fi = min(max(2 * i + a, 0), gf.n[0] - 1), fj = min(max(2 * j + q, 0), gf.n[1] - 1), fk = min(max(2 * k + p, 0), gf.n[2] - 1);
+                acc += (a == 0 ? 2.0 : 1.0) * (q == 0 ? 2.0 : 1.0) * (p == 0 ? 2.0 : 1.0) * esf[i3(gf, fi, fj, fk)];
+            }
+    esc[c] = acc * (1.0 / 64.0);
+    const int ci = min(i, gc.n[0] - 2), cj = min(j, gc.n[1] - 2), ck = min(k, gc.n[2] - 2);      // ghost entries copy their neighbour
+    const long long b = i3(gf, 2 * ci, 2 * cj, 2 * ck);
+    double s = 0.0;
+    for (int a = 0; a < 2; a++) for (int q = 0; q < 2; q++) for (int p = 0; p < 2; p++) s += enf[b + a * gf.s[0] + q * gf.s[1] + p * gf.s[2]];
+    enc[c] = 0.125 * s;
+}
+// make x satisfy the constraint rows of A x = b exactly (bs = scaled b): walls / ghosts x = bs, slaves x = x_master + bs
+template <int D> __device__ inline void close3(const Op3& op, double* __restrict__ x, const double* __restrict__ bs, long long c, const int* idx) {
+    long long moff;
+    const int cl = cls3<D>(op, idx, moff);
+    if (cl == C3_ZERO) x[c] = bs[c];
+    else if (cl == C3_SLAVE) x[c] = x[c + moff] + bs[c];
+}
+__global__ __launch_bounds__(256) void k3_close(Op3 op, W3 x, V3 bs) {
+    K3_PROLOGUE(op.g)
+    close3<0>(op, x.p[0], bs.p[0], c, idx);
+    close3<1>(op, x.p[1], bs.p[1], c, idx);
+    close3<2>(op, x.p[2], bs.p[2], c, idx);
+}
+
+// ---- flat vector kernels (the ring / padding entries of every vector are zero and stay zero) ----------------------
+__global__ void k3_axpby(long long n, double* __restrict__ y, double a, const double* __restrict__ x, double b, const double* __restrict__ z) {
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) y[t] = a * x[t] + b * z[t];
+}
+__global__ void k3_p_update(long long n, double* __restrict__ p, const double* __restrict__ r, const double* __restrict__ v, double beta, double omega) {
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) p[t] = r[t] + beta * (p[t] - omega * v[t]);
+}
+__global__ void k3_xr_update(long long n, double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z, double* __restrict__ r,
+                             const double* __restrict__ s, const double* __restrict__ t_, double alpha, double omega) {
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        x[t] += alpha * y[t] + omega * z[t]; r[t] = s[t] - omega * t_[t];
+    }
+}
+#define D3_BLOCKS 1024
+// up to five dot products in one pass: part[5 b + q] = sum a_q[t] b_q[t]
+struct Dot5 { const double* a[5]; const double* b[5]; int n; };
+__global__ __launch_bounds__(256) void k3_dots(long long n, Dot5 d, double* __restrict__ part) {
+    double acc[5] = {0, 0, 0, 0, 0};
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long long)gridDim.x * 256)
+        for (int q = 0; q < d.n; q++) acc[q] += d.a[q][t] * d.b[q][t];
+    __shared__ double sh[5][4];
+    for (int q = 0; q < 5; q++) {
+        double a = acc[q];
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+        if ((threadIdx.x & 63) == 0) sh[q][threadIdx.x >> 6] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) part[5 * blockIdx.x + threadIdx.x] = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
+}
+__global__ __launch_bounds__(256) void k3_random(G3 g, double* __restrict__ v, unsigned seed) {
+    K3_PROLOGUE(g)
+    unsigned h = (unsigned)(((unsigned)i * 73856093u) ^ ((unsigned)j * 19349663u) ^ ((unsigned)k * 83492791u)) ^ seed;
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    v[c] = (i < g.n[0] - 1 && j < g.n[1] - 1 && k < g.n[2] - 1) ? (double)h * (2.0 / 4294967296.0) - 1.0 : 0.0;
+}
+
+// ---- heat ------------------------------------------------------------------------------------------------------------
+struct Heat3 {
+    G3 g;
+    const double* kk[3];             // conductivity on the faces normal to z, x, y: kz at (z_i+1/2, x_j, y_k) ...
+    const double* cdt;               // dt / (rho Cp) at the nodes
+    const double* rdb[3];            // 1 / (mid[i] - mid[i-1]) per axis
+    int bc[6];                       // z0, x0, y0, zL, xL, yL  (pylamp_diff.py: FIXTEMP 0 / FIXFLOW 1)
+};
+// pylamp_diff.py:99-179 extended: z-walls own their edges, then x-walls, then y-walls
+template <bool SCALED> __global__ __launch_bounds__(256) void k3_heat_apply(Heat3 op, const double* __restrict__ T, double* __restrict__ y) {
+    K3_PROLOGUE(op.g)
+    const G3& g = op.g;
+    const double t = T[c];
+    double r, dg = 1.0;
+    int wall = -1, ax = 0, hi = 0;
+    for (int a = 0; a < 3 && wall < 0; a++) {
+        if (idx[a] == 0) { wall = a; ax = a; hi = 0; }
+        else if (idx[a] == g.n[a] - 1) { wall = a + 3; ax = a; hi = 1; }
+    }
+    if (wall >= 0) {
+        if (op.bc[wall] == PL_BC_FIXTEMP) r = t;
+        else if (!hi) { const double kq = op.kk[ax][c] * TB(g.rd[ax], 0); r = kq * (T[c + g.s[ax]] - t); dg = -kq; }
+        else { const double kq = op.kk[ax][c - g.s[ax]] * TB(g.rd[ax], g.n[ax] - 2); r = kq * (t - T[c - g.s[ax]]); dg = kq; }
+    } else {
+        double fl = 0.0, dsum = 0.0;
+        for (int a = 0; a < 3; a++) {
+            const double kp = op.kk[a][c] * TB(g.rd[a], idx[a]), km = op.kk[a][c - g.s[a]] * TB(g.rd[a], idx[a] - 1);
+            const double rb = TB(op.rdb[a], idx[a]);
+            fl += (kp * (T[c + g.s[a]] - t) - km * (t - T[c - g.s[a]])) * rb;
+            dsum += (kp + km) * rb;
+        }
+        const double cc = op.cdt[c];
+        r = cc * fl - t;
+        if (SCALED) dg = -cc * dsum - 1.0;
+    }
+    y[c] = SCALED ? r / dg : r;
+}
+__global__ __launch_bounds__(256) void k3_heat_rhs(Heat3 op, const double* __restrict__ Told, const double* __restrict__ H, const double* bcv,
+                                                   double* __restrict__ rhs, int scaled) {
+    K3_PROLOGUE(op.g)
+    const G3& g = op.g;
+    int wall = -1, ax = 0, hi = 0;
+    for (int a = 0; a < 3 && wall < 0; a++) {
+        if (idx[a] == 0) { wall = a; ax = a; hi = 0; }
+        else if (idx[a] == g.n[a] - 1) { wall = a + 3; ax = a; hi = 1; }
+    }
+    double r, dg = 1.0;
+    if (wall >= 0) {
+        r = bcv[wall];
+        if (op.bc[wall] != PL_BC_FIXTEMP) dg = hi ? op.kk[ax][c - g.s[ax]] * TB(g.rd[ax], g.n[ax] - 2) : -op.kk[ax][c] * TB(g.rd[ax], 0);
+    } else {
+        r = -Told[c] - op.cdt[c] * H[c];
+        if (scaled) {
+            double dsum = 0.0;
+            for (int a = 0; a < 3; a++)
+                dsum += (op.kk[a][c] * TB(g.rd[a], idx[a]) + op.kk[a][c - g.s[a]] * TB(g.rd[a], idx[a] - 1)) * TB(op.rdb[a], idx[a]);
+            dg = -op.cdt[c] * dsum - 1.0;
+        }
+    }
+    rhs[c] = scaled ? r / dg : r;
+}
+__global__ __launch_bounds__(256) void k3_heat_coef(G3 g, const double* __restrict__ rho, const double* __restrict__ cp, double dt, double* __restrict__ out) {
+    K3_PROLOGUE(g)
+    out[c] = dt / (rho[c] * cp[c]);
+}
+
+// ---- host <-> device layout ------------------------------------------------------------------------------------------
+// host arrays are C-order (nz, nx, ny) [optionally with ncomp interleaved components last]
+__global__ __launch_bounds__(256) void k3_from_host(G3 g, const double* __restrict__ src, int ncomp, int comp, double* __restrict__ dst) {
+    K3_PROLOGUE(g)
+    dst[c] = src[(((long long)i * g.n[1] + j) * g.n[2] + k) * ncomp + comp];
+}
+__global__ __launch_bounds__(256) void k3_to_host(G3 g, const double* __restrict__ src, int ncomp, int comp, double* __restrict__ dst) {
+    K3_PROLOGUE(g)
+    dst[(((long long)i * g.n[1] + j) * g.n[2] + k) * ncomp + comp] = src[c];
+}
+
+// =====================================================================================================================
+// host side
+// =====================================================================================================================
+struct G3Host { G3 d; std::vector<double> c[3]; double* tables = nullptr; };
+struct Lev3 {
+    G3Host gh; Op3 op{};
+    double *es = nullptr, *en = nullptr; bool own = false;
+    double* v[3][3] = {{nullptr}}; double* f[3] = {nullptr}; double* r[3] = {nullptr};
+    double lmax = 3.0;
+};
+struct pl3_ctx {
+    int device = 0; hipStream_t stream = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    G3Host geom;
+    double *es = nullptr, *en = nullptr, *rho = nullptr; Op3 op{}; bool op_ready = false;
+    std::vector<Lev3*> levels;
+    double* vec[14][4] = {{nullptr}};           // BiCGStab work vectors (4 arrays each)
+    double* part = nullptr; double* hpart = nullptr;
+    double* stage = nullptr; size_t stage_bytes = 0;
+    // heat
+    Heat3 hop{}; bool hop_ready = false; double* hk[3] = {nullptr}; double *hT = nullptr, *hH = nullptr, *hcdt = nullptr, *hrho = nullptr, *hcp = nullptr;
+    double* hbcv = nullptr; double* htab = nullptr; double* hvec[12] = {nullptr}; double hbcv_host[6] = {0};
+    int nu = 2, coarse_sweeps = 12; double cheb_ratio = 6.0;
+};
+static thread_local std::string p3_tls_error;
+static int p3_fail(pl3_ctx* ctx, const std::string& m) { if (ctx) ctx->err = m; p3_tls_error = m; return 1; }
+#define P3_HIP(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return p3_fail(ctx, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+#define P3_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+
+static int g3_build(pl3_ctx* ctx, G3Host& gh, const int n[3], const double* const c[3]) {
+    G3& g = gh.d;
+    for (int a = 0; a < 3; a++) { g.n[a] = n[a]; gh.c[a].assign(c[a], c[a] + n[a]); }
+    const long long py = ((P3_PAD + n[2] + 1 + 15) / 16) * 16;
+    g.s[2] = 1; g.s[1] = py; g.s[0] = (long long)(n[1] + 2) * py;
+    g.vol = (long long)(n[0] + 2) * g.s[0];
+    size_t len[3], tot = 0;
+    for (int a = 0; a < 3; a++) { len[a] = ((size_t)n[a] + 2 * PL_TOFF + 3) & ~(size_t)1; tot += 2 * len[a]; }
+    std::vector<double> t(tot, 0.0);
+    size_t off = 0, offs[3][2];
+    for (int a = 0; a < 3; a++) {
+        offs[a][0] = off; off += len[a]; offs[a][1] = off; off += len[a];
+        for (int i = 0; i + 1 < n[a]; i++) t[offs[a][0] + i + PL_TOFF] = 1.0 / (c[a][i + 1] - c[a][i]);
+        for (int i = 1; i + 1 < n[a]; i++) t[offs[a][1] + i + PL_TOFF] = 1.0 / (c[a][i + 1] - c[a][i - 1]);
+    }
+    if (gh.tables) (void)hipFree(gh.tables);
+    P3_HIP(ctx, hipMalloc((void**)&gh.tables, tot * sizeof(double)));
+    P3_HIP(ctx, hipMemcpy(gh.tables, t.data(), tot * sizeof(double), hipMemcpyHostToDevice));
+    for (int a = 0; a < 3; a++) { g.rd[a] = gh.tables + offs[a][0]; g.rD[a] = gh.tables + offs[a][1]; }
+    return 0;
+}
+static int dmal(pl3_ctx* ctx, double** p, long long n) {
+    P3_HIP(ctx, hipMalloc((void**)p, (size_t)n * sizeof(double)));
+    P3_HIP(ctx, hipMemsetAsync(*p, 0, (size_t)n * sizeof(double), ctx->stream));
+    return 0;
+}
+static dim3 g1(long long n) { long long b = (n + 255) / 256; return dim3((unsigned)(b > 8192 ? 8192 : b)); }
+
+extern "C" const char* pl3_last_error(const pl3_ctx* ctx) { return ctx ? ctx->err.c_str() : p3_tls_error.c_str(); }
+
+extern "C" int pl3_create(pl3_ctx** out, int device, int nz, int nx, int ny, const double* zc, const double* xc, const double* yc) {
+    if (!out) return p3_fail(nullptr, "pl3_create: out is NULL");
+    *out = nullptr;
+    if (nz < 5 || nx < 5 || ny < 5 || !zc || !xc || !yc) return p3_fail(nullptr, "pl3_create: need at least 5 nodes per axis and the three coordinate arrays");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return p3_fail(nullptr, "pl3_create: no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return p3_fail(nullptr, "pl3_create: bad device index");
+    pl3_ctx* ctx = new pl3_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { delete ctx; return p3_fail(nullptr, "pl3_create: stream creation failed"); }
+    const int n[3] = {nz, nx, ny}; const double* c[3] = {zc, xc, yc};
+    if (g3_build(ctx, ctx->geom, n, c)) { std::string m = ctx->err; delete ctx; return p3_fail(nullptr, m); }
+    if (const char* e = getenv("PYLAMP_MG_NU3")) { int a = atoi(e); if (a >= 1 && a <= 6) ctx->nu = a; }
+    *out = ctx;
+    return 0;
+}
+static void free_levels3(pl3_ctx* ctx) {
+    for (Lev3* L : ctx->levels) {
+        if (L->own) { (void)hipFree(L->es); (void)hipFree(L->en); }
+        for (int b = 0; b < 3; b++) for (int q = 0; q < 3; q++) if (L->v[b][q]) (void)hipFree(L->v[b][q]);
+        for (int q = 0; q < 3; q++) { if (L->f[q]) (void)hipFree(L->f[q]); if (L->r[q]) (void)hipFree(L->r[q]); }
+        if (L->gh.tables) (void)hipFree(L->gh.tables);
+        delete L;
+    }
+    ctx->levels.clear();
+}
+extern "C" void pl3_destroy(pl3_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    free_levels3(ctx);
+    for (double* q : {ctx->es, ctx->en, ctx->rho, ctx->part, ctx->stage, ctx->hT, ctx->hH, ctx->hcdt, ctx->hrho, ctx->hcp, ctx->hbcv, ctx->htab}) if (q) (void)hipFree(q);
+    for (auto& v : ctx->vec) for (double* q : v) if (q) (void)hipFree(q);
+    for (double* q : ctx->hk) if (q) (void)hipFree(q);
+    for (double* q : ctx->hvec) if (q) (void)hipFree(q);
+    if (ctx->hpart) (void)hipHostFree(ctx->hpart);
+    if (ctx->geom.tables) (void)hipFree(ctx->geom.tables);
+    (void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1); (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+static int stage3(pl3_ctx* ctx, size_t bytes) {
+    if (ctx->stage_bytes >= bytes) return 0;
+    if (ctx->stage) { P3_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->stage); ctx->stage = nullptr; }
+    P3_HIP(ctx, hipMalloc((void**)&ctx->stage, bytes));
+    ctx->stage_bytes = bytes;
+    return 0;
+}
+static int upload3(pl3_ctx* ctx, const double* host, int ncomp, double* const* dst) {
+    const G3& g = ctx->geom.d;
+    const size_t bytes = (size_t)g.n[0] * g.n[1] * g.n[2] * ncomp * sizeof(double);
+    P3_TRY(stage3(ctx, bytes));
+    P3_HIP(ctx, hipMemcpyAsync(ctx->stage, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    for (int q = 0; q < ncomp; q++) hipLaunchKernelGGL(k3_from_host, grid3(g), dim3(64, 4), 0, ctx->stream, g, (const double*)ctx->stage, ncomp, q, dst[q]);
+    P3_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+static int download3(pl3_ctx* ctx, double* const* src, int ncomp, double* host) {
+    const G3& g = ctx->geom.d;
+    const size_t bytes = (size_t)g.n[0] * g.n[1] * g.n[2] * ncomp * sizeof(double);
+    P3_TRY(stage3(ctx, bytes));
+    for (int q = 0; q < ncomp; q++) hipLaunchKernelGGL(k3_to_host, grid3(g), dim3(64, 4), 0, ctx->stream, g, (const double*)src[q], ncomp, q, ctx->stage);
+    P3_HIP(ctx, hipMemcpyAsync(host, ctx->stage, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    P3_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+static int need_vecs(pl3_ctx* ctx, int nvec) {
+    const long long vol = ctx->geom.d.vol;
+    for (int v = 0; v < nvec; v++) for (int q = 0; q < 4; q++) if (!ctx->vec[v][q]) P3_TRY(dmal(ctx, &ctx->vec[v][q], vol));
+    if (!ctx->part) {
+        P3_TRY(dmal(ctx, &ctx->part, 5 * D3_BLOCKS));
+        P3_HIP(ctx, hipHostMalloc((void**)&ctx->hpart, 5 * D3_BLOCKS * sizeof(double)));
+    }
+    return 0;
+}
+
+// pylamp_stokes.py:116-122 extended dimension-wise: Kcont = DIM mineta / sum(avgd), Kbond = DIM^2 mineta / sum(avgd)^2
+extern "C" int pl3_stokes_set_coeffs(pl3_ctx* ctx, const double* etas, const double* etan, const double* rho, const double grav[3]) {
+    if (!etas || !etan || !rho) return p3_fail(ctx, "pl3_stokes_set_coeffs: NULL argument");
+    P3_HIP(ctx, hipSetDevice(ctx->device));
+    const G3& g = ctx->geom.d;
+    for (double** q : {&ctx->es, &ctx->en, &ctx->rho}) if (!*q) P3_TRY(dmal(ctx, q, g.vol));
+    double* d1[1];
+    d1[0] = ctx->es; P3_TRY(upload3(ctx, etas, 1, d1));
+    d1[0] = ctx->en; P3_TRY(upload3(ctx, etan, 1, d1));
+    d1[0] = ctx->rho; P3_TRY(upload3(ctx, rho, 1, d1));
+    const size_t N = (size_t)g.n[0] * g.n[1] * g.n[2];
+    double mes = INFINITY, men = INFINITY; bool nes = false, nen = false;
+    for (size_t t = 0; t < N; t++) { if (etas[t] != etas[t]) nes = true; else mes = std::min(mes, etas[t]); if (etan[t] != etan[t]) nen = true; else men = std::min(men, etan[t]); }
+    if (nes) mes = NAN; if (nen) men = NAN;
+    const double mineta = (men < mes) ? men : mes;                  // python's min(a, b), pylamp_stokes.py:116-118
+    double sum = 0.0;
+    for (int a = 0; a < 3; a++) sum += (ctx->geom.c[a].back() - ctx->geom.c[a].front()) / g.n[a];     // avgd = L / n (sic, :119-120)
+    Op3& op = ctx->op;
+    op.g = g; op.es = ctx->es; op.en = ctx->en; op.rho = ctx->rho;
+    op.Kc = 3.0 * mineta / sum; op.Kb = 9.0 * mineta / (sum * sum); op.iKc = 1.0 / op.Kc;
+    op.slave = 1;
+    for (int a = 0; a < 3; a++) op.grav[a] = grav ? grav[a] : (a == 0 ? 9.81 : 0.0);
+    op.anchor[0] = 3; op.anchor[1] = 2; op.anchor[2] = 2;
+    ctx->op_ready = true;
+    return 0;
+}
+// slaved != 0 (default): the reference's wall treatment extended to 3-D -- the outermost in-domain tangential velocities are
+// slaved to their inner neighbours (pylamp_stokes.py:170-175,209-214,249-255,296-301), which imposes free slip half a cell
+// inside the wall: first-order accurate.  0: natural (mirror) wall rows, second-order accurate.
+extern "C" int pl3_stokes_set_wall_rows(pl3_ctx* ctx, int slaved) {
+    if (!ctx->op_ready) return p3_fail(ctx, "stokes operator not set");
+    ctx->op.slave = slaved ? 1 : 0;
+    return 0;
+}
+extern "C" int pl3_stokes_get_scaling(pl3_ctx* ctx, double* kc, double* kb) {
+    if (!ctx->op_ready) return p3_fail(ctx, "stokes operator not set");
+    if (kc) *kc = ctx->op.Kc; if (kb) *kb = ctx->op.Kb;
+    return 0;
+}
+static V4 cv4(double* const* p) { V4 v; for (int q = 0; q < 4; q++) v.p[q] = p[q]; return v; }
+static W4 wv4(double* const* p) { W4 v; for (int q = 0; q < 4; q++) v.p[q] = p[q]; return v; }
+static V3 cv3(double* const* p) { V3 v; for (int q = 0; q < 3; q++) v.p[q] = p[q]; return v; }
+static W3 wv3(double* const* p) { W3 v; for (int q = 0; q < 3; q++) v.p[q] = p[q]; return v; }
+
+extern "C" int pl3_stokes_apply(pl3_ctx* ctx, const double* x, double* y) {
+    if (!ctx->op_ready) return p3_fail(ctx, "stokes operator not set");
+    P3_HIP(ctx, hipSetDevice(ctx->device));
+    P3_TRY(need_vecs(ctx, 2));
+    P3_TRY(upload3(ctx, x, 4, ctx->vec[0]));
+    hipLaunchKernelGGL(k3_apply<false>, grid3(ctx->op.g), dim3(64, 4), 0, ctx->stream, ctx->op, cv4(ctx->vec[0]), wv4(ctx->vec[1]));
+    P3_HIP(ctx, hipGetLastError());
+    return download3(ctx, ctx->vec[1], 4, y);
+}
+extern "C" int pl3_stokes_rhs(pl3_ctx* ctx, double* rhs) {
+    if (!ctx->op_ready) return p3_fail(ctx, "stokes operator not set");
+    P3_HIP(ctx, hipSetDevice(ctx->device));
+    P3_TRY(need_vecs(ctx, 2));
+    hipLaunchKernelGGL(k3_rhs, grid3(ctx->op.g), dim3(64, 4), 0, ctx->stream, ctx->op, wv4(ctx->vec[1]), 0);
+    P3_HIP(ctx, hipGetLastError());
+    return download3(ctx, ctx->vec[1], 4, rhs);
+}
+extern "C" int pl3_stokes_apply_bench(pl3_ctx* ctx, int scaled, int reps, double* avg_ms) {
+    if (!ctx->op_ready) return p3_fail(ctx, "stokes operator not set");
+    P3_HIP(ctx, hipSetDevice(ctx->device));
+    P3_TRY(need_vecs(ctx, 2));
+    for (int q = 0; q < 4; q++) hipLaunchKernelGGL(k3_random, grid3(ctx->op.g), dim3(64, 4), 0, ctx->stream, ctx->op.g, ctx->vec[0][q], 99u + q);
+    auto launch = [&]() {
+        if (scaled) hipLaunchKernelGGL(k3_apply<true>, grid3(ctx->op.g), dim3(64, 4), 0, ctx->stream, ctx->op, cv4(ctx->vec[0]), wv4(ctx->vec[1]));
+        else hipLaunchKernelGGL(k3_apply<false>, grid3(ctx->op.g), dim3(64, 4), 0, ctx->stream, ctx->op, cv4(ctx->vec[0]), wv4(ctx->vec[1]));
+    };
+    launch();
+    P3_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    for (int r = 0; r < reps; r++) launch();
+    P3_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    P3_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0; P3_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    if (avg_ms) *avg_ms = ms / reps;
+    return 0;
+}
+
+// ---- reductions -----------------------------------------------------------------------------------------------------------
+static int dots3(pl3_ctx* ctx, long long n, int nd, const double* const* a, const double* const* b, double* out) {
+    Dot5 d{}; d.n = nd;
+    for (int q = 0; q < nd; q++) { d.a[q] = a[q]; d.b[q] = b[q]; }
+    hipLaunchKernelGGL(k3_dots, dim3(D3_BLOCKS), dim3(256), 0, ctx->stream, n, d, ctx->part);
+    P3_HIP(ctx, hipMemcpyAsync(ctx->hpart, ctx->part, 5 * D3_BLOCKS * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    P3_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int q = 0; q < nd; q++) { double s = 0.0; for (int k = 0; k < D3_BLOCKS; k++) s += ctx->hpart[5 * k + q]; out[q] = s; }
+    return 0;
+}
+// dot products of multi-array vectors (na arrays each)
+static int vdots(pl3_ctx* ctx, long long vol, int na, int nd, double* const* const* a, double* const* const* b, double* out) {
+    for (int q = 0; q < nd; q++) out[q] = 0.0;
+    for (int c = 0; c < na; c++) {
+        const double* aa[5]; const double* bb[5]; double o[5];
+        for (int q = 0; q < nd; q++) { aa[q] = a[q][c]; bb[q] = b[q][c]; }
+        P3_TRY(dots3(ctx, vol, nd, aa, bb, o));
+        for (int q = 0; q < nd; q++) out[q] += o[q];
+    }
+    return 0;
+}
+
+// ---- multigrid -----------------------------------------------------------------------------------------------------------
+static int build_levels3(pl3_ctx* ctx) {
+    if (ctx->levels.empty()) {
+        int n[3] = {ctx->geom.d.n[0], ctx->geom.d.n[1], ctx->geom.d.n[2]};
+        std::vector<double> c[3] = {ctx->geom.c[0], ctx->geom.c[1], ctx->geom.c[2]};
+        for (int l = 0;; l++) {
+            Lev3* L = new Lev3();
+            const double* cc[3] = {c[0].data(), c[1].data(), c[2].data()};
+            if (g3_build(ctx, L->gh, n, cc)) { delete L; return 1; }
+            const long long vol = L->gh.d.vol;
+            if (l > 0) { L->own = true; P3_TRY(dmal(ctx, &L->es, vol)); P3_TRY(dmal(ctx, &L->en, vol)); }
+            for (int b = 0; b < 3; b++) for (int q = 0; q < 3; q++) P3_TRY(dmal(ctx, &L->v[b][q], vol));
+            for (int q = 0; q < 3; q++) { P3_TRY(dmal(ctx, &L->f[q], vol)); P3_TRY(dmal(ctx, &L->r[q], vol)); }
+            ctx->levels.push_back(L);
+            bool stop = false;
+            for (int a = 0; a < 3; a++) if ((n[a] - 1) % 2 || (n[a] - 1) / 2 < 4) stop = true;
+            if (stop) break;
+            for (int a = 0; a < 3; a++) {
+                std::vector<double> c2;
+                for (int i = 0; i < n[a]; i += 2) c2.push_back(c[a][i]);
+                c[a].swap(c2); n[a] = (n[a] - 1) / 2 + 1;
+            }
+        }
+    }
+    ctx->levels[0]->es = ctx->es; ctx->levels[0]->en = ctx->en;
+    for (size_t l = 0; l < ctx->levels.size(); l++) {
+        Lev3* L = ctx->levels[l];
+        if (l > 0) {
+            Lev3* F = ctx->levels[l - 1];
+            hipLaunchKernelGGL(k3_coarsen, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, F->gh.d, (const double*)F->es, (const double*)F->en, L->gh.d, L->es, L->en);
+        }
+        L->op = ctx->op; L->op.g = L->gh.d; L->op.es = L->es; L->op.en = L->en; L->op.slave = (l == 0) ? ctx->op.slave : 0;
+        // lambda_max of D^-1 A_vv by power iteration
+        const long long vol = L->gh.d.vol;
+        for (int q = 0; q < 3; q++) hipLaunchKernelGGL(k3_random, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, L->gh.d, L->v[0][q], 777u + q);
+        {   // the random start vector must satisfy the constraints: close it
+            for (int q = 0; q < 3; q++) P3_HIP(ctx, hipMemsetAsync(L->r[q], 0, (size_t)vol * sizeof(double), ctx->stream));
+            hipLaunchKernelGGL(k3_close, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, wv3(L->v[0]), cv3(L->r));
+        }
+        double lam = 2.5;
+        for (int it = 0; it < 12; it++) {
+            hipLaunchKernelGGL(k3_resid, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, cv3(L->v[0]), cv3(L->f), wv3(L->v[1]), 1);
+            double* const* aa[2] = {L->v[1], L->v[0]}; double* const* bb[2] = {L->v[1], L->v[0]};
+            double nn[2];
+            P3_TRY(vdots(ctx, vol, 3, 2, aa, bb, nn));
+            if (!(nn[0] > 0.0) || !(nn[1] > 0.0)) break;
+            lam = std::sqrt(nn[0] / nn[1]);
+            for (int q = 0; q < 3; q++) hipLaunchKernelGGL(k3_axpby, g1(vol), dim3(256), 0, ctx->stream, vol, L->v[0][q], 1.0 / std::sqrt(nn[0]), (const double*)L->v[1][q], 0.0, (const double*)L->v[1][q]);
+        }
+        L->lmax = 1.1 * lam;
+    }
+    P3_HIP(ctx, hipGetLastError());
+    return 0;
+}
+// nsweep sweeps; cur = index of the buffer holding the iterate on entry (ignored if zero_guess) and on exit
+static void smooth3(pl3_ctx* ctx, Lev3* L, double* const* f, int nsweep, double ratio, bool zero_guess, int& cur) {
+    const double lmax = L->lmax, lmin = lmax / ratio, theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
+    double rho_old = 1.0 / sigma;
+    int prev = (cur + 1) % 3;
+    for (int k = 0; k < nsweep; k++) {
+        double c1, c2;
+        if (k == 0) { c1 = 0.0; c2 = 1.0 / theta; }
+        else { const double rho = 1.0 / (2.0 * sigma - rho_old); c1 = rho * rho_old; c2 = 2.0 * rho / delta; rho_old = rho; }
+        int nxt = 0; while (nxt == cur || nxt == prev) nxt++;
+        V3 vp = cv3(L->v[prev]);
+        if (k == 1 && zero_guess) for (int q = 0; q < 3; q++) vp.p[q] = nullptr;
+        hipLaunchKernelGGL(k3_cheb, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, cv3(L->v[cur]), vp, cv3(f), wv3(L->v[nxt]), c1, c2,
+                           (k == 0 && zero_guess) ? 1 : 0);
+        prev = cur; cur = nxt;
+    }
+}
+static void vcycle3(pl3_ctx* ctx, size_t l, double* const* f, int& out_buf) {
+    Lev3* L = ctx->levels[l];
+    int cur = 0;
+    if (l + 1 == ctx->levels.size()) {
+        const G3& g = L->gh.d;
+        double ratio = 0.4 * std::pow((double)g.n[0] * g.n[1] * g.n[2], 2.0 / 3.0); if (ratio < 30.0) ratio = 30.0;
+        int n = std::max((int)std::sqrt(ratio), ctx->coarse_sweeps); if (n > 150) n = 150;
+        smooth3(ctx, L, f, n, ratio, true, cur);
+        out_buf = cur;
+        return;
+    }
+    smooth3(ctx, L, f, ctx->nu, ctx->cheb_ratio, true, cur);
+    hipLaunchKernelGGL(k3_resid, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, cv3(L->v[cur]), cv3(f), wv3(L->r), 0);
+    Lev3* C = ctx->levels[l + 1];
+    hipLaunchKernelGGL(k3_restrict, grid3(C->gh.d), dim3(64, 4), 0, ctx->stream, L->gh.d, C->op, cv3(L->r), wv3(C->f));
+    int cb = 0;
+    vcycle3(ctx, l + 1, C->f, cb);
+    const int nxt = (cur + 1) % 3;
+    hipLaunchKernelGGL(k3_prolong_add, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, C->gh.d, cv3(C->v[cb]), cv3(L->v[cur]), wv3(L->v[nxt]));
+    cur = nxt;
+    smooth3(ctx, L, f, ctx->nu, ctx->cheb_ratio, false, cur);
+    out_buf = cur;
+}
+
+// ---- generic right-preconditioned BiCGStab on multi-array vectors (correction form, true-residual stopping) --------------------
+typedef std::function<int(double* const*, double* const*)> Op3Fn;
+struct Stats3 { int iterations, converged; double rel_residual; int napply, nprec; };
+static int bicgstab3(pl3_ctx* ctx, long long vol, int na, const Op3Fn& A, const Op3Fn* M, double* const* b, double* const* x, bool use_x0,
+                     double rtol, int maxit, double* const* const* w /* r rt p v s t y z dx r0 */, G3 g, Stats3* st, double ref_norm) {
+    double* const* r = w[0]; double* const* rt = w[1]; double* const* p = w[2]; double* const* v = w[3]; double* const* s = w[4];
+    double* const* t = w[5]; double* const* y = w[6]; double* const* z = w[7]; double* const* dxb = w[8]; double* const* r0b = w[9];
+    auto axpby = [&](double* const* yy, double a, double* const* xx, double bb, double* const* zz) {
+        for (int c = 0; c < na; c++) hipLaunchKernelGGL(k3_axpby, g1(vol), dim3(256), 0, ctx->stream, vol, yy[c], a, (const double*)xx[c], bb, (const double*)zz[c]);
+    };
+    auto zero = [&](double* const* yy) { for (int c = 0; c < na; c++) (void)hipMemsetAsync(yy[c], 0, (size_t)vol * sizeof(double), ctx->stream); };
+    double d[5];
+    { double* const* aa[1] = {b}; P3_TRY(vdots(ctx, vol, na, 1, aa, aa, d)); }
+    double bnorm = std::sqrt(d[0]);
+    if (ref_norm > 0.0 && bnorm > 0.0) bnorm = ref_norm;
+    st->iterations = 0; st->converged = 0; st->rel_residual = 0.0;
+    if (!(bnorm > 0.0)) { zero(x); st->converged = 1; return 0; }
+    double* const* dx = x; double* const* r0 = b;
+    if (use_x0) { dx = dxb; P3_TRY(A(x, v)); axpby(r0b, 1.0, b, -1.0, v); r0 = r0b; }
+    zero(dx);
+    axpby(r, 1.0, r0, 0.0, r0);
+    for (int c = 0; c < na; c++) hipLaunchKernelGGL(k3_random, grid3(g), dim3(64, 4), 0, ctx->stream, g, rt[c], 1234u + c);
+    int it = 0, restarts = 0; double true_norm = -1.0, last_true = -1.0;
+    for (;;) {
+        zero(p); zero(v);
+        double rho = 1.0, alpha = 1.0, omega = 1.0;
+        { double* const* aa[2] = {rt, r}; double* const* bb[2] = {r, r}; P3_TRY(vdots(ctx, vol, na, 2, aa, bb, d)); }
+        double rho_new = d[0], rnorm = std::sqrt(d[1]);
+        bool broke = false;
+        double best = rnorm; int best_it = it;
+        while (it < maxit && rnorm > rtol * bnorm) {
+            it++;
+            if (!(std::fabs(rho_new) > 0.0) || !std::isfinite(rho_new)) { broke = true; break; }
+            const double beta = (rho_new / rho) * (alpha / omega);
+            for (int c = 0; c < na; c++) hipLaunchKernelGGL(k3_p_update, g1(vol), dim3(256), 0, ctx->stream, vol, p[c], (const double*)r[c], (const double*)v[c], beta, omega);
+            double* const* yv = p;
+            if (M) { P3_TRY((*M)(p, y)); yv = y; }
+            P3_TRY(A(yv, v));
+            { double* const* aa[1] = {rt}; double* const* bb[1] = {v}; P3_TRY(vdots(ctx, vol, na, 1, aa, bb, d)); }
+            if (!(std::fabs(d[0]) > 0.0) || !std::isfinite(d[0])) { broke = true; break; }
+            alpha = rho_new / d[0];
+            axpby(s, 1.0, r, -alpha, v);
+            double* const* zv = s;
+            if (M) { P3_TRY((*M)(s, z)); zv = z; }
+            P3_TRY(A(zv, t));
+            // one reduction: t.s, t.t, rt.s, rt.t, s.s  ->  omega, rho' = rt.s - omega rt.t, |r|^2 = s.s - 2 omega t.s + omega^2 t.t
+            { double* const* aa[5] = {t, t, rt, rt, s}; double* const* bb[5] = {s, t, s, t, s}; P3_TRY(vdots(ctx, vol, na, 5, aa, bb, d)); }
+            omega = (d[1] > 0.0) ? d[0] / d[1] : 0.0;
+            for (int c = 0; c < na; c++)
+                hipLaunchKernelGGL(k3_xr_update, g1(vol), dim3(256), 0, ctx->stream, vol, dx[c], (const double*)yv[c], (const double*)zv[c], r[c],
+                                   (const double*)s[c], (const double*)t[c], alpha, omega);
+            rho = rho_new; rho_new = d[2] - omega * d[3];
+            const double rr = d[4] - 2.0 * omega * d[0] + omega * omega * d[1];
+            rnorm = rr > 0.0 ? std::sqrt(rr) : 0.0;
+            if (!std::isfinite(rnorm) || !(std::fabs(omega) > 0.0)) { broke = true; break; }
+            if (rnorm < best) { best = rnorm; best_it = it; }
+            if (it - best_it > 80 || rnorm > 1e8 * best) { broke = true; break; }
+        }
+        P3_TRY(A(dx, t));
+        axpby(s, 1.0, r0, -1.0, t);
+        { double* const* aa[1] = {s}; P3_TRY(vdots(ctx, vol, na, 1, aa, aa, d)); }
+        last_true = true_norm; true_norm = std::sqrt(d[0]);
+        if (true_norm <= rtol * bnorm || broke || it >= maxit || restarts >= 4) break;
+        if (last_true >= 0.0 && !(true_norm < 0.5 * last_true)) break;
+        restarts++;
+        axpby(r, 1.0, s, 0.0, s);
+    }
+    if (dx != x) axpby(x, 1.0, x, 1.0, dx);
+    st->iterations = it; st->rel_residual = true_norm / bnorm; st->converged = (st->rel_residual <= rtol) ? 1 : 0;
+    return 0;
+}
+
+// hydrostatic pressure guess: with v = 0 the interior z-momentum rows reduce to -2 Kc rDz_i (P[i] - P[i-1]) = b_z; integrate down
+// every column, anchor cell to zero (same construction as pl_solver.hip)
+__global__ __launch_bounds__(256) void k3_hydro(Op3 op, double* __restrict__ P) {
+    const int k = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+    const G3& g = op.g;
+    if (k >= g.n[2] || j >= g.n[1]) return;
+    const double* r = op.rho;
+    const int jn = (j + 1 < g.n[1]) ? 1 : 0, kn = (k + 1 < g.n[2]) ? 1 : 0;
+    double acc = 0.0;
+    for (int i = 0; i < g.n[0]; i++) {
+        const long long c = i3(g, i, j, k);
+        if (i >= 1 && i <= g.n[0] - 2)
+            acc += 0.25 * ((r[c] + r[c + jn * g.s[1]]) + (r[c + kn * g.s[2]] + r[c + jn * g.s[1] + kn * g.s[2]])) * op.grav[0] / (2.0 * op.Kc * TB(g.rD[0], i));
+        P[c] = (i >= g.n[0] - 1 || j >= g.n[1] - 1 || k >= g.n[2] - 1) ? 0.0 : acc;
+    }
+}
+__global__ __launch_bounds__(256) void k3_shift(G3 g, double* __restrict__ P, const double* __restrict__ anchor_val) {
+    K3_PROLOGUE(g)
+    if (i < g.n[0] - 1 && j < g.n[1] - 1 && k < g.n[2] - 1) P[c] -= *anchor_val;
+}
+
+extern "C" int pl3_stokes_solve(pl3_ctx* ctx, const double* rhs, double* x, int use_x0, double rtol, int maxit, pl_solve_stats* stats) {
+    if (!ctx->op_ready) return p3_fail(ctx, "stokes operator not set");
+    if (!x) return p3_fail(ctx, "pl3_stokes_solve: x is NULL");
+    P3_HIP(ctx, hipSetDevice(ctx->device));
+    P3_TRY(need_vecs(ctx, 13));
+    if (rtol <= 0) rtol = 1e-10;
+    if (maxit <= 0) maxit = 600;
+    const G3& g = ctx->geom.d;
+    const long long vol = g.vol;
+    P3_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    P3_TRY(build_levels3(ctx));
+    double* const* B = ctx->vec[10]; double* const* X = ctx->vec[11]; double* const* XH = ctx->vec[12];
+    if (rhs) { P3_TRY(upload3(ctx, rhs, 4, B)); hipLaunchKernelGGL(k3_scale_rows, grid3(g), dim3(64, 4), 0, ctx->stream, ctx->op, wv4(B)); }
+    else hipLaunchKernelGGL(k3_rhs, grid3(g), dim3(64, 4), 0, ctx->stream, ctx->op, wv4(B), 1);
+    int napply = 0, nprec = 0;
+    Op3Fn A = [&](double* const* in, double* const* out) -> int {
+        hipLaunchKernelGGL(k3_apply<true>, grid3(g), dim3(64, 4), 0, ctx->stream, ctx->op, cv4(in), wv4(out));
+        napply++; return 0;
+    };
+    Op3Fn M = [&](double* const* in, double* const* out) -> int {
+        Lev3* L0 = ctx->levels[0];
+        hipLaunchKernelGGL(k3_stage1, grid3(g), dim3(64, 4), 0, ctx->stream, ctx->op, cv4(in), out[3], wv3(L0->f));
+        int ob = 0;
+        vcycle3(ctx, 0, L0->f, ob);
+        for (int q = 0; q < 3; q++) P3_HIP(ctx, hipMemcpyAsync(out[q], L0->v[ob][q], (size_t)vol * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        nprec++; return 0;
+    };
+    // hydrostatic start and the dynamic-load reference norm
+    double ref = 0.0;
+    {
+        for (int q = 0; q < 3; q++) P3_HIP(ctx, hipMemsetAsync(XH[q], 0, (size_t)vol * sizeof(double), ctx->stream));
+        hipLaunchKernelGGL(k3_hydro, dim3((g.n[2] + 63) / 64, (g.n[1] + 3) / 4), dim3(64, 4), 0, ctx->stream, ctx->op, XH[3]);
+        P3_HIP(ctx, hipMemcpyAsync(ctx->part, XH[3] + i3(g, 3, 2, 2), sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));   // anchor value
+        hipLaunchKernelGGL(k3_shift, grid3(g), dim3(64, 4), 0, ctx->stream, g, XH[3], (const double*)ctx->part);
+        P3_TRY(A(XH, ctx->vec[5]));
+        for (int c = 0; c < 4; c++) hipLaunchKernelGGL(k3_axpby, g1(vol), dim3(256), 0, ctx->stream, vol, ctx->vec[4][c], 1.0, (const double*)B[c], -1.0, (const double*)ctx->vec[5][c]);
+        double d[2];
+        double* const* aa[2] = {ctx->vec[4], B}; P3_TRY(vdots(ctx, vol, 4, 2, aa, aa, d));
+        ref = std::sqrt(d[0]);
+        if (!(ref > 1e-9 * std::sqrt(d[1]))) ref = 0.0;
+    }
+    if (use_x0) P3_TRY(upload3(ctx, x, 4, X));
+    else for (int c = 0; c < 4; c++) P3_HIP(ctx, hipMemcpyAsync(X[c], XH[c], (size_t)vol * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(k3_close, grid3(g), dim3(64, 4), 0, ctx->stream, ctx->op, wv3(X), cv3(B));
+    double* const* w[10] = {ctx->vec[0], ctx->vec[1], ctx->vec[2], ctx->vec[3], ctx->vec[4], ctx->vec[5], ctx->vec[6], ctx->vec[7], ctx->vec[8], ctx->vec[9]};
+    Stats3 st{};
+    P3_TRY(bicgstab3(ctx, vol, 4, A, &M, B, X, true, rtol, maxit, w, g, &st, ref));
+    P3_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    P3_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0; P3_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    P3_TRY(download3(ctx, X, 4, x));
+    if (stats) { stats->iterations = st.iterations; stats->converged = st.converged; stats->rel_residual = st.rel_residual; stats->solve_ms = ms;
+                 stats->operator_applies = napply; stats->precond_applies = nprec; }
+    return 0;
+}
+extern "C" int pl3_stokes_mg_info(pl3_ctx* ctx, int* nlevels, double* lmax, int max_levels) {
+    if (nlevels) *nlevels = (int)ctx->levels.size();
+    for (int l = 0; lmax && l < max_levels && l < (int)ctx->levels.size(); l++) lmax[l] = ctx->levels[l]->lmax;
+    return 0;
+}
+
+// ---- heat ----------------------------------------------------------------------------------------------------------------------
+extern "C" int pl3_heat_set_coeffs(pl3_ctx* ctx, const double* zmp, const double* xmp, const double* ymp, const double* T, const double* kz,
+                                   const double* kx, const double* ky, const double* cp, const double* rho, const double* H, const int bc[6],
+                                   const double bcvalue[6], double tstep) {
+    if (!zmp || !xmp || !ymp || !T || !kz || !kx || !ky || !cp || !rho || !H || !bc || !bcvalue) return p3_fail(ctx, "pl3_heat_set_coeffs: NULL argument");
+    for (int w = 0; w < 6; w++) if (bc[w] != PL_BC_FIXTEMP && bc[w] != PL_BC_FIXFLOW) return p3_fail(ctx, "heat: boundary condition must be FIXTEMP or FIXFLOW");
+    P3_HIP(ctx, hipSetDevice(ctx->device));
+    const G3& g = ctx->geom.d;
+    for (double** q : {&ctx->hk[0], &ctx->hk[1], &ctx->hk[2], &ctx->hT, &ctx->hH, &ctx->hcdt, &ctx->hrho, &ctx->hcp}) if (!*q) P3_TRY(dmal(ctx, q, g.vol));
+    const double* src[7] = {kz, kx, ky, T, H, rho, cp}; double* dst[7] = {ctx->hk[0], ctx->hk[1], ctx->hk[2], ctx->hT, ctx->hH, ctx->hrho, ctx->hcp};
+    for (int q = 0; q < 7; q++) { double* d1[1] = {dst[q]}; P3_TRY(upload3(ctx, src[q], 1, d1)); }
+    const double* mp[3] = {zmp, xmp, ymp};
+    size_t len[3], tot = 0;
+    for (int a = 0; a < 3; a++) { len[a] = (size_t)g.n[a] + 2 * PL_TOFF + 2; tot += len[a]; }
+    std::vector<double> t(tot, 0.0);
+    size_t off = 0, offs[3];
+    for (int a = 0; a < 3; a++) { offs[a] = off; for (int i = 1; i < g.n[a]; i++) t[off + i + PL_TOFF] = 1.0 / (mp[a][i] - mp[a][i - 1]); off += len[a]; }
+    if (!ctx->htab) P3_HIP(ctx, hipMalloc((void**)&ctx->htab, tot * sizeof(double)));
+    P3_HIP(ctx, hipMemcpy(ctx->htab, t.data(), tot * sizeof(double), hipMemcpyHostToDevice));
+    if (!ctx->hbcv) P3_HIP(ctx, hipMalloc((void**)&ctx->hbcv, 6 * sizeof(double)));
+    P3_HIP(ctx, hipMemcpy(ctx->hbcv, bcvalue, 6 * sizeof(double), hipMemcpyHostToDevice));
+    Heat3& op = ctx->hop;
+    op.g = g; for (int a = 0; a < 3; a++) { op.kk[a] = ctx->hk[a]; op.rdb[a] = ctx->htab + offs[a]; }
+    op.cdt = ctx->hcdt; for (int w = 0; w < 6; w++) op.bc[w] = bc[w];
+    hipLaunchKernelGGL(k3_heat_coef, grid3(g), dim3(64, 4), 0, ctx->stream, g, (const double*)ctx->hrho, (const double*)ctx->hcp, tstep, ctx->hcdt);
+    P3_HIP(ctx, hipGetLastError());
+    ctx->hop_ready = true;
+    return 0;
+}
+static int need_hvecs(pl3_ctx* ctx) {
+    for (int v = 0; v < 12; v++) if (!ctx->hvec[v]) P3_TRY(dmal(ctx, &ctx->hvec[v], ctx->geom.d.vol));
+    if (!ctx->part) { P3_TRY(dmal(ctx, &ctx->part, 5 * D3_BLOCKS)); P3_HIP(ctx, hipHostMalloc((void**)&ctx->hpart, 5 * D3_BLOCKS * sizeof(double))); }
+    return 0;
+}
+extern "C" int pl3_heat_apply(pl3_ctx* ctx, const double* x, double* y) {
+    if (!ctx->hop_ready) return p3_fail(ctx, "heat operator not set");
+    P3_HIP(ctx, hipSetDevice(ctx->device));
+    P3_TRY(need_hvecs(ctx));
+    double* a[1] = {ctx->hvec[0]}; double* b[1] = {ctx->hvec[1]};
+    P3_TRY(upload3(ctx, x, 1, a));
+    hipLaunchKernelGGL(k3_heat_apply<false>, grid3(ctx->hop.g), dim3(64, 4), 0, ctx->stream, ctx->hop, (const double*)a[0], b[0]);
+    P3_HIP(ctx, hipGetLastError());
+    return download3(ctx, b, 1, y);
+}
+extern "C" int pl3_heat_rhs(pl3_ctx* ctx, double* rhs) {
+    if (!ctx->hop_ready) return p3_fail(ctx, "heat operator not set");
+    P3_HIP(ctx, hipSetDevice(ctx->device));
+    P3_TRY(need_hvecs(ctx));
+    double* b[1] = {ctx->hvec[1]};
+    hipLaunchKernelGGL(k3_heat_rhs, grid3(ctx->hop.g), dim3(64, 4), 0, ctx->stream, ctx->hop, (const double*)ctx->hT, (const double*)ctx->hH, (const double*)ctx->hbcv, b[0], 0);
+    P3_HIP(ctx, hipGetLastError());
+    return download3(ctx, b, 1, rhs);
+}
+extern "C" int pl3_heat_solve(pl3_ctx* ctx, const double* rhs, double* x, double rtol, int maxit, pl_solve_stats* stats) {
+    if (!ctx->hop_ready) return p3_fail(ctx, "heat operator not set");
+    if (!x) return p3_fail(ctx, "pl3_heat_solve: x is NULL");
+    P3_HIP(ctx, hipSetDevice(ctx->device));
+    P3_TRY(need_hvecs(ctx));
+    if (rtol <= 0) rtol = 1e-12;
+    if (maxit <= 0) maxit = 2000;
+    const G3& g = ctx->geom.d;
+    P3_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    double* B[1] = {ctx->hvec[10]}; double* X[1] = {ctx->hvec[11]};
+    if (rhs) return p3_fail(ctx, "pl3_heat_solve: pass rhs = NULL (the operator's own right-hand side)");
+    hipLaunchKernelGGL(k3_heat_rhs, grid3(g), dim3(64, 4), 0, ctx->stream, ctx->hop, (const double*)ctx->hT, (const double*)ctx->hH, (const double*)ctx->hbcv, B[0], 1);
+    int napply = 0;
+    Op3Fn A = [&](double* const* in, double* const* out) -> int {
+        hipLaunchKernelGGL(k3_heat_apply<true>, grid3(g), dim3(64, 4), 0, ctx->stream, ctx->hop, (const double*)in[0], out[0]);
+        napply++; return 0;
+    };
+    double* wv[10][1]; double* const* w[10];
+    for (int q = 0; q < 10; q++) { wv[q][0] = ctx->hvec[q]; w[q] = wv[q]; }
+    Stats3 st{};
+    P3_TRY(bicgstab3(ctx, g.vol, 1, A, nullptr, B, X, false, rtol, maxit, w, g, &st, 0.0));
+    P3_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    P3_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0; P3_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    P3_TRY(download3(ctx, X, 1, x));
+    if (stats) { stats->iterations = st.iterations; stats->converged = st.converged; stats->rel_residual = st.rel_residual; stats->solve_ms = ms;
+                 stats->operator_applies = napply; stats->precond_applies = 0; }
+    return 0;
+}

@@ -12,7 +12,7 @@ from conftest import ROOT
 def _declared():
     txt = open(os.path.join(ROOT, "include", "pylamp_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(pl_[a-z0-9_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(pl3?_[a-z0-9_]+)\s*\(", txt)))
 
 
 def test_header_symbols_exported_and_bound():
