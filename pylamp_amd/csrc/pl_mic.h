@@ -43,6 +43,9 @@ struct PlGatherGrid {
     // cells [ie_lo, ie_hi] x [je_lo, je_hi] are held in memory (a rank's window of the field; all zero: the whole
     // grid).  A lookup outside is clamped into the window and counted in *n_outside_window by the kernels that have it.
     int ie_lo, ie_hi, je_lo, je_hi;
+    // resident step on a regular grid: in-cell coordinates by multiplication with sz, sx (= 1/h) instead of the reference's
+    // division dz0 / (dz0 + dz1) (pylamp_trac.py:89-90) -- equal to within an ulp; the module API keeps the division
+    int fast_uniform; double hx_over_hz, hz_over_hx;
 };
 
 struct PlGatherArgs {

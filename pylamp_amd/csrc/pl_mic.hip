@@ -287,8 +287,12 @@ __device__ inline CellLoc mic_locate(const PlGatherGrid& g, double z, double x) 
     mic_window(g, c);
     const double dz0 = z - g.gz[c.ie], dz1 = g.gz[c.ie + 1] - z;
     const double dx0 = x - g.gx[c.je], dx1 = g.gx[c.je + 1] - x;
-    c.a = dz0 / (dz0 + dz1);
-    c.b = dx0 / (dx0 + dx1);
+    if (g.fast_uniform) {                 // resident step on a regular grid: dz0 + dz1 = h, no FP64 divisions (8 per RK4 tracer otherwise)
+        c.a = dz0 * g.sz; c.b = dx0 * g.sx;
+    } else {
+        c.a = dz0 / (dz0 + dz1);
+        c.b = dx0 / (dx0 + dx1);
+    }
     return c;
 }
 
@@ -305,11 +309,12 @@ __device__ inline void mic_veldiv(const PlGatherGrid& g, const double* __restric
     const CellLoc c = mic_locate(g, z, x);
     const long long o = g.off + (long long)c.ie * g.pitch + c.je;
     const double hz = g.gz[c.ie + 1] - g.gz[c.ie], hx = g.gx[c.je + 1] - g.gx[c.je];
+    const double rzx = g.fast_uniform ? g.hx_over_hz : hx / hz, rxz = g.fast_uniform ? g.hz_over_hx : hz / hx;
     const double z00 = Vz[o], z01 = Vz[o + 1], z10 = Vz[o + g.pitch], z11 = Vz[o + g.pitch + 1];
     const double x00 = Vx[o], x01 = Vx[o + 1], x10 = Vx[o + g.pitch], x11 = Vx[o + g.pitch + 1];
     const double w00 = (1 - c.b) * (1 - c.a), w01 = c.b * (1 - c.a), w10 = (1 - c.b) * c.a, w11 = c.b * c.a;
-    const double C10 = (0.5 * hx / hz) * (z00 - z10 + z11 - z01);
-    const double C20 = (0.5 * hz / hx) * (x00 - x01 + x11 - x10);
+    const double C10 = (0.5 * rzx) * (z00 - z10 + z11 - z01);
+    const double C20 = (0.5 * rxz) * (x00 - x01 + x11 - x10);
     ux = w00 * x00 + w01 * x01 + w10 * x10 + w11 * x11 + c.b * (1 - c.b) * C10;
     uz = w00 * z00 + w01 * z01 + w10 * z10 + w11 * z11 + c.a * (1 - c.a) * C20;
     // Reference quirk (pylamp_trac.py:83,156): only the LAST field (vx) receives defval for an
@@ -362,7 +367,8 @@ __global__ __launch_bounds__(256) void k_rk4(PlRk4Args a) {
     if (oow && a.n_outside_window) atomicAdd(a.n_outside_window, 1ull);
     const double zn = z + (1.0 / 6.0) * dt * (k1z + k2z + k3z + k4z);
     const double xn = x + (1.0 / 6.0) * dt * (k1x + k2x + k3x + k4x);
-    a.vz_out[t] = (zn - z) / dt; a.vx_out[t] = (xn - x) / dt;
+    if (a.g.fast_uniform) { const double rdt = 1.0 / dt; a.vz_out[t] = (zn - z) * rdt; a.vx_out[t] = (xn - x) * rdt; }
+    else { a.vz_out[t] = (zn - z) / dt; a.vx_out[t] = (xn - x) / dt; }
     double zf = zn, xf = xn;
     if (a.fence) {                                     // pylamp2.py:563-570
         if (zf <= 0.0) zf = a.eps; if (zf >= a.Lz) zf = a.Lz - a.eps;

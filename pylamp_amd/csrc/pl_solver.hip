@@ -1048,6 +1048,7 @@ struct PlSolver {
     // transfer (identical numerics to one rank); 1 = once per level and direction; 0 = none (slab-local
     // smoothing with frozen zero halos; only the replicated coarse tail couples the slabs)
     int mg_halo = 2;
+    double schur_scale = 1.0;    // S^ = schur_scale * Kc^2 / eta_n (PYLAMP_SCHUR_SCALE)
     bool deep = true;            // PYLAMP_MG_DEEP=0: distributed levels exchange before every sweep instead of once per smoothing sequence
     int tail_nu_pre = -1, tail_nu_post = -1;        // smoothing sweeps on the replicated tail levels (-1: same as nu)
     double cheb_ratio = 6.0, lmax_safety = 1.1;     // smoothing window [lmax/ratio, lmax]; lmax = safety * power-iteration estimate
@@ -1070,6 +1071,7 @@ static PlSolver* solver_of(pl_ctx* ctx) {
         if (const char* e = getenv("PYLAMP_MG_TAIL_NODES")) { long long v = atoll(e); if (v >= 25 && v <= PL_TAIL_MAX_NODES) S->tail_knob = v; }
         if (const char* e = getenv("PYLAMP_MG_HALO")) S->mg_halo = atoi(e);
         if (const char* e = getenv("PYLAMP_MG_DEEP")) S->deep = atoi(e) != 0;
+        if (const char* e = getenv("PYLAMP_SCHUR_SCALE")) { double v = atof(e); if (v > 0.0) S->schur_scale = v; }
         if (const char* e = getenv("PYLAMP_MG_TAIL_NU")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a + b > 0) { S->tail_nu_pre = a; S->tail_nu_post = b; } }
         if (const char* e = getenv("PYLAMP_MG_RATIO")) { double v = atof(e); if (v > 1.5) { S->cheb_ratio = v; S->ratio_knob = true; } }
         if (const char* e = getenv("PYLAMP_MG_ANISO")) S->aniso_auto = atoi(e) != 0;
@@ -1608,6 +1610,7 @@ static int stokes_precond(pl_ctx* ctx, PlSolver* S, const double* rs, double* z)
         else PL_TRY(pl_halo(ctx, g, (double*)rs + 2 * g.plane, 1, g.plane));
     }
     op.g = V.op.g; op.etas -= V.sh; op.etan -= V.sh; if (op.rho) op.rho -= V.sh;
+    op.iKc /= S->schur_scale;                     // only the S^-1 r_p evaluations of stage 1 use it
     if (g_vv_vec && (g.plane % 2) == 0)
         hipLaunchKernelGGL(k_prec_stage1_v2, pl_grid_rows2(op.g), dim3(64, 4), 0, ctx->stream, op, V.op, rs - V.sh, z - V.sh, L0->f - V.sh);
     else

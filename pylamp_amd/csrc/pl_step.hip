@@ -1095,6 +1095,7 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
         ra.g.zmin = gz0; ra.g.xmin = gx0; ra.g.Lz = S->gmz[nz - 1] - gz0; ra.g.Lx = S->gmx[nx - 1] - gx0;
     }
     ra.g.rect = ctx->geom.uniform ? 0 : 1;
+    ra.g.fast_uniform = ctx->geom.uniform ? 1 : 0; ra.g.hx_over_hz = hx / hz; ra.g.hz_over_hx = hz / hx;
     ra.g.pitch = nVc; ra.g.off = -((long long)I0 * nVc + J0);      // cell indices are GLOBAL
     ra.g.ie_lo = I0; ra.g.ie_hi = I1 - 1; ra.g.je_lo = J0; ra.g.je_hi = J1 - 1;      // cells held locally
     ra.Vz = V; ra.Vx = V + VN; ra.dt = tstep;

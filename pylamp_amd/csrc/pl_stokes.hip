@@ -8,6 +8,7 @@
 // Bound: HBM.  Algorithmic traffic per node and apply: x 24 B + etas 8 + etan 8 + y 24
 // = 64 B.
 #include "pl_internal.h"
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <limits>
@@ -523,8 +524,12 @@ extern "C" int pl_stream_triad_bench(pl_ctx* ctx, int64_t n, int reps, double* a
     double* buf;
     PL_TRY(pl_buf(ctx, "triad", (size_t)3 * n * sizeof(double), &buf, false));
     hipLaunchKernelGGL(k_fill_pseudo, dim3(2048), dim3(256), 0, ctx->stream, buf, 3 * n, 777u);
+    // one double2 per thread measured fastest on MI355X (tools/triad_sweep.py: 6.07 TB/s at 3 x 1 GiB against 4.6 TB/s with 8192
+    // grid-striding blocks)
+    unsigned nblk = (unsigned)std::min<long long>((n / 2 + 255) / 256, 1 << 20);
+    if (const char* e = getenv("PYLAMP_TRIAD_BLOCKS")) { long v = atol(e); if (v >= 64 && v <= (1 << 22)) nblk = (unsigned)v; }
     auto launch = [&]() {
-        hipLaunchKernelGGL(k_triad, dim3(8192), dim3(256), 0, ctx->stream, (long long)(n / 2), (double2*)buf, (const double2*)(buf + n),
+        hipLaunchKernelGGL(k_triad, dim3(nblk), dim3(256), 0, ctx->stream, (long long)(n / 2), (double2*)buf, (const double2*)(buf + n),
                            (const double2*)(buf + 2 * n), 0.5);
     };
     launch();
