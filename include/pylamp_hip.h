@@ -47,6 +47,10 @@ typedef struct pl_solve_stats {
     double solve_ms;        /* device time of the solve (HIP events)              */
     int    operator_applies;
     int    precond_applies;
+    int    used_direct;     /* 1: the multigrid-preconditioned iteration did not converge and the banded-LU fallback for
+                             * small single-GPU systems finished the solve (indefinite systems: the reference's
+                             * free-surface stabilisation sign at the Courant step, pylamp2.py:387-405) */
+    int    reserved_;
 } pl_solve_stats;
 
 /* ---- context --------------------------------------------------------------------- */

@@ -92,6 +92,7 @@ struct pl_ctx {
     void* krylov = nullptr;   // pl_solver.hip
     void* mic = nullptr;      // pl_mic.hip
     void* step = nullptr;     // pl_step.hip
+    void* direct = nullptr;   // pl_direct.hip: banded LU of the last direct fallback
 };
 
 // ---- node-kernel launch shape -------------------------------------------------------------------
@@ -211,6 +212,12 @@ double* pl_stokes_solution_device(pl_ctx* ctx);
 double* pl_stokes_rhs_buffer_device(pl_ctx* ctx);
 int  pl_heat_solve_device(pl_ctx* ctx, const double* b_dev, double rtol, int maxit, pl_solve_stats* st,
                           double** x_out);
+
+// direct fallback for small systems (pl_direct.hip)
+bool pl_direct_possible(pl_ctx* ctx);
+int  pl_direct_factor(pl_ctx* ctx, const PlStokesOp& op_scaled);
+int  pl_direct_solve(pl_ctx* ctx, const double* in, double* out);
+void pl_direct_free(pl_ctx* ctx);
 
 // krylov / MIC / step teardown hooks
 void pl_solver_free(pl_ctx* ctx);

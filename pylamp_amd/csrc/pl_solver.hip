@@ -1032,7 +1032,7 @@ struct PlSolver {
                                          // (~9 launch-bound kernels) than its 8 halo exchanges per cycle
     // BiCGStab work vectors (3 planes each)
     double *r = nullptr, *rt = nullptr, *p = nullptr, *v = nullptr, *s = nullptr, *t = nullptr, *y = nullptr,
-           *z = nullptr, *b = nullptr, *x = nullptr, *xb = nullptr, *dx = nullptr, *r0 = nullptr;
+           *z = nullptr, *b = nullptr, *x = nullptr, *xb = nullptr, *dx = nullptr, *r0 = nullptr, *xh = nullptr;
     double* scal = nullptr;     // device scalars [0..16) + dot partials [16..16+5*DOT_BLOCKS)
     double* hpart = nullptr;    // pinned host copy of the dot partials
     int nu_pre = 2, nu_post = 2, coarse_sweeps = 12;
@@ -1097,7 +1097,7 @@ void pl_solver_free(pl_ctx* ctx) {
     PlSolver* S = (PlSolver*)ctx->krylov;
     if (!S) return;
     free_levels(S);
-    for (double* q : {S->r, S->rt, S->p, S->v, S->s, S->t, S->y, S->z, S->b, S->x, S->xb, S->dx, S->r0, S->scal})
+    for (double* q : {S->r, S->rt, S->p, S->v, S->s, S->t, S->y, S->z, S->b, S->x, S->xb, S->dx, S->r0, S->xh, S->scal})
         if (q) (void)hipFree(q);
     for (double* q : S->h) if (q) (void)hipFree(q);
     if (S->hpart) (void)hipHostFree(S->hpart);
@@ -1342,7 +1342,8 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
             PL_TRY(pl_halo(ctx, L->gh.d, L->etan, 1, L->gh.d.plane, dep));
         }
     }
-    if (sop.surfstab && sop.ss != 0.0 && sop.gz != 0.0) {
+    const bool stab_in_mg = !getenv("PYLAMP_STAB_PRECOND") || atoi(getenv("PYLAMP_STAB_PRECOND")) != 0;
+    if (sop.surfstab && sop.ss != 0.0 && sop.gz != 0.0 && stab_in_mg) {
         // stabilisation-aware velocity block: density coarsened like the nodal viscosity, terms rediscretised per level
         const double coef = sop.ss * sop.gz;
         for (size_t l = 0; l < S->levels.size(); l++) {
@@ -1834,6 +1835,10 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
         // no dynamic load (density contrasts below 1e-9 of the hydrostatic load are marker-averaging round-off):
         // fall back to ||b||, against which the hydrostatic state already is the solution
         if (!(ref > 1e-9 * std::sqrt(d2[1]))) ref = 0.0;
+        if (pl_direct_possible(ctx)) {                               // kept for the direct fallback (S->y is a work vector of the iteration)
+            if (!S->xh) PL_TRY(dmalloc0(ctx, &S->xh, (size_t)n3 * sizeof(double)));
+            PL_HIP(ctx, hipMemcpyAsync(S->xh, S->y, (size_t)n3 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        }
         if (!use_x0) {                                               // cold start from the hydrostatic state
             PL_HIP(ctx, hipMemcpyAsync(S->x, S->y, (size_t)n3 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
             use_x0 = true;
@@ -1841,6 +1846,20 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
     }
     hipLaunchKernelGGL(k_close_constraints, grid2d(g), dim3(64, 4), 0, ctx->stream, sop, S->levels[0]->op, S->b, S->x);
     PL_TRY(bicgstab(ctx, S, g, 3, A, &M, S->b, S->x, use_x0, rtol, maxit, w, st, ref));
+    st->used_direct = 0;
+    if (!st->converged && pl_direct_possible(ctx) && !getenv("PYLAMP_NO_DIRECT")) {
+        // Small system the iteration could not solve (an indefinite velocity block: the reference's stabilisation sign at the
+        // Courant step): factorise D_r A (banded LU, pl_direct.hip) and let it precondition the same iteration -- the LU is exact
+        // up to rounding, BiCGStab then only refines.  Restart from the hydrostatic state: the failed iterate may be far off.
+        PL_TRY(pl_direct_factor(ctx, sop_scaled));
+        VecOp MD = [&](const double* in, double* out) -> int { S->nprec++; return pl_direct_solve(ctx, in, out); };
+        const int it0 = st->iterations;
+        PL_HIP(ctx, hipMemcpyAsync(S->x, S->xh, (size_t)3 * g.plane * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_close_constraints, grid2d(g), dim3(64, 4), 0, ctx->stream, sop, S->levels[0]->op, S->b, S->x);
+        PL_TRY(bicgstab(ctx, S, g, 3, A, &MD, S->b, S->x, true, rtol, 50, w, st, ref));
+        st->iterations += it0;
+        st->used_direct = 1;
+    }
     double ms = 0;
     PL_TRY(pl_timer_stop_ms(ctx, &ms));
     st->solve_ms = ms; st->operator_applies = S->napply; st->precond_applies = S->nprec;

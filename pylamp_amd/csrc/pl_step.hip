@@ -994,6 +994,7 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
             rep->stokes.iterations += st2.iterations; rep->stokes.converged &= st2.converged;
             rep->stokes.rel_residual = st2.rel_residual; rep->stokes.solve_ms += st2.solve_ms;
             rep->stokes.operator_applies += st2.operator_applies; rep->stokes.precond_applies += st2.precond_applies;
+            rep->stokes.used_direct |= st2.used_direct;
             PL_TRY(reduce_minmax(ctx, S, g, p_vz, nullptr, nullptr, 0, &mn, &vmax_z, &hn));
             PL_TRY(reduce_minmax(ctx, S, g, p_vx, nullptr, nullptr, 0, &mn, &vmax_x, &hn));
             const double check = cfg->tstep_modifier * std::fmin(dz, dx) / std::fmax(vmax_z, vmax_x);
