@@ -76,8 +76,8 @@ def kernel_roofline(sim, reps):
     from pylamp_amd import pylamp_stokes as S
     ctx = sim.ctx
     ms = C.c_double()
-    first, count = ctx.local_rows()
-    n = count * sim.nx[1]                   # nodes of this rank's slab (the whole grid on one GPU)
+    _, ni_, _, nj_, _, _ = ctx.local_block()
+    n = ni_ * nj_                           # nodes of this rank's block (the whole grid on one GPU)
     tj = {}
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tf):
@@ -85,7 +85,7 @@ def kernel_roofline(sim, reps):
             tj = json.load(open(tf))
         except Exception:
             tj = {}
-    whole = abs(count - sim.nx[0]) <= 1
+    whole = sim.ctx.nranks == 1              # the traffic table and the 4097^2 point are single-GPU figures
 
     def tr(kernel, size):
         return tj.get(kernel, {}).get(str(size)) if whole else None
