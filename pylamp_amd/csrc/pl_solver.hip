@@ -355,8 +355,15 @@ __global__ __launch_bounds__(256) void k_vv_sweep2(PlVvOp op, const double* __re
     }
 }
 
+// wave-uniform: every node of the 128-column wave at row i is of the interior class in stage 1 (and in the first sweep)
+__device__ inline bool stage1_fast_wave(const PlGeom& g, int i, int jw, int bx, int anchor_i, int anchor_j) {
+    const bool anchor_near = (anchor_i == i || anchor_i == i - 1) && anchor_j >= jw - 1 && anchor_j <= jw + 127;
+    return !(i < 1 || i > g.nz - 3 || jw < 1 || jw + 127 > g.nx - 3 || anchor_near || bx * 128 + 127 >= g.lnx);
+}
 // First sweep from the zero guess, two columns per lane (see cheb_first_node): v1 = -c2 f / diag.
-__global__ __launch_bounds__(256) void k_vv_first2(PlVvOp op, const double* __restrict__ f, double* __restrict__ out, double c2) {
+// only_slow != 0: stage 1 has already written the waves it treats as interior (stage1_fast_wave); do the others only
+__global__ __launch_bounds__(256) void k_vv_first2(PlVvOp op, const double* __restrict__ f, double* __restrict__ out, double c2,
+                                                   int only_slow = 0, int anchor_i = -9, int anchor_j = -9) {
     const PlGeom& g = op.g;
     const int lane = threadIdx.x;
     const int lj0 = (blockIdx.x * 64 + lane) * 2;
@@ -369,8 +376,9 @@ __global__ __launch_bounds__(256) void k_vv_first2(PlVvOp op, const double* __re
     const int c = (int)pl_idx(g, li, lj0);
     const int i = g.gi0 + li, j0 = g.gj0 + lj0;
     const int jw = g.gj0 + blockIdx.x * 128;
+    if (only_slow && stage1_fast_wave(g, i, jw, blockIdx.x, anchor_i, anchor_j)) return;
     // walls, slaves, stabilised rows, or a wave that sticks out of the block (wave-uniform)
-    if (i <= 0 || i >= nz - 2 || jw < 1 || jw + 127 > nx - 3 || op.szz || blockIdx.x * 128 + 127 >= g.lnx) {
+    if (only_slow || i <= 0 || i >= nz - 2 || jw < 1 || jw + 127 > nx - 3 || op.szz || blockIdx.x * 128 + 127 >= g.lnx) {
         if (!active) return;
         for (int q = 0; q < 2 && lj0 + q < g.lnx; q++) cheb_first_node(op, f, out, c2, i, j0 + q, c + q);
         return;
@@ -877,8 +885,11 @@ __global__ __launch_bounds__(256) void k_prec_stage1(PlStokesOp op, PlVvOp vop, 
 }
 
 // Two columns per lane; interior waves run straight-line code, the others the per-node function above.
+// v1 != NULL: the first Chebyshev sweep of level 0 from the zero guess, v1 = -c2 f / diag, is written in the same pass (the
+// diagonal sums are the row scales this kernel computes anyway): the separate k_vv_first2 pass over f and the viscosities
+// is then only needed for the waves that take the per-node path here (k_vv_first2 with only_slow = 1).
 __global__ __launch_bounds__(256) void k_prec_stage1_v2(PlStokesOp op, PlVvOp vop, const double* __restrict__ rs,
-                                                        double* __restrict__ z, double* __restrict__ f) {
+                                                        double* __restrict__ z, double* __restrict__ f, double* __restrict__ v1, double c2) {
     const PlGeom& g = op.g;
     const int lane = threadIdx.x;
     const int lj0 = (blockIdx.x * 64 + lane) * 2;
@@ -890,8 +901,8 @@ __global__ __launch_bounds__(256) void k_prec_stage1_v2(PlStokesOp op, PlVvOp vo
     const int c = (int)pl_idx(g, li, lj0);
     const int i = g.gi0 + li;
     const int jw = g.gj0 + blockIdx.x * 128;
-    const bool anchor_near = (op.anchor_i == i || op.anchor_i == i - 1) && op.anchor_j >= jw - 1 && op.anchor_j <= jw + 127;
-    if (i < 1 || i > nz - 3 || jw < 1 || jw + 127 > nx - 3 || anchor_near || blockIdx.x * 128 + 127 >= g.lnx) {     // (or the wave sticks out of the block)
+    (void)nz; (void)nx;
+    if (!stage1_fast_wave(g, i, jw, blockIdx.x, op.anchor_i, op.anchor_j)) {     // walls, slaves, anchor, or the wave sticks out of the block
         for (int q = 0; q < 2 && lj0 + q < g.lnx; q++) stage1_node(op, vop, rs, z, f, li, lj0 + q);
         return;
     }
@@ -906,7 +917,7 @@ __global__ __launch_bounds__(256) void k_prec_stage1_v2(PlStokesOp op, PlVvOp vo
     const double rdz_i = TB(g.rdz, i), rdz_m = TB(g.rdz, i - 1), rDz_i = TB(g.rDz, i), rDz_p = TB(g.rDz, i + 1);
     const double Az = 4.0 * rdz_i * rDz_i, Azm = 4.0 * rdz_m * rDz_i, r2 = 2.0 * rdz_i, twoKc = 2.0 * op.Kc, Pz = twoKc * rDz_i;
     const double iKc = op.iKc;
-    double fz[2], fx[2], zp[2];
+    double fz[2], fx[2], zp[2], dz[2], dx[2];
     {   // column A
         const double rdx_j = t_rdx.v.x, rdx_m = t_rdx.w, rDx_j = t_rDx.v.x, rDx_p = t_rDx.v.y, k2 = 2.0 * rdx_j, B4 = 4.0 * rDx_j;
         zp[0] = rp_i.v.x * (rdx_j + rdz_i) * en_i.v.x * iKc;
@@ -915,6 +926,7 @@ __global__ __launch_bounds__(256) void k_prec_stage1_v2(PlStokesOp op, PlVvOp vo
         const double sx = en_i.v.x * (B4 * rdx_j) + en_i.w * (B4 * rdx_m) + (es_n.v.x * r2) * rDz_p + (es_i.v.x * r2) * rDz_i;
         fz[0] = rz.x * sz + Pz * (zp[0] - zp_s);
         fx[0] = rx.x * sx + (twoKc * rDx_j) * (zp[0] - zp_w);
+        dz[0] = sz; dx[0] = sx;
     }
     {   // column B (its west neighbour is column A)
         const double rdx_j = t_rdx.v.y, rdx_m = t_rdx.v.x, rDx_j = t_rDx.v.y, rDx_p = t_rDx.e, k2 = 2.0 * rdx_j, B4 = 4.0 * rDx_j;
@@ -924,10 +936,16 @@ __global__ __launch_bounds__(256) void k_prec_stage1_v2(PlStokesOp op, PlVvOp vo
         const double sx = en_i.v.y * (B4 * rdx_j) + en_i.v.x * (B4 * rdx_m) + (es_n.v.y * r2) * rDz_p + (es_i.v.y * r2) * rDz_i;
         fz[1] = rz.y * sz + Pz * (zp[1] - zp_s);
         fx[1] = rx.y * sx + (twoKc * rDx_j) * (zp[1] - zp[0]);
+        dz[1] = sz; dx[1] = sx;
     }
     *reinterpret_cast<double2*>(f + c) = make_double2(fz[0], fz[1]);
     *reinterpret_cast<double2*>(f + PLN + c) = make_double2(fx[0], fx[1]);
     *reinterpret_cast<double2*>(z + 2 * PLN + c) = make_double2(zp[0], zp[1]);
+    if (v1) {                                               // wave-uniform; same expressions as k_vv_first2's interior path
+        const double nc2 = -c2;
+        *reinterpret_cast<double2*>(v1 + c) = make_double2((nc2 * fz[0]) * pl_rcp(dz[0]), (nc2 * fz[1]) * pl_rcp(dz[1]));
+        *reinterpret_cast<double2*>(v1 + PLN + c) = make_double2((nc2 * fx[0]) * pl_rcp(dx[0]), (nc2 * fx[1]) * pl_rcp(dx[1]));
+    }
 }
 
 // Make x satisfy the constraint rows of A x = b exactly (b given SCALED, bs = b / Kc on these rows):
@@ -1049,6 +1067,7 @@ struct PlSolver {
     // smoothing with frozen zero halos; only the replicated coarse tail couples the slabs)
     int mg_halo = 2;
     double schur_scale = 1.0;    // S^ = schur_scale * Kc^2 / eta_n (PYLAMP_SCHUR_SCALE)
+    bool fuse_first = true;      // PYLAMP_FUSE_FIRST=0: the first sweep of level 0 as a pass of its own
     bool deep = true;            // PYLAMP_MG_DEEP=0: distributed levels exchange before every sweep instead of once per smoothing sequence
     int tail_nu_pre = -1, tail_nu_post = -1;        // smoothing sweeps on the replicated tail levels (-1: same as nu)
     double cheb_ratio = 6.0, lmax_safety = 1.1;     // smoothing window [lmax/ratio, lmax]; lmax = safety * power-iteration estimate
@@ -1071,6 +1090,7 @@ static PlSolver* solver_of(pl_ctx* ctx) {
         if (const char* e = getenv("PYLAMP_MG_TAIL_NODES")) { long long v = atoll(e); if (v >= 25 && v <= PL_TAIL_MAX_NODES) S->tail_knob = v; }
         if (const char* e = getenv("PYLAMP_MG_HALO")) S->mg_halo = atoi(e);
         if (const char* e = getenv("PYLAMP_MG_DEEP")) S->deep = atoi(e) != 0;
+        if (const char* e = getenv("PYLAMP_FUSE_FIRST")) S->fuse_first = atoi(e) != 0;
         if (const char* e = getenv("PYLAMP_SCHUR_SCALE")) { double v = atof(e); if (v > 0.0) S->schur_scale = v; }
         if (const char* e = getenv("PYLAMP_MG_TAIL_NU")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a + b > 0) { S->tail_nu_pre = a; S->tail_nu_post = b; } }
         if (const char* e = getenv("PYLAMP_MG_RATIO")) { double v = atof(e); if (v > 1.5) { S->cheb_ratio = v; S->ratio_knob = true; } }
@@ -1439,7 +1459,7 @@ static ExtView ext_view(pl_ctx* ctx, const MgLevel* L, int e) {
 // ext_first < 0: one halo exchange before every sweep that needs one (halo policy `halo`).
 static void smooth(pl_ctx* ctx, MgLevel* L, double* buf[3], const double* f, int nsweep, double ratio,
                    double* final_out = nullptr, bool zero_guess = false, int halo = 2, bool first_halo_valid = false,
-                   int ext_first = -1) {
+                   int ext_first = -1, const int* first_done_anchor = nullptr) {
     const double lmax = L->lmax, lmin = lmax / ratio;
     const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
     double rho_old = 1.0 / sigma;
@@ -1453,7 +1473,10 @@ static void smooth(pl_ctx* ctx, MgLevel* L, double* buf[3], const double* f, int
         const long long sh = V.sh;
         double* dst = (final_out && k == nsweep - 1) ? final_out : buf[2];
         if (k == 0 && zero_guess) {        // buf[0] is NOT read (and need not be zeroed)
-            if (g_vv_vec) hipLaunchKernelGGL(k_vv_first2, pl_grid_rows2(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, f - sh, dst - sh, c2);
+            if (g_vv_vec && first_done_anchor)        // stage 1 wrote the interior waves of this sweep already (into dst = buf[2])
+                hipLaunchKernelGGL(k_vv_first2, pl_grid_rows2(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, f - sh, dst - sh, c2, 1,
+                                   first_done_anchor[0], first_done_anchor[1]);
+            else if (g_vv_vec) hipLaunchKernelGGL(k_vv_first2, pl_grid_rows2(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, f - sh, dst - sh, c2);
             else hipLaunchKernelGGL(k_vv_cheb_first, pl_grid_rows(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, f - sh, dst - sh, c2,
                                     pl_row_iters(V.op.g));
         }
@@ -1507,7 +1530,7 @@ static bool level_deep_plan(const PlSolver* S, const MgLevel* L, size_t l, int& 
 // final_out (level 0 only): the last post-smoothing sweep writes its result there (zero-copy into z)
 // f_valid_depth: how deep into the halo the caller has already made f valid (level 0: stage 1 computes it there)
 static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const double* f, double** out, double* final_out = nullptr,
-                   int f_valid_depth = 0) {
+                   int f_valid_depth = 0, const int* first_done_anchor = nullptr) {
     MgLevel* L = S->levels[l];
     const PlGeom& g = L->gh.d;
     if (S->use_tail && l > 0 && (long long)g.nz * g.nx <= S->tail_max_nodes &&
@@ -1544,7 +1567,7 @@ static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const double* f, double**
         // ---- ONE exchange on the way down: the right-hand side, deep enough for the whole pre-smoothing sequence,
         //      the residual and (later) the post-smoothing sequence
         if (f_valid_depth < f_depth) (void)pl_halo(ctx, g, (double*)f, 2, g.plane, f_depth);
-        smooth(ctx, L, buf, f, npre, S->cheb_ratio, nullptr, true, hp, false, e_last + npre - 1);      // iterate valid e_last deep
+        smooth(ctx, L, buf, f, npre, S->cheb_ratio, nullptr, true, hp, false, e_last + npre - 1, first_done_anchor);      // iterate valid e_last deep
         const ExtView V = ext_view(ctx, L, e_last - 1);
         if (g_vv_vec)
             hipLaunchKernelGGL(k_vv_sweep2<1>, pl_grid_rows2(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, (const double*)(buf[0] - V.sh),
@@ -1553,7 +1576,7 @@ static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const double* f, double**
             hipLaunchKernelGGL(k_vv_residual, pl_grid_rows(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, (const double*)(buf[0] - V.sh), f - V.sh,
                                L->r - V.sh, pl_row_iters(V.op.g));
     } else {
-        smooth(ctx, L, buf, f, npre, S->cheb_ratio, nullptr, true, hp);
+        smooth(ctx, L, buf, f, npre, S->cheb_ratio, nullptr, true, hp, false, -1, first_done_anchor);
         if (L->dist && hp >= 1) (void)pl_halo(ctx, g, buf[0], 2, g.plane);
         if (g_vv_vec)
             hipLaunchKernelGGL(k_vv_sweep2<1>, pl_grid_rows2(g), dim3(64, 4), 0, ctx->stream, L->op, buf[0], (const double*)nullptr, f,
@@ -1612,13 +1635,21 @@ static int stokes_precond(pl_ctx* ctx, PlSolver* S, const double* rs, double* z)
     }
     op.g = V.op.g; op.etas -= V.sh; op.etan -= V.sh; if (op.rho) op.rho -= V.sh;
     op.iKc /= S->schur_scale;                     // only the S^-1 r_p evaluations of stage 1 use it
-    if (g_vv_vec && (g.plane % 2) == 0)
-        hipLaunchKernelGGL(k_prec_stage1_v2, pl_grid_rows2(op.g), dim3(64, 4), 0, ctx->stream, op, V.op, rs - V.sh, z - V.sh, L0->f - V.sh);
-    else
+    // the first pre-smoothing sweep of level 0 (from the zero guess: v1 = -c2 f / diag) is written by stage 1 itself
+    int npre0, npost0;
+    level_nu(S, 0, npre0, npost0);
+    const bool tail0 = false;
+    const bool fuse_first = S->fuse_first && g_vv_vec && (g.plane % 2) == 0 && S->levels.size() > 1 && npre0 >= 1 && !L0->op.szz && !tail0;
+    const int anchor[2] = {ctx->sop.anchor_i, ctx->sop.anchor_j};
+    if (g_vv_vec && (g.plane % 2) == 0) {
+        const double lmax = L0->lmax, lmin = lmax / S->cheb_ratio, c2 = 1.0 / (0.5 * (lmax + lmin));     // as smooth() computes it
+        hipLaunchKernelGGL(k_prec_stage1_v2, pl_grid_rows2(op.g), dim3(64, 4), 0, ctx->stream, op, V.op, rs - V.sh, z - V.sh, L0->f - V.sh,
+                           fuse_first ? L0->v[2] - V.sh : (double*)nullptr, c2);
+    } else
         hipLaunchKernelGGL(k_prec_stage1, pl_grid_rows(op.g), dim3(64, 4), 0, ctx->stream, op, V.op, rs - V.sh, z - V.sh, L0->f - V.sh, pl_row_iters(op.g));
     double* e = nullptr;
     const bool direct = S->levels.size() > 1 && S->nu_post > 0;     // last sweep writes into z
-    vcycle(ctx, S, 0, L0->f, &e, direct ? z : nullptr, deep ? f_depth : 0);
+    vcycle(ctx, S, 0, L0->f, &e, direct ? z : nullptr, deep ? f_depth : 0, fuse_first ? anchor : nullptr);
     if (e != z) hipLaunchKernelGGL(k_copy_vel, grid2d(g), dim3(64, 4), 0, ctx->stream, g, e, z);
     PL_HIP(ctx, hipGetLastError());
     S->nprec++;
