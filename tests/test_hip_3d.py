@@ -154,3 +154,32 @@ def test_heat_extrusion_matches_2d_oracle(oracle):
     T2 = oracle.heat_solve(nx2, grid2, gm2, T0, [kz, kx], Cp, rho, H, [0, 1, 0, 1], [273.0, 0.0, 1623.0, 0.0], dt).reshape(nx2)
     for k in range(ny):
         assert relerr(T3[:, :, k], T2) < 1e-6
+
+
+def test_config5_solve_129_cubed():
+    """A 129^3 instance of BASELINE config 5 (257^3 itself runs in `bench.py --config 3d257`): T-dependent viscosity over
+    three decades with 3-D structure; converged at the default tolerance, true residual recomputed on the host side of the
+    C ABI, discretely divergence-free, multigrid hierarchy of 6 levels."""
+    from pylamp_amd import pylamp3d as P3
+    n = 129; L = [660e3] * 3
+    grid = [np.linspace(0, L[d], n) for d in range(3)]
+    mid = [np.append(0.5 * (g[1:] + g[:-1]), g[-1] + 0.5 * (g[-1] - g[-2])) for g in grid]
+
+    def field(c):
+        Z, X, Y = np.meshgrid(*c, indexing="ij", sparse=True)
+        return 273 + 1350 * np.clip(Z / L[0], 0, 1) + 60 * np.sin(3 * np.pi * X / L[1]) * np.sin(np.pi * Z / L[0]) * np.cos(2 * np.pi * Y / L[2])
+    eta = lambda T: np.clip(1e20 * np.exp(120e3 / (8.31446 * T) - 120e3 / (8.31446 * 1623)), 1e17, 1e23)
+    Tn = field(grid)
+    A, rhs = P3.makeStokesMatrix([n, n, n], grid, eta(Tn), eta(field(mid)), 3300 / (3.5e-5 * (Tn - 1623) + 1))
+    x = P3.solve(A)
+    st = A.last_stats
+    assert st["converged"] == 1 and st["rel_residual"] <= P3.DEFAULT_RTOL and st["iterations"] < 120, st
+    assert A.mg_info()[0] == 6
+    r = rhs - A @ x
+    assert np.linalg.norm(r) / np.linalg.norm(rhs) < 1e-6
+    (vz, vx, vy), p = P3.x2vp(x, [n, n, n])
+    h = L[0] / (n - 1)
+    div = (vz[1:, :-1, :-1] - vz[:-1, :-1, :-1]) / h + (vx[:-1, 1:, :-1] - vx[:-1, :-1, :-1]) / h + (vy[:-1, :-1, 1:] - vy[:-1, :-1, :-1]) / h
+    vmax = max(np.abs(vz).max(), np.abs(vx).max(), np.abs(vy).max())
+    assert np.abs(div[1:-1, 1:-1, 1:-1]).max() < 1e-6 * vmax / h and np.abs(vy).max() > 1e-3 * vmax          # genuinely 3-D flow
+    A._ctx.close()
