@@ -112,16 +112,10 @@ template <int D> __device__ inline double diag3(const Op3& op, long long c, cons
     const int idx[3] = {i, j, k};                                                               \
     (void)idx;
 static dim3 grid3(const G3& g) { return dim3((g.n[2] + 63) / 64, (g.n[1] + 3) / 4, g.n[0]); }
-// The stencil kernels can march in z: a workgroup owns a 64 x 4 tile in (y, x) and walks P3_ZC planes, so that the planes
-// i-1, i, i+1 it needs are the ones it has just touched.  Measured at 257^3 on MI355X: P3_ZC = 32 is SLOWER (apply 1.44 ms
-// against 0.93 ms with one plane per workgroup) -- the kernel is bound by the latency of its ~70 dependent 8-byte loads per
-// node, not by HBM traffic, and marching cuts the parallelism that hides it.  Kept at 1 (= one plane per workgroup).
-#define P3_ZC 1
-#define K3_MARCH(g)                                                                             \
-    const int k = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;              \
-    if (k >= (g).n[2] || j >= (g).n[1]) return;                                                 \
-    for (int i = blockIdx.z * P3_ZC, iend_ = min(i + P3_ZC, (g).n[0]); i < iend_; i++)
-static dim3 grid3m(const G3& g) { return dim3((g.n[2] + 63) / 64, (g.n[1] + 3) / 4, (g.n[0] + P3_ZC - 1) / P3_ZC); }
+// (Tried: z-marching -- a workgroup owns a 64 x 4 tile in (y, x) and walks 32 planes so that the planes i-1, i, i+1 it needs
+// are the ones it has just touched.  Measured at 257^3 on MI355X: apply 1.44 ms against 0.93 ms with one plane per workgroup
+// -- the kernel is bound by the latency of its ~70 dependent 8-byte loads per node, not by HBM traffic, and marching cuts the
+// parallelism that hides it.  Removed.)
 
 // ---- full Stokes operator --------------------------------------------------------------------------------------
 struct V4 { const double* p[4]; };
@@ -166,11 +160,9 @@ template <int D> __device__ inline double apply_vel3(const Op3& op, const double
 }
 
 template <bool SCALED> __global__ __launch_bounds__(256) void k3_apply(Op3 op, V4 x, W4 y) {
+    K3_PROLOGUE(op.g)
     const double* v[3] = {x.p[0], x.p[1], x.p[2]};
     const double* __restrict__ P = x.p[3];
-    K3_MARCH(op.g) {
-    const long long c = i3(op.g, i, j, k);
-    const int idx[3] = {i, j, k};
     y.p[0][c] = apply_vel3<0>(op, v, P, c, idx, SCALED);
     y.p[1][c] = apply_vel3<1>(op, v, P, c, idx, SCALED);
     y.p[2][c] = apply_vel3<2>(op, v, P, c, idx, SCALED);
@@ -186,7 +178,6 @@ template <bool SCALED> __global__ __launch_bounds__(256) void k3_apply(Op3 op, V
         yp = SCALED ? div / (rz + rx + ry) : op.Kc * div;
     }
     y.p[3][c] = yp;
-    }
 }
 
 // rhs (pylamp_stokes.py:429,490 extended: density averaged onto the face), optionally row-scaled like k3_apply<true>
@@ -252,15 +243,12 @@ template <int D> __device__ inline double stage1_vel3(const Op3& op, const doubl
 }
 // z_p = S^-1 r_p and f = r_v - A_vp z_p on the interior momentum rows (unscaled), 0 elsewhere
 __global__ __launch_bounds__(256) void k3_stage1(Op3 op, V4 rs, double* __restrict__ zp, W3 f) {
-    K3_MARCH(op.g) {
-        const long long c = i3(op.g, i, j, k);
-        const int idx[3] = {i, j, k};
-        const double z0 = prec_p3(op, rs.p[3], c, idx);
-        zp[c] = z0;
-        f.p[0][c] = stage1_vel3<0>(op, rs.p[0], rs.p[3], c, idx, z0);
-        f.p[1][c] = stage1_vel3<1>(op, rs.p[1], rs.p[3], c, idx, z0);
-        f.p[2][c] = stage1_vel3<2>(op, rs.p[2], rs.p[3], c, idx, z0);
-    }
+    K3_PROLOGUE(op.g)
+    const double z0 = prec_p3(op, rs.p[3], c, idx);
+    zp[c] = z0;
+    f.p[0][c] = stage1_vel3<0>(op, rs.p[0], rs.p[3], c, idx, z0);
+    f.p[1][c] = stage1_vel3<1>(op, rs.p[1], rs.p[3], c, idx, z0);
+    f.p[2][c] = stage1_vel3<2>(op, rs.p[2], rs.p[3], c, idx, z0);
 }
 
 // one Chebyshev-Jacobi sweep  v_next = v + c1 (v - v_prev) + c2 D^-1 (f - A v)  with the constraint rows closed in the same
@@ -285,14 +273,11 @@ template <int D> __device__ inline double cheb3(const Op3& op, const double* con
     return v0 + mom + (c2 * (Av - f[cm])) / dg;                                  // D = -dg
 }
 __global__ __launch_bounds__(256) void k3_cheb(Op3 op, V3 vcur, V3 vprev, V3 f, W3 vnext, double c1, double c2, int zero) {
+    K3_PROLOGUE(op.g)
     const double* v[3] = {vcur.p[0], vcur.p[1], vcur.p[2]};
-    K3_MARCH(op.g) {
-        const long long c = i3(op.g, i, j, k);
-        const int idx[3] = {i, j, k};
-        vnext.p[0][c] = cheb3<0>(op, v, vprev.p[0], f.p[0], c1, c2, c, idx, zero);
-        vnext.p[1][c] = cheb3<1>(op, v, vprev.p[1], f.p[1], c1, c2, c, idx, zero);
-        vnext.p[2][c] = cheb3<2>(op, v, vprev.p[2], f.p[2], c1, c2, c, idx, zero);
-    }
+    vnext.p[0][c] = cheb3<0>(op, v, vprev.p[0], f.p[0], c1, c2, c, idx, zero);
+    vnext.p[1][c] = cheb3<1>(op, v, vprev.p[1], f.p[1], c1, c2, c, idx, zero);
+    vnext.p[2][c] = cheb3<2>(op, v, vprev.p[2], f.p[2], c1, c2, c, idx, zero);
 }
 // mode 0: r = f - A v on interior rows (0 elsewhere); mode 1: y = D^-1 A v with closure (power iteration)
 template <int D> __device__ inline double resid3(const Op3& op, const double* const* v, const double* __restrict__ f, long long c,
@@ -312,14 +297,11 @@ template <int D> __device__ inline double resid3(const Op3& op, const double* co
     return mode == 0 ? f[c] - Av : Av / dg;
 }
 __global__ __launch_bounds__(256) void k3_resid(Op3 op, V3 vv, V3 f, W3 r, int mode) {
+    K3_PROLOGUE(op.g)
     const double* v[3] = {vv.p[0], vv.p[1], vv.p[2]};
-    K3_MARCH(op.g) {
-        const long long c = i3(op.g, i, j, k);
-        const int idx[3] = {i, j, k};
-        r.p[0][c] = resid3<0>(op, v, f.p[0], c, idx, mode);
-        r.p[1][c] = resid3<1>(op, v, f.p[1], c, idx, mode);
-        r.p[2][c] = resid3<2>(op, v, f.p[2], c, idx, mode);
-    }
+    r.p[0][c] = resid3<0>(op, v, f.p[0], c, idx, mode);
+    r.p[1][c] = resid3<1>(op, v, f.p[1], c, idx, mode);
+    r.p[2][c] = resid3<2>(op, v, f.p[2], c, idx, mode);
 }
 
 // full-weighting restriction: vertex-centred [1/4 1/2 1/4] along the component's own axis, cell-centred [1/8 3/8 3/8 1/8]
@@ -714,7 +696,7 @@ extern "C" int pl3_stokes_apply(pl3_ctx* ctx, const double* x, double* y) {
     P3_HIP(ctx, hipSetDevice(ctx->device));
     P3_TRY(need_vecs(ctx, 2));
     P3_TRY(upload3(ctx, x, 4, ctx->vec[0]));
-    hipLaunchKernelGGL(k3_apply<false>, grid3m(ctx->op.g), dim3(64, 4), 0, ctx->stream, ctx->op, cv4(ctx->vec[0]), wv4(ctx->vec[1]));
+    hipLaunchKernelGGL(k3_apply<false>, grid3(ctx->op.g), dim3(64, 4), 0, ctx->stream, ctx->op, cv4(ctx->vec[0]), wv4(ctx->vec[1]));
     P3_HIP(ctx, hipGetLastError());
     return download3(ctx, ctx->vec[1], 4, y);
 }
@@ -732,8 +714,8 @@ extern "C" int pl3_stokes_apply_bench(pl3_ctx* ctx, int scaled, int reps, double
     P3_TRY(need_vecs(ctx, 2));
     for (int q = 0; q < 4; q++) hipLaunchKernelGGL(k3_random, grid3(ctx->op.g), dim3(64, 4), 0, ctx->stream, ctx->op.g, ctx->vec[0][q], 99u + q);
     auto launch = [&]() {
-        if (scaled) hipLaunchKernelGGL(k3_apply<true>, grid3m(ctx->op.g), dim3(64, 4), 0, ctx->stream, ctx->op, cv4(ctx->vec[0]), wv4(ctx->vec[1]));
-        else hipLaunchKernelGGL(k3_apply<false>, grid3m(ctx->op.g), dim3(64, 4), 0, ctx->stream, ctx->op, cv4(ctx->vec[0]), wv4(ctx->vec[1]));
+        if (scaled) hipLaunchKernelGGL(k3_apply<true>, grid3(ctx->op.g), dim3(64, 4), 0, ctx->stream, ctx->op, cv4(ctx->vec[0]), wv4(ctx->vec[1]));
+        else hipLaunchKernelGGL(k3_apply<false>, grid3(ctx->op.g), dim3(64, 4), 0, ctx->stream, ctx->op, cv4(ctx->vec[0]), wv4(ctx->vec[1]));
     };
     launch();
     P3_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
@@ -808,7 +790,7 @@ static int build_levels3(pl3_ctx* ctx) {
         }
         double lam = 2.5;
         for (int it = 0; it < 12; it++) {
-            hipLaunchKernelGGL(k3_resid, grid3m(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, cv3(L->v[0]), cv3(L->f), wv3(L->v[1]), 1);
+            hipLaunchKernelGGL(k3_resid, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, cv3(L->v[0]), cv3(L->f), wv3(L->v[1]), 1);
             double* const* aa[2] = {L->v[1], L->v[0]}; double* const* bb[2] = {L->v[1], L->v[0]};
             double nn[2];
             P3_TRY(vdots(ctx, vol, 3, 2, aa, bb, nn));
@@ -833,7 +815,7 @@ static void smooth3(pl3_ctx* ctx, Lev3* L, double* const* f, int nsweep, double 
         int nxt = 0; while (nxt == cur || nxt == prev) nxt++;
         V3 vp = cv3(L->v[prev]);
         if (k == 1 && zero_guess) for (int q = 0; q < 3; q++) vp.p[q] = nullptr;
-        hipLaunchKernelGGL(k3_cheb, grid3m(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, cv3(L->v[cur]), vp, cv3(f), wv3(L->v[nxt]), c1, c2,
+        hipLaunchKernelGGL(k3_cheb, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, cv3(L->v[cur]), vp, cv3(f), wv3(L->v[nxt]), c1, c2,
                            (k == 0 && zero_guess) ? 1 : 0);
         prev = cur; cur = nxt;
     }
@@ -850,7 +832,7 @@ static void vcycle3(pl3_ctx* ctx, size_t l, double* const* f, int& out_buf) {
         return;
     }
     smooth3(ctx, L, f, ctx->nu, ctx->cheb_ratio, true, cur);
-    hipLaunchKernelGGL(k3_resid, grid3m(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, cv3(L->v[cur]), cv3(f), wv3(L->r), 0);
+    hipLaunchKernelGGL(k3_resid, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, cv3(L->v[cur]), cv3(f), wv3(L->r), 0);
     Lev3* C = ctx->levels[l + 1];
     hipLaunchKernelGGL(k3_restrict, grid3(C->gh.d), dim3(64, 4), 0, ctx->stream, L->gh.d, C->op, cv3(L->r), wv3(C->f));
     int cb = 0;
@@ -971,12 +953,12 @@ extern "C" int pl3_stokes_solve(pl3_ctx* ctx, const double* rhs, double* x, int 
     else hipLaunchKernelGGL(k3_rhs, grid3(g), dim3(64, 4), 0, ctx->stream, ctx->op, wv4(B), 1);
     int napply = 0, nprec = 0;
     Op3Fn A = [&](double* const* in, double* const* out) -> int {
-        hipLaunchKernelGGL(k3_apply<true>, grid3m(g), dim3(64, 4), 0, ctx->stream, ctx->op, cv4(in), wv4(out));
+        hipLaunchKernelGGL(k3_apply<true>, grid3(g), dim3(64, 4), 0, ctx->stream, ctx->op, cv4(in), wv4(out));
         napply++; return 0;
     };
     Op3Fn M = [&](double* const* in, double* const* out) -> int {
         Lev3* L0 = ctx->levels[0];
-        hipLaunchKernelGGL(k3_stage1, grid3m(g), dim3(64, 4), 0, ctx->stream, ctx->op, cv4(in), out[3], wv3(L0->f));
+        hipLaunchKernelGGL(k3_stage1, grid3(g), dim3(64, 4), 0, ctx->stream, ctx->op, cv4(in), out[3], wv3(L0->f));
         int ob = 0;
         vcycle3(ctx, 0, L0->f, ob);
         for (int q = 0; q < 3; q++) P3_HIP(ctx, hipMemcpyAsync(out[q], L0->v[ob][q], (size_t)vol * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
