@@ -1,7 +1,7 @@
 """Time-loop driver: the counterpart of the script body of the reference's pylamp2.py.
 
 `Simulation` keeps tracers and every grid field resident on the GPU and advances them with
-one C-ABI call per time step (pl_step: pylamp2.py:273-581 without tracer injection).  The
+one C-ABI call per time step (pl_step: pylamp2.py:273-633, fence/deletion and census/injection included).  The
 model set-ups mirror the parameter blocks the BASELINE configs use (pylamp2.py:146-183), and
 `write_snapshot` emits the reference's griddata/tracs .npz files with the same keys
 (pylamp2.py:637-650) so pylamp_post.py can read them.
