@@ -155,6 +155,14 @@ int  pl_stokes_mg_info(pl_ctx* ctx, int* nlevels, double* lmax, int max_levels);
 /* Average duration (HIP events) of one Chebyshev smoothing sweep on the finest multigrid level -- the kernel
  * with the largest share of a time step (80 B/node algorithmic).  Call after at least one solve. */
 int  pl_stokes_sweep_bench(pl_ctx* ctx, int reps, double* avg_ms);
+/* Precision of the velocity-block multigrid of the last solve: the first *nlevels_fp32 of the *nlevels levels store and
+ * sweep in FP32 (the large, bandwidth-bound ones; off by default, PYLAMP_MG_FP32=1 or pl_stokes_set_mg_precision).  BiCGStab, the operator and
+ * the stopping test are FP64 always: the V-cycle only approximates A_vv^-1.  pl_stokes_sweep_bench times the finest
+ * level in the precision reported here (40 B/node algorithmic in FP32, 80 in FP64). */
+int  pl_stokes_mg_precision(pl_ctx* ctx, int* nlevels, int* nlevels_fp32);
+/* fp32 = 0: all levels FP64 (default); 1: the large levels in FP32.  min_nodes > 0: smallest level, in nodes of the rank's block, that
+ * runs in FP32 (default 200000: smaller levels are launch-latency bound and gain nothing). */
+int  pl_stokes_set_mg_precision(pl_ctx* ctx, int fp32, long long min_nodes);
 
 /* ---- Heat: replaces makeDiffusionMatrix (pylamp_diff.py:85-183) + spsolve
  *      (pylamp2.py:419) --------------------------------------------------------------- */

@@ -95,6 +95,8 @@ SIGNATURES = {
     "pl_stream_triad_bench": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, c_double_p]),
     "pl_stokes_precond_apply": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     "pl_stokes_mg_info": (C.c_int, [C.c_void_p, c_int_p, c_double_p, C.c_int]),
+    "pl_stokes_mg_precision": (C.c_int, [C.c_void_p, c_int_p, c_int_p]),
+    "pl_stokes_set_mg_precision": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong]),
     "pl_stokes_sweep_bench": (C.c_int, [C.c_void_p, C.c_int, c_double_p]),
     "pl_heat_set_coeffs": (C.c_int, [C.c_void_p] + [c_double_p] * 8 + [c_int_p, c_double_p, C.c_double]),
     "pl_heat_apply": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),

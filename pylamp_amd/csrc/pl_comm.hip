@@ -233,7 +233,7 @@ extern "C" int pl_comm_info(pl_ctx* ctx, int* rank, int* nranks, int* native) {
 // Regions are rectangles in LOCAL node coordinates (owned node (0,0) = origin); a segment holds the region of every
 // plane, plane after plane.
 struct HaloDesc {
-    int n;
+    int n, nplanes;
     int r0[8], nr[8], c0[8], nc[8];
     long long off[9];                 // element offset of segment k in the buffer; off[n] = total
 };
@@ -245,23 +245,28 @@ __device__ inline void halo_locate(const HaloDesc& d, long long t, int& k, int& 
     const long long local = t - d.off[k];
     const long long per = (long long)d.nr[k] * d.nc[k];
     q = (int)(local / per);
+    if (q >= d.nplanes) { q = -1; i = j = 0; return; }     // segments of float planes are padded to an even element count
     const int e = (int)(local % per);
     i = d.r0[k] + e / d.nc[k]; j = d.c0[k] + e % d.nc[k];
 }
-__global__ __launch_bounds__(256) void k_halo_pack(HaloDesc d, const double* __restrict__ origin, long long pitch,
-                                                   long long stride, double* __restrict__ buf) {
+template <typename T>
+__global__ __launch_bounds__(256) void k_halo_pack(HaloDesc d, const T* __restrict__ origin, long long pitch,
+                                                   long long stride, T* __restrict__ buf) {
     for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < d.off[d.n]; t += (long long)gridDim.x * 256) {
         int k, q, i, j;
         halo_locate(d, t, k, q, i, j);
+        if (q < 0) continue;                               // padding element of a single-precision segment
         buf[t] = origin[q * stride + (long long)i * pitch + j];
     }
 }
-__global__ __launch_bounds__(256) void k_halo_unpack(HaloDesc d, double* __restrict__ origin, long long pitch,
-                                                     long long stride, const double* __restrict__ buf, int add) {
+template <typename T>
+__global__ __launch_bounds__(256) void k_halo_unpack(HaloDesc d, T* __restrict__ origin, long long pitch,
+                                                     long long stride, const T* __restrict__ buf, int add) {
     for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < d.off[d.n]; t += (long long)gridDim.x * 256) {
         int k, q, i, j;
         halo_locate(d, t, k, q, i, j);
-        double* p = origin + q * stride + (long long)i * pitch + j;
+        if (q < 0) continue;
+        T* p = origin + q * stride + (long long)i * pitch + j;
         // reverse halo: the owned strips facing N, W and NW overlap in the corner node -> three segments add to it
         if (add) unsafeAtomicAdd(p, buf[t]); else *p = buf[t];
     }
@@ -269,10 +274,14 @@ __global__ __launch_bounds__(256) void k_halo_unpack(HaloDesc d, double* __restr
 
 static const int DZ[8] = {-1, 1, 0, 0, -1, -1, 1, 1}, DX[8] = {0, 0, -1, 1, -1, 1, -1, 1};
 
-int pl_halo_generic(pl_ctx* ctx, int lnz, int lnx, double* origin, long long pitch, int nplanes, long long stride, int depth, bool add) {
+// T = double, or float (the FP32 multigrid levels): messages are counted in doubles, so every segment of a float halo is
+// padded to an even number of elements
+template <typename T>
+static int halo_generic_t(pl_ctx* ctx, int lnz, int lnx, T* origin, long long pitch, int nplanes, long long stride, int depth, bool add) {
     if (ctx->nranks <= 1) return 0;
     if (depth < 1 || depth > PL_RING || depth > lnz || depth > lnx) return pl_fail(ctx, "pl_halo: bad depth");
     ctx->comm_calls[0]++;
+    const int per_double = (int)(sizeof(double) / sizeof(T));
     HaloDesc S{}, R{};
     int peers[8];
     long long off = 0;
@@ -288,30 +297,41 @@ int pl_halo_generic(pl_ctx* ctx, int lnz, int lnx, double* origin, long long pit
         S.r0[n] = add ? rr0 : or0; S.c0[n] = add ? rc0 : oc0; S.nr[n] = onr; S.nc[n] = onc;
         R.r0[n] = add ? or0 : rr0; R.c0[n] = add ? oc0 : rc0; R.nr[n] = onr; R.nc[n] = onc;
         S.off[n] = R.off[n] = off;
-        off += (long long)nplanes * onr * onc;
+        long long cnt = (long long)nplanes * onr * onc;
+        cnt = (cnt + per_double - 1) / per_double * per_double;
+        off += cnt;
         peers[n++] = qz * ctx->Px + qx;
     }
-    S.n = R.n = n; S.off[n] = R.off[n] = off;
+    S.n = R.n = n; S.nplanes = R.nplanes = nplanes; S.off[n] = R.off[n] = off;
     if (n == 0) return 0;
-    double *sb, *rb;
-    PL_TRY(pl_buf(ctx, "halo_send", (size_t)off * sizeof(double), &sb, false));
-    PL_TRY(pl_buf(ctx, "halo_recv", (size_t)off * sizeof(double), &rb, false));
+    double *sbd, *rbd;
+    PL_TRY(pl_buf(ctx, "halo_send", (size_t)off * sizeof(T), &sbd, false));
+    PL_TRY(pl_buf(ctx, "halo_recv", (size_t)off * sizeof(T), &rbd, false));
+    T* sb = reinterpret_cast<T*>(sbd); T* rb = reinterpret_cast<T*>(rbd);
     const unsigned nb = (unsigned)std::min<long long>((off + 255) / 256, 1024);
-    hipLaunchKernelGGL(k_halo_pack, dim3(nb), dim3(256), 0, ctx->stream, S, (const double*)origin, pitch, stride, sb);
+    hipLaunchKernelGGL(k_halo_pack<T>, dim3(nb), dim3(256), 0, ctx->stream, S, (const T*)origin, pitch, stride, sb);
     PlMsg msgs[8];
     for (int k = 0; k < n; k++) {
-        const long long cnt = S.off[k + 1] - S.off[k];
-        msgs[k] = PlMsg{peers[k], sb + S.off[k], cnt, rb + R.off[k], cnt};
+        const long long cnt = (S.off[k + 1] - S.off[k]) / per_double;          // in doubles
+        msgs[k] = PlMsg{peers[k], sbd + S.off[k] / per_double, cnt, rbd + R.off[k] / per_double, cnt};
     }
     PL_TRY(pl_comm_sendrecv(ctx, msgs, n));
-    hipLaunchKernelGGL(k_halo_unpack, dim3(nb), dim3(256), 0, ctx->stream, R, origin, pitch, stride, (const double*)rb, add ? 1 : 0);
+    hipLaunchKernelGGL(k_halo_unpack<T>, dim3(nb), dim3(256), 0, ctx->stream, R, origin, pitch, stride, (const T*)rb, add ? 1 : 0);
     PL_HIP(ctx, hipGetLastError());
     return 0;
+}
+
+int pl_halo_generic(pl_ctx* ctx, int lnz, int lnx, double* origin, long long pitch, int nplanes, long long stride, int depth, bool add) {
+    return halo_generic_t<double>(ctx, lnz, lnx, origin, pitch, nplanes, stride, depth, add);
 }
 
 int pl_halo(pl_ctx* ctx, const PlGeom& g, double* planes, int nplanes, long long plane_stride, int depth, bool add) {
     if (ctx->nranks <= 1) return 0;
     return pl_halo_generic(ctx, g.lnz, g.lnx, planes + pl_idx(g, 0, 0), g.pitch, nplanes, plane_stride, depth, add);
+}
+int pl_halo(pl_ctx* ctx, const PlGeom& g, float* planes, int nplanes, long long plane_stride, int depth, bool add) {
+    if (ctx->nranks <= 1) return 0;
+    return halo_generic_t<float>(ctx, g.lnz, g.lnx, planes + pl_idx(g, 0, 0), g.pitch, nplanes, plane_stride, depth, add);
 }
 
 // ---- replicated level from per-rank blocks ------------------------------------------------------------------------

@@ -113,21 +113,31 @@ __device__ inline double pl_rcp(double x) {
     return fma(fma(-x, r, 1.0), r, r);
 }
 
-// ---- two-columns-per-lane row loads (see k_stokes_apply_v2) ----
-struct Row2 { double2 v; double w, e; };           // w = value at j-1 of .x ; e = value at j+1 of .y
+// single precision (the FP32 multigrid levels): v_rcp_f32 is good to 1 ulp
+__device__ inline float pl_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
-__device__ inline Row2 load_row2(const double* __restrict__ row, int lj0, bool active, bool need_w, bool need_e,
-                                 int lane, bool has_right) {
-    Row2 r;
-    r.v = active ? *reinterpret_cast<const double2*>(row + lj0) : make_double2(0.0, 0.0);
-    r.w = 0.0; r.e = 0.0;
+// ---- two-columns-per-lane row loads (see k_stokes_apply_v2) ----
+template <typename T> struct PlVec2;
+template <> struct PlVec2<double> { typedef double2 type; static __host__ __device__ inline double2 make(double a, double b) { return make_double2(a, b); } };
+template <> struct PlVec2<float> { typedef float2 type; static __host__ __device__ inline float2 make(float a, float b) { return make_float2(a, b); } };
+
+template <typename T> struct Row2T { typename PlVec2<T>::type v; T w, e; };   // w = value at j-1 of .x ; e = value at j+1 of .y
+typedef Row2T<double> Row2;
+
+template <typename T>
+__device__ inline Row2T<T> load_row2(const T* __restrict__ row, int lj0, bool active, bool need_w, bool need_e,
+                                     int lane, bool has_right) {
+    typedef typename PlVec2<T>::type V2;
+    Row2T<T> r;
+    r.v = active ? *reinterpret_cast<const V2*>(row + lj0) : PlVec2<T>::make(T(0), T(0));
+    r.w = T(0); r.e = T(0);
     if (need_w) {
-        const double up = __shfl_up(r.v.y, 1, 64);
-        r.w = (lane == 0) ? (active ? row[lj0 - 1] : 0.0) : up;
+        const T up = __shfl_up(r.v.y, 1, 64);
+        r.w = (lane == 0) ? (active ? row[lj0 - 1] : T(0)) : up;
     }
     if (need_e) {
-        const double dn = __shfl_down(r.v.x, 1, 64);
-        r.e = (lane == 63 || !has_right) ? (active ? row[lj0 + 2] : 0.0) : dn;
+        const T dn = __shfl_down(r.v.x, 1, 64);
+        r.e = (lane == 63 || !has_right) ? (active ? row[lj0 + 2] : T(0)) : dn;
     }
     return r;
 }
@@ -168,6 +178,7 @@ inline void pl_block_1d(int n, int P, int p, int* first, int* count) {
 // Halo exchange with the (up to 8) neighbour blocks, `depth` <= PL_RING nodes deep, of nplanes planes (no-op on one
 // rank).  add: reverse (accumulating) halo - the ring contributions are ADDED to the neighbours' owned boundary nodes.
 int pl_halo(pl_ctx* ctx, const PlGeom& g, double* planes, int nplanes, long long plane_stride, int depth = 1, bool add = false);
+int pl_halo(pl_ctx* ctx, const PlGeom& g, float* planes, int nplanes, long long plane_stride, int depth = 1, bool add = false);   // FP32 multigrid levels
 // the same for any dense 2-D layout: `origin` points at the owned node (0,0) of plane 0
 int pl_halo_generic(pl_ctx* ctx, int lnz, int lnx, double* origin, long long pitch, int nplanes, long long plane_stride,
                     int depth, bool add);

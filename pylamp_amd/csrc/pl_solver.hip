@@ -24,35 +24,43 @@
 void pl_launch_heat_rhs(pl_ctx* ctx, const PlHeatOp& op, const double* Told, const double* H, double* rhs);
 
 // =========================================================================================
-// Velocity block
+// Velocity block.  Everything here is a template over the storage / arithmetic type T of the multigrid level:
+// double, or float for the large (bandwidth-bound) levels -- the preconditioner is only an approximation of
+// A_vv^-1, BiCGStab itself stays FP64 ("FP32 multigrid levels").
 // =========================================================================================
-struct PlVvOp {
+template <typename T>
+struct PlVvOpT {
     PlGeom g;
-    const double* etas; const double* etan;
+    const T* etas; const T* etan;
+    const T *rdz, *rDz, *rdx, *rDx;     // the tables of g in T (T = double: g's own)
     int slave_x;            // vz rows j=0 / j=nx-2 slaved to their inner neighbour (reference rows)
     int slave_z0, slave_zL; // vx rows i=0 / i=nz-2 slaved (reference rows, or NOSLIP on any level)
-    double s0, sL;          // slave factor: v_slave = s * v_master
+    T s0, sL;               // slave factor: v_slave = s * v_master
     // free-surface stabilisation terms of the z-momentum rows (pylamp_stokes.py:422-426), or NULL:
     // row_z += szz * vz[c] + szx * vx[c]   (the x rows carry G[IX] = 0 and are left alone)
-    const double* szz; const double* szx;
+    const T* szz; const T* szx;
 };
+typedef PlVvOpT<double> PlVvOp;
+typedef PlVvOpT<float> PlVvOpF;
 
 enum { VV_ZERO = 0, VV_INT = 1, VV_SLAVE = 2 };
 
-__device__ inline int vv_cls_z(const PlVvOp& op, int i, int j, int& moff, double& s) {
+template <typename T>
+__device__ inline int vv_cls_z(const PlVvOpT<T>& op, int i, int j, int& moff, T& s) {
     const int nz = op.g.nz, nx = op.g.nx;
-    moff = 0; s = 1.0;
+    moff = 0; s = T(1);
     if (j >= nx - 1 || i <= 0 || i >= nz - 1) return VV_ZERO;
     if (op.slave_x) {
-        if (j == 0) { moff = 1; s = 1.0; return VV_SLAVE; }
-        if (j == nx - 2) { moff = -1; s = 1.0; return VV_SLAVE; }
+        if (j == 0) { moff = 1; s = T(1); return VV_SLAVE; }
+        if (j == nx - 2) { moff = -1; s = T(1); return VV_SLAVE; }
     }
     return VV_INT;
 }
 
-__device__ inline int vv_cls_x(const PlVvOp& op, int i, int j, int& moff, double& s) {
+template <typename T>
+__device__ inline int vv_cls_x(const PlVvOpT<T>& op, int i, int j, int& moff, T& s) {
     const int nz = op.g.nz, nx = op.g.nx;
-    moff = 0; s = 1.0;
+    moff = 0; s = T(1);
     if (i >= nz - 1 || j <= 0 || j >= nx - 1) return VV_ZERO;
     if (i == 0 && op.slave_z0) { moff = op.g.pitch; s = op.s0; return VV_SLAVE; }
     if (i == nz - 2 && op.slave_zL) { moff = -op.g.pitch; s = op.sL; return VV_SLAVE; }
@@ -61,42 +69,43 @@ __device__ inline int vv_cls_x(const PlVvOp& op, int i, int j, int& moff, double
 
 // diagonal of a stabilised row is -dg + szz; the smoother keeps it at least half the viscous one
 // (the reference's sign of the term REDUCES the diagonal)
-__device__ inline double vv_stab_diag(double dg, double szz) { const double d = dg - szz; return d > 0.5 * dg ? d : 0.5 * dg; }
+template <typename T>
+__device__ inline T vv_stab_diag(T dg, T szz) { const T d = dg - szz; return d > T(0.5) * dg ? d : T(0.5) * dg; }
 
 // (A_vv v)_z and -diag at global node (i,j), plane offset c.  Zero-padded tables make the
 // mirror terms of the natural rows vanish (rDx[0] = rDx[nx-1] = 0, same in z).
-__device__ inline void vv_row_z(const PlVvOp& op, const double* __restrict__ vz, const double* __restrict__ vx,
-                                int c, int i, int j, double& Av, double& dg) {
-    const PlGeom& g = op.g;
-    const int p = g.pitch;
-    const double rdz_i = TB(g.rdz, i), rdz_m = TB(g.rdz, i - 1), rDz_i = TB(g.rDz, i);
-    const double rdx_j = TB(g.rdx, j), rDx_j = TB(g.rDx, j), rDx_p = TB(g.rDx, j + 1);
-    const double esC = op.etas[c], esE = op.etas[c + 1];
-    const double cN = 4.0 * op.etan[c] * rdz_i * rDz_i, cS = 4.0 * op.etan[c - p] * rdz_m * rDz_i;
-    const double cE = 2.0 * esE * rDx_p * rdx_j, cW = 2.0 * esC * rDx_j * rdx_j;
-    const double xE = 2.0 * esE * rDz_i * rdx_j, xW = 2.0 * esC * rDz_i * rdx_j;
-    const double v0 = vz[c];
+template <typename T>
+__device__ inline void vv_row_z(const PlVvOpT<T>& op, const T* __restrict__ vz, const T* __restrict__ vx,
+                                int c, int i, int j, T& Av, T& dg) {
+    const int p = op.g.pitch;
+    const T rdz_i = TB(op.rdz, i), rdz_m = TB(op.rdz, i - 1), rDz_i = TB(op.rDz, i);
+    const T rdx_j = TB(op.rdx, j), rDx_j = TB(op.rDx, j), rDx_p = TB(op.rDx, j + 1);
+    const T esC = op.etas[c], esE = op.etas[c + 1];
+    const T cN = T(4) * op.etan[c] * rdz_i * rDz_i, cS = T(4) * op.etan[c - p] * rdz_m * rDz_i;
+    const T cE = T(2) * esE * rDx_p * rdx_j, cW = T(2) * esC * rDx_j * rdx_j;
+    const T xE = T(2) * esE * rDz_i * rdx_j, xW = T(2) * esC * rDz_i * rdx_j;
+    const T v0 = vz[c];
     Av = cN * (vz[c + p] - v0) - cS * (v0 - vz[c - p]) + cE * (vz[c + 1] - v0) - cW * (v0 - vz[c - 1]) +
          xE * (vx[c + 1] - vx[c - p + 1]) - xW * (vx[c] - vx[c - p]);
     dg = cN + cS + cE + cW;
     if (op.szz) {                                   // wave-uniform
-        const double sd = op.szz[c];
+        const T sd = op.szz[c];
         Av += sd * v0 + op.szx[c] * vx[c];
         dg = vv_stab_diag(dg, sd);
     }
 }
 
-__device__ inline void vv_row_x(const PlVvOp& op, const double* __restrict__ vz, const double* __restrict__ vx,
-                                int c, int i, int j, double& Av, double& dg) {
-    const PlGeom& g = op.g;
-    const int p = g.pitch;
-    const double rdx_j = TB(g.rdx, j), rdx_m = TB(g.rdx, j - 1), rDx_j = TB(g.rDx, j);
-    const double rdz_i = TB(g.rdz, i), rDz_i = TB(g.rDz, i), rDz_p = TB(g.rDz, i + 1);
-    const double esC = op.etas[c], esN = op.etas[c + p];
-    const double cE = 4.0 * op.etan[c] * rdx_j * rDx_j, cW = 4.0 * op.etan[c - 1] * rdx_m * rDx_j;
-    const double cN = 2.0 * esN * rDz_p * rdz_i, cS = 2.0 * esC * rDz_i * rdz_i;
-    const double zN = 2.0 * esN * rDx_j * rdz_i, zS = 2.0 * esC * rDx_j * rdz_i;
-    const double v0 = vx[c];
+template <typename T>
+__device__ inline void vv_row_x(const PlVvOpT<T>& op, const T* __restrict__ vz, const T* __restrict__ vx,
+                                int c, int i, int j, T& Av, T& dg) {
+    const int p = op.g.pitch;
+    const T rdx_j = TB(op.rdx, j), rdx_m = TB(op.rdx, j - 1), rDx_j = TB(op.rDx, j);
+    const T rdz_i = TB(op.rdz, i), rDz_i = TB(op.rDz, i), rDz_p = TB(op.rDz, i + 1);
+    const T esC = op.etas[c], esN = op.etas[c + p];
+    const T cE = T(4) * op.etan[c] * rdx_j * rDx_j, cW = T(4) * op.etan[c - 1] * rdx_m * rDx_j;
+    const T cN = T(2) * esN * rDz_p * rdz_i, cS = T(2) * esC * rDz_i * rdz_i;
+    const T zN = T(2) * esN * rDx_j * rdz_i, zS = T(2) * esC * rDx_j * rdz_i;
+    const T v0 = vx[c];
     Av = cE * (vx[c + 1] - v0) - cW * (v0 - vx[c - 1]) + cN * (vx[c + p] - v0) - cS * (v0 - vx[c - p]) +
          zN * (vz[c + p] - vz[c + p - 1]) - zS * (vz[c] - vz[c - 1]);
     dg = cE + cW + cN + cS;
@@ -111,70 +120,77 @@ __device__ inline void vv_row_x(const PlVvOp& op, const double* __restrict__ vz,
 // One Chebyshev-Jacobi sweep in three-term form:
 //     v_next = v_cur + c1 (v_cur - v_prev) + c2 D^-1 (f - A v_cur)
 // with the constraint rows closed in the same pass (a slave thread evaluates its master's
-// update; all inputs are read-only so there is no ordering hazard).  80 B/node/sweep.
+// update; all inputs are read-only so there is no ordering hazard).  80 B/node/sweep (FP64).
 // (32-bit element offsets from wave-uniform plane bases keep the address arithmetic in SGPR-base +
 // VGPR-offset form: fewer VGPRs, more waves per SIMD)
-__device__ inline double cheb_val_z(const PlVvOp& op, const double* __restrict__ vcur, const double* __restrict__ vprev,
-                                    const double* __restrict__ f, double c1, double c2, int i, int j, int c) {
-    int moff = 0; double s = 1.0;
-    if (vv_cls_z(op, i, j, moff, s) == VV_ZERO) return 0.0;
+template <typename T>
+__device__ inline T cheb_val_z(const PlVvOpT<T>& op, const T* __restrict__ vcur, const T* __restrict__ vprev,
+                               const T* __restrict__ f, T c1, T c2, int i, int j, int c) {
+    int moff = 0; T s = T(1);
+    if (vv_cls_z(op, i, j, moff, s) == VV_ZERO) return T(0);
     const int cm = c + moff;
-    double Av, dg;
+    T Av, dg;
     vv_row_z(op, vcur, vcur + op.g.plane, cm, i, j + moff, Av, dg);   // moff is +-1 for vz
-    const double v0 = vcur[cm];
-    const double mom = (c1 != 0.0) ? c1 * (v0 - (vprev ? vprev[cm] : 0.0)) : 0.0;   // nullptr: previous iterate is zero
+    const T v0 = vcur[cm];
+    const T mom = (c1 != T(0)) ? c1 * (v0 - (vprev ? vprev[cm] : T(0))) : T(0);   // nullptr: previous iterate is zero
     return s * (v0 + mom + (c2 * (Av - f[cm])) * pl_rcp(dg));                     // D = -dg
 }
-__device__ inline double cheb_val_x(const PlVvOp& op, const double* __restrict__ vcur, const double* __restrict__ vprev,
-                                    const double* __restrict__ f, double c1, double c2, int i, int j, int c) {
+template <typename T>
+__device__ inline T cheb_val_x(const PlVvOpT<T>& op, const T* __restrict__ vcur, const T* __restrict__ vprev,
+                               const T* __restrict__ f, T c1, T c2, int i, int j, int c) {
     const long long P = op.g.plane;
-    int moff = 0; double s = 1.0;
-    if (vv_cls_x(op, i, j, moff, s) == VV_ZERO) return 0.0;
+    int moff = 0; T s = T(1);
+    if (vv_cls_x(op, i, j, moff, s) == VV_ZERO) return T(0);
     const int cm = c + moff;
     const int im = i + (moff > 0 ? 1 : (moff < 0 ? -1 : 0));
-    double Av, dg;
+    T Av, dg;
     vv_row_x(op, vcur, vcur + P, cm, im, j, Av, dg);
-    const double v0 = (vcur + P)[cm];
-    const double mom = (c1 != 0.0) ? c1 * (v0 - (vprev ? (vprev + P)[cm] : 0.0)) : 0.0;
+    const T v0 = (vcur + P)[cm];
+    const T mom = (c1 != T(0)) ? c1 * (v0 - (vprev ? (vprev + P)[cm] : T(0))) : T(0);
     return s * (v0 + mom + (c2 * (Av - (f + P)[cm])) * pl_rcp(dg));
 }
-__device__ inline void cheb_node(const PlVvOp& op, const double* __restrict__ vcur, const double* __restrict__ vprev,
-                                 const double* __restrict__ f, double* __restrict__ vnext, double c1, double c2, int i,
-                                 int j, long long c64) {
+// TO: type of the destination (the last sweep of an FP32 level 0 writes the FP64 Krylov vector, times oscale)
+template <typename T, typename TO>
+__device__ inline void cheb_node(const PlVvOpT<T>& op, const T* __restrict__ vcur, const T* __restrict__ vprev,
+                                 const T* __restrict__ f, TO* __restrict__ vnext, T c1, T c2, int i,
+                                 int j, long long c64, TO oscale = TO(1)) {
     const int c = (int)c64;
-    vnext[c] = cheb_val_z(op, vcur, vprev, f, c1, c2, i, j, c);
-    (vnext + op.g.plane)[c] = cheb_val_x(op, vcur, vprev, f, c1, c2, i, j, c);
+    vnext[c] = (TO)cheb_val_z(op, vcur, vprev, f, c1, c2, i, j, c) * oscale;
+    (vnext + op.g.plane)[c] = (TO)cheb_val_x(op, vcur, vprev, f, c1, c2, i, j, c) * oscale;
 }
 
 // diagonal sums only (no velocity reads)
-__device__ inline double vv_diag_z(const PlVvOp& op, int c, int i, int j) {
-    const PlGeom& g = op.g; const int p = g.pitch;
-    const double rDz_i = TB(g.rDz, i), rdx_j = TB(g.rdx, j);
-    const double dg = 4.0 * op.etan[c] * TB(g.rdz, i) * rDz_i + 4.0 * op.etan[c - p] * TB(g.rdz, i - 1) * rDz_i +
-                      2.0 * op.etas[c + 1] * TB(g.rDx, j + 1) * rdx_j + 2.0 * op.etas[c] * TB(g.rDx, j) * rdx_j;
+template <typename T>
+__device__ inline T vv_diag_z(const PlVvOpT<T>& op, int c, int i, int j) {
+    const int p = op.g.pitch;
+    const T rDz_i = TB(op.rDz, i), rdx_j = TB(op.rdx, j);
+    const T dg = T(4) * op.etan[c] * TB(op.rdz, i) * rDz_i + T(4) * op.etan[c - p] * TB(op.rdz, i - 1) * rDz_i +
+                 T(2) * op.etas[c + 1] * TB(op.rDx, j + 1) * rdx_j + T(2) * op.etas[c] * TB(op.rDx, j) * rdx_j;
     return op.szz ? vv_stab_diag(dg, op.szz[c]) : dg;
 }
-__device__ inline double vv_diag_x(const PlVvOp& op, int c, int i, int j) {
-    const PlGeom& g = op.g; const int p = g.pitch;
-    const double rDx_j = TB(g.rDx, j), rdz_i = TB(g.rdz, i);
-    return 4.0 * op.etan[c] * TB(g.rdx, j) * rDx_j + 4.0 * op.etan[c - 1] * TB(g.rdx, j - 1) * rDx_j +
-           2.0 * op.etas[c + p] * TB(g.rDz, i + 1) * rdz_i + 2.0 * op.etas[c] * TB(g.rDz, i) * rdz_i;
+template <typename T>
+__device__ inline T vv_diag_x(const PlVvOpT<T>& op, int c, int i, int j) {
+    const int p = op.g.pitch;
+    const T rDx_j = TB(op.rDx, j), rdz_i = TB(op.rdz, i);
+    return T(4) * op.etan[c] * TB(op.rdx, j) * rDx_j + T(4) * op.etan[c - 1] * TB(op.rdx, j - 1) * rDx_j +
+           T(2) * op.etas[c + p] * TB(op.rDz, i + 1) * rdz_i + T(2) * op.etas[c] * TB(op.rDz, i) * rdz_i;
 }
 
 // First sweep from a ZERO guess: A v = 0, so v1 = -c2 f / diag needs no stencil and no memset of the
 // iterate (48 instead of 80 + 16 B/node).  Slaves copy their master's value as usual.
-__device__ inline void cheb_first_node(const PlVvOp& op, const double* __restrict__ f, double* __restrict__ vnext,
-                                       double c2, int i, int j, long long c64) {
+template <typename T>
+__device__ inline void cheb_first_node(const PlVvOpT<T>& op, const T* __restrict__ f, T* __restrict__ vnext,
+                                       T c2, int i, int j, long long c64) {
     const long long P = op.g.plane;
     const int c = (int)c64;
-    const double* __restrict__ fz = f; const double* __restrict__ fx = f + P;
-    int moff = 0; double s = 1.0;
+    const T* __restrict__ fz = f; const T* __restrict__ fx = f + P;
+    int moff = 0; T s = T(1);
     int cls = vv_cls_z(op, i, j, moff, s);
-    double out = 0.0;
+    T out = T(0);
     if (cls != VV_ZERO) { const int cm = c + moff; out = (-s * c2 * fz[cm]) * pl_rcp(vv_diag_z(op, cm, i, j + moff)); }
     vnext[c] = out;
     cls = vv_cls_x(op, i, j, moff, s);
-    out = 0.0;
+    out = T(0);
     if (cls != VV_ZERO) {
         const int cm = c + moff;
         const int im = i + (moff > 0 ? 1 : (moff < 0 ? -1 : 0));
@@ -183,8 +199,9 @@ __device__ inline void cheb_first_node(const PlVvOp& op, const double* __restric
     (vnext + P)[c] = out;
 }
 
-__global__ __launch_bounds__(256) void k_vv_cheb_first(PlVvOp op, const double* __restrict__ f, double* __restrict__ vnext,
-                                                       double c2, int iters) {
+template <typename T>
+__global__ __launch_bounds__(256) void k_vv_cheb_first(PlVvOpT<T> op, const T* __restrict__ f, T* __restrict__ vnext,
+                                                       T c2, int iters) {
     PL_ROW_LOOP(op.g, iters)
         cheb_first_node(op, f, vnext, c2, op.g.gi0 + li, op.g.gj0 + lj, pl_idx(op.g, li, lj));
 }
@@ -192,29 +209,32 @@ __global__ __launch_bounds__(256) void k_vv_cheb_first(PlVvOp op, const double* 
 #ifndef PL_CHEB_WAVES
 #define PL_CHEB_WAVES 4
 #endif
-__global__ __launch_bounds__(256, PL_CHEB_WAVES) void k_vv_cheb(PlVvOp op, const double* __restrict__ vcur,
-                                                 const double* __restrict__ vprev, const double* __restrict__ f,
-                                                 double* __restrict__ vnext, double c1, double c2, int iters) {
+template <typename T, typename TO>
+__global__ __launch_bounds__(256, PL_CHEB_WAVES) void k_vv_cheb(PlVvOpT<T> op, const T* __restrict__ vcur,
+                                                 const T* __restrict__ vprev, const T* __restrict__ f,
+                                                 TO* __restrict__ vnext, T c1, T c2, int iters, TO oscale) {
     PL_ROW_LOOP(op.g, iters)
-        cheb_node(op, vcur, vprev, f, vnext, c1, c2, op.g.gi0 + li, op.g.gj0 + lj, pl_idx(op.g, li, lj));
+        cheb_node(op, vcur, vprev, f, vnext, c1, c2, op.g.gi0 + li, op.g.gj0 + lj, pl_idx(op.g, li, lj), oscale);
 }
 
 // r = f - A v on interior rows, 0 elsewhere
 // (f and r may alias: every thread reads only its own f entries before writing r)
-__device__ inline void residual_node(const PlVvOp& op, const double* __restrict__ v, const double* f, double* r, int i,
+template <typename T>
+__device__ inline void residual_node(const PlVvOpT<T>& op, const T* __restrict__ v, const T* f, T* r, int i,
                                      int j, long long c64) {
     const long long P = op.g.plane;
     const int c = (int)c64;
-    const double* fx = f + P; double* rx_ = r + P;
-    int moff; double s, Av, dg;
-    double rz = 0.0, rx = 0.0;
+    const T* fx = f + P; T* rx_ = r + P;
+    int moff; T s, Av, dg;
+    T rz = T(0), rx = T(0);
     if (vv_cls_z(op, i, j, moff, s) == VV_INT) { vv_row_z(op, v, v + P, c, i, j, Av, dg); rz = f[c] - Av; }
     if (vv_cls_x(op, i, j, moff, s) == VV_INT) { vv_row_x(op, v, v + P, c, i, j, Av, dg); rx = fx[c] - Av; }
     r[c] = rz; rx_[c] = rx;
 }
 
-__global__ __launch_bounds__(256) void k_vv_residual(PlVvOp op, const double* __restrict__ v, const double* f,
-                                                     double* r, int iters) {
+template <typename T>
+__global__ __launch_bounds__(256) void k_vv_residual(PlVvOpT<T> op, const T* __restrict__ v, const T* f,
+                                                     T* r, int iters) {
     PL_ROW_LOOP(op.g, iters)
         residual_node(op, v, f, r, op.g.gi0 + li, op.g.gj0 + lj, pl_idx(op.g, li, lj));
 }
@@ -222,36 +242,39 @@ __global__ __launch_bounds__(256) void k_vv_residual(PlVvOp op, const double* __
 // ---------------------------------------------------------------------------------------------------
 // Two-columns-per-lane sweep (same reasoning as k_stokes_apply_v2: the scalar kernels keep the texture
 // address unit busy 88 % of the time).  MODE 0: Chebyshev sweep, MODE 1: residual.  A wave covers 128
-// columns of one row with double2 loads; west/east neighbours come from the adjacent lanes.  The two
+// columns of one row with 2-element vector loads; west/east neighbours come from the adjacent lanes.  The two
 // wall-adjacent rows (vx slaved or zero) and the two slaved vz columns take the scalar path.
+template <typename T>
 struct VvVals {
-    double vz_c, vz_w, vz_e, vz_n, vz_s, vz_nw;
-    double vx_c, vx_w, vx_e, vx_n, vx_s, vx_se;
-    double en_c, en_w, en_s, es_c, es_e, es_n;
-    double rdx_j, rdx_m, rDx_j, rDx_p;
+    T vz_c, vz_w, vz_e, vz_n, vz_s, vz_nw;
+    T vx_c, vx_w, vx_e, vx_n, vx_s, vx_se;
+    T en_c, en_w, en_s, es_c, es_e, es_n;
+    T rdx_j, rdx_m, rDx_j, rDx_p;
 };
 // Row-only products are shared by the lane's two columns, every viscosity is multiplied once (the arithmetic
 // of these sweeps is not hidden behind the memory traffic: FP64 issues at half rate on CDNA4).
-struct VvRowK { double Az, Azm, rDz_i, rDz_p, r2; };
-template <bool NEED_D>
-__device__ inline void vv_rows_vals(const VvVals& q, const VvRowK& k, double& Az, double& dz, double& Ax, double& dx) {
-    const double k2 = 2.0 * q.rdx_j;
-    const double tE = q.es_e * k2, tW = q.es_c * k2;
-    const double cN = q.en_c * k.Az, cS = q.en_s * k.Azm, cE = tE * q.rDx_p, cW = tW * q.rDx_j;
+template <typename T> struct VvRowK { T Az, Azm, rDz_i, rDz_p, r2; };
+template <bool NEED_D, typename T>
+__device__ inline void vv_rows_vals(const VvVals<T>& q, const VvRowK<T>& k, T& Az, T& dz, T& Ax, T& dx) {
+    const T k2 = T(2) * q.rdx_j;
+    const T tE = q.es_e * k2, tW = q.es_c * k2;
+    const T cN = q.en_c * k.Az, cS = q.en_s * k.Azm, cE = tE * q.rDx_p, cW = tW * q.rDx_j;
     Az = cN * (q.vz_n - q.vz_c) - cS * (q.vz_c - q.vz_s) + cE * (q.vz_e - q.vz_c) - cW * (q.vz_c - q.vz_w) +
          (tE * k.rDz_i) * (q.vx_e - q.vx_se) - (tW * k.rDz_i) * (q.vx_c - q.vx_s);
     if (NEED_D) dz = cN + cS + cE + cW;
-    const double B4 = 4.0 * q.rDx_j;
-    const double uN = q.es_n * k.r2, uS = q.es_c * k.r2;
-    const double dE = q.en_c * (B4 * q.rdx_j), dW = q.en_w * (B4 * q.rdx_m), dN = uN * k.rDz_p, dS = uS * k.rDz_i;
+    const T B4 = T(4) * q.rDx_j;
+    const T uN = q.es_n * k.r2, uS = q.es_c * k.r2;
+    const T dE = q.en_c * (B4 * q.rdx_j), dW = q.en_w * (B4 * q.rdx_m), dN = uN * k.rDz_p, dS = uS * k.rDz_i;
     Ax = dE * (q.vx_e - q.vx_c) - dW * (q.vx_c - q.vx_w) + dN * (q.vx_n - q.vx_c) - dS * (q.vx_c - q.vx_s) +
          (uN * q.rDx_j) * (q.vz_n - q.vz_nw) - (uS * q.rDx_j) * (q.vz_c - q.vz_w);
     if (NEED_D) dx = dE + dW + dN + dS;
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void k_vv_sweep2(PlVvOp op, const double* __restrict__ vcur, const double* __restrict__ vprev,
-                                                   const double* f, double* out, double c1, double c2) {
+template <int MODE, typename T, typename TO>
+__global__ __launch_bounds__(256) void k_vv_sweep2(PlVvOpT<T> op, const T* __restrict__ vcur, const T* __restrict__ vprev,
+                                                   const T* f, TO* out, T c1, T c2, TO oscale) {
+    typedef typename PlVec2<T>::type V2;
+    typedef typename PlVec2<TO>::type VO2;
     const PlGeom& g = op.g;
     const int lane = threadIdx.x;
     const int lj0 = (blockIdx.x * 64 + lane) * 2;
@@ -266,35 +289,35 @@ __global__ __launch_bounds__(256) void k_vv_sweep2(PlVvOp op, const double* __re
     if (i <= 0 || i >= nz - 2) {                            // wall rows and the slaved vx rows (wave-uniform)
         if (!active) return;
         for (int q = 0; q < 2 && lj0 + q < g.lnx; q++) {
-            if (MODE == 0) cheb_node(op, vcur, vprev, f, out, c1, c2, i, j0 + q, c + q);
+            if constexpr (MODE == 0) cheb_node(op, vcur, vprev, f, out, c1, c2, i, j0 + q, c + q, oscale);
             else residual_node(op, vcur, f, out, i, j0 + q, c + q);
         }
         return;
     }
-    const double* __restrict__ vz = vcur;
-    const double* __restrict__ vx = vcur + PLN;
+    const T* __restrict__ vz = vcur;
+    const T* __restrict__ vx = vcur + PLN;
 #define ROW(ptr, dr, w, e) load_row2((ptr) + (long long)c - lj0 + (long long)(dr) * p, lj0, active, w, e, lane, has_right)
-    const Row2 vz_s = ROW(vz, -1, false, false), vz_i = ROW(vz, 0, true, true), vz_n = ROW(vz, 1, true, false);
-    const Row2 vx_s = ROW(vx, -1, false, true), vx_i = ROW(vx, 0, true, true), vx_n = ROW(vx, 1, false, false);
-    const Row2 en_s = ROW(op.etan, -1, false, false), en_i = ROW(op.etan, 0, true, false);
-    const Row2 es_i = ROW(op.etas, 0, false, true), es_n = ROW(op.etas, 1, false, false);
+    const Row2T<T> vz_s = ROW(vz, -1, false, false), vz_i = ROW(vz, 0, true, true), vz_n = ROW(vz, 1, true, false);
+    const Row2T<T> vx_s = ROW(vx, -1, false, true), vx_i = ROW(vx, 0, true, true), vx_n = ROW(vx, 1, false, false);
+    const Row2T<T> en_s = ROW(op.etan, -1, false, false), en_i = ROW(op.etan, 0, true, false);
+    const Row2T<T> es_i = ROW(op.etas, 0, false, true), es_n = ROW(op.etas, 1, false, false);
 #undef ROW
-    const Row2 t_rdx = load_row2(g.rdx + PL_TOFF + g.gj0, lj0, active, true, false, lane, has_right);
-    const Row2 t_rDx = load_row2(g.rDx + PL_TOFF + g.gj0, lj0, active, false, true, lane, has_right);
+    const Row2T<T> t_rdx = load_row2(op.rdx + PL_TOFF + g.gj0, lj0, active, true, false, lane, has_right);
+    const Row2T<T> t_rDx = load_row2(op.rDx + PL_TOFF + g.gj0, lj0, active, false, true, lane, has_right);
     if (!active) return;
     const bool colB = (lj0 + 1) < g.lnx;
-    const double2 fz = *reinterpret_cast<const double2*>(f + c), fx = *reinterpret_cast<const double2*>(f + PLN + c);
-    double2 pz = make_double2(0.0, 0.0), px = pz;
-    if (MODE == 0 && c1 != 0.0 && vprev) {
-        pz = *reinterpret_cast<const double2*>(vprev + c); px = *reinterpret_cast<const double2*>(vprev + PLN + c);
+    const V2 fz = *reinterpret_cast<const V2*>(f + c), fx = *reinterpret_cast<const V2*>(f + PLN + c);
+    V2 pz = PlVec2<T>::make(T(0), T(0)), px = pz;
+    if (MODE == 0 && c1 != T(0) && vprev) {
+        pz = *reinterpret_cast<const V2*>(vprev + c); px = *reinterpret_cast<const V2*>(vprev + PLN + c);
     }
-    VvRowK rk;
+    VvRowK<T> rk;
     {
-        const double rdz_i = TB(g.rdz, i), rdz_m = TB(g.rdz, i - 1), rDz_i = TB(g.rDz, i);
-        rk.Az = 4.0 * rdz_i * rDz_i; rk.Azm = 4.0 * rdz_m * rDz_i; rk.rDz_i = rDz_i; rk.rDz_p = TB(g.rDz, i + 1); rk.r2 = 2.0 * rdz_i;
+        const T rdz_i = TB(op.rdz, i), rdz_m = TB(op.rdz, i - 1), rDz_i = TB(op.rDz, i);
+        rk.Az = T(4) * rdz_i * rDz_i; rk.Azm = T(4) * rdz_m * rDz_i; rk.rDz_i = rDz_i; rk.rDz_p = TB(op.rDz, i + 1); rk.r2 = T(2) * rdz_i;
     }
-    VvVals q;
-    double Az[2], dz[2] = {1.0, 1.0}, Ax[2], dx[2] = {1.0, 1.0};
+    VvVals<T> q;
+    T Az[2], dz[2] = {T(1), T(1)}, Ax[2], dx[2] = {T(1), T(1)};
     q.vz_c = vz_i.v.x; q.vz_w = vz_i.w; q.vz_e = vz_i.v.y; q.vz_n = vz_n.v.x; q.vz_s = vz_s.v.x; q.vz_nw = vz_n.w;
     q.vx_c = vx_i.v.x; q.vx_w = vx_i.w; q.vx_e = vx_i.v.y; q.vx_n = vx_n.v.x; q.vx_s = vx_s.v.x; q.vx_se = vx_s.v.y;
     q.en_c = en_i.v.x; q.en_w = en_i.w; q.en_s = en_s.v.x;
@@ -307,29 +330,29 @@ __global__ __launch_bounds__(256) void k_vv_sweep2(PlVvOp op, const double* __re
     q.es_c = es_i.v.y; q.es_e = es_i.e; q.es_n = es_n.v.y;
     q.rdx_j = t_rdx.v.y; q.rdx_m = t_rdx.v.x; q.rDx_j = t_rDx.v.y; q.rDx_p = t_rDx.e;
     vv_rows_vals<MODE == 0>(q, rk, Az[1], dz[1], Ax[1], dx[1]);
-    const double v0z[2] = {vz_i.v.x, vz_i.v.y}, v0x[2] = {vx_i.v.x, vx_i.v.y};
+    const T v0z[2] = {vz_i.v.x, vz_i.v.y}, v0x[2] = {vx_i.v.x, vx_i.v.y};
     if (op.szz) {                                                   // wave-uniform
-        const double2 sd = *reinterpret_cast<const double2*>(op.szz + c), sx = *reinterpret_cast<const double2*>(op.szx + c);
+        const V2 sd = *reinterpret_cast<const V2*>(op.szz + c), sx = *reinterpret_cast<const V2*>(op.szx + c);
         Az[0] += sd.x * v0z[0] + sx.x * v0x[0]; dz[0] = vv_stab_diag(dz[0], sd.x);
         Az[1] += sd.y * v0z[1] + sx.y * v0x[1]; dz[1] = vv_stab_diag(dz[1], sd.y);
     }
-    const double fzv[2] = {fz.x, fz.y}, fxv[2] = {fx.x, fx.y}, pzv[2] = {pz.x, pz.y}, pxv[2] = {px.x, px.y};
-    double oz[2], ox[2];
+    const T fzv[2] = {fz.x, fz.y}, fxv[2] = {fx.x, fx.y}, pzv[2] = {pz.x, pz.y}, pxv[2] = {px.x, px.y};
+    T oz[2], ox[2];
     // wave-uniform: all 128 columns are interior in both components (no slaves, no zero rows): straight-line code
     const int jw = g.gj0 + blockIdx.x * 128;
     if (jw >= 1 && jw + 127 <= nx - 3) {
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             if (MODE == 0) {
-                const double mz = c1 * (v0z[k] - pzv[k]), mx = c1 * (v0x[k] - pxv[k]);      // c1 = 0 on the first sweep
+                const T mz = c1 * (v0z[k] - pzv[k]), mx = c1 * (v0x[k] - pxv[k]);      // c1 = 0 on the first sweep
                 oz[k] = v0z[k] + mz + (c2 * (Az[k] - fzv[k])) * pl_rcp(dz[k]);
                 ox[k] = v0x[k] + mx + (c2 * (Ax[k] - fxv[k])) * pl_rcp(dx[k]);
             } else {
                 oz[k] = fzv[k] - Az[k]; ox[k] = fxv[k] - Ax[k];
             }
         }
-        *reinterpret_cast<double2*>(out + c) = make_double2(oz[0], oz[1]);
-        *reinterpret_cast<double2*>(out + PLN + c) = make_double2(ox[0], ox[1]);
+        *reinterpret_cast<VO2*>(out + c) = PlVec2<TO>::make((TO)oz[0] * oscale, (TO)oz[1] * oscale);
+        *reinterpret_cast<VO2*>(out + PLN + c) = PlVec2<TO>::make((TO)ox[0] * oscale, (TO)ox[1] * oscale);
         return;
     }
 #pragma unroll
@@ -338,20 +361,20 @@ __global__ __launch_bounds__(256) void k_vv_sweep2(PlVvOp op, const double* __re
         const bool zslave = op.slave_x && (j == 0 || j == nx - 2);
         const bool zint = j < nx - 1 && !zslave, xint = j > 0 && j < nx - 1;
         if (MODE == 0) {
-            const double mz = (c1 != 0.0) ? c1 * (v0z[k] - pzv[k]) : 0.0, mx = (c1 != 0.0) ? c1 * (v0x[k] - pxv[k]) : 0.0;
-            oz[k] = zint ? v0z[k] + mz + (c2 * (Az[k] - fzv[k])) * pl_rcp(dz[k]) : 0.0;
-            ox[k] = xint ? v0x[k] + mx + (c2 * (Ax[k] - fxv[k])) * pl_rcp(dx[k]) : 0.0;
+            const T mz = (c1 != T(0)) ? c1 * (v0z[k] - pzv[k]) : T(0), mx = (c1 != T(0)) ? c1 * (v0x[k] - pxv[k]) : T(0);
+            oz[k] = zint ? v0z[k] + mz + (c2 * (Az[k] - fzv[k])) * pl_rcp(dz[k]) : T(0);
+            ox[k] = xint ? v0x[k] + mx + (c2 * (Ax[k] - fxv[k])) * pl_rcp(dx[k]) : T(0);
             if (zslave && (k == 0 || colB)) oz[k] = cheb_val_z(op, vcur, vprev, f, c1, c2, i, j, c + k);
         } else {
-            oz[k] = zint ? fzv[k] - Az[k] : 0.0;
-            ox[k] = xint ? fxv[k] - Ax[k] : 0.0;
+            oz[k] = zint ? fzv[k] - Az[k] : T(0);
+            ox[k] = xint ? fxv[k] - Ax[k] : T(0);
         }
     }
     if (colB) {
-        *reinterpret_cast<double2*>(out + c) = make_double2(oz[0], oz[1]);
-        *reinterpret_cast<double2*>(out + PLN + c) = make_double2(ox[0], ox[1]);
+        *reinterpret_cast<VO2*>(out + c) = PlVec2<TO>::make((TO)oz[0] * oscale, (TO)oz[1] * oscale);
+        *reinterpret_cast<VO2*>(out + PLN + c) = PlVec2<TO>::make((TO)ox[0] * oscale, (TO)ox[1] * oscale);
     } else {
-        out[c] = oz[0]; out[PLN + c] = ox[0];
+        out[c] = (TO)oz[0] * oscale; out[PLN + c] = (TO)ox[0] * oscale;
     }
 }
 
@@ -362,8 +385,10 @@ __device__ inline bool stage1_fast_wave(const PlGeom& g, int i, int jw, int bx, 
 }
 // First sweep from the zero guess, two columns per lane (see cheb_first_node): v1 = -c2 f / diag.
 // only_slow != 0: stage 1 has already written the waves it treats as interior (stage1_fast_wave); do the others only
-__global__ __launch_bounds__(256) void k_vv_first2(PlVvOp op, const double* __restrict__ f, double* __restrict__ out, double c2,
-                                                   int only_slow = 0, int anchor_i = -9, int anchor_j = -9) {
+template <typename T>
+__global__ __launch_bounds__(256) void k_vv_first2(PlVvOpT<T> op, const T* __restrict__ f, T* __restrict__ out, T c2,
+                                                   int only_slow, int anchor_i, int anchor_j) {
+    typedef typename PlVec2<T>::type V2;
     const PlGeom& g = op.g;
     const int lane = threadIdx.x;
     const int lj0 = (blockIdx.x * 64 + lane) * 2;
@@ -384,29 +409,29 @@ __global__ __launch_bounds__(256) void k_vv_first2(PlVvOp op, const double* __re
         return;
     }
 #define ROW(ptr, dr, w, e) load_row2((ptr) + (long long)c - lj0 + (long long)(dr) * p, lj0, true, w, e, lane, has_right)
-    const Row2 en_s = ROW(op.etan, -1, false, false), en_i = ROW(op.etan, 0, true, false);
-    const Row2 es_i = ROW(op.etas, 0, false, true), es_n = ROW(op.etas, 1, false, false);
+    const Row2T<T> en_s = ROW(op.etan, -1, false, false), en_i = ROW(op.etan, 0, true, false);
+    const Row2T<T> es_i = ROW(op.etas, 0, false, true), es_n = ROW(op.etas, 1, false, false);
 #undef ROW
-    const Row2 t_rdx = load_row2(g.rdx + PL_TOFF + g.gj0, lj0, true, true, false, lane, has_right);
-    const Row2 t_rDx = load_row2(g.rDx + PL_TOFF + g.gj0, lj0, true, false, true, lane, has_right);
-    const double2 fz = *reinterpret_cast<const double2*>(f + c), fx = *reinterpret_cast<const double2*>(f + PLN + c);
-    const double rdz_i = TB(g.rdz, i), rdz_m = TB(g.rdz, i - 1), rDz_i = TB(g.rDz, i), rDz_p = TB(g.rDz, i + 1);
-    const double Az = 4.0 * rdz_i * rDz_i, Azm = 4.0 * rdz_m * rDz_i, r2 = 2.0 * rdz_i, nc2 = -c2;
-    double oz[2], ox[2];
+    const Row2T<T> t_rdx = load_row2(op.rdx + PL_TOFF + g.gj0, lj0, true, true, false, lane, has_right);
+    const Row2T<T> t_rDx = load_row2(op.rDx + PL_TOFF + g.gj0, lj0, true, false, true, lane, has_right);
+    const V2 fz = *reinterpret_cast<const V2*>(f + c), fx = *reinterpret_cast<const V2*>(f + PLN + c);
+    const T rdz_i = TB(op.rdz, i), rdz_m = TB(op.rdz, i - 1), rDz_i = TB(op.rDz, i), rDz_p = TB(op.rDz, i + 1);
+    const T Az = T(4) * rdz_i * rDz_i, Azm = T(4) * rdz_m * rDz_i, r2 = T(2) * rdz_i, nc2 = -c2;
+    T oz[2], ox[2];
     {   // column A
-        const double rdx_j = t_rdx.v.x, rdx_m = t_rdx.w, rDx_j = t_rDx.v.x, rDx_p = t_rDx.v.y, k2 = 2.0 * rdx_j, B4 = 4.0 * rDx_j;
-        const double dz = en_i.v.x * Az + en_s.v.x * Azm + (es_i.v.y * k2) * rDx_p + (es_i.v.x * k2) * rDx_j;
-        const double dx = en_i.v.x * (B4 * rdx_j) + en_i.w * (B4 * rdx_m) + (es_n.v.x * r2) * rDz_p + (es_i.v.x * r2) * rDz_i;
+        const T rdx_j = t_rdx.v.x, rdx_m = t_rdx.w, rDx_j = t_rDx.v.x, rDx_p = t_rDx.v.y, k2 = T(2) * rdx_j, B4 = T(4) * rDx_j;
+        const T dz = en_i.v.x * Az + en_s.v.x * Azm + (es_i.v.y * k2) * rDx_p + (es_i.v.x * k2) * rDx_j;
+        const T dx = en_i.v.x * (B4 * rdx_j) + en_i.w * (B4 * rdx_m) + (es_n.v.x * r2) * rDz_p + (es_i.v.x * r2) * rDz_i;
         oz[0] = (nc2 * fz.x) * pl_rcp(dz); ox[0] = (nc2 * fx.x) * pl_rcp(dx);
     }
     {   // column B
-        const double rdx_j = t_rdx.v.y, rdx_m = t_rdx.v.x, rDx_j = t_rDx.v.y, rDx_p = t_rDx.e, k2 = 2.0 * rdx_j, B4 = 4.0 * rDx_j;
-        const double dz = en_i.v.y * Az + en_s.v.y * Azm + (es_i.e * k2) * rDx_p + (es_i.v.y * k2) * rDx_j;
-        const double dx = en_i.v.y * (B4 * rdx_j) + en_i.v.x * (B4 * rdx_m) + (es_n.v.y * r2) * rDz_p + (es_i.v.y * r2) * rDz_i;
+        const T rdx_j = t_rdx.v.y, rdx_m = t_rdx.v.x, rDx_j = t_rDx.v.y, rDx_p = t_rDx.e, k2 = T(2) * rdx_j, B4 = T(4) * rDx_j;
+        const T dz = en_i.v.y * Az + en_s.v.y * Azm + (es_i.e * k2) * rDx_p + (es_i.v.y * k2) * rDx_j;
+        const T dx = en_i.v.y * (B4 * rdx_j) + en_i.v.x * (B4 * rdx_m) + (es_n.v.y * r2) * rDz_p + (es_i.v.y * r2) * rDz_i;
         oz[1] = (nc2 * fz.y) * pl_rcp(dz); ox[1] = (nc2 * fx.y) * pl_rcp(dx);
     }
-    *reinterpret_cast<double2*>(out + c) = make_double2(oz[0], oz[1]);
-    *reinterpret_cast<double2*>(out + PLN + c) = make_double2(ox[0], ox[1]);
+    *reinterpret_cast<V2*>(out + c) = PlVec2<T>::make(oz[0], oz[1]);
+    *reinterpret_cast<V2*>(out + PLN + c) = PlVec2<T>::make(ox[0], ox[1]);
 }
 
 static inline dim3 pl_grid_rows2(const PlGeom& g) { return dim3((g.lnx + 127) / 128, (g.lnz + 3) / 4); }
@@ -432,14 +457,17 @@ __global__ __launch_bounds__(256) void k_vv_dinv_apply(PlVvOp op, const double* 
 
 // Full-weighting restriction of the velocity residual (uniform-grid weights):
 // vz is vertex-centred in z [1/4,1/2,1/4] and cell-centred in x [1/8,3/8,3/8,1/8]; vx mirrored.
-__device__ inline void restrict_node(const PlGeom& gf, const PlVvOp& opc, const double* __restrict__ rf,
-                                     double* __restrict__ fc, int i, int j, long long c) {
-    int moff; double s;
+// TF / TC: types of the fine residual and of the coarse right-hand side (an FP32 level above an FP64 one converts here)
+// cscale: 1, or sigma where an FP32 level (operator A/sigma) hands its residual to an FP64 one (operator A)
+template <typename TF, typename TC>
+__device__ inline void restrict_node(const PlGeom& gf, const PlVvOpT<TC>& opc, const TF* __restrict__ rf,
+                                     TC* __restrict__ fc, int i, int j, long long c, TC cscale = TC(1)) {
+    int moff; TC s;
     const int pf = gf.pitch;
-    double oz = 0.0, ox = 0.0;
+    TF oz = TF(0), ox = TF(0);
     if (vv_cls_z(opc, i, j, moff, s) == VV_INT) {
         const long long b = pl_idx(gf, 2 * i - gf.gi0, 2 * j - gf.gj0);
-        const double wz[3] = {0.25, 0.5, 0.25}, wx[4] = {0.125, 0.375, 0.375, 0.125};
+        const TF wz[3] = {TF(0.25), TF(0.5), TF(0.25)}, wx[4] = {TF(0.125), TF(0.375), TF(0.375), TF(0.125)};
 #pragma unroll
         for (int a = 0; a < 3; a++)
 #pragma unroll
@@ -447,63 +475,68 @@ __device__ inline void restrict_node(const PlGeom& gf, const PlVvOp& opc, const 
     }
     if (vv_cls_x(opc, i, j, moff, s) == VV_INT) {
         const long long b = pl_idx(gf, 2 * i - gf.gi0, 2 * j - gf.gj0) + gf.plane;
-        const double wz[4] = {0.125, 0.375, 0.375, 0.125}, wx[3] = {0.25, 0.5, 0.25};
+        const TF wz[4] = {TF(0.125), TF(0.375), TF(0.375), TF(0.125)}, wx[3] = {TF(0.25), TF(0.5), TF(0.25)};
 #pragma unroll
         for (int a = 0; a < 4; a++)
 #pragma unroll
             for (int q = 0; q < 3; q++) ox += wz[a] * wx[q] * rf[b + (long long)(a - 1) * pf + (q - 1)];
     }
-    fc[c] = oz; fc[c + opc.g.plane] = ox;
+    fc[c] = (TC)oz * cscale; fc[c + opc.g.plane] = (TC)ox * cscale;
 }
 
-__global__ __launch_bounds__(256) void k_vv_restrict(PlGeom gf, PlVvOp opc, const double* __restrict__ rf,
-                                                     double* __restrict__ fc) {
+template <typename TF, typename TC>
+__global__ __launch_bounds__(256) void k_vv_restrict(PlGeom gf, PlVvOpT<TC> opc, const TF* __restrict__ rf,
+                                                     TC* __restrict__ fc, TC cscale) {
     PL_NODE_PROLOGUE(opc.g)
-    restrict_node(gf, opc, rf, fc, i, j, c);
+    restrict_node(gf, opc, rf, fc, i, j, c, cscale);
 }
 
 // (P e)(i,j) for vz / vx on the fine grid from the coarse correction e (bilinear; mirror clamp)
-__device__ inline double prolong_z_at(const PlGeom& gc, const double* __restrict__ ez, int i, int j) {
+template <typename TC>
+__device__ inline TC prolong_z_at(const PlGeom& gc, const TC* __restrict__ ez, int i, int j) {
     const int I0 = i >> 1, I1 = (i + 1) >> 1;
     int Jn = j >> 1, Jo = (j & 1) ? Jn + 1 : Jn - 1;
     const int jmax = gc.nx - 2;
     Jn = min(max(Jn, 0), jmax); Jo = min(max(Jo, 0), jmax);
     const int o0 = gc.gi0, o1 = gc.gj0;            // coarse indices are global; the block may be a slab
-    const double a = 0.5 * (ez[pl_idx(gc, I0 - o0, Jn - o1)] + ez[pl_idx(gc, I1 - o0, Jn - o1)]);
-    const double b = 0.5 * (ez[pl_idx(gc, I0 - o0, Jo - o1)] + ez[pl_idx(gc, I1 - o0, Jo - o1)]);
-    return 0.75 * a + 0.25 * b;
+    const TC a = TC(0.5) * (ez[pl_idx(gc, I0 - o0, Jn - o1)] + ez[pl_idx(gc, I1 - o0, Jn - o1)]);
+    const TC b = TC(0.5) * (ez[pl_idx(gc, I0 - o0, Jo - o1)] + ez[pl_idx(gc, I1 - o0, Jo - o1)]);
+    return TC(0.75) * a + TC(0.25) * b;
 }
 
-__device__ inline double prolong_x_at(const PlGeom& gc, const double* __restrict__ ex, int i, int j) {
+template <typename TC>
+__device__ inline TC prolong_x_at(const PlGeom& gc, const TC* __restrict__ ex, int i, int j) {
     const int J0 = j >> 1, J1 = (j + 1) >> 1;
     int In = i >> 1, Io = (i & 1) ? In + 1 : In - 1;
     const int imax = gc.nz - 2;
     In = min(max(In, 0), imax); Io = min(max(Io, 0), imax);
     const int o0 = gc.gi0, o1 = gc.gj0;
-    const double a = 0.5 * (ex[pl_idx(gc, In - o0, J0 - o1)] + ex[pl_idx(gc, In - o0, J1 - o1)]);
-    const double b = 0.5 * (ex[pl_idx(gc, Io - o0, J0 - o1)] + ex[pl_idx(gc, Io - o0, J1 - o1)]);
-    return 0.75 * a + 0.25 * b;
+    const TC a = TC(0.5) * (ex[pl_idx(gc, In - o0, J0 - o1)] + ex[pl_idx(gc, In - o0, J1 - o1)]);
+    const TC b = TC(0.5) * (ex[pl_idx(gc, Io - o0, J0 - o1)] + ex[pl_idx(gc, Io - o0, J1 - o1)]);
+    return TC(0.75) * a + TC(0.25) * b;
 }
 
-__device__ inline void prolong_node(const PlVvOp& opf, const PlGeom& gc, const double* __restrict__ ec,
-                                    const double* __restrict__ vin, double* __restrict__ vout, int i, int j, long long c) {
+template <typename TF, typename TC>
+__device__ inline void prolong_node(const PlVvOpT<TF>& opf, const PlGeom& gc, const TC* __restrict__ ec,
+                                    const TF* __restrict__ vin, TF* __restrict__ vout, int i, int j, long long c) {
     const long long P = opf.g.plane;
-    int moff = 0; double s = 1.0;
+    int moff = 0; TF s = TF(1);
     int cls = vv_cls_z(opf, i, j, moff, s);
-    double o = 0.0;
-    if (cls != VV_ZERO) o = s * (vin[c + moff] + prolong_z_at(gc, ec, i, j + moff));
+    TF o = TF(0);
+    if (cls != VV_ZERO) o = s * (vin[c + moff] + (TF)prolong_z_at(gc, ec, i, j + moff));
     vout[c] = o;
     cls = vv_cls_x(opf, i, j, moff, s);
-    o = 0.0;
+    o = TF(0);
     if (cls != VV_ZERO) {
         const int im = i + (moff > 0 ? 1 : (moff < 0 ? -1 : 0));
-        o = s * (vin[c + moff + P] + prolong_x_at(gc, ec + gc.plane, im, j));
+        o = s * (vin[c + moff + P] + (TF)prolong_x_at(gc, ec + gc.plane, im, j));
     }
     vout[c + P] = o;
 }
 
-__global__ __launch_bounds__(256) void k_vv_prolong_add(PlVvOp opf, PlGeom gc, const double* __restrict__ ec,
-                                                        const double* __restrict__ vin, double* __restrict__ vout) {
+template <typename TF, typename TC>
+__global__ __launch_bounds__(256) void k_vv_prolong_add(PlVvOpT<TF> opf, PlGeom gc, const TC* __restrict__ ec,
+                                                        const TF* __restrict__ vin, TF* __restrict__ vout) {
     PL_NODE_PROLOGUE(opf.g)
     prolong_node(opf, gc, ec, vin, vout, i, j, c);
 }
@@ -849,15 +882,17 @@ __device__ inline double prec_p_value(const PlStokesOp& op, const double* __rest
 // Constraint-row residuals are NOT lifted: inside the Krylov iteration they are identically zero,
 // because x0 is closed with k_close_constraints and every preconditioned direction satisfies the
 // homogeneous wall/slave rows, so (A y)_constraint = 0 for all iterates.
-__device__ inline void stage1_node(const PlStokesOp& op, const PlVvOp& vop, const double* __restrict__ rs,
-                                   double* __restrict__ z, double* __restrict__ f, int li, int lj) {
+// TF: type of the velocity right-hand side f (float on an FP32 level 0: f is written times fscale, see stokes_precond)
+template <typename TF>
+__device__ inline void stage1_node(const PlStokesOp& op, const PlVvOpT<TF>& vop, const double* __restrict__ rs,
+                                   double* __restrict__ z, TF* __restrict__ f, int li, int lj, double fscale) {
     const int i = op.g.gi0 + li, j = op.g.gj0 + lj;
     const long long c = pl_idx(op.g, li, lj);
     const long long P = op.g.plane;
     const int p = op.g.pitch;
     const double* rs_p = rs + 2 * P;
     const double zp_c = prec_p_value(op, rs_p, i, j, c);
-    int moff; double s;
+    int moff; TF s;
     double fz = 0.0, fx = 0.0;
     // un-scaling an interior momentum row = multiplying by the sum of its 4 own-component coefficients
     if (vv_cls_z(vop, i, j, moff, s) == VV_INT) {
@@ -876,20 +911,25 @@ __device__ inline void stage1_node(const PlStokesOp& op, const PlVvOp& vop, cons
                            2.0 * op.etas[c + p] * rDz_p * rdz_i + 2.0 * op.etas[c] * rDz_i * rdz_i;
         fx = rs[c + P] * sum + 2.0 * op.Kc * rDx_j * (zp_c - prec_p_value(op, rs_p, i, j - 1, c - 1));
     }
-    f[c] = fz; f[c + P] = fx; z[c + 2 * P] = zp_c;
+    f[c] = (TF)(fz * fscale); f[c + P] = (TF)(fx * fscale); z[c + 2 * P] = zp_c;
 }
 
-__global__ __launch_bounds__(256) void k_prec_stage1(PlStokesOp op, PlVvOp vop, const double* __restrict__ rs,
-                                                     double* __restrict__ z, double* __restrict__ f, int iters) {
-    PL_ROW_LOOP(op.g, iters) stage1_node(op, vop, rs, z, f, li, lj);
+template <typename TF>
+__global__ __launch_bounds__(256) void k_prec_stage1(PlStokesOp op, PlVvOpT<TF> vop, const double* __restrict__ rs,
+                                                     double* __restrict__ z, TF* __restrict__ f, int iters, double fscale) {
+    PL_ROW_LOOP(op.g, iters) stage1_node(op, vop, rs, z, f, li, lj, fscale);
 }
 
 // Two columns per lane; interior waves run straight-line code, the others the per-node function above.
 // v1 != NULL: the first Chebyshev sweep of level 0 from the zero guess, v1 = -c2 f / diag, is written in the same pass (the
 // diagonal sums are the row scales this kernel computes anyway): the separate k_vv_first2 pass over f and the viscosities
 // is then only needed for the waves that take the per-node path here (k_vv_first2 with only_slow = 1).
-__global__ __launch_bounds__(256) void k_prec_stage1_v2(PlStokesOp op, PlVvOp vop, const double* __restrict__ rs,
-                                                        double* __restrict__ z, double* __restrict__ f, double* __restrict__ v1, double c2) {
+// TF = float (FP32 level 0): f is written times fscale and v1 times v1scale (stokes_precond explains the two factors)
+template <typename TF>
+__global__ __launch_bounds__(256) void k_prec_stage1_v2(PlStokesOp op, PlVvOpT<TF> vop, const double* __restrict__ rs,
+                                                        double* __restrict__ z, TF* __restrict__ f, TF* __restrict__ v1, double c2,
+                                                        double fscale, double v1scale) {
+    typedef typename PlVec2<TF>::type VF2;
     const PlGeom& g = op.g;
     const int lane = threadIdx.x;
     const int lj0 = (blockIdx.x * 64 + lane) * 2;
@@ -903,7 +943,7 @@ __global__ __launch_bounds__(256) void k_prec_stage1_v2(PlStokesOp op, PlVvOp vo
     const int jw = g.gj0 + blockIdx.x * 128;
     (void)nz; (void)nx;
     if (!stage1_fast_wave(g, i, jw, blockIdx.x, op.anchor_i, op.anchor_j)) {     // walls, slaves, anchor, or the wave sticks out of the block
-        for (int q = 0; q < 2 && lj0 + q < g.lnx; q++) stage1_node(op, vop, rs, z, f, li, lj0 + q);
+        for (int q = 0; q < 2 && lj0 + q < g.lnx; q++) stage1_node(op, vop, rs, z, f, li, lj0 + q, fscale);
         return;
     }
 #define ROW(ptr, dr, w, e) load_row2((ptr) + (long long)c - lj0 + (long long)(dr) * p, lj0, true, w, e, lane, has_right)
@@ -938,13 +978,13 @@ __global__ __launch_bounds__(256) void k_prec_stage1_v2(PlStokesOp op, PlVvOp vo
         fx[1] = rx.y * sx + (twoKc * rDx_j) * (zp[1] - zp[0]);
         dz[1] = sz; dx[1] = sx;
     }
-    *reinterpret_cast<double2*>(f + c) = make_double2(fz[0], fz[1]);
-    *reinterpret_cast<double2*>(f + PLN + c) = make_double2(fx[0], fx[1]);
+    *reinterpret_cast<VF2*>(f + c) = PlVec2<TF>::make((TF)(fz[0] * fscale), (TF)(fz[1] * fscale));
+    *reinterpret_cast<VF2*>(f + PLN + c) = PlVec2<TF>::make((TF)(fx[0] * fscale), (TF)(fx[1] * fscale));
     *reinterpret_cast<double2*>(z + 2 * PLN + c) = make_double2(zp[0], zp[1]);
     if (v1) {                                               // wave-uniform; same expressions as k_vv_first2's interior path
-        const double nc2 = -c2;
-        *reinterpret_cast<double2*>(v1 + c) = make_double2((nc2 * fz[0]) * pl_rcp(dz[0]), (nc2 * fz[1]) * pl_rcp(dz[1]));
-        *reinterpret_cast<double2*>(v1 + PLN + c) = make_double2((nc2 * fx[0]) * pl_rcp(dx[0]), (nc2 * fx[1]) * pl_rcp(dx[1]));
+        const double nc2 = -c2 * v1scale;
+        *reinterpret_cast<VF2*>(v1 + c) = PlVec2<TF>::make((TF)((nc2 * fz[0]) * pl_rcp(dz[0])), (TF)((nc2 * fz[1]) * pl_rcp(dz[1])));
+        *reinterpret_cast<VF2*>(v1 + PLN + c) = PlVec2<TF>::make((TF)((nc2 * fx[0]) * pl_rcp(dx[0])), (TF)((nc2 * fx[1]) * pl_rcp(dx[1])));
     }
 }
 
@@ -966,13 +1006,6 @@ __global__ __launch_bounds__(256) void k_close_constraints(PlStokesOp op, PlVvOp
         if (i == op.g.nz - 2 && op.bc_zL != PL_BC_FREESLIP) g0 /= (TB(op.g.rDz, op.g.nz - 2) + TB(op.g.rdz, op.g.nz - 2));
         x[c + P] = s * x[c + moff + P] + g0;
     }
-}
-
-// copy 2 velocity planes
-__global__ __launch_bounds__(256) void k_copy_vel(PlGeom g, const double* __restrict__ e, double* __restrict__ z) {
-    PL_NODE_PROLOGUE(g)
-    (void)i; (void)j;
-    z[c] = e[c]; z[c + g.plane] = e[c + g.plane];
 }
 
 // Hydrostatic pressure guess: with v = 0 the interior z-momentum rows reduce to
@@ -1038,7 +1071,27 @@ struct MgLevel {
     bool own_rho = false;
     double* v[3] = {nullptr, nullptr, nullptr};      // rotating Chebyshev buffers (2 planes each)
     double *f = nullptr, *r = nullptr;
+    double* fe = nullptr;        // early coarse branch: R^l f of the finest level (levels 1 .. early_K-1)
     double lmax = 3.0;
+    // FP32 twin (large levels only, see build_hierarchy): viscosity planes times 1/sigma, the 1-D tables, work planes
+    bool f32 = false;
+    PlVvOpF opf{};
+    float *etas_f = nullptr, *etan_f = nullptr, *tab_f = nullptr;
+    float* vf[3] = {nullptr, nullptr, nullptr};
+    float *ff = nullptr, *rf = nullptr;
+};
+template <typename T> struct LevelT;
+template <> struct LevelT<double> {
+    static const PlVvOp& op(const MgLevel* L) { return L->op; }
+    static double** v(MgLevel* L) { return L->v; }
+    static double* f(MgLevel* L) { return L->f; }
+    static double* r(MgLevel* L) { return L->r; }
+};
+template <> struct LevelT<float> {
+    static const PlVvOpF& op(const MgLevel* L) { return L->opf; }
+    static float** v(MgLevel* L) { return L->vf; }
+    static float* f(MgLevel* L) { return L->ff; }
+    static float* r(MgLevel* L) { return L->rf; }
 };
 
 struct PlSolver {
@@ -1066,6 +1119,14 @@ struct PlSolver {
     // transfer (identical numerics to one rank); 1 = once per level and direction; 0 = none (slab-local
     // smoothing with frozen zero halos; only the replicated coarse tail couples the slabs)
     int mg_halo = 2;
+    // FP32 multigrid levels: OFF by default (PYLAMP_MG_FP32=1 / pl_stokes_set_mg_precision switch them on;
+    // PYLAMP_MG_FP32_NODES: smallest level, in local nodes, that is worth it -- the smaller ones are launch-latency bound).
+    // Measured at 2049^2: the FP32 sweep takes 40 instead of 75 us, an iteration 1.79 instead of 2.08 ms -- but storing the
+    // smooth part of the iterate in FP32 puts high-frequency rounding noise of eps |v| into every preconditioned direction,
+    // which A amplifies by (L/h)^2 relative to the signal: eps (L/h)^2 = 0.25 at 2049^2, and BiCGStab needs 41-49 instead of
+    // 35-36 iterations (1025^2: 34-38 instead of 33).
+    bool f32_enable = false; long long f32_min_nodes = 200000;
+    double kappa = 1.0, sigma = 1.0;     // scaling of the FP32 velocity solve (stokes_precond)
     double schur_scale = 1.0;    // S^ = schur_scale * Kc^2 / eta_n (PYLAMP_SCHUR_SCALE)
     bool fuse_first = true;      // PYLAMP_FUSE_FIRST=0: the first sweep of level 0 as a pass of its own
     bool deep = true;            // PYLAMP_MG_DEEP=0: distributed levels exchange before every sweep instead of once per smoothing sequence
@@ -1074,6 +1135,16 @@ struct PlSolver {
     // heat work vectors (1 plane each)
     double* h[11] = {nullptr};
     int napply = 0, nprec = 0;
+    // Early coarse branch (single rank): the levels >= early_K get R^K f -- the right-hand side itself, restricted K
+    // times -- instead of the restricted residual of level K-1, which makes them independent of the pre-smoothing of the
+    // fine levels: they run on a second stream, concurrently with it.  The coarse levels are pure launch latency
+    // (~235 us of a 730 us preconditioner application at 2049^2 with the GPU idle), the fine ones pure bandwidth.
+    // The NumPy prototype needs the same number of BiCGStab iterations either way (tools/early_coarse.py: mantle model,
+    // 129^2: 33 / 33 / 32 for K = off / 2 / 3; 257^2: 36 / 37 / 35 / 36 for off / 2 / 3 / 4).
+    // PYLAMP_MG_EARLY=K (0: off; default: automatic, the first level of <= early_max_nodes nodes on large grids).
+    int early_knob = -1; long long early_max_nodes = 300000;
+    int early_K = 0;                         // decided by build_hierarchy
+    hipStream_t stream2 = nullptr; hipEvent_t ev_f = nullptr, ev_b = nullptr;
 };
 
 static PlSolver* solver_of(pl_ctx* ctx) {
@@ -1090,6 +1161,9 @@ static PlSolver* solver_of(pl_ctx* ctx) {
         if (const char* e = getenv("PYLAMP_MG_TAIL_NODES")) { long long v = atoll(e); if (v >= 25 && v <= PL_TAIL_MAX_NODES) S->tail_knob = v; }
         if (const char* e = getenv("PYLAMP_MG_HALO")) S->mg_halo = atoi(e);
         if (const char* e = getenv("PYLAMP_MG_DEEP")) S->deep = atoi(e) != 0;
+        if (const char* e = getenv("PYLAMP_MG_EARLY")) S->early_knob = atoi(e);
+        if (const char* e = getenv("PYLAMP_MG_FP32")) S->f32_enable = atoi(e) != 0;
+        if (const char* e = getenv("PYLAMP_MG_FP32_NODES")) { long long v = atoll(e); if (v >= 1) S->f32_min_nodes = v; }
         if (const char* e = getenv("PYLAMP_FUSE_FIRST")) S->fuse_first = atoi(e) != 0;
         if (const char* e = getenv("PYLAMP_SCHUR_SCALE")) { double v = atof(e); if (v > 0.0) S->schur_scale = v; }
         if (const char* e = getenv("PYLAMP_MG_TAIL_NU")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a + b > 0) { S->tail_nu_pre = a; S->tail_nu_post = b; } }
@@ -1106,7 +1180,8 @@ static void free_levels(PlSolver* S) {
         if (L->own_visc) { (void)hipFree(L->etas); (void)hipFree(L->etan); }
         if (L->own_rho && L->rho) (void)hipFree(L->rho);
         for (double* q : {L->szz, L->szx, L->eig}) if (q) (void)hipFree(q);
-        for (double* q : {L->v[0], L->v[1], L->v[2], L->f, L->r}) if (q) (void)hipFree(q);
+        for (double* q : {L->v[0], L->v[1], L->v[2], L->f, L->r, L->fe}) if (q) (void)hipFree(q);
+        for (float* q : {L->etas_f, L->etan_f, L->tab_f, L->vf[0], L->vf[1], L->vf[2], L->ff, L->rf}) if (q) (void)hipFree(q);
         pl_geom_free(L->gh);
         delete L;
     }
@@ -1121,6 +1196,9 @@ void pl_solver_free(pl_ctx* ctx) {
         if (q) (void)hipFree(q);
     for (double* q : S->h) if (q) (void)hipFree(q);
     if (S->hpart) (void)hipHostFree(S->hpart);
+    if (S->stream2) (void)hipStreamDestroy(S->stream2);
+    if (S->ev_f) (void)hipEventDestroy(S->ev_f);
+    if (S->ev_b) (void)hipEventDestroy(S->ev_b);
     delete S;
     ctx->krylov = nullptr;
 }
@@ -1239,6 +1317,7 @@ static int dots_dev(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const dou
 static void level_flags(MgLevel* L, const PlStokesOp& sop, bool finest) {
     PlVvOp& o = L->op;
     o.g = L->gh.d; o.etas = L->etas; o.etan = L->etan;
+    o.rdz = o.g.rdz; o.rDz = o.g.rDz; o.rdx = o.g.rdx; o.rDx = o.g.rDx;
     o.szz = nullptr; o.szx = nullptr;               // attached by build_hierarchy when the operator is stabilised
     o.slave_x = finest ? 1 : 0;
     const bool ns0 = sop.bc_z0 != PL_BC_FREESLIP, nsL = sop.bc_zL != PL_BC_FREESLIP;
@@ -1249,6 +1328,65 @@ static void level_flags(MgLevel* L, const PlStokesOp& sop, bool finest) {
     // NOSLIP extrapolation rows (pylamp_stokes.py:165-166,204-205): a0 v_s + a1 v_m = 0
     o.s0 = ns0 ? (1.0 / (z[2] - z[0])) / (1.0 / (z[2] - z[0]) + 1.0 / (z[1] - z[0])) : 1.0;
     o.sL = nsL ? (1.0 / (z[nz - 1] - z[nz - 3])) / (1.0 / (z[nz - 1] - z[nz - 3]) + 1.0 / (z[nz - 1] - z[nz - 2])) : 1.0;
+}
+
+// plane (or any array) to single precision, times a factor
+__global__ void k_to_float(long long n, const double* __restrict__ a, float* __restrict__ o, double scale) {
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x)
+        o[t] = (float)(a[t] * scale);
+}
+static int fmalloc0(pl_ctx* ctx, float** p, size_t bytes) {
+    PL_HIP(ctx, hipMalloc((void**)p, bytes));
+    PL_HIP(ctx, hipMemsetAsync(*p, 0, bytes, ctx->stream));
+    return 0;
+}
+// FP32 twins of the large levels (a prefix of the hierarchy): the V-cycle is only an approximation of A_vv^-1 inside an
+// FP64 BiCGStab, and on these levels the sweeps are bound by bytes and by the half-rate FP64 pipe.  The hierarchy itself
+// (coarsening, eigenvalue estimates) is built in FP64 first; this converts the coefficients of the current solve.
+static int setup_f32_levels(pl_ctx* ctx, PlSolver* S) {
+    const PlStokesOp& sop = ctx->sop;
+    const double hz = (ctx->geom.zc.back() - ctx->geom.zc.front()) / (ctx->nz - 1);
+    const double hx = (ctx->geom.xc.back() - ctx->geom.xc.front()) / (ctx->nx - 1);
+    S->sigma = sop.Kc / (0.5 * (hz + hx));                  // ~ eta_min / h^2
+    if (!(S->sigma > 0.0) || !std::isfinite(S->sigma)) S->sigma = 1.0;
+    bool prefix = true;
+    for (size_t l = 0; l < S->levels.size(); l++) {
+        MgLevel* L = S->levels[l];
+        const PlGeom& g = L->gh.d;
+        const bool tail = S->use_tail && l > 0 && (long long)g.nz * g.nx <= S->tail_max_nodes && S->levels.size() - l <= PL_TAIL_MAX_LEVELS;
+        const bool want = S->f32_enable && prefix && !tail && l + 1 < S->levels.size() && (long long)g.lnz * g.lnx >= S->f32_min_nodes &&
+                          !L->op.szz && (ctx->nranks == 1 || L->dist) && (g.plane % 2) == 0;
+        L->f32 = want;
+        prefix = prefix && want;
+        if (!want) continue;
+        const size_t pb = (size_t)g.plane * sizeof(float);
+        if (!L->etas_f) {
+            PL_TRY(fmalloc0(ctx, &L->etas_f, pb)); PL_TRY(fmalloc0(ctx, &L->etan_f, pb));
+            for (int q = 0; q < 3; q++) PL_TRY(fmalloc0(ctx, &L->vf[q], 2 * pb));
+            PL_TRY(fmalloc0(ctx, &L->ff, 2 * pb)); PL_TRY(fmalloc0(ctx, &L->rf, 2 * pb));
+            // the four reciprocal-spacing tables of the level, same layout as PlGeom's (index + PL_TOFF, zero padded, even lengths)
+            const std::vector<double>& zc = L->gh.zc; const std::vector<double>& xc = L->gh.xc;
+            const int nz = (int)zc.size(), nx = (int)xc.size();
+            const size_t lz = ((size_t)nz + 2 * PL_TOFF + 2 + 1) & ~(size_t)1, lx = ((size_t)nx + 2 * PL_TOFF + 2 + 1) & ~(size_t)1;
+            std::vector<float> t(2 * lz + 2 * lx, 0.0f);
+            float* rdz = t.data(); float* rDz = rdz + lz; float* rdx = rDz + lz; float* rDx = rdx + lx;
+            for (int i = 0; i + 1 < nz; i++) rdz[i + PL_TOFF] = (float)(1.0 / (zc[i + 1] - zc[i]));
+            for (int i = 1; i + 1 < nz; i++) rDz[i + PL_TOFF] = (float)(1.0 / (zc[i + 1] - zc[i - 1]));
+            for (int j = 0; j + 1 < nx; j++) rdx[j + PL_TOFF] = (float)(1.0 / (xc[j + 1] - xc[j]));
+            for (int j = 1; j + 1 < nx; j++) rDx[j + PL_TOFF] = (float)(1.0 / (xc[j + 1] - xc[j - 1]));
+            PL_HIP(ctx, hipMalloc((void**)&L->tab_f, t.size() * sizeof(float)));
+            PL_HIP(ctx, hipMemcpy(L->tab_f, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+            L->opf.rdz = L->tab_f; L->opf.rDz = L->tab_f + lz; L->opf.rdx = L->tab_f + 2 * lz; L->opf.rDx = L->tab_f + 2 * lz + lx;
+        }
+        // whole planes, halo ring included (level 0 arrives with its halo filled, the coarser ones were exchanged above)
+        hipLaunchKernelGGL(k_to_float, grid1d(g.plane), dim3(256), 0, ctx->stream, g.plane, (const double*)L->etas, L->etas_f, 1.0 / S->sigma);
+        hipLaunchKernelGGL(k_to_float, grid1d(g.plane), dim3(256), 0, ctx->stream, g.plane, (const double*)L->etan, L->etan_f, 1.0 / S->sigma);
+        PlVvOpF& o = L->opf;
+        o.g = L->op.g; o.etas = L->etas_f; o.etan = L->etan_f; o.szz = nullptr; o.szx = nullptr;
+        o.slave_x = L->op.slave_x; o.slave_z0 = L->op.slave_z0; o.slave_zL = L->op.slave_zL; o.s0 = (float)L->op.s0; o.sL = (float)L->op.sL;
+    }
+    PL_HIP(ctx, hipGetLastError());
+    return 0;
 }
 
 static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
@@ -1424,6 +1562,27 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
         PL_HIP(ctx, hipMemcpyAsync(L->eig, L->v[0], (size_t)n2 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
         L->eig_valid = std::isfinite(lam) && lam > 0.0;
     }
+    PL_TRY(setup_f32_levels(ctx, S));
+    // early coarse branch: first level of at most early_max_nodes nodes, on one rank, when at least two levels lie above it
+    S->early_K = 0;
+    if (ctx->nranks == 1 && S->early_knob != 0 && !S->levels[0]->f32) {
+        int K = S->early_knob > 0 ? S->early_knob : 0;
+        if (K == 0 && (long long)ctx->nz * ctx->nx >= 1000000LL)
+            for (size_t l = 2; l < S->levels.size(); l++)
+                if ((long long)S->levels[l]->gh.d.nz * S->levels[l]->gh.d.nx <= S->early_max_nodes) { K = (int)l; break; }
+        if (K >= 1 && K + 1 <= (int)S->levels.size() - 0 && K < (int)S->levels.size() && S->nu_pre >= 1) {
+            S->early_K = K;
+            if (!S->stream2) {
+                PL_HIP(ctx, hipStreamCreateWithFlags(&S->stream2, hipStreamNonBlocking));
+                PL_HIP(ctx, hipEventCreateWithFlags(&S->ev_f, hipEventDisableTiming));
+                PL_HIP(ctx, hipEventCreateWithFlags(&S->ev_b, hipEventDisableTiming));
+            }
+            for (int l = 1; l < K; l++) {
+                MgLevel* L = S->levels[l];
+                if (!L->fe) PL_TRY(dmalloc0(ctx, &L->fe, (size_t)2 * L->gh.d.plane * sizeof(double)));
+            }
+        }
+    }
     return 0;
 }
 
@@ -1441,9 +1600,10 @@ static const bool g_vv_vec_env = [] { const char* e = getenv("PYLAMP_VV_VEC"); r
 // global node (gi0-a, gj0-c).  The extension is clipped at the domain walls; towards -x it is rounded up to an even
 // number (aligned double2 accesses of the two-columns-per-lane kernels) -- the extra column is computed from data
 // one node beyond the valid depth, i.e. garbage that no needed node ever reads.
-struct ExtView { PlVvOp op; long long sh; };
-static ExtView ext_view(pl_ctx* ctx, const MgLevel* L, int e) {
-    ExtView v; v.op = L->op; v.sh = 0;
+template <typename T> struct ExtViewT { PlVvOpT<T> op; long long sh; };
+template <typename T>
+static ExtViewT<T> ext_view(pl_ctx* ctx, const MgLevel* L, int e) {
+    ExtViewT<T> v; v.op = LevelT<T>::op(L); v.sh = 0;
     if (e <= 0 || !L->dist) return v;
     const PlGeom& g = L->gh.d;
     const int a = ctx->pz > 0 ? e : 0, b = ctx->pz < ctx->Pz - 1 ? e : 0;
@@ -1457,42 +1617,56 @@ static ExtView ext_view(pl_ctx* ctx, const MgLevel* L, int e) {
 // nsweep Chebyshev-Jacobi sweeps on level L; buf[0] is the current iterate on entry and on exit.
 // ext_first >= 0 (deep mode): sweep k runs on the block extended by ext_first - k nodes, no exchanges in here;
 // ext_first < 0: one halo exchange before every sweep that needs one (halo policy `halo`).
-static void smooth(pl_ctx* ctx, MgLevel* L, double* buf[3], const double* f, int nsweep, double ratio,
-                   double* final_out = nullptr, bool zero_guess = false, int halo = 2, bool first_halo_valid = false,
-                   int ext_first = -1, const int* first_done_anchor = nullptr) {
+// final_out: the LAST sweep writes its result there -- always an FP64 Krylov vector -- times final_scale, and buf is
+// left as it was before that sweep.  Returns true when it did.
+template <typename T>
+static bool smooth(pl_ctx* ctx, MgLevel* L, T* buf[3], const T* f, int nsweep, double ratio,
+                   double* final_out = nullptr, double final_scale = 1.0, bool zero_guess = false, int halo = 2,
+                   bool first_halo_valid = false, int ext_first = -1, const int* first_done_anchor = nullptr) {
     const double lmax = L->lmax, lmin = lmax / ratio;
     const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
     double rho_old = 1.0 / sigma;
+    bool wrote_final = false;
     for (int k = 0; k < nsweep; k++) {
         double c1, c2;
         if (k == 0) { c1 = 0.0; c2 = 1.0 / theta; }
         else { const double rho = 1.0 / (2.0 * sigma - rho_old); c1 = rho * rho_old; c2 = 2.0 * rho / delta; rho_old = rho; }
         if (ext_first < 0 && L->dist && !(k == 0 && (zero_guess || first_halo_valid)) && (halo == 2 || (halo == 1 && k == 0)))
             (void)pl_halo(ctx, L->gh.d, buf[0], 2, L->gh.d.plane);
-        const ExtView V = ext_view(ctx, L, ext_first < 0 ? 0 : std::max(ext_first - k, 0));
+        const ExtViewT<T> V = ext_view<T>(ctx, L, ext_first < 0 ? 0 : std::max(ext_first - k, 0));
         const long long sh = V.sh;
-        double* dst = (final_out && k == nsweep - 1) ? final_out : buf[2];
-        if (k == 0 && zero_guess) {        // buf[0] is NOT read (and need not be zeroed)
+        const bool to_final = final_out && k == nsweep - 1;
+        T* dst = buf[2];
+        if (k == 0 && zero_guess) {        // buf[0] is NOT read (and need not be zeroed); never the final sweep of level 0 (a
+                                           // V-cycle with a coarse level has a prolongation before its last sweep)
             if (g_vv_vec && first_done_anchor)        // stage 1 wrote the interior waves of this sweep already (into dst = buf[2])
-                hipLaunchKernelGGL(k_vv_first2, pl_grid_rows2(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, f - sh, dst - sh, c2, 1,
+                hipLaunchKernelGGL(k_vv_first2<T>, pl_grid_rows2(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, f - sh, dst - sh, (T)c2, 1,
                                    first_done_anchor[0], first_done_anchor[1]);
-            else if (g_vv_vec) hipLaunchKernelGGL(k_vv_first2, pl_grid_rows2(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, f - sh, dst - sh, c2);
-            else hipLaunchKernelGGL(k_vv_cheb_first, pl_grid_rows(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, f - sh, dst - sh, c2,
+            else if (g_vv_vec) hipLaunchKernelGGL(k_vv_first2<T>, pl_grid_rows2(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, f - sh, dst - sh, (T)c2, 0, -9, -9);
+            else hipLaunchKernelGGL(k_vv_cheb_first<T>, pl_grid_rows(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, f - sh, dst - sh, (T)c2,
                                     pl_row_iters(V.op.g));
-        }
-        else
-        {
-            const double* prev = (k == 1 && zero_guess) ? (const double*)nullptr : buf[1] - sh;
+        } else {
+            const T* prev = (k == 1 && zero_guess) ? (const T*)nullptr : buf[1] - sh;
+            if (to_final) {
+                if (g_vv_vec)
+                    hipLaunchKernelGGL((k_vv_sweep2<0, T, double>), pl_grid_rows2(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, (const T*)(buf[0] - sh), prev,
+                                       f - sh, final_out - sh, (T)c1, (T)c2, final_scale);
+                else
+                    hipLaunchKernelGGL((k_vv_cheb<T, double>), pl_grid_rows(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, (const T*)(buf[0] - sh), prev, f - sh,
+                                       final_out - sh, (T)c1, (T)c2, pl_row_iters(V.op.g), final_scale);
+                wrote_final = true;
+                break;
+            }
             if (g_vv_vec)
-                hipLaunchKernelGGL(k_vv_sweep2<0>, pl_grid_rows2(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, (const double*)(buf[0] - sh), prev,
-                                   f - sh, dst - sh, c1, c2);
+                hipLaunchKernelGGL((k_vv_sweep2<0, T, T>), pl_grid_rows2(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, (const T*)(buf[0] - sh), prev,
+                                   f - sh, dst - sh, (T)c1, (T)c2, T(1));
             else
-                hipLaunchKernelGGL(k_vv_cheb, pl_grid_rows(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, (const double*)(buf[0] - sh), prev, f - sh,
-                                   dst - sh, c1, c2, pl_row_iters(V.op.g));
+                hipLaunchKernelGGL((k_vv_cheb<T, T>), pl_grid_rows(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, (const T*)(buf[0] - sh), prev, f - sh,
+                                   dst - sh, (T)c1, (T)c2, pl_row_iters(V.op.g), T(1));
         }
-        if (dst != buf[2]) { buf[1] = buf[0]; buf[0] = dst; }
-        else { double* nxt = buf[2]; buf[2] = buf[1]; buf[1] = buf[0]; buf[0] = nxt; }    // (cur, prev, free)
+        { T* nxt = buf[2]; buf[2] = buf[1]; buf[1] = buf[0]; buf[0] = nxt; }    // (cur, prev, free)
     }
+    return wrote_final;
 }
 
 // Chebyshev sweeps on the coarsest level: enough for the eigenvalue window [lmax/ratio, lmax] of a
@@ -1526,35 +1700,108 @@ static bool level_deep_plan(const PlSolver* S, const MgLevel* L, size_t l, int& 
     return f_depth <= PL_RING - 1 && f_depth + 1 <= std::min(L->gh.d.lnz, L->gh.d.lnx);
 }
 
+// residual of level L -> its r buffer, restriction into the coarse level C (type TC), recursive solve there,
+// prolongation of the correction into buf[2] of L.  Separate function so that the FP32 / FP64 type of C is a template
+// parameter: the FP32 levels are a prefix of the hierarchy, an FP32 level may sit above an FP64 one, never below.
+template <typename T> static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const T* f, T** out, bool* wrote_final, double* final_out,
+                                         double final_scale, int f_valid_depth, const int* first_done_anchor);
+
+template <typename T, typename TC>
+static void coarse_correction(pl_ctx* ctx, PlSolver* S, size_t l, MgLevel* L, MgLevel* C, T* buf[3], bool deep, int npost, int hp) {
+    const PlGeom& g = L->gh.d;
+    T* r = LevelT<T>::r(L);
+    TC* cf = LevelT<TC>::f(C);
+    // an FP32 level works with A / sigma (stokes_precond), an FP64 one with A: the residual changes units here
+    const TC cscale = (std::is_same<T, float>::value && std::is_same<TC, double>::value) ? (TC)S->sigma : TC(1);
+    if (L->dist && !C->dist) {
+        // restrict my block of the replicated coarse rhs, then gather everybody's (replicated levels are FP64)
+        PlVvOpT<TC> wop = LevelT<TC>::op(C); wop.g = C->win;
+        const long long sh = C->win_shift;
+        hipLaunchKernelGGL((k_vv_restrict<T, TC>), grid2d(C->win), dim3(64, 4), 0, ctx->stream, g, wop, (const T*)r, cf + sh, cscale);
+        if constexpr (std::is_same<TC, double>::value) (void)pl_gather_blocks(ctx, C->gh.d, cf, 2, C->gh.d.plane);
+    } else {
+        hipLaunchKernelGGL((k_vv_restrict<T, TC>), grid2d(C->gh.d), dim3(64, 4), 0, ctx->stream, g, LevelT<TC>::op(C), (const T*)r, cf, cscale);
+    }
+    TC* ec = nullptr;
+    bool wf = false;
+    vcycle<TC>(ctx, S, l + 1, cf, &ec, &wf, nullptr, 1.0, 0, nullptr);
+    // ---- way up.  The correction is prolonged into the halo as well -- `pe` nodes deep -- so that the post-smoothing
+    // sequence needs no exchange of its own; the coarse correction must then be known (pe+1)/2 + 1 coarse nodes deep
+    // (ONE exchange, none when the coarse level is replicated).
+    const int pe = deep ? npost : ((L->dist && hp == 2) ? 1 : 0);
+    if (C->dist && (deep || hp >= 1))
+        (void)pl_halo(ctx, C->gh.d, ec, 2, C->gh.d.plane, std::min(std::max((pe + 1) / 2 + 1, 2), std::min(PL_RING, std::min(C->gh.d.lnz, C->gh.d.lnx))));
+    ExtViewT<T> V = ext_view<T>(ctx, L, pe);
+    if (!deep && pe == 1) {            // legacy extension by exactly one node (no rounding: the prolongation kernel is scalar)
+        V.op = LevelT<T>::op(L);
+        const int lo = ctx->pz > 0 ? 1 : 0, hi = ctx->pz < ctx->Pz - 1 ? 1 : 0, we = ctx->px > 0 ? 1 : 0, ea = ctx->px < ctx->Px - 1 ? 1 : 0;
+        V.op.g.gi0 -= lo; V.op.g.lnz += lo + hi; V.op.g.gj0 -= we; V.op.g.lnx += we + ea;
+        V.sh = (long long)lo * g.pitch + we;
+    }
+    hipLaunchKernelGGL((k_vv_prolong_add<T, TC>), grid2d(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, C->gh.d, (const TC*)ec, (const T*)(buf[0] - V.sh),
+                       buf[2] - V.sh);
+}
+
+// Early coarse branch (PlSolver::early_K), level l = K-1 of the fine branch: on the second stream, as soon as stage 1 has
+// written the right-hand side of level 0, restrict IT down to level K and solve there; the fine branch (this stream) has
+// meanwhile pre-smoothed levels 0 .. K-1 and now waits for the correction, which it prolongs as usual.
+static void early_coarse_branch(pl_ctx* ctx, PlSolver* S, size_t l, MgLevel* L, MgLevel* C, double* buf[3]) {
+    hipStream_t main_stream = ctx->stream;
+    ctx->stream = S->stream2;                       // everything below is enqueued on the second stream
+    (void)hipStreamWaitEvent(S->stream2, S->ev_f, 0);
+    const double* src = S->levels[0]->f;
+    for (size_t q = 1; q <= l + 1; q++) {
+        MgLevel* F = S->levels[q - 1];
+        MgLevel* Q = S->levels[q];
+        double* dst = (q == l + 1) ? Q->f : Q->fe;
+        hipLaunchKernelGGL((k_vv_restrict<double, double>), grid2d(Q->gh.d), dim3(64, 4), 0, ctx->stream, F->gh.d, Q->op, src, dst, 1.0);
+        src = dst;
+    }
+    double* ec = nullptr;
+    bool wf = false;
+    vcycle<double>(ctx, S, l + 1, C->f, &ec, &wf, nullptr, 1.0, 0, nullptr);
+    (void)hipEventRecord(S->ev_b, S->stream2);
+    ctx->stream = main_stream;
+    (void)hipStreamWaitEvent(main_stream, S->ev_b, 0);
+    hipLaunchKernelGGL((k_vv_prolong_add<double, double>), grid2d(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, C->gh.d, (const double*)ec,
+                       (const double*)buf[0], buf[2]);
+}
+
 // solves A_vv e = f(level l) approximately; result in *out (one of the level's v buffers)
-// final_out (level 0 only): the last post-smoothing sweep writes its result there (zero-copy into z)
+// final_out (level 0 only): the last post-smoothing sweep writes its result there (zero-copy into z), times final_scale;
+// *wrote_final tells whether that happened (otherwise the result is in *out)
 // f_valid_depth: how deep into the halo the caller has already made f valid (level 0: stage 1 computes it there)
-static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const double* f, double** out, double* final_out = nullptr,
-                   int f_valid_depth = 0, const int* first_done_anchor = nullptr) {
+template <typename T>
+static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const T* f, T** out, bool* wrote_final, double* final_out,
+                   double final_scale, int f_valid_depth, const int* first_done_anchor) {
     MgLevel* L = S->levels[l];
     const PlGeom& g = L->gh.d;
-    if (S->use_tail && l > 0 && (long long)g.nz * g.nx <= S->tail_max_nodes &&
-        S->levels.size() - l <= PL_TAIL_MAX_LEVELS && f == L->f) {
-        TailArgs ta{};
-        ta.nlev = (int)(S->levels.size() - l);
-        ta.nu_pre = S->tail_nu_pre >= 0 ? S->tail_nu_pre : S->nu_pre; ta.nu_post = S->tail_nu_post >= 0 ? S->tail_nu_post : S->nu_post;
-        ta.coarse_sweeps = coarsest_sweeps(S, S->levels.back()->gh.d); ta.ratio = S->cheb_ratio;
-        for (int q = 0; q < ta.nlev; q++) {
-            MgLevel* T = S->levels[l + q];
-            ta.L[q].op = T->op; ta.L[q].f = T->f; ta.L[q].r = T->r; ta.L[q].lmax = T->lmax;
-            for (int b = 0; b < 3; b++) ta.L[q].v[b] = T->v[b];
+    *wrote_final = false;
+    if constexpr (std::is_same<T, double>::value) {
+        if (S->use_tail && l > 0 && (long long)g.nz * g.nx <= S->tail_max_nodes &&
+            S->levels.size() - l <= PL_TAIL_MAX_LEVELS && f == L->f) {
+            TailArgs ta{};
+            ta.nlev = (int)(S->levels.size() - l);
+            ta.nu_pre = S->tail_nu_pre >= 0 ? S->tail_nu_pre : S->nu_pre; ta.nu_post = S->tail_nu_post >= 0 ? S->tail_nu_post : S->nu_post;
+            ta.coarse_sweeps = coarsest_sweeps(S, S->levels.back()->gh.d); ta.ratio = S->cheb_ratio;
+            for (int q = 0; q < ta.nlev; q++) {
+                MgLevel* T_ = S->levels[l + q];
+                ta.L[q].op = T_->op; ta.L[q].f = T_->f; ta.L[q].r = T_->r; ta.L[q].lmax = T_->lmax;
+                for (int b = 0; b < 3; b++) ta.L[q].v[b] = T_->v[b];
+            }
+            hipLaunchKernelGGL(k_mg_tail, dim3(1), dim3(1024), 0, ctx->stream, ta);
+            *out = L->v[0];
+            return;
         }
-        hipLaunchKernelGGL(k_mg_tail, dim3(1), dim3(1024), 0, ctx->stream, ta);
-        *out = L->v[0];
-        return;
     }
-    double* buf[3] = {L->v[0], L->v[1], L->v[2]};
+    T** lv = LevelT<T>::v(L);
+    T* buf[3] = {lv[0], lv[1], lv[2]};
     const bool coarsest = l + 1 == S->levels.size();
     if (!coarsest && S->nu_pre == 0)       // otherwise the zero guess is implicit (k_vv_cheb_first)
-        (void)hipMemsetAsync(buf[0], 0, (size_t)2 * g.plane * sizeof(double), ctx->stream);
+        (void)hipMemsetAsync(buf[0], 0, (size_t)2 * g.plane * sizeof(T), ctx->stream);
     if (coarsest) {
         double ratio = 0.4 * g.nz * g.nx; if (ratio < 30.0) ratio = 30.0;
-        smooth(ctx, L, buf, f, coarsest_sweeps(S, g), ratio, nullptr, true, S->mg_halo);
+        smooth<T>(ctx, L, buf, f, coarsest_sweeps(S, g), ratio, nullptr, 1.0, true, S->mg_halo);
         *out = buf[0];
         return;
     }
@@ -1563,70 +1810,95 @@ static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const double* f, double**
     level_nu(S, l, npre, npost);
     const bool deep = level_deep_plan(S, L, l, e_last, f_depth);
     MgLevel* C = S->levels[l + 1];
-    if (deep) {
+    T* r = LevelT<T>::r(L);
+    // early coarse branch: the coarse levels do not see this level's residual (see PlSolver::early_K)
+    const bool early_here = std::is_same<T, double>::value && S->early_K > 0 && (int)l + 1 == S->early_K && !L->dist;
+    if (early_here) {
+        smooth<T>(ctx, L, buf, f, npre, S->cheb_ratio, nullptr, 1.0, true, hp, false, -1, first_done_anchor);
+    } else if (deep) {
         // ---- ONE exchange on the way down: the right-hand side, deep enough for the whole pre-smoothing sequence,
         //      the residual and (later) the post-smoothing sequence
-        if (f_valid_depth < f_depth) (void)pl_halo(ctx, g, (double*)f, 2, g.plane, f_depth);
-        smooth(ctx, L, buf, f, npre, S->cheb_ratio, nullptr, true, hp, false, e_last + npre - 1, first_done_anchor);      // iterate valid e_last deep
-        const ExtView V = ext_view(ctx, L, e_last - 1);
+        if (f_valid_depth < f_depth) (void)pl_halo(ctx, g, (T*)f, 2, g.plane, f_depth);
+        smooth<T>(ctx, L, buf, f, npre, S->cheb_ratio, nullptr, 1.0, true, hp, false, e_last + npre - 1, first_done_anchor);      // iterate valid e_last deep
+        const ExtViewT<T> V = ext_view<T>(ctx, L, e_last - 1);
         if (g_vv_vec)
-            hipLaunchKernelGGL(k_vv_sweep2<1>, pl_grid_rows2(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, (const double*)(buf[0] - V.sh),
-                               (const double*)nullptr, f - V.sh, L->r - V.sh, 0.0, 0.0);
+            hipLaunchKernelGGL((k_vv_sweep2<1, T, T>), pl_grid_rows2(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, (const T*)(buf[0] - V.sh),
+                               (const T*)nullptr, f - V.sh, r - V.sh, T(0), T(0), T(1));
         else
-            hipLaunchKernelGGL(k_vv_residual, pl_grid_rows(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, (const double*)(buf[0] - V.sh), f - V.sh,
-                               L->r - V.sh, pl_row_iters(V.op.g));
+            hipLaunchKernelGGL(k_vv_residual<T>, pl_grid_rows(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, (const T*)(buf[0] - V.sh), f - V.sh,
+                               r - V.sh, pl_row_iters(V.op.g));
     } else {
-        smooth(ctx, L, buf, f, npre, S->cheb_ratio, nullptr, true, hp, false, -1, first_done_anchor);
+        smooth<T>(ctx, L, buf, f, npre, S->cheb_ratio, nullptr, 1.0, true, hp, false, -1, first_done_anchor);
         if (L->dist && hp >= 1) (void)pl_halo(ctx, g, buf[0], 2, g.plane);
         if (g_vv_vec)
-            hipLaunchKernelGGL(k_vv_sweep2<1>, pl_grid_rows2(g), dim3(64, 4), 0, ctx->stream, L->op, buf[0], (const double*)nullptr, f,
-                               L->r, 0.0, 0.0);
+            hipLaunchKernelGGL((k_vv_sweep2<1, T, T>), pl_grid_rows2(g), dim3(64, 4), 0, ctx->stream, LevelT<T>::op(L), (const T*)buf[0], (const T*)nullptr, f,
+                               r, T(0), T(0), T(1));
         else
-            hipLaunchKernelGGL(k_vv_residual, pl_grid_rows(g), dim3(64, 4), 0, ctx->stream, L->op, buf[0], f, L->r, pl_row_iters(g));
-        if (L->dist && hp >= 1) (void)pl_halo(ctx, g, L->r, 2, g.plane, 2);
+            hipLaunchKernelGGL(k_vv_residual<T>, pl_grid_rows(g), dim3(64, 4), 0, ctx->stream, LevelT<T>::op(L), (const T*)buf[0], f, r, pl_row_iters(g));
+        if (L->dist && hp >= 1) (void)pl_halo(ctx, g, r, 2, g.plane, 2);
     }
-    if (L->dist && !C->dist) {
-        // restrict my block of the replicated coarse rhs, then gather everybody's
-        PlVvOp wop = C->op; wop.g = C->win;
-        const long long sh = C->win_shift;
-        hipLaunchKernelGGL(k_vv_restrict, grid2d(C->win), dim3(64, 4), 0, ctx->stream, g, wop, L->r, C->f + sh);
-        (void)pl_gather_blocks(ctx, C->gh.d, C->f, 2, C->gh.d.plane);
+    if constexpr (std::is_same<T, float>::value) {
+        if (C->f32) coarse_correction<float, float>(ctx, S, l, L, C, buf, deep, npost, hp);
+        else coarse_correction<float, double>(ctx, S, l, L, C, buf, deep, npost, hp);
     } else {
-        hipLaunchKernelGGL(k_vv_restrict, grid2d(C->gh.d), dim3(64, 4), 0, ctx->stream, g, C->op, L->r, C->f);
-    }
-    double* ec = nullptr;
-    vcycle(ctx, S, l + 1, C->f, &ec);
-    // ---- way up.  The correction is prolonged into the halo as well -- `pe` nodes deep -- so that the post-smoothing
-    // sequence needs no exchange of its own; the coarse correction must then be known (pe+1)/2 + 1 coarse nodes deep
-    // (ONE exchange, none when the coarse level is replicated).
-    const int pe = deep ? npost : ((L->dist && hp == 2) ? 1 : 0);
-    if (C->dist && (deep || hp >= 1))
-        (void)pl_halo(ctx, C->gh.d, ec, 2, C->gh.d.plane, std::min(std::max((pe + 1) / 2 + 1, 2), std::min(PL_RING, std::min(C->gh.d.lnz, C->gh.d.lnx))));
-    {
-        ExtView V = ext_view(ctx, L, pe);
-        if (!deep && pe == 1) {            // legacy extension by exactly one node (no rounding: the prolongation kernel is scalar)
-            V.op = L->op;
-            const int lo = ctx->pz > 0 ? 1 : 0, hi = ctx->pz < ctx->Pz - 1 ? 1 : 0, we = ctx->px > 0 ? 1 : 0, ea = ctx->px < ctx->Px - 1 ? 1 : 0;
-            V.op.g.gi0 -= lo; V.op.g.lnz += lo + hi; V.op.g.gj0 -= we; V.op.g.lnx += we + ea;
-            V.sh = (long long)lo * g.pitch + we;
-        }
-        hipLaunchKernelGGL(k_vv_prolong_add, grid2d(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, C->gh.d, ec, buf[0] - V.sh, buf[2] - V.sh);
+        if (early_here) early_coarse_branch(ctx, S, l, L, C, buf);
+        else coarse_correction<double, double>(ctx, S, l, L, C, buf, deep, npost, hp);
     }
     std::swap(buf[0], buf[2]);
-    if (deep) smooth(ctx, L, buf, f, npost, S->cheb_ratio, final_out, false, hp, true, npost - 1);
-    else smooth(ctx, L, buf, f, npost, S->cheb_ratio, final_out, false, hp, pe == 1);
+    const int pe = deep ? npost : ((L->dist && hp == 2) ? 1 : 0);
+    if (deep) *wrote_final = smooth<T>(ctx, L, buf, f, npost, S->cheb_ratio, final_out, final_scale, false, hp, true, npost - 1);
+    else *wrote_final = smooth<T>(ctx, L, buf, f, npost, S->cheb_ratio, final_out, final_scale, false, hp, pe == 1);
     *out = buf[0];
 }
 
+// copy 2 velocity planes into the FP64 Krylov vector (times oscale)
+template <typename T>
+__global__ __launch_bounds__(256) void k_copy_vel(PlGeom g, const T* __restrict__ e, double* __restrict__ z, double oscale) {
+    PL_NODE_PROLOGUE(g)
+    (void)i; (void)j;
+    z[c] = (double)e[c] * oscale; z[c + g.plane] = (double)e[c + g.plane] * oscale;
+}
+
+// Constraint rows of a preconditioned direction, closed in FP64: walls 0, slaves s * master.  Stage 1 does not lift the
+// residual of these rows because every direction satisfies them exactly (see stage1_node) -- true to 1e-16 when the
+// last sweep runs in FP64, but a slave and its master evaluated in FP32 by two different code paths differ by 1e-7,
+// which would leave a residual on those rows that nothing ever removes (BiCGStab then stalls near 1e-6).
+// One thread per node of the frame: rows 0, nz-2, nz-1 and columns 0, nx-2, nx-1.
+__global__ __launch_bounds__(256) void k_vv_close_frame(PlVvOp op, double* __restrict__ z) {
+    const PlGeom& g = op.g;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    int i, j;
+    if (t < 3 * g.lnx) { const int q = t / g.lnx; i = q == 0 ? 0 : g.nz - 3 + q; j = g.gj0 + t % g.lnx; }
+    else if (t < 3 * g.lnx + 3 * g.lnz) { const int u = t - 3 * g.lnx, q = u / g.lnz; j = q == 0 ? 0 : g.nx - 3 + q; i = g.gi0 + u % g.lnz; }
+    else return;
+    const int li = i - g.gi0, lj = j - g.gj0;
+    if (li < 0 || li >= g.lnz || lj < 0 || lj >= g.lnx) return;
+    const long long c = pl_idx(g, li, lj), P = g.plane;
+    int moff; double s;
+    int cls = vv_cls_z(op, i, j, moff, s);
+    if (cls == VV_ZERO) z[c] = 0.0; else if (cls == VV_SLAVE) z[c] = s * z[c + moff];
+    cls = vv_cls_x(op, i, j, moff, s);
+    if (cls == VV_ZERO) z[c + P] = 0.0; else if (cls == VV_SLAVE) z[c + P] = s * z[c + moff + P];
+}
+
 // z = M^-1 rs   (rs: scaled residual, 3 planes)
-static int stokes_precond(pl_ctx* ctx, PlSolver* S, const double* rs, double* z) {
+//
+// FP32 level 0 (S->levels[0]->f32): the velocity block is solved in single precision as  A~ v~ = f~  with
+//     A~ = A_vv / sigma  (viscosity planes stored times 1/sigma, sigma ~ eta_min / h^2: coefficients O(1) and above),
+//     f~ = f kappa / sigma,   v~ = kappa v,   kappa = sqrt(n) / ||r||  (the current residual norm: v~ = O(1)),
+// so that nothing leaves the FP32 range whatever the units of the model and however far the residual has dropped.
+// stage 1 writes f~ (and the first sweep v~1), the last post-smoothing sweep writes v = v~ / kappa into z.
+template <typename T>
+static int stokes_precond_t(pl_ctx* ctx, PlSolver* S, const double* rs, double* z) {
     PlStokesOp op = ctx->sop;
     MgLevel* L0 = S->levels[0];
     MgLevel* L = L0;                                  // (g_vv_vec looks at L)
     const PlGeom& g = ctx->sop.g;
+    const bool f32 = std::is_same<T, float>::value;
+    const double kappa = f32 ? S->kappa : 1.0, fscale = f32 ? S->kappa / S->sigma : 1.0, oscale = f32 ? 1.0 / S->kappa : 1.0;
     int e_last = 0, f_depth = 0;
     const bool deep = level_deep_plan(S, L0, 0, e_last, f_depth);
-    ExtView V = ext_view(ctx, L0, deep ? f_depth : 0);
+    ExtViewT<T> V = ext_view<T>(ctx, L0, deep ? f_depth : 0);
     if (L0->dist) {
         // stage 1 reads the pressure residual one node up / left; in deep mode it is evaluated f_depth nodes into the halo,
         // which makes the velocity right-hand side of level 0 valid there without an exchange of its own
@@ -1638,22 +1910,29 @@ static int stokes_precond(pl_ctx* ctx, PlSolver* S, const double* rs, double* z)
     // the first pre-smoothing sweep of level 0 (from the zero guess: v1 = -c2 f / diag) is written by stage 1 itself
     int npre0, npost0;
     level_nu(S, 0, npre0, npost0);
-    const bool tail0 = false;
-    const bool fuse_first = S->fuse_first && g_vv_vec && (g.plane % 2) == 0 && S->levels.size() > 1 && npre0 >= 1 && !L0->op.szz && !tail0;
+    const bool fuse_first = S->fuse_first && g_vv_vec && (g.plane % 2) == 0 && S->levels.size() > 1 && npre0 >= 1 && !L0->op.szz;
     const int anchor[2] = {ctx->sop.anchor_i, ctx->sop.anchor_j};
+    T* f0 = LevelT<T>::f(L0);
     if (g_vv_vec && (g.plane % 2) == 0) {
         const double lmax = L0->lmax, lmin = lmax / S->cheb_ratio, c2 = 1.0 / (0.5 * (lmax + lmin));     // as smooth() computes it
-        hipLaunchKernelGGL(k_prec_stage1_v2, pl_grid_rows2(op.g), dim3(64, 4), 0, ctx->stream, op, V.op, rs - V.sh, z - V.sh, L0->f - V.sh,
-                           fuse_first ? L0->v[2] - V.sh : (double*)nullptr, c2);
+        hipLaunchKernelGGL(k_prec_stage1_v2<T>, pl_grid_rows2(op.g), dim3(64, 4), 0, ctx->stream, op, V.op, rs - V.sh, z - V.sh, f0 - V.sh,
+                           fuse_first ? LevelT<T>::v(L0)[2] - V.sh : (T*)nullptr, c2, fscale, kappa);
     } else
-        hipLaunchKernelGGL(k_prec_stage1, pl_grid_rows(op.g), dim3(64, 4), 0, ctx->stream, op, V.op, rs - V.sh, z - V.sh, L0->f - V.sh, pl_row_iters(op.g));
-    double* e = nullptr;
+        hipLaunchKernelGGL(k_prec_stage1<T>, pl_grid_rows(op.g), dim3(64, 4), 0, ctx->stream, op, V.op, rs - V.sh, z - V.sh, f0 - V.sh,
+                           pl_row_iters(op.g), fscale);
+    if (S->early_K > 0 && !f32) (void)hipEventRecord(S->ev_f, ctx->stream);        // level 0's right-hand side is complete
+    T* e = nullptr;
+    bool wrote = false;
     const bool direct = S->levels.size() > 1 && S->nu_post > 0;     // last sweep writes into z
-    vcycle(ctx, S, 0, L0->f, &e, direct ? z : nullptr, deep ? f_depth : 0, fuse_first ? anchor : nullptr);
-    if (e != z) hipLaunchKernelGGL(k_copy_vel, grid2d(g), dim3(64, 4), 0, ctx->stream, g, e, z);
+    vcycle<T>(ctx, S, 0, f0, &e, &wrote, direct ? z : nullptr, oscale, deep ? f_depth : 0, fuse_first ? anchor : nullptr);
+    if (!wrote) hipLaunchKernelGGL(k_copy_vel<T>, grid2d(g), dim3(64, 4), 0, ctx->stream, g, (const T*)e, z, oscale);
+    if (f32) hipLaunchKernelGGL(k_vv_close_frame, dim3((3 * g.lnx + 3 * g.lnz + 255) / 256), dim3(256), 0, ctx->stream, L0->op, z);
     PL_HIP(ctx, hipGetLastError());
     S->nprec++;
     return 0;
+}
+static int stokes_precond(pl_ctx* ctx, PlSolver* S, const double* rs, double* z) {
+    return S->levels[0]->f32 ? stokes_precond_t<float>(ctx, S, rs, z) : stokes_precond_t<double>(ctx, S, rs, z);
 }
 
 // =========================================================================================
@@ -1702,6 +1981,7 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
     PL_HIP(ctx, hipMemsetAsync(w.rt, 0, bytes, ctx->stream));
     hipLaunchKernelGGL(k_random_interior, grid2d(g), dim3(64, 4), 0, ctx->stream, g, np, w.rt, 1234u);
     const bool on_device = dots_on_device(ctx, g) && !getenv("PYLAMP_HOST_SCALARS");
+    static const bool trace = getenv("PYLAMP_SOLVER_TRACE") != nullptr;        // residual history on stderr
     int it = 0, restarts = 0;
     double true_norm = -1.0, last_true = -1.0;          // ||r0 - A dx|| of the current dx (< 0: not evaluated)
     // BiCGStab is not monotone and, past the attainable accuracy, drifts and can blow up: keep the best
@@ -1715,6 +1995,10 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
         PL_TRY(dots(ctx, S, g, np, w.rt, w.r, w.r, w.r, d2));
         double rho_new = d2[0], rnorm = std::sqrt(d2[1]);
         if (restarts == 0) best = rnorm;
+        // scale of the FP32 velocity solve inside the preconditioner: v~ = kappa v = O(1) at the current residual level
+        const double sqrt_n = std::sqrt((double)np * ctx->nz * ctx->nx);
+        auto set_kappa = [&](double rn) { S->kappa = (std::isfinite(rn) && rn > 0.0) ? sqrt_n / rn : 1.0; };
+        set_kappa(rnorm);
         bool broke = false;
         while (it < maxit && rnorm > rtol * bnorm) {
             it++;
@@ -1759,6 +2043,8 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
                 rho_new = d2[0]; rnorm = std::sqrt(d2[1]);
             }
             if (!std::isfinite(rnorm) || !(std::fabs(omega) > 0.0)) { broke = true; break; }
+            set_kappa(rnorm);
+            if (trace) fprintf(stderr, "[pylamp bicgstab] it %3d  |r|/|b| %.3e  alpha %.3e omega %.3e\n", it, rnorm / bnorm, alpha, omega);
             if (rnorm < 0.9 * best && w.xbest) {
                 best = rnorm; best_it = it; have_best = true;
                 PL_HIP(ctx, hipMemcpyAsync(w.xbest, dx, bytes, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1772,6 +2058,7 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
         hipLaunchKernelGGL(k_axpy_out, grid1d(n), dim3(256), 0, ctx->stream, n, w.s, r0, w.t, -1.0);
         PL_TRY(dots(ctx, S, g, np, w.s, w.s, nullptr, nullptr, d2));
         last_true = true_norm; true_norm = std::sqrt(d2[0]);
+        if (trace) fprintf(stderr, "[pylamp bicgstab] it %3d  TRUE |r|/|b| %.3e (recurrence %.3e) restarts %d\n", it, true_norm / bnorm, rnorm / bnorm, restarts);
         if (true_norm <= rtol * bnorm || broke || it >= maxit || restarts >= PL_MAX_RESTARTS) break;
         if (last_true >= 0.0 && !(true_norm < 0.5 * last_true)) break;      // a restart no longer pays: attainable accuracy
         // ---- residual replacement: continue from the TRUE residual
@@ -1934,8 +2221,22 @@ extern "C" int pl_stokes_precond_apply(pl_ctx* ctx, const double* r, double* z) 
     const PlGeom& g = ctx->geom.d;
     PL_TRY(pl_vec3_upload(ctx, g, r, S->s));
     hipLaunchKernelGGL(k_stokes_scale_rows, grid2d(g), dim3(64, 4), 0, ctx->stream, ctx->sop, S->s);
+    {   // scale of the FP32 velocity solve, as bicgstab sets it from the residual norm
+        double d2[2];
+        PL_TRY(dots(ctx, S, g, 3, S->s, S->s, nullptr, nullptr, d2));
+        S->kappa = (std::isfinite(d2[0]) && d2[0] > 0.0) ? std::sqrt(3.0 * ctx->nz * ctx->nx / d2[0]) : 1.0;
+    }
     PL_TRY(stokes_precond(ctx, S, S->s, S->z));
     PL_TRY(pl_vec3_download(ctx, g, S->z, z));
+    return 0;
+}
+
+// fp32 = 0: every multigrid level in FP64; 1: FP32 on the large levels (the default, also PYLAMP_MG_FP32)
+// min_nodes > 0: smallest level (local nodes) that runs in FP32 (default 200000, PYLAMP_MG_FP32_NODES)
+extern "C" int pl_stokes_set_mg_precision(pl_ctx* ctx, int fp32, long long min_nodes) {
+    PlSolver* S = solver_of(ctx);
+    S->f32_enable = fp32 != 0;
+    if (min_nodes > 0) S->f32_min_nodes = min_nodes;
     return 0;
 }
 
@@ -1943,6 +2244,16 @@ extern "C" int pl_stokes_mg_info(pl_ctx* ctx, int* nlevels, double* lmax, int ma
     PlSolver* S = solver_of(ctx);
     if (nlevels) *nlevels = (int)S->levels.size();
     for (int l = 0; lmax && l < max_levels && l < (int)S->levels.size(); l++) lmax[l] = S->levels[l]->lmax;
+    return 0;
+}
+
+// Shape of the multigrid hierarchy of the last solve: number of levels, how many of them (a prefix) run in FP32
+extern "C" int pl_stokes_mg_precision(pl_ctx* ctx, int* nlevels, int* nlevels_fp32) {
+    PlSolver* S = solver_of(ctx);
+    int nf = 0;
+    for (MgLevel* L : S->levels) nf += L->f32 ? 1 : 0;
+    if (nlevels) *nlevels = (int)S->levels.size();
+    if (nlevels_fp32) *nlevels_fp32 = nf;
     return 0;
 }
 
@@ -1959,8 +2270,13 @@ extern "C" int pl_stokes_sweep_bench(pl_ctx* ctx, int reps, double* avg_ms) {
     const double lmax = L->lmax, lmin = lmax / S->cheb_ratio, theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
     const double sigma = theta / delta, rho1 = 1.0 / (2.0 * sigma - 1.0 / sigma);
     const double c1 = rho1 / sigma, c2 = 2.0 * rho1 / delta;           // coefficients of a second sweep
-    auto launch = [&]() {
-        hipLaunchKernelGGL(k_vv_sweep2<0>, pl_grid_rows2(g), dim3(64, 4), 0, ctx->stream, L->op, L->v[0], L->v[1], L->f, L->v[2], c1, c2);
+    auto launch = [&]() {      // in the precision the solver uses on this level (pl_stokes_mg_precision)
+        if (L->f32)
+            hipLaunchKernelGGL((k_vv_sweep2<0, float, float>), pl_grid_rows2(g), dim3(64, 4), 0, ctx->stream, L->opf, (const float*)L->vf[0],
+                               (const float*)L->vf[1], (const float*)L->ff, L->vf[2], (float)c1, (float)c2, 1.0f);
+        else
+            hipLaunchKernelGGL((k_vv_sweep2<0, double, double>), pl_grid_rows2(g), dim3(64, 4), 0, ctx->stream, L->op, (const double*)L->v[0],
+                               (const double*)L->v[1], (const double*)L->f, L->v[2], c1, c2, 1.0);
     };
     launch();
     PL_TRY(pl_timer_start(ctx));

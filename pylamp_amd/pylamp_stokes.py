@@ -119,6 +119,17 @@ class StokesOperator:
         self._ctx.check(self._ctx.lib.pl_stokes_mg_info(self._ctx.handle(), C.byref(n), lm, 32))
         return n.value, [lm[k] for k in range(n.value)]
 
+    def mg_precision(self):
+        """(levels, levels in FP32) of the multigrid hierarchy of the last solve."""
+        n = C.c_int(); nf = C.c_int()
+        self._ctx.check(self._ctx.lib.pl_stokes_mg_precision(self._ctx.handle(), C.byref(n), C.byref(nf)))
+        return n.value, nf.value
+
+    def set_mg_precision(self, fp32, min_nodes=0):
+        """True: the large multigrid levels store and sweep in FP32 (default: all FP64; BiCGStab is FP64 either way).
+        min_nodes > 0: smallest level that runs in FP32 (default 200000 nodes)."""
+        self._ctx.check(self._ctx.lib.pl_stokes_set_mg_precision(self._ctx.handle(), int(bool(fp32)), int(min_nodes)))
+
     def tocsc(self):
         """Explicit scipy CSC equal to the reference's matrix (probing: every row reaches
         only nodes within +-1 in i and j, so 3x3x3 colours separate all its entries)."""
