@@ -183,6 +183,11 @@ __global__ __launch_bounds__(256) void k_scatter_binned(PlScatterArgs a, int til
     }
 }
 
+// (Tried and removed: PL_PRIV_COPIES = 16 private copies of the window in LDS, lane l adding into copy l & 15 -- no same-
+// address conflicts, no run sums, (nf+1) x 4 ds_add_f64 per marker from all 64 lanes.  9.6 ms against 6.4 ms for the
+// four scatters of a step: ds_add_f64 retires about one LANE per cycle and CU, so the atomics themselves -- 52 per marker
+// -- become the bound.  The run sums above cut them 16-fold; that is why they pay despite ~20 VALU instructions each.)
+
 // out = g^-1(acc / den), written into a ring/pitch plane or a dense (nz,nx) array
 // acc / den point at the accumulator element of output node (0,0); acc_pitch = accumulator columns
 __global__ __launch_bounds__(256) void k_scatter_finalize(int nz, int nx, const double* __restrict__ acc,

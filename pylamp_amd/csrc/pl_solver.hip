@@ -391,8 +391,19 @@ __global__ __launch_bounds__(256) void k_vv_first2(PlVvOpT<T> op, const T* __res
     typedef typename PlVec2<T>::type V2;
     const PlGeom& g = op.g;
     const int lane = threadIdx.x;
-    const int lj0 = (blockIdx.x * 64 + lane) * 2;
-    const int li = blockIdx.y * 4 + threadIdx.y;
+    // only_slow == 2: a 1-D launch over the FRAME of workgroups that can hold a slow wave (first / last two block rows,
+    // first / last two block columns, the anchor's blocks) instead of the whole grid, most of which would exit at once
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (only_slow == 2) {
+        const int nbx = (g.lnx + 127) / 128, nby = (g.lnz + 3) / 4;
+        int q = blockIdx.x;
+        if (q < 3 * nbx) { bx = q % nbx; by = q / nbx == 0 ? 0 : nby - (q / nbx); }
+        else if ((q -= 3 * nbx) < 3 * nby) { bx = q / nby == 0 ? 0 : nbx - (q / nby); by = q % nby; }     // column nx-2 can sit in the last but one
+        else { q -= 3 * nby; bx = (anchor_j - g.gj0) / 128; by = (anchor_i + q - g.gi0) / 4; }
+        if (bx < 0 || bx >= nbx || by < 0 || by >= nby) return;
+    }
+    const int lj0 = (bx * 64 + lane) * 2;
+    const int li = by * 4 + threadIdx.y;
     if (li >= g.lnz) return;                                // wave-uniform
     const bool active = lj0 < g.lnx;
     const bool has_right = (lj0 + 2) < g.lnx;
@@ -400,10 +411,10 @@ __global__ __launch_bounds__(256) void k_vv_first2(PlVvOpT<T> op, const T* __res
     const long long PLN = g.plane;
     const int c = (int)pl_idx(g, li, lj0);
     const int i = g.gi0 + li, j0 = g.gj0 + lj0;
-    const int jw = g.gj0 + blockIdx.x * 128;
-    if (only_slow && stage1_fast_wave(g, i, jw, blockIdx.x, anchor_i, anchor_j)) return;
+    const int jw = g.gj0 + bx * 128;
+    if (only_slow && stage1_fast_wave(g, i, jw, bx, anchor_i, anchor_j)) return;
     // walls, slaves, stabilised rows, or a wave that sticks out of the block (wave-uniform)
-    if (only_slow || i <= 0 || i >= nz - 2 || jw < 1 || jw + 127 > nx - 3 || op.szz || blockIdx.x * 128 + 127 >= g.lnx) {
+    if (only_slow || i <= 0 || i >= nz - 2 || jw < 1 || jw + 127 > nx - 3 || op.szz || bx * 128 + 127 >= g.lnx) {
         if (!active) return;
         for (int q = 0; q < 2 && lj0 + q < g.lnx; q++) cheb_first_node(op, f, out, c2, i, j0 + q, c + q);
         return;
@@ -755,13 +766,15 @@ __global__ __launch_bounds__(256) void k_dot5(PlGeom g, int nplanes, const doubl
     __syncthreads();
     if (threadIdx.x < 5) part[5 * blockIdx.x + threadIdx.x] = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
 }
-// sums of the k_dot5 partials -> out[8..12]; derive = 1: also omega -> out[3], rho' -> out[5], |r|^2 -> out[6]
+// sums of the k_dot5 partials -> out[8..12]; derive = 1: also omega -> out[3], rho' -> out[5], |r|^2 -> out[6], next beta -> out[7]
+// (out[2] = alpha and out[4] = rho were left there by the first reduction point of the iteration)
 __device__ inline void bicg_derive(double* __restrict__ out) {
     const double ts = out[8], tt = out[9], rts = out[10], rtt = out[11], ss = out[12];
     const double om = (tt > 0.0) ? ts / tt : 0.0;       // t = 0: s is already the residual
     out[3] = om; out[5] = rts - om * rtt;
     const double rr = ss - 2.0 * om * ts + om * om * tt;
     out[6] = rr > 0.0 ? rr : 0.0;
+    out[7] = (out[5] / out[4]) * (out[2] / om);          // beta of the NEXT iteration: (rho' / rho) (alpha / omega)
 }
 __global__ __launch_bounds__(256) void k_sum_partials5(int nb, const double* __restrict__ part, double* __restrict__ out, int derive) {
     __shared__ double sh[5][4];
@@ -1141,8 +1154,12 @@ struct PlSolver {
     // (~235 us of a 730 us preconditioner application at 2049^2 with the GPU idle), the fine ones pure bandwidth.
     // The NumPy prototype needs the same number of BiCGStab iterations either way (tools/early_coarse.py: mantle model,
     // 129^2: 33 / 33 / 32 for K = off / 2 / 3; 257^2: 36 / 37 / 35 / 36 for off / 2 / 3 / 4).
-    // PYLAMP_MG_EARLY=K (0: off; default: automatic, the first level of <= early_max_nodes nodes on large grids).
-    int early_knob = -1; long long early_max_nodes = 300000;
+    // On the GPU (2049^2, K = 2 / 3 / 4) the branch costs 2-4 more iterations than the standard cycle (V(1,1) + V(3,3) smooth
+    // harder than the prototype's V(2,2), so more of what the coarse levels are asked to remove is already gone), the
+    // coarse kernels run 1.5-3 x slower while the bandwidth-bound fine kernels are in flight, and the 100 us tail kernel
+    // stays on the critical path: 74-78 ms per solve against 73-74.  OFF by default.
+    // PYLAMP_MG_EARLY=K switches it on (-1: automatic K, the first level of <= early_max_nodes nodes on large grids).
+    int early_knob = 0; long long early_max_nodes = 300000;
     int early_K = 0;                         // decided by build_hierarchy
     hipStream_t stream2 = nullptr; hipEvent_t ev_f = nullptr, ev_b = nullptr;
 };
@@ -1213,7 +1230,7 @@ static int dmalloc0(pl_ctx* ctx, double** p, size_t bytes) {
 // alpha and omega are produced and consumed on the device (sc[0], sc[1] hold the two sums of the last
 // dots_dev call; sc[2] = alpha, sc[3] = omega): two of the three host round trips per iteration (~30 us of
 // idle GPU each) disappear; the third (rho, ||r||) stays because the host decides whether to go on.
-__global__ void k_scalar_alpha(double* __restrict__ sc, double rho_new) { sc[2] = rho_new / sc[0]; }
+__global__ void k_scalar_alpha(double* __restrict__ sc, double rho_new) { sc[2] = rho_new / sc[0]; sc[4] = rho_new; }
 __global__ void k_scalar_omega(double* __restrict__ sc) { sc[3] = (sc[1] > 0.0) ? sc[0] / sc[1] : 0.0; }   // t = 0: s is already the residual
 // y = a - alpha b
 __global__ void k_s_update_dev(long long n, double* __restrict__ y, const double* __restrict__ a, const double* __restrict__ b,
@@ -1223,6 +1240,20 @@ __global__ void k_s_update_dev(long long n, double* __restrict__ y, const double
     for (; k < n; k += (long long)gridDim.x * blockDim.x) y[k] = a[k] - alpha * b[k];
 }
 // x += alpha y + omega z ; r = s - omega t
+// x += alpha y + omega z ; r = s - omega t ; and the NEXT iteration's direction p = r + beta (p - omega v) in the same
+// pass (beta from the fused reduction, sc[7]): r is not read back, 10 instead of 13 vector passes
+__global__ void k_xrp_update_dev(long long n, double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z,
+                                 double* __restrict__ r, const double* __restrict__ s, const double* __restrict__ t,
+                                 double* __restrict__ p, const double* __restrict__ v, const double* __restrict__ sc) {
+    const double alpha = sc[2], omega = sc[3], beta = sc[7];
+    long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; k < n; k += (long long)gridDim.x * blockDim.x) {
+        x[k] += alpha * y[k] + omega * z[k];
+        const double rn = s[k] - omega * t[k];
+        r[k] = rn;
+        p[k] = rn + beta * (p[k] - omega * v[k]);
+    }
+}
 __global__ void k_xr_update_dev(long long n, double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z,
                                 double* __restrict__ r, const double* __restrict__ s, const double* __restrict__ t,
                                 const double* __restrict__ sc) {
@@ -1245,7 +1276,7 @@ __global__ __launch_bounds__(256) void k_sum_partials(int nb, const double* __re
     if (threadIdx.x == 0) {
         const double a0 = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3], a1 = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
         out[0] = a0; out[1] = a1;
-        if (mode == 1) out[2] = rho_new / a0;
+        if (mode == 1) { out[2] = rho_new / a0; out[4] = rho_new; }
         if (mode == 2) out[3] = (a1 > 0.0) ? a0 / a1 : 0.0;
     }
 }
@@ -1565,7 +1596,7 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
     PL_TRY(setup_f32_levels(ctx, S));
     // early coarse branch: first level of at most early_max_nodes nodes, on one rank, when at least two levels lie above it
     S->early_K = 0;
-    if (ctx->nranks == 1 && S->early_knob != 0 && !S->levels[0]->f32) {
+    if (ctx->nranks == 1 && S->early_knob != 0 && !S->levels[0]->f32 && S->levels.size() > 2) {
         int K = S->early_knob > 0 ? S->early_knob : 0;
         if (K == 0 && (long long)ctx->nz * ctx->nx >= 1000000LL)
             for (size_t l = 2; l < S->levels.size(); l++)
@@ -1639,9 +1670,11 @@ static bool smooth(pl_ctx* ctx, MgLevel* L, T* buf[3], const T* f, int nsweep, d
         T* dst = buf[2];
         if (k == 0 && zero_guess) {        // buf[0] is NOT read (and need not be zeroed); never the final sweep of level 0 (a
                                            // V-cycle with a coarse level has a prolongation before its last sweep)
-            if (g_vv_vec && first_done_anchor)        // stage 1 wrote the interior waves of this sweep already (into dst = buf[2])
-                hipLaunchKernelGGL(k_vv_first2<T>, pl_grid_rows2(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, f - sh, dst - sh, (T)c2, 1,
+            if (g_vv_vec && first_done_anchor) {      // stage 1 wrote the interior waves of this sweep already (into dst = buf[2])
+                const dim3 full = pl_grid_rows2(V.op.g);
+                hipLaunchKernelGGL(k_vv_first2<T>, dim3(3 * full.x + 3 * full.y + 2), dim3(64, 4), 0, ctx->stream, V.op, f - sh, dst - sh, (T)c2, 2,
                                    first_done_anchor[0], first_done_anchor[1]);
+            }
             else if (g_vv_vec) hipLaunchKernelGGL(k_vv_first2<T>, pl_grid_rows2(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, f - sh, dst - sh, (T)c2, 0, -9, -9);
             else hipLaunchKernelGGL(k_vv_cheb_first<T>, pl_grid_rows(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, f - sh, dst - sh, (T)c2,
                                     pl_row_iters(V.op.g));
@@ -1992,6 +2025,7 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
         PL_HIP(ctx, hipMemsetAsync(w.p, 0, bytes, ctx->stream));
         PL_HIP(ctx, hipMemsetAsync(w.v, 0, bytes, ctx->stream));
         double rho = 1.0, alpha = 1.0, omega = 1.0;
+        bool p_fused = false;                       // p of the coming iteration was already written by k_xrp_update_dev
         PL_TRY(dots(ctx, S, g, np, w.rt, w.r, w.r, w.r, d2));
         double rho_new = d2[0], rnorm = std::sqrt(d2[1]);
         if (restarts == 0) best = rnorm;
@@ -2004,7 +2038,7 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
             it++;
             if (!(std::fabs(rho_new) > 0.0) || !std::isfinite(rho_new)) { broke = true; break; }
             const double beta = (rho_new / rho) * (alpha / omega);
-            hipLaunchKernelGGL(k_p_update, grid1d(n), dim3(256), 0, ctx->stream, n, w.p, w.r, w.v, beta, omega);
+            if (!p_fused) hipLaunchKernelGGL(k_p_update, grid1d(n), dim3(256), 0, ctx->stream, n, w.p, w.r, w.v, beta, omega);
             const double* yv = w.p;
             if (M) { PL_TRY((*M)(w.p, w.y)); yv = w.y; }
             PL_TRY(A(yv, w.v));
@@ -2016,7 +2050,12 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
                 if (M) { PL_TRY((*M)(w.s, w.z)); zv = w.z; }
                 PL_TRY(A(zv, w.t));
                 PL_TRY(dots5_dev(ctx, S, g, np, w.t, w.s, w.rt));            // omega, rho' and |r|^2 from ONE reduction
-                hipLaunchKernelGGL(k_xr_update_dev, grid1d(n), dim3(256), 0, ctx->stream, n, dx, yv, zv, w.r, w.s, w.t, S->scal);
+                // ... and the next direction in the same pass (the host's beta above is then only the breakdown test)
+                if (yv != w.p) {
+                    hipLaunchKernelGGL(k_xrp_update_dev, grid1d(n), dim3(256), 0, ctx->stream, n, dx, yv, zv, w.r, w.s, w.t, w.p, w.v, S->scal);
+                    p_fused = true;
+                } else            // no preconditioner: y IS p
+                    hipLaunchKernelGGL(k_xr_update_dev, grid1d(n), dim3(256), 0, ctx->stream, n, dx, yv, zv, w.r, w.s, w.t, S->scal);
                 PL_HIP(ctx, hipMemcpyAsync(S->hpart + 5 * DOT_BLOCKS, S->scal + 2, 5 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
                 PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 rho = rho_new;
