@@ -284,6 +284,23 @@ def main():
         roof = kernel_roofline(sim, args.apply_reps)
         stage_keys = ["ms_sort", "ms_props", "ms_scatter", "ms_stokes", "ms_heat", "ms_gather", "ms_advect", "ms_total"]
         stages = {k: round(float(np.mean([r[k] for r in timed])), 3) for k in stage_keys}
+        # marker stages against the HBM roof: algorithmic bytes of one step (this rank's tracers and nodes) over the stage's
+        # wall time (host-timed with a stream sync each side, so launch gaps are inside -- these stages are 1.7-6 ms long).
+        #   scatter  4 passes: positions 16 B + 8 B per field read per marker (6 + 1 + 1 + 1 fields = 136 B / marker), one
+        #            weight and nf value accumulators read-modify-written and nf planes written per node (208 B / node)
+        #   rk4      positions read and written, velocities written: 48 B / marker (the 32 velocity gathers per marker hit
+        #            a cache-resident window)
+        #   sort     key pass 16 B + placement 12 B + permutation of 17 columns + index 2 x 144 B = 316 B / marker
+        _, ni_, _, nj_, _, _ = sim.ctx.local_block()
+        nt, nn = float(sim.ntrac), float(ni_ * nj_)
+
+        def stage_roof(ms, nbytes, what):
+            gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                    "algorithmic_bytes_per_step": nbytes, "ms": ms, "bytes": what}
+        roof["scatter"] = stage_roof(stages["ms_scatter"], 136.0 * nt + 208.0 * nn, "136 B/marker + 208 B/node")
+        roof["rk4"] = stage_roof(stages["ms_advect"], 48.0 * nt, "48 B/marker")
+        roof["sort"] = stage_roof(stages["ms_sort"], 316.0 * nt, "316 B/marker")
         out = {
             "metric": "stokes_heat_mic_cell_updates_per_s", "value": round(value, 1), "unit": "cell-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),

@@ -27,6 +27,9 @@ struct PlScatterArgs {
     // cell_start[ci*ncx+cj+1]); the sort grid has ncz x ncx cells.  NULL -> unsorted path.
     const int* cell_start; int ncz, ncx;
     int crow0, ccol0;           // global cell row / column of sort cell (0,0)
+    // target node set shifted by half a cell against the sort cells along z / x (cell centres, mid-faces): the markers of a
+    // sort cell then reach 3 instead of 2 node rows / columns (informational)
+    int stag_z, stag_x;
 };
 
 // tile of sort cells handled by one workgroup of the LDS-binned scatter

@@ -188,6 +188,12 @@ __global__ __launch_bounds__(256) void k_scatter_binned(PlScatterArgs a, int til
 // four scatters of a step: ds_add_f64 retires about one LANE per cycle and CU, so the atomics themselves -- 52 per marker
 // -- become the bound.  The run sums above cut them 16-fold; that is why they pay despite ~20 VALU instructions each.)
 
+// (Also tried and removed: per-cell serial sums through LDS -- phase A one lane per marker writes its slot weights and
+// values to LDS, phase B one lane per (sort cell, accumulator, slot row) adds up the cell's ~16 markers serially, no
+// atomics and no cross-lane steps at all.  Correct (the GPU suite passed), but 15.3 ms against 6.3 ms for the four scatters
+// of a step: ~84 dependent LDS reads per marker from lanes that all sit at different addresses, two barriers per 256
+// markers and 58 KB of LDS per workgroup (8 waves per CU) cost more than the DPP steps they replace.)
+
 // out = g^-1(acc / den), written into a ring/pitch plane or a dense (nz,nx) array
 // acc / den point at the accumulator element of output node (0,0); acc_pitch = accumulator columns
 __global__ __launch_bounds__(256) void k_scatter_finalize(int nz, int nx, const double* __restrict__ acc,

@@ -868,6 +868,7 @@ static int scatter_to_planes(pl_ctx* ctx, PlStepState* S, int nf, const int* fid
     a.z0 = z0; a.hz = hz; a.x0 = x0; a.hx = hx; a.nz = g.nz; a.nx = g.nx;
     a.zc = coords_z(ctx, S, stag_z); a.xc = coords_x(ctx, S, stag_x);
     a.cell_start = S->cell_start; a.ncz = S->ncz; a.ncx = S->ncx; a.crow0 = S->crow0; a.ccol0 = S->ccol0;     // cell-sorted (sort_tracers)
+    a.stag_z = stag_z; a.stag_x = stag_x;
     return pl_scatter_device(ctx, a, planes, g.pitch, pl_idx(g, 0, 0), &g);
 }
 
