@@ -154,8 +154,9 @@ def test_unattainable_tolerance_returns_best_iterate():
 
 def test_cross_check_kernel_variants(oracle):
     """The scalar one-column-per-lane multigrid kernels (PYLAMP_VV_VEC=0) and the host-scalar BiCGStab loop
-    (PYLAMP_HOST_SCALARS=1) are kept as cross-checks of the vectorised / device-scalar defaults: same problem,
-    every variant must reach the oracle's direct solution, with iteration counts in the same range."""
+    (PYLAMP_HOST_SCALARS=1) are kept as cross-checks of the vectorised / device-scalar defaults, and the optional FP32
+    multigrid levels and early coarse branch must not change the answer either: same problem, every variant must
+    reach the oracle's direct solution, with iteration counts in the same range."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = r'''
@@ -181,7 +182,13 @@ err = float(np.sqrt((np.sum((vz - rz) ** 2) + np.sum((vx - rx) ** 2)) / (np.sum(
 print("RESULT", json.dumps(dict(its=A.last_stats["iterations"], conv=A.last_stats["converged"], err=err)))
 ''' % root
     res = {}
-    for name, env in (("default", {}), ("scalar_kernels", {"PYLAMP_VV_VEC": "0"}), ("host_scalars", {"PYLAMP_HOST_SCALARS": "1"})):
+    variants = (("default", {}), ("scalar_kernels", {"PYLAMP_VV_VEC": "0"}), ("host_scalars", {"PYLAMP_HOST_SCALARS": "1"}),
+                # optional paths (off by default, DESIGN.md section 5): FP32 multigrid levels under the FP64 BiCGStab, with the
+                # vectorised and with the scalar kernels; the early coarse branch on a second stream
+                ("fp32_levels", {"PYLAMP_MG_FP32": "1", "PYLAMP_MG_FP32_NODES": "1000"}),
+                ("fp32_levels_scalar_kernels", {"PYLAMP_MG_FP32": "1", "PYLAMP_MG_FP32_NODES": "1000", "PYLAMP_VV_VEC": "0"}),
+                ("early_coarse_branch", {"PYLAMP_MG_EARLY": "1"}))
+    for name, env in variants:
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
         assert r.returncode == 0, (name, r.stderr[-1500:])
         line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0]
@@ -200,3 +207,32 @@ def test_randomised_solve_campaign():
                        timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "failures: 0" in r.stdout, r.stdout[-3000:]
+
+
+def test_fp32_multigrid_levels_report_and_agree():
+    """pl_stokes_set_mg_precision / pl_stokes_mg_precision: with FP32 levels the preconditioner is the FP64 one up to
+    single-precision rounding, the solve converges to the same solution (BiCGStab, the operator and the stopping test
+    stay FP64), and the constraint rows of the preconditioned direction are closed exactly."""
+    from pylamp_amd import pylamp_stokes as S
+    n = 257; nx = [n, n]; L = [660e3, 500e3]
+    grid = [np.linspace(0, L[0], n), np.linspace(0, L[1], n)]
+    Z, X = np.meshgrid(*grid, indexing='ij')
+    gm = [np.append(0.5 * (g[1:] + g[:-1]), g[-1] + 0.5 * (g[-1] - g[-2])) for g in grid]
+    Zc, Xc = np.meshgrid(*gm, indexing='ij')
+    f = lambda z, x: 1e20 * 10 ** (1.5 * np.sin(2 * np.pi * x / L[1]) * np.cos(np.pi * z / L[0]))
+    rho = 3300 + 40 * np.sin(2 * np.pi * X / L[1]) * np.sin(np.pi * Z / L[0])
+    A, rhs = S.makeStokesMatrix(nx, grid, f(Z, X), f(Zc, Xc), rho, [1, 1, 1, 1])
+    out = {}
+    for fp32 in (False, True):
+        A.set_mg_precision(fp32, 1000)
+        x = S.solve(A, rhs)
+        st = dict(A.last_stats)
+        nl, nf = A.mg_precision()
+        assert st["converged"] == 1, (fp32, st)
+        assert (nf > 0) == fp32 and nf < nl, (fp32, nl, nf)
+        out[fp32] = (x, st["iterations"])
+    A.set_mg_precision(False, 200000)
+    (x0, it0), (x1, it1) = out[False], out[True]
+    v = lambda x: x.reshape(n, n, 3)[:, :, :2]
+    assert np.linalg.norm(v(x1) - v(x0)) / np.linalg.norm(v(x0)) < 1e-8
+    assert it1 <= 1.5 * it0 + 5, (it0, it1)

@@ -59,12 +59,15 @@ def side(name, grid):
 
 out = {"_provenance": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on tools/pmc_run.py, MI355X, %s; FETCH_SIZE "
                       "doubled per MI355X_MICROARCH.md; bytes per launch (median over dispatches), Infinity-Cache hits included" % tag,
-       "_commit": subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip(),
+       "_commit": os.environ.get("PYLAMP_COMMIT") or subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip(),
        "_triad_calibration": calib}
 names = {"k_stokes_apply_v2<4, true>": "k_stokes_apply_scaled", "k_stokes_apply_v2<16, true>": "k_stokes_apply_scaled",
          "k_stokes_apply_v2<4, false>": "k_stokes_apply", "k_stokes_apply_v2<16, false>": "k_stokes_apply",
          "k_vv_sweep2<0>": "k_vv_sweep2_cheb", "k_vv_sweep2<1>": "k_vv_sweep2_residual", "k_prec_stage1_v2": "k_prec_stage1_v2",
-         "k_vv_first2": "k_vv_first2"}
+         "k_vv_first2": "k_vv_first2",
+         # names since the multigrid kernels are templates over the level type
+         "k_vv_sweep2<0, double, double>": "k_vv_sweep2_cheb", "k_vv_sweep2<1, double, double>": "k_vv_sweep2_residual",
+         "k_prec_stage1_v2<double>": "k_prec_stage1_v2", "k_vv_first2<double>": "k_vv_first2"}
 rows = []
 for (name, grid), fb in sorted(F.items()):
     wb = W.get((name, grid), 0.0)
