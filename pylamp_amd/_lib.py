@@ -18,7 +18,7 @@ c_int_p = C.POINTER(C.c_int)
 class SolveStats(C.Structure):
     _fields_ = [("iterations", C.c_int), ("converged", C.c_int), ("rel_residual", C.c_double),
                 ("solve_ms", C.c_double), ("operator_applies", C.c_int), ("precond_applies", C.c_int),
-                ("used_direct", C.c_int), ("reserved_", C.c_int)]
+                ("used_direct", C.c_int), ("reserved_", C.c_int), ("error_estimate", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -692,6 +692,7 @@ __global__ __launch_bounds__(256) void k_coarsen_visc(PlGeom gf, const double* _
 // no atomics; the host adds the (<= DOT_BLOCKS) partials in a fixed order, so the result is
 // deterministic.
 #define DOT_BLOCKS 1024
+#define PL_SCAL_N 24            // device scalars in front of the dot partials (PlSolver::scal)
 template <bool HAS_A, bool HAS_C>
 __global__ __launch_bounds__(256) void k_dot2(PlGeom g, int nplanes, const double* __restrict__ a,
                                               const double* __restrict__ b, const double* __restrict__ cc,
@@ -735,38 +736,46 @@ __global__ __launch_bounds__(256) void k_dot2(PlGeom g, int nplanes, const doubl
 //   part[5b..] = (t.s, t.t, r~.s, r~.t, s.s)
 // from which omega = ts/tt and -- algebraically, r = s - omega t -- rho' = r~.r = r~.s - omega r~.t and
 // |r|^2 = s.s - 2 omega t.s + omega^2 t.t follow without another pass over r (and without a third all-reduce).
-__global__ __launch_bounds__(256) void k_dot5(PlGeom g, int nplanes, const double* __restrict__ t, const double* __restrict__ sv,
+__global__ __launch_bounds__(256) void k_dot5(PlGeom g, int nplanes, int nsplit, const double* __restrict__ t, const double* __restrict__ sv,
                                               const double* __restrict__ rt, double* __restrict__ part) {
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0;
+    // a5..a7: t.s, t.t, s.s over the planes >= nsplit only (the continuity block of the Stokes residual, see bicgstab)
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0, a6 = 0.0, a7 = 0.0;
     const long long rows = (long long)g.lnz * nplanes;
     const int npair = g.lnx >> 1;
     for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
         const int q = (int)(r / g.lnz), li = (int)(r % g.lnz);
         const long long base = pl_idx(g, li, 0) + q * g.plane;
+        double b0 = 0.0, b1 = 0.0, b4 = 0.0;                    // this row's t.s, t.t, s.s
 #pragma unroll 2
         for (int k = threadIdx.x; k < npair; k += 256) {
             const long long o = base + 2 * k;
             const double2 T = *reinterpret_cast<const double2*>(t + o), Sv = *reinterpret_cast<const double2*>(sv + o),
                           Rt = *reinterpret_cast<const double2*>(rt + o);
-            a0 += T.x * Sv.x + T.y * Sv.y; a1 += T.x * T.x + T.y * T.y; a2 += Rt.x * Sv.x + Rt.y * Sv.y;
-            a3 += Rt.x * T.x + Rt.y * T.y; a4 += Sv.x * Sv.x + Sv.y * Sv.y;
+            b0 += T.x * Sv.x + T.y * Sv.y; b1 += T.x * T.x + T.y * T.y; a2 += Rt.x * Sv.x + Rt.y * Sv.y;
+            a3 += Rt.x * T.x + Rt.y * T.y; b4 += Sv.x * Sv.x + Sv.y * Sv.y;
         }
         if ((g.lnx & 1) && threadIdx.x == 0) {
             const long long o = base + g.lnx - 1;
-            a0 += t[o] * sv[o]; a1 += t[o] * t[o]; a2 += rt[o] * sv[o]; a3 += rt[o] * t[o]; a4 += sv[o] * sv[o];
+            b0 += t[o] * sv[o]; b1 += t[o] * t[o]; a2 += rt[o] * sv[o]; a3 += rt[o] * t[o]; b4 += sv[o] * sv[o];
         }
+        a0 += b0; a1 += b1; a4 += b4;
+        if (q >= nsplit) { a5 += b0; a6 += b1; a7 += b4; }      // row-uniform
     }
-    __shared__ double sh[5][4];
+    __shared__ double sh[8][4];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         a0 += __shfl_down(a0, o, 64); a1 += __shfl_down(a1, o, 64); a2 += __shfl_down(a2, o, 64);
-        a3 += __shfl_down(a3, o, 64); a4 += __shfl_down(a4, o, 64);
+        a3 += __shfl_down(a3, o, 64); a4 += __shfl_down(a4, o, 64); a5 += __shfl_down(a5, o, 64);
+        a6 += __shfl_down(a6, o, 64); a7 += __shfl_down(a7, o, 64);
     }
-    if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; sh[0][w] = a0; sh[1][w] = a1; sh[2][w] = a2; sh[3][w] = a3; sh[4][w] = a4; }
+    if ((threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+        sh[0][w] = a0; sh[1][w] = a1; sh[2][w] = a2; sh[3][w] = a3; sh[4][w] = a4; sh[5][w] = a5; sh[6][w] = a6; sh[7][w] = a7;
+    }
     __syncthreads();
-    if (threadIdx.x < 5) part[5 * blockIdx.x + threadIdx.x] = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
+    if (threadIdx.x < 8) part[8 * blockIdx.x + threadIdx.x] = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
 }
-// sums of the k_dot5 partials -> out[8..12]; derive = 1: also omega -> out[3], rho' -> out[5], |r|^2 -> out[6], next beta -> out[7]
+// sums of the k_dot5 partials -> out[8..15] (8..12: t.s, t.t, rt.s, rt.t, s.s; 13..15: t.s, t.t, s.s of the continuity planes); derive = 1: also omega -> out[3], rho' -> out[5], |r|^2 -> out[6], next beta -> out[7]
 // (out[2] = alpha and out[4] = rho were left there by the first reduction point of the iteration)
 __device__ inline void bicg_derive(double* __restrict__ out) {
     const double ts = out[8], tt = out[9], rts = out[10], rtt = out[11], ss = out[12];
@@ -777,19 +786,19 @@ __device__ inline void bicg_derive(double* __restrict__ out) {
     out[7] = (out[5] / out[4]) * (out[2] / om);          // beta of the NEXT iteration: (rho' / rho) (alpha / omega)
 }
 __global__ __launch_bounds__(256) void k_sum_partials5(int nb, const double* __restrict__ part, double* __restrict__ out, int derive) {
-    __shared__ double sh[5][4];
-    double a[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    __shared__ double sh[8][4];
+    double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     for (int k = threadIdx.x; k < nb; k += 256)
 #pragma unroll
-        for (int q = 0; q < 5; q++) a[q] += part[5 * k + q];
+        for (int q = 0; q < 8; q++) a[q] += part[8 * k + q];
 #pragma unroll
-    for (int q = 0; q < 5; q++) {
+    for (int q = 0; q < 8; q++) {
         for (int o = 32; o > 0; o >>= 1) a[q] += __shfl_down(a[q], o, 64);
         if ((threadIdx.x & 63) == 0) sh[q][threadIdx.x >> 6] = a[q];
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int q = 0; q < 5; q++) out[8 + q] = sh[q][0] + sh[q][1] + sh[q][2] + sh[q][3];
+        for (int q = 0; q < 8; q++) out[8 + q] = sh[q][0] + sh[q][1] + sh[q][2] + sh[q][3];
         if (derive) bicg_derive(out);
     }
 }
@@ -1117,7 +1126,7 @@ struct PlSolver {
     // BiCGStab work vectors (3 planes each)
     double *r = nullptr, *rt = nullptr, *p = nullptr, *v = nullptr, *s = nullptr, *t = nullptr, *y = nullptr,
            *z = nullptr, *b = nullptr, *x = nullptr, *xb = nullptr, *dx = nullptr, *r0 = nullptr, *xh = nullptr;
-    double* scal = nullptr;     // device scalars [0..16) + dot partials [16..16+5*DOT_BLOCKS)
+    double* scal = nullptr;     // device scalars [0..PL_SCAL_N) + dot partials [PL_SCAL_N .. PL_SCAL_N + 8*DOT_BLOCKS)
     double* hpart = nullptr;    // pinned host copy of the dot partials
     int nu_pre = 2, nu_post = 2, coarse_sweeps = 12;
     int nu0_pre = -1, nu0_post = -1;                    // finest level only (PYLAMP_MG_NU0), -1: as the other levels
@@ -1139,6 +1148,10 @@ struct PlSolver {
     // which A amplifies by (L/h)^2 relative to the signal: eps (L/h)^2 = 0.25 at 2049^2, and BiCGStab needs 41-49 instead of
     // 35-36 iterations (1025^2: 34-38 instead of 33).
     bool f32_enable = false; long long f32_min_nodes = 200000;
+    // velocity-error estimate that a converged Stokes solve must meet (bicgstab); PYLAMP_STOKES_ETOL, 0: off.  The estimate is
+    // within a factor ~3 of the true error where it was below it (and up to 60 x above it): 3e-8 keeps the error below 1e-7,
+    // a tenth of the 1e-6 the drop-in promises, so that quantities derived from maxima (the time step) stay within 1e-6 too
+    double etol = 3e-8;
     double kappa = 1.0, sigma = 1.0;     // scaling of the FP32 velocity solve (stokes_precond)
     double schur_scale = 1.0;    // S^ = schur_scale * Kc^2 / eta_n (PYLAMP_SCHUR_SCALE)
     bool fuse_first = true;      // PYLAMP_FUSE_FIRST=0: the first sweep of level 0 as a pass of its own
@@ -1179,6 +1192,7 @@ static PlSolver* solver_of(pl_ctx* ctx) {
         if (const char* e = getenv("PYLAMP_MG_HALO")) S->mg_halo = atoi(e);
         if (const char* e = getenv("PYLAMP_MG_DEEP")) S->deep = atoi(e) != 0;
         if (const char* e = getenv("PYLAMP_MG_EARLY")) S->early_knob = atoi(e);
+        if (const char* e = getenv("PYLAMP_STOKES_ETOL")) { const double v = atof(e); if (v >= 0.0) S->etol = v; }
         if (const char* e = getenv("PYLAMP_MG_FP32")) S->f32_enable = atoi(e) != 0;
         if (const char* e = getenv("PYLAMP_MG_FP32_NODES")) { long long v = atoll(e); if (v >= 1) S->f32_min_nodes = v; }
         if (const char* e = getenv("PYLAMP_FUSE_FIRST")) S->fuse_first = atoi(e) != 0;
@@ -1285,19 +1299,19 @@ static int dots(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const double*
                 const double* d, double* out2) {
     long long rows = (long long)g.lnz * np;
     const int nb = (int)(rows < DOT_BLOCKS ? rows : DOT_BLOCKS);
-    if (a && c) hipLaunchKernelGGL((k_dot2<true, true>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 16);
-    else if (a) hipLaunchKernelGGL((k_dot2<true, false>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 16);
-    else hipLaunchKernelGGL((k_dot2<false, true>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 16);
+    if (a && c) hipLaunchKernelGGL((k_dot2<true, true>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + PL_SCAL_N);
+    else if (a) hipLaunchKernelGGL((k_dot2<true, false>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + PL_SCAL_N);
+    else hipLaunchKernelGGL((k_dot2<false, true>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + PL_SCAL_N);
     if (ctx->nranks > 1 && pl_geom_is_dist(g) && pl_comm_native_enabled(ctx)) {
         // slab + native RCCL: reduce on the device, all-reduce 2 doubles over xGMI, one 16-byte copy back
-        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, nb, S->scal + 16, S->scal);
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, nb, S->scal + PL_SCAL_N, S->scal);
         PL_TRY(pl_comm_allreduce_dev(ctx, S->scal, 2));
         PL_HIP(ctx, hipMemcpyAsync(S->hpart, S->scal, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
         out2[0] = S->hpart[0]; out2[1] = S->hpart[1];
         return 0;
     }
-    PL_HIP(ctx, hipMemcpyAsync(S->hpart, S->scal + 16, (size_t)2 * nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PL_HIP(ctx, hipMemcpyAsync(S->hpart, S->scal + PL_SCAL_N, (size_t)2 * nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     double s0 = 0.0, s1 = 0.0;
     for (int k = 0; k < nb; k++) { s0 += S->hpart[2 * k]; s1 += S->hpart[2 * k + 1]; }
@@ -1312,16 +1326,42 @@ static bool dots_on_device(pl_ctx* ctx, const PlGeom& g) {
     return true;       // pl_comm_allreduce_dev stages through the host on the non-native transports
 }
 // second reduction point of BiCGStab: omega -> scal[3], rho' -> scal[5], |r|^2 -> scal[6] (ONE all-reduce of 5 doubles)
-static int dots5_dev(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const double* t, const double* sv, const double* rt) {
+static int dots5_dev(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, int nsplit, const double* t, const double* sv, const double* rt) {
     long long rows = (long long)g.lnz * np;
     const int nb = (int)(rows < DOT_BLOCKS ? rows : DOT_BLOCKS);
-    hipLaunchKernelGGL(k_dot5, dim3(nb), dim3(256), 0, ctx->stream, g, np, t, sv, rt, S->scal + 16);
+    hipLaunchKernelGGL(k_dot5, dim3(nb), dim3(256), 0, ctx->stream, g, np, nsplit, t, sv, rt, S->scal + PL_SCAL_N);
     const bool reduce = ctx->nranks > 1 && pl_geom_is_dist(g);
-    hipLaunchKernelGGL(k_sum_partials5, dim3(1), dim3(256), 0, ctx->stream, nb, S->scal + 16, S->scal, reduce ? 0 : 1);
+    hipLaunchKernelGGL(k_sum_partials5, dim3(1), dim3(256), 0, ctx->stream, nb, S->scal + PL_SCAL_N, S->scal, reduce ? 0 : 1);
     if (reduce) {
-        PL_TRY(pl_comm_allreduce_dev(ctx, S->scal + 8, 5));
+        PL_TRY(pl_comm_allreduce_dev(ctx, S->scal + 8, 9));         // scal[16]: the local ||x_vel||^2 rides along (norm2_sum_local)
         hipLaunchKernelGGL(k_bicg_derive, dim3(1), dim3(1), 0, ctx->stream, S->scal);
     }
+    return 0;
+}
+// ||a + b||^2 over the interior nodes of the first nplanes planes -> S->scal[0] (b may be NULL)
+__global__ __launch_bounds__(256) void k_norm2_sum(PlGeom g, int nplanes, const double* __restrict__ a, const double* __restrict__ b,
+                                                   double* __restrict__ part) {
+    double s0 = 0.0;
+    const long long rows = (long long)g.lnz * nplanes;
+    for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
+        const int q = (int)(r / g.lnz), li = (int)(r % g.lnz);
+        const long long base = pl_idx(g, li, 0) + q * g.plane;
+        for (int k = threadIdx.x; k < g.lnx; k += 256) { const double v = a[base + k] + (b ? b[base + k] : 0.0); s0 += v * v; }
+    }
+    __shared__ double sh[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s0 += __shfl_down(s0, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s0;
+    __syncthreads();
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3]; part[2 * blockIdx.x + 1] = 0.0; }
+}
+// -> S->scal[16] (this rank's share when reduce = false: the fused reduction of the iteration all-reduces it)
+static int norm2_sum_dev(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const double* a, const double* b, bool reduce) {
+    long long rows = (long long)g.lnz * np;
+    const int nb = (int)(rows < DOT_BLOCKS ? rows : DOT_BLOCKS);
+    hipLaunchKernelGGL(k_norm2_sum, dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, S->scal + PL_SCAL_N);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, nb, S->scal + PL_SCAL_N, S->scal + 16, 0, 0.0);
+    if (reduce && ctx->nranks > 1 && pl_geom_is_dist(g)) PL_TRY(pl_comm_allreduce_dev(ctx, S->scal + 16, 2));
     return 0;
 }
 // sums of the two dot products into S->scal[0..1], no host synchronisation
@@ -1331,11 +1371,11 @@ static int dots_dev(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const dou
                     const double* d, int mode, double rho_new) {
     long long rows = (long long)g.lnz * np;
     const int nb = (int)(rows < DOT_BLOCKS ? rows : DOT_BLOCKS);
-    if (a && c) hipLaunchKernelGGL((k_dot2<true, true>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 16);
-    else if (a) hipLaunchKernelGGL((k_dot2<true, false>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 16);
-    else hipLaunchKernelGGL((k_dot2<false, true>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + 16);
+    if (a && c) hipLaunchKernelGGL((k_dot2<true, true>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + PL_SCAL_N);
+    else if (a) hipLaunchKernelGGL((k_dot2<true, false>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + PL_SCAL_N);
+    else hipLaunchKernelGGL((k_dot2<false, true>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + PL_SCAL_N);
     const bool reduce = ctx->nranks > 1 && pl_geom_is_dist(g);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, nb, S->scal + 16, S->scal, reduce ? 0 : mode, rho_new);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, nb, S->scal + PL_SCAL_N, S->scal, reduce ? 0 : mode, rho_new);
     if (reduce) {
         PL_TRY(pl_comm_allreduce_dev(ctx, S->scal, 2));
         if (mode == 1) hipLaunchKernelGGL(k_scalar_alpha, dim3(1), dim3(1), 0, ctx->stream, S->scal, rho_new);
@@ -1987,9 +2027,23 @@ struct BicgVecs { double *r, *rt, *p, *v, *s, *t, *y, *z; double* xbest; double 
 // meets rtol.
 // ref_norm > 0 replaces ||b|| as the reference of the stopping test and of rel_residual.
 #define PL_MAX_RESTARTS 4
+// etol > 0 (Stokes): the residual test alone does not bound the velocity error -- the ratio error / residual is ~10 on the
+// 513^2 mantle problem and ~2e4 on the coarse 33 x 41 fixture of the reference trajectory.  What the norm misses is the
+// CONTINUITY part of the residual: in the row-scaled system it is h div(v) / 2, a velocity, but it is compared with ||b||,
+// which is dominated by the momentum rows of the low-viscosity regions and can be 1e4 x the velocity scale; a divergence
+// error integrates over the domain, so the velocity error it causes is ~ (L/h) ||r_cont|| (measured on the fixture with
+// the NumPy prototype: 1.8e-4 of the 1.8e-4 velocity error at rtol 1e-10 comes from the continuity rows, tools/ratio.py).
+// The error of the first np_vel planes is therefore estimated as
+//     ( n ||r_cont|| + ||(M^-1 r)_vel|| ) / ||x_vel||,   n = max(nz, nx)
+// -- the second term is the velocity response to the momentum residual through one V-cycle -- (within a factor ~2 of the
+// true error on every case checked against direct or much tighter solves: 33x41, 41^2, 129^2, 513^2, 1025^2, 2049^2 with the
+// mantle and block models), and the solve ends when BOTH the residual meets rtol and the estimate
+// meets etol.  Near the end the estimate is evaluated in every iteration from the recurrence (the fused reduction also
+// returns the continuity block's share; one extra norm of the iterate); before the solve is declared converged it is
+// evaluated from the true residual, and if that fails the same iteration continues -- no restart.
 static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const VecOp& A, const VecOp* M,
                     const double* b, double* x, bool use_x0, double rtol, int maxit, BicgVecs w,
-                    pl_solve_stats* st, double ref_norm = 0.0) {
+                    pl_solve_stats* st, double ref_norm = 0.0, double etol = 0.0, int np_vel = 0) {
     const long long n = (long long)np * g.plane;
     const size_t bytes = (size_t)n * sizeof(double);
     double d2[2];
@@ -2020,21 +2074,40 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
     // BiCGStab is not monotone and, past the attainable accuracy, drifts and can blow up: keep the best
     // iterate, stop after 60 iterations without a new best or when the residual explodes, return the best.
     double best = 0.0; int best_it = 0; bool have_best = false;
+    double tol = rtol;                              // lowered when the velocity-error estimate asks for it
+    int est_checks = 0;
+    // velocity-error estimate (see above): from the recurrence residual in every iteration near the end, from the true
+    // residual before the solve is declared converged
+    const bool use_est = etol > 0.0 && np_vel > 0 && np > np_vel;
+    const double n_amp = (double)std::max(ctx->nz, ctx->nx);
+    double est_rec = 0.0;                           // 0: unknown (far from convergence) -- only the residual test applies
+    double a_mom = 1.0;                             // ||A_vv^-1 r_mom|| / ||r_mom|| as measured at the last true check (below)
+    auto estimate = [&](double rr_cont, double rr_total, double xx) {
+        const double rc = rr_cont > 0.0 ? rr_cont : 0.0, rm = rr_total - rc > 0.0 ? rr_total - rc : 0.0;
+        return xx > 0.0 ? (n_amp * std::sqrt(rc) + a_mom * std::sqrt(rm)) / std::sqrt(xx) : 0.0;
+    };
+    bool resume = false;                            // continue the running iteration instead of restarting it
+    double rho = 1.0, alpha = 1.0, omega = 1.0, rho_new = 0.0, rnorm = 0.0;
+    bool p_fused = false, broke = false;            // p_fused: p of the coming iteration was already written by k_xrp_update_dev
+    // scale of the FP32 velocity solve inside the preconditioner: v~ = kappa v = O(1) at the current residual level
+    const double sqrt_n = std::sqrt((double)np * ctx->nz * ctx->nx);
+    auto set_kappa = [&](double rn) { S->kappa = (std::isfinite(rn) && rn > 0.0) ? sqrt_n / rn : 1.0; };
+    st->error_estimate = 0.0;
     for (;;) {
-        // ---- (re)start from the residual in w.r
-        PL_HIP(ctx, hipMemsetAsync(w.p, 0, bytes, ctx->stream));
-        PL_HIP(ctx, hipMemsetAsync(w.v, 0, bytes, ctx->stream));
-        double rho = 1.0, alpha = 1.0, omega = 1.0;
-        bool p_fused = false;                       // p of the coming iteration was already written by k_xrp_update_dev
-        PL_TRY(dots(ctx, S, g, np, w.rt, w.r, w.r, w.r, d2));
-        double rho_new = d2[0], rnorm = std::sqrt(d2[1]);
-        if (restarts == 0) best = rnorm;
-        // scale of the FP32 velocity solve inside the preconditioner: v~ = kappa v = O(1) at the current residual level
-        const double sqrt_n = std::sqrt((double)np * ctx->nz * ctx->nx);
-        auto set_kappa = [&](double rn) { S->kappa = (std::isfinite(rn) && rn > 0.0) ? sqrt_n / rn : 1.0; };
-        set_kappa(rnorm);
-        bool broke = false;
-        while (it < maxit && rnorm > rtol * bnorm) {
+        if (!resume) {
+            // ---- (re)start from the residual in w.r
+            PL_HIP(ctx, hipMemsetAsync(w.p, 0, bytes, ctx->stream));
+            PL_HIP(ctx, hipMemsetAsync(w.v, 0, bytes, ctx->stream));
+            rho = alpha = omega = 1.0;
+            p_fused = false;
+            PL_TRY(dots(ctx, S, g, np, w.rt, w.r, w.r, w.r, d2));
+            rho_new = d2[0]; rnorm = std::sqrt(d2[1]);
+            if (restarts == 0) best = rnorm;
+            set_kappa(rnorm);
+            broke = false;
+        }
+        resume = false;
+        while (it < maxit && (rnorm > tol * bnorm || (use_est && est_rec > 0.7 * etol))) {
             it++;
             if (!(std::fabs(rho_new) > 0.0) || !std::isfinite(rho_new)) { broke = true; break; }
             const double beta = (rho_new / rho) * (alpha / omega);
@@ -2049,19 +2122,26 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
                 hipLaunchKernelGGL(k_s_update_dev, grid1d(n), dim3(256), 0, ctx->stream, n, w.s, w.r, w.v, S->scal);
                 if (M) { PL_TRY((*M)(w.s, w.z)); zv = w.z; }
                 PL_TRY(A(zv, w.t));
-                PL_TRY(dots5_dev(ctx, S, g, np, w.t, w.s, w.rt));            // omega, rho' and |r|^2 from ONE reduction
+                // near the end: ||x_vel||^2 for the error estimate (-> scal[16]; of the iterate BEFORE this update, so that
+                // it can ride along in the fused reduction -- the estimate needs it to ~10 %)
+                const bool want_xx = use_est && rnorm <= 1e3 * tol * bnorm;
+                if (want_xx) PL_TRY(norm2_sum_dev(ctx, S, g, np_vel, dx, dx != x ? (const double*)x : (const double*)nullptr, false));
+                PL_TRY(dots5_dev(ctx, S, g, np, use_est ? np_vel : np, w.t, w.s, w.rt));       // omega, rho' and |r|^2 from ONE reduction
                 // ... and the next direction in the same pass (the host's beta above is then only the breakdown test)
                 if (yv != w.p) {
                     hipLaunchKernelGGL(k_xrp_update_dev, grid1d(n), dim3(256), 0, ctx->stream, n, dx, yv, zv, w.r, w.s, w.t, w.p, w.v, S->scal);
                     p_fused = true;
                 } else            // no preconditioner: y IS p
                     hipLaunchKernelGGL(k_xr_update_dev, grid1d(n), dim3(256), 0, ctx->stream, n, dx, yv, zv, w.r, w.s, w.t, S->scal);
-                PL_HIP(ctx, hipMemcpyAsync(S->hpart + 5 * DOT_BLOCKS, S->scal + 2, 5 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+                double* hs = S->hpart + 8 * DOT_BLOCKS;
+                PL_HIP(ctx, hipMemcpyAsync(hs, S->scal, PL_SCAL_N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
                 PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 rho = rho_new;
-                alpha = S->hpart[5 * DOT_BLOCKS]; omega = S->hpart[5 * DOT_BLOCKS + 1];
-                rho_new = S->hpart[5 * DOT_BLOCKS + 3]; rnorm = std::sqrt(S->hpart[5 * DOT_BLOCKS + 4]);
+                alpha = hs[2]; omega = hs[3];
+                rho_new = hs[5]; rnorm = std::sqrt(hs[6]);
                 if (!std::isfinite(alpha)) { broke = true; break; }
+                if (want_xx) est_rec = estimate(hs[15] - 2.0 * omega * hs[13] + omega * omega * hs[14], hs[6], hs[16]);
+                else est_rec = 0.0;
             } else {
                 PL_TRY(dots(ctx, S, g, np, w.rt, w.v, nullptr, nullptr, d2));
                 if (!(std::fabs(d2[0]) > 0.0) || !std::isfinite(d2[0])) { broke = true; break; }
@@ -2080,6 +2160,14 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
                 rho = rho_new;
                 PL_TRY(dots(ctx, S, g, np, w.rt, w.r, w.r, w.r, d2));
                 rho_new = d2[0]; rnorm = std::sqrt(d2[1]);
+                if (use_est && rnorm <= 1e3 * tol * bnorm) {        // the same estimate as the device-scalar path, with host round trips
+                    double dc[2];
+                    PL_TRY(dots(ctx, S, g, np - np_vel, w.r + (long long)np_vel * g.plane, w.r + (long long)np_vel * g.plane, nullptr, nullptr, dc));
+                    PL_TRY(norm2_sum_dev(ctx, S, g, np_vel, dx, dx != x ? (const double*)x : (const double*)nullptr, true));
+                    PL_HIP(ctx, hipMemcpyAsync(S->hpart + 8 * DOT_BLOCKS, S->scal + 16, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+                    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                    est_rec = estimate(dc[0], d2[1], S->hpart[8 * DOT_BLOCKS]);
+                } else est_rec = 0.0;
             }
             if (!std::isfinite(rnorm) || !(std::fabs(omega) > 0.0)) { broke = true; break; }
             set_kappa(rnorm);
@@ -2098,7 +2186,34 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
         PL_TRY(dots(ctx, S, g, np, w.s, w.s, nullptr, nullptr, d2));
         last_true = true_norm; true_norm = std::sqrt(d2[0]);
         if (trace) fprintf(stderr, "[pylamp bicgstab] it %3d  TRUE |r|/|b| %.3e (recurrence %.3e) restarts %d\n", it, true_norm / bnorm, rnorm / bnorm, restarts);
-        if (true_norm <= rtol * bnorm || broke || it >= maxit || restarts >= PL_MAX_RESTARTS) break;
+        if (true_norm <= tol * bnorm && !broke && it < maxit && use_est && M && est_checks < 6) {
+            // the estimate of this iterate from the TRUE residual (which is in w.s): continuity part n ||r_cont||, momentum part
+            // ||(M^-1 r)_vel|| -- one V-cycle is A_vv^-1 to ~10 %, so this is the velocity response to the momentum residual
+            // (the block preconditioner's answer to the continuity residual is part of it too, but far too small: its Schur
+            // complement is only an approximation; measured 37 x below the true error on the 33 x 41 fixture)
+            double dc[2], dz[2];
+            PL_TRY(dots(ctx, S, g, np - np_vel, w.s + (long long)np_vel * g.plane, w.s + (long long)np_vel * g.plane, nullptr, nullptr, dc));
+            PL_TRY((*M)(w.s, w.z));
+            PL_TRY(dots(ctx, S, g, np_vel, w.z, w.z, nullptr, nullptr, dz));
+            PL_TRY(norm2_sum_dev(ctx, S, g, np_vel, dx, dx != x ? (const double*)x : (const double*)nullptr, true));
+            PL_HIP(ctx, hipMemcpyAsync(S->hpart + 8 * DOT_BLOCKS, S->scal + 16, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            est_checks++;
+            const double xx = S->hpart[8 * DOT_BLOCKS];
+            const double rc = dc[0] > 0.0 ? dc[0] : 0.0, rm = true_norm * true_norm - rc;
+            const double est = xx > 0.0 ? (n_amp * std::sqrt(rc) + std::sqrt(dz[0] > 0.0 ? dz[0] : 0.0)) / std::sqrt(xx) : 0.0;
+            if (rm > 0.0 && dz[0] > 0.0) a_mom = std::min(std::max(std::sqrt(dz[0] / rm), 1.0), n_amp * n_amp);
+            st->error_estimate = est;
+            if (trace) fprintf(stderr, "[pylamp bicgstab] it %3d  velocity-error estimate %.3e (etol %.1e): continuity %.3e momentum %.3e (amplification %.1f)\n",
+                               it, est, etol, xx > 0.0 ? n_amp * std::sqrt(rc / xx) : 0.0, xx > 0.0 ? std::sqrt(dz[0] / xx) : 0.0, a_mom);
+            if (est > etol && tol > 1e-15) {
+                tol = std::min(tol, true_norm / bnorm) * std::min(0.5, 0.7 * etol / est);
+                est_rec = est;
+                resume = true;
+                continue;                               // same Krylov iteration, smaller target
+            }
+        }
+        if (true_norm <= tol * bnorm || broke || it >= maxit || restarts >= PL_MAX_RESTARTS) break;
         if (last_true >= 0.0 && !(true_norm < 0.5 * last_true)) break;      // a restart no longer pays: attainable accuracy
         // ---- residual replacement: continue from the TRUE residual
         restarts++;
@@ -2108,7 +2223,7 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
     if (dx != x) hipLaunchKernelGGL(k_add_inplace, grid1d(n), dim3(256), 0, ctx->stream, n, x, dx);     // x = x0 + dx
     st->iterations = it;
     st->rel_residual = true_norm / bnorm;
-    st->converged = (st->rel_residual <= rtol) ? 1 : 0;
+    st->converged = (st->rel_residual <= rtol && !(use_est && st->error_estimate > 1.5 * etol)) ? 1 : 0;
     return 0;
 }
 
@@ -2121,8 +2236,8 @@ static int stokes_alloc(pl_ctx* ctx, PlSolver* S) {
     for (double** q : {&S->r, &S->rt, &S->p, &S->v, &S->s, &S->t, &S->y, &S->z, &S->b, &S->x, &S->xb, &S->dx, &S->r0})
         PL_TRY(dmalloc0(ctx, q, vb));
     if (!S->scal) {
-        PL_TRY(dmalloc0(ctx, &S->scal, (16 + 5 * DOT_BLOCKS) * sizeof(double)));
-        PL_HIP(ctx, hipHostMalloc((void**)&S->hpart, (5 * DOT_BLOCKS + 16) * sizeof(double)));
+        PL_TRY(dmalloc0(ctx, &S->scal, (PL_SCAL_N + 8 * DOT_BLOCKS) * sizeof(double)));
+        PL_HIP(ctx, hipHostMalloc((void**)&S->hpart, (8 * DOT_BLOCKS + PL_SCAL_N) * sizeof(double)));
     }
     return 0;
 }
@@ -2202,7 +2317,7 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
         }
     }
     hipLaunchKernelGGL(k_close_constraints, grid2d(g), dim3(64, 4), 0, ctx->stream, sop, S->levels[0]->op, S->b, S->x);
-    PL_TRY(bicgstab(ctx, S, g, 3, A, &M, S->b, S->x, use_x0, rtol, maxit, w, st, ref));
+    PL_TRY(bicgstab(ctx, S, g, 3, A, &M, S->b, S->x, use_x0, rtol, maxit, w, st, ref, S->etol, 2));
     st->used_direct = 0;
     if (!st->converged && pl_direct_possible(ctx) && !getenv("PYLAMP_NO_DIRECT")) {
         // Small system the iteration could not solve (an indefinite velocity block: the reference's stabilisation sign at the
@@ -2213,7 +2328,7 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
         const int it0 = st->iterations;
         PL_HIP(ctx, hipMemcpyAsync(S->x, S->xh, (size_t)3 * g.plane * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
         hipLaunchKernelGGL(k_close_constraints, grid2d(g), dim3(64, 4), 0, ctx->stream, sop, S->levels[0]->op, S->b, S->x);
-        PL_TRY(bicgstab(ctx, S, g, 3, A, &MD, S->b, S->x, true, rtol, 50, w, st, ref));
+        PL_TRY(bicgstab(ctx, S, g, 3, A, &MD, S->b, S->x, true, rtol, 50, w, st, ref, S->etol, 2));
         st->iterations += it0;
         st->used_direct = 1;
     }
@@ -2351,8 +2466,8 @@ int pl_heat_solve_device(pl_ctx* ctx, const double* b_dev, double rtol, int maxi
     size_t pb = (size_t)g.plane * sizeof(double);
     for (int k = 0; k < 11; k++) if (!S->h[k]) PL_TRY(dmalloc0(ctx, &S->h[k], pb));
     if (!S->scal) {
-        PL_TRY(dmalloc0(ctx, &S->scal, (16 + 5 * DOT_BLOCKS) * sizeof(double)));
-        PL_HIP(ctx, hipHostMalloc((void**)&S->hpart, (5 * DOT_BLOCKS + 16) * sizeof(double)));
+        PL_TRY(dmalloc0(ctx, &S->scal, (PL_SCAL_N + 8 * DOT_BLOCKS) * sizeof(double)));
+        PL_HIP(ctx, hipHostMalloc((void**)&S->hpart, (8 * DOT_BLOCKS + PL_SCAL_N) * sizeof(double)));
     }
     PL_TRY(pl_timer_start(ctx));
     PlHeatOp hop = ctx->hop;

