@@ -217,6 +217,7 @@ int  pl_stokes_check_bc(pl_ctx* ctx, const int bc[4]);
 void pl_stokes_scaling_host(const PlGeomHost& gh, double minetas, double minetan, double* Kc, double* Kb);
 void pl_stokes_fill_op(pl_ctx* ctx, double* etas, double* etan, double* rho, const int bc[4], int surfstab,
                        double tstep, double theta, double Kc, double Kb);
+void pl_stokes_deflation(pl_ctx* ctx, bool persistent);     // consecutive solves of one model: keep the deflation vector
 int  pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double rtol, int maxit,
                             pl_solve_stats* st);
 double* pl_stokes_solution_device(pl_ctx* ctx);

@@ -1153,6 +1153,13 @@ struct PlSolver {
     // a tenth of the 1e-6 the drop-in promises, so that quantities derived from maxima (the time step) stay within 1e-6 too
     double etol = 3e-8;
     double kappa = 1.0, sigma = 1.0;     // scaling of the FP32 velocity solve (stokes_precond)
+    // Deflation of the pressure-anchor mode (pl_stokes_solve_device): w = A^-1 u for the one residual-space vector u that the
+    // block preconditioner cannot treat, kept across the solves of a time loop and refreshed every defl_refresh solves
+    bool defl_enable = true;             // PYLAMP_DEFLATE=0 switches it off
+    bool defl_persistent = false;        // set by the time-step driver (pl_stokes_deflation): consecutive solves of one model
+    bool defl_valid = false, defl_active = false;
+    int defl_age = 0, defl_refresh = 10;
+    double *wdefl = nullptr, *udefl = nullptr;
     double schur_scale = 1.0;    // S^ = schur_scale * Kc^2 / eta_n (PYLAMP_SCHUR_SCALE)
     bool fuse_first = true;      // PYLAMP_FUSE_FIRST=0: the first sweep of level 0 as a pass of its own
     bool deep = true;            // PYLAMP_MG_DEEP=0: distributed levels exchange before every sweep instead of once per smoothing sequence
@@ -1192,6 +1199,8 @@ static PlSolver* solver_of(pl_ctx* ctx) {
         if (const char* e = getenv("PYLAMP_MG_HALO")) S->mg_halo = atoi(e);
         if (const char* e = getenv("PYLAMP_MG_DEEP")) S->deep = atoi(e) != 0;
         if (const char* e = getenv("PYLAMP_MG_EARLY")) S->early_knob = atoi(e);
+        if (const char* e = getenv("PYLAMP_DEFLATE")) S->defl_enable = atoi(e) != 0;
+        if (const char* e = getenv("PYLAMP_DEFLATE_REFRESH")) { const int v = atoi(e); if (v >= 1) S->defl_refresh = v; }
         if (const char* e = getenv("PYLAMP_STOKES_ETOL")) { const double v = atof(e); if (v >= 0.0) S->etol = v; }
         if (const char* e = getenv("PYLAMP_MG_FP32")) S->f32_enable = atoi(e) != 0;
         if (const char* e = getenv("PYLAMP_MG_FP32_NODES")) { long long v = atoll(e); if (v >= 1) S->f32_min_nodes = v; }
@@ -1223,7 +1232,7 @@ void pl_solver_free(pl_ctx* ctx) {
     PlSolver* S = (PlSolver*)ctx->krylov;
     if (!S) return;
     free_levels(S);
-    for (double* q : {S->r, S->rt, S->p, S->v, S->s, S->t, S->y, S->z, S->b, S->x, S->xb, S->dx, S->r0, S->xh, S->scal})
+    for (double* q : {S->r, S->rt, S->p, S->v, S->s, S->t, S->y, S->z, S->b, S->x, S->xb, S->dx, S->r0, S->xh, S->scal, S->wdefl, S->udefl})
         if (q) (void)hipFree(q);
     for (double* q : S->h) if (q) (void)hipFree(q);
     if (S->hpart) (void)hipHostFree(S->hpart);
@@ -2242,6 +2251,76 @@ static int stokes_alloc(pl_ctx* ctx, PlSolver* S) {
     return 0;
 }
 
+// ---- deflation of the pressure-anchor mode ------------------------------------------------------------------------
+// The reference pins the pressure by replacing the continuity row of ONE cell (the anchor, P[3,2] = 0, pylamp_stokes.py)
+// -- so a net divergence defect of all other cells can only be absorbed by a sink flow towards that cell.  For the
+// block-triangular preconditioner this is one eigenvalue of A M^-1 near 1/(number of cells) (7e-6 at 33 x 33 with a
+// layered viscosity, everything else in [0.16, 1]; dense eigen-decomposition of the NumPy prototype, tools/spectrum.py):
+// BiCGStab -- and GMRES alike -- sit on a plateau for ~15 iterations until the Krylov space has found it.
+//   right eigenvector (residual space)  u: continuity residual 1 / (eta_n (rdz + rdx)), which M^-1 turns into a CONSTANT pressure
+//   left eigenvector                    y: (hz + hx) on the continuity rows: y.(D_r A x) = sum of area x div(x) over these cells
+//                                          = -(the same sum over the anchor and the four corner cells), by Gauss, for any x
+//                                          whose wall-normal velocities vanish -- five cells, no operator application
+// With w = A^-1 u (one extra solve to 1e-3, kept over the time steps and refreshed every few solves from the old w) the
+// preconditioner becomes  z = M^-1 r,  z += w y.(r - A z) / y.(A w):  the eigenvalue moves to 1, all others stay.
+// NumPy prototype (tools/defl.py, mantle model 129^2, rtol 1e-10): 33 -> 21 iterations, no plateau.
+__device__ inline bool defl_is_cont(const PlStokesOp& op, int i, int j) {
+    const int nz = op.g.nz, nx = op.g.nx;
+    if (i >= nz - 1 || j >= nx - 1 || (i == op.anchor_i && j == op.anchor_j)) return false;
+    if ((i == 0 || i == nz - 2) && (j == 0 || j == nx - 2)) return false;
+    return true;
+}
+__global__ __launch_bounds__(256) void k_defl_u(PlStokesOp op, double* __restrict__ u) {
+    PL_NODE_PROLOGUE(op.g)
+    const long long P = op.g.plane;
+    u[c] = 0.0; u[c + P] = 0.0;
+    u[c + 2 * P] = defl_is_cont(op, i, j) ? 1.0 / (op.etan[c] * (TB(op.g.rdz, i) + TB(op.g.rdx, j))) : 0.0;
+}
+// partial sums of y . r over the continuity rows (r: the pressure plane of a scaled residual)
+__global__ __launch_bounds__(256) void k_defl_ysum(PlStokesOp op, const double* __restrict__ rp, double* __restrict__ part) {
+    const PlGeom& g = op.g;
+    double s0 = 0.0;
+    for (int li = blockIdx.x; li < g.lnz; li += gridDim.x) {
+        const int i = g.gi0 + li;
+        const double hz = (i < g.nz - 1) ? 1.0 / TB(g.rdz, i) : 0.0;
+        for (int lj = threadIdx.x; lj < g.lnx; lj += 256) {
+            const int j = g.gj0 + lj;
+            if (defl_is_cont(op, i, j)) s0 += (hz + 1.0 / TB(g.rdx, j)) * rp[pl_idx(g, li, lj)];
+        }
+    }
+    __shared__ double sh[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s0 += __shfl_down(s0, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s0;
+    __syncthreads();
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3]; part[2 * blockIdx.x + 1] = 0.0; }
+}
+// y . (D_r A x) from the five cells without a continuity row.  mode 1: sc[18] = y.(A x) (the denominator, x = w);
+// mode 0: sc[19] = (sc[20] - y.(A x)) / sc[18]  (sc[20] = y . r, x = z)
+__global__ void k_defl_coef(PlStokesOp op, const double* __restrict__ x, double* __restrict__ sc, int mode) {
+    const PlGeom& g = op.g;
+    const int ci[5] = {op.anchor_i, 0, 0, g.nz - 2, g.nz - 2}, cj[5] = {op.anchor_j, 0, g.nx - 2, 0, g.nx - 2};
+    const double* vz = x; const double* vx = x + g.plane;
+    double five = 0.0;
+    for (int k = 0; k < 5; k++) {
+        const int i = ci[k], j = cj[k];
+        if (i < 0 || j < 0 || i >= g.nz - 1 || j >= g.nx - 1) continue;
+        if (k > 0 && i == op.anchor_i && j == op.anchor_j) continue;         // an anchor in a corner counts once
+        const long long c = pl_idx(g, i - g.gi0, j - g.gj0);
+        five += (vz[c + g.pitch] - vz[c]) / TB(g.rdx, j) + (vx[c + 1] - vx[c]) / TB(g.rdz, i);      // area x div = hx dvz + hz dvx
+    }
+    const double yAx = -five;
+    if (mode == 1) sc[18] = yAx;
+    else sc[19] = (sc[18] != 0.0 && isfinite(sc[18])) ? (sc[20] - yAx) / sc[18] : 0.0;
+}
+__global__ void k_axpy_dev_scalar(long long n, double* __restrict__ z, const double* __restrict__ w, const double* __restrict__ sc) {
+    const double a = sc[0];
+    long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; k < n; k += (long long)gridDim.x * blockDim.x) z[k] += a * w[k];
+}
+// the time-step driver announces consecutive solves of one slowly changing model (deflation vector kept between them)
+void pl_stokes_deflation(pl_ctx* ctx, bool persistent) { solver_of(ctx)->defl_persistent = persistent; }
+
 // Solve A x = b for device vectors (3 planes, UNSCALED b).  x is S->x on return.
 int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double rtol, int maxit,
                            pl_solve_stats* st) {
@@ -2259,11 +2338,42 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
         S->napply++;
         return 0;
     };
-    VecOp M = [&](const double* in, double* out) -> int { return stokes_precond(ctx, S, in, out); };
+    const long long n3v = 3 * g.plane;
+    VecOp M = [&](const double* in, double* out) -> int {
+        PL_TRY(stokes_precond(ctx, S, in, out));
+        if (S->defl_active) {                               // z += w y.(r - A z) / y.(A w), all scalars on the device
+            const int nb = g.lnz < DOT_BLOCKS ? g.lnz : DOT_BLOCKS;
+            hipLaunchKernelGGL(k_defl_ysum, dim3(nb), dim3(256), 0, ctx->stream, sop, in + 2 * g.plane, S->scal + PL_SCAL_N);
+            hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, nb, S->scal + PL_SCAL_N, S->scal + 20, 0, 0.0);
+            hipLaunchKernelGGL(k_defl_coef, dim3(1), dim3(1), 0, ctx->stream, sop, (const double*)out, S->scal, 0);
+            hipLaunchKernelGGL(k_axpy_dev_scalar, grid1d(n3v), dim3(256), 0, ctx->stream, n3v, out, (const double*)S->wdefl, (const double*)(S->scal + 19));
+        }
+        return 0;
+    };
+    BicgVecs w{S->r, S->rt, S->p, S->v, S->s, S->t, S->y, S->z, S->xb, S->dx, S->r0};
+    S->defl_active = false;
+    if (S->defl_enable && S->defl_persistent && ctx->nranks == 1 && !sop.surfstab && S->levels.size() > 1) {
+        if (!S->wdefl) { PL_TRY(dmalloc0(ctx, &S->wdefl, (size_t)n3v * sizeof(double))); PL_TRY(dmalloc0(ctx, &S->udefl, (size_t)n3v * sizeof(double))); S->defl_valid = false; }
+        if (S->defl_valid) {                                // denominator of the old w under the new coefficients
+            hipLaunchKernelGGL(k_defl_coef, dim3(1), dim3(1), 0, ctx->stream, sop, (const double*)S->wdefl, S->scal, 1);
+            S->defl_active = true;
+        }
+        if (!S->defl_valid || S->defl_age >= S->defl_refresh) {
+            // (re)compute w = A^-1 u to 1e-3 -- from the old w, with the old deflation active, this takes a few iterations
+            hipLaunchKernelGGL(k_defl_u, grid2d(g), dim3(64, 4), 0, ctx->stream, sop, S->udefl);
+            if (!S->defl_valid) PL_HIP(ctx, hipMemsetAsync(S->wdefl, 0, (size_t)n3v * sizeof(double), ctx->stream));
+            pl_solve_stats st2{};
+            PL_TRY(bicgstab(ctx, S, g, 3, A, &M, S->udefl, S->wdefl, S->defl_valid, 1e-3, 80, w, &st2));
+            S->defl_valid = st2.rel_residual < 0.05 && std::isfinite(st2.rel_residual);
+            S->defl_age = 0;
+            if (S->defl_valid) hipLaunchKernelGGL(k_defl_coef, dim3(1), dim3(1), 0, ctx->stream, sop, (const double*)S->wdefl, S->scal, 1);
+            S->defl_active = S->defl_valid;
+        }
+        S->defl_age++;
+    }
     if (b_dev != S->b)
         PL_HIP(ctx, hipMemcpyAsync(S->b, b_dev, (size_t)3 * g.plane * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     hipLaunchKernelGGL(k_stokes_scale_rows, grid2d(g), dim3(64, 4), 0, ctx->stream, sop, S->b);
-    BicgVecs w{S->r, S->rt, S->p, S->v, S->s, S->t, S->y, S->z, S->xb, S->dx, S->r0};
     // hydrostatic pressure x_h (in S->y) and the dynamic-load reference norm ||D_r (b - A x_h)||
     double d2[2], ref = 0.0;
     {
@@ -2359,6 +2469,7 @@ extern "C" int pl_stokes_solve(pl_ctx* ctx, const double* rhs, double* x, int us
     pl_solve_stats st{};
     if (rtol <= 0) rtol = 1e-10;
     if (maxit <= 0) maxit = 400;
+    S->defl_persistent = false; S->defl_valid = false;     // one-off problems: the deflation vector of a time loop does not apply
     PL_TRY(pl_stokes_solve_device(ctx, S->b, use_x0 != 0, rtol, maxit, &st));
     PL_TRY(pl_vec3_download(ctx, g, S->x, x));
     if (stats) *stats = st;

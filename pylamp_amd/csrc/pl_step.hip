@@ -965,6 +965,7 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
     double* b = pl_stokes_rhs_buffer_device(ctx);
     if (!b) return 1;
     pl_launch_stokes_rhs(ctx, ctx->sop, b);
+    pl_stokes_deflation(ctx, true);
     PL_TRY(pl_stokes_solve_device(ctx, b, S->have_solution, cfg->stokes_rtol > 0 ? cfg->stokes_rtol : 1e-10,
                                   cfg->stokes_maxit > 0 ? cfg->stokes_maxit : 400, &rep->stokes));
     S->have_solution = true;
