@@ -311,12 +311,16 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else "%d x %d blocks of the node grid (8-neighbour halo exchange with corners + all-reduce), transport: %s" %
                                       (sim.ctx.local_block()[4], sim.ctx.local_block()[5], "direct RCCL on the solver stream" if (sim.ctx.comm is not None and sim.ctx.comm.native)
                                        else "torch.distributed (%s)" % (dist.get_backend() if dist is not None else "-")),
-                       "stokes_rtol": sim.opt.stokes_rtol, "heat_rtol": sim.opt.heat_rtol},
+                       "stokes_rtol": sim.opt.stokes_rtol, "heat_rtol": sim.opt.heat_rtol,
+                       "stokes_stop": "true relative residual <= stokes_rtol AND estimated relative velocity error <= %s "
+                                      "(pl_solve_stats.error_estimate; the drop-in's promise against the reference's direct solve is 1e-6)"
+                                      % os.environ.get("PYLAMP_STOKES_ETOL", "3e-8")},
             "time_steps_per_s": round(args.steps / elapsed, 4),
             "stage_ms": stages,
             "stokes_iterations": [r["stokes"]["iterations"] for r in timed],
             "stokes_rel_residual": [float("%.3g" % r["stokes"]["rel_residual"]) for r in timed],
             "stokes_converged": [r["stokes"]["converged"] for r in timed],
+            "stokes_error_estimate": [float("%.3g" % r["stokes"]["error_estimate"]) for r in timed],
             "heat_iterations": [r["heat"]["iterations"] for r in timed],
             "tracers_injected": [int(r["ninjected"]) for r in timed],
             "roofline": roof,
