@@ -2296,7 +2296,7 @@ __global__ __launch_bounds__(256) void k_defl_ysum(PlStokesOp op, const double* 
     if (threadIdx.x == 0) { part[2 * blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3]; part[2 * blockIdx.x + 1] = 0.0; }
 }
 // y . (D_r A x) from the five cells without a continuity row.  mode 1: sc[18] = y.(A x) (the denominator, x = w);
-// mode 0: sc[19] = (sc[20] - y.(A x)) / sc[18]  (sc[20] = y . r, x = z)
+// mode 0: sc[19] = (sc[20] - y.(A x)) / sc[18]  (sc[20] = y . r, x = z); mode 2 + k_defl_divide: the same with an all-reduce in between
 __global__ void k_defl_coef(PlStokesOp op, const double* __restrict__ x, double* __restrict__ sc, int mode) {
     const PlGeom& g = op.g;
     const int ci[5] = {op.anchor_i, 0, 0, g.nz - 2, g.nz - 2}, cj[5] = {op.anchor_j, 0, g.nx - 2, 0, g.nx - 2};
@@ -2306,13 +2306,16 @@ __global__ void k_defl_coef(PlStokesOp op, const double* __restrict__ x, double*
         const int i = ci[k], j = cj[k];
         if (i < 0 || j < 0 || i >= g.nz - 1 || j >= g.nx - 1) continue;
         if (k > 0 && i == op.anchor_i && j == op.anchor_j) continue;         // an anchor in a corner counts once
+        if (i < g.gi0 || i >= g.gi0 + g.lnz || j < g.gj0 || j >= g.gj0 + g.lnx) continue;     // another rank's cell
         const long long c = pl_idx(g, i - g.gi0, j - g.gj0);
         five += (vz[c + g.pitch] - vz[c]) / TB(g.rdx, j) + (vx[c + 1] - vx[c]) / TB(g.rdz, i);      // area x div = hx dvz + hz dvx
     }
     const double yAx = -five;
-    if (mode == 1) sc[18] = yAx;
+    if (mode == 1) sc[18] = yAx;                                                                  // (this rank's share on several ranks)
+    else if (mode == 2) sc[21] = sc[20] - yAx;                                                    // this rank's share of the numerator
     else sc[19] = (sc[18] != 0.0 && isfinite(sc[18])) ? (sc[20] - yAx) / sc[18] : 0.0;
 }
+__global__ void k_defl_divide(double* __restrict__ sc) { sc[19] = (sc[18] != 0.0 && isfinite(sc[18])) ? sc[21] / sc[18] : 0.0; }
 __global__ void k_axpy_dev_scalar(long long n, double* __restrict__ z, const double* __restrict__ w, const double* __restrict__ sc) {
     const double a = sc[0];
     long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2345,17 +2348,23 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
             const int nb = g.lnz < DOT_BLOCKS ? g.lnz : DOT_BLOCKS;
             hipLaunchKernelGGL(k_defl_ysum, dim3(nb), dim3(256), 0, ctx->stream, sop, in + 2 * g.plane, S->scal + PL_SCAL_N);
             hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, nb, S->scal + PL_SCAL_N, S->scal + 20, 0, 0.0);
-            hipLaunchKernelGGL(k_defl_coef, dim3(1), dim3(1), 0, ctx->stream, sop, (const double*)out, S->scal, 0);
+            if (ctx->nranks > 1) {                          // one scalar per application: y.r and the five cells live on different ranks
+                hipLaunchKernelGGL(k_defl_coef, dim3(1), dim3(1), 0, ctx->stream, sop, (const double*)out, S->scal, 2);
+                PL_TRY(pl_comm_allreduce_dev(ctx, S->scal + 21, 1));
+                hipLaunchKernelGGL(k_defl_divide, dim3(1), dim3(1), 0, ctx->stream, S->scal);
+            } else
+                hipLaunchKernelGGL(k_defl_coef, dim3(1), dim3(1), 0, ctx->stream, sop, (const double*)out, S->scal, 0);
             hipLaunchKernelGGL(k_axpy_dev_scalar, grid1d(n3v), dim3(256), 0, ctx->stream, n3v, out, (const double*)S->wdefl, (const double*)(S->scal + 19));
         }
         return 0;
     };
     BicgVecs w{S->r, S->rt, S->p, S->v, S->s, S->t, S->y, S->z, S->xb, S->dx, S->r0};
     S->defl_active = false;
-    if (S->defl_enable && S->defl_persistent && ctx->nranks == 1 && !sop.surfstab && S->levels.size() > 1) {
+    if (S->defl_enable && S->defl_persistent && !sop.surfstab && S->levels.size() > 1) {
         if (!S->wdefl) { PL_TRY(dmalloc0(ctx, &S->wdefl, (size_t)n3v * sizeof(double))); PL_TRY(dmalloc0(ctx, &S->udefl, (size_t)n3v * sizeof(double))); S->defl_valid = false; }
         if (S->defl_valid) {                                // denominator of the old w under the new coefficients
             hipLaunchKernelGGL(k_defl_coef, dim3(1), dim3(1), 0, ctx->stream, sop, (const double*)S->wdefl, S->scal, 1);
+            if (ctx->nranks > 1) PL_TRY(pl_comm_allreduce_dev(ctx, S->scal + 18, 1));
             S->defl_active = true;
         }
         if (!S->defl_valid || S->defl_age >= S->defl_refresh) {
@@ -2366,7 +2375,10 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
             PL_TRY(bicgstab(ctx, S, g, 3, A, &M, S->udefl, S->wdefl, S->defl_valid, 1e-3, 80, w, &st2));
             S->defl_valid = st2.rel_residual < 0.05 && std::isfinite(st2.rel_residual);
             S->defl_age = 0;
-            if (S->defl_valid) hipLaunchKernelGGL(k_defl_coef, dim3(1), dim3(1), 0, ctx->stream, sop, (const double*)S->wdefl, S->scal, 1);
+            if (S->defl_valid) {
+                hipLaunchKernelGGL(k_defl_coef, dim3(1), dim3(1), 0, ctx->stream, sop, (const double*)S->wdefl, S->scal, 1);
+                if (ctx->nranks > 1) PL_TRY(pl_comm_allreduce_dev(ctx, S->scal + 18, 1));
+            }
             S->defl_active = S->defl_valid;
         }
         S->defl_age++;

@@ -126,7 +126,8 @@ def test_blocks_injection_deletion_and_graded_grid(oracle):
 def test_blocks_communication_budget(monkeypatch):
     """Three distributed multigrid levels on 2 x 4 blocks (replication threshold lowered so that a 257 x 513 grid has
     them): with deep halos a preconditioner application costs at most 8 neighbour exchanges (one per smoothing sequence
-    of a level instead of one per sweep) and a BiCGStab iteration two all-reduces; the exchange-per-sweep mode
+    of a level instead of one per sweep) and a BiCGStab iteration two all-reduces plus one scalar per application for the
+    pressure-anchor deflation; the exchange-per-sweep mode
     (PYLAMP_MG_DEEP=0) gives the same iterates at several times the exchanges."""
     from pylamp_amd import driver
     nx = [257, 513]; L = [660e3, 1320e3]
@@ -146,6 +147,8 @@ def test_blocks_communication_budget(monkeypatch):
     d, l = res["1"], res["0"]
     other = 80                                   # set-up (coefficient halos, power iterations), scatter, advection
     assert d["exchanges"] <= 8 * d["nprec"] + d["napply"] + other, d
-    assert d["allreduces"] <= 2 * d["its"] + other, d
+    # two per BiCGStab iteration (= per two preconditioner applications; the short solve for the deflation vector included) plus
+    # the deflation scalar of every application
+    assert d["allreduces"] <= 2 * d["nprec"] + other, d
     assert l["exchanges"] > 2.0 * d["exchanges"], (d, l)
     assert relerr(d["velz"], l["velz"]) < 1e-7

@@ -350,3 +350,39 @@ def test_step_with_unreachable_nodes_fails_loudly():
     with pytest.raises(Exception, match="time step is not finite"):
         sim.step()
     sim.close()
+
+
+def test_pressure_anchor_deflation_same_fields_fewer_iterations():
+    """The rank-1 deflation of the pressure-anchor mode in the Stokes preconditioner changes the
+    iteration count, not the answer: two resident runs of the mantle model at 257 x 257, with and without it
+    (PYLAMP_DEFLATE is read when a context's solver is created, hence the subprocesses)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, json
+sys.path.insert(0, %r)
+import numpy as np
+from pylamp_amd import driver
+n = 257; nx = [n, n]; L = [660e3, 660e3]
+tr_x, tr_f = driver.mantle_tracers(nx, L, 12, np.random.default_rng(11))
+sim = driver.Simulation(nx, L, tr_x, tr_f, driver.Options())
+its = []
+for k in range(3):
+    rep = sim.step(); its.append(rep["stokes"]["iterations"]); assert rep["stokes"]["converged"] == 1, rep
+np.save(sys.argv[1], np.stack([sim.field("velz"), sim.field("velx"), sim.field("temp")]))
+print("RESULT", json.dumps(dict(its=its, est=rep["stokes"]["error_estimate"])))
+''' % root
+    out = {}
+    for name, env in (("deflated", {}), ("plain", {"PYLAMP_DEFLATE": "0"})):
+        path = os.path.join(root, "gpurun_out", "defl_%s.npy" % name)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0, (name, r.stderr[-1500:])
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0]
+        out[name] = (json.loads(line[7:]), np.load(path))
+        os.remove(path)
+    (sd, fd), (sp, fp) = out["deflated"], out["plain"]
+    for q in range(3):
+        assert relerr(fd[q], fp[q]) < 1e-6, q                  # both within the solver's error bound of the same solution
+    assert sum(sd["its"]) < 0.85 * sum(sp["its"]), (sd, sp)
+    assert sd["est"] <= 3e-8 and sp["est"] <= 3e-8
