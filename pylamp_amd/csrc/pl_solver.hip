@@ -1156,9 +1156,8 @@ struct PlSolver {
     // Deflation of the pressure-anchor mode (pl_stokes_solve_device): w = A^-1 u for the one residual-space vector u that the
     // block preconditioner cannot treat, kept across the solves of a time loop and refreshed every defl_refresh solves
     bool defl_enable = true;             // PYLAMP_DEFLATE=0 switches it off
-    bool defl_persistent = false;        // set by the time-step driver (pl_stokes_deflation): consecutive solves of one model
+    bool defl_persistent = false;        // (informational) set by the time-step driver: consecutive solves of one model
     bool defl_valid = false, defl_active = false;
-    int defl_age = 0, defl_refresh = 10;
     double *wdefl = nullptr, *udefl = nullptr;
     double schur_scale = 1.0;    // S^ = schur_scale * Kc^2 / eta_n (PYLAMP_SCHUR_SCALE)
     bool fuse_first = true;      // PYLAMP_FUSE_FIRST=0: the first sweep of level 0 as a pass of its own
@@ -1200,7 +1199,6 @@ static PlSolver* solver_of(pl_ctx* ctx) {
         if (const char* e = getenv("PYLAMP_MG_DEEP")) S->deep = atoi(e) != 0;
         if (const char* e = getenv("PYLAMP_MG_EARLY")) S->early_knob = atoi(e);
         if (const char* e = getenv("PYLAMP_DEFLATE")) S->defl_enable = atoi(e) != 0;
-        if (const char* e = getenv("PYLAMP_DEFLATE_REFRESH")) { const int v = atoi(e); if (v >= 1) S->defl_refresh = v; }
         if (const char* e = getenv("PYLAMP_STOKES_ETOL")) { const double v = atof(e); if (v >= 0.0) S->etol = v; }
         if (const char* e = getenv("PYLAMP_MG_FP32")) S->f32_enable = atoi(e) != 0;
         if (const char* e = getenv("PYLAMP_MG_FP32_NODES")) { long long v = atoll(e); if (v >= 1) S->f32_min_nodes = v; }
@@ -2261,7 +2259,8 @@ static int stokes_alloc(pl_ctx* ctx, PlSolver* S) {
 //   left eigenvector                    y: (hz + hx) on the continuity rows: y.(D_r A x) = sum of area x div(x) over these cells
 //                                          = -(the same sum over the anchor and the four corner cells), by Gauss, for any x
 //                                          whose wall-normal velocities vanish -- five cells, no operator application
-// With w = A^-1 u (one extra solve to 1e-3, kept over the time steps and refreshed every few solves from the old w) the
+// With w = A^-1 u (one extra solve to 1e-3; the vector is kept on the context, checked against the new operator before every
+// solve -- ||u - A w|| / ||u||, one application -- and refreshed from itself when that exceeds 0.1) the
 // preconditioner becomes  z = M^-1 r,  z += w y.(r - A z) / y.(A w):  the eigenvalue moves to 1, all others stay.
 // NumPy prototype (tools/defl.py, mantle model 129^2, rtol 1e-10): 33 -> 21 iterations, no plateau.
 __device__ inline bool defl_is_cont(const PlStokesOp& op, int i, int j) {
@@ -2360,28 +2359,40 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
     };
     BicgVecs w{S->r, S->rt, S->p, S->v, S->s, S->t, S->y, S->z, S->xb, S->dx, S->r0};
     S->defl_active = false;
-    if (S->defl_enable && S->defl_persistent && !sop.surfstab && S->levels.size() > 1) {
+    if (S->defl_enable && !sop.surfstab && S->levels.size() > 1) {
         if (!S->wdefl) { PL_TRY(dmalloc0(ctx, &S->wdefl, (size_t)n3v * sizeof(double))); PL_TRY(dmalloc0(ctx, &S->udefl, (size_t)n3v * sizeof(double))); S->defl_valid = false; }
-        if (S->defl_valid) {                                // denominator of the old w under the new coefficients
+        hipLaunchKernelGGL(k_defl_u, grid2d(g), dim3(64, 4), 0, ctx->stream, sop, S->udefl);
+        // How good is the vector kept from the previous solve on this context for THIS operator?  ||u - A w|| / ||u||
+        // (one operator application).  <= 0.1: use it as it is (measured at 2049^2: 2-3e-2 after one time step, and the
+        // iteration count does not notice); < 0.5 (a few time steps later, a similar model): refresh it from itself with the
+        // old deflation active -- a few iterations; otherwise (first solve, another problem): from zero.
+        double q = 1.0;
+        if (S->defl_valid) {
+            double dq[2];
+            PL_TRY(A(S->wdefl, S->t));
+            hipLaunchKernelGGL(k_axpy_out, grid1d(n3v), dim3(256), 0, ctx->stream, n3v, S->s, (const double*)S->udefl, (const double*)S->t, -1.0);
+            PL_TRY(dots(ctx, S, g, 3, S->s, S->s, S->udefl, S->udefl, dq));
+            q = (dq[1] > 0.0 && std::isfinite(dq[0])) ? std::sqrt(dq[0] / dq[1]) : 1.0;
+        }
+        static const bool trace_d = getenv("PYLAMP_SOLVER_TRACE") != nullptr;
+        if (trace_d) fprintf(stderr, "[pylamp deflation] kept vector: ||u - A w|| / ||u|| = %.3e\n", q);
+        const bool reuse = S->defl_valid && q < 0.5;
+        if (reuse) {                                        // denominator y.(A w) of the old w under the new coefficients
             hipLaunchKernelGGL(k_defl_coef, dim3(1), dim3(1), 0, ctx->stream, sop, (const double*)S->wdefl, S->scal, 1);
             if (ctx->nranks > 1) PL_TRY(pl_comm_allreduce_dev(ctx, S->scal + 18, 1));
             S->defl_active = true;
         }
-        if (!S->defl_valid || S->defl_age >= S->defl_refresh) {
-            // (re)compute w = A^-1 u to 1e-3 -- from the old w, with the old deflation active, this takes a few iterations
-            hipLaunchKernelGGL(k_defl_u, grid2d(g), dim3(64, 4), 0, ctx->stream, sop, S->udefl);
-            if (!S->defl_valid) PL_HIP(ctx, hipMemsetAsync(S->wdefl, 0, (size_t)n3v * sizeof(double), ctx->stream));
+        if (!reuse || q > 0.1) {
+            if (!reuse) PL_HIP(ctx, hipMemsetAsync(S->wdefl, 0, (size_t)n3v * sizeof(double), ctx->stream));
             pl_solve_stats st2{};
-            PL_TRY(bicgstab(ctx, S, g, 3, A, &M, S->udefl, S->wdefl, S->defl_valid, 1e-3, 80, w, &st2));
+            PL_TRY(bicgstab(ctx, S, g, 3, A, &M, S->udefl, S->wdefl, reuse, 1e-3, 80, w, &st2));
             S->defl_valid = st2.rel_residual < 0.05 && std::isfinite(st2.rel_residual);
-            S->defl_age = 0;
             if (S->defl_valid) {
                 hipLaunchKernelGGL(k_defl_coef, dim3(1), dim3(1), 0, ctx->stream, sop, (const double*)S->wdefl, S->scal, 1);
                 if (ctx->nranks > 1) PL_TRY(pl_comm_allreduce_dev(ctx, S->scal + 18, 1));
             }
             S->defl_active = S->defl_valid;
         }
-        S->defl_age++;
     }
     if (b_dev != S->b)
         PL_HIP(ctx, hipMemcpyAsync(S->b, b_dev, (size_t)3 * g.plane * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
@@ -2481,7 +2492,6 @@ extern "C" int pl_stokes_solve(pl_ctx* ctx, const double* rhs, double* x, int us
     pl_solve_stats st{};
     if (rtol <= 0) rtol = 1e-10;
     if (maxit <= 0) maxit = 400;
-    S->defl_persistent = false; S->defl_valid = false;     // one-off problems: the deflation vector of a time loop does not apply
     PL_TRY(pl_stokes_solve_device(ctx, S->b, use_x0 != 0, rtol, maxit, &st));
     PL_TRY(pl_vec3_download(ctx, g, S->x, x));
     if (stats) *stats = st;
