@@ -535,6 +535,9 @@ struct pl3_ctx {
     Heat3 hop{}; bool hop_ready = false; double* hk[3] = {nullptr}; double *hT = nullptr, *hH = nullptr, *hcdt = nullptr, *hrho = nullptr, *hcp = nullptr;
     double* hbcv = nullptr; double* htab = nullptr; double* hvec[12] = {nullptr}; double hbcv_host[6] = {0};
     int nu = 2, coarse_sweeps = 12; double cheb_ratio = 6.0;
+    // deflation of the pressure-anchor mode (see pl_solver.hip): the vector w = A^-1 u lives in vec[13], kept between solves
+    double *dfl_y = nullptr, *dfl_t = nullptr; bool dfl_valid = false;
+    double etol = 3e-8;                     // bound on the velocity-error estimate of a converged Stokes solve (PYLAMP_STOKES_ETOL)
 };
 static thread_local std::string p3_tls_error;
 static int p3_fail(pl3_ctx* ctx, const std::string& m) { if (ctx) ctx->err = m; p3_tls_error = m; return 1; }
@@ -846,9 +849,36 @@ static void vcycle3(pl3_ctx* ctx, size_t l, double* const* f, int& out_buf) {
 
 // ---- generic right-preconditioned BiCGStab on multi-array vectors (correction form, true-residual stopping) --------------------
 typedef std::function<int(double* const*, double* const*)> Op3Fn;
-struct Stats3 { int iterations, converged; double rel_residual; int napply, nprec; };
+// ---- deflation of the pressure-anchor mode and the velocity-error estimate: the 3-D counterparts of pl_solver.hip --------------
+// u: the continuity residual that the block preconditioner turns into a constant pressure; yw: cell volume x (rdz + rdx + rdy) on the
+// continuity rows, so that yw . (scaled continuity row of v) = sum of volume x div(v)
+__global__ __launch_bounds__(256) void k3_defl_setup(Op3 op, W4 u, double* __restrict__ yw) {
+    K3_PROLOGUE(op.g)
+    long long moff;
+    const bool cont = cls3_p(op, idx, moff) == 1;
+    const G3& g = op.g;
+    const double rs = TB(g.rd[0], i) + TB(g.rd[1], j) + TB(g.rd[2], k);
+    u.p[0][c] = 0.0; u.p[1][c] = 0.0; u.p[2][c] = 0.0;
+    u.p[3][c] = cont ? 1.0 / (op.en[c] * rs) : 0.0;
+    yw[c] = cont ? rs / (TB(g.rd[0], i) * TB(g.rd[1], j) * TB(g.rd[2], k)) : 0.0;
+}
+// the scaled continuity rows of a velocity field (0 on the other pressure rows)
+__global__ __launch_bounds__(256) void k3_cont_rows(Op3 op, V3 v, double* __restrict__ out) {
+    K3_PROLOGUE(op.g)
+    long long moff;
+    double o = 0.0;
+    if (cls3_p(op, idx, moff) == 1) {
+        const G3& g = op.g;
+        const double rz = TB(g.rd[0], i), rx = TB(g.rd[1], j), ry = TB(g.rd[2], k);
+        o = ((v.p[0][c + g.s[0]] - v.p[0][c]) * rz + (v.p[1][c + g.s[1]] - v.p[1][c]) * rx + (v.p[2][c + g.s[2]] - v.p[2][c]) * ry) / (rz + rx + ry);
+    }
+    out[c] = o;
+}
+
+struct Stats3 { int iterations, converged; double rel_residual; int napply, nprec; double error_estimate; };
 static int bicgstab3(pl3_ctx* ctx, long long vol, int na, const Op3Fn& A, const Op3Fn* M, double* const* b, double* const* x, bool use_x0,
-                     double rtol, int maxit, double* const* const* w /* r rt p v s t y z dx r0 */, G3 g, Stats3* st, double ref_norm) {
+                     double rtol, int maxit, double* const* const* w /* r rt p v s t y z dx r0 */, G3 g, Stats3* st, double ref_norm,
+                     double etol = 0.0) {
     double* const* r = w[0]; double* const* rt = w[1]; double* const* p = w[2]; double* const* v = w[3]; double* const* s = w[4];
     double* const* t = w[5]; double* const* y = w[6]; double* const* z = w[7]; double* const* dxb = w[8]; double* const* r0b = w[9];
     auto axpby = [&](double* const* yy, double a, double* const* xx, double bb, double* const* zz) {
@@ -867,14 +897,34 @@ static int bicgstab3(pl3_ctx* ctx, long long vol, int na, const Op3Fn& A, const 
     axpby(r, 1.0, r0, 0.0, r0);
     for (int c = 0; c < na; c++) hipLaunchKernelGGL(k3_random, grid3(g), dim3(64, 4), 0, ctx->stream, g, rt[c], 1234u + c);
     int it = 0, restarts = 0; double true_norm = -1.0, last_true = -1.0;
+    static const bool trace3 = getenv("PYLAMP_SOLVER_TRACE") != nullptr;
+    // velocity-error estimate (n |r_cont| + |(M^-1 r)_vel|) / |x_vel| as in pl_solver.hip (na = 4: three velocity arrays + pressure)
+    const bool use_est = etol > 0.0 && na == 4 && M;
+    const double n_amp = (double)std::max(g.n[0], std::max(g.n[1], g.n[2]));
+    double tol = rtol, est_rec = 0.0, a_mom = 1.0;
+    int est_checks = 0;
+    bool resume = false, broke = false;
+    double rho = 1.0, alpha = 1.0, omega = 1.0, rho_new = 0.0, rnorm = 0.0, best = 0.0; int best_it = 0;
+    st->error_estimate = 0.0;
+    auto vel_norm2 = [&](double& xx) -> int {        // |(x0 + dx)_vel|^2, through t as scratch
+        double* const* src = dx;
+        if (dx != x) { for (int c = 0; c < 3; c++) hipLaunchKernelGGL(k3_axpby, g1(vol), dim3(256), 0, ctx->stream, vol, t[c], 1.0, (const double*)x[c], 1.0, (const double*)dx[c]); src = t; }
+        double* const* aa[1] = {src}; double o[1];
+        P3_TRY(vdots(ctx, vol, 3, 1, aa, aa, o));
+        xx = o[0];
+        return 0;
+    };
     for (;;) {
-        zero(p); zero(v);
-        double rho = 1.0, alpha = 1.0, omega = 1.0;
-        { double* const* aa[2] = {rt, r}; double* const* bb[2] = {r, r}; P3_TRY(vdots(ctx, vol, na, 2, aa, bb, d)); }
-        double rho_new = d[0], rnorm = std::sqrt(d[1]);
-        bool broke = false;
-        double best = rnorm; int best_it = it;
-        while (it < maxit && rnorm > rtol * bnorm) {
+        if (!resume) {
+            zero(p); zero(v);
+            rho = alpha = omega = 1.0;
+            { double* const* aa[2] = {rt, r}; double* const* bb[2] = {r, r}; P3_TRY(vdots(ctx, vol, na, 2, aa, bb, d)); }
+            rho_new = d[0]; rnorm = std::sqrt(d[1]);
+            broke = false;
+            best = rnorm; best_it = it;
+        }
+        resume = false;
+        while (it < maxit && (rnorm > tol * bnorm || (use_est && est_rec > 0.7 * etol))) {
             it++;
             if (!(std::fabs(rho_new) > 0.0) || !std::isfinite(rho_new)) { broke = true; break; }
             const double beta = (rho_new / rho) * (alpha / omega);
@@ -900,19 +950,47 @@ static int bicgstab3(pl3_ctx* ctx, long long vol, int na, const Op3Fn& A, const 
             rnorm = rr > 0.0 ? std::sqrt(rr) : 0.0;
             if (!std::isfinite(rnorm) || !(std::fabs(omega) > 0.0)) { broke = true; break; }
             if (rnorm < best) { best = rnorm; best_it = it; }
+            if (trace3) fprintf(stderr, "[pylamp3 bicgstab] it %3d  |r|/|b| %.3e\n", it, rnorm / bnorm);
+            est_rec = 0.0;
+            if (use_est && rnorm <= 1e3 * tol * bnorm) {          // near the end: the estimate from the recurrence residual
+                double rc[1], xx = 0.0;
+                { double* const* aa[1] = {r + 3}; P3_TRY(vdots(ctx, vol, 1, 1, aa, aa, rc)); }
+                P3_TRY(vel_norm2(xx));
+                const double rm = rr - rc[0] > 0.0 ? rr - rc[0] : 0.0;
+                if (xx > 0.0) est_rec = (n_amp * std::sqrt(rc[0] > 0.0 ? rc[0] : 0.0) + a_mom * std::sqrt(rm)) / std::sqrt(xx);
+            }
             if (it - best_it > 80 || rnorm > 1e8 * best) { broke = true; break; }
         }
         P3_TRY(A(dx, t));
         axpby(s, 1.0, r0, -1.0, t);
         { double* const* aa[1] = {s}; P3_TRY(vdots(ctx, vol, na, 1, aa, aa, d)); }
         last_true = true_norm; true_norm = std::sqrt(d[0]);
-        if (true_norm <= rtol * bnorm || broke || it >= maxit || restarts >= 4) break;
+        if (true_norm <= tol * bnorm && !broke && it < maxit && use_est && est_checks < 6) {
+            double rc[1], zz[1], xx = 0.0;
+            { double* const* aa[1] = {s + 3}; P3_TRY(vdots(ctx, vol, 1, 1, aa, aa, rc)); }
+            P3_TRY((*M)(s, z));
+            { double* const* aa[1] = {z}; P3_TRY(vdots(ctx, vol, 3, 1, aa, aa, zz)); }
+            P3_TRY(vel_norm2(xx));
+            est_checks++;
+            const double rcc = rc[0] > 0.0 ? rc[0] : 0.0, rm = true_norm * true_norm - rcc;
+            const double est = xx > 0.0 ? (n_amp * std::sqrt(rcc) + std::sqrt(zz[0] > 0.0 ? zz[0] : 0.0)) / std::sqrt(xx) : 0.0;
+            if (rm > 0.0 && zz[0] > 0.0) a_mom = std::min(std::max(std::sqrt(zz[0] / rm), 1.0), n_amp * n_amp);
+            st->error_estimate = est;
+            if (trace3) fprintf(stderr, "[pylamp3 bicgstab] it %3d  velocity-error estimate %.3e (etol %.1e)\n", it, est, etol);
+            if (est > etol && tol > 1e-15) {
+                tol = std::min(tol, true_norm / bnorm) * std::min(0.5, 0.7 * etol / est);
+                est_rec = est; resume = true;
+                continue;
+            }
+        }
+        if (true_norm <= tol * bnorm || broke || it >= maxit || restarts >= 4) break;
         if (last_true >= 0.0 && !(true_norm < 0.5 * last_true)) break;
         restarts++;
         axpby(r, 1.0, s, 0.0, s);
     }
     if (dx != x) axpby(x, 1.0, x, 1.0, dx);
-    st->iterations = it; st->rel_residual = true_norm / bnorm; st->converged = (st->rel_residual <= rtol) ? 1 : 0;
+    st->iterations = it; st->rel_residual = true_norm / bnorm;
+    st->converged = (st->rel_residual <= rtol && !(use_est && st->error_estimate > 1.5 * etol)) ? 1 : 0;
     return 0;
 }
 
@@ -941,8 +1019,8 @@ extern "C" int pl3_stokes_solve(pl3_ctx* ctx, const double* rhs, double* x, int 
     if (!ctx->op_ready) return p3_fail(ctx, "stokes operator not set");
     if (!x) return p3_fail(ctx, "pl3_stokes_solve: x is NULL");
     P3_HIP(ctx, hipSetDevice(ctx->device));
-    P3_TRY(need_vecs(ctx, 13));
-    if (rtol <= 0) rtol = 1e-10;
+    P3_TRY(need_vecs(ctx, 14));
+    if (rtol <= 0) rtol = 1e-7;
     if (maxit <= 0) maxit = 600;
     const G3& g = ctx->geom.d;
     const long long vol = g.vol;
@@ -952,6 +1030,8 @@ extern "C" int pl3_stokes_solve(pl3_ctx* ctx, const double* rhs, double* x, int 
     if (rhs) { P3_TRY(upload3(ctx, rhs, 4, B)); hipLaunchKernelGGL(k3_scale_rows, grid3(g), dim3(64, 4), 0, ctx->stream, ctx->op, wv4(B)); }
     else hipLaunchKernelGGL(k3_rhs, grid3(g), dim3(64, 4), 0, ctx->stream, ctx->op, wv4(B), 1);
     int napply = 0, nprec = 0;
+    bool defl_active = false; double yAw = 1.0;
+    double* const* W = ctx->vec[13];
     Op3Fn A = [&](double* const* in, double* const* out) -> int {
         hipLaunchKernelGGL(k3_apply<true>, grid3(g), dim3(64, 4), 0, ctx->stream, ctx->op, cv4(in), wv4(out));
         napply++; return 0;
@@ -962,7 +1042,15 @@ extern "C" int pl3_stokes_solve(pl3_ctx* ctx, const double* rhs, double* x, int 
         int ob = 0;
         vcycle3(ctx, 0, L0->f, ob);
         for (int q = 0; q < 3; q++) P3_HIP(ctx, hipMemcpyAsync(out[q], L0->v[ob][q], (size_t)vol * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-        nprec++; return 0;
+        nprec++;
+        if (defl_active) {                  // z += w yw.(r - A z) / yw.(A w); the continuity rows of A z come from z's velocities alone
+            const double* a1[2] = {ctx->dfl_y, ctx->dfl_y}; const double* b1[2] = {in[3], ctx->dfl_t}; double o[2];
+            hipLaunchKernelGGL(k3_cont_rows, grid3(g), dim3(64, 4), 0, ctx->stream, ctx->op, cv3(out), ctx->dfl_t);
+            P3_TRY(dots3(ctx, vol, 2, a1, b1, o));
+            const double coef = (o[0] - o[1]) / yAw;
+            for (int c = 0; c < 4; c++) hipLaunchKernelGGL(k3_axpby, g1(vol), dim3(256), 0, ctx->stream, vol, out[c], 1.0, (const double*)out[c], coef, (const double*)W[c]);
+        }
+        return 0;
     };
     // hydrostatic start and the dynamic-load reference norm
     double ref = 0.0;
@@ -982,14 +1070,47 @@ extern "C" int pl3_stokes_solve(pl3_ctx* ctx, const double* rhs, double* x, int 
     else for (int c = 0; c < 4; c++) P3_HIP(ctx, hipMemcpyAsync(X[c], XH[c], (size_t)vol * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     hipLaunchKernelGGL(k3_close, grid3(g), dim3(64, 4), 0, ctx->stream, ctx->op, wv3(X), cv3(B));
     double* const* w[10] = {ctx->vec[0], ctx->vec[1], ctx->vec[2], ctx->vec[3], ctx->vec[4], ctx->vec[5], ctx->vec[6], ctx->vec[7], ctx->vec[8], ctx->vec[9]};
+    static const bool defl_on = !(getenv("PYLAMP_DEFLATE") && atoi(getenv("PYLAMP_DEFLATE")) == 0);
+    if (const char* e = getenv("PYLAMP_STOKES_ETOL")) { const double v = atof(e); if (v >= 0.0) ctx->etol = v; }
+    if (defl_on && ctx->levels.size() > 1) {
+        // the deflation vector w = A^-1 u (pl_solver.hip, "deflation of the pressure-anchor mode"), kept in vec[13] between solves
+        if (!ctx->dfl_y) { P3_TRY(dmal(ctx, &ctx->dfl_y, vol)); P3_TRY(dmal(ctx, &ctx->dfl_t, vol)); ctx->dfl_valid = false; }
+        double* const* U = XH;               // the hydrostatic vector is not needed any more
+        hipLaunchKernelGGL(k3_defl_setup, grid3(g), dim3(64, 4), 0, ctx->stream, ctx->op, wv4(U), ctx->dfl_y);
+        auto denominator = [&]() -> int {
+            const double* a1[1] = {ctx->dfl_y}; const double* b1[1] = {ctx->dfl_t}; double o[1];
+            hipLaunchKernelGGL(k3_cont_rows, grid3(g), dim3(64, 4), 0, ctx->stream, ctx->op, cv3(W), ctx->dfl_t);
+            P3_TRY(dots3(ctx, vol, 1, a1, b1, o));
+            yAw = o[0];
+            return 0;
+        };
+        double q = 1.0;
+        if (ctx->dfl_valid) {               // quality of the kept vector for this operator: ||u - A w|| / ||u||
+            double dq[2];
+            P3_TRY(A(W, ctx->vec[5]));
+            for (int c = 0; c < 4; c++) hipLaunchKernelGGL(k3_axpby, g1(vol), dim3(256), 0, ctx->stream, vol, ctx->vec[4][c], 1.0, (const double*)U[c], -1.0, (const double*)ctx->vec[5][c]);
+            double* const* aa[2] = {ctx->vec[4], U}; P3_TRY(vdots(ctx, vol, 4, 2, aa, aa, dq));
+            q = (dq[1] > 0.0 && std::isfinite(dq[0])) ? std::sqrt(dq[0] / dq[1]) : 1.0;
+        }
+        const bool reuse = ctx->dfl_valid && q < 0.5;
+        if (reuse) { P3_TRY(denominator()); defl_active = yAw != 0.0 && std::isfinite(yAw); }
+        if (!reuse || q > 0.1) {
+            if (!reuse) for (int c = 0; c < 4; c++) P3_HIP(ctx, hipMemsetAsync(W[c], 0, (size_t)vol * sizeof(double), ctx->stream));
+            Stats3 st2{};
+            P3_TRY(bicgstab3(ctx, vol, 4, A, &M, U, W, reuse, 1e-3, 80, w, g, &st2, 0.0));
+            ctx->dfl_valid = st2.rel_residual < 0.05 && std::isfinite(st2.rel_residual);
+            defl_active = false;
+            if (ctx->dfl_valid) { P3_TRY(denominator()); defl_active = yAw != 0.0 && std::isfinite(yAw); }
+        }
+    }
     Stats3 st{};
-    P3_TRY(bicgstab3(ctx, vol, 4, A, &M, B, X, true, rtol, maxit, w, g, &st, ref));
+    P3_TRY(bicgstab3(ctx, vol, 4, A, &M, B, X, true, rtol, maxit, w, g, &st, ref, ctx->etol));
     P3_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     P3_HIP(ctx, hipEventSynchronize(ctx->ev1));
     float ms = 0; P3_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     P3_TRY(download3(ctx, X, 4, x));
     if (stats) { stats->iterations = st.iterations; stats->converged = st.converged; stats->rel_residual = st.rel_residual; stats->solve_ms = ms;
-                 stats->operator_applies = napply; stats->precond_applies = nprec; }
+                 stats->operator_applies = napply; stats->precond_applies = nprec; stats->used_direct = 0; stats->error_estimate = st.error_estimate; }
     return 0;
 }
 extern "C" int pl3_stokes_mg_info(pl3_ctx* ctx, int* nlevels, double* lmax, int max_levels) {
