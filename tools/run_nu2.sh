@@ -1,0 +1,15 @@
+run() {
+  env "$@" python bench.py --steps 8 --warmup 2 --no-cpu-baseline --apply-reps 2 2>/dev/null | python -c "
+import sys, json
+for line in sys.stdin:
+    if line.startswith('{'):
+        d = json.loads(line); print('$*', d['ms_per_step'], d['stage_ms']['ms_stokes'], d['stokes_iterations'], min(d['stokes_converged']))
+"
+}
+run X=1
+run PYLAMP_MG_NU0=1,2 PYLAMP_MG_NU=3,3
+run PYLAMP_MG_NU0=2,2 PYLAMP_MG_NU=3,3
+run PYLAMP_MG_NU0=1,1 PYLAMP_MG_NU=2,2
+run PYLAMP_MG_NU0=1,1 PYLAMP_MG_NU=2,3
+run PYLAMP_MG_NU0=1,1 PYLAMP_MG_NU=4,4
+run PYLAMP_MG_POWER=1
