@@ -93,12 +93,18 @@ template <int D> __device__ inline double dpp_row_shr(double v) {
     hi = __builtin_amdgcn_update_dpp(0, hi, 0x110 + D, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
+// PL_RUN_MAX: longest run summed in registers (runs are cut at multiples of it): 16 needs four DPP steps, 8 three -- at the
+// price of two LDS atomics per 16-marker cell instead of one.  Measured at 68 M markers: the four scatters of a step take
+// 5.8 ms with 8 against 6.4 ms with 16
+#ifndef PL_RUN_MAX
+#define PL_RUN_MAX 8
+#endif
 __device__ inline double run_sum(double v, int reach) {
     double o;
     o = dpp_row_shr<1>(v); v += (reach >= 1) ? o : 0.0;
     o = dpp_row_shr<2>(v); v += (reach >= 2) ? o : 0.0;
     o = dpp_row_shr<4>(v); v += (reach >= 4) ? o : 0.0;
-    o = dpp_row_shr<8>(v); v += (reach >= 8) ? o : 0.0;
+    if (PL_RUN_MAX > 8) { o = dpp_row_shr<8>(v); v += (reach >= 8) ? o : 0.0; }
     return v;
 }
 
@@ -143,7 +149,7 @@ __global__ __launch_bounds__(256) void k_scatter_binned(PlScatterArgs a, int til
             // 16-way same-address conflict (~150 cycles per wave instruction)
             const int ie_p = __builtin_amdgcn_update_dpp(0, ie, 0x111, 0xf, 0xf, false);
             const int je_p = __builtin_amdgcn_update_dpp(0, je, 0x111, 0xf, 0xf, false);
-            const bool head = (lane & 15) == 0 || ie_p != ie || je_p != je;
+            const bool head = (lane & (PL_RUN_MAX - 1)) == 0 || ie_p != ie || je_p != je;
             const unsigned long long heads = __ballot(head);
             const int seg0 = 63 - __clzll(heads & (~0ull >> (63 - lane)));       // first lane of my run (same row of 16)
             const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
