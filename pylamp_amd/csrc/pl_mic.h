@@ -5,6 +5,8 @@
 #define PL_MAX_SCATTER_FIELDS 8
 #define PL_MAX_GATHER_FIELDS 8
 
+// internal scheme bit: the field values are logarithms already (the resident step takes log(eta) once per marker and step)
+#define PL_AVG_PRELOG 64
 struct PlScatterArgs {
     long long n;
     const double* tz; const double* tx;

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_scatter_atomic(PlScatterArgs a) {
     double val[PL_MAX_SCATTER_FIELDS];
     for (int k = 0; k < a.nf; k++) {
         double v = a.f[k][t];
-        val[k] = (a.scheme[k] & PL_AVG_GEOMETRIC) && !(a.scheme[k] & PL_AVG_ARITHMETIC) ? log(v) : v;
+        val[k] = (a.scheme[k] & PL_AVG_GEOMETRIC) && !(a.scheme[k] & (PL_AVG_ARITHMETIC | PL_AVG_PRELOG)) ? log(v) : v;
     }
 #pragma unroll
     for (int cnr = 0; cnr < 4; cnr++) {
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void k_scatter_binned(PlScatterArgs a, int til
             double val[PL_MAX_SCATTER_FIELDS];
             for (int k = 0; k < a.nf; k++) {
                 const double v = valid ? a.f[k][t] : 1.0;
-                val[k] = (a.scheme[k] & PL_AVG_GEOMETRIC) && !(a.scheme[k] & PL_AVG_ARITHMETIC) ? log(v) : v;
+                val[k] = (a.scheme[k] & PL_AVG_GEOMETRIC) && !(a.scheme[k] & (PL_AVG_ARITHMETIC | PL_AVG_PRELOG)) ? log(v) : v;
             }
             // runs of consecutive lanes in the same target cell (the tracers are cell-sorted) are summed in registers
             // first, so that one lane per run issues the LDS atomics: 16 markers per cell made every ds_add_f64 a

@@ -249,7 +249,8 @@ __global__ __launch_bounds__(256) void k_property_update(long long n, const doub
                                                          const double* __restrict__ rh0, const double* __restrict__ alp,
                                                          const double* __restrict__ ace, const double* __restrict__ et0,
                                                          double* __restrict__ rho, double* __restrict__ eta, int tdep_rho,
-                                                         int tdep_eta, double tref, double etamin, double etamax) {
+                                                         int tdep_eta, double tref, double etamin, double etamax,
+                                                         double* __restrict__ logeta) {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const double Tt = T[t];
@@ -261,6 +262,7 @@ __global__ __launch_bounds__(256) void k_property_update(long long n, const doub
         if (e > etamax) e = etamax;
     }
     eta[t] = e;
+    logeta[t] = log(e);         // for the two geometric-mean scatters of the viscosity (PL_AVG_PRELOG): one log per marker and step instead of two
 }
 
 // block partials of min / max / nan-flag of a ring plane over the lnz x lnx interior
@@ -908,19 +910,20 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
     t0 = now_ms();
     hipLaunchKernelGGL(k_property_update, grid1d(n), dim3(256), 0, ctx->stream, n, S->f[TR_TMP], S->f[TR_RH0], S->f[TR_ALP],
                        S->f[TR_ACE], S->f[TR_ET0], S->f[TR_RHO], S->f[TR_ETA], cfg->tdep_rho, cfg->tdep_eta, cfg->tref,
-                       cfg->etamin, cfg->etamax);
+                       cfg->etamin, cfg->etamax, S->tmp[2]);
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     rep->ms_props = now_ms() - t0;
 
     // ---- 2. tracer -> grid (pylamp2.py:307-319) ------------------------------------------------
     t0 = now_ms();
-    const int AW = PL_AVG_ARITHMETIC | PL_AVG_WEIGHTED, GW = PL_AVG_GEOMETRIC | PL_AVG_WEIGHTED;
+    const int AW = PL_AVG_ARITHMETIC | PL_AVG_WEIGHTED, GW = PL_AVG_GEOMETRIC | PL_AVG_WEIGHTED | PL_AVG_PRELOG;
+    const int ETA_LOG = -3;                     // S->tmp[2]: log(eta) written by k_property_update
     if (cfg->do_heatdiff) {
-        const int fi[6] = {TR_RHO, TR_ETA, TR_HCP, TR_TMP, TR_IHT, TR_MAT};
+        const int fi[6] = {TR_RHO, ETA_LOG, TR_HCP, TR_TMP, TR_IHT, TR_MAT};
         const int sc[6] = {AW, GW, AW, AW, AW, AW};
         double* pl6[6] = {p_rho, p_etas, p_cp, p_T, p_H, p_mat};
         PL_TRY(scatter_to_planes(ctx, S, 6, fi, sc, z0, hz, x0, hx, pl6));
-        const int f1[1] = {TR_ETA}; const int s1[1] = {GW}; double* pn[1] = {p_etan};
+        const int f1[1] = {ETA_LOG}; const int s1[1] = {GW}; double* pn[1] = {p_etan};
         PL_TRY(scatter_to_planes(ctx, S, 1, f1, s1, z0 + 0.5 * hz, hz, x0 + 0.5 * hx, hx, pn, 1, 1));
         const int f2[1] = {TR_HCD}; const int s2[1] = {AW};
         double* pk[1] = {p_kz};
@@ -930,10 +933,10 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
         if (it > 1 && S->have_newtemp)
             hipLaunchKernelGGL(k_copy_boundary, grid2d(g), dim3(64, 4), 0, ctx->stream, g, p_newT, p_T);
     } else {
-        const int fi[2] = {TR_RHO, TR_ETA}; const int sc[2] = {AW, GW};
+        const int fi[2] = {TR_RHO, ETA_LOG}; const int sc[2] = {AW, GW};
         double* pl2[2] = {p_rho, p_etas};
         PL_TRY(scatter_to_planes(ctx, S, 2, fi, sc, z0, hz, x0, hx, pl2));
-        const int f1[1] = {TR_ETA}; const int s1[1] = {PL_AVG_GEOMETRIC}; double* pn[1] = {p_etan};   // pylamp2.py:319 (unweighted)
+        const int f1[1] = {ETA_LOG}; const int s1[1] = {PL_AVG_GEOMETRIC | PL_AVG_PRELOG}; double* pn[1] = {p_etan};   // pylamp2.py:319 (unweighted)
         PL_TRY(scatter_to_planes(ctx, S, 1, f1, s1, z0 + 0.5 * hz, hz, x0 + 0.5 * hx, hx, pn, 1, 1));
     }
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
