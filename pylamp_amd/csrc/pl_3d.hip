@@ -537,6 +537,7 @@ struct pl3_ctx {
     int nu = 2, coarse_sweeps = 12; double cheb_ratio = 6.0;
     // deflation of the pressure-anchor mode (see pl_solver.hip): the vector w = A^-1 u lives in vec[13], kept between solves
     double *dfl_y = nullptr, *dfl_t = nullptr; bool dfl_valid = false;
+    bool dfl_active = false; double dfl_yAw = 0.0, dfl_wvel2 = 0.0;      // of the running solve: the anchor-mode term of the error estimate
     double etol = 3e-8;                     // bound on the velocity-error estimate of a converged Stokes solve (PYLAMP_STOKES_ETOL)
 };
 static thread_local std::string p3_tls_error;
@@ -906,6 +907,16 @@ static int bicgstab3(pl3_ctx* ctx, long long vol, int na, const Op3Fn& A, const 
     bool resume = false, broke = false;
     double rho = 1.0, alpha = 1.0, omega = 1.0, rho_new = 0.0, rnorm = 0.0, best = 0.0; int best_it = 0;
     st->error_estimate = 0.0;
+    // the component of the residual along the deflated anchor mode has its own amplification |w| / |u| (see pl_solver.hip)
+    const bool anchor_term = use_est && ctx->dfl_active && ctx->dfl_yAw != 0.0;
+    auto anchor_part = [&](double* const* res, double xx, double& out) -> int {
+        out = 0.0;
+        if (!anchor_term || !(xx > 0.0)) return 0;
+        const double* a1[1] = {ctx->dfl_y}; const double* b1[1] = {res[3]}; double o[1];
+        P3_TRY(dots3(ctx, vol, 1, a1, b1, o));
+        out = std::fabs(o[0] / ctx->dfl_yAw) * std::sqrt(ctx->dfl_wvel2 / xx);
+        return 0;
+    };
     auto vel_norm2 = [&](double& xx) -> int {        // |(x0 + dx)_vel|^2, through t as scratch
         double* const* src = dx;
         if (dx != x) { for (int c = 0; c < 3; c++) hipLaunchKernelGGL(k3_axpby, g1(vol), dim3(256), 0, ctx->stream, vol, t[c], 1.0, (const double*)x[c], 1.0, (const double*)dx[c]); src = t; }
@@ -957,7 +968,9 @@ static int bicgstab3(pl3_ctx* ctx, long long vol, int na, const Op3Fn& A, const 
                 { double* const* aa[1] = {r + 3}; P3_TRY(vdots(ctx, vol, 1, 1, aa, aa, rc)); }
                 P3_TRY(vel_norm2(xx));
                 const double rm = rr - rc[0] > 0.0 ? rr - rc[0] : 0.0;
-                if (xx > 0.0) est_rec = (n_amp * std::sqrt(rc[0] > 0.0 ? rc[0] : 0.0) + a_mom * std::sqrt(rm)) / std::sqrt(xx);
+                double ap = 0.0;
+                P3_TRY(anchor_part(r, xx, ap));
+                if (xx > 0.0) est_rec = (n_amp * std::sqrt(rc[0] > 0.0 ? rc[0] : 0.0) + a_mom * std::sqrt(rm)) / std::sqrt(xx) + ap;
             }
             if (it - best_it > 80 || rnorm > 1e8 * best) { broke = true; break; }
         }
@@ -973,7 +986,9 @@ static int bicgstab3(pl3_ctx* ctx, long long vol, int na, const Op3Fn& A, const 
             P3_TRY(vel_norm2(xx));
             est_checks++;
             const double rcc = rc[0] > 0.0 ? rc[0] : 0.0, rm = true_norm * true_norm - rcc;
-            const double est = xx > 0.0 ? (n_amp * std::sqrt(rcc) + std::sqrt(zz[0] > 0.0 ? zz[0] : 0.0)) / std::sqrt(xx) : 0.0;
+            double ap = 0.0;
+            P3_TRY(anchor_part(s, xx, ap));
+            const double est = (xx > 0.0 ? (n_amp * std::sqrt(rcc) + std::sqrt(zz[0] > 0.0 ? zz[0] : 0.0)) / std::sqrt(xx) : 0.0) + ap;
             if (rm > 0.0 && zz[0] > 0.0) a_mom = std::min(std::max(std::sqrt(zz[0] / rm), 1.0), n_amp * n_amp);
             st->error_estimate = est;
             if (trace3) fprintf(stderr, "[pylamp3 bicgstab] it %3d  velocity-error estimate %.3e (etol %.1e)\n", it, est, etol);
@@ -1103,8 +1118,11 @@ extern "C" int pl3_stokes_solve(pl3_ctx* ctx, const double* rhs, double* x, int 
             if (ctx->dfl_valid) { P3_TRY(denominator()); defl_active = yAw != 0.0 && std::isfinite(yAw); }
         }
     }
+    ctx->dfl_active = defl_active; ctx->dfl_yAw = yAw; ctx->dfl_wvel2 = 0.0;
+    if (defl_active) { double* const* aa[1] = {W}; double o[1]; P3_TRY(vdots(ctx, vol, 3, 1, aa, aa, o)); ctx->dfl_wvel2 = o[0]; }
     Stats3 st{};
     P3_TRY(bicgstab3(ctx, vol, 4, A, &M, B, X, true, rtol, maxit, w, g, &st, ref, ctx->etol));
+    ctx->dfl_active = false;
     P3_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     P3_HIP(ctx, hipEventSynchronize(ctx->ev1));
     float ms = 0; P3_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));

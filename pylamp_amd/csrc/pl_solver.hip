@@ -15,6 +15,7 @@
 //
 // Algorithm prototype with the same structure: oracle/proto_stokes_solver.py (tests only).
 #include "pl_internal.h"
+#include <chrono>
 #include <cmath>
 #include <functional>
 #include <limits>
@@ -692,7 +693,7 @@ __global__ __launch_bounds__(256) void k_coarsen_visc(PlGeom gf, const double* _
 // no atomics; the host adds the (<= DOT_BLOCKS) partials in a fixed order, so the result is
 // deterministic.
 #define DOT_BLOCKS 1024
-#define PL_SCAL_N 24            // device scalars in front of the dot partials (PlSolver::scal)
+#define PL_SCAL_N 32            // device scalars in front of the dot partials (PlSolver::scal)
 template <bool HAS_A, bool HAS_C>
 __global__ __launch_bounds__(256) void k_dot2(PlGeom g, int nplanes, const double* __restrict__ a,
                                               const double* __restrict__ b, const double* __restrict__ cc,
@@ -1160,6 +1161,7 @@ struct PlSolver {
     bool defl_persistent = false;        // (informational) set by the time-step driver: consecutive solves of one model
     bool defl_valid = false, defl_active = false;
     double *wdefl = nullptr, *udefl = nullptr;
+    double defl_yAw = 0.0, defl_wvel2 = 0.0;     // host copies: y.(A w) and ||w_vel||^2 (the anchor-mode term of the error estimate)
     double schur_scale = 1.0;    // S^ = schur_scale * Kc^2 / eta_n (PYLAMP_SCHUR_SCALE)
     bool fuse_first = true;      // PYLAMP_FUSE_FIRST=0: the first sweep of level 0 as a pass of its own
     bool deep = true;            // PYLAMP_MG_DEEP=0: distributed levels exchange before every sweep instead of once per smoothing sequence
@@ -1341,7 +1343,7 @@ static int dots5_dev(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, int nspl
     const bool reduce = ctx->nranks > 1 && pl_geom_is_dist(g);
     hipLaunchKernelGGL(k_sum_partials5, dim3(1), dim3(256), 0, ctx->stream, nb, S->scal + PL_SCAL_N, S->scal, reduce ? 0 : 1);
     if (reduce) {
-        PL_TRY(pl_comm_allreduce_dev(ctx, S->scal + 8, 9));         // scal[16]: the local ||x_vel||^2 rides along (norm2_sum_local)
+        PL_TRY(pl_comm_allreduce_dev(ctx, S->scal + 8, 11));        // scal[16..18]: the local ||x_vel||^2, y.s and y.t ride along
         hipLaunchKernelGGL(k_bicg_derive, dim3(1), dim3(1), 0, ctx->stream, S->scal);
     }
     return 0;
@@ -2016,6 +2018,8 @@ static int stokes_precond(pl_ctx* ctx, PlSolver* S, const double* rs, double* z)
     return S->levels[0]->f32 ? stokes_precond_t<float>(ctx, S, rs, z) : stokes_precond_t<double>(ctx, S, rs, z);
 }
 
+__global__ void k_defl_ysum(PlStokesOp op, const double* __restrict__ rp, double* __restrict__ part);      // defined with the deflation below
+
 // =========================================================================================
 // Generic right-preconditioned BiCGStab (host-driven scalars)
 // =========================================================================================
@@ -2090,9 +2094,30 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
     const double n_amp = (double)std::max(ctx->nz, ctx->nx);
     double est_rec = 0.0;                           // 0: unknown (far from convergence) -- only the residual test applies
     double a_mom = 1.0;                             // ||A_vv^-1 r_mom|| / ||r_mom|| as measured at the last true check (below)
-    auto estimate = [&](double rr_cont, double rr_total, double xx) {
+    // With the pressure-anchor deflation active the component of the residual along that mode needs its own term: its
+    // amplification is ||w|| / ||u|| (1e4 and more), far beyond n -- r = gamma u + ..., gamma = y.r / y.u, and the error it stands
+    // for is gamma w (A w = u).  Without the deflation BiCGStab has removed this component by the time it leaves its plateau;
+    // with it nothing in the residual NORM shows it (found as a 1.9e-6 error behind an estimate of 2e-8 on the 33 x 41 fixture).
+    const bool anchor_term = use_est && S->defl_active && S->defl_yAw != 0.0 && np == 3;
+    auto estimate = [&](double rr_cont, double rr_total, double xx, double yr) {
         const double rc = rr_cont > 0.0 ? rr_cont : 0.0, rm = rr_total - rc > 0.0 ? rr_total - rc : 0.0;
-        return xx > 0.0 ? (n_amp * std::sqrt(rc) + a_mom * std::sqrt(rm)) / std::sqrt(xx) : 0.0;
+        if (!(xx > 0.0)) return 0.0;
+        double e = (n_amp * std::sqrt(rc) + a_mom * std::sqrt(rm)) / std::sqrt(xx);
+        if (anchor_term) e += std::fabs(yr / S->defl_yAw) * std::sqrt(S->defl_wvel2 / xx);
+        return e;
+    };
+    auto ysum_dev = [&](const double* rp, double* out_slot) {       // y . r over the continuity rows -> *out_slot (this rank's share)
+        const int nb = g.lnz < DOT_BLOCKS ? g.lnz : DOT_BLOCKS;
+        hipLaunchKernelGGL(k_defl_ysum, dim3(nb), dim3(256), 0, ctx->stream, ctx->sop, rp, S->scal + PL_SCAL_N);
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, nb, S->scal + PL_SCAL_N, out_slot, 0, 0.0);
+    };
+    auto ysum_host = [&](const double* rp, double& yr) -> int {     // the same, reduced over the ranks, on the host
+        ysum_dev(rp, S->scal + 28);
+        if (ctx->nranks > 1 && pl_geom_is_dist(g)) PL_TRY(pl_comm_allreduce_dev(ctx, S->scal + 28, 1));
+        PL_HIP(ctx, hipMemcpyAsync(S->hpart + 8 * DOT_BLOCKS, S->scal + 28, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        yr = S->hpart[8 * DOT_BLOCKS];
+        return 0;
     };
     bool resume = false;                            // continue the running iteration instead of restarting it
     double rho = 1.0, alpha = 1.0, omega = 1.0, rho_new = 0.0, rnorm = 0.0;
@@ -2134,6 +2159,10 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
                 // it can ride along in the fused reduction -- the estimate needs it to ~10 %)
                 const bool want_xx = use_est && rnorm <= 1e3 * tol * bnorm;
                 if (want_xx) PL_TRY(norm2_sum_dev(ctx, S, g, np_vel, dx, dx != x ? (const double*)x : (const double*)nullptr, false));
+                if (want_xx && anchor_term) {            // y.r of the updated residual = y.s - omega y.t: both ride in the reduction as well
+                    ysum_dev(w.s + (long long)np_vel * g.plane, S->scal + 17);
+                    ysum_dev(w.t + (long long)np_vel * g.plane, S->scal + 18);
+                }
                 PL_TRY(dots5_dev(ctx, S, g, np, use_est ? np_vel : np, w.t, w.s, w.rt));       // omega, rho' and |r|^2 from ONE reduction
                 // ... and the next direction in the same pass (the host's beta above is then only the breakdown test)
                 if (yv != w.p) {
@@ -2148,7 +2177,7 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
                 alpha = hs[2]; omega = hs[3];
                 rho_new = hs[5]; rnorm = std::sqrt(hs[6]);
                 if (!std::isfinite(alpha)) { broke = true; break; }
-                if (want_xx) est_rec = estimate(hs[15] - 2.0 * omega * hs[13] + omega * omega * hs[14], hs[6], hs[16]);
+                if (want_xx) est_rec = estimate(hs[15] - 2.0 * omega * hs[13] + omega * omega * hs[14], hs[6], hs[16], hs[17] - omega * hs[18]);
                 else est_rec = 0.0;
             } else {
                 PL_TRY(dots(ctx, S, g, np, w.rt, w.v, nullptr, nullptr, d2));
@@ -2174,7 +2203,10 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
                     PL_TRY(norm2_sum_dev(ctx, S, g, np_vel, dx, dx != x ? (const double*)x : (const double*)nullptr, true));
                     PL_HIP(ctx, hipMemcpyAsync(S->hpart + 8 * DOT_BLOCKS, S->scal + 16, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
                     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                    est_rec = estimate(dc[0], d2[1], S->hpart[8 * DOT_BLOCKS]);
+                    const double xxh = S->hpart[8 * DOT_BLOCKS];
+                    double yr = 0.0;
+                    if (anchor_term) PL_TRY(ysum_host(w.r + (long long)np_vel * g.plane, yr));
+                    est_rec = estimate(dc[0], d2[1], xxh, yr);
                 } else est_rec = 0.0;
             }
             if (!std::isfinite(rnorm) || !(std::fabs(omega) > 0.0)) { broke = true; break; }
@@ -2209,11 +2241,18 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
             est_checks++;
             const double xx = S->hpart[8 * DOT_BLOCKS];
             const double rc = dc[0] > 0.0 ? dc[0] : 0.0, rm = true_norm * true_norm - rc;
-            const double est = xx > 0.0 ? (n_amp * std::sqrt(rc) + std::sqrt(dz[0] > 0.0 ? dz[0] : 0.0)) / std::sqrt(xx) : 0.0;
+            double est = xx > 0.0 ? (n_amp * std::sqrt(rc) + std::sqrt(dz[0] > 0.0 ? dz[0] : 0.0)) / std::sqrt(xx) : 0.0;
+            double anchor_part = 0.0;
+            if (anchor_term && xx > 0.0) {
+                double yr = 0.0;
+                PL_TRY(ysum_host(w.s + (long long)np_vel * g.plane, yr));
+                anchor_part = std::fabs(yr / S->defl_yAw) * std::sqrt(S->defl_wvel2 / xx);
+                est += anchor_part;
+            }
             if (rm > 0.0 && dz[0] > 0.0) a_mom = std::min(std::max(std::sqrt(dz[0] / rm), 1.0), n_amp * n_amp);
             st->error_estimate = est;
-            if (trace) fprintf(stderr, "[pylamp bicgstab] it %3d  velocity-error estimate %.3e (etol %.1e): continuity %.3e momentum %.3e (amplification %.1f)\n",
-                               it, est, etol, xx > 0.0 ? n_amp * std::sqrt(rc / xx) : 0.0, xx > 0.0 ? std::sqrt(dz[0] / xx) : 0.0, a_mom);
+            if (trace) fprintf(stderr, "[pylamp bicgstab] it %3d  velocity-error estimate %.3e (etol %.1e): continuity %.3e momentum %.3e (amplification %.1f) anchor mode %.3e\n",
+                               it, est, etol, xx > 0.0 ? n_amp * std::sqrt(rc / xx) : 0.0, xx > 0.0 ? std::sqrt(dz[0] / xx) : 0.0, a_mom, anchor_part);
             if (est > etol && tol > 1e-15) {
                 tol = std::min(tol, true_norm / bnorm) * std::min(0.5, 0.7 * etol / est);
                 est_rec = est;
@@ -2295,8 +2334,8 @@ __global__ __launch_bounds__(256) void k_defl_ysum(PlStokesOp op, const double* 
     __syncthreads();
     if (threadIdx.x == 0) { part[2 * blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3]; part[2 * blockIdx.x + 1] = 0.0; }
 }
-// y . (D_r A x) from the five cells without a continuity row.  mode 1: sc[18] = y.(A x) (the denominator, x = w);
-// mode 0: sc[19] = (sc[20] - y.(A x)) / sc[18]  (sc[20] = y . r, x = z); mode 2 + k_defl_divide: the same with an all-reduce in between
+// y . (D_r A x) from the five cells without a continuity row.  mode 1: sc[24] = y.(A x) (the denominator, x = w);
+// mode 0: sc[25] = (sc[26] - y.(A x)) / sc[24]  (sc[26] = y . r, x = z); mode 2 + k_defl_divide: the same with an all-reduce in between
 __global__ void k_defl_coef(PlStokesOp op, const double* __restrict__ x, double* __restrict__ sc, int mode) {
     const PlGeom& g = op.g;
     const int ci[5] = {op.anchor_i, 0, 0, g.nz - 2, g.nz - 2}, cj[5] = {op.anchor_j, 0, g.nx - 2, 0, g.nx - 2};
@@ -2311,11 +2350,11 @@ __global__ void k_defl_coef(PlStokesOp op, const double* __restrict__ x, double*
         five += (vz[c + g.pitch] - vz[c]) / TB(g.rdx, j) + (vx[c + 1] - vx[c]) / TB(g.rdz, i);      // area x div = hx dvz + hz dvx
     }
     const double yAx = -five;
-    if (mode == 1) sc[18] = yAx;                                                                  // (this rank's share on several ranks)
-    else if (mode == 2) sc[21] = sc[20] - yAx;                                                    // this rank's share of the numerator
-    else sc[19] = (sc[18] != 0.0 && isfinite(sc[18])) ? (sc[20] - yAx) / sc[18] : 0.0;
+    if (mode == 1) sc[24] = yAx;                                                                  // (this rank's share on several ranks)
+    else if (mode == 2) sc[27] = sc[26] - yAx;                                                    // this rank's share of the numerator
+    else sc[25] = (sc[24] != 0.0 && isfinite(sc[24])) ? (sc[26] - yAx) / sc[24] : 0.0;
 }
-__global__ void k_defl_divide(double* __restrict__ sc) { sc[19] = (sc[18] != 0.0 && isfinite(sc[18])) ? sc[21] / sc[18] : 0.0; }
+__global__ void k_defl_divide(double* __restrict__ sc) { sc[25] = (sc[24] != 0.0 && isfinite(sc[24])) ? sc[27] / sc[24] : 0.0; }
 __global__ void k_axpy_dev_scalar(long long n, double* __restrict__ z, const double* __restrict__ w, const double* __restrict__ sc) {
     const double a = sc[0];
     long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2330,7 +2369,12 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
     PlSolver* S = solver_of(ctx);
     PL_TRY(stokes_alloc(ctx, S));
     PL_TRY(pl_timer_start(ctx));
+    static const bool trace_t = getenv("PYLAMP_SOLVER_TRACE") != nullptr;        // phase times (host clock, stream synchronised)
+    auto now = [&]() { (void)hipStreamSynchronize(ctx->stream); return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tph[5] = {0, 0, 0, 0, 0};
+    if (trace_t) tph[0] = now();
     PL_TRY(build_hierarchy(ctx, S));
+    if (trace_t) tph[1] = now();
     const PlGeom& g = ctx->geom.d;
     PlStokesOp sop = ctx->sop;
     PlStokesOp sop_scaled = sop; sop_scaled.scaled = 1;
@@ -2347,14 +2391,14 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
         if (S->defl_active) {                               // z += w y.(r - A z) / y.(A w), all scalars on the device
             const int nb = g.lnz < DOT_BLOCKS ? g.lnz : DOT_BLOCKS;
             hipLaunchKernelGGL(k_defl_ysum, dim3(nb), dim3(256), 0, ctx->stream, sop, in + 2 * g.plane, S->scal + PL_SCAL_N);
-            hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, nb, S->scal + PL_SCAL_N, S->scal + 20, 0, 0.0);
+            hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, nb, S->scal + PL_SCAL_N, S->scal + 26, 0, 0.0);
             if (ctx->nranks > 1) {                          // one scalar per application: y.r and the five cells live on different ranks
                 hipLaunchKernelGGL(k_defl_coef, dim3(1), dim3(1), 0, ctx->stream, sop, (const double*)out, S->scal, 2);
-                PL_TRY(pl_comm_allreduce_dev(ctx, S->scal + 21, 1));
+                PL_TRY(pl_comm_allreduce_dev(ctx, S->scal + 27, 1));
                 hipLaunchKernelGGL(k_defl_divide, dim3(1), dim3(1), 0, ctx->stream, S->scal);
             } else
                 hipLaunchKernelGGL(k_defl_coef, dim3(1), dim3(1), 0, ctx->stream, sop, (const double*)out, S->scal, 0);
-            hipLaunchKernelGGL(k_axpy_dev_scalar, grid1d(n3v), dim3(256), 0, ctx->stream, n3v, out, (const double*)S->wdefl, (const double*)(S->scal + 19));
+            hipLaunchKernelGGL(k_axpy_dev_scalar, grid1d(n3v), dim3(256), 0, ctx->stream, n3v, out, (const double*)S->wdefl, (const double*)(S->scal + 25));
         }
         return 0;
     };
@@ -2380,7 +2424,7 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
         const bool reuse = S->defl_valid && q < 0.5;
         if (reuse) {                                        // denominator y.(A w) of the old w under the new coefficients
             hipLaunchKernelGGL(k_defl_coef, dim3(1), dim3(1), 0, ctx->stream, sop, (const double*)S->wdefl, S->scal, 1);
-            if (ctx->nranks > 1) PL_TRY(pl_comm_allreduce_dev(ctx, S->scal + 18, 1));
+            if (ctx->nranks > 1) PL_TRY(pl_comm_allreduce_dev(ctx, S->scal + 24, 1));
             S->defl_active = true;
         }
         if (!reuse || q > 0.1) {
@@ -2390,11 +2434,20 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
             S->defl_valid = st2.rel_residual < 0.05 && std::isfinite(st2.rel_residual);
             if (S->defl_valid) {
                 hipLaunchKernelGGL(k_defl_coef, dim3(1), dim3(1), 0, ctx->stream, sop, (const double*)S->wdefl, S->scal, 1);
-                if (ctx->nranks > 1) PL_TRY(pl_comm_allreduce_dev(ctx, S->scal + 18, 1));
+                if (ctx->nranks > 1) PL_TRY(pl_comm_allreduce_dev(ctx, S->scal + 24, 1));
             }
             S->defl_active = S->defl_valid;
         }
     }
+    if (S->defl_active) {                                   // host copies for the anchor-mode term of the error estimate
+        double dw[2];
+        PL_TRY(dots(ctx, S, g, 2, S->wdefl, S->wdefl, nullptr, nullptr, dw));
+        S->defl_wvel2 = dw[0];
+        PL_HIP(ctx, hipMemcpyAsync(S->hpart + 8 * DOT_BLOCKS, S->scal + 24, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        S->defl_yAw = S->hpart[8 * DOT_BLOCKS];
+    }
+    if (trace_t) tph[2] = now();
     if (b_dev != S->b)
         PL_HIP(ctx, hipMemcpyAsync(S->b, b_dev, (size_t)3 * g.plane * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     hipLaunchKernelGGL(k_stokes_scale_rows, grid2d(g), dim3(64, 4), 0, ctx->stream, sop, S->b);
@@ -2451,7 +2504,13 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
         }
     }
     hipLaunchKernelGGL(k_close_constraints, grid2d(g), dim3(64, 4), 0, ctx->stream, sop, S->levels[0]->op, S->b, S->x);
+    if (trace_t) tph[3] = now();
     PL_TRY(bicgstab(ctx, S, g, 3, A, &M, S->b, S->x, use_x0, rtol, maxit, w, st, ref, S->etol, 2));
+    if (trace_t) {
+        tph[4] = now();
+        fprintf(stderr, "[pylamp stokes] phases: hierarchy + eigenvalues %.2f ms, deflation vector %.2f ms, hydrostatic state + reference norm %.2f ms, "
+                        "BiCGStab %.2f ms (%d iterations)\n", tph[1] - tph[0], tph[2] - tph[1], tph[3] - tph[2], tph[4] - tph[3], st->iterations);
+    }
     st->used_direct = 0;
     if (!st->converged && pl_direct_possible(ctx) && !getenv("PYLAMP_NO_DIRECT")) {
         // Small system the iteration could not solve (an indefinite velocity block: the reference's stabilisation sign at the

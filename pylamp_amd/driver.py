@@ -35,7 +35,7 @@ class Options:
                        pylamp_diff.BC_TYPE_FIXTEMP, pylamp_diff.BC_TYPE_FIXFLOW]
         self.bcheatvals = [273.0, 0.0, 1623.0, 0.0]
         self.stokes_rtol, self.stokes_maxit = 1e-7, 400       # + velocity-error estimate <= 3e-8 (pl_stokes_solve)
-        self.heat_rtol, self.heat_maxit = 1e-12, 2000
+        self.heat_rtol, self.heat_maxit = 1e-12, 2000             # 1e-10 is NOT enough: on the 33x41 reference trajectory it puts 1.9e-6 into the next step's velocity (heat solver)
         self.tracdens, self.tracdens_min, self.inject_seed = 0, 0, 12345     # pylamp2.py:39-40; 0 = no injection
         # False: the reference's ID rule for injected tracers (first new ID of every refilled cell repeats the last one
         # handed out, pylamp2.py:621-622); True: unique IDs

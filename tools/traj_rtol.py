@@ -11,6 +11,7 @@ for name, heat in (("traj_mantle33x41", True), ("traj_block41", False)):
     nx = [gz.size, gx.size]; L = [gz[-1], gx[-1]]
     for rtol in (1e-6, 1e-7, 1e-8, 1e-10, 1e-12):
         opt = driver.Options(do_heatdiff=heat, tdep_rho=heat, tdep_eta=heat); opt.stokes_rtol = rtol
+        if os.environ.get('HEAT_RTOL'): opt.heat_rtol = float(os.environ['HEAT_RTOL'])
         sim = driver.Simulation(nx, L, g["init_tr_x"], g["init_tr_f"], opt)
         out = []
         for it in range(1, int(g["nsteps"]) + 1):
