@@ -35,7 +35,9 @@ struct PlScatterArgs {
 };
 
 // tile of sort cells handled by one workgroup of the LDS-binned scatter
+#ifndef PL_TILE_R
 #define PL_TILE_R 8
+#endif
 #define PL_TILE_C 32
 
 struct PlGatherGrid {

@@ -115,10 +115,16 @@ __device__ inline double run_sum(double v, int reach) {
 // Global atomic traffic drops from 4*(nf+1) per TRACER to <= (nf+1) per NODE of the window.
 // A contribution outside the window (a tracer that the sort had to clamp) falls back to a
 // global atomic, so the result does not depend on the sort being exact.
+// NF > 0: number of fields known at compile time (1, 2 and 6 are what the resident step uses; the loops over fields and
+// accumulators unroll and val[] stays in registers); NF = 0: generic.  FAST: regular grid, every field weighted and already
+// in the form that is summed (arithmetic, or geometric with the logarithm taken beforehand), no count accumulator -- the
+// resident step's case; the per-field scheme tests, the count path and the coordinate-search branch drop out.
+template <int NF, bool FAST>
 __global__ __launch_bounds__(256) void k_scatter_binned(PlScatterArgs a, int tiles_x) {
     extern __shared__ double lds[];
     const int W = PL_TILE_C + 2, H = PL_TILE_R + 2, WH = W * H;
-    const int nacc = a.nf + 2;                                  // [0]=wsum, [1]=cnt, [2+k]=field k
+    const int nf = NF > 0 ? NF : a.nf;
+    const int nacc = nf + 2;                                    // [0]=wsum, [1]=cnt, [2+k]=field k
     const int tid = threadIdx.x, lane = tid & 63;
     const int ti = blockIdx.x / tiles_x, tj = blockIdx.x % tiles_x;
     const int ci0 = ti * PL_TILE_R, cj0 = tj * PL_TILE_C;
@@ -136,13 +142,17 @@ __global__ __launch_bounds__(256) void k_scatter_binned(PlScatterArgs a, int til
             double z = 0.0, x = 0.0;
             if (valid) { z = a.tz[t]; x = a.tx[t]; }
             int ie, je; double ca, cb;
-            mic_scatter_locate(a, z, x, ie, je, ca, cb);
+            if (FAST) {
+                const double fz = floor((z - a.z0) * a.rhz), fx = floor((x - a.x0) * a.rhx);
+                ie = (int)fz; je = (int)fx;
+                ca = (z - (a.z0 + fz * a.hz)) * a.rhz; cb = (x - (a.x0 + fx * a.hx)) * a.rhx;
+            } else mic_scatter_locate(a, z, x, ie, je, ca, cb);
             if (!valid) ie = -0x40000000 - lane;                                  // invalid lanes never share a segment
             const double w[4] = {(1 - cb) * (1 - ca), (1 - cb) * ca, cb * (1 - ca), cb * ca};
-            double val[PL_MAX_SCATTER_FIELDS];
-            for (int k = 0; k < a.nf; k++) {
+            double val[NF > 0 ? NF : PL_MAX_SCATTER_FIELDS];
+            for (int k = 0; k < nf; k++) {
                 const double v = valid ? a.f[k][t] : 1.0;
-                val[k] = (a.scheme[k] & PL_AVG_GEOMETRIC) && !(a.scheme[k] & (PL_AVG_ARITHMETIC | PL_AVG_PRELOG)) ? log(v) : v;
+                val[k] = FAST ? v : (a.scheme[k] & PL_AVG_GEOMETRIC) && !(a.scheme[k] & (PL_AVG_ARITHMETIC | PL_AVG_PRELOG)) ? log(v) : v;
             }
             // runs of consecutive lanes in the same target cell (the tracers are cell-sorted) are summed in registers
             // first, so that one lane per run issues the LDS atomics: 16 markers per cell made every ds_add_f64 a
@@ -164,9 +174,12 @@ __global__ __launch_bounds__(256) void k_scatter_binned(PlScatterArgs a, int til
                 const int o = li * W + lj;
                 const long long go = (long long)(ni - a.row0) * a.ncols + (nj - a.col0);
                 for (int q = 0; q < nacc; q++) {
-                    if (q == 0 && !a.wsum) continue;                              // wave-uniform
-                    if (q == 1 && !a.cnt) continue;
-                    double v = (q == 0) ? w[cnr] : (q == 1) ? 1.0 : ((a.scheme[q - 2] & PL_AVG_WEIGHTED) ? val[q - 2] * w[cnr] : val[q - 2]);
+                    if (FAST) { if (q == 1) continue; }
+                    else {
+                        if (q == 0 && !a.wsum) continue;                          // wave-uniform
+                        if (q == 1 && !a.cnt) continue;
+                    }
+                    double v = (q == 0) ? w[cnr] : (q == 1) ? 1.0 : ((FAST || (a.scheme[q - 2] & PL_AVG_WEIGHTED)) ? val[q - 2] * w[cnr] : val[q - 2]);
                     if (!valid) v = 0.0;
                     v = run_sum(v, reach);
                     if (tail && ok) {
@@ -185,7 +198,7 @@ __global__ __launch_bounds__(256) void k_scatter_binned(PlScatterArgs a, int til
         const long long go = (long long)(ni - a.row0) * a.ncols + (nj - a.col0);
         if (a.wsum) { const double v = lds[o]; if (v != 0.0) mic_atomic_add(a.wsum + go, v); }
         if (a.cnt) { const double v = lds[WH + o]; if (v != 0.0) mic_atomic_add(a.cnt + go, v); }
-        for (int k = 0; k < a.nf; k++) { const double v = lds[(2 + k) * WH + o]; if (v != 0.0) mic_atomic_add(a.acc[k] + go, v); }
+        for (int k = 0; k < nf; k++) { const double v = lds[(2 + k) * WH + o]; if (v != 0.0) mic_atomic_add(a.acc[k] + go, v); }
     }
 }
 
@@ -242,7 +255,16 @@ int pl_scatter_device(pl_ctx* ctx, PlScatterArgs& a, double* const* out, long lo
     if (a.n > 0 && a.cell_start) {
         const int tiles_x = (a.ncx + PL_TILE_C - 1) / PL_TILE_C, tiles_z = (a.ncz + PL_TILE_R - 1) / PL_TILE_R;
         const size_t shm = (size_t)(a.nf + 2) * (PL_TILE_R + 2) * (PL_TILE_C + 2) * sizeof(double);
-        hipLaunchKernelGGL(k_scatter_binned, dim3((unsigned)(tiles_x * tiles_z)), dim3(256), shm, ctx->stream, a, tiles_x);
+        const dim3 gt((unsigned)(tiles_x * tiles_z));
+        bool fast = has_w && !has_c && !a.zc;
+        for (int k = 0; k < a.nf; k++)
+            fast = fast && (a.scheme[k] & PL_AVG_WEIGHTED) && ((a.scheme[k] & PL_AVG_ARITHMETIC) || (a.scheme[k] & PL_AVG_PRELOG));
+        if (fast && a.nf == 1) hipLaunchKernelGGL((k_scatter_binned<1, true>), gt, dim3(256), shm, ctx->stream, a, tiles_x);
+        else if (fast && a.nf == 2) hipLaunchKernelGGL((k_scatter_binned<2, true>), gt, dim3(256), shm, ctx->stream, a, tiles_x);
+        else if (fast && a.nf == 6) hipLaunchKernelGGL((k_scatter_binned<6, true>), gt, dim3(256), shm, ctx->stream, a, tiles_x);
+        else if (a.nf == 1) hipLaunchKernelGGL((k_scatter_binned<1, false>), gt, dim3(256), shm, ctx->stream, a, tiles_x);
+        else if (a.nf == 2) hipLaunchKernelGGL((k_scatter_binned<2, false>), gt, dim3(256), shm, ctx->stream, a, tiles_x);
+        else hipLaunchKernelGGL((k_scatter_binned<0, false>), gt, dim3(256), shm, ctx->stream, a, tiles_x);
         PL_HIP(ctx, hipGetLastError());
     } else if (a.n > 0) {
         hipLaunchKernelGGL(k_scatter_atomic, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, ctx->stream, a);
