@@ -308,9 +308,12 @@ __device__ inline void mic_window(const PlGatherGrid& g, CellLoc& c) {
 // Cell lookup + normalised in-cell coordinates exactly as pylamp_trac.py:42-52,63-75,89-90.
 // A cell index equal to n-1 passes the reference's range test but then indexes one past
 // its coordinate array (IndexError); here it is treated as outside.
+// FAST (compile time): regular grid with precomputed reciprocals (g.rect == 0, g.fast_uniform != 0) -- the resident step on a
+// uniform grid; the coordinate-search path and every FP64 division drop out of the kernel
+template <bool FAST = false>
 __device__ inline CellLoc mic_locate(const PlGatherGrid& g, double z, double x) {
     CellLoc c;
-    if (g.rect) {                                         // wave-uniform; at or beyond the last coordinate = outside
+    if (!FAST && g.rect) {                                         // wave-uniform; at or beyond the last coordinate = outside
         c.bad = !(z >= g.gz[0] && z < g.gz[g.nz - 1] && x >= g.gx[0] && x < g.gx[g.nx - 1]);
         c.ie = 0; c.je = 0; c.a = 0.0; c.b = 0.0;
         if (!c.bad) { mic_axis_locate(g.gz, g.nz, z, c.ie, c.a); mic_axis_locate(g.gx, g.nx, x, c.je, c.b); }
@@ -326,7 +329,7 @@ __device__ inline CellLoc mic_locate(const PlGatherGrid& g, double z, double x) 
     mic_window(g, c);
     const double dz0 = z - g.gz[c.ie], dz1 = g.gz[c.ie + 1] - z;
     const double dx0 = x - g.gx[c.je], dx1 = g.gx[c.je + 1] - x;
-    if (g.fast_uniform) {                 // resident step on a regular grid: dz0 + dz1 = h, no FP64 divisions (8 per RK4 tracer otherwise)
+    if (FAST || g.fast_uniform) {         // resident step on a regular grid: dz0 + dz1 = h, no FP64 divisions (8 per RK4 tracer otherwise)
         c.a = dz0 * g.sz; c.b = dx0 * g.sx;
     } else {
         c.a = dz0 / (dz0 + dz1);
@@ -342,13 +345,14 @@ __device__ inline double mic_bilinear(const double* __restrict__ F, const PlGath
 }
 
 // divergence-conserving velocity interpolation (pylamp_trac.py:98-154)
+template <bool FAST = false>
 __device__ inline void mic_veldiv(const PlGatherGrid& g, const double* __restrict__ Vz,
                                   const double* __restrict__ Vx, double z, double x, double defval, double& uz,
                                   double& ux, bool& bad, bool& oow) {
-    const CellLoc c = mic_locate(g, z, x);
+    const CellLoc c = mic_locate<FAST>(g, z, x);
     const long long o = g.off + (long long)c.ie * g.pitch + c.je;
     const double hz = g.gz[c.ie + 1] - g.gz[c.ie], hx = g.gx[c.je + 1] - g.gx[c.je];
-    const double rzx = g.fast_uniform ? g.hx_over_hz : hx / hz, rxz = g.fast_uniform ? g.hz_over_hx : hz / hx;
+    const double rzx = (FAST || g.fast_uniform) ? g.hx_over_hz : hx / hz, rxz = (FAST || g.fast_uniform) ? g.hz_over_hx : hz / hx;
     const double z00 = Vz[o], z01 = Vz[o + 1], z10 = Vz[o + g.pitch], z11 = Vz[o + g.pitch + 1];
     const double x00 = Vx[o], x01 = Vx[o + 1], x10 = Vx[o + g.pitch], x11 = Vx[o + g.pitch + 1];
     const double w00 = (1 - c.b) * (1 - c.a), w01 = c.b * (1 - c.a), w10 = (1 - c.b) * c.a, w11 = c.b * c.a;
@@ -363,11 +367,13 @@ __device__ inline void mic_veldiv(const PlGatherGrid& g, const double* __restric
     oow = oow || c.oow;
 }
 
+// FAST: regular grid with reciprocal spacings, bilinear method (the resident step's temperature interpolation)
+template <bool FAST>
 __global__ __launch_bounds__(256) void k_gather(PlGatherArgs a) {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= a.n) return;
     const double z = a.tz[t], x = a.tx[t];
-    if (a.method & PL_INTERP_NEAREST) {
+    if (!FAST && (a.method & PL_INTERP_NEAREST)) {
         const CellLoc c = mic_locate(a.g, z, x);
         const double dz0 = z - a.g.gz[c.ie], dz1 = a.g.gz[c.ie + 1] - z;
         const double dx0 = x - a.g.gx[c.je], dx1 = a.g.gx[c.je + 1] - x;
@@ -377,8 +383,8 @@ __global__ __launch_bounds__(256) void k_gather(PlGatherArgs a) {
         const long long o = a.g.off + (long long)(c.ie + (m >> 1)) * a.g.pitch + (c.je + (m & 1));
         for (int k = 0; k < a.nf; k++) a.out[k][t] = c.bad ? a.defval : a.fields[k][o];
         if (c.bad) atomicAdd(a.n_outside, 1ull);
-    } else if (a.method & PL_INTERP_LINEAR) {
-        const CellLoc c = mic_locate(a.g, z, x);
+    } else if (FAST || (a.method & PL_INTERP_LINEAR)) {
+        const CellLoc c = mic_locate<FAST>(a.g, z, x);
         for (int k = 0; k < a.nf; k++) {
             const double v = mic_bilinear(a.fields[k], a.g, c);
             a.out[k][t] = c.bad ? a.defval : (a.accumulate ? a.out[k][t] + v : v);
@@ -394,19 +400,20 @@ __global__ __launch_bounds__(256) void k_gather(PlGatherArgs a) {
 
 // RK4 with the reference's weights (1,1,1,1)/6 (pylamp_trac.py:385) and v = (x_new - x)/dt.
 // 48 B/tracer: read (z,x), write (z',x') and (vz,vx); the velocity grid is read through L2.
+template <bool FAST>
 __global__ __launch_bounds__(256) void k_rk4(PlRk4Args a) {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= a.n) return;
     const double z = a.tz[t], x = a.tx[t], dt = a.dt;
     double k1z, k1x, k2z, k2x, k3z, k3x, k4z, k4x; bool bad, oow = false;
-    mic_veldiv(a.g, a.Vz, a.Vx, z, x, 0.0, k1z, k1x, bad, oow);
-    mic_veldiv(a.g, a.Vz, a.Vx, z + 0.5 * dt * k1z, x + 0.5 * dt * k1x, 0.0, k2z, k2x, bad, oow);
-    mic_veldiv(a.g, a.Vz, a.Vx, z + 0.5 * dt * k2z, x + 0.5 * dt * k2x, 0.0, k3z, k3x, bad, oow);
-    mic_veldiv(a.g, a.Vz, a.Vx, z + dt * k3z, x + dt * k3x, 0.0, k4z, k4x, bad, oow);
+    mic_veldiv<FAST>(a.g, a.Vz, a.Vx, z, x, 0.0, k1z, k1x, bad, oow);
+    mic_veldiv<FAST>(a.g, a.Vz, a.Vx, z + 0.5 * dt * k1z, x + 0.5 * dt * k1x, 0.0, k2z, k2x, bad, oow);
+    mic_veldiv<FAST>(a.g, a.Vz, a.Vx, z + 0.5 * dt * k2z, x + 0.5 * dt * k2x, 0.0, k3z, k3x, bad, oow);
+    mic_veldiv<FAST>(a.g, a.Vz, a.Vx, z + dt * k3z, x + dt * k3x, 0.0, k4z, k4x, bad, oow);
     if (oow && a.n_outside_window) atomicAdd(a.n_outside_window, 1ull);
     const double zn = z + (1.0 / 6.0) * dt * (k1z + k2z + k3z + k4z);
     const double xn = x + (1.0 / 6.0) * dt * (k1x + k2x + k3x + k4x);
-    if (a.g.fast_uniform) { const double rdt = 1.0 / dt; a.vz_out[t] = (zn - z) * rdt; a.vx_out[t] = (xn - x) * rdt; }
+    if (FAST || a.g.fast_uniform) { const double rdt = 1.0 / dt; a.vz_out[t] = (zn - z) * rdt; a.vx_out[t] = (xn - x) * rdt; }
     else { a.vz_out[t] = (zn - z) / dt; a.vx_out[t] = (xn - x) / dt; }
     double zf = zn, xf = xn;
     if (a.fence) {                                     // pylamp2.py:563-570
@@ -420,14 +427,17 @@ void pl_launch_gather(pl_ctx* ctx, const PlGatherArgs& a_in) {
     if (a_in.n <= 0) return;
     PlGatherArgs a = a_in;
     a.g.sz = (a.g.nz - 1) / a.g.Lz; a.g.sx = (a.g.nx - 1) / a.g.Lx;
-    hipLaunchKernelGGL(k_gather, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    if (!a.g.rect && a.g.fast_uniform && (a.method & PL_INTERP_LINEAR) && !(a.method & PL_INTERP_NEAREST))
+        hipLaunchKernelGGL(k_gather<true>, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(k_gather<false>, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, ctx->stream, a);
 }
 
 void pl_launch_rk4(pl_ctx* ctx, const PlRk4Args& a_in) {
     if (a_in.n <= 0) return;
     PlRk4Args a = a_in;
     a.g.sz = (a.g.nz - 1) / a.g.Lz; a.g.sx = (a.g.nx - 1) / a.g.Lx;
-    hipLaunchKernelGGL(k_rk4, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    if (!a.g.rect && a.g.fast_uniform) hipLaunchKernelGGL(k_rk4<true>, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(k_rk4<false>, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, ctx->stream, a);
 }
 
 // ---------------------------------------------------------------------------------------
