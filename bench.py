@@ -245,6 +245,9 @@ def main():
                 torch.cuda.synchronize()
 
     device = int(os.environ["PYLAMP_DEVICE"]) if os.environ.get("PYLAMP_DEVICE") else local_rank
+    if world > 1 and not os.environ.get("PYLAMP_DEVICE") and os.environ.get("PYLAMP_DIST_BACKEND", "nccl") != "nccl":
+        import torch                                                # rehearsal: several gloo ranks may share the GPUs of the box
+        device = local_rank % max(torch.cuda.device_count(), 1)
     sim = build_sim(args.n, args.tracdens, 20260103, device, rank, world, args.scaling)
     ctx = sim.ctx
     reports = []
