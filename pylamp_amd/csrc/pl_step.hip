@@ -26,8 +26,9 @@ struct PlStepState {
     double* partial = nullptr;                       // reduction partials (device)
     std::vector<double> hpartial;
     double* gcoords = nullptr;                       // device copies of node / padded-centre coordinates
-    bool have_newtemp = false, have_solution = false, have_prev = false;
-    double dt_hist[2] = {0.0, 0.0};             // the last two time steps taken (newest first): weight of the extrapolated initial guess
+    bool have_newtemp = false, have_solution = false;
+    int n_prev = 0;                             // older solutions kept for the extrapolated initial guess (0..2)
+    double dt_hist[3] = {0.0, 0.0, 0.0};             // the last two time steps taken (newest first): weight of the extrapolated initial guess
     // cell sort
     double* f2[NFTRAC] = {nullptr};                  // permutation targets (swapped with f)
     int* cell = nullptr; int* dest = nullptr;        // per tracer: sort cell, destination slot
@@ -196,6 +197,15 @@ __global__ __launch_bounds__(256) void k_extrap_x0(long long n, double* __restri
     const double xo = x[t];
     x[t] = xo + w * (xo - xp[t]);
     xp[t] = xo;
+}
+// x <- l0 x + l1 xp + l2 xpp, xpp <- xp, xp <- the old x
+__global__ __launch_bounds__(256) void k_extrap_x0_quad(long long n, double* __restrict__ x, double* __restrict__ xp, double* __restrict__ xpp,
+                                                        double l0, double l1, double l2) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const double xo = x[t], x1 = xp[t];
+    x[t] = l0 * xo + l1 * x1 + l2 * xpp[t];
+    xpp[t] = x1; xp[t] = xo;
 }
 __global__ __launch_bounds__(256) void k_iota(long long n, int* __restrict__ v, int first = 0) {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -517,7 +527,7 @@ extern "C" int pl_tracers_upload(pl_ctx* ctx, int64_t n, const double* tr_x, con
     PL_HIP(ctx, hipGetLastError());
     if (n > 0) hipLaunchKernelGGL(k_iota, grid1d(n), dim3(256), 0, ctx->stream, (long long)n, S->orig, 0);
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    S->n = n; S->have_newtemp = false; S->have_solution = false; S->have_prev = false; S->dt_hist[0] = S->dt_hist[1] = 0.0;
+    S->n = n; S->have_newtemp = false; S->have_solution = false; S->n_prev = 0; S->dt_hist[0] = S->dt_hist[1] = S->dt_hist[2] = 0.0;
     double idmax[1] = {-1.0};
     for (int64_t t = 0; t < n; t++) if (tr_f[NFTRAC * t + TR__ID] > idmax[0]) idmax[0] = tr_f[NFTRAC * t + TR__ID];
     PL_TRY(pl_allreduce_host(ctx, idmax, 1, 2));
@@ -987,10 +997,27 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
             double* xs = pl_stokes_solution_device(ctx);
             double* xp; PL_TRY(pl_buf(ctx, "x_prev", (size_t)3 * g.plane * sizeof(double), &xp));
             const long long n3 = 3 * g.plane;
-            double w = 0.0;
-            if (S->have_prev && S->dt_hist[0] > 0.0 && S->dt_hist[1] > 0.0) w = std::min(2.0, wx * S->dt_hist[0] / S->dt_hist[1]);
-            hipLaunchKernelGGL(k_extrap_x0, grid1d(n3), dim3(256), 0, ctx->stream, n3, xs, xp, w);
-            S->have_prev = true;
+            static const int order = getenv("PYLAMP_X0_ORDER") ? atoi(getenv("PYLAMP_X0_ORDER")) : 1;
+            const double d0 = S->dt_hist[0], d1 = S->dt_hist[1], d2 = S->dt_hist[2];
+            if (order >= 2) {
+                double* xpp; PL_TRY(pl_buf(ctx, "x_prev2", (size_t)3 * g.plane * sizeof(double), &xpp));
+                double l0 = 1.0, l1 = 0.0, l2 = 0.0;
+                if (S->n_prev >= 2 && d0 > 0.0 && d1 > 0.0 && d2 > 0.0 && d0 <= 2.0 * d1) {
+                    const double T = wx * d0, t1 = -d1, t2 = -(d1 + d2);      // Lagrange weights through (0, t1, t2) at T
+                    l0 = (T - t1) * (T - t2) / (t1 * t2);
+                    l1 = T * (T - t2) / (t1 * (t1 - t2));
+                    l2 = T * (T - t1) / (t2 * (t2 - t1));
+                } else if (S->n_prev >= 1 && d0 > 0.0 && d1 > 0.0) {
+                    const double w = std::min(2.0, wx * d0 / d1);
+                    l0 = 1.0 + w; l1 = -w;
+                }
+                hipLaunchKernelGGL(k_extrap_x0_quad, grid1d(n3), dim3(256), 0, ctx->stream, n3, xs, xp, xpp, l0, l1, l2);
+            } else {
+                double w = 0.0;
+                if (S->n_prev >= 1 && d0 > 0.0 && d1 > 0.0) w = std::min(2.0, wx * d0 / d1);
+                hipLaunchKernelGGL(k_extrap_x0, grid1d(n3), dim3(256), 0, ctx->stream, n3, xs, xp, w);
+            }
+            S->n_prev = std::min(2, S->n_prev + 1);
         }
     }
     PL_TRY(pl_stokes_solve_device(ctx, b, S->have_solution, cfg->stokes_rtol > 0 ? cfg->stokes_rtol : 1e-10,
@@ -1033,7 +1060,7 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
     }
     rep->ms_stokes = now_ms() - t0;
     rep->tstep = tstep; rep->limiter = limiter; rep->tstep_heat = tstep_temp; rep->tstep_stokes = tstep_stokes;
-    S->dt_hist[1] = S->dt_hist[0]; S->dt_hist[0] = tstep;
+    S->dt_hist[2] = S->dt_hist[1]; S->dt_hist[1] = S->dt_hist[0]; S->dt_hist[0] = tstep;
     // the reference would carry a NaN time step on (NaN positions from the next advection); say what happened instead
     if (!std::isfinite(tstep))
         return pl_fail(ctx, "pl_step: the time step is not finite - a grid node without any marker in reach makes the interpolated "
