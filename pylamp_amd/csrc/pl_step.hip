@@ -27,8 +27,9 @@ struct PlStepState {
     std::vector<double> hpartial;
     double* gcoords = nullptr;                       // device copies of node / padded-centre coordinates
     bool have_newtemp = false, have_solution = false;
-    int n_prev = 0;                             // older solutions kept for the extrapolated initial guess (0..2)
-    double dt_hist[3] = {0.0, 0.0, 0.0};             // the last two time steps taken (newest first): weight of the extrapolated initial guess
+    int n_prev = 0;                             // older solutions kept for the extrapolated initial guess (0..3)
+    double* x_hist[3] = {nullptr, nullptr, nullptr};   // ... newest first (pl_buf storage, rotated by pointer)
+    double dt_hist[4] = {0.0, 0.0, 0.0, 0.0};             // the last two time steps taken (newest first): weight of the extrapolated initial guess
     // cell sort
     double* f2[NFTRAC] = {nullptr};                  // permutation targets (swapped with f)
     int* cell = nullptr; int* dest = nullptr;        // per tracer: sort cell, destination slot
@@ -190,22 +191,16 @@ __global__ __launch_bounds__(256) void k_cell_place(long long n, const int* __re
     base = __shfl(base, seg0, 64);
     if (c >= 0) dest[t] = start[c] + base + (lane - seg0);
 }
-// x <- x + w (x - xp), xp <- the old x
-__global__ __launch_bounds__(256) void k_extrap_x0(long long n, double* __restrict__ x, double* __restrict__ xp, double w) {
+// x <- l0 x + sum_k l[k] h[k] over nh older solutions; the old x replaces the oldest kept one, h[nk-1] (the host rotates the pointers)
+struct ExtrapArgs { double* h[3]; double l0, l[3]; int nh, nk; };
+__global__ __launch_bounds__(256) void k_extrap_x0(long long n, double* __restrict__ x, ExtrapArgs a) {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const double xo = x[t];
-    x[t] = xo + w * (xo - xp[t]);
-    xp[t] = xo;
-}
-// x <- l0 x + l1 xp + l2 xpp, xpp <- xp, xp <- the old x
-__global__ __launch_bounds__(256) void k_extrap_x0_quad(long long n, double* __restrict__ x, double* __restrict__ xp, double* __restrict__ xpp,
-                                                        double l0, double l1, double l2) {
-    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    const double xo = x[t], x1 = xp[t];
-    x[t] = l0 * xo + l1 * x1 + l2 * xpp[t];
-    xpp[t] = x1; xp[t] = xo;
+    double v = a.l0 * xo;
+    for (int k = 0; k < a.nh; k++) v += a.l[k] * a.h[k][t];
+    x[t] = v;
+    a.h[a.nk - 1][t] = xo;
 }
 __global__ __launch_bounds__(256) void k_iota(long long n, int* __restrict__ v, int first = 0) {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -527,7 +522,8 @@ extern "C" int pl_tracers_upload(pl_ctx* ctx, int64_t n, const double* tr_x, con
     PL_HIP(ctx, hipGetLastError());
     if (n > 0) hipLaunchKernelGGL(k_iota, grid1d(n), dim3(256), 0, ctx->stream, (long long)n, S->orig, 0);
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    S->n = n; S->have_newtemp = false; S->have_solution = false; S->n_prev = 0; S->dt_hist[0] = S->dt_hist[1] = S->dt_hist[2] = 0.0;
+    S->n = n; S->have_newtemp = false; S->have_solution = false; S->n_prev = 0; for (double& d : S->dt_hist) d = 0.0;
+    for (double*& h : S->x_hist) h = nullptr;
     double idmax[1] = {-1.0};
     for (int64_t t = 0; t < n; t++) if (tr_f[NFTRAC * t + TR__ID] > idmax[0]) idmax[0] = tr_f[NFTRAC * t + TR__ID];
     PL_TRY(pl_allreduce_host(ctx, idmax, 1, 2));
@@ -988,36 +984,51 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
     if (!b) return 1;
     pl_launch_stokes_rhs(ctx, ctx->sop, b);
     pl_stokes_deflation(ctx, true);
-    {   // Initial guess extrapolated in time: x_n + (dt_n / dt_{n-1}) (x_n - x_{n-1}) instead of x_n.  With the plateau of the
-        // pressure-anchor mode gone (pl_solver.hip) every factor 3 in the initial residual is an iteration: 15.3 -> 13.8 iterations,
-        // 38.6 -> 34.7 ms per solve at 2049^2 (PYLAMP_X0_EXTRAP scales the weight; 0 switches it off).  In round 1 the same
-        // extrapolation changed nothing -- the plateau ate whatever the start gained.
+    {   // Initial guess extrapolated in model time from the last solutions (Lagrange polynomial through up to PYLAMP_X0_ORDER + 1
+        // of them, default 2 = quadratic; PYLAMP_X0_EXTRAP scales the target time, 0 switches the extrapolation off).  With the
+        // plateau of the pressure-anchor mode gone (pl_solver.hip) every factor 3 in the initial residual is an iteration; at 2049^2:
+        // none 15.3 iterations / 38.6 ms per solve, linear 13.3 / 33.5 ms, quadratic 11.5 / 29.9 ms.  In round 1 the same
+        // extrapolation changed nothing -- the plateau ate whatever the start gained.  Only the iteration count depends on it: the
+        // stopping rule is the same whatever the start.
         static const double wx = getenv("PYLAMP_X0_EXTRAP") ? atof(getenv("PYLAMP_X0_EXTRAP")) : 1.0;
         if (wx != 0.0 && S->have_solution) {
             double* xs = pl_stokes_solution_device(ctx);
-            double* xp; PL_TRY(pl_buf(ctx, "x_prev", (size_t)3 * g.plane * sizeof(double), &xp));
             const long long n3 = 3 * g.plane;
-            static const int order = getenv("PYLAMP_X0_ORDER") ? atoi(getenv("PYLAMP_X0_ORDER")) : 1;
-            const double d0 = S->dt_hist[0], d1 = S->dt_hist[1], d2 = S->dt_hist[2];
-            if (order >= 2) {
-                double* xpp; PL_TRY(pl_buf(ctx, "x_prev2", (size_t)3 * g.plane * sizeof(double), &xpp));
-                double l0 = 1.0, l1 = 0.0, l2 = 0.0;
-                if (S->n_prev >= 2 && d0 > 0.0 && d1 > 0.0 && d2 > 0.0 && d0 <= 2.0 * d1) {
-                    const double T = wx * d0, t1 = -d1, t2 = -(d1 + d2);      // Lagrange weights through (0, t1, t2) at T
-                    l0 = (T - t1) * (T - t2) / (t1 * t2);
-                    l1 = T * (T - t2) / (t1 * (t1 - t2));
-                    l2 = T * (T - t1) / (t2 * (t2 - t1));
-                } else if (S->n_prev >= 1 && d0 > 0.0 && d1 > 0.0) {
-                    const double w = std::min(2.0, wx * d0 / d1);
-                    l0 = 1.0 + w; l1 = -w;
-                }
-                hipLaunchKernelGGL(k_extrap_x0_quad, grid1d(n3), dim3(256), 0, ctx->stream, n3, xs, xp, xpp, l0, l1, l2);
-            } else {
-                double w = 0.0;
-                if (S->n_prev >= 1 && d0 > 0.0 && d1 > 0.0) w = std::min(2.0, wx * d0 / d1);
-                hipLaunchKernelGGL(k_extrap_x0, grid1d(n3), dim3(256), 0, ctx->stream, n3, xs, xp, w);
+            static const int order = std::max(1, std::min(3, getenv("PYLAMP_X0_ORDER") ? atoi(getenv("PYLAMP_X0_ORDER")) : 2));
+            if (!S->x_hist[0]) {
+                const char* nm[3] = {"x_prev", "x_prev2", "x_prev3"};
+                for (int k = 0; k < order; k++) PL_TRY(pl_buf(ctx, nm[k], (size_t)n3 * sizeof(double), &S->x_hist[k]));
             }
-            S->n_prev = std::min(2, S->n_prev + 1);
+            // Lagrange weights of the solutions at model times 0, -dt1, -dt1-dt2, ... evaluated at +dt0.  A time step that more
+            // than doubled (or a missing history) falls back to the linear formula with its weight capped at 2.
+            const double* d = S->dt_hist;
+            int np = std::min(order, S->n_prev);               // older solutions used
+            for (int k = 0; k <= np && k < 4; k++) if (!(d[k] > 0.0)) np = std::min(np, std::max(0, k - 1));
+            if (np >= 2 && d[0] > 2.0 * d[1]) np = 1;
+            ExtrapArgs ea{};
+            ea.nk = order; ea.nh = np; ea.l0 = 1.0;
+            for (int k = 0; k < order; k++) ea.h[k] = S->x_hist[k];
+            if (np == 1) {
+                const double w = std::min(2.0, wx * d[0] / d[1]);
+                ea.l0 = 1.0 + w; ea.l[0] = -w;
+            } else if (np >= 2) {
+                double tau[4] = {0.0, 0.0, 0.0, 0.0}, L[4];
+                for (int k = 1; k <= np; k++) tau[k] = tau[k - 1] - d[k];
+                const double T = wx * d[0];
+                for (int i = 0; i <= np; i++) {
+                    L[i] = 1.0;
+                    for (int j = 0; j <= np; j++) if (j != i) L[i] *= (T - tau[j]) / (tau[i] - tau[j]);
+                }
+                ea.l0 = L[0];
+                for (int k = 0; k < np; k++) ea.l[k] = L[k + 1];
+            }
+            hipLaunchKernelGGL(k_extrap_x0, grid1d(n3), dim3(256), 0, ctx->stream, n3, xs, ea);
+            {   // the slot that took the old x becomes the newest
+                double* newest = S->x_hist[order - 1];
+                for (int k = order - 1; k > 0; k--) S->x_hist[k] = S->x_hist[k - 1];
+                S->x_hist[0] = newest;
+            }
+            S->n_prev = std::min(order, S->n_prev + 1);
         }
     }
     PL_TRY(pl_stokes_solve_device(ctx, b, S->have_solution, cfg->stokes_rtol > 0 ? cfg->stokes_rtol : 1e-10,
@@ -1060,7 +1071,8 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
     }
     rep->ms_stokes = now_ms() - t0;
     rep->tstep = tstep; rep->limiter = limiter; rep->tstep_heat = tstep_temp; rep->tstep_stokes = tstep_stokes;
-    S->dt_hist[2] = S->dt_hist[1]; S->dt_hist[1] = S->dt_hist[0]; S->dt_hist[0] = tstep;
+    for (int k = 3; k > 0; k--) S->dt_hist[k] = S->dt_hist[k - 1];
+    S->dt_hist[0] = tstep;
     // the reference would carry a NaN time step on (NaN positions from the next advection); say what happened instead
     if (!std::isfinite(tstep))
         return pl_fail(ctx, "pl_step: the time step is not finite - a grid node without any marker in reach makes the interpolated "
