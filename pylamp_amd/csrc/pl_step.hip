@@ -16,6 +16,7 @@ enum { TR_RHO = 0, TR_ETA, TR_MRK, TR_TMP, TR_HCD, TR_HCP, TR_RH0, TR_ALP, TR_MA
 #define GASR 8.31446
 #define PL_EPS (1.0 / 1024.0)      // pylamp_const.py:46
 
+constexpr int X0_HIST = 5;                     // older Stokes solutions kept at most for the extrapolated initial guess
 struct PlStepState {
     long long n = 0, cap = 0;
     double* tz = nullptr; double* tx = nullptr;      // positions (SoA)
@@ -27,9 +28,9 @@ struct PlStepState {
     std::vector<double> hpartial;
     double* gcoords = nullptr;                       // device copies of node / padded-centre coordinates
     bool have_newtemp = false, have_solution = false;
-    int n_prev = 0;                             // older solutions kept for the extrapolated initial guess (0..3)
-    double* x_hist[3] = {nullptr, nullptr, nullptr};   // ... newest first (pl_buf storage, rotated by pointer)
-    double dt_hist[4] = {0.0, 0.0, 0.0, 0.0};             // the last two time steps taken (newest first): weight of the extrapolated initial guess
+    int n_prev = 0;                             // older solutions kept for the extrapolated initial guess (0..X0_HIST)
+    double* x_hist[X0_HIST] = {};               // ... newest first (pl_buf storage, rotated by pointer)
+    double dt_hist[X0_HIST + 1] = {};           // the last time steps taken (newest first): the model times of those solutions
     // cell sort
     double* f2[NFTRAC] = {nullptr};                  // permutation targets (swapped with f)
     int* cell = nullptr; int* dest = nullptr;        // per tracer: sort cell, destination slot
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void k_cell_place(long long n, const int* __re
     if (c >= 0) dest[t] = start[c] + base + (lane - seg0);
 }
 // x <- l0 x + sum_k l[k] h[k] over nh older solutions; the old x replaces the oldest kept one, h[nk-1] (the host rotates the pointers)
-struct ExtrapArgs { double* h[3]; double l0, l[3]; int nh, nk; };
+struct ExtrapArgs { double* h[X0_HIST]; double l0, l[X0_HIST]; int nh, nk; };
 __global__ __launch_bounds__(256) void k_extrap_x0(long long n, double* __restrict__ x, ExtrapArgs a) {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
@@ -995,40 +996,61 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
             double* xs = pl_stokes_solution_device(ctx);
             const long long n3 = 3 * g.plane;
             static const int order = std::max(1, std::min(3, getenv("PYLAMP_X0_ORDER") ? atoi(getenv("PYLAMP_X0_ORDER")) : 2));
+            static const int keep = std::max(order, std::min((int)X0_HIST, getenv("PYLAMP_X0_POINTS") ? atoi(getenv("PYLAMP_X0_POINTS")) : order));
             if (!S->x_hist[0]) {
-                const char* nm[3] = {"x_prev", "x_prev2", "x_prev3"};
-                for (int k = 0; k < order; k++) PL_TRY(pl_buf(ctx, nm[k], (size_t)n3 * sizeof(double), &S->x_hist[k]));
+                const char* nm[X0_HIST] = {"x_prev", "x_prev2", "x_prev3", "x_prev4", "x_prev5"};
+                for (int k = 0; k < keep; k++) PL_TRY(pl_buf(ctx, nm[k], (size_t)n3 * sizeof(double), &S->x_hist[k]));
             }
-            // Lagrange weights of the solutions at model times 0, -dt1, -dt1-dt2, ... evaluated at +dt0.  A time step that more
+            // Weights of the polynomial of degree `order` fitted (least squares when more than order + 1 solutions are kept, else
+            // interpolating) to the solutions at model times 0, -dt1, -dt1-dt2, ... and evaluated at +dt0.  A time step that more
             // than doubled (or a missing history) falls back to the linear formula with its weight capped at 2.
             const double* d = S->dt_hist;
-            int np = std::min(order, S->n_prev);               // older solutions used
-            for (int k = 0; k <= np && k < 4; k++) if (!(d[k] > 0.0)) np = std::min(np, std::max(0, k - 1));
+            int np = std::min(keep, S->n_prev);                // older solutions used
+            for (int k = 0; k <= np; k++) if (!(d[k] > 0.0)) np = std::min(np, std::max(0, k - 1));
             if (np >= 2 && d[0] > 2.0 * d[1]) np = 1;
             ExtrapArgs ea{};
-            ea.nk = order; ea.nh = np; ea.l0 = 1.0;
-            for (int k = 0; k < order; k++) ea.h[k] = S->x_hist[k];
+            ea.nk = keep; ea.nh = np; ea.l0 = 1.0;
+            for (int k = 0; k < keep; k++) ea.h[k] = S->x_hist[k];
             if (np == 1) {
                 const double w = std::min(2.0, wx * d[0] / d[1]);
                 ea.l0 = 1.0 + w; ea.l[0] = -w;
             } else if (np >= 2) {
-                double tau[4] = {0.0, 0.0, 0.0, 0.0}, L[4];
-                for (int k = 1; k <= np; k++) tau[k] = tau[k - 1] - d[k];
-                const double T = wx * d[0];
-                for (int i = 0; i <= np; i++) {
-                    L[i] = 1.0;
-                    for (int j = 0; j <= np; j++) if (j != i) L[i] *= (T - tau[j]) / (tau[i] - tau[j]);
+                const int deg = std::min(order, np), m = np + 1;
+                double tau[X0_HIST + 1] = {}, G[4][5] = {};              // times in units of dt0; normal equations (V^T V) c = t
+                for (int k = 1; k <= np; k++) tau[k] = tau[k - 1] - d[k] / d[0];
+                const double T = wx;
+                for (int a2 = 0; a2 <= deg; a2++) {
+                    for (int b2 = 0; b2 <= deg; b2++) for (int i = 0; i < m; i++) G[a2][b2] += std::pow(tau[i], a2 + b2);
+                    G[a2][deg + 1] = std::pow(T, a2);
                 }
-                ea.l0 = L[0];
-                for (int k = 0; k < np; k++) ea.l[k] = L[k + 1];
+                bool ok = true;
+                for (int c = 0; c <= deg && ok; c++) {                    // Gauss-Jordan with partial pivoting on the (deg+1) system
+                    int pv = c;
+                    for (int r = c + 1; r <= deg; r++) if (std::fabs(G[r][c]) > std::fabs(G[pv][c])) pv = r;
+                    if (!(std::fabs(G[pv][c]) > 1e-300)) { ok = false; break; }
+                    for (int k = 0; k <= deg + 1; k++) std::swap(G[c][k], G[pv][k]);
+                    for (int r = 0; r <= deg; r++) if (r != c) {
+                        const double f = G[r][c] / G[c][c];
+                        for (int k = c; k <= deg + 1; k++) G[r][k] -= f * G[c][k];
+                    }
+                }
+                if (ok) {
+                    double L[X0_HIST + 1];
+                    for (int i = 0; i < m; i++) {
+                        L[i] = 0.0;
+                        for (int a2 = 0; a2 <= deg; a2++) L[i] += std::pow(tau[i], a2) * G[a2][deg + 1] / G[a2][a2];
+                    }
+                    ea.l0 = L[0];
+                    for (int k = 0; k < np; k++) ea.l[k] = L[k + 1];
+                } else ea.nh = 0;
             }
             hipLaunchKernelGGL(k_extrap_x0, grid1d(n3), dim3(256), 0, ctx->stream, n3, xs, ea);
             {   // the slot that took the old x becomes the newest
-                double* newest = S->x_hist[order - 1];
-                for (int k = order - 1; k > 0; k--) S->x_hist[k] = S->x_hist[k - 1];
+                double* newest = S->x_hist[keep - 1];
+                for (int k = keep - 1; k > 0; k--) S->x_hist[k] = S->x_hist[k - 1];
                 S->x_hist[0] = newest;
             }
-            S->n_prev = std::min(order, S->n_prev + 1);
+            S->n_prev = std::min(keep, S->n_prev + 1);
         }
     }
     PL_TRY(pl_stokes_solve_device(ctx, b, S->have_solution, cfg->stokes_rtol > 0 ? cfg->stokes_rtol : 1e-10,
@@ -1071,7 +1093,7 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
     }
     rep->ms_stokes = now_ms() - t0;
     rep->tstep = tstep; rep->limiter = limiter; rep->tstep_heat = tstep_temp; rep->tstep_stokes = tstep_stokes;
-    for (int k = 3; k > 0; k--) S->dt_hist[k] = S->dt_hist[k - 1];
+    for (int k = X0_HIST; k > 0; k--) S->dt_hist[k] = S->dt_hist[k - 1];
     S->dt_hist[0] = tstep;
     // the reference would carry a NaN time step on (NaN positions from the next advection); say what happened instead
     if (!std::isfinite(tstep))
