@@ -223,7 +223,7 @@ int  pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, doubl
 double* pl_stokes_solution_device(pl_ctx* ctx);
 double* pl_stokes_rhs_buffer_device(pl_ctx* ctx);
 int  pl_heat_solve_device(pl_ctx* ctx, const double* b_dev, double rtol, int maxit, pl_solve_stats* st,
-                          double** x_out);
+                          double** x_out, const double* x0_dev = nullptr);
 
 // direct fallback for small systems (pl_direct.hip)
 bool pl_direct_possible(pl_ctx* ctx);

@@ -2653,7 +2653,7 @@ __global__ __launch_bounds__(256) void k_heat_dinv(PlHeatOp op, double* __restri
 }
 
 int pl_heat_solve_device(pl_ctx* ctx, const double* b_dev, double rtol, int maxit, pl_solve_stats* st,
-                         double** x_out) {
+                         double** x_out, const double* x0_dev) {
     PlSolver* S = solver_of(ctx);
     const PlGeom& g = ctx->geom.d;
     size_t pb = (size_t)g.plane * sizeof(double);
@@ -2675,7 +2675,8 @@ int pl_heat_solve_device(pl_ctx* ctx, const double* b_dev, double rtol, int maxi
     PL_HIP(ctx, hipMemcpyAsync(b, b_dev, pb, hipMemcpyDeviceToDevice, ctx->stream));
     hipLaunchKernelGGL(k_heat_dinv, grid2d(g), dim3(64, 4), 0, ctx->stream, hop, b);
     BicgVecs w{S->h[0], S->h[1], S->h[2], S->h[3], S->h[4], S->h[5], nullptr, nullptr, S->h[6], S->h[9], S->h[10]};
-    PL_TRY(bicgstab(ctx, S, g, 1, A, nullptr, b, S->h[7], false, rtol, maxit, w, st));
+    if (x0_dev) PL_HIP(ctx, hipMemcpyAsync(S->h[7], x0_dev, pb, hipMemcpyDeviceToDevice, ctx->stream));     // start from the caller's guess
+    PL_TRY(bicgstab(ctx, S, g, 1, A, nullptr, b, S->h[7], x0_dev != nullptr, rtol, maxit, w, st));
     double ms = 0;
     PL_TRY(pl_timer_stop_ms(ctx, &ms));
     st->solve_ms = ms; st->operator_applies = S->napply; st->precond_applies = 0;

@@ -27,7 +27,7 @@ struct PlStepState {
     double* partial = nullptr;                       // reduction partials (device)
     std::vector<double> hpartial;
     double* gcoords = nullptr;                       // device copies of node / padded-centre coordinates
-    bool have_newtemp = false, have_solution = false;
+    bool have_newtemp = false, have_solution = false, have_dT = false;
     int n_prev = 0;                             // older solutions kept for the extrapolated initial guess (0..X0_HIST)
     double* x_hist[X0_HIST] = {};               // ... newest first (pl_buf storage, rotated by pointer)
     double dt_hist[X0_HIST + 1] = {};           // the last time steps taken (newest first): the model times of those solutions
@@ -191,6 +191,12 @@ __global__ __launch_bounds__(256) void k_cell_place(long long n, const int* __re
     if (lane == seg0 && c >= 0) base = atomicAdd(&fill[c], len);
     base = __shfl(base, seg0, 64);
     if (c >= 0) dest[t] = start[c] + base + (lane - seg0);
+}
+// out = a + w b over a whole ring plane
+__global__ __launch_bounds__(256) void k_plane_axpy(long long n, double* __restrict__ out, const double* __restrict__ a,
+                                                    const double* __restrict__ b, double w) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = a[t] + w * b[t];
 }
 // x <- l0 x + sum_k l[k] h[k] over nh older solutions; the old x replaces the oldest kept one, h[nk-1] (the host rotates the pointers)
 struct ExtrapArgs { double* h[X0_HIST]; double l0, l[X0_HIST]; int nh, nk; };
@@ -523,7 +529,7 @@ extern "C" int pl_tracers_upload(pl_ctx* ctx, int64_t n, const double* tr_x, con
     PL_HIP(ctx, hipGetLastError());
     if (n > 0) hipLaunchKernelGGL(k_iota, grid1d(n), dim3(256), 0, ctx->stream, (long long)n, S->orig, 0);
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    S->n = n; S->have_newtemp = false; S->have_solution = false; S->n_prev = 0; for (double& d : S->dt_hist) d = 0.0;
+    S->n = n; S->have_newtemp = false; S->have_solution = false; S->have_dT = false; S->n_prev = 0; for (double& d : S->dt_hist) d = 0.0;
     for (double*& h : S->x_hist) h = nullptr;
     double idmax[1] = {-1.0};
     for (int64_t t = 0; t < n; t++) if (tr_f[NFTRAC * t + TR__ID] > idmax[0]) idmax[0] = tr_f[NFTRAC * t + TR__ID];
@@ -1113,8 +1119,22 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
         PL_TRY(pl_buf(ctx, "api_hx", pb, &hb));
         pl_launch_heat_rhs(ctx, hop, p_T, p_H, hb);
         double* xs = nullptr;
+        // Initial guess: the nodal temperature the right-hand side was built from, plus (from the third step on) the last step's
+        // implicit increment scaled to this step's length -- instead of zero (PYLAMP_HEAT_X0 = 0: zero, 1: the old temperature only).
+        static const int hx0 = getenv("PYLAMP_HEAT_X0") ? atoi(getenv("PYLAMP_HEAT_X0")) : 2;
+        const double* guess = nullptr;
+        if (hx0 >= 1) {
+            guess = p_T;
+            if (hx0 >= 2 && S->have_dT && S->dt_hist[1] > 0.0 && tstep <= 2.0 * S->dt_hist[1]) {
+                double* hg;
+                PL_TRY(pl_buf(ctx, "heat_x0", pb, &hg));
+                const long long np1 = g.plane;
+                hipLaunchKernelGGL(k_plane_axpy, grid1d(np1), dim3(256), 0, ctx->stream, np1, hg, p_T, p_dT, tstep / S->dt_hist[1]);
+                guess = hg;
+            }
+        }
         PL_TRY(pl_heat_solve_device(ctx, hb, cfg->heat_rtol > 0 ? cfg->heat_rtol : 1e-12,
-                                    cfg->heat_maxit > 0 ? cfg->heat_maxit : 2000, &rep->heat, &xs));
+                                    cfg->heat_maxit > 0 ? cfg->heat_maxit : 2000, &rep->heat, &xs, guess));
         PL_HIP(ctx, hipMemcpyAsync(p_newT, xs, pb, hipMemcpyDeviceToDevice, ctx->stream));
         PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
         PL_TRY(pl_halo(ctx, g, p_newT, 1, g.plane));
@@ -1139,6 +1159,7 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
         } else {
             hipLaunchKernelGGL(k_plane_sub, grid2d(g), dim3(64, 4), 0, ctx->stream, g, p_newT, p_T, p_dT);
             PL_TRY(pl_halo(ctx, g, p_dT, 1, g.plane));
+            S->have_dT = true;
             ga.fields[0] = p_dT; ga.out[0] = S->tmp[0];
             pl_launch_gather(ctx, ga);
             const double inv2 = (2.0 / dx) * (2.0 / dx) + (2.0 / dz) * (2.0 / dz);
