@@ -386,3 +386,44 @@ print("RESULT", json.dumps(dict(its=its, est=rep["stokes"]["error_estimate"])))
         assert relerr(fd[q], fp[q]) < 1e-6, q                  # both within the solver's error bound of the same solution
     assert sum(sd["its"]) < 0.85 * sum(sp["its"]), (sd, sp)
     assert sd["est"] <= 3e-8 and sp["est"] <= 3e-8
+
+
+def test_warm_starts_same_fields_fewer_iterations():
+    """The initial guesses of the time-step loop -- Stokes: quadratic extrapolation in model time of the last three solutions with
+    the initial residual as BiCGStab's shadow vector; heat: old nodal temperature + scaled last increment --
+    change the iteration counts, not the answer: two resident runs of the mantle model at 257 x 257, with and without them
+    (the knobs are read once per process, hence the subprocesses)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, json
+sys.path.insert(0, %r)
+import numpy as np
+from pylamp_amd import driver
+n = 257; nx = [n, n]; L = [660e3, 660e3]
+tr_x, tr_f = driver.mantle_tracers(nx, L, 12, np.random.default_rng(11))
+sim = driver.Simulation(nx, L, tr_x, tr_f, driver.Options())
+its, hits = [], []
+for k in range(7):
+    rep = sim.step(); its.append(rep["stokes"]["iterations"]); hits.append(rep["heat"]["iterations"])
+    assert rep["stokes"]["converged"] == 1 and rep["heat"]["converged"] == 1, rep
+np.save(sys.argv[1], np.stack([sim.field("velz"), sim.field("velx"), sim.field("temp")]))
+print("RESULT", json.dumps(dict(its=its, hits=hits, est=rep["stokes"]["error_estimate"], time=sim.totaltime)))
+''' % root
+    out = {}
+    off = {"PYLAMP_X0_EXTRAP": "0", "PYLAMP_HEAT_X0": "0", "PYLAMP_SHADOW": "0"}
+    for name, env in (("warm", {}), ("plain", off)):
+        path = os.path.join(root, "gpurun_out", "warm_%s.npy" % name)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0, (name, r.stderr[-1500:])
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0]
+        out[name] = (json.loads(line[7:]), np.load(path))
+        os.remove(path)
+    (sw, fw), (sp, fp) = out["warm"], out["plain"]
+    for q in range(3):
+        assert relerr(fw[q], fp[q]) < 1e-6, q                  # both within the solvers' error bounds of the same trajectory
+    assert abs(sw["time"] - sp["time"]) <= 1e-6 * sp["time"]
+    assert sum(sw["its"][3:]) < sum(sp["its"][3:]), (sw, sp)   # from the fourth step on the history is complete
+    assert sum(sw["hits"][2:]) < sum(sp["hits"][2:]), (sw, sp)
+    assert sw["est"] <= 3e-8 and sp["est"] <= 3e-8
