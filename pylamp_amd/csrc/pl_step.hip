@@ -1104,7 +1104,8 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
     // the reference would carry a NaN time step on (NaN positions from the next advection); say what happened instead
     if (!std::isfinite(tstep))
         return pl_fail(ctx, "pl_step: the time step is not finite - a grid node without any marker in reach makes the interpolated "
-                            "fields NaN (raise the marker density or enable injection)");
+                            "fields NaN, and so do tracers injected into a cell without residents (their fields are 0/0 as in "
+                            "pylamp2.py:624-629): raise the marker density or enable injection before cells run empty");
 
     // ---- 5. heat (pylamp2.py:412-480) ----------------------------------------------------------------
     if (cfg->do_heatdiff) {
