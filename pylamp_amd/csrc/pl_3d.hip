@@ -19,7 +19,11 @@
 #include <functional>
 
 #define P3_PAD 16                    // left padding of a y-line: node k = 0 is 128-B aligned
-#define TB(tab, k) (tab)[(k) + PL_TOFF]
+// Coefficient tables are read through the constant address space: with a wave-uniform index (the z and x axes: blockIdx.z and the
+// readfirstlane'd row of the workgroup, K3_PROLOGUE) the load is a scalar one (s_load, scalar cache) instead of 64 identical lanes
+// of a vector load.  The tables are written by the host before any kernel that reads them.
+typedef const double __attribute__((address_space(4))) * pl_ctab;
+#define TB(tab, k) (((pl_ctab)(tab))[(k) + PL_TOFF])
 
 struct G3 {
     int n[3];                        // nz, nx, ny
@@ -106,7 +110,7 @@ template <int D> __device__ inline double diag3(const Op3& op, long long c, cons
 }
 
 #define K3_PROLOGUE(g)                                                                          \
-    const int k = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, i = blockIdx.z; \
+    const int k = blockIdx.x * 64 + threadIdx.x, j = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y), i = blockIdx.z; \
     if (k >= (g).n[2] || j >= (g).n[1]) return;                                                 \
     const long long c = i3((g), i, j, k);                                                       \
     const int idx[3] = {i, j, k};                                                               \
