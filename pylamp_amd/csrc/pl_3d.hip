@@ -160,7 +160,7 @@ template <int D> __device__ inline double apply_vel3(const Op3& op, const double
     double Av, dg;
     row3<D>(op, v, c, idx, Av, dg);
     Av -= 2.0 * op.Kc * TB(op.g.rD[D], idx[D]) * (P[c] - P[c - op.g.s[D]]);
-    return scaled ? Av / dg : Av;
+    return scaled ? Av * pl_rcp(dg) : Av;
 }
 
 template <bool SCALED> __global__ __launch_bounds__(256) void k3_apply(Op3 op, V4 x, W4 y) {
@@ -179,7 +179,7 @@ template <bool SCALED> __global__ __launch_bounds__(256) void k3_apply(Op3 op, V
         const G3& g = op.g;
         const double rz = TB(g.rd[0], i), rx = TB(g.rd[1], j), ry = TB(g.rd[2], k);
         const double div = (v[0][c + g.s[0]] - v[0][c]) * rz + (v[1][c + g.s[1]] - v[1][c]) * rx + (v[2][c + g.s[2]] - v[2][c]) * ry;
-        yp = SCALED ? div / (rz + rx + ry) : op.Kc * div;
+        yp = SCALED ? div * pl_rcp(rz + rx + ry) : op.Kc * div;
     }
     y.p[3][c] = yp;
 }
@@ -269,12 +269,12 @@ template <int D> __device__ inline double cheb3(const Op3& op, const double* con
         if (idx[E] == 0) im[E] = 1; else if (idx[E] == op.g.n[E] - 2) im[E] = op.g.n[E] - 3;
         if (idx[F] == 0) im[F] = 1; else if (idx[F] == op.g.n[F] - 2) im[F] = op.g.n[F] - 3;
     }
-    if (zero) return (-c2 * f[cm]) / diag3<D>(op, cm, im);
+    if (zero) return (-c2 * f[cm]) * pl_rcp(diag3<D>(op, cm, im));
     double Av, dg;
     row3<D>(op, v, cm, im, Av, dg);
     const double v0 = v[D][cm];
     const double mom = (c1 != 0.0) ? c1 * (v0 - (vprev ? vprev[cm] : 0.0)) : 0.0;
-    return v0 + mom + (c2 * (Av - f[cm])) / dg;                                  // D = -dg
+    return v0 + mom + (c2 * (Av - f[cm])) * pl_rcp(dg);                                  // D = -dg
 }
 __global__ __launch_bounds__(256) void k3_cheb(Op3 op, V3 vcur, V3 vprev, V3 f, W3 vnext, double c1, double c2, int zero) {
     K3_PROLOGUE(op.g)
@@ -298,7 +298,7 @@ template <int D> __device__ inline double resid3(const Op3& op, const double* co
     }
     double Av, dg;
     row3<D>(op, v, cm, im, Av, dg);
-    return mode == 0 ? f[c] - Av : Av / dg;
+    return mode == 0 ? f[c] - Av : Av * pl_rcp(dg);
 }
 __global__ __launch_bounds__(256) void k3_resid(Op3 op, V3 vv, V3 f, W3 r, int mode) {
     K3_PROLOGUE(op.g)
@@ -538,7 +538,7 @@ struct pl3_ctx {
     // heat
     Heat3 hop{}; bool hop_ready = false; double* hk[3] = {nullptr}; double *hT = nullptr, *hH = nullptr, *hcdt = nullptr, *hrho = nullptr, *hcp = nullptr;
     double* hbcv = nullptr; double* htab = nullptr; double* hvec[12] = {nullptr}; double hbcv_host[6] = {0};
-    int nu = 2, coarse_sweeps = 12; double cheb_ratio = 6.0;
+    int nu = 2, nu_fine = 0; bool nu_set = false; int coarse_sweeps = 12; double cheb_ratio = 6.0;      // nu_fine: sweeps on the finest level (0 = nu)
     // deflation of the pressure-anchor mode (see pl_solver.hip): the vector w = A^-1 u lives in vec[13], kept between solves
     double *dfl_y = nullptr, *dfl_t = nullptr; bool dfl_valid = false;
     bool dfl_active = false; double dfl_yAw = 0.0, dfl_wvel2 = 0.0;      // of the running solve: the anchor-mode term of the error estimate
@@ -592,7 +592,8 @@ extern "C" int pl3_create(pl3_ctx** out, int device, int nz, int nx, int ny, con
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { delete ctx; return p3_fail(nullptr, "pl3_create: stream creation failed"); }
     const int n[3] = {nz, nx, ny}; const double* c[3] = {zc, xc, yc};
     if (g3_build(ctx, ctx->geom, n, c)) { std::string m = ctx->err; delete ctx; return p3_fail(nullptr, m); }
-    if (const char* e = getenv("PYLAMP_MG_NU3")) { int a = atoi(e); if (a >= 1 && a <= 6) ctx->nu = a; }
+    if (const char* e = getenv("PYLAMP_MG_NU3")) { int a = atoi(e); if (a >= 1 && a <= 6) { ctx->nu = a; ctx->nu_set = true; } }
+    if (const char* e = getenv("PYLAMP_MG_NU3_FINE")) { int a = atoi(e); if (a >= 1 && a <= 6) ctx->nu_fine = a; }
     *out = ctx;
     return 0;
 }
@@ -839,7 +840,14 @@ static void vcycle3(pl3_ctx* ctx, size_t l, double* const* f, int& out_buf) {
         out_buf = cur;
         return;
     }
-    smooth3(ctx, L, f, ctx->nu, ctx->cheb_ratio, true, cur);
+    // From 10^6 nodes up: V(1,1) on the finest level, V(3,3) below (the 2-D solver's choice, pl_solver.hip) -- 257^3: 494 ms per solve
+    // pair with 24 iterations against 539 ms with 23 for V(2,2) throughout (1/4: 492, 2/3: 499, 1/2: 504; tools/run_nu3.sh).
+    // PYLAMP_MG_NU3 / PYLAMP_MG_NU3_FINE override the two counts.
+    const bool big = (long long)ctx->levels[0]->gh.d.n[0] * ctx->levels[0]->gh.d.n[1] * ctx->levels[0]->gh.d.n[2] >= 1000000;
+    const int nu_fine = ctx->nu_fine > 0 ? ctx->nu_fine : (big && !ctx->nu_set ? 1 : ctx->nu);
+    const int nu_rest = (big && !ctx->nu_set) ? 3 : ctx->nu;
+    const int nu = l == 0 ? nu_fine : nu_rest;
+    smooth3(ctx, L, f, nu, ctx->cheb_ratio, true, cur);
     hipLaunchKernelGGL(k3_resid, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, cv3(L->v[cur]), cv3(f), wv3(L->r), 0);
     Lev3* C = ctx->levels[l + 1];
     hipLaunchKernelGGL(k3_restrict, grid3(C->gh.d), dim3(64, 4), 0, ctx->stream, L->gh.d, C->op, cv3(L->r), wv3(C->f));
@@ -848,7 +856,7 @@ static void vcycle3(pl3_ctx* ctx, size_t l, double* const* f, int& out_buf) {
     const int nxt = (cur + 1) % 3;
     hipLaunchKernelGGL(k3_prolong_add, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, C->gh.d, cv3(C->v[cb]), cv3(L->v[cur]), wv3(L->v[nxt]));
     cur = nxt;
-    smooth3(ctx, L, f, ctx->nu, ctx->cheb_ratio, false, cur);
+    smooth3(ctx, L, f, nu, ctx->cheb_ratio, false, cur);
     out_buf = cur;
 }
 
