@@ -266,7 +266,12 @@ int  pl_tracers_count(pl_ctx* ctx, int64_t* n);
 /* Census of the resident tracers (pylamp2.py:588-598: np.bincount of the cell index): counts[c] for this rank's
  * owned cells, row-major (n_cell_rows x (nx-1)), ncells = their number.  counts == NULL only queries the rows. */
 int  pl_tracers_census(pl_ctx* ctx, int64_t ncells, int32_t* counts, int* first_cell_row, int* n_cell_rows);
-/* One full time step on the device-resident state. */
+/* One full time step on the device-resident state (pylamp2.py:284-583: properties, tracer -> grid, Stokes, time step, heat,
+ * grid -> tracer with subgrid diffusion, RK4 advection, census + injection).  The iterative solves are warm-started from the
+ * context's own history -- Stokes from the polynomial through its last three solutions evaluated at the new model time, heat
+ * from the old nodal temperature plus the last increment scaled by the time-step ratio; pl_tracers_upload forgets the history.
+ * The stopping rules are those of pl_stokes_solve / pl_heat_solve whatever the start, so the reference's results are reproduced
+ * within the solver tolerances either way (PYLAMP_X0_EXTRAP=0 / PYLAMP_HEAT_X0=0 start from the last solution / from zero). */
 int  pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_report* rep);
 /* Copy a named grid field of the last step to host, shape (nz,nx): "velz","velx","pres",
  * "rho","etas","etan","temp","f_T","kz","kx","cp","H". */
