@@ -409,10 +409,9 @@ static int reduce_minmax(pl_ctx* ctx, PlStepState* S, const PlGeom& g, const dou
         if (S->hpartial[3 * k + 2] > 0) nf = true;
     }
     if (ctx->nranks > 1) {
-        double v[1] = {m0};
-        PL_TRY(pl_allreduce_host(ctx, v, 1, 1)); m0 = v[0];
-        v[0] = m1; PL_TRY(pl_allreduce_host(ctx, v, 1, 2)); m1 = v[0];
-        v[0] = nf ? 1.0 : 0.0; PL_TRY(pl_allreduce_host(ctx, v, 1, 2)); nf = v[0] > 0.0;
+        double v[3] = {-m0, m1, nf ? 1.0 : 0.0};                   // ONE max-reduction: min = -max(-x)
+        PL_TRY(pl_allreduce_host(ctx, v, 3, 2));
+        m0 = -v[0]; m1 = v[1]; nf = v[2] > 0.0;
     }
     *mn = m0; *mx = m1; *has_nan = nf;
     return 0;
