@@ -66,6 +66,15 @@ struct PlGatherArgs {
     double defval;
     int accumulate;                                // LINEAR only: out += value
     unsigned long long* n_outside;
+    // Optional epilogue of the resident step's temperature interpolation (regular grid, one field; pylamp2.py:455,473-480): the
+    // interpolated value v is consumed in registers instead of being written for a second per-marker kernel to read.
+    //   epi = 1: Told = T[t], Tnew = Told + v; without subgrid diffusion T[t] = Tnew, else dt0 = hcp rho / (hcd inv2),
+    //            Tsub[t] = Told - (Told - Tnew) exp(-0.5 dt / dt0), dTs[t] = Tsub[t] - Tnew
+    //   epi = 2: T[t] = Tsub[t] - v
+    int epi; int epi_subgrid;
+    double* epi_T; const double* epi_hcp; const double* epi_rho; const double* epi_hcd;
+    double epi_inv2, epi_dt;
+    double* epi_Tsub; double* epi_dTs;
 };
 
 struct PlRk4Args {

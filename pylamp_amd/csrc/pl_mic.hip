@@ -368,11 +368,24 @@ __device__ inline void mic_veldiv(const PlGatherGrid& g, const double* __restric
 }
 
 // FAST: regular grid with reciprocal spacings, bilinear method (the resident step's temperature interpolation)
-template <bool FAST>
+template <bool FAST, int EPI = 0>
 __global__ __launch_bounds__(256) void k_gather(PlGatherArgs a) {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= a.n) return;
     const double z = a.tz[t], x = a.tx[t];
+    if (EPI != 0) {                                     // FAST, one field, value consumed by the subgrid-diffusion formulas
+        const CellLoc c = mic_locate<true>(a.g, z, x);
+        const double v = c.bad ? a.defval : mic_bilinear(a.fields[0], a.g, c);
+        if (c.bad) atomicAdd(a.n_outside, 1ull);
+        if (EPI == 1) {
+            const double Told = a.epi_T[t], Tnew = Told + v;
+            if (!a.epi_subgrid) { a.epi_T[t] = Tnew; return; }
+            const double dt0 = a.epi_hcp[t] * a.epi_rho[t] / (a.epi_hcd[t] * a.epi_inv2);
+            const double ts = Told - (Told - Tnew) * exp(-0.5 * a.epi_dt / dt0);
+            a.epi_Tsub[t] = ts; a.epi_dTs[t] = ts - Tnew;
+        } else a.epi_T[t] = a.epi_Tsub[t] - v;
+        return;
+    }
     if (!FAST && (a.method & PL_INTERP_NEAREST)) {
         const CellLoc c = mic_locate(a.g, z, x);
         const double dz0 = z - a.g.gz[c.ie], dz1 = a.g.gz[c.ie + 1] - z;
@@ -427,9 +440,13 @@ void pl_launch_gather(pl_ctx* ctx, const PlGatherArgs& a_in) {
     if (a_in.n <= 0) return;
     PlGatherArgs a = a_in;
     a.g.sz = (a.g.nz - 1) / a.g.Lz; a.g.sx = (a.g.nx - 1) / a.g.Lx;
-    if (!a.g.rect && a.g.fast_uniform && (a.method & PL_INTERP_LINEAR) && !(a.method & PL_INTERP_NEAREST))
-        hipLaunchKernelGGL(k_gather<true>, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, ctx->stream, a);
-    else hipLaunchKernelGGL(k_gather<false>, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    const bool fast = !a.g.rect && a.g.fast_uniform && (a.method & PL_INTERP_LINEAR) && !(a.method & PL_INTERP_NEAREST);
+    const dim3 gr((unsigned)((a.n + 255) / 256));
+    if (a.epi == 1 && fast && a.nf == 1) hipLaunchKernelGGL((k_gather<true, 1>), gr, dim3(256), 0, ctx->stream, a);
+    else if (a.epi == 2 && fast && a.nf == 1) hipLaunchKernelGGL((k_gather<true, 2>), gr, dim3(256), 0, ctx->stream, a);
+    else if (a.epi != 0) { (void)pl_fail(ctx, "pl_launch_gather: the fused epilogue needs the regular-grid bilinear path"); }
+    else if (fast) hipLaunchKernelGGL((k_gather<true, 0>), gr, dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((k_gather<false, 0>), gr, dim3(256), 0, ctx->stream, a);
 }
 
 void pl_launch_rk4(pl_ctx* ctx, const PlRk4Args& a_in) {
