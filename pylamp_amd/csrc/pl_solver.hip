@@ -1626,7 +1626,9 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
         if (L->eig_valid) PL_HIP(ctx, hipMemcpyAsync(L->v[0], L->eig, (size_t)n2 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
         else hipLaunchKernelGGL(k_random_interior, grid2d(g), dim3(64, 4), 0, ctx->stream, g, 2, L->v[0], 777u);
         const bool warm = L->eig_valid;
-        double lam = 2.5, lam_prev = 0.0, nn[2];
+        // warm: the previous solve's estimate is the value the first iteration is compared with, so that ONE iteration suffices
+        // when it confirms it to 1 % (the iteration then simply continues from solve to solve)
+        double lam = (warm && L->lmax > 0.0 && S->lmax_safety > 0.0) ? L->lmax / S->lmax_safety : 2.5, lam_prev = 0.0, nn[2];
         for (int it = 0; it < 12; it++) {
             // warm restart: at least power_its_warm iterations, then stop once the estimate moves by < 1 %
             if (warm && it >= S->power_its_warm && std::fabs(lam - lam_prev) < 0.01 * lam) break;
