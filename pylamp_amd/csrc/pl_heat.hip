@@ -3,6 +3,7 @@
 // Bound: HBM; algorithmic traffic 40 B/node/apply with dt/(rho*Cp) pre-multiplied
 // (T 8 + kz 8 + kx 8 + c 8 + y 8), 48 B/node counted the reference way.
 #include "pl_internal.h"
+#include <algorithm>
 
 #define TB(tab, k) (tab)[(k) + PL_TOFF]
 
@@ -88,6 +89,13 @@ void pl_launch_heat_coef(pl_ctx* ctx, const PlGeom& g, const double* rho, const 
 // midpoint tables 1/(zm[i]-zm[i-1]) (pylamp_diff.py:167-170), indexed global + 1
 int pl_heat_tables(pl_ctx* ctx, const double* zmp, const double* xmp) {
     int nz = ctx->nz, nx = ctx->nx;
+    // the time-step loop passes the same midpoints every step: keep the uploaded tables
+    if (ctx->hop.rdzb && (int)ctx->zmp.size() == nz && (int)ctx->xmp.size() == nx &&
+        std::equal(zmp, zmp + nz, ctx->zmp.begin()) && std::equal(xmp, xmp + nx, ctx->xmp.begin())) {
+        double* d0;
+        PL_TRY(pl_buf(ctx, "heat_tables", ((size_t)nz + 2 * PL_TOFF + 2 + nx + 2 * PL_TOFF + 2) * sizeof(double), &d0));
+        if (d0 == ctx->hop.rdzb) return 0;
+    }
     ctx->zmp.assign(zmp, zmp + nz); ctx->xmp.assign(xmp, xmp + nx);
     const size_t lz = (size_t)nz + 2 * PL_TOFF + 2;
     std::vector<double> t(lz + nx + 2 * PL_TOFF + 2, 0.0);
