@@ -525,6 +525,7 @@ struct Lev3 {
     double *es = nullptr, *en = nullptr; bool own = false;
     double* v[3][3] = {{nullptr}}; double* f[3] = {nullptr}; double* r[3] = {nullptr};
     double lmax = 3.0;
+    double* eig[3] = {nullptr, nullptr, nullptr}; bool eig_valid = false;      // eigenvector of the last power iteration (warm restart)
 };
 struct pl3_ctx {
     int device = 0; hipStream_t stream = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -601,7 +602,7 @@ static void free_levels3(pl3_ctx* ctx) {
     for (Lev3* L : ctx->levels) {
         if (L->own) { (void)hipFree(L->es); (void)hipFree(L->en); }
         for (int b = 0; b < 3; b++) for (int q = 0; q < 3; q++) if (L->v[b][q]) (void)hipFree(L->v[b][q]);
-        for (int q = 0; q < 3; q++) { if (L->f[q]) (void)hipFree(L->f[q]); if (L->r[q]) (void)hipFree(L->r[q]); }
+        for (int q = 0; q < 3; q++) { if (L->f[q]) (void)hipFree(L->f[q]); if (L->r[q]) (void)hipFree(L->r[q]); if (L->eig[q]) (void)hipFree(L->eig[q]); }
         if (L->gh.tables) (void)hipFree(L->gh.tables);
         delete L;
     }
@@ -792,13 +793,20 @@ static int build_levels3(pl3_ctx* ctx) {
         L->op = ctx->op; L->op.g = L->gh.d; L->op.es = L->es; L->op.en = L->en; L->op.slave = (l == 0) ? ctx->op.slave : 0;
         // lambda_max of D^-1 A_vv by power iteration
         const long long vol = L->gh.d.vol;
-        for (int q = 0; q < 3; q++) hipLaunchKernelGGL(k3_random, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, L->gh.d, L->v[0][q], 777u + q);
-        {   // the random start vector must satisfy the constraints: close it
+        // Warm restart as in the 2-D solver (pl_solver.hip): consecutive solves on one context (a time loop, or the same operator
+        // again) start from the eigenvector of the last one and stop as soon as an iteration confirms the last estimate to 1 % --
+        // 12 cold iterations per level were 5 % of a 257^3 solve.
+        const bool warm = L->eig_valid && L->eig[0];
+        if (warm) for (int q = 0; q < 3; q++) P3_HIP(ctx, hipMemcpyAsync(L->v[0][q], L->eig[q], (size_t)vol * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        else for (int q = 0; q < 3; q++) hipLaunchKernelGGL(k3_random, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, L->gh.d, L->v[0][q], 777u + q);
+        {   // the start vector must satisfy the constraints of THIS operator: close it
             for (int q = 0; q < 3; q++) P3_HIP(ctx, hipMemsetAsync(L->r[q], 0, (size_t)vol * sizeof(double), ctx->stream));
             hipLaunchKernelGGL(k3_close, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, wv3(L->v[0]), cv3(L->r));
         }
-        double lam = 2.5;
+        double lam = warm ? L->lmax / 1.1 : 2.5, lam_prev = 0.0;
         for (int it = 0; it < 12; it++) {
+            if (warm && it >= 1 && std::fabs(lam - lam_prev) < 0.01 * lam) break;
+            lam_prev = lam;
             hipLaunchKernelGGL(k3_resid, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, cv3(L->v[0]), cv3(L->f), wv3(L->v[1]), 1);
             double* const* aa[2] = {L->v[1], L->v[0]}; double* const* bb[2] = {L->v[1], L->v[0]};
             double nn[2];
@@ -808,12 +816,15 @@ static int build_levels3(pl3_ctx* ctx) {
             for (int q = 0; q < 3; q++) hipLaunchKernelGGL(k3_axpby, g1(vol), dim3(256), 0, ctx->stream, vol, L->v[0][q], 1.0 / std::sqrt(nn[0]), (const double*)L->v[1][q], 0.0, (const double*)L->v[1][q]);
         }
         L->lmax = 1.1 * lam;
+        if (!L->eig[0]) for (int q = 0; q < 3; q++) P3_TRY(dmal(ctx, &L->eig[q], vol));
+        for (int q = 0; q < 3; q++) P3_HIP(ctx, hipMemcpyAsync(L->eig[q], L->v[0][q], (size_t)vol * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        L->eig_valid = std::isfinite(lam) && lam > 0.0;
     }
     P3_HIP(ctx, hipGetLastError());
     return 0;
 }
 // nsweep sweeps; cur = index of the buffer holding the iterate on entry (ignored if zero_guess) and on exit
-static void smooth3(pl3_ctx* ctx, Lev3* L, double* const* f, int nsweep, double ratio, bool zero_guess, int& cur) {
+static void smooth3(pl3_ctx* ctx, Lev3* L, double* const* f, int nsweep, double ratio, bool zero_guess, int& cur, const W3* final_out = nullptr) {
     const double lmax = L->lmax, lmin = lmax / ratio, theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
     double rho_old = 1.0 / sigma;
     int prev = (cur + 1) % 3;
@@ -824,12 +835,14 @@ static void smooth3(pl3_ctx* ctx, Lev3* L, double* const* f, int nsweep, double 
         int nxt = 0; while (nxt == cur || nxt == prev) nxt++;
         V3 vp = cv3(L->v[prev]);
         if (k == 1 && zero_guess) for (int q = 0; q < 3; q++) vp.p[q] = nullptr;
-        hipLaunchKernelGGL(k3_cheb, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, cv3(L->v[cur]), vp, cv3(f), wv3(L->v[nxt]), c1, c2,
+        // the last sweep may write straight into the caller's arrays (the preconditioner's output) instead of a level buffer
+        const W3 dst = (final_out && k == nsweep - 1) ? *final_out : wv3(L->v[nxt]);
+        hipLaunchKernelGGL(k3_cheb, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, cv3(L->v[cur]), vp, cv3(f), dst, c1, c2,
                            (k == 0 && zero_guess) ? 1 : 0);
         prev = cur; cur = nxt;
     }
 }
-static void vcycle3(pl3_ctx* ctx, size_t l, double* const* f, int& out_buf) {
+static void vcycle3(pl3_ctx* ctx, size_t l, double* const* f, int& out_buf, const W3* final_out = nullptr) {
     Lev3* L = ctx->levels[l];
     int cur = 0;
     if (l + 1 == ctx->levels.size()) {
@@ -856,7 +869,7 @@ static void vcycle3(pl3_ctx* ctx, size_t l, double* const* f, int& out_buf) {
     const int nxt = (cur + 1) % 3;
     hipLaunchKernelGGL(k3_prolong_add, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, C->gh.d, cv3(C->v[cb]), cv3(L->v[cur]), wv3(L->v[nxt]));
     cur = nxt;
-    smooth3(ctx, L, f, nu, ctx->cheb_ratio, false, cur);
+    smooth3(ctx, L, f, nu, ctx->cheb_ratio, false, cur, final_out);
     out_buf = cur;
 }
 
@@ -1067,8 +1080,13 @@ extern "C" int pl3_stokes_solve(pl3_ctx* ctx, const double* rhs, double* x, int 
         Lev3* L0 = ctx->levels[0];
         hipLaunchKernelGGL(k3_stage1, grid3(g), dim3(64, 4), 0, ctx->stream, ctx->op, cv4(in), out[3], wv3(L0->f));
         int ob = 0;
-        vcycle3(ctx, 0, L0->f, ob);
-        for (int q = 0; q < 3; q++) P3_HIP(ctx, hipMemcpyAsync(out[q], L0->v[ob][q], (size_t)vol * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        if (ctx->levels.size() > 1) {           // the post-smoothing sweep of the finest level writes the velocities into out[0..2] itself
+            const W3 fo = wv3(out);
+            vcycle3(ctx, 0, L0->f, ob, &fo);
+        } else {
+            vcycle3(ctx, 0, L0->f, ob);
+            for (int q = 0; q < 3; q++) P3_HIP(ctx, hipMemcpyAsync(out[q], L0->v[ob][q], (size_t)vol * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        }
         nprec++;
         if (defl_active) {                  // z += w yw.(r - A z) / yw.(A w); the continuity rows of A z come from z's velocities alone
             const double* a1[2] = {ctx->dfl_y, ctx->dfl_y}; const double* b1[2] = {in[3], ctx->dfl_t}; double o[2];
