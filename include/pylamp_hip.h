@@ -273,6 +273,18 @@ int  pl_tracers_census(pl_ctx* ctx, int64_t ncells, int32_t* counts, int* first_
  * The stopping rules are those of pl_stokes_solve / pl_heat_solve whatever the start, so the reference's results are reproduced
  * within the solver tolerances either way (PYLAMP_X0_EXTRAP=0 / PYLAMP_HEAT_X0=0 start from the last solution / from zero). */
 int  pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_report* rep);
+/* The marker stages of pl_step ONE AT A TIME on the resident, cell-sorted tracers (one rank) -- the same functions and kernels
+ * the timed step runs (fused k_scatter_cells, k_gather<true, 0|1|2>, k_rk4<true>), so that tests can pin them directly against
+ * the reference's fixtures (pylamp_trac.py:161-318 trac2grid, :30-158 grid2trac, :321-388 RK) instead of through trajectories.
+ * pl_resident_scatter: properties + the step's tracer -> grid calls (pylamp2.py:291-319); results by pl_get_field ("rho", "etas",
+ *   "etan", "cp", "f_T", "H", "mat", "kz", "kx").
+ * pl_resident_temp_to_tracers: pylamp2.py:436-480 with the new nodal temperature newtemp (nz,nx); the old nodal temperature is
+ *   the plane "f_T" of the last scatter; first != 0 is the it == 1 branch; results in column TR_TMP (pl_tracers_download).
+ * pl_resident_rk4: RK4 through vz_pad, vx_pad on the padded (nz+1, nx+1) centre grid (pylamp2.py:547-572, fence optional), then
+ *   the end-of-step cell sort; positions by pl_tracers_download, velocities by pl_get_tracer_velocity. */
+int  pl_resident_scatter(pl_ctx* ctx, const pl_step_config* cfg, int it);
+int  pl_resident_temp_to_tracers(pl_ctx* ctx, const pl_step_config* cfg, int first, const double* newtemp, double tstep);
+int  pl_resident_rk4(pl_ctx* ctx, const double* vz_pad, const double* vx_pad, double tstep, int fence, const double length[2]);
 /* Copy a named grid field of the last step to host, shape (nz,nx): "velz","velx","pres",
  * "rho","etas","etan","temp","f_T","kz","kx","cp","H". */
 int  pl_get_field(pl_ctx* ctx, const char* name, double* out);

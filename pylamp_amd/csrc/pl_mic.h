@@ -88,6 +88,29 @@ struct PlRk4Args {
     unsigned long long* n_outside_window;          // stage positions whose cell lies outside the local window (or NULL)
 };
 
+// Fused scatter of a time step's four target sets over cell-sorted tracers (pl_mic_cells.hip)
+struct PlScatterCellsArgs {
+    const double* tz; const double* tx;
+    const double* fn[6];            // node-set fields (all weighted; arithmetic, or geometric with the logarithm already taken)
+    const double* fm;               // field of the two mid-face sets (heat conductivity)
+    double z0, hz, rhz, x0, hx, rhx;   // node grid: node k at z0 + k hz; the shifted sets start half a cell later
+    int nz, nx;                     // nodes per target set (every set is nz x nx)
+    int row0, nrows, col0, ncols;   // accumulator window (as PlScatterArgs)
+    const int* cell_start; int ncz, ncx, crow0, ccol0;
+    double* accN; double* accC; double* accZ; double* accX;   // (1 + NFN) | 2 | 2 | 2 planes of N doubles: denominator first
+    long long N;
+    int* slow_count; int* slow_list; int slow_cap;            // tracers found outside their sort cell
+    int dbg;                        // PYLAMP_SC_DBG (timing experiments only): 1 no tracer loop, 2 no row epilogue, 4 no emission, 8 no staging
+};
+#define PL_SCF_MAX 10
+struct PlScatterFinalArgs {
+    int nz, nx, nf;                 // owned nodes, fields
+    const double* acc[PL_SCF_MAX]; const double* den[PL_SCF_MAX]; int scheme[PL_SCF_MAX]; double* out[PL_SCF_MAX];
+    long long acc_pitch, out_pitch, out_off;
+};
+int pl_scatter_cells_device(pl_ctx* ctx, PlScatterCellsArgs& a, int variant);
+void pl_launch_scatter_finalize_multi(pl_ctx* ctx, const PlScatterFinalArgs& a);
+
 // Cell index and in-cell coordinate on a rectilinear axis c[0..n-1] (largest ie with c[ie] <= z; a marker exactly
 // on the last coordinate belongs to the last cell with a = 1).  Outside the axis the grid continues with the
 // spacing of its end cell, like the reference's auto-extension (pylamp_trac.py:207-220): ie < 0 or ie >= n-1.

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void k_cell_count(long long n, const double* _
     } else if (t < n) {
         int ci, cj;
         if (zc) { double a_; mic_axis_locate(zc, gcz + 1, tz[t], ci, a_); mic_axis_locate(xc, gcx + 1, tx[t], cj, a_); }   // rectilinear node grid
-        else { ci = (int)floor((tz[t] - z0) / hz); cj = (int)floor((tx[t] - x0) / hx); }
+        else { ci = (int)floor((tz[t] - z0) * (1.0 / hz)); cj = (int)floor((tx[t] - x0) * (1.0 / hx)); }   // the lookup of the scatter kernels
         ci = min(max(ci, 0), gcz - 1) - crow0;              // global cell (clamped to the domain) -> block cell
         cj = min(max(cj, 0), gcx - 1) - ccol0;
         const int dz = ci < 0 ? -1 : (ci >= ncz ? 1 : 0), dx = cj < 0 ? -1 : (cj >= ncx ? 1 : 0);
@@ -895,6 +895,244 @@ static int scatter_to_planes(pl_ctx* ctx, PlStepState* S, int nf, const int* fid
     return pl_scatter_device(ctx, a, planes, g.pitch, pl_idx(g, 0, 0), &g);
 }
 
+// The scatters of a time step in ONE pass over the cell-sorted tracers (pl_mic_cells.hip; regular grids).
+//   variant 0 (heat on):  nodes {rho AW, log eta GW, cp, T, H, mat AW} -> out[0..5], centres {log eta GW} -> out[6],
+//                         z-mid {k AW} -> out[7], x-mid {k AW} -> out[8]                      (pylamp2.py:307-314)
+//   variant 1 (heat off): nodes {rho AW, log eta GW} -> out[0..1], centres {log eta, UNWEIGHTED} -> out[2]   (pylamp2.py:316-319)
+//   variant 2:            nodes {fn[0] AW} -> out[0]                                          (subgrid diffusion, pylamp2.py:477)
+// PYLAMP_SCATTER=0 keeps the one-set-per-pass kernels (k_scatter_binned) -- the cross-check of the tests.
+static bool scatter_cells_on() { const char* e = getenv("PYLAMP_SCATTER"); return !(e && atoi(e) == 0); }    // read per call: tests switch it
+static int scatter_cells(pl_ctx* ctx, PlStepState* S, int variant, const double* const* fn, const double* fm, double z0, double hz,
+                         double x0, double hx, double* const* out) {
+    const PlGeom& g = ctx->geom.d;
+    const int AW = PL_AVG_ARITHMETIC | PL_AVG_WEIGHTED, GW = PL_AVG_GEOMETRIC | PL_AVG_WEIGHTED, G0 = PL_AVG_GEOMETRIC;
+    const int nfn = variant == 0 ? 6 : (variant == 1 ? 2 : 1);
+    const bool cen = variant <= 1, mid = variant == 0;
+    const int nplanes = (1 + nfn) + (cen ? 2 : 0) + (mid ? 4 : 0);
+    PlScatterCellsArgs a{};
+    a.tz = S->tz; a.tx = S->tx;
+    for (int k = 0; k < nfn; k++) a.fn[k] = fn[k];
+    a.fm = fm;
+    a.z0 = z0; a.hz = hz; a.x0 = x0; a.hx = hx; a.nz = g.nz; a.nx = g.nx;
+    a.row0 = g.gi0 - 1; a.nrows = g.lnz + 2; a.col0 = g.gj0 - 1; a.ncols = g.lnx + 2;
+    a.cell_start = S->cell_start; a.ncz = S->ncz; a.ncx = S->ncx; a.crow0 = S->crow0; a.ccol0 = S->ccol0;
+    const size_t N = (size_t)a.nrows * a.ncols;
+    a.N = (long long)N;
+    double* accbuf;
+    PL_TRY(pl_buf(ctx, "scatter_acc", (size_t)nplanes * N * sizeof(double), &accbuf, false));
+    // every node of the block is written by exactly one wave (plain stores); only the ring that the reverse halo reads on
+    // several ranks needs zeros where no tracer contributes
+    if (ctx->nranks > 1) PL_HIP(ctx, hipMemsetAsync(accbuf, 0, (size_t)nplanes * N * sizeof(double), ctx->stream));
+    a.accN = accbuf; a.accC = accbuf + (size_t)(1 + nfn) * N; a.accZ = a.accC + (cen ? 2 : 0) * N; a.accX = a.accZ + 2 * N;
+    double* sc;
+    PL_TRY(pl_buf(ctx, "scatter_slow_count", 64, &sc, false));
+    a.slow_count = (int*)sc; a.slow_list = S->dest; a.slow_cap = (int)std::min<long long>(S->cap, 0x7fffffff);   // `dest` is free outside the sort
+    a.dbg = getenv("PYLAMP_SC_DBG") ? atoi(getenv("PYLAMP_SC_DBG")) : 0;
+    PL_TRY(pl_scatter_cells_device(ctx, a, variant));
+    if (ctx->nranks > 1)       // what I accumulated for nodes of the neighbour blocks is added to their accumulators
+        PL_TRY(pl_halo_generic(ctx, g.lnz, g.lnx, accbuf + a.ncols + 1, a.ncols, nplanes, (long long)N, 1, true));
+    PlScatterFinalArgs f{};
+    f.nz = g.lnz; f.nx = g.lnx; f.acc_pitch = a.ncols; f.out_pitch = g.pitch; f.out_off = pl_idx(g, 0, 0);
+    const double* base = accbuf + a.ncols + 1;                 // owned node (0,0)
+    auto add = [&](const double* set, int k, int scheme, double* o) {
+        f.acc[f.nf] = set + (size_t)(1 + k) * N; f.den[f.nf] = set; f.scheme[f.nf] = scheme; f.out[f.nf] = o; f.nf++;
+    };
+    if (variant == 0) {
+        const int sch[6] = {AW, GW, AW, AW, AW, AW};
+        for (int k = 0; k < 6; k++) add(base, k, sch[k], out[k]);
+        add(base + 7 * N, 0, GW, out[6]); add(base + 9 * N, 0, AW, out[7]); add(base + 11 * N, 0, AW, out[8]);
+    } else if (variant == 1) {
+        add(base, 0, AW, out[0]); add(base, 1, GW, out[1]); add(base + 3 * N, 0, G0, out[2]);
+    } else add(base, 0, AW, out[0]);
+    const int nout = f.nf;
+    pl_launch_scatter_finalize_multi(ctx, f);
+    PL_HIP(ctx, hipGetLastError());
+    if (ctx->nranks > 1)
+        for (int k = 0; k < nout; k++)
+            PL_TRY(pl_halo(ctx, g, out[k], 1, g.plane, std::min(PL_RING, std::min(g.lnz, g.lnx))));
+    return 0;
+}
+
+// ---- the marker stages of a time step; pl_step runs them in order, the pl_resident_* entry points one at a time ------------
+struct StepPlanes { double *rho, *etas, *etan, *cp, *T, *H, *mat, *kz, *kx, *newT, *c, *sgc, *dT; };
+static int step_planes(pl_ctx* ctx, StepPlanes& P) {
+    const size_t pb = (size_t)ctx->geom.d.plane * sizeof(double);
+    PL_TRY(pl_buf(ctx, "rho", pb, &P.rho)); PL_TRY(pl_buf(ctx, "etas", pb, &P.etas)); PL_TRY(pl_buf(ctx, "etan", pb, &P.etan));
+    PL_TRY(pl_buf(ctx, "cp", pb, &P.cp)); PL_TRY(pl_buf(ctx, "f_T", pb, &P.T)); PL_TRY(pl_buf(ctx, "H", pb, &P.H));
+    PL_TRY(pl_buf(ctx, "mat", pb, &P.mat)); PL_TRY(pl_buf(ctx, "kz", pb, &P.kz)); PL_TRY(pl_buf(ctx, "kx", pb, &P.kx));
+    PL_TRY(pl_buf(ctx, "temp", pb, &P.newT)); PL_TRY(pl_buf(ctx, "heat_c", pb, &P.c)); PL_TRY(pl_buf(ctx, "sgc", pb, &P.sgc));
+    PL_TRY(pl_buf(ctx, "dT", pb, &P.dT));
+    return 0;
+}
+struct StepGrid { double z0, hz, x0, hx; };
+static StepGrid step_grid(pl_ctx* ctx) {
+    const int nz = ctx->nz, nx = ctx->nx;
+    StepGrid q; q.z0 = ctx->geom.zc[0]; q.x0 = ctx->geom.xc[0];
+    q.hz = (ctx->geom.zc[nz - 1] - q.z0) / (nz - 1); q.hx = (ctx->geom.xc[nx - 1] - q.x0) / (nx - 1);
+    return q;
+}
+
+// stage 1: tracer properties (pylamp2.py:291-303)
+static int stage_props(pl_ctx* ctx, PlStepState* S, const pl_step_config* cfg) {
+    const long long n = S->n;
+    hipLaunchKernelGGL(k_property_update, grid1d(n), dim3(256), 0, ctx->stream, n, S->f[TR_TMP], S->f[TR_RH0], S->f[TR_ALP],
+                       S->f[TR_ACE], S->f[TR_ET0], S->f[TR_RHO], S->f[TR_ETA], cfg->tdep_rho, cfg->tdep_eta, cfg->tref,
+                       cfg->etamin, cfg->etamax, S->tmp[2]);
+    PL_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+// stage 2: tracer -> grid (pylamp2.py:307-319); S->tmp[2] holds log(eta) (stage 1)
+static int stage_scatter(pl_ctx* ctx, PlStepState* S, const pl_step_config* cfg, int it, const StepPlanes& P) {
+    const PlGeom& g = ctx->geom.d;
+    const StepGrid q = step_grid(ctx);
+    const double z0 = q.z0, hz = q.hz, x0 = q.x0, hx = q.hx;
+    const int AW = PL_AVG_ARITHMETIC | PL_AVG_WEIGHTED, GW = PL_AVG_GEOMETRIC | PL_AVG_WEIGHTED | PL_AVG_PRELOG;
+    const int ETA_LOG = -3;                     // S->tmp[2]: log(eta) written by k_property_update
+    const bool cells = scatter_cells_on() && ctx->geom.uniform;
+    if (cfg->do_heatdiff) {
+        if (cells) {
+            const double* fn[6] = {S->f[TR_RHO], S->tmp[2], S->f[TR_HCP], S->f[TR_TMP], S->f[TR_IHT], S->f[TR_MAT]};
+            double* out[9] = {P.rho, P.etas, P.cp, P.T, P.H, P.mat, P.etan, P.kz, P.kx};
+            PL_TRY(scatter_cells(ctx, S, 0, fn, S->f[TR_HCD], z0, hz, x0, hx, out));
+        } else {
+            const int fi[6] = {TR_RHO, ETA_LOG, TR_HCP, TR_TMP, TR_IHT, TR_MAT};
+            const int sc[6] = {AW, GW, AW, AW, AW, AW};
+            double* pl6[6] = {P.rho, P.etas, P.cp, P.T, P.H, P.mat};
+            PL_TRY(scatter_to_planes(ctx, S, 6, fi, sc, z0, hz, x0, hx, pl6));
+            const int f1[1] = {ETA_LOG}; const int s1[1] = {GW}; double* pn[1] = {P.etan};
+            PL_TRY(scatter_to_planes(ctx, S, 1, f1, s1, z0 + 0.5 * hz, hz, x0 + 0.5 * hx, hx, pn, 1, 1));
+            const int f2[1] = {TR_HCD}; const int s2[1] = {AW};
+            double* pk[1] = {P.kz};
+            PL_TRY(scatter_to_planes(ctx, S, 1, f2, s2, z0 + 0.5 * hz, hz, x0, hx, pk, 1, 0));
+            pk[0] = P.kx;
+            PL_TRY(scatter_to_planes(ctx, S, 1, f2, s2, z0, hz, x0 + 0.5 * hx, hx, pk, 0, 1));
+        }
+        if (it > 1 && S->have_newtemp)
+            hipLaunchKernelGGL(k_copy_boundary, grid2d(g), dim3(64, 4), 0, ctx->stream, g, P.newT, P.T);
+    } else if (cells) {
+        const double* fn[2] = {S->f[TR_RHO], S->tmp[2]};
+        double* out[3] = {P.rho, P.etas, P.etan};
+        PL_TRY(scatter_cells(ctx, S, 1, fn, nullptr, z0, hz, x0, hx, out));
+    } else {
+        const int fi[2] = {TR_RHO, ETA_LOG}; const int sc[2] = {AW, GW};
+        double* pl2[2] = {P.rho, P.etas};
+        PL_TRY(scatter_to_planes(ctx, S, 2, fi, sc, z0, hz, x0, hx, pl2));
+        const int f1[1] = {ETA_LOG}; const int s1[1] = {PL_AVG_GEOMETRIC | PL_AVG_PRELOG}; double* pn[1] = {P.etan};   // pylamp2.py:319 (unweighted)
+        PL_TRY(scatter_to_planes(ctx, S, 1, f1, s1, z0 + 0.5 * hz, hz, x0 + 0.5 * hx, hx, pn, 1, 1));
+    }
+    PL_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+// stage 5b: temperature to the tracers (+ subgrid diffusion), pylamp2.py:436-480.  P.newT: the new nodal temperature (halo
+// filled), P.T: the nodal temperature the heat system was built from.  first: the it == 1 branch (plain interpolation).
+static int stage_temp_to_tracers(pl_ctx* ctx, PlStepState* S, const pl_step_config* cfg, bool first, const StepPlanes& P, double tstep) {
+    const PlGeom& g = ctx->geom.d;
+    const int nz = g.nz, nx = g.nx;
+    const long long n = S->n;
+    const StepGrid q = step_grid(ctx);
+    const double dz = cfg->length[0] / (nz - 1), dx = cfg->length[1] / (nx - 1);           // pylamp2.py:87
+    const int AW = PL_AVG_ARITHMETIC | PL_AVG_WEIGHTED;
+    double* cnt;
+    PL_TRY(pl_buf(ctx, "mic_counter", 64, &cnt, false));
+    PL_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
+    PlGatherArgs ga{};
+    ga.n = n; ga.tz = S->tz; ga.tx = S->tx; ga.nf = 1; ga.method = PL_INTERP_LINEAR;
+    ga.defval = std::numeric_limits<double>::quiet_NaN(); ga.accumulate = 0; ga.n_outside = (unsigned long long*)cnt;
+    ga.g.nz = nz; ga.g.nx = nx; ga.g.gz = S->gcoords; ga.g.gx = S->gcoords + nz;
+    ga.g.zmin = ctx->geom.zc[0]; ga.g.xmin = ctx->geom.xc[0];
+    ga.g.Lz = ctx->geom.zc[nz - 1] - ctx->geom.zc[0]; ga.g.Lx = ctx->geom.xc[nx - 1] - ctx->geom.xc[0];
+    ga.g.rect = ctx->geom.uniform ? 0 : 1;
+    ga.g.fast_uniform = ctx->geom.uniform ? 1 : 0;            // regular grid: k_gather<true> (no coordinate search, no divisions)
+    ga.g.pitch = g.pitch; ga.g.off = pl_idx(g, -g.gi0, -g.gj0);      // field indices are GLOBAL
+    if (first) {
+        ga.fields[0] = P.newT; ga.out[0] = S->f[TR_TMP];
+        pl_launch_gather(ctx, ga);
+    } else {
+        hipLaunchKernelGGL(k_plane_sub, grid2d(g), dim3(64, 4), 0, ctx->stream, g, P.newT, P.T, P.dT);
+        PL_TRY(pl_halo(ctx, g, P.dT, 1, g.plane));
+        S->have_dT = true;
+        const double inv2 = (2.0 / dx) * (2.0 / dx) + (2.0 / dz) * (2.0 / dz);
+        // regular grid: the two per-marker subgrid kernels ride in the gathers (the interpolated value never goes to memory:
+        // 152 -> 120 B per marker over the stage)
+        const bool fuse = ga.g.fast_uniform && !ga.g.rect;
+        ga.fields[0] = P.dT; ga.out[0] = S->tmp[0];
+        if (fuse) {
+            ga.epi = 1; ga.epi_subgrid = cfg->do_subgrid_heatdiff; ga.epi_T = S->f[TR_TMP]; ga.epi_hcp = S->f[TR_HCP];
+            ga.epi_rho = S->f[TR_RHO]; ga.epi_hcd = S->f[TR_HCD]; ga.epi_inv2 = inv2; ga.epi_dt = tstep;
+            ga.epi_Tsub = S->tmp[1]; ga.epi_dTs = S->tmp[2];
+        }
+        pl_launch_gather(ctx, ga);
+        if (!fuse)
+            hipLaunchKernelGGL(k_subgrid_part1, grid1d(n), dim3(256), 0, ctx->stream, n, S->f[TR_TMP], S->tmp[0], S->f[TR_HCP],
+                               S->f[TR_RHO], S->f[TR_HCD], inv2, tstep, cfg->do_subgrid_heatdiff, S->tmp[1], S->tmp[2]);
+        if (cfg->do_subgrid_heatdiff) {
+            // T currently holds Told for the subgrid branch; dTs = tmp[2] -> nodes -> back to tracers
+            if (scatter_cells_on() && ctx->geom.uniform) {
+                const double* fn[1] = {S->tmp[2]}; double* out[1] = {P.sgc};
+                PL_TRY(scatter_cells(ctx, S, 2, fn, nullptr, q.z0, q.hz, q.x0, q.hx, out));
+            } else {
+                const int fs[1] = {-3}; const int ss[1] = {AW}; double* ps[1] = {P.sgc};
+                PL_TRY(scatter_to_planes(ctx, S, 1, fs, ss, q.z0, q.hz, q.x0, q.hx, ps));
+            }
+            ga.fields[0] = P.sgc; ga.out[0] = S->tmp[0];
+            if (fuse) ga.epi = 2;
+            pl_launch_gather(ctx, ga);
+            if (!fuse) hipLaunchKernelGGL(k_subgrid_part2, grid1d(n), dim3(256), 0, ctx->stream, n, S->f[TR_TMP], S->tmp[1], S->tmp[0]);
+        }
+        ga.epi = 0;
+    }
+    unsigned long long nout = 0;
+    PL_HIP(ctx, hipMemcpyAsync(&nout, cnt, sizeof(nout), hipMemcpyDeviceToHost, ctx->stream));
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    { double v[1] = {(double)nout}; PL_TRY(pl_allreduce_host(ctx, v, 1, 0)); nout = (unsigned long long)v[0]; }
+    if (nout > 0) return pl_fail(ctx, "stopOnError in grid2trac");        // pylamp2.py:445,453 stopOnError=True
+    return 0;
+}
+
+// stage 6b: RK4 through the advection velocities V = (Vz | Vx), the window [I0, I1] x [J0, J1] of the padded centre grid held
+// as dense (I1-I0+1) x (J1-J0+1) arrays; positions -> tz2/tx2 (swapped in), tracer velocities -> vtz/vtx (pylamp2.py:547-572)
+static int stage_rk4(pl_ctx* ctx, PlStepState* S, const double* V, int I0, int I1, int J0, int J1, double tstep, int fence, double Lz, double Lx) {
+    const int nz = ctx->nz, nx = ctx->nx;
+    const StepGrid q = step_grid(ctx);
+    const int nVr = I1 - I0 + 1, nVc = J1 - J0 + 1;
+    const size_t VN = (size_t)nVr * nVc;
+    PlRk4Args ra{};
+    ra.n = S->n; ra.tz = S->tz; ra.tx = S->tx;
+    ra.g.nz = nz + 1; ra.g.nx = nx + 1; ra.g.gz = S->gcoords + nz + nx; ra.g.gx = S->gcoords + nz + nx + (nz + 1);
+    {
+        const double gz0 = S->gmz[0] - (S->gmz[1] - S->gmz[0]), gx0 = S->gmx[0] - (S->gmx[1] - S->gmx[0]);
+        ra.g.zmin = gz0; ra.g.xmin = gx0; ra.g.Lz = S->gmz[nz - 1] - gz0; ra.g.Lx = S->gmx[nx - 1] - gx0;
+    }
+    ra.g.rect = ctx->geom.uniform ? 0 : 1;
+    ra.g.fast_uniform = ctx->geom.uniform ? 1 : 0; ra.g.hx_over_hz = q.hx / q.hz; ra.g.hz_over_hx = q.hz / q.hx;
+    ra.g.pitch = nVc; ra.g.off = -((long long)I0 * nVc + J0);      // cell indices are GLOBAL
+    ra.g.ie_lo = I0; ra.g.ie_hi = I1 - 1; ra.g.je_lo = J0; ra.g.je_hi = J1 - 1;      // cells held locally
+    ra.Vz = V; ra.Vx = V + VN; ra.dt = tstep;
+    ra.tz_out = S->tz2; ra.tx_out = S->tx2; ra.vz_out = S->vtz; ra.vx_out = S->vtx;
+    ra.fence = fence; ra.eps = PL_EPS; ra.Lz = Lz; ra.Lx = Lx;
+    double* oowc = nullptr;
+    if (ctx->nranks > 1) {
+        PL_TRY(pl_buf(ctx, "rk4_counter", 64, &oowc, false));
+        PL_HIP(ctx, hipMemsetAsync(oowc, 0, 64, ctx->stream));
+        ra.n_outside_window = (unsigned long long*)oowc;
+    }
+    pl_launch_rk4(ctx, ra);
+    PL_HIP(ctx, hipGetLastError());
+    std::swap(S->tz, S->tz2); std::swap(S->tx, S->tx2);
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->nranks > 1) {      // collective: a stage that left the local velocity window means the step was not CFL-limited
+        unsigned long long no = 0;
+        PL_HIP(ctx, hipMemcpy(&no, oowc, sizeof(no), hipMemcpyDeviceToHost));
+        double v[1] = {(double)no};
+        PL_TRY(pl_allreduce_host(ctx, v, 1, 0));
+        if (v[0] > 0) return pl_fail(ctx, "pl_step: a tracer moved by more than one cell in an RK4 stage (time step not CFL-limited); the "
+                                          "block decomposition holds the advection velocity one cell around each block only");
+    }
+    return 0;
+}
+
 extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_report* rep) {
     if (!cfg || !rep) return pl_fail(ctx, "pl_step: NULL argument");
     PL_HIP(ctx, hipSetDevice(ctx->device));
@@ -915,51 +1153,24 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
     double t_all = now_ms(), t0;
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
 
-    // planes
-    double *p_rho, *p_etas, *p_etan, *p_cp, *p_T, *p_H, *p_mat, *p_kz, *p_kx, *p_newT, *p_c, *p_sgc, *p_dT;
-    PL_TRY(pl_buf(ctx, "rho", pb, &p_rho)); PL_TRY(pl_buf(ctx, "etas", pb, &p_etas)); PL_TRY(pl_buf(ctx, "etan", pb, &p_etan));
-    PL_TRY(pl_buf(ctx, "cp", pb, &p_cp)); PL_TRY(pl_buf(ctx, "f_T", pb, &p_T)); PL_TRY(pl_buf(ctx, "H", pb, &p_H));
-    PL_TRY(pl_buf(ctx, "mat", pb, &p_mat)); PL_TRY(pl_buf(ctx, "kz", pb, &p_kz)); PL_TRY(pl_buf(ctx, "kx", pb, &p_kx));
-    PL_TRY(pl_buf(ctx, "temp", pb, &p_newT)); PL_TRY(pl_buf(ctx, "heat_c", pb, &p_c)); PL_TRY(pl_buf(ctx, "sgc", pb, &p_sgc));
-    PL_TRY(pl_buf(ctx, "dT", pb, &p_dT));
+    StepPlanes P;
+    PL_TRY(step_planes(ctx, P));
+    double* const p_rho = P.rho; double* const p_etas = P.etas; double* const p_etan = P.etan; double* const p_cp = P.cp;
+    double* const p_T = P.T; double* const p_H = P.H; double* const p_kz = P.kz; double* const p_kx = P.kx;
+    double* const p_newT = P.newT; double* const p_c = P.c; double* const p_dT = P.dT;
 
     // tracers arrive cell-sorted (pl_tracers_upload / end of the previous step)
     if (!S->sorted) return pl_fail(ctx, "pl_step: tracers are not sorted (internal error)");
-    const long long n = S->n;
 
     // ---- 1. tracer properties --------------------------------------------------------------
     t0 = now_ms();
-    hipLaunchKernelGGL(k_property_update, grid1d(n), dim3(256), 0, ctx->stream, n, S->f[TR_TMP], S->f[TR_RH0], S->f[TR_ALP],
-                       S->f[TR_ACE], S->f[TR_ET0], S->f[TR_RHO], S->f[TR_ETA], cfg->tdep_rho, cfg->tdep_eta, cfg->tref,
-                       cfg->etamin, cfg->etamax, S->tmp[2]);
+    PL_TRY(stage_props(ctx, S, cfg));
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     rep->ms_props = now_ms() - t0;
 
     // ---- 2. tracer -> grid (pylamp2.py:307-319) ------------------------------------------------
     t0 = now_ms();
-    const int AW = PL_AVG_ARITHMETIC | PL_AVG_WEIGHTED, GW = PL_AVG_GEOMETRIC | PL_AVG_WEIGHTED | PL_AVG_PRELOG;
-    const int ETA_LOG = -3;                     // S->tmp[2]: log(eta) written by k_property_update
-    if (cfg->do_heatdiff) {
-        const int fi[6] = {TR_RHO, ETA_LOG, TR_HCP, TR_TMP, TR_IHT, TR_MAT};
-        const int sc[6] = {AW, GW, AW, AW, AW, AW};
-        double* pl6[6] = {p_rho, p_etas, p_cp, p_T, p_H, p_mat};
-        PL_TRY(scatter_to_planes(ctx, S, 6, fi, sc, z0, hz, x0, hx, pl6));
-        const int f1[1] = {ETA_LOG}; const int s1[1] = {GW}; double* pn[1] = {p_etan};
-        PL_TRY(scatter_to_planes(ctx, S, 1, f1, s1, z0 + 0.5 * hz, hz, x0 + 0.5 * hx, hx, pn, 1, 1));
-        const int f2[1] = {TR_HCD}; const int s2[1] = {AW};
-        double* pk[1] = {p_kz};
-        PL_TRY(scatter_to_planes(ctx, S, 1, f2, s2, z0 + 0.5 * hz, hz, x0, hx, pk, 1, 0));
-        pk[0] = p_kx;
-        PL_TRY(scatter_to_planes(ctx, S, 1, f2, s2, z0, hz, x0 + 0.5 * hx, hx, pk, 0, 1));
-        if (it > 1 && S->have_newtemp)
-            hipLaunchKernelGGL(k_copy_boundary, grid2d(g), dim3(64, 4), 0, ctx->stream, g, p_newT, p_T);
-    } else {
-        const int fi[2] = {TR_RHO, ETA_LOG}; const int sc[2] = {AW, GW};
-        double* pl2[2] = {p_rho, p_etas};
-        PL_TRY(scatter_to_planes(ctx, S, 2, fi, sc, z0, hz, x0, hx, pl2));
-        const int f1[1] = {ETA_LOG}; const int s1[1] = {PL_AVG_GEOMETRIC | PL_AVG_PRELOG}; double* pn[1] = {p_etan};   // pylamp2.py:319 (unweighted)
-        PL_TRY(scatter_to_planes(ctx, S, 1, f1, s1, z0 + 0.5 * hz, hz, x0 + 0.5 * hx, hx, pn, 1, 1));
-    }
+    PL_TRY(stage_scatter(ctx, S, cfg, it, P));
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     rep->ms_scatter = now_ms() - t0;
 
@@ -1142,55 +1353,7 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
 
         // temperature to tracers
         t0 = now_ms();
-        double* cnt;
-        PL_TRY(pl_buf(ctx, "mic_counter", 64, &cnt, false));
-        PL_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
-        PlGatherArgs ga{};
-        ga.n = n; ga.tz = S->tz; ga.tx = S->tx; ga.nf = 1; ga.method = PL_INTERP_LINEAR;
-        ga.defval = std::numeric_limits<double>::quiet_NaN(); ga.accumulate = 0; ga.n_outside = (unsigned long long*)cnt;
-        ga.g.nz = nz; ga.g.nx = nx; ga.g.gz = S->gcoords; ga.g.gx = S->gcoords + nz;
-        ga.g.zmin = ctx->geom.zc[0]; ga.g.xmin = ctx->geom.xc[0];
-        ga.g.Lz = ctx->geom.zc[nz - 1] - ctx->geom.zc[0]; ga.g.Lx = ctx->geom.xc[nx - 1] - ctx->geom.xc[0];
-        ga.g.rect = ctx->geom.uniform ? 0 : 1;
-        ga.g.fast_uniform = ctx->geom.uniform ? 1 : 0;            // regular grid: k_gather<true> (no coordinate search, no divisions)
-        ga.g.pitch = g.pitch; ga.g.off = pl_idx(g, -g.gi0, -g.gj0);      // field indices are GLOBAL
-        if (it == 1 || !S->have_newtemp) {
-            ga.fields[0] = p_newT; ga.out[0] = S->f[TR_TMP];
-            pl_launch_gather(ctx, ga);
-        } else {
-            hipLaunchKernelGGL(k_plane_sub, grid2d(g), dim3(64, 4), 0, ctx->stream, g, p_newT, p_T, p_dT);
-            PL_TRY(pl_halo(ctx, g, p_dT, 1, g.plane));
-            S->have_dT = true;
-            const double inv2 = (2.0 / dx) * (2.0 / dx) + (2.0 / dz) * (2.0 / dz);
-            // regular grid: the two per-marker subgrid kernels ride in the gathers (the interpolated value never goes to memory:
-            // 152 -> 120 B per marker over the stage)
-            const bool fuse = ga.g.fast_uniform && !ga.g.rect;
-            ga.fields[0] = p_dT; ga.out[0] = S->tmp[0];
-            if (fuse) {
-                ga.epi = 1; ga.epi_subgrid = cfg->do_subgrid_heatdiff; ga.epi_T = S->f[TR_TMP]; ga.epi_hcp = S->f[TR_HCP];
-                ga.epi_rho = S->f[TR_RHO]; ga.epi_hcd = S->f[TR_HCD]; ga.epi_inv2 = inv2; ga.epi_dt = tstep;
-                ga.epi_Tsub = S->tmp[1]; ga.epi_dTs = S->tmp[2];
-            }
-            pl_launch_gather(ctx, ga);
-            if (!fuse)
-                hipLaunchKernelGGL(k_subgrid_part1, grid1d(n), dim3(256), 0, ctx->stream, n, S->f[TR_TMP], S->tmp[0], S->f[TR_HCP],
-                                   S->f[TR_RHO], S->f[TR_HCD], inv2, tstep, cfg->do_subgrid_heatdiff, S->tmp[1], S->tmp[2]);
-            if (cfg->do_subgrid_heatdiff) {
-                // T currently holds Told for the subgrid branch; dTs = tmp[2] -> nodes -> back to tracers
-                const int fs[1] = {-3}; const int ss[1] = {AW}; double* ps[1] = {p_sgc};
-                PL_TRY(scatter_to_planes(ctx, S, 1, fs, ss, z0, hz, x0, hx, ps));
-                ga.fields[0] = p_sgc; ga.out[0] = S->tmp[0];
-                if (fuse) ga.epi = 2;
-                pl_launch_gather(ctx, ga);
-                if (!fuse) hipLaunchKernelGGL(k_subgrid_part2, grid1d(n), dim3(256), 0, ctx->stream, n, S->f[TR_TMP], S->tmp[1], S->tmp[0]);
-            }
-            ga.epi = 0;
-        }
-        unsigned long long nout = 0;
-        PL_HIP(ctx, hipMemcpyAsync(&nout, cnt, sizeof(nout), hipMemcpyDeviceToHost, ctx->stream));
-        PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        { double v[1] = {(double)nout}; PL_TRY(pl_allreduce_host(ctx, v, 1, 0)); nout = (unsigned long long)v[0]; }
-        if (nout > 0) return pl_fail(ctx, "stopOnError in grid2trac");        // pylamp2.py:445,453 stopOnError=True
+        PL_TRY(stage_temp_to_tracers(ctx, S, cfg, it == 1 || !S->have_newtemp, P, tstep));
         S->have_newtemp = true;
         rep->ms_gather = now_ms() - t0;
     }
@@ -1212,38 +1375,7 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
                            (cfg->bcstokes[0] & PL_BC_FREESLIP) ? 1 : 0, (cfg->bcstokes[1] & PL_BC_FREESLIP) ? 1 : 0,
                            (cfg->bcstokes[2] & PL_BC_FREESLIP) ? 1 : 0, (cfg->bcstokes[3] & PL_BC_FREESLIP) ? 1 : 0, I0, J0, nVr, nVc, V, V + VN);
     }
-    PlRk4Args ra{};
-    ra.n = n; ra.tz = S->tz; ra.tx = S->tx;
-    ra.g.nz = nz + 1; ra.g.nx = nx + 1; ra.g.gz = S->gcoords + nz + nx; ra.g.gx = S->gcoords + nz + nx + (nz + 1);
-    {
-        const double gz0 = S->gmz[0] - (S->gmz[1] - S->gmz[0]), gx0 = S->gmx[0] - (S->gmx[1] - S->gmx[0]);
-        ra.g.zmin = gz0; ra.g.xmin = gx0; ra.g.Lz = S->gmz[nz - 1] - gz0; ra.g.Lx = S->gmx[nx - 1] - gx0;
-    }
-    ra.g.rect = ctx->geom.uniform ? 0 : 1;
-    ra.g.fast_uniform = ctx->geom.uniform ? 1 : 0; ra.g.hx_over_hz = hx / hz; ra.g.hz_over_hx = hz / hx;
-    ra.g.pitch = nVc; ra.g.off = -((long long)I0 * nVc + J0);      // cell indices are GLOBAL
-    ra.g.ie_lo = I0; ra.g.ie_hi = I1 - 1; ra.g.je_lo = J0; ra.g.je_hi = J1 - 1;      // cells held locally
-    ra.Vz = V; ra.Vx = V + VN; ra.dt = tstep;
-    ra.tz_out = S->tz2; ra.tx_out = S->tx2; ra.vz_out = S->vtz; ra.vx_out = S->vtx;
-    ra.fence = cfg->tracs_fence_disabled ? 0 : 1; ra.eps = PL_EPS; ra.Lz = Lz; ra.Lx = Lx;
-    double* oowc = nullptr;
-    if (ctx->nranks > 1) {
-        PL_TRY(pl_buf(ctx, "rk4_counter", 64, &oowc, false));
-        PL_HIP(ctx, hipMemsetAsync(oowc, 0, 64, ctx->stream));
-        ra.n_outside_window = (unsigned long long*)oowc;
-    }
-    pl_launch_rk4(ctx, ra);
-    PL_HIP(ctx, hipGetLastError());
-    std::swap(S->tz, S->tz2); std::swap(S->tx, S->tx2);
-    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->nranks > 1) {      // collective: a stage that left the local velocity window means the step was not CFL-limited
-        unsigned long long no = 0;
-        PL_HIP(ctx, hipMemcpy(&no, oowc, sizeof(no), hipMemcpyDeviceToHost));
-        double v[1] = {(double)no};
-        PL_TRY(pl_allreduce_host(ctx, v, 1, 0));
-        if (v[0] > 0) return pl_fail(ctx, "pl_step: a tracer moved by more than one cell in an RK4 stage (time step not CFL-limited); the "
-                                          "block decomposition holds the advection velocity one cell around each block only");
-    }
+    PL_TRY(stage_rk4(ctx, S, V, I0, I1, J0, J1, tstep, cfg->tracs_fence_disabled ? 0 : 1, Lz, Lx));
     rep->ms_advect = now_ms() - t0;
 
     // ---- 7. cell sort of the advected tracers, slab migration, census + injection --------------------
@@ -1263,6 +1395,62 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
     rep->ms_sort = now_ms() - t0;
     rep->ntrac = S->n;
     rep->ms_total = now_ms() - t_all;
+    return 0;
+}
+
+// ---- the marker stages one at a time (tests pin the kernels the timed step launches against the reference's fixtures) -----
+static int resident_ready(pl_ctx* ctx, PlStepState* S, const char* who) {
+    if (ctx->nranks != 1) return pl_fail(ctx, std::string(who) + ": single-rank entry point (several ranks run pl_step)");
+    if (!S->cell_start || !S->sorted) return pl_fail(ctx, std::string(who) + ": no cell-sorted tracers resident (call pl_tracers_upload)");
+    return 0;
+}
+
+extern "C" int pl_resident_scatter(pl_ctx* ctx, const pl_step_config* cfg, int it) {
+    if (!cfg) return pl_fail(ctx, "pl_resident_scatter: NULL argument");
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    PlStepState* S = state_of(ctx);
+    PL_TRY(resident_ready(ctx, S, "pl_resident_scatter"));
+    PL_TRY(ensure_coords(ctx, S));
+    StepPlanes P;
+    PL_TRY(step_planes(ctx, P));
+    PL_TRY(stage_props(ctx, S, cfg));
+    PL_TRY(stage_scatter(ctx, S, cfg, it, P));
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int pl_resident_temp_to_tracers(pl_ctx* ctx, const pl_step_config* cfg, int first, const double* newtemp, double tstep) {
+    if (!cfg || !newtemp) return pl_fail(ctx, "pl_resident_temp_to_tracers: NULL argument");
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    PlStepState* S = state_of(ctx);
+    PL_TRY(resident_ready(ctx, S, "pl_resident_temp_to_tracers"));
+    PL_TRY(ensure_coords(ctx, S));
+    StepPlanes P;
+    PL_TRY(step_planes(ctx, P));
+    PL_TRY(pl_plane_upload(ctx, ctx->geom.d, newtemp, P.newT));
+    PL_TRY(stage_temp_to_tracers(ctx, S, cfg, first != 0, P, tstep));
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int pl_resident_rk4(pl_ctx* ctx, const double* vz_pad, const double* vx_pad, double tstep, int fence, const double length[2]) {
+    if (!vz_pad || !vx_pad || !length) return pl_fail(ctx, "pl_resident_rk4: NULL argument");
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    PlStepState* S = state_of(ctx);
+    PL_TRY(resident_ready(ctx, S, "pl_resident_rk4"));
+    PL_TRY(ensure_coords(ctx, S));
+    const int nz = ctx->nz, nx = ctx->nx;
+    const size_t VN = (size_t)(nz + 1) * (nx + 1);
+    double* V;
+    PL_TRY(pl_buf(ctx, "advect_vel", 2 * VN * sizeof(double), &V, false));
+    PL_HIP(ctx, hipMemcpyAsync(V, vz_pad, VN * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PL_HIP(ctx, hipMemcpyAsync(V + VN, vx_pad, VN * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PL_TRY(stage_rk4(ctx, S, V, 0, nz, 0, nx, tstep, fence ? 1 : 0, length[0], length[1]));
+    S->sorted = false;
+    const StepGrid q = step_grid(ctx);
+    PL_TRY(sort_tracers(ctx, S, q.z0, q.hz, q.x0, q.hx));
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    S->sorted = true;
     return 0;
 }
 

@@ -15,125 +15,6 @@
 
 #define TB(tab, k) (tab)[(k) + PL_TOFF]
 
-// One thread per node, 64 x 4 thread blocks: each wave owns 64 consecutive columns of ONE
-// row, so every z-table value is wave-uniform (scalar loads) and all plane accesses are
-// 512-B contiguous per wave-instruction; the +-1 column / +-pitch row neighbours are
-// re-reads of lines the same or the adjacent wave just touched (L1/L2 hits).
-__device__ inline void stokes_apply_node(const PlStokesOp& op, const double* __restrict__ x, double* __restrict__ y,
-                                         int li, int lj) {
-    const PlGeom& g = op.g;
-    const int i = g.gi0 + li, j = g.gj0 + lj;
-    const int nz = g.nz, nx = g.nx;
-    const int p = g.pitch;
-    // 32-bit element offsets from wave-uniform base pointers: lets the compiler use the
-    // SGPR-base + VGPR-offset addressing mode instead of a 64-bit address per neighbour
-    const int c = (li + PL_RING) * p + (lj + PL_PADL);
-    const double* __restrict__ vz = x;
-    const double* __restrict__ vx = x + g.plane;
-    const double* __restrict__ P = x + 2 * g.plane;
-    const double* __restrict__ es = op.etas;
-    const double* __restrict__ en = op.etan;
-    const double Kc = op.Kc;
-    const double vz_c = vz[c], vx_c = vx[c], p_c = P[c];
-
-    // row scale factors D_r (used only when op.scaled): 1/(sum of the 4 own-component
-    // coefficients) on interior momentum rows, 1/Kc on constraint rows, 1/(Kc (1/dx+1/dz)) on
-    // continuity rows, 1/Kb on corner rows.  No extra memory traffic.
-    const double iKc = 1.0 / Kc;
-    double sz = iKc, sx = iKc, sp = iKc;
-
-    // ---------------- vz row (z-momentum) ----------------
-    double yz;
-    if (j == nx - 1 || i == 0 || i == nz - 1) {
-        yz = Kc * vz_c;                                   // ghost column / no flow through z-walls
-    } else if (j == 0) {
-        yz = Kc * (vz_c - vz[c + 1]);                     // free slip at x = 0  (pylamp_stokes.py:249-255)
-    } else if (j == nx - 2) {
-        yz = Kc * (vz_c - vz[c - 1]);                     // free slip at x = Lx (pylamp_stokes.py:296-301)
-    } else {
-        const double rdz_i = TB(g.rdz, i), rdz_m = TB(g.rdz, i - 1), rDz_i = TB(g.rDz, i);
-        const double rdx_j = TB(g.rdx, j), rDx_j = TB(g.rDx, j), rDx_p = TB(g.rDx, j + 1);
-        const double esC = es[c], esE = es[c + 1];
-        const double cN = 4.0 * en[c] * rdz_i * rDz_i;
-        const double cS = 4.0 * en[c - p] * rdz_m * rDz_i;
-        const double cE = 2.0 * esE * rDx_p * rdx_j;
-        const double cW = 2.0 * esC * rDx_j * rdx_j;
-        const double xE = 2.0 * esE * rDz_i * rdx_j;
-        const double xW = 2.0 * esC * rDz_i * rdx_j;
-        yz = cN * (vz[c + p] - vz_c) - cS * (vz_c - vz[c - p]) + cE * (vz[c + 1] - vz_c) -
-             cW * (vz_c - vz[c - 1]) + xE * (vx[c + 1] - vx[c - p + 1]) - xW * (vx_c - vx[c - p]) -
-             2.0 * Kc * rDz_i * (p_c - P[c - p]);
-        sz = 1.0 / (cN + cS + cE + cW);
-        if (op.surfstab) {
-            const double* __restrict__ r = op.rho;
-            yz += op.ss * op.gz * 0.5 *
-                  ((r[c + 1] + r[c + p + 1] - r[c - 1] - r[c + p - 1]) * rDx_j * vx_c +
-                   (r[c + p] + r[c + p + 1] - r[c - p] - r[c - p + 1]) * rDz_i * vz_c);
-        }
-    }
-    y[c] = op.scaled ? yz * sz : yz;            // each row is stored as soon as it is complete;
-    __builtin_amdgcn_sched_barrier(0);          // the fence keeps the next row's loads from being hoisted
-                                                // above it (110 -> fewer VGPRs, more waves per SIMD)
-
-    // ---------------- vx row (x-momentum) ----------------
-    double yx;
-    if (i == nz - 1 || j == 0 || j == nx - 1) {
-        yx = Kc * vx_c;                                   // ghost row / no flow through x-walls
-    } else if (i == 0) {
-        if (op.bc_z0 == PL_BC_FREESLIP) yx = Kc * (vx_c - vx[c + p]);
-        else yx = Kc * ((-TB(g.rDz, 1) - TB(g.rdz, 0)) * vx_c + TB(g.rDz, 1) * vx[c + p]);
-    } else if (i == nz - 2) {
-        if (op.bc_zL == PL_BC_FREESLIP) yx = Kc * (vx_c - vx[c - p]);
-        else yx = Kc * ((TB(g.rDz, nz - 2) + TB(g.rdz, nz - 2)) * vx_c - TB(g.rDz, nz - 2) * vx[c - p]);
-    } else {
-        const double rdx_j = TB(g.rdx, j), rdx_m = TB(g.rdx, j - 1), rDx_j = TB(g.rDx, j);
-        const double rdz_i = TB(g.rdz, i), rDz_i = TB(g.rDz, i), rDz_p = TB(g.rDz, i + 1);
-        const double esC = es[c], esN = es[c + p];
-        const double cE = 4.0 * en[c] * rdx_j * rDx_j;
-        const double cW = 4.0 * en[c - 1] * rdx_m * rDx_j;
-        const double cN = 2.0 * esN * rDz_p * rdz_i;
-        const double cS = 2.0 * esC * rDz_i * rdz_i;
-        const double zN = 2.0 * esN * rDx_j * rdz_i;
-        const double zS = 2.0 * esC * rDx_j * rdz_i;
-        yx = cE * (vx[c + 1] - vx_c) - cW * (vx_c - vx[c - 1]) + cN * (vx[c + p] - vx_c) -
-             cS * (vx_c - vx[c - p]) + zN * (vz[c + p] - vz[c + p - 1]) - zS * (vz_c - vz[c - 1]) -
-             2.0 * Kc * rDx_j * (p_c - P[c - 1]);
-        sx = 1.0 / (cE + cW + cN + cS);
-        if (op.surfstab && op.gx != 0.0) {
-            const double* __restrict__ r = op.rho;
-            yx += op.ss * op.gx * 0.5 *
-                  ((r[c + 1] + r[c + p + 1] - r[c - 1] - r[c + p - 1]) * rDx_j * vx_c +
-                   (r[c + p] + r[c + p + 1] - r[c - p] - r[c - p + 1]) * rDz_i * vz_c);
-        }
-    }
-    y[c + g.plane] = op.scaled ? yx * sx : yx;
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---------------- P row (continuity) ----------------
-    double yp;
-    if (i == nz - 1 || j == nx - 1 || (i == op.anchor_i && j == op.anchor_j)) {
-        yp = Kc * p_c;                                    // ghosts, pressure anchor
-    } else if ((i == 0 || i == nz - 2) && j == 0) {
-        yp = op.Kb * (P[c + 1] - p_c);                    // corner symmetry (pylamp_stokes.py:358-369)
-        sp = 1.0 / op.Kb;
-    } else if ((i == 0 || i == nz - 2) && j == nx - 2) {
-        yp = op.Kb * (P[c - 1] - p_c);
-        sp = 1.0 / op.Kb;
-    } else {
-        yp = Kc * ((vx[c + 1] - vx_c) * TB(g.rdx, j) + (vz[c + p] - vz_c) * TB(g.rdz, i));
-        sp = 1.0 / (Kc * (TB(g.rdx, j) + TB(g.rdz, i)));
-    }
-    y[c + 2 * g.plane] = op.scaled ? yp * sp : yp;
-}
-
-#ifndef PL_APPLY_WAVES
-#define PL_APPLY_WAVES 4
-#endif
-__global__ __launch_bounds__(256, PL_APPLY_WAVES) void k_stokes_apply(PlStokesOp op, const double* __restrict__ x,
-                                                                      double* __restrict__ y, int iters) {
-    PL_ROW_LOOP(op.g, iters) stokes_apply_node(op, x, y, li, lj);
-}
-
 // ---------------------------------------------------------------------------------------------------
 // Two-columns-per-lane variant: every plane row is read with 16-byte (double2) loads, the j-1 / j+1
 // neighbours come from the adjacent lanes (ds_bpermute), only the two edge lanes issue an extra
@@ -352,9 +233,10 @@ void pl_launch_stokes_apply(pl_ctx* ctx, const PlStokesOp& op, const double* x, 
     // operator 76 us, factored coefficients 73 us, branch-free interior path 64 us.  Sharing the rows of a
     // 4- or 8-row tile through LDS (5 instead of 12 global row loads per wave) is SLOWER (68 us): the L1 re-reads
     // were never the limit, the barrier is one.
-    // PYLAMP_VV_VEC=0 selects the scalar one-column-per-lane kernel (cross-check of the vectorised one, like the multigrid kernels)
-    static const bool vec = [] { const char* e = getenv("PYLAMP_VV_VEC"); return !(e && e[0] == '0'); }();
-    if (vec && (op.g.plane % 2) == 0 && !(op.g.gj0 & 1)) {     // double2 accesses need even plane strides (pitch is a multiple of 16) and an even first column
+    // (The scalar one-column-per-lane kernel of round 1 is gone: the vectorised one is pinned directly against the reference's
+    // explicit matrices on five grids, tests/test_hip_parity.py.)  double2 accesses need even plane strides and an even first
+    // column: the pitch is a multiple of 16 and block columns start at even multiples (pl_set_comm_2d enforces even block widths).
+    {
         const int gx = (op.g.lnx + 127) / 128;
 #define PL_APPLY_LAUNCH(KERNEL, ROWS)                                                                                   \
         do {                                                                                                            \
@@ -368,9 +250,7 @@ void pl_launch_stokes_apply(pl_ctx* ctx, const PlStokesOp& op, const double* x, 
         else if (rows == 2) PL_APPLY_LAUNCH(k_stokes_apply_v2, 2);
         else PL_APPLY_LAUNCH(k_stokes_apply_v2, 4);
 #undef PL_APPLY_LAUNCH
-        return;
     }
-    hipLaunchKernelGGL(k_stokes_apply, pl_grid_rows(op.g), dim3(64, 4), 0, ctx->stream, op, x, y, pl_row_iters(op.g));
 }
 
 void pl_launch_stokes_rhs(pl_ctx* ctx, const PlStokesOp& op, double* rhs) {

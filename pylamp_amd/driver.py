@@ -227,6 +227,36 @@ class Simulation:
         self.last = out
         return out
 
+    # -- the marker stages of a step one at a time (same kernels as step(); parity tests) ------------
+    def scatter_fields(self, it=1):
+        """Stages 1 + 2 of the step (properties, tracer -> grid: pylamp2.py:291-319) on the resident tracers;
+        returns the grid fields the stage produces."""
+        cfg = self._config()
+        self.ctx.check(self.ctx.lib.pl_resident_scatter(self.ctx.handle(), C.byref(cfg), int(it)))
+        names = ["rho", "etas", "etan"] + (["cp", "f_T", "H", "mat", "kz", "kx"] if self.opt.do_heatdiff else [])
+        return {k: self.field(k) for k in names}
+
+    def temp_to_tracers(self, newtemp, tstep, first=False):
+        """Stage 5b of the step (pylamp2.py:436-480): new nodal temperature -> tracers (+ subgrid diffusion); the old nodal
+        temperature is the f_T of the last scatter_fields().  Returns the tracers' temperature column (upload order)."""
+        cfg = self._config()
+        nt = _lib.f64(newtemp)
+        if nt.shape != tuple(self.nx):
+            raise Exception("temp_to_tracers: newtemp must be (nz, nx)")
+        self.ctx.check(self.ctx.lib.pl_resident_temp_to_tracers(self.ctx.handle(), C.byref(cfg), int(bool(first)), _lib.dptr(nt), float(tstep)))
+        return self.tracers()[1][:, TR_TMP]
+
+    def advect(self, vz_pad, vx_pad, tstep, fence=None):
+        """Stage 6b of the step: RK4 through velocities on the padded (nz+1, nx+1) centre grid (pylamp2.py:547-572),
+        then the end-of-step sort.  Returns (tracer velocities, new positions) in upload order, like pylamp_trac.RK."""
+        vz = _lib.f64(vz_pad); vx = _lib.f64(vx_pad)
+        if vz.shape != (self.nx[0] + 1, self.nx[1] + 1) or vx.shape != vz.shape:
+            raise Exception("advect: velocities must be (nz+1, nx+1)")
+        fence = self.opt.tracs_fence_enabled if fence is None else fence
+        Lc = (C.c_double * 2)(*self.L)
+        self.ctx.check(self.ctx.lib.pl_resident_rk4(self.ctx.handle(), _lib.dptr(vz), _lib.dptr(vx), float(tstep), int(bool(fence)), Lc))
+        return self.tracer_velocity(), self.tracers()[0]
+
     # -- snapshot writer (pylamp2.py:637-650) ----------------------------------------------------------
     def write_snapshot(self, outdir="out"):
         """Collective under several ranks: fields and tracers are gathered, rank 0 writes the two files."""

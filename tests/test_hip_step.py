@@ -352,7 +352,7 @@ def test_step_with_unreachable_nodes_fails_loudly():
     sim.close()
 
 
-def test_pressure_anchor_deflation_same_fields_fewer_iterations():
+def test_pressure_anchor_deflation_same_fields_fewer_iterations(tmp_path):
     """The rank-1 deflation of the pressure-anchor mode in the Stokes preconditioner changes the
     iteration count, not the answer: two resident runs of the mantle model at 257 x 257, with and without it
     (PYLAMP_DEFLATE is read when a context's solver is created, hence the subprocesses)."""
@@ -374,8 +374,7 @@ print("RESULT", json.dumps(dict(its=its, est=rep["stokes"]["error_estimate"])))
 ''' % root
     out = {}
     for name, env in (("deflated", {}), ("plain", {"PYLAMP_DEFLATE": "0"})):
-        path = os.path.join(root, "gpurun_out", "defl_%s.npy" % name)
-        os.makedirs(os.path.dirname(path), exist_ok=True)
+        path = str(tmp_path / ("defl_%s.npy" % name))
         r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
         assert r.returncode == 0, (name, r.stderr[-1500:])
         line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0]
@@ -388,7 +387,7 @@ print("RESULT", json.dumps(dict(its=its, est=rep["stokes"]["error_estimate"])))
     assert sd["est"] <= 3e-8 and sp["est"] <= 3e-8
 
 
-def test_warm_starts_same_fields_fewer_iterations():
+def test_warm_starts_same_fields_fewer_iterations(tmp_path):
     """The initial guesses of the time-step loop -- Stokes: quadratic extrapolation in model time of the last three solutions with
     the initial residual as BiCGStab's shadow vector; heat: old nodal temperature + scaled last increment --
     change the iteration counts, not the answer: two resident runs of the mantle model at 257 x 257, with and without them
@@ -413,8 +412,7 @@ print("RESULT", json.dumps(dict(its=its, hits=hits, est=rep["stokes"]["error_est
     out = {}
     off = {"PYLAMP_X0_EXTRAP": "0", "PYLAMP_HEAT_X0": "0", "PYLAMP_SHADOW": "0"}
     for name, env in (("warm", {}), ("plain", off)):
-        path = os.path.join(root, "gpurun_out", "warm_%s.npy" % name)
-        os.makedirs(os.path.dirname(path), exist_ok=True)
+        path = str(tmp_path / ("warm_%s.npy" % name))
         r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
         assert r.returncode == 0, (name, r.stderr[-1500:])
         line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0]
