@@ -30,6 +30,9 @@
 #define SC_CAP 320                  // tracers staged per window (a strip row with more is processed in several windows)
 #endif
 #define SC_CAPP (SC_CAP + SC_CAP / 16 + 2)
+#ifndef SC_NB
+#define SC_NB 2                     // staging batches per window
+#endif
 
 __device__ inline int sc_pidx(int o) { return o + (o >> 4); }       // one pad slot per 16 tracers: lanes of neighbouring cells hit different banks
 
@@ -103,16 +106,39 @@ __global__ __launch_bounds__(64) void k_scatter_cells(PlScatterCellsArgs a, int 
         csl[r][c] = a.cell_start[(long long)(i0 + r) * a.ncx + col];
     }
     const double xc = a.x0 + gj * a.hx;                        // origin of my cell column
-    // carries between rows (see the header): node-like rows one, shifted rows two
-    double cN[1 + NFN]; double cX[2]; double qZ[2], pZ[2], qC[2], pC[2];
-#pragma unroll
-    for (int k = 0; k <= NFN; k++) cN[k] = 0.0;
-    cX[0] = cX[1] = qZ[0] = qZ[1] = pZ[0] = pZ[1] = qC[0] = qC[1] = pC[0] = pC[1] = 0.0;
+    // carries between rows (see the header): node-like rows one, shifted rows two.  They live in LDS (the q = 0 lane of a
+    // column owns its 17 slots): 34 VGPRs less across the tracer loop, where the 70 accumulators and the staging registers
+    // already decide the occupancy
+    __shared__ double car[NFN + 11][SC_NL];
+    double* const cN = &car[0][L];                  // cN[k] -> car[k][L], stride SC_NL
+    double* const cX = &car[NFN + 1][L]; double* const qZ = &car[NFN + 3][L]; double* const pZ = &car[NFN + 5][L];
+    double* const qC = &car[NFN + 7][L]; double* const pC = &car[NFN + 9][L];
+    if (q == 0)
+        for (int k = 0; k < NFN + 11; k++) car[k][L] = 0.0;
     auto emit = [&](double* plane, int gi_row, double v) {
         if (!col_own || gi_row < R0 || gi_row >= R1 || gi_row < 0 || gi_row >= a.nz || gi_row < a.row0 || gi_row >= a.row0 + a.nrows) return;
         plane[(long long)(gi_row - a.row0) * a.ncols + (gj - a.col0)] = v;
     };
     __syncthreads();
+    // Software pipeline: the first window of the NEXT row is loaded into registers while the tracers of the current row are
+    // summed (one or two waves per SIMD cannot hide the load latency by themselves: without this the kernel took the SUM of its
+    // memory time and its arithmetic time)
+    constexpr int NU = SC_CAP / 64;
+    double pf[NU][NST];
+    auto prefetch = [&](int row) {
+        const int b0 = csl[row - i0][0], b1 = min(b0 + SC_CAP, csl[row - i0][SC_NL]);
+#pragma unroll
+        for (int u = 0; u < NU; u++) {
+            const int t = b0 + lane + 64 * u;
+            if (t < b1) {
+                pf[u][0] = a.tz[t]; pf[u][1] = a.tx[t];
+#pragma unroll
+                for (int k = 0; k < NFN; k++) pf[u][2 + k] = a.fn[k][t];
+                if (MID) pf[u][2 + NFN] = a.fm[t];
+            }
+        }
+    };
+    if (i0 < i1 && !(a.dbg & 8)) prefetch(i0);
     for (int i = i0; i < i1; i++) {
         const int gi = a.crow0 + i;
         const double zc = a.z0 + gi * a.hz;                    // origin of this cell row
@@ -138,33 +164,50 @@ __global__ __launch_bounds__(64) void k_scatter_cells(PlScatterCellsArgs a, int 
 #pragma unroll
                 for (int v = 0; v < 2; v++) { A.Z[u][v][0] = 0.0; A.Z[u][v][1] = 0.0; A.X[v][u][0] = 0.0; A.X[v][u][1] = 0.0; }
         }
-        for (int wb = wrow0; wb < wrow1; wb += SC_CAP) {
-            const int we = min(wb + SC_CAP, wrow1);
-            if (wb != wrow0) __syncthreads();                  // the previous window has been consumed
-            if (!(a.dbg & 8)) {   // stage: coalesced, ALL loads of the window in flight before the first LDS write (a rolled loop waits for
-                // every trip's loads: 4 dependent memory latencies per row)
-                double st[SC_CAP / 64][NST];
+        if (!(a.dbg & 8)) {                                    // first window: what was prefetched during the previous row
+            const int we0 = min(wrow0 + SC_CAP, wrow1);
 #pragma unroll
-                for (int u = 0; u < SC_CAP / 64; u++) {
-                    const int t = wb + lane + 64 * u;
-                    if (t < we) {
-                        st[u][0] = a.tz[t]; st[u][1] = a.tx[t];
+            for (int u = 0; u < NU; u++) {
+                const int t = wrow0 + lane + 64 * u;
+                if (t < we0) {
+                    const int o = sc_pidx(t - wrow0);
 #pragma unroll
-                        for (int k = 0; k < NFN; k++) st[u][2 + k] = a.fn[k][t];
-                        if (MID) st[u][2 + NFN] = a.fm[t];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < SC_CAP / 64; u++) {
-                    const int t = wb + lane + 64 * u;
-                    if (t < we) {
-                        const int o = sc_pidx(t - wb);
-#pragma unroll
-                        for (int k = 0; k < NST; k++) lds[k][o] = st[u][k];
-                    }
+                    for (int k = 0; k < NST; k++) lds[k][o] = pf[u][k];
                 }
             }
-            __syncthreads();
+        }
+        __syncthreads();
+        if (i + 1 < i1 && !(a.dbg & 8)) prefetch(i + 1);
+        for (int wb = wrow0; wb < wrow1; wb += SC_CAP) {
+            const int we = min(wb + SC_CAP, wrow1);
+            if (wb != wrow0) {                                 // a row with more tracers than a window holds (rare): stage in line
+                __syncthreads();                               // the previous window has been consumed
+                constexpr int UB = (NU + SC_NB - 1) / SC_NB;
+#pragma unroll
+                for (int b = 0; b < SC_NB; b++) {
+                    double st[UB][NST];
+#pragma unroll
+                    for (int u = 0; u < UB; u++) {
+                        const int t = wb + lane + 64 * (b * UB + u);
+                        if (b * UB + u < NU && t < we) {
+                            st[u][0] = a.tz[t]; st[u][1] = a.tx[t];
+#pragma unroll
+                            for (int k = 0; k < NFN; k++) st[u][2 + k] = a.fn[k][t];
+                            if (MID) st[u][2 + NFN] = a.fm[t];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < UB; u++) {
+                        const int t = wb + lane + 64 * (b * UB + u);
+                        if (b * UB + u < NU && t < we) {
+                            const int o = sc_pidx(t - wb);
+#pragma unroll
+                            for (int k = 0; k < NST; k++) lds[k][o] = st[u][k];
+                        }
+                    }
+                }
+                __syncthreads();
+            }
             int t = s + q;
             if (t < wb) t += ((wb - t + SC_Q - 1) / SC_Q) * SC_Q;
             const int tend = min(e, we);
@@ -250,23 +293,23 @@ __global__ __launch_bounds__(64) void k_scatter_cells(PlScatterCellsArgs a, int 
         if (q == 0 && !(a.dbg & 4)) {
 #pragma unroll
             for (int k = 0; k <= NFN; k++) {
-                emit(a.accN + (long long)k * a.N, gi, Hn[0][k] + cN[k]);
-                cN[k] = Hn[1][k];
+                emit(a.accN + (long long)k * a.N, gi, Hn[0][k] + cN[k * SC_NL]);
+                cN[k * SC_NL] = Hn[1][k];
             }
             if (MID) {
 #pragma unroll
                 for (int k = 0; k < 2; k++) {
-                    emit(a.accX + (long long)k * a.N, gi, Hx[0][k] + cX[k]);
-                    cX[k] = Hx[1][k];
-                    emit(a.accZ + (long long)k * a.N, gi - 1, qZ[k] + Hz[0][k]);
-                    qZ[k] = Hz[1][k] + pZ[k]; pZ[k] = Hz[2][k];
+                    emit(a.accX + (long long)k * a.N, gi, Hx[0][k] + cX[k * SC_NL]);
+                    cX[k * SC_NL] = Hx[1][k];
+                    emit(a.accZ + (long long)k * a.N, gi - 1, qZ[k * SC_NL] + Hz[0][k]);
+                    qZ[k * SC_NL] = Hz[1][k] + pZ[k * SC_NL]; pZ[k * SC_NL] = Hz[2][k];
                 }
             }
             if (CEN) {
 #pragma unroll
                 for (int k = 0; k < 2; k++) {
-                    emit(a.accC + (long long)k * a.N, gi - 1, qC[k] + Hc[0][k]);
-                    qC[k] = Hc[1][k] + pC[k]; pC[k] = Hc[2][k];
+                    emit(a.accC + (long long)k * a.N, gi - 1, qC[k * SC_NL] + Hc[0][k]);
+                    qC[k * SC_NL] = Hc[1][k] + pC[k * SC_NL]; pC[k * SC_NL] = Hc[2][k];
                 }
             }
         }
@@ -275,20 +318,20 @@ __global__ __launch_bounds__(64) void k_scatter_cells(PlScatterCellsArgs a, int 
     if (q == 0 && i1 > i0 && !(a.dbg & 4)) {                   // below the last visited cell row (owned only where no cell row follows)
         const int gl = a.crow0 + i1;
 #pragma unroll
-        for (int k = 0; k <= NFN; k++) emit(a.accN + (long long)k * a.N, gl, cN[k]);
+        for (int k = 0; k <= NFN; k++) emit(a.accN + (long long)k * a.N, gl, cN[k * SC_NL]);
         if (MID) {
 #pragma unroll
             for (int k = 0; k < 2; k++) {
-                emit(a.accX + (long long)k * a.N, gl, cX[k]);
-                emit(a.accZ + (long long)k * a.N, gl - 1, qZ[k]);
-                emit(a.accZ + (long long)k * a.N, gl, pZ[k]);
+                emit(a.accX + (long long)k * a.N, gl, cX[k * SC_NL]);
+                emit(a.accZ + (long long)k * a.N, gl - 1, qZ[k * SC_NL]);
+                emit(a.accZ + (long long)k * a.N, gl, pZ[k * SC_NL]);
             }
         }
         if (CEN) {
 #pragma unroll
             for (int k = 0; k < 2; k++) {
-                emit(a.accC + (long long)k * a.N, gl - 1, qC[k]);
-                emit(a.accC + (long long)k * a.N, gl, pC[k]);
+                emit(a.accC + (long long)k * a.N, gl - 1, qC[k * SC_NL]);
+                emit(a.accC + (long long)k * a.N, gl, pC[k * SC_NL]);
             }
         }
     }
