@@ -1163,6 +1163,8 @@ struct PlSolver {
     double *wdefl = nullptr, *udefl = nullptr;
     double defl_yAw = 0.0, defl_wvel2 = 0.0;     // host copies: y.(A w) and ||w_vel||^2 (the anchor-mode term of the error estimate)
     double schur_scale = 1.0;    // S^ = schur_scale * Kc^2 / eta_n (PYLAMP_SCHUR_SCALE)
+    long long fused_max_nodes = 1100000;      // PYLAMP_MG_FUSED_MAX: largest level (nodes) that takes the tile kernels
+    bool fused = true;           // PYLAMP_MG_FUSED=0: every multigrid stage as a kernel of its own (the path the tile kernels are checked against)
     bool fuse_first = true;      // PYLAMP_FUSE_FIRST=0: the first sweep of level 0 as a pass of its own
     bool deep = true;            // PYLAMP_MG_DEEP=0: distributed levels exchange before every sweep instead of once per smoothing sequence
     int tail_nu_pre = -1, tail_nu_post = -1;        // smoothing sweeps on the replicated tail levels (-1: same as nu)
@@ -1206,6 +1208,8 @@ static PlSolver* solver_of(pl_ctx* ctx) {
         if (const char* e = getenv("PYLAMP_MG_FP32")) S->f32_enable = atoi(e) != 0;
         if (const char* e = getenv("PYLAMP_MG_FP32_NODES")) { long long v = atoll(e); if (v >= 1) S->f32_min_nodes = v; }
         if (const char* e = getenv("PYLAMP_FUSE_FIRST")) S->fuse_first = atoi(e) != 0;
+        if (const char* e = getenv("PYLAMP_MG_FUSED")) S->fused = atoi(e) != 0;
+        if (const char* e = getenv("PYLAMP_MG_FUSED_MAX")) { long long v = atoll(e); if (v > 0) S->fused_max_nodes = v; }
         if (const char* e = getenv("PYLAMP_SCHUR_SCALE")) { double v = atof(e); if (v > 0.0) S->schur_scale = v; }
         if (const char* e = getenv("PYLAMP_MG_TAIL_NU")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a + b > 0) { S->tail_nu_pre = a; S->tail_nu_post = b; } }
         if (const char* e = getenv("PYLAMP_MG_RATIO")) { double v = atof(e); if (v > 1.5) { S->cheb_ratio = v; S->ratio_knob = true; } }
@@ -1790,6 +1794,9 @@ static bool level_deep_plan(const PlSolver* S, const MgLevel* L, size_t l, int& 
 // parameter: the FP32 levels are a prefix of the hierarchy, an FP32 level may sit above an FP64 one, never below.
 template <typename T> static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const T* f, T** out, bool* wrote_final, double* final_out,
                                          double final_scale, int f_valid_depth, const int* first_done_anchor);
+static bool mg_fused_level_ok(pl_ctx* ctx, const PlSolver* S, size_t l);
+static void vcycle_fused_level(pl_ctx* ctx, PlSolver* S, size_t l, const double* f, double** out, double* final_out, double final_scale,
+                               const PlStokesOp* sop, const double* rs, double* z);
 
 template <typename T, typename TC>
 static void coarse_correction(pl_ctx* ctx, PlSolver* S, size_t l, MgLevel* L, MgLevel* C, T* buf[3], bool deep, int npost, int hp) {
@@ -1879,6 +1886,12 @@ static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const T* f, T** out, bool
             return;
         }
     }
+    if constexpr (std::is_same<T, double>::value) {
+        if (l > 0 && !final_out && f == L->f && mg_fused_level_ok(ctx, S, l)) {       // the tile kernels (level 0: stokes_precond_t)
+            vcycle_fused_level(ctx, S, l, f, out, nullptr, 1.0, nullptr, nullptr, nullptr);
+            return;
+        }
+    }
     T** lv = LevelT<T>::v(L);
     T* buf[3] = {lv[0], lv[1], lv[2]};
     const bool coarsest = l + 1 == S->levels.size();
@@ -1934,6 +1947,401 @@ static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const T* f, T** out, bool
     if (deep) *wrote_final = smooth<T>(ctx, L, buf, f, npost, S->cheb_ratio, final_out, final_scale, false, hp, true, npost - 1);
     else *wrote_final = smooth<T>(ctx, L, buf, f, npost, S->cheb_ratio, final_out, final_scale, false, hp, pe == 1);
     *out = buf[0];
+}
+
+// =========================================================================================
+// Fused multigrid level kernels ("tile kernels"): one launch for everything a level does on the way down, one for the way up.
+//
+// A V-cycle visit of a level used to be 10 dependent launches (first sweep, sweeps, residual, restriction ... prolongation,
+// sweeps), each at least the 4.5-6 us a dependent kernel costs on this GPU: at 2049^2 the levels 513^2 ... 65^2 were pure latency
+// with the GPU idle (~27 % of a preconditioner application), and the two large levels moved every vector through HBM once per
+// sweep.  Here a workgroup owns a tile of MGT_TS x MGT_TS nodes, loads the tile plus a halo into LDS once and runs the whole
+// sequence there, each stage on a region one node smaller than the one before (temporal blocking: the halo is recomputed instead
+// of exchanged):
+//     k_mg_pre :  [level 0: stage 1 of the block preconditioner -- S^-1 r_p, f = r_v - A_vp z_p --] first sweep from the zero
+//                 guess, NS - 1 Chebyshev sweeps, residual, full-weighting restriction  ->  iterate (this level), rhs (coarse level)
+//     k_mg_post:  prolongation + correction, NS Chebyshev sweeps                        ->  iterate (this level, or z on level 0)
+// LDS-resident data: three rotating iterates, the right-hand side, the two viscosity planes, the reciprocal-spacing tables of
+// the region (so rectilinear grids work), all in named __shared__ arrays (ds_read / ds_write; the earlier attempt that called the
+// generic node functions through flat pointers gained nothing).  Row classes (wall, slaved, interior) are
+// decided per node from the global index exactly as the one-kernel-per-stage path does, and a slaved node evaluates its
+// master's update -- so both paths compute the same numbers (tests/test_hip_solve.py::test_fused_levels_match_the_staged_path).
+// Requirements (vcycle_fused_ok): one rank, FP64 level, no stabilisation terms, 1 <= sweeps <= 3; otherwise the staged path runs.
+// =========================================================================================
+#define MGT_TS 16
+#ifndef MGT_NT
+#define MGT_NT 1024
+#endif
+struct MgTileArgs {
+    PlVvOp op;                         // this (fine) level
+    PlVvOp opc;                        // the coarse level: geometry and row classes
+    const double* f; double* fout;     // right-hand side of this level: read (levels >= 1) | written (level 0: computed from rs)
+    double* v;                         // pre: iterate after the pre-smoothing sequence (written); post: the same (read)
+    double* fc;                        // pre: right-hand side of the coarse level (written)
+    const double* ec;                  // post: coarse correction
+    double* out; double oscale; long long out_plane;      // post: result, two planes out_plane doubles apart
+    double c1[4], c2[4];               // Chebyshev coefficients of the sweeps of the sequence
+    PlStokesOp sop; const double* rs; double* z;           // level 0 pre: the preconditioner's stage 1
+    int tiles_x;
+};
+
+struct MgtTab { const double* es; const double* en; const double* rdz; const double* rDz; const double* rdx; const double* rDx; };
+
+// row classes as vv_cls_z / vv_cls_x; a node outside the grid (tile halo beyond the walls) is a zero row
+__device__ inline int mgt_cls_z(const PlVvOp& op, int i, int j, int& db, double& s) {
+    db = 0; s = 1.0;
+    if (i <= 0 || i >= op.g.nz - 1 || j < 0 || j >= op.g.nx - 1) return VV_ZERO;
+    if (op.slave_x) {
+        if (j == 0) { db = 1; return VV_SLAVE; }
+        if (j == op.g.nx - 2) { db = -1; return VV_SLAVE; }
+    }
+    return VV_INT;
+}
+__device__ inline int mgt_cls_x(const PlVvOp& op, int i, int j, int& da, double& s) {
+    da = 0; s = 1.0;
+    if (j <= 0 || j >= op.g.nx - 1 || i < 0 || i >= op.g.nz - 1) return VV_ZERO;
+    if (i == 0 && op.slave_z0) { da = 1; s = op.s0; return VV_SLAVE; }
+    if (i == op.g.nz - 2 && op.slave_zL) { da = -1; s = op.sL; return VV_SLAVE; }
+    return VV_INT;
+}
+// (A_vv v)_z, (A_vv v)_x and -diagonal at region node (a, b) = LDS index c (row pitch CR): vv_row_z / vv_row_x on LDS arrays.
+// The tables are stored shifted by one: rdz[a + 1] belongs to region row a.
+template <int CR, bool NEED_A>
+__device__ inline void mgt_row_z(const MgtTab& t, const double* vz, const double* vx, int c, int a, int b, double& Av, double& dg) {
+    const double rdz_i = t.rdz[a + 1], rdz_m = t.rdz[a], rDz_i = t.rDz[a + 1];
+    const double rdx_j = t.rdx[b + 1], rDx_j = t.rDx[b + 1], rDx_p = t.rDx[b + 2];
+    const double esC = t.es[c], esE = t.es[c + 1];
+    const double cN = 4.0 * t.en[c] * rdz_i * rDz_i, cS = 4.0 * t.en[c - CR] * rdz_m * rDz_i;
+    const double cE = 2.0 * esE * rDx_p * rdx_j, cW = 2.0 * esC * rDx_j * rdx_j;
+    dg = cN + cS + cE + cW;
+    if (NEED_A) {
+        const double xE = 2.0 * esE * rDz_i * rdx_j, xW = 2.0 * esC * rDz_i * rdx_j;
+        const double v0 = vz[c];
+        Av = cN * (vz[c + CR] - v0) - cS * (v0 - vz[c - CR]) + cE * (vz[c + 1] - v0) - cW * (v0 - vz[c - 1]) +
+             xE * (vx[c + 1] - vx[c - CR + 1]) - xW * (vx[c] - vx[c - CR]);
+    }
+}
+template <int CR, bool NEED_A>
+__device__ inline void mgt_row_x(const MgtTab& t, const double* vz, const double* vx, int c, int a, int b, double& Av, double& dg) {
+    const double rdx_j = t.rdx[b + 1], rdx_m = t.rdx[b], rDx_j = t.rDx[b + 1];
+    const double rdz_i = t.rdz[a + 1], rDz_i = t.rDz[a + 1], rDz_p = t.rDz[a + 2];
+    const double esC = t.es[c], esN = t.es[c + CR];
+    const double cE = 4.0 * t.en[c] * rdx_j * rDx_j, cW = 4.0 * t.en[c - 1] * rdx_m * rDx_j;
+    const double cN = 2.0 * esN * rDz_p * rdz_i, cS = 2.0 * esC * rDz_i * rdz_i;
+    dg = cE + cW + cN + cS;
+    if (NEED_A) {
+        const double zN = 2.0 * esN * rDx_j * rdz_i, zS = 2.0 * esC * rDx_j * rdz_i;
+        const double v0 = vx[c];
+        Av = cE * (vx[c + 1] - v0) - cW * (v0 - vx[c - 1]) + cN * (vx[c + CR] - v0) - cS * (v0 - vx[c - CR]) +
+             zN * (vz[c + CR] - vz[c + CR - 1]) - zS * (vz[c] - vz[c - 1]);
+    }
+}
+
+// everything the stages of one tile share
+template <int CR>
+struct MgtTile {
+    int ci0, cj0;                      // global node of region element (0, 0)
+    MgtTab t;
+    // first sweep from the zero guess (cheb_first_node): v1 = -c2 f / diag, slaves copy s x their master's value
+    __device__ inline void first(const PlVvOp& op, const double* fz, const double* fx, double* oz, double* ox, double c2, int a, int b) const {
+        const int i = ci0 + a, j = cj0 + b, c = a * CR + b;
+        int d; double s, Av, dg;
+        double o = 0.0;
+        int cls = mgt_cls_z(op, i, j, d, s);
+        if (cls != VV_ZERO && b + d >= 1 && b + d <= CR - 2) { mgt_row_z<CR, false>(t, nullptr, nullptr, c + d, a, b + d, Av, dg); o = (-s * c2 * fz[c + d]) * pl_rcp(dg); }
+        oz[c] = o;
+        o = 0.0;
+        cls = mgt_cls_x(op, i, j, d, s);
+        if (cls != VV_ZERO && a + d >= 1 && a + d <= CR - 2) { mgt_row_x<CR, false>(t, nullptr, nullptr, c + d * CR, a + d, b, Av, dg); o = (-s * c2 * fx[c + d * CR]) * pl_rcp(dg); }
+        ox[c] = o;
+    }
+    // one Chebyshev sweep (cheb_node); pz == nullptr: the previous iterate is zero
+    __device__ inline void cheb(const PlVvOp& op, const double* vz, const double* vx, const double* pz, const double* px, const double* fz,
+                                const double* fx, double c1, double c2, int a, int b, double& oz, double& ox) const {
+        const int i = ci0 + a, j = cj0 + b, c = a * CR + b;
+        int d; double s, Av, dg;
+        oz = 0.0; ox = 0.0;
+        int cls = mgt_cls_z(op, i, j, d, s);
+        if (cls != VV_ZERO && b + d >= 1 && b + d <= CR - 2) {
+            const int cm = c + d;
+            mgt_row_z<CR, true>(t, vz, vx, cm, a, b + d, Av, dg);
+            const double v0 = vz[cm], mom = (c1 != 0.0) ? c1 * (v0 - (pz ? pz[cm] : 0.0)) : 0.0;
+            oz = s * (v0 + mom + (c2 * (Av - fz[cm])) * pl_rcp(dg));
+        }
+        cls = mgt_cls_x(op, i, j, d, s);
+        if (cls != VV_ZERO && a + d >= 1 && a + d <= CR - 2) {
+            const int cm = c + d * CR;
+            mgt_row_x<CR, true>(t, vz, vx, cm, a + d, b, Av, dg);
+            const double v0 = vx[cm], mom = (c1 != 0.0) ? c1 * (v0 - (px ? px[cm] : 0.0)) : 0.0;
+            ox = s * (v0 + mom + (c2 * (Av - fx[cm])) * pl_rcp(dg));
+        }
+    }
+};
+
+// the tables of the region: value of table tab (indexed by global node + PL_TOFF, defined for -PL_TOFF .. n + PL_TOFF) at region rows / columns -1 .. CR + 1
+__device__ inline void mgt_load_table(double* dst, const double* tab, int first_global, int count, int n) {
+    for (int k = threadIdx.x; k < count; k += MGT_NT) {
+        const int gk = first_global + k;
+        dst[k] = (gk >= -PL_TOFF && gk < n + PL_TOFF) ? TB(tab, gk) : 0.0;
+    }
+}
+
+// NS: sweeps of the pre-smoothing sequence, the first from the zero guess included (1..3).  L0: level 0 of the Stokes
+// preconditioner -- the right-hand side is computed from the scaled residual rs (stage1_node) instead of read.
+template <int NS, bool L0>
+__global__ __launch_bounds__(MGT_NT) void k_mg_pre(MgTileArgs a) {
+    constexpr int TS = MGT_TS, H = NS + 1, HC = H + 1, CR = TS + 2 * HC, NN = CR * CR;
+    __shared__ double V[3][2][NN];
+    __shared__ double F[2][NN];
+    __shared__ double ES[NN], EN[NN];
+    __shared__ double ZP[L0 ? NN : 1];
+    __shared__ double TAB[4][CR + 4];
+    const PlGeom& g = a.op.g;
+    const int tid = threadIdx.x;
+    const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x % a.tiles_x;
+    const int ti0 = ty * TS, tj0 = tx * TS;
+    MgtTile<CR> T;
+    T.ci0 = ti0 - HC; T.cj0 = tj0 - HC;
+    T.t.es = ES; T.t.en = EN; T.t.rdz = TAB[0]; T.t.rDz = TAB[1]; T.t.rdx = TAB[2]; T.t.rDx = TAB[3];
+    mgt_load_table(TAB[0], a.op.rdz, T.ci0 - 1, CR + 3, g.nz); mgt_load_table(TAB[1], a.op.rDz, T.ci0 - 1, CR + 3, g.nz);
+    mgt_load_table(TAB[2], a.op.rdx, T.cj0 - 1, CR + 3, g.nx); mgt_load_table(TAB[3], a.op.rDx, T.cj0 - 1, CR + 3, g.nx);
+    const long long P = g.plane;
+    // ---- load: viscosities (and the right-hand side, or the pressure residual) of the whole region; 0 beyond the planes' ring
+    for (int idx = tid; idx < NN; idx += MGT_NT) {
+        const int ra = idx / CR, rb = idx % CR, i = T.ci0 + ra, j = T.cj0 + rb;
+        const bool inmem = i >= -PL_RING && i < g.nz + PL_RING && j >= -PL_RING && j < g.nx + PL_RING;
+        const long long c = pl_idx(g, i - g.gi0, j - g.gj0);
+        ES[idx] = inmem ? a.op.etas[c] : 0.0; EN[idx] = inmem ? a.op.etan[c] : 0.0;
+        if (L0) {
+            const bool indom = i >= 0 && i < g.nz && j >= 0 && j < g.nx;
+            ZP[idx] = indom ? prec_p_value(a.sop, a.rs + 2 * P, i, j, c) : 0.0;
+        } else {
+            F[0][idx] = inmem ? a.f[c] : 0.0; F[1][idx] = inmem ? a.f[c + P] : 0.0;
+        }
+    }
+    __syncthreads();
+    if (L0) {
+        // stage 1 (stage1_node): f = r_v - A_vp z_p on the interior momentum rows; un-scaling a row = multiplying by the sum of
+        // its four own-component coefficients (= the diagonal the sweeps use)
+        for (int idx = tid; idx < NN; idx += MGT_NT) {
+            const int ra = idx / CR, rb = idx % CR, i = T.ci0 + ra, j = T.cj0 + rb;
+            double fz = 0.0, fx = 0.0;
+            if (ra >= HC - H && ra < HC + TS + H && rb >= HC - H && rb < HC + TS + H) {
+                const long long c = pl_idx(g, i - g.gi0, j - g.gj0);
+                int d; double s, Av, dg;
+                if (mgt_cls_z(a.op, i, j, d, s) == VV_INT) {
+                    mgt_row_z<CR, false>(T.t, nullptr, nullptr, idx, ra, rb, Av, dg);
+                    fz = a.rs[c] * dg + 2.0 * a.sop.Kc * TAB[1][ra + 1] * (ZP[idx] - ZP[idx - CR]);
+                }
+                if (mgt_cls_x(a.op, i, j, d, s) == VV_INT) {
+                    mgt_row_x<CR, false>(T.t, nullptr, nullptr, idx, ra, rb, Av, dg);
+                    fx = a.rs[c + P] * dg + 2.0 * a.sop.Kc * TAB[3][rb + 1] * (ZP[idx] - ZP[idx - 1]);
+                }
+                if (ra >= HC && ra < HC + TS && rb >= HC && rb < HC + TS && i < g.nz && j < g.nx) {      // the tile itself: keep f and z_p
+                    a.fout[c] = fz; a.fout[c + P] = fx; a.z[c + 2 * P] = ZP[idx];
+                }
+            }
+            F[0][idx] = fz; F[1][idx] = fx;
+        }
+        __syncthreads();
+    }
+    // ---- first sweep from the zero guess on the region +-H
+    int cur = 0, prv = 1, nxt = 2;
+    for (int idx = tid; idx < NN; idx += MGT_NT) {
+        const int ra = idx / CR, rb = idx % CR;
+        if (ra >= HC - H && ra < HC + TS + H && rb >= HC - H && rb < HC + TS + H) T.first(a.op, F[0], F[1], V[cur][0], V[cur][1], a.c2[0], ra, rb);
+    }
+    __syncthreads();
+    // ---- Chebyshev sweeps, each on a region one node smaller
+#pragma unroll
+    for (int k = 1; k < NS; k++) {
+        const int h = H - k;
+        for (int idx = tid; idx < NN; idx += MGT_NT) {
+            const int ra = idx / CR, rb = idx % CR;
+            if (ra >= HC - h && ra < HC + TS + h && rb >= HC - h && rb < HC + TS + h) {
+                double oz, ox;
+                T.cheb(a.op, V[cur][0], V[cur][1], k == 1 ? nullptr : V[prv][0], k == 1 ? nullptr : V[prv][1], F[0], F[1], a.c1[k], a.c2[k], ra, rb, oz, ox);
+                V[nxt][0][idx] = oz; V[nxt][1][idx] = ox;
+            }
+        }
+        __syncthreads();
+        const int o = prv; prv = cur; cur = nxt; nxt = o;
+    }
+    // ---- residual on the region +-1 (interior rows; 0 elsewhere) into the free buffer; the tile's iterate goes to memory
+    for (int idx = tid; idx < NN; idx += MGT_NT) {
+        const int ra = idx / CR, rb = idx % CR, i = T.ci0 + ra, j = T.cj0 + rb;
+        if (ra >= HC - 1 && ra < HC + TS + 1 && rb >= HC - 1 && rb < HC + TS + 1) {
+            int d; double s, Av, dg, rz = 0.0, rx = 0.0;
+            if (mgt_cls_z(a.op, i, j, d, s) == VV_INT) { mgt_row_z<CR, true>(T.t, V[cur][0], V[cur][1], idx, ra, rb, Av, dg); rz = F[0][idx] - Av; }
+            if (mgt_cls_x(a.op, i, j, d, s) == VV_INT) { mgt_row_x<CR, true>(T.t, V[cur][0], V[cur][1], idx, ra, rb, Av, dg); rx = F[1][idx] - Av; }
+            V[nxt][0][idx] = rz; V[nxt][1][idx] = rx;
+            if (ra >= HC && ra < HC + TS && rb >= HC && rb < HC + TS && i < g.nz && j < g.nx) {
+                const long long c = pl_idx(g, i - g.gi0, j - g.gj0);
+                a.v[c] = V[cur][0][idx]; a.v[c + P] = V[cur][1][idx];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- full-weighting restriction (restrict_node) onto the coarse nodes of the tile
+    const PlGeom& gc = a.opc.g;
+    for (int idx = tid; idx < (TS / 2) * (TS / 2); idx += MGT_NT) {
+        const int I = ty * (TS / 2) + idx / (TS / 2), J = tx * (TS / 2) + idx % (TS / 2);
+        if (I >= gc.nz || J >= gc.nx) continue;
+        const int b0 = (2 * I - T.ci0) * CR + (2 * J - T.cj0);
+        int d; double s;
+        double oz = 0.0, ox = 0.0;
+        if (vv_cls_z(a.opc, I, J, d, s) == VV_INT) {
+            const double wz[3] = {0.25, 0.5, 0.25}, wx[4] = {0.125, 0.375, 0.375, 0.125};
+#pragma unroll
+            for (int u = 0; u < 3; u++)
+#pragma unroll
+                for (int w = 0; w < 4; w++) oz += wz[u] * wx[w] * V[nxt][0][b0 + (u - 1) * CR + (w - 1)];
+        }
+        if (vv_cls_x(a.opc, I, J, d, s) == VV_INT) {
+            const double wz[4] = {0.125, 0.375, 0.375, 0.125}, wx[3] = {0.25, 0.5, 0.25};
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int w = 0; w < 3; w++) ox += wz[u] * wx[w] * V[nxt][1][b0 + (u - 1) * CR + (w - 1)];
+        }
+        const long long cc = pl_idx(gc, I - gc.gi0, J - gc.gj0);
+        a.fc[cc] = oz; a.fc[cc + gc.plane] = ox;
+    }
+}
+
+// NS: sweeps of the post-smoothing sequence (1..3); the last one writes the tile to `out` (times oscale)
+template <int NS>
+__global__ __launch_bounds__(MGT_NT) void k_mg_post(MgTileArgs a) {
+    constexpr int TS = MGT_TS, H = NS, HC = H + 1, CR = TS + 2 * HC, NN = CR * CR, ECR = TS / 2 + H + 6, ENN = ECR * ECR;
+    __shared__ double V[3][2][NN];
+    __shared__ double F[2][NN];
+    __shared__ double ES[NN], EN[NN];
+    __shared__ double EC[2][ENN];
+    __shared__ double TAB[4][CR + 4];
+    const PlGeom& g = a.op.g; const PlGeom& gc = a.opc.g;
+    const int tid = threadIdx.x;
+    const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x % a.tiles_x;
+    const int ti0 = ty * TS, tj0 = tx * TS;
+    MgtTile<CR> T;
+    T.ci0 = ti0 - HC; T.cj0 = tj0 - HC;
+    T.t.es = ES; T.t.en = EN; T.t.rdz = TAB[0]; T.t.rDz = TAB[1]; T.t.rdx = TAB[2]; T.t.rDx = TAB[3];
+    mgt_load_table(TAB[0], a.op.rdz, T.ci0 - 1, CR + 3, g.nz); mgt_load_table(TAB[1], a.op.rDz, T.ci0 - 1, CR + 3, g.nz);
+    mgt_load_table(TAB[2], a.op.rdx, T.cj0 - 1, CR + 3, g.nx); mgt_load_table(TAB[3], a.op.rDx, T.cj0 - 1, CR + 3, g.nx);
+    const long long P = g.plane;
+    const int eI0 = ((ti0 - H) >> 1) - 2, eJ0 = ((tj0 - H) >> 1) - 2;      // coarse node of EC element (0, 0)
+    for (int idx = tid; idx < NN; idx += MGT_NT) {
+        const int ra = idx / CR, rb = idx % CR, i = T.ci0 + ra, j = T.cj0 + rb;
+        const bool inmem = i >= -PL_RING && i < g.nz + PL_RING && j >= -PL_RING && j < g.nx + PL_RING;
+        const long long c = pl_idx(g, i - g.gi0, j - g.gj0);
+        ES[idx] = inmem ? a.op.etas[c] : 0.0; EN[idx] = inmem ? a.op.etan[c] : 0.0;
+        F[0][idx] = inmem ? a.f[c] : 0.0; F[1][idx] = inmem ? a.f[c + P] : 0.0;
+        V[1][0][idx] = inmem ? a.v[c] : 0.0; V[1][1][idx] = inmem ? a.v[c + P] : 0.0;     // the pre-smoothed iterate
+    }
+    for (int idx = tid; idx < ENN; idx += MGT_NT) {
+        const int I = eI0 + idx / ECR, J = eJ0 + idx % ECR;
+        const bool inmem = I >= -PL_RING && I < gc.nz + PL_RING && J >= -PL_RING && J < gc.nx + PL_RING;
+        const long long cc = pl_idx(gc, I - gc.gi0, J - gc.gj0);
+        EC[0][idx] = inmem ? a.ec[cc] : 0.0; EC[1][idx] = inmem ? a.ec[cc + gc.plane] : 0.0;
+    }
+    __syncthreads();
+    // ---- prolongation + correction (prolong_node) on the region +-H: cur = s (v[master] + P e at the master)
+    auto ecz = [&](int I, int J) { return EC[0][(I - eI0) * ECR + (J - eJ0)]; };
+    auto ecx = [&](int I, int J) { return EC[1][(I - eI0) * ECR + (J - eJ0)]; };
+    int cur = 0, prv = 1, nxt = 2;
+    for (int idx = tid; idx < NN; idx += MGT_NT) {
+        const int ra = idx / CR, rb = idx % CR, i = T.ci0 + ra, j = T.cj0 + rb;
+        if (ra >= HC - H && ra < HC + TS + H && rb >= HC - H && rb < HC + TS + H) {
+            int d; double s;
+            double oz = 0.0, ox = 0.0;
+            if (mgt_cls_z(a.op, i, j, d, s) != VV_ZERO) {
+                const int jm = j + d;
+                const int I0 = i >> 1, I1 = (i + 1) >> 1;
+                int Jn = jm >> 1, Jo = (jm & 1) ? Jn + 1 : Jn - 1;
+                Jn = min(max(Jn, 0), gc.nx - 2); Jo = min(max(Jo, 0), gc.nx - 2);
+                const double pa = 0.5 * (ecz(I0, Jn) + ecz(I1, Jn)), pb = 0.5 * (ecz(I0, Jo) + ecz(I1, Jo));
+                oz = s * (V[1][0][idx + d] + (0.75 * pa + 0.25 * pb));
+            }
+            if (mgt_cls_x(a.op, i, j, d, s) != VV_ZERO) {
+                const int im = i + d;
+                const int J0 = j >> 1, J1 = (j + 1) >> 1;
+                int In = im >> 1, Io = (im & 1) ? In + 1 : In - 1;
+                In = min(max(In, 0), gc.nz - 2); Io = min(max(Io, 0), gc.nz - 2);
+                const double pa = 0.5 * (ecx(In, J0) + ecx(In, J1)), pb = 0.5 * (ecx(Io, J0) + ecx(Io, J1));
+                ox = s * (V[1][1][idx + d * CR] + (0.75 * pa + 0.25 * pb));
+            }
+            V[0][0][idx] = oz; V[0][1][idx] = ox;
+        }
+    }
+    __syncthreads();
+    // ---- Chebyshev sweeps (the first with c1 = 0); the last one covers the tile only and goes to memory
+#pragma unroll
+    for (int k = 0; k < NS; k++) {
+        const int h = H - 1 - k;
+        for (int idx = tid; idx < NN; idx += MGT_NT) {
+            const int ra = idx / CR, rb = idx % CR;
+            if (ra >= HC - h && ra < HC + TS + h && rb >= HC - h && rb < HC + TS + h) {
+                double oz, ox;
+                T.cheb(a.op, V[cur][0], V[cur][1], V[prv][0], V[prv][1], F[0], F[1], k == 0 ? 0.0 : a.c1[k], a.c2[k], ra, rb, oz, ox);
+                if (k == NS - 1) {
+                    const int i = T.ci0 + ra, j = T.cj0 + rb;
+                    if (i < g.nz && j < g.nx) { const long long c = pl_idx(g, i - g.gi0, j - g.gj0); a.out[c] = oz * a.oscale; a.out[c + a.out_plane] = ox * a.oscale; }
+                } else { V[nxt][0][idx] = oz; V[nxt][1][idx] = ox; }
+            }
+        }
+        if (k < NS - 1) { __syncthreads(); const int o = prv; prv = cur; cur = nxt; nxt = o; }
+    }
+}
+
+// Chebyshev coefficients of a sequence of n sweeps on [lmax / ratio, lmax], as smooth() computes them
+static void cheb_coeffs(double lmax, double ratio, int n, double* c1, double* c2) {
+    const double lmin = lmax / ratio, theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
+    double rho_old = 1.0 / sigma;
+    for (int k = 0; k < n; k++) {
+        if (k == 0) { c1[k] = 0.0; c2[k] = 1.0 / theta; }
+        else { const double rho = 1.0 / (2.0 * sigma - rho_old); c1[k] = rho * rho_old; c2[k] = 2.0 * rho / delta; rho_old = rho; }
+    }
+}
+static bool mg_fused_level_ok(pl_ctx* ctx, const PlSolver* S, size_t l) {
+    if (!S->fused || ctx->nranks != 1 || l + 1 >= S->levels.size() || S->early_K > 0) return false;
+    const MgLevel* L = S->levels[l];
+    if (L->dist || L->f32 || L->op.szz) return false;
+    const PlGeom& g = L->gh.d;
+    if ((long long)g.nz * g.nx > S->fused_max_nodes) return false;
+    if (S->use_tail && l > 0 && (long long)g.nz * g.nx <= S->tail_max_nodes && S->levels.size() - l <= PL_TAIL_MAX_LEVELS) return false;   // the tail kernel's levels
+    int npre, npost;
+    level_nu(S, l, npre, npost);
+    return npre >= 1 && npre <= 3 && npost >= 1 && npost <= 3;
+}
+// One visit of level l by the tile kernels: pre (-> iterate in L->v[0], coarse rhs in C->f), the coarse levels, post
+// (-> final_out times final_scale if given, else L->v[2]; *out tells where).  rs != NULL (level 0 of the Stokes
+// preconditioner): the right-hand side is computed from the scaled residual and kept in L->f, z_p goes to z.
+static void vcycle_fused_level(pl_ctx* ctx, PlSolver* S, size_t l, const double* f, double** out, double* final_out, double final_scale,
+                               const PlStokesOp* sop, const double* rs, double* z) {
+    MgLevel* L = S->levels[l];
+    MgLevel* C = S->levels[l + 1];
+    const PlGeom& g = L->gh.d;
+    int npre, npost;
+    level_nu(S, l, npre, npost);
+    MgTileArgs a{};
+    a.op = L->op; a.opc = C->op;
+    a.f = rs ? (const double*)L->f : f; a.fout = L->f; a.v = L->v[0]; a.fc = C->f;
+    a.tiles_x = (g.nx + MGT_TS - 1) / MGT_TS;
+    const dim3 grid((unsigned)(a.tiles_x * ((g.nz + MGT_TS - 1) / MGT_TS)));
+    cheb_coeffs(L->lmax, S->cheb_ratio, npre, a.c1, a.c2);
+    if (rs) { a.sop = *sop; a.rs = rs; a.z = z; }
+#define MGT_PRE(NS, L0) hipLaunchKernelGGL((k_mg_pre<NS, L0>), grid, dim3(MGT_NT), 0, ctx->stream, a)
+    if (rs) { if (npre == 1) MGT_PRE(1, true); else if (npre == 2) MGT_PRE(2, true); else MGT_PRE(3, true); }
+    else { if (npre == 1) MGT_PRE(1, false); else if (npre == 2) MGT_PRE(2, false); else MGT_PRE(3, false); }
+#undef MGT_PRE
+    double* ec = nullptr;
+    bool wf = false;
+    vcycle<double>(ctx, S, l + 1, C->f, &ec, &wf, nullptr, 1.0, 0, nullptr);      // (takes the tile kernels itself where it can)
+    a.ec = ec; a.out = final_out ? final_out : L->v[2]; a.oscale = final_out ? final_scale : 1.0; a.out_plane = g.plane;
+    cheb_coeffs(L->lmax, S->cheb_ratio, npost, a.c1, a.c2);
+    if (npost == 1) hipLaunchKernelGGL((k_mg_post<1>), grid, dim3(MGT_NT), 0, ctx->stream, a);
+    else if (npost == 2) hipLaunchKernelGGL((k_mg_post<2>), grid, dim3(MGT_NT), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((k_mg_post<3>), grid, dim3(MGT_NT), 0, ctx->stream, a);
+    *out = final_out ? nullptr : L->v[2];
 }
 
 // copy 2 velocity planes into the FP64 Krylov vector (times oscale)
@@ -1992,6 +2400,15 @@ static int stokes_precond_t(pl_ctx* ctx, PlSolver* S, const double* rs, double* 
     }
     op.g = V.op.g; op.etas -= V.sh; op.etan -= V.sh; if (op.rho) op.rho -= V.sh;
     op.iKc /= S->schur_scale;                     // only the S^-1 r_p evaluations of stage 1 use it
+    if constexpr (std::is_same<T, double>::value) {
+        if (mg_fused_level_ok(ctx, S, 0)) {           // stage 1, the pre-smoothing, residual and restriction in one launch; post likewise
+            double* e2 = nullptr;
+            vcycle_fused_level(ctx, S, 0, nullptr, &e2, z, 1.0, &op, rs, z);
+            PL_HIP(ctx, hipGetLastError());
+            S->nprec++;
+            return 0;
+        }
+    }
     // the first pre-smoothing sweep of level 0 (from the zero guess: v1 = -c2 f / diag) is written by stage 1 itself
     int npre0, npost0;
     level_nu(S, 0, npre0, npost0);

@@ -187,7 +187,9 @@ print("RESULT", json.dumps(dict(its=A.last_stats["iterations"], conv=A.last_stat
                 # vectorised and with the scalar kernels; the early coarse branch on a second stream
                 ("fp32_levels", {"PYLAMP_MG_FP32": "1", "PYLAMP_MG_FP32_NODES": "1000"}),
                 ("fp32_levels_scalar_kernels", {"PYLAMP_MG_FP32": "1", "PYLAMP_MG_FP32_NODES": "1000", "PYLAMP_VV_VEC": "0"}),
-                ("early_coarse_branch", {"PYLAMP_MG_EARLY": "1"}))
+                ("early_coarse_branch", {"PYLAMP_MG_EARLY": "1"}),
+                # every multigrid stage as a kernel of its own instead of the fused tile kernels (k_mg_pre / k_mg_post)
+                ("staged_levels", {"PYLAMP_MG_FUSED": "0"}), ("staged_levels_scalar", {"PYLAMP_MG_FUSED": "0", "PYLAMP_VV_VEC": "0"}))
     for name, env in variants:
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
         assert r.returncode == 0, (name, r.stderr[-1500:])
@@ -236,3 +238,45 @@ def test_fp32_multigrid_levels_report_and_agree():
     v = lambda x: x.reshape(n, n, 3)[:, :, :2]
     assert np.linalg.norm(v(x1) - v(x0)) / np.linalg.norm(v(x0)) < 1e-8
     assert it1 <= 1.5 * it0 + 5, (it0, it1)
+
+
+@pytest.mark.parametrize("nx,uniform,bc", [([129, 97], True, [1, 1, 1, 1]), ([161, 129], False, [0, 1, 0, 1]), ([257, 257], True, [1, 1, 0, 1]),
+                                           ([513, 385], True, [1, 1, 1, 1]), ([1025, 1025], True, [1, 1, 1, 1])])
+def test_fused_levels_match_the_staged_path(nx, uniform, bc):
+    """The tile kernels (k_mg_pre: stage 1 / first sweep / sweeps / residual / restriction of a level in one launch, k_mg_post:
+    prolongation + sweeps) against the one-kernel-per-stage path they replace: the same preconditioned vector z = M^-1 r to
+    rounding, on uniform and rectilinear grids, FREESLIP and NOSLIP walls, from 3 to 6 fused levels (V(2,2) on the small grids,
+    V(1,1) + V(3,3) from 10^6 nodes up).  PYLAMP_MG_FUSED is read when a context's solver is created: one context per mode."""
+    import os
+    from pylamp_amd import pylamp_stokes as S, _context
+    rng = np.random.default_rng(31)
+    L = [660e3, 500e3]
+
+    def nonuni(n, Ld):
+        w = rng.uniform(0.8, 1.25, n - 1); g = np.concatenate([[0.0], np.cumsum(w)]); return g * (Ld / g[-1])
+    grid = [np.linspace(0, L[d], nx[d]) if uniform else nonuni(nx[d], L[d]) for d in range(2)]
+    Z, X = np.meshgrid(*grid, indexing='ij')
+    gm = [np.append(0.5 * (g[1:] + g[:-1]), g[-1] + 0.5 * (g[-1] - g[-2])) for g in grid]
+    Zc, Xc = np.meshgrid(*gm, indexing='ij')
+    f = lambda z, x: 1e20 * 10 ** (1.5 * np.sin(2 * np.pi * x / L[1]) * np.cos(np.pi * z / L[0]) + 0.3 * np.sin(17 * x / L[1]) * np.sin(23 * z / L[0]))
+    rho = 3300 + 40 * np.sin(2 * np.pi * X / L[1]) * np.sin(np.pi * Z / L[0])
+    r = rng.standard_normal(3 * nx[0] * nx[1])
+    out = {}
+    for mode in ("1", "0"):
+        os.environ["PYLAMP_MG_FUSED"] = mode
+        try:
+            _context.clear_contexts()
+            A, rhs = S.makeStokesMatrix(nx, grid, f(Z, X), f(Zc, Xc), rho, bc)
+            z = A.precond(r)
+            x = S.solve(A, rhs)
+            out[mode] = (z.reshape(nx[0], nx[1], 3), x.reshape(nx[0], nx[1], 3), dict(A.last_stats))
+            del A
+        finally:
+            del os.environ["PYLAMP_MG_FUSED"]
+            _context.clear_contexts()
+    (zf, xf, sf), (zs, xs, ss) = out["1"], out["0"]
+    for q in range(3):
+        assert np.max(np.abs(zf[:, :, q] - zs[:, :, q])) < 1e-10 * np.max(np.abs(zs[:, :, q])), q
+    assert sf["converged"] == 1 and ss["converged"] == 1 and abs(sf["iterations"] - ss["iterations"]) <= 2, (sf, ss)
+    v = lambda x: x[:, :, :2]
+    assert np.linalg.norm(v(xf) - v(xs)) / np.linalg.norm(v(xs)) < 1e-6
