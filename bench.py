@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 
-def build_sim(n, tracdens, seed, device, rank, world, scaling):
+def build_sim(n, tracdens, seed, device, rank, world, scaling, model="mantle"):
     """strong (default, what BASELINE.json's metric names: the 2048^2-cell problem at 1/2/4/8 GPUs): the SAME n x n
     grid for every N, split into Pz x Px blocks (1x2, 2x2, 2x4).  weak (--scaling weak): every GPU holds one
     (n-1) x (n-1)-cell block of a ((n-1) Pz + 1) x ((n-1) Px + 1) grid over a correspondingly larger domain (square
@@ -39,12 +39,20 @@ def build_sim(n, tracdens, seed, device, rank, world, scaling):
         nx = [n, n]; L = [660e3, 660e3]
     # census + injection inside the timed step, like the reference (pylamp2.py:39-40,588-633; its stock values are
     # 45 / 25): cells below 9 markers are refilled to 16
-    sim = driver.Simulation(nx, L, options=driver.Options(tracdens=tracdens, tracdens_min=(tracdens * 9) // 16), device=device)
+    opt = driver.Options(tracdens=tracdens, tracdens_min=(tracdens * 9) // 16)
+    if model == "block":            # SURVEY 8d C3 "same physics as C1": the 10^3 falling block of pylamp2.py:172-183, heat off
+        opt = driver.Options(tracdens=tracdens, tracdens_min=(tracdens * 9) // 16, do_heatdiff=False, tdep_rho=False, tdep_eta=False)
+    sim = driver.Simulation(nx, L, options=opt, device=device)
     rng = np.random.default_rng(seed + rank)
     zr, xr = sim.block()
     per_rank = nx[0] * nx[1] * tracdens // max(world, 1)
-    tr_x, tr_f = driver.mantle_tracers(nx, L, tracdens, rng, zrange=None if world == 1 else zr, xrange=None if world == 1 else xr,
-                                       id0=rank * per_rank)
+    if model == "block":
+        if world > 1:
+            raise Exception("--model block is a single-GPU secondary mode")
+        tr_x, tr_f = driver.falling_block_tracers(nx, L, tracdens, rng)
+    else:
+        tr_x, tr_f = driver.mantle_tracers(nx, L, tracdens, rng, zrange=None if world == 1 else zr, xrange=None if world == 1 else xr,
+                                           id0=rank * per_rank)
     sim.upload(tr_x, tr_f)
     del tr_x, tr_f
     return sim
@@ -215,6 +223,11 @@ def main():
     ap.add_argument("--tracdens", type=int, default=16)
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1: strong = the same grid split over N GPUs (BASELINE's metric); weak = one --grid slab per GPU")
+    ap.add_argument("--model", choices=["mantle", "block"], default="mantle",
+                    help="mantle (default, the headline): T-dependent convection with heat; block: the 10^3 falling block of config 1 "
+                         "(heat off) at the same size -- the slower-converging Stokes problem, a secondary figure")
+    ap.add_argument("--transport", choices=["torch", "native"], default="torch",
+                    help="N > 1: torch.distributed callbacks (default) or direct RCCL calls on the solver stream (opt-in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--apply-reps", type=int, default=50)
     args = ap.parse_args()
@@ -230,7 +243,13 @@ def main():
         import torch.distributed as dist
         backend = os.environ.get("PYLAMP_DIST_BACKEND", "nccl")     # "gloo": several ranks sharing one GPU (tests)
         if backend == "nccl":
-            os.environ.setdefault("PYLAMP_RCCL", "1")               # native RCCL transport (self-tested at start-up, falls back)
+            # Transport of the halo exchanges / all-reduces inside the library: "native" = direct RCCL calls on the solver's
+            # stream (self-tested at start-up against a 60 s deadline watched on an event, collective fall-back), "torch" =
+            # the callback table into torch.distributed (RCCL as well, but host-synchronous per call).  The native path has
+            # never run on more than one GPU (no multi-GPU node was available to the build), so it stays OPT-IN until it has
+            # passed once on a real node: --transport native, or PYLAMP_RCCL=1.
+            if args.transport == "native":
+                os.environ["PYLAMP_RCCL"] = "1"
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -248,7 +267,7 @@ def main():
     if world > 1 and not os.environ.get("PYLAMP_DEVICE") and os.environ.get("PYLAMP_DIST_BACKEND", "nccl") != "nccl":
         import torch                                                # rehearsal: several gloo ranks may share the GPUs of the box
         device = local_rank % max(torch.cuda.device_count(), 1)
-    sim = build_sim(args.n, args.tracdens, 20260103, device, rank, world, args.scaling)
+    sim = build_sim(args.n, args.tracdens, 20260103, device, rank, world, args.scaling, args.model)
     ctx = sim.ctx
     reports = []
     for _ in range(args.warmup):
@@ -308,8 +327,9 @@ def main():
             "metric": "stokes_heat_mic_cell_updates_per_s", "value": round(value, 1), "unit": "cell-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "2D %dx%d nodes (%dx%d cells), %d markers/node (%d tracers), T-dependent mantle "
-                                   "model, heat + subgrid diffusion on, all free-slip, full time step" %
+            "config": {"workload": ("2D %dx%d nodes (%dx%d cells), %d markers/node (%d tracers), " + ("T-dependent mantle "
+                                   "model, heat + subgrid diffusion on" if args.model == "mantle" else "falling block (density +50 kg/m3, viscosity x 1e3; "
+                                   "pylamp2.py:172-183), heat off: SECONDARY mode, not the headline") + ", all free-slip, full time step") %
                                    (sim.nx[0], sim.nx[1], sim.nx[0] - 1, sim.nx[1] - 1, args.tracdens, ntrac_global),
                        "parallelism": "1 GPU" if world == 1 else "%d x %d blocks of the node grid (8-neighbour halo exchange with corners + all-reduce), transport: %s" %
                                       (sim.ctx.local_block()[4], sim.ctx.local_block()[5], "direct RCCL on the solver stream" if (sim.ctx.comm is not None and sim.ctx.comm.native)

@@ -40,7 +40,7 @@ enum { PL_INTERP_NEAREST = 8, PL_INTERP_LINEAR = 16, PL_INTERP_VELDIV = 32 };
 typedef struct pl_solve_stats {
     int    iterations;      /* outer Krylov iterations used                       */
     int    converged;       /* 1 iff rel_residual <= rtol (the recomputed residual, never the recurrence) and, for Stokes,
-                             * error_estimate <= 2 x its bound (below) */
+                             * error_estimate <= 1.5 x its bound (below) */
     double rel_residual;    /* TRUE residual ||D(r0 - A dx)|| / ref, recomputed with the operator, where
                              * r0 = b - A x0 is evaluated once and x = x0 + dx (correction form);
                              * D = row scaling; ref = ||D b|| (heat) or the dynamic load
@@ -51,7 +51,7 @@ typedef struct pl_solve_stats {
     int    used_direct;     /* 1: the multigrid-preconditioned iteration did not converge and the banded-LU fallback for
                              * small single-GPU systems finished the solve (indefinite systems: the reference's
                              * free-surface stabilisation sign at the Courant step, pylamp2.py:387-405) */
-    int    reserved_;
+    int    reserved_;       /* 0 */
     double error_estimate;  /* Stokes: estimate of the relative velocity error of the returned iterate from its true residual
                              * (the residual norm alone does not bound it: error / residual
                              * is ~10 on large smooth problems and ~1e4 on coarse ones): (n |r_cont| + |(M^-1 r)_v|) / |x_v|,
@@ -311,6 +311,8 @@ int  pl3_stokes_set_wall_rows(pl3_ctx* ctx, int slaved);
 int  pl3_stokes_get_scaling(pl3_ctx* ctx, double* kcont, double* kbond);
 int  pl3_stokes_apply(pl3_ctx* ctx, const double* x, double* y);
 int  pl3_stokes_rhs(pl3_ctx* ctx, double* rhs);
+/* x == NULL: device-resident solve -- nothing crosses PCIe, the solution stays in the context (pl3_get_solution), and use_x0 != 0
+ * starts from the solution of the context's previous solve. */
 int  pl3_stokes_solve(pl3_ctx* ctx, const double* rhs, double* x, int use_x0, double rtol, int maxit, pl_solve_stats* stats);
 int  pl3_stokes_apply_bench(pl3_ctx* ctx, int scaled, int reps, double* avg_ms);     /* 80 B/node algorithmic */
 int  pl3_stokes_mg_info(pl3_ctx* ctx, int* nlevels, double* lmax, int max_levels);
@@ -319,7 +321,10 @@ int  pl3_heat_set_coeffs(pl3_ctx* ctx, const double* zmp, const double* xmp, con
                          const double bcvalue[6], double tstep);
 int  pl3_heat_apply(pl3_ctx* ctx, const double* x, double* y);
 int  pl3_heat_rhs(pl3_ctx* ctx, double* rhs);
-int  pl3_heat_solve(pl3_ctx* ctx, const double* rhs /* NULL: the operator's own */, double* x, double rtol, int maxit, pl_solve_stats* stats);
+/* rhs must be NULL (the operator's own right-hand side, pl3_heat_rhs); x == NULL keeps the solution on the device */
+int  pl3_heat_solve(pl3_ctx* ctx, const double* rhs, double* x, double rtol, int maxit, pl_solve_stats* stats);
+/* solution of the last solve of this context: which = 0 Stokes (nz, nx, ny, 4), 1 heat (nz, nx, ny) */
+int  pl3_get_solution(pl3_ctx* ctx, int which, double* out);
 
 /* sizeof / offsetof of the structs above as compiled into the library: out = { sizeof(pl_solve_stats),
  * sizeof(pl_step_config), sizeof(pl_step_report), offsetof(config.length), offsetof(config.inject_seed),

@@ -67,6 +67,7 @@ SIGNATURES = {
     "pl3_heat_apply": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     "pl3_heat_rhs": (C.c_int, [C.c_void_p, c_double_p]),
     "pl3_heat_solve": (C.c_int, [C.c_void_p, c_double_p, c_double_p, C.c_double, C.c_int, C.POINTER(SolveStats)]),
+    "pl3_get_solution": (C.c_int, [C.c_void_p, C.c_int, c_double_p]),
     "pl_device_info": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, c_int_p, C.POINTER(C.c_size_t)]),
     "pl_set_comm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "pl_set_comm_2d": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -528,6 +528,7 @@ struct Lev3 {
     double* eig[3] = {nullptr, nullptr, nullptr}; bool eig_valid = false;      // eigenvector of the last power iteration (warm restart)
 };
 struct pl3_ctx {
+    bool have_x = false, have_T = false;      // a device-resident Stokes / heat solution exists (pl3_get_solution)
     int device = 0; hipStream_t stream = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
     G3Host geom;
@@ -1057,7 +1058,9 @@ __global__ __launch_bounds__(256) void k3_shift(G3 g, double* __restrict__ P, co
 
 extern "C" int pl3_stokes_solve(pl3_ctx* ctx, const double* rhs, double* x, int use_x0, double rtol, int maxit, pl_solve_stats* stats) {
     if (!ctx->op_ready) return p3_fail(ctx, "stokes operator not set");
-    if (!x) return p3_fail(ctx, "pl3_stokes_solve: x is NULL");
+    // x == NULL: device-resident solve -- the solution stays in the context (pl3_get_solution fetches it), use_x0 starts from the
+    // solution the context holds from its previous solve
+    if (!x && use_x0 && !ctx->have_x) return p3_fail(ctx, "pl3_stokes_solve: no resident solution to start from");
     P3_HIP(ctx, hipSetDevice(ctx->device));
     P3_TRY(need_vecs(ctx, 14));
     if (rtol <= 0) rtol = 1e-7;
@@ -1111,7 +1114,7 @@ extern "C" int pl3_stokes_solve(pl3_ctx* ctx, const double* rhs, double* x, int 
         ref = std::sqrt(d[0]);
         if (!(ref > 1e-9 * std::sqrt(d[1]))) ref = 0.0;
     }
-    if (use_x0) P3_TRY(upload3(ctx, x, 4, X));
+    if (use_x0) { if (x) P3_TRY(upload3(ctx, x, 4, X)); }
     else for (int c = 0; c < 4; c++) P3_HIP(ctx, hipMemcpyAsync(X[c], XH[c], (size_t)vol * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     hipLaunchKernelGGL(k3_close, grid3(g), dim3(64, 4), 0, ctx->stream, ctx->op, wv3(X), cv3(B));
     double* const* w[10] = {ctx->vec[0], ctx->vec[1], ctx->vec[2], ctx->vec[3], ctx->vec[4], ctx->vec[5], ctx->vec[6], ctx->vec[7], ctx->vec[8], ctx->vec[9]};
@@ -1156,7 +1159,8 @@ extern "C" int pl3_stokes_solve(pl3_ctx* ctx, const double* rhs, double* x, int 
     P3_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     P3_HIP(ctx, hipEventSynchronize(ctx->ev1));
     float ms = 0; P3_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-    P3_TRY(download3(ctx, X, 4, x));
+    ctx->have_x = true;
+    if (x) P3_TRY(download3(ctx, X, 4, x));
     if (stats) { stats->iterations = st.iterations; stats->converged = st.converged; stats->rel_residual = st.rel_residual; stats->solve_ms = ms;
                  stats->operator_applies = napply; stats->precond_applies = nprec; stats->used_direct = 0; stats->error_estimate = st.error_estimate; }
     return 0;
@@ -1222,15 +1226,14 @@ extern "C" int pl3_heat_rhs(pl3_ctx* ctx, double* rhs) {
 }
 extern "C" int pl3_heat_solve(pl3_ctx* ctx, const double* rhs, double* x, double rtol, int maxit, pl_solve_stats* stats) {
     if (!ctx->hop_ready) return p3_fail(ctx, "heat operator not set");
-    if (!x) return p3_fail(ctx, "pl3_heat_solve: x is NULL");
-    P3_HIP(ctx, hipSetDevice(ctx->device));
+    P3_HIP(ctx, hipSetDevice(ctx->device));       // x == NULL: the solution stays on the device (pl3_get_solution)
     P3_TRY(need_hvecs(ctx));
     if (rtol <= 0) rtol = 1e-12;
     if (maxit <= 0) maxit = 2000;
     const G3& g = ctx->geom.d;
     P3_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     double* B[1] = {ctx->hvec[10]}; double* X[1] = {ctx->hvec[11]};
-    if (rhs) return p3_fail(ctx, "pl3_heat_solve: pass rhs = NULL (the operator's own right-hand side)");
+    if (rhs) return p3_fail(ctx, "pl3_heat_solve: rhs must be NULL -- the system is solved for the operator's own right-hand side (pl3_heat_rhs)");
     hipLaunchKernelGGL(k3_heat_rhs, grid3(g), dim3(64, 4), 0, ctx->stream, ctx->hop, (const double*)ctx->hT, (const double*)ctx->hH, (const double*)ctx->hbcv, B[0], 1);
     int napply = 0;
     Op3Fn A = [&](double* const* in, double* const* out) -> int {
@@ -1244,8 +1247,22 @@ extern "C" int pl3_heat_solve(pl3_ctx* ctx, const double* rhs, double* x, double
     P3_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     P3_HIP(ctx, hipEventSynchronize(ctx->ev1));
     float ms = 0; P3_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-    P3_TRY(download3(ctx, X, 1, x));
+    ctx->have_T = true;
+    if (x) P3_TRY(download3(ctx, X, 1, x));
     if (stats) { stats->iterations = st.iterations; stats->converged = st.converged; stats->rel_residual = st.rel_residual; stats->solve_ms = ms;
                  stats->operator_applies = napply; stats->precond_applies = 0; }
     return 0;
+}
+
+// the solution of the last device-resident solve: which = 0 Stokes (nz, nx, ny, 4), 1 heat (nz, nx, ny)
+extern "C" int pl3_get_solution(pl3_ctx* ctx, int which, double* out) {
+    if (!out) return p3_fail(ctx, "pl3_get_solution: NULL argument");
+    P3_HIP(ctx, hipSetDevice(ctx->device));
+    if (which == 0) {
+        if (!ctx->have_x) return p3_fail(ctx, "pl3_get_solution: no Stokes solution yet");
+        return download3(ctx, ctx->vec[11], 4, out);
+    }
+    if (!ctx->have_T) return p3_fail(ctx, "pl3_get_solution: no heat solution yet");
+    double* X[1] = {ctx->hvec[11]};
+    return download3(ctx, X, 1, out);
 }

@@ -460,17 +460,24 @@ int pl_comm_native_init(pl_ctx* ctx) {
         if (r < R - 1) m[nm++] = PlMsg{r + 1, t + 2 * cnt, cnt, t + 3 * cnt, cnt};
         pass = pass && (nm == 0 || pl_comm_sendrecv(ctx, m, nm) == 0) &&
                N->AllGather(mine, t + 4 * cnt, (size_t)cnt, PL_NCCL_DOUBLE, N->comm, ctx->stream) == 0 &&
-               N->AllReduce(t + 4 * cnt + (long long)R * cnt, t + 4 * cnt + (long long)R * cnt, 2, PL_NCCL_DOUBLE, PL_NCCL_SUM, N->comm, ctx->stream) == 0 &&
-               hipMemcpyAsync(h.data(), t, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+               N->AllReduce(t + 4 * cnt + (long long)R * cnt, t + 4 * cnt + (long long)R * cnt, 2, PL_NCCL_DOUBLE, PL_NCCL_SUM, N->comm, ctx->stream) == 0;
+        // The deadline is watched on an EVENT recorded behind the collectives: nothing on the host may wait on the stream
+        // before it has fired.  (A device-to-host copy into pageable memory -- what this used to enqueue -- blocks the host
+        // until the stream reaches it, so a hung send / receive never got to the polling loop: ADVICE r2.)
+        hipEvent_t done = nullptr;
+        pass = pass && hipEventCreateWithFlags(&done, hipEventDisableTiming) == hipSuccess && hipEventRecord(done, ctx->stream) == hipSuccess;
         if (pass) {
             const auto t0 = std::chrono::steady_clock::now();
             hipError_t q;
-            while ((q = hipStreamQuery(ctx->stream)) == hipErrorNotReady) {
+            while ((q = hipEventQuery(done)) == hipErrorNotReady) {
                 if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 60.0) { hung = true; break; }
                 std::this_thread::sleep_for(std::chrono::milliseconds(1));
             }
             if (hung || q != hipSuccess) pass = false;
         }
+        // the stream is idle now: a plain (synchronous) copy cannot block on the transport any more
+        if (pass && hipMemcpy(h.data(), t, h.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) pass = false;
+        if (done && !hung) (void)hipEventDestroy(done);
     }
     ctx->stream = main_stream;
     if (hung && N->comm) {                 // abort the communicator BEFORE the stream is abandoned: its kernels must leave the device

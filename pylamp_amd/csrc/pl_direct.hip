@@ -128,11 +128,13 @@ void pl_direct_free(pl_ctx* ctx) {
     ctx->direct = nullptr;
 }
 
-// can this context's Stokes system be factorised directly? (one rank, band storage below ~1.6 GB)
+// can this context's Stokes system be factorised directly?  One rank, band storage below ~0.5 GB (up to ~130 x 130 nodes):
+// factorisation and the triangular solves run column by column in ONE workgroup -- tens of milliseconds at 25 000 unknowns,
+// about a second at the limit; beyond it the iteration's answer stands with converged = 0
 bool pl_direct_possible(pl_ctx* ctx) {
     if (ctx->nranks != 1) return false;
     const long long n = 3LL * ctx->nz * ctx->nx, k = 3LL * (ctx->nx + 1) + 2;
-    return n * (3 * k + 1) <= 200000000LL;
+    return n * (3 * k + 1) <= 60000000LL;
 }
 
 // factorise D_r A (the row-scaled operator the Krylov solver works on)

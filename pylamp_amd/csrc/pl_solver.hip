@@ -1171,6 +1171,7 @@ struct PlSolver {
     double cheb_ratio = 6.0, lmax_safety = 1.1;     // smoothing window [lmax/ratio, lmax]; lmax = safety * power-iteration estimate
     // heat work vectors (1 plane each)
     double* h[11] = {nullptr};
+    double* hc[9] = {nullptr}; double* hc_part = nullptr; int hc_nb = 0, hc_last_its = 0;      // CG work planes (wall entries of d, r, z, p, q stay 0)
     int napply = 0, nprec = 0;
     // Early coarse branch (single rank): the levels >= early_K get R^K f -- the right-hand side itself, restricted K
     // times -- instead of the restricted residual of level K-1, which makes them independent of the pre-smoothing of the
@@ -1240,6 +1241,8 @@ void pl_solver_free(pl_ctx* ctx) {
     for (double* q : {S->r, S->rt, S->p, S->v, S->s, S->t, S->y, S->z, S->b, S->x, S->xb, S->dx, S->r0, S->xh, S->scal, S->wdefl, S->udefl})
         if (q) (void)hipFree(q);
     for (double* q : S->h) if (q) (void)hipFree(q);
+    for (double* q : S->hc) if (q) (void)hipFree(q);
+    if (S->hc_part) (void)hipFree(S->hc_part);
     if (S->hpart) (void)hipHostFree(S->hpart);
     if (S->stream2) (void)hipStreamDestroy(S->stream2);
     if (S->ev_f) (void)hipEventDestroy(S->ev_f);
@@ -2518,7 +2521,16 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
     // velocity-error estimate (see above): from the recurrence residual in every iteration near the end, from the true
     // residual before the solve is declared converged
     const bool use_est = etol > 0.0 && np_vel > 0 && np > np_vel;
-    const double n_amp = (double)std::max(ctx->nz, ctx->nx);
+    // amplification of a divergence error: domain length over the SMALLEST cell along an axis (= max(nz, nx) - 1 on a uniform grid;
+    // on a graded grid L / h_min can be far larger than the node count)
+    double n_amp = (double)std::max(ctx->nz, ctx->nx);
+    {
+        const std::vector<double>& zc = ctx->geom.zc; const std::vector<double>& xc = ctx->geom.xc;
+        double hzmin = zc.back() - zc.front(), hxmin = xc.back() - xc.front();
+        for (size_t k = 0; k + 1 < zc.size(); k++) hzmin = std::min(hzmin, zc[k + 1] - zc[k]);
+        for (size_t k = 0; k + 1 < xc.size(); k++) hxmin = std::min(hxmin, xc[k + 1] - xc[k]);
+        if (hzmin > 0.0 && hxmin > 0.0) n_amp = std::max(n_amp, std::max((zc.back() - zc.front()) / hzmin, (xc.back() - xc.front()) / hxmin));
+    }
     double est_rec = 0.0;                           // 0: unknown (far from convergence) -- only the residual test applies
     double a_mom = 1.0;                             // ||A_vv^-1 r_mom|| / ||r_mom|| as measured at the last true check (below)
     // With the pressure-anchor deflation active the component of the residual along that mode needs its own term: its
@@ -2645,8 +2657,11 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
             }
             if (w.xbest && (it - best_it > 60 || rnorm > 1e6 * best)) { broke = true; break; }       // stagnation / divergence
         }
-        if (have_best && w.xbest && !(rnorm <= 1.5 * best))
+        bool restored = false;                      // dx was replaced by the best iterate: the Krylov recurrence no longer belongs to it
+        if (have_best && w.xbest && !(rnorm <= 1.5 * best)) {
             PL_HIP(ctx, hipMemcpyAsync(dx, w.xbest, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+            restored = true;
+        }
         // ---- true residual of the current dx
         PL_TRY(A(dx, w.t));
         hipLaunchKernelGGL(k_axpy_out, grid1d(n), dim3(256), 0, ctx->stream, n, w.s, r0, w.t, -1.0);
@@ -2683,8 +2698,13 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
             if (est > etol && tol > 1e-15) {
                 tol = std::min(tol, true_norm / bnorm) * std::min(0.5, 0.7 * etol / est);
                 est_rec = est;
-                resume = true;
-                continue;                               // same Krylov iteration, smaller target
+                if (!restored) { resume = true; continue; }            // same Krylov iteration, smaller target
+                // the iterate is the restored best one: w.r / w.p / rho belong to another dx -- restart from its true residual
+                // (in w.s) instead of resuming
+                restarts++;
+                PL_HIP(ctx, hipMemcpyAsync(w.r, w.s, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+                best = true_norm; best_it = it; have_best = false;
+                continue;
             }
         }
         if (true_norm <= tol * bnorm || broke || it >= maxit || restarts >= PL_MAX_RESTARTS) break;
@@ -2696,6 +2716,7 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
     }
     if (dx != x) hipLaunchKernelGGL(k_add_inplace, grid1d(n), dim3(256), 0, ctx->stream, n, x, dx);     // x = x0 + dx
     st->iterations = it;
+    st->reserved_ = (it >= maxit && !broke) ? 1 : 0;            // ended by the caller's iteration limit (not stagnation / breakdown)
     st->rel_residual = true_norm / bnorm;
     st->converged = (st->rel_residual <= rtol && !(use_est && st->error_estimate > 1.5 * etol)) ? 1 : 0;
     return 0;
@@ -2939,7 +2960,11 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
                         "BiCGStab %.2f ms (%d iterations)\n", tph[1] - tph[0], tph[2] - tph[1], tph[3] - tph[2], tph[4] - tph[3], st->iterations);
     }
     st->used_direct = 0;
-    if (!st->converged && pl_direct_possible(ctx) && !getenv("PYLAMP_NO_DIRECT")) {
+    // (not when the iteration merely ran into a small caller-chosen maxit: the fallback is for systems the multigrid-preconditioned
+    // iteration cannot solve -- stagnation, breakdown, or the default budget exhausted)
+    const bool limit_only = st->reserved_ == 1 && maxit < 200;
+    st->reserved_ = 0;
+    if (!st->converged && !limit_only && pl_direct_possible(ctx) && !getenv("PYLAMP_NO_DIRECT")) {
         // Small system the iteration could not solve (an indefinite velocity block: the reference's stabilisation sign at the
         // Courant step): factorise D_r A (banded LU, pl_direct.hip) and let it precondition the same iteration -- the LU is exact
         // up to rounding, BiCGStab then only refines.  Restart from the hydrostatic state: the failed iterate may be far off.
@@ -3079,9 +3104,257 @@ __global__ __launch_bounds__(256) void k_heat_dinv(PlHeatOp op, double* __restri
     v[c] /= dg;
 }
 
+// -----------------------------------------------------------------------------------------------------------------
+// Conjugate gradients on the SYMMETRISED heat system (one rank).
+// The reference's backward-Euler rows (pylamp_diff.py:157-179) read  c [ (k_e dT_e - k_w dT_w) / dxb + (k_n dT_n - k_s dT_s) / dzb ] - T
+// = -T_old - c H  with c = dt / (rho Cp); multiplied by  S = -dxb dzb / c  (cell volume x heat capacity / dt) they become
+//     w_e (T - T_e) + w_w (T - T_w) + w_n (T - T_n) + w_s (T - T_s) + m T,     w_e = k_e dzb = w_w of the node to the east, ...
+// a symmetric M-matrix with positive diagonal: SPD once the wall rows are eliminated -- FIXTEMP: the wall value is known
+// (pylamp_diff.py:99-152), FIXFLOW: the wall value is its inner neighbour's plus a constant, so the coupling drops out of the
+// matrix.  The iteration solves for the CORRECTION d of a guess x0 whose wall nodes satisfy their own equations exactly
+// (k_heat_close_walls), so that d vanishes on FIXTEMP walls and copies its inner neighbour on FIXFLOW walls, and the reduced
+// residual is S times the interior rows of the reference system's residual.  Preconditioner: the diagonal.
+// One operator application per iteration (BiCGStab: two), two fused kernels per iteration:
+//     k_heat_cg_apply :  p <- z + beta p (new direction, written once),  q = A_red p,  partial p.q
+//     k_heat_cg_update:  d += alpha p,  r -= alpha q,  z = r / diag,  partial r.z, z.z
+// Stopping test: || D^-1 r || <= rtol || D^-1 b || over the interior rows -- the quantity the BiCGStab path tests -- confirmed on
+// the TRUE residual at the end.  pl_solve_stats.error_estimate: the Hestenes-Stiefel estimate of the energy-norm error,
+// sqrt(sum of the last 4 alpha_j r_j.z_j), relative to the mass-weighted norm of the temperature.
+struct HeatRed { double w[4]; double m; };          // E, W, N, S couplings kept in the matrix, and the mass term
+__device__ inline HeatRed heat_red(const PlHeatOp& op, int i, int j, long long c) {
+    const PlGeom& g = op.g;
+    const int p = g.pitch;
+    const double dzb = 1.0 / TB(op.rdzb, i), dxb = 1.0 / TB(op.rdxb, j);
+    HeatRed h;
+    h.w[0] = op.kx[c] * TB(g.rdx, j) * dzb; h.w[1] = op.kx[c - 1] * TB(g.rdx, j - 1) * dzb;
+    h.w[2] = op.kz[c] * TB(g.rdz, i) * dxb; h.w[3] = op.kz[c - p] * TB(g.rdz, i - 1) * dxb;
+    h.m = dxb * dzb / op.rhocp_inv_dt[c];
+    // a FIXFLOW wall node follows its inner neighbour: no coupling (bc = [z0, x0, zL, xL])
+    if (j + 1 == g.nx - 1 && op.bc[3] != PL_BC_FIXTEMP) h.w[0] = 0.0;
+    if (j - 1 == 0 && op.bc[1] != PL_BC_FIXTEMP) h.w[1] = 0.0;
+    if (i + 1 == g.nz - 1 && op.bc[2] != PL_BC_FIXTEMP) h.w[2] = 0.0;
+    if (i - 1 == 0 && op.bc[0] != PL_BC_FIXTEMP) h.w[3] = 0.0;
+    return h;
+}
+// wall nodes of x from their own equations and the current interior values; pass 0: x-walls (rows 1 .. nz-2), pass 1: z-walls
+// (all columns: they own the corners and read the x-wall nodes of pass 0)
+__global__ __launch_bounds__(256) void k_heat_close_walls(PlHeatOp op, double bz0, double bx0, double bzL, double bxL, double* __restrict__ x, int pass) {
+    const PlGeom& g = op.g;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int p = g.pitch;
+    if (pass == 0) {
+        if (t >= 2 * (g.nz - 2)) return;
+        const int i = 1 + t % (g.nz - 2), right = t / (g.nz - 2);
+        const long long c = pl_idx(g, i, right ? g.nx - 1 : 0);
+        if (!right) x[c] = (op.bc[1] == PL_BC_FIXTEMP) ? bx0 : x[c + 1] - bx0 / (op.kx[c] * TB(g.rdx, 0));
+        else x[c] = (op.bc[3] == PL_BC_FIXTEMP) ? bxL : x[c - 1] + bxL / (op.kx[c - 1] * TB(g.rdx, g.nx - 2));
+    } else {
+        if (t >= 2 * g.nx) return;
+        const int j = t % g.nx, bottom = t / g.nx;
+        const long long c = pl_idx(g, bottom ? g.nz - 1 : 0, j);
+        if (!bottom) x[c] = (op.bc[0] == PL_BC_FIXTEMP) ? bz0 : x[c + p] - bz0 / (op.kz[c] * TB(g.rdz, 0));
+        else x[c] = (op.bc[2] == PL_BC_FIXTEMP) ? bzL : x[c - p] + bzL / (op.kz[c - p] * TB(g.rdz, g.nz - 2));
+    }
+}
+__device__ inline void heat_block_sum3(double a0, double a1, double a2, double* __restrict__ part) {
+    __shared__ double sh[3][4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a0 += __shfl_down(a0, o, 64); a1 += __shfl_down(a1, o, 64); a2 += __shfl_down(a2, o, 64); }
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    if ((tid & 63) == 0) { sh[0][tid >> 6] = a0; sh[1][tid >> 6] = a1; sh[2][tid >> 6] = a2; }
+    __syncthreads();
+    if (tid == 0) {
+        const long long b = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+        part[3 * b] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]; part[3 * b + 1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+        part[3 * b + 2] = sh[2][0] + sh[2][1] + sh[2][2] + sh[2][3];
+    }
+}
+// mode 0 (start): r = S (b - A x) on the interior rows (x with closed walls), dinv = 1 / diag, z = r dinv, p = z, d = 0;
+//                 partials: r.z, z.z, and (first call) the reference sum_int (dinv S b)^2 in slot 2
+// mode 1 (check): r = S (b - A x) only; partials: (r dinv)^2 in slot 1
+__global__ __launch_bounds__(256) void k_heat_cg_residual(PlHeatOp op, const double* __restrict__ b, const double* __restrict__ x, double* __restrict__ r,
+                                                          double* __restrict__ dinv, double* __restrict__ z, double* __restrict__ pdir, double* __restrict__ d,
+                                                          int mode, double* __restrict__ part) {
+    const PlGeom& g = op.g;
+    const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    if (i >= 1 && i <= g.nz - 2 && j >= 1 && j <= g.nx - 2) {
+        const long long c = pl_idx(g, i, j);
+        const int p = g.pitch;
+        const double dzb = 1.0 / TB(op.rdzb, i), dxb = 1.0 / TB(op.rdxb, j), t = x[c];
+        const double wE = op.kx[c] * TB(g.rdx, j) * dzb, wW = op.kx[c - 1] * TB(g.rdx, j - 1) * dzb;
+        const double wN = op.kz[c] * TB(g.rdz, i) * dxb, wS = op.kz[c - p] * TB(g.rdz, i - 1) * dxb, m = dxb * dzb / op.rhocp_inv_dt[c];
+        // S x (reference row) with the actual wall values of x: S b - [ w (t - T_nb) ... + m t ]
+        const double Sb = -m * b[c];                       // S b = -dxb dzb / c * b
+        const double res = Sb - (wE * (t - x[c + 1]) + wW * (t - x[c - 1]) + wN * (t - x[c + p]) + wS * (t - x[c - p]) + m * t);
+        const HeatRed h = heat_red(op, i, j, c);
+        const double di = 1.0 / (h.w[0] + h.w[1] + h.w[2] + h.w[3] + h.m);
+        r[c] = res;
+        const double zz = res * di;
+        if (mode == 0) { dinv[c] = di; z[c] = zz; pdir[c] = zz; d[c] = 0.0; s0 = res * zz; s1 = zz * zz; s2 = (Sb * di) * (Sb * di); }
+        else s1 = zz * zz;
+    }
+    heat_block_sum3(s0, s1, s2, part);
+}
+// p_new = z + beta p_old at the node and its four neighbours (beta = sc[3]; first iteration: use_beta = 0, p_old holds z), q = A_red p_new
+__global__ __launch_bounds__(256) void k_heat_cg_apply(PlHeatOp op, const double* __restrict__ z, const double* __restrict__ pold, double* __restrict__ pnew,
+                                                       double* __restrict__ q, const double* __restrict__ sc, int use_beta, double* __restrict__ part) {
+    const PlGeom& g = op.g;
+    const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
+    double s0 = 0.0;
+    if (i >= 1 && i <= g.nz - 2 && j >= 1 && j <= g.nx - 2) {
+        const long long c = pl_idx(g, i, j);
+        const int p = g.pitch;
+        const double beta = use_beta ? sc[3] : 0.0;
+        auto pv = [&](long long k) { return use_beta ? z[k] + beta * pold[k] : pold[k]; };     // wall entries of z and p are 0 and stay 0
+        const double pc = pv(c);
+        const HeatRed h = heat_red(op, i, j, c);
+        const double qq = h.w[0] * (pc - pv(c + 1)) + h.w[1] * (pc - pv(c - 1)) + h.w[2] * (pc - pv(c + p)) + h.w[3] * (pc - pv(c - p)) + h.m * pc;
+        pnew[c] = pc; q[c] = qq;
+        s0 = pc * qq;
+    }
+    heat_block_sum3(s0, 0.0, 0.0, part);
+}
+// alpha = sc[2]:  d += alpha p,  r -= alpha q,  z = r dinv;  partials r.z, z.z
+__global__ __launch_bounds__(256) void k_heat_cg_update(PlGeom g, const double* __restrict__ pdir, const double* __restrict__ q, const double* __restrict__ dinv,
+                                                        double* __restrict__ d, double* __restrict__ r, double* __restrict__ z, const double* __restrict__ sc,
+                                                        double* __restrict__ part) {
+    const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
+    double s0 = 0.0, s1 = 0.0;
+    if (i >= 1 && i <= g.nz - 2 && j >= 1 && j <= g.nx - 2) {
+        const long long c = pl_idx(g, i, j);
+        const double alpha = sc[2];
+        d[c] += alpha * pdir[c];
+        const double rn = r[c] - alpha * q[c];
+        r[c] = rn;
+        const double zz = rn * dinv[c];
+        z[c] = zz;
+        s0 = rn * zz; s1 = zz * zz;
+    }
+    heat_block_sum3(s0, s1, 0.0, part);
+}
+// sums of the block partials and the CG scalars: sc[0] = r.z (current), sc[1] = z.z, sc[2] = alpha, sc[3] = beta, sc[4] = p.q, sc[5] = reference
+// what 0: start (sc[0] = r.z, sc[1] = z.z, sc[5] = ref);  1: after apply (sc[4] = p.q, alpha = sc[0] / p.q);
+//      2: after update (beta = r.z_new / sc[0], sc[6] = alpha * old r.z (Hestenes-Stiefel term), sc[0] = r.z_new, sc[1] = z.z);  3: check (sc[1] = z.z)
+__global__ __launch_bounds__(256) void k_heat_cg_scalars(int nb, const double* __restrict__ part, double* __restrict__ sc, int what) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int k = threadIdx.x; k < nb; k += 256) { a0 += part[3 * k]; a1 += part[3 * k + 1]; a2 += part[3 * k + 2]; }
+    __shared__ double sh[3][4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a0 += __shfl_down(a0, o, 64); a1 += __shfl_down(a1, o, 64); a2 += __shfl_down(a2, o, 64); }
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = a0; sh[1][threadIdx.x >> 6] = a1; sh[2][threadIdx.x >> 6] = a2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a0 = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]; a1 = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]; a2 = sh[2][0] + sh[2][1] + sh[2][2] + sh[2][3];
+        if (what == 0) { sc[0] = a0; sc[1] = a1; sc[5] = a2; }
+        else if (what == 1) { sc[4] = a0; sc[2] = (a0 > 0.0) ? sc[0] / a0 : 0.0; }
+        else if (what == 2) { sc[3] = (sc[0] > 0.0) ? a0 / sc[0] : 0.0; sc[6] = sc[2] * sc[0]; sc[0] = a0; sc[1] = a1; }
+        else sc[1] = a1;
+    }
+}
+__global__ __launch_bounds__(256) void k_heat_mass_norm(PlHeatOp op, const double* __restrict__ x, double* __restrict__ part) {
+    const PlGeom& g = op.g;
+    const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
+    double s0 = 0.0;
+    if (i >= 1 && i <= g.nz - 2 && j >= 1 && j <= g.nx - 2) {
+        const long long c = pl_idx(g, i, j);
+        s0 = x[c] * x[c] / (TB(op.rdzb, i) * TB(op.rdxb, j) * op.rhocp_inv_dt[c]);
+    }
+    heat_block_sum3(s0, 0.0, 0.0, part);
+}
+
+static int heat_solve_cg(pl_ctx* ctx, PlSolver* S, const double* b_dev, double rtol, int maxit, pl_solve_stats* st, double** x_out,
+                         const double* x0_dev) {
+    const PlGeom& g = ctx->geom.d;
+    const size_t pb = (size_t)g.plane * sizeof(double);
+    for (int k = 0; k < 9; k++) if (!S->hc[k]) PL_TRY(dmalloc0(ctx, &S->hc[k], pb));
+    if (!S->scal) {
+        PL_TRY(dmalloc0(ctx, &S->scal, (PL_SCAL_N + 8 * DOT_BLOCKS) * sizeof(double)));
+        PL_HIP(ctx, hipHostMalloc((void**)&S->hpart, (8 * DOT_BLOCKS + PL_SCAL_N) * sizeof(double)));
+    }
+    const dim3 gr = grid2d(g), bl(64, 4);
+    const int nb = (int)(gr.x * gr.y);
+    if (!S->hc_part || S->hc_nb < nb) {
+        if (S->hc_part) (void)hipFree(S->hc_part);
+        PL_TRY(dmalloc0(ctx, &S->hc_part, (size_t)3 * nb * sizeof(double)));
+        S->hc_nb = nb;
+    }
+    PL_TRY(pl_timer_start(ctx));
+    const PlHeatOp hop = ctx->hop;
+    double *x = S->hc[0], *d = S->hc[1], *r = S->hc[2], *z = S->hc[3], *q = S->hc[4], *dinv = S->hc[5], *pa = S->hc[6], *pbuf = S->hc[7];
+    double* sc = S->scal; double* hs = S->hpart;
+    if (x0_dev) PL_HIP(ctx, hipMemcpyAsync(x, x0_dev, pb, hipMemcpyDeviceToDevice, ctx->stream));
+    else PL_HIP(ctx, hipMemsetAsync(x, 0, pb, ctx->stream));
+    const double* bv = ctx->heat_bcvalue;
+    auto close_walls = [&](double* v) {
+        hipLaunchKernelGGL(k_heat_close_walls, dim3((2 * (g.nz - 2) + 255) / 256), dim3(256), 0, ctx->stream, hop, bv[0], bv[1], bv[2], bv[3], v, 0);
+        hipLaunchKernelGGL(k_heat_close_walls, dim3((2 * g.nx + 255) / 256), dim3(256), 0, ctx->stream, hop, bv[0], bv[1], bv[2], bv[3], v, 1);
+    };
+    auto fetch = [&]() -> int {
+        PL_HIP(ctx, hipMemcpyAsync(hs, sc, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return 0;
+    };
+    close_walls(x);
+    hipLaunchKernelGGL(k_heat_mass_norm, gr, bl, 0, ctx->stream, hop, (const double*)x, S->hc_part);
+    hipLaunchKernelGGL(k_heat_cg_scalars, dim3(1), dim3(256), 0, ctx->stream, nb, (const double*)S->hc_part, sc, 1);     // -> sc[4]
+    PL_TRY(fetch());
+    const double xmass = hs[4];
+    st->iterations = 0; st->converged = 0; st->rel_residual = 0.0; st->error_estimate = 0.0;
+    S->napply = 0;
+    double ref = 0.0, hist[4] = {0, 0, 0, 0};
+    int it = 0;
+    for (int pass = 0; pass < 5; pass++) {               // (re)start from the true residual of the current x = x0 + d (the last pass only checks)
+        hipLaunchKernelGGL(k_heat_cg_residual, gr, bl, 0, ctx->stream, hop, b_dev, (const double*)x, r, dinv, z, pa, d, 0, S->hc_part);
+        hipLaunchKernelGGL(k_heat_cg_scalars, dim3(1), dim3(256), 0, ctx->stream, nb, (const double*)S->hc_part, sc, 0);
+        S->napply++;
+        PL_TRY(fetch());
+        if (pass == 0) ref = std::sqrt(hs[5]);
+        double znorm = std::sqrt(hs[1]);
+        if (!(ref > 0.0)) { st->converged = 1; break; }      // b = 0 on the interior: x0 with closed walls is the answer
+        st->rel_residual = znorm / ref;
+        if (znorm <= rtol * ref || it >= maxit || pass == 4) { st->converged = znorm <= rtol * ref ? 1 : 0; break; }
+        double* pold = pa; double* pnew = pbuf;
+        bool first = true, ok = true;
+        while (it < maxit) {
+            it++;
+            hipLaunchKernelGGL(k_heat_cg_apply, gr, bl, 0, ctx->stream, hop, (const double*)z, (const double*)pold, pnew, q, (const double*)sc, first ? 0 : 1, S->hc_part);
+            hipLaunchKernelGGL(k_heat_cg_scalars, dim3(1), dim3(256), 0, ctx->stream, nb, (const double*)S->hc_part, sc, 1);
+            hipLaunchKernelGGL(k_heat_cg_update, gr, bl, 0, ctx->stream, g, (const double*)pnew, (const double*)q, (const double*)dinv, d, r, z, (const double*)sc, S->hc_part);
+            hipLaunchKernelGGL(k_heat_cg_scalars, dim3(1), dim3(256), 0, ctx->stream, nb, (const double*)S->hc_part, sc, 2);
+            S->napply++;
+            std::swap(pold, pnew); first = false;
+            // the host only looks at the scalars (one stream synchronisation, ~35 us) where the iteration may end: from three iterations
+            // before the previous solve's count on (consecutive time steps need the same number to within one or two)
+            if (it + 3 < S->hc_last_its && it < maxit) continue;
+            PL_TRY(fetch());
+            hist[it & 3] = hs[6];
+            znorm = std::sqrt(hs[1]);
+            if (!std::isfinite(znorm) || !(hs[4] > 0.0)) { ok = false; break; }
+            if (znorm <= rtol * ref) break;
+        }
+        // x = x0 + d with its wall nodes re-closed; the next pass confirms the TRUE residual (and restarts from it if need be)
+        hipLaunchKernelGGL(k_add_inplace, grid1d(g.plane), dim3(256), 0, ctx->stream, (long long)g.plane, x, (const double*)d);
+        close_walls(x);
+        if (!ok) break;
+    }
+    PL_HIP(ctx, hipGetLastError());
+    st->iterations = it;
+    S->hc_last_its = st->converged ? it : 0;
+    if (xmass > 0.0) st->error_estimate = std::sqrt(std::fabs(hist[0]) + std::fabs(hist[1]) + std::fabs(hist[2]) + std::fabs(hist[3])) / std::sqrt(xmass);
+    double ms = 0;
+    PL_TRY(pl_timer_stop_ms(ctx, &ms));
+    st->solve_ms = ms; st->operator_applies = S->napply; st->precond_applies = 0;
+    *x_out = x;
+    return 0;
+}
+
 int pl_heat_solve_device(pl_ctx* ctx, const double* b_dev, double rtol, int maxit, pl_solve_stats* st,
                          double** x_out, const double* x0_dev) {
     PlSolver* S = solver_of(ctx);
+    // one rank: CG on the symmetrised system (PYLAMP_HEAT_CG=0: the Jacobi-scaled BiCGStab below, which several ranks still use)
+    static const bool use_cg = !(getenv("PYLAMP_HEAT_CG") && atoi(getenv("PYLAMP_HEAT_CG")) == 0);
+    if (use_cg && ctx->nranks == 1 && ctx->nz >= 3 && ctx->nx >= 3) return heat_solve_cg(ctx, S, b_dev, rtol, maxit, st, x_out, x0_dev);
     const PlGeom& g = ctx->geom.d;
     size_t pb = (size_t)g.plane * sizeof(double);
     for (int k = 0; k < 11; k++) if (!S->h[k]) PL_TRY(dmalloc0(ctx, &S->h[k], pb));

@@ -1297,7 +1297,7 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
                                           cfg->stokes_maxit > 0 ? cfg->stokes_maxit : 400, &st2));
             rep->stokes_resolves++;
             rep->stokes.iterations += st2.iterations; rep->stokes.converged &= st2.converged;
-            rep->stokes.rel_residual = st2.rel_residual; rep->stokes.solve_ms += st2.solve_ms;
+            rep->stokes.rel_residual = st2.rel_residual; rep->stokes.error_estimate = st2.error_estimate; rep->stokes.solve_ms += st2.solve_ms;
             rep->stokes.operator_applies += st2.operator_applies; rep->stokes.precond_applies += st2.precond_applies;
             rep->stokes.used_direct |= st2.used_direct;
             PL_TRY(reduce_minmax(ctx, S, g, p_vz, nullptr, nullptr, 0, &mn, &vmax_z, &hn));

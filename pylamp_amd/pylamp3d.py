@@ -56,6 +56,12 @@ class Context3:
         self.h = h
         self._fin = weakref.finalize(self, lib.pl3_destroy, h)
 
+    def handle(self):
+        """Native handle for a library call; a closed context raises instead of handing NULL to C."""
+        if self.h is None:
+            raise Exception("pylamp_amd: this 3-D context has been closed")
+        return self.h
+
     def check(self, rc):
         if self.h is None:
             raise Exception("pylamp_amd: this 3-D context has been closed")
@@ -84,7 +90,7 @@ class StokesOperator3:
         self.dtype = np.dtype(np.float64)
         self.last_stats = None
         kc = C.c_double(); kb = C.c_double()
-        ctx.check(ctx.lib.pl3_stokes_get_scaling(ctx.h, C.byref(kc), C.byref(kb)))
+        ctx.check(ctx.lib.pl3_stokes_get_scaling(ctx.handle(), C.byref(kc), C.byref(kb)))
         self.Kcont, self.Kbond = kc.value, kb.value
 
     def matvec(self, x):
@@ -92,7 +98,7 @@ class StokesOperator3:
         if x.size != self.shape[0]:
             raise Exception("dimension mismatch")
         y = np.empty_like(x)
-        self._ctx.check(self._ctx.lib.pl3_stokes_apply(self._ctx.h, _lib.dptr(x), _lib.dptr(y)))
+        self._ctx.check(self._ctx.lib.pl3_stokes_apply(self._ctx.handle(), _lib.dptr(x), _lib.dptr(y)))
         return y
 
     dot = matvec
@@ -102,17 +108,17 @@ class StokesOperator3:
 
     def rhs(self):
         r = np.empty(self.shape[0])
-        self._ctx.check(self._ctx.lib.pl3_stokes_rhs(self._ctx.h, _lib.dptr(r)))
+        self._ctx.check(self._ctx.lib.pl3_stokes_rhs(self._ctx.handle(), _lib.dptr(r)))
         return r
 
     def apply_bench(self, reps=20, scaled=True):
         ms = C.c_double()
-        self._ctx.check(self._ctx.lib.pl3_stokes_apply_bench(self._ctx.h, 1 if scaled else 0, int(reps), C.byref(ms)))
+        self._ctx.check(self._ctx.lib.pl3_stokes_apply_bench(self._ctx.handle(), 1 if scaled else 0, int(reps), C.byref(ms)))
         return ms.value
 
     def mg_info(self):
         n = C.c_int(); lm = (C.c_double * 32)()
-        self._ctx.check(self._ctx.lib.pl3_stokes_mg_info(self._ctx.h, C.byref(n), lm, 32))
+        self._ctx.check(self._ctx.lib.pl3_stokes_mg_info(self._ctx.handle(), C.byref(n), lm, 32))
         return n.value, [lm[k] for k in range(n.value)]
 
 
@@ -128,19 +134,28 @@ def makeStokesMatrix(nx, grid, f_etas, f_etan, f_rho, bc=None, grav=None, device
     shp = ctx.nx
     es, en, rho = _f3(f_etas, shp), _f3(f_etan, shp), _f3(f_rho, shp)
     g = None if grav is None else (C.c_double * 3)(*[float(v) for v in grav])
-    ctx.check(ctx.lib.pl3_stokes_set_coeffs(ctx.h, _lib.dptr(es), _lib.dptr(en), _lib.dptr(rho), g))
-    ctx.check(ctx.lib.pl3_stokes_set_wall_rows(ctx.h, 1 if strict_reference else 0))
+    ctx.check(ctx.lib.pl3_stokes_set_coeffs(ctx.handle(), _lib.dptr(es), _lib.dptr(en), _lib.dptr(rho), g))
+    ctx.check(ctx.lib.pl3_stokes_set_wall_rows(ctx.handle(), 1 if strict_reference else 0))
     A = StokesOperator3(ctx)
     return A, A.rhs()
 
 
-def solve(A, rhs=None, x0=None, rtol=DEFAULT_RTOL, maxit=DEFAULT_MAXIT):
-    """x = A^-1 rhs (rhs None: the operator's own right-hand side): multigrid-preconditioned BiCGStab on the GPU."""
+def solve(A, rhs=None, x0=None, rtol=DEFAULT_RTOL, maxit=DEFAULT_MAXIT, resident=False, warm=False):
+    """x = A^-1 rhs (rhs None: the operator's own right-hand side): multigrid-preconditioned BiCGStab on the GPU.
+    resident=True: nothing crosses PCIe -- the operator's own right-hand side, the solution stays on the device (returns None;
+    solution(A) fetches it), warm=True starts from the previous resident solution."""
     ctx = A._ctx
+    if resident:
+        if rhs is not None or x0 is not None:
+            raise Exception("solve(resident=True) works on the operator's own right-hand side and the resident solution")
+        st = _lib.SolveStats()
+        ctx.check(ctx.lib.pl3_stokes_solve(ctx.handle(), None, None, 1 if warm else 0, float(rtol), int(maxit), C.byref(st)))
+        A.last_stats = st.as_dict()
+        return None
     x = np.zeros(A.shape[0]) if x0 is None else _lib.f64(x0).reshape(-1).copy()
     st = _lib.SolveStats()
     r = None if rhs is None else _lib.dptr(_lib.f64(rhs).reshape(-1))
-    ctx.check(ctx.lib.pl3_stokes_solve(ctx.h, r, _lib.dptr(x), 0 if x0 is None else 1, float(rtol), int(maxit), C.byref(st)))
+    ctx.check(ctx.lib.pl3_stokes_solve(ctx.handle(), r, _lib.dptr(x), 0 if x0 is None else 1, float(rtol), int(maxit), C.byref(st)))
     A.last_stats = st.as_dict()
     return x
 
@@ -155,7 +170,7 @@ class HeatOperator3:
     def matvec(self, x):
         x = _lib.f64(x).reshape(-1)
         y = np.empty_like(x)
-        self._ctx.check(self._ctx.lib.pl3_heat_apply(self._ctx.h, _lib.dptr(x), _lib.dptr(y)))
+        self._ctx.check(self._ctx.lib.pl3_heat_apply(self._ctx.handle(), _lib.dptr(x), _lib.dptr(y)))
         return y
 
     def __matmul__(self, x):
@@ -163,7 +178,7 @@ class HeatOperator3:
 
     def rhs(self):
         r = np.empty(self.shape[0])
-        self._ctx.check(self._ctx.lib.pl3_heat_rhs(self._ctx.h, _lib.dptr(r)))
+        self._ctx.check(self._ctx.lib.pl3_heat_rhs(self._ctx.handle(), _lib.dptr(r)))
         return r
 
 
@@ -175,15 +190,28 @@ def makeDiffusionMatrix(nx, grid, gridmp, f_T, f_k, f_Cp, f_rho, f_H, bc, bcvalu
     arrs = [_f3(a, shp) for a in (f_T, f_k[0], f_k[1], f_k[2], f_Cp, f_rho, f_H)]
     mp = [np.ascontiguousarray(m, dtype=np.float64) for m in gridmp]
     bc_arr = (C.c_int * 6)(*[int(b) for b in bc]); bv = (C.c_double * 6)(*[float(b) for b in bcvalue])
-    ctx.check(ctx.lib.pl3_heat_set_coeffs(ctx.h, *[_lib.dptr(m) for m in mp], *[_lib.dptr(a) for a in arrs], bc_arr, bv, float(tstep)))
+    ctx.check(ctx.lib.pl3_heat_set_coeffs(ctx.handle(), *[_lib.dptr(m) for m in mp], *[_lib.dptr(a) for a in arrs], bc_arr, bv, float(tstep)))
     A = HeatOperator3(ctx)
     return A, A.rhs()
 
 
-def solve_heat(A, rtol=1e-12, maxit=2000):
+def solution(A, heat=False):
+    """The device-resident solution of the last solve(A, resident=True) / solve_heat(A, resident=True)."""
     ctx = A._ctx
     x = np.zeros(A.shape[0])
+    ctx.check(ctx.lib.pl3_get_solution(ctx.handle(), 1 if heat else 0, _lib.dptr(x)))
+    return x
+
+
+def solve_heat(A, rtol=1e-12, maxit=2000, resident=False):
+    ctx = A._ctx
+    if resident:
+        st = _lib.SolveStats()
+        ctx.check(ctx.lib.pl3_heat_solve(ctx.handle(), None, None, float(rtol), int(maxit), C.byref(st)))
+        A.last_stats = st.as_dict()
+        return None
+    x = np.zeros(A.shape[0])
     st = _lib.SolveStats()
-    ctx.check(ctx.lib.pl3_heat_solve(ctx.h, None, _lib.dptr(x), float(rtol), int(maxit), C.byref(st)))
+    ctx.check(ctx.lib.pl3_heat_solve(ctx.handle(), None, _lib.dptr(x), float(rtol), int(maxit), C.byref(st)))
     A.last_stats = st.as_dict()
     return x

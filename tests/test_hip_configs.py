@@ -49,6 +49,38 @@ def test_config2_513_mantle_vs_direct_solve(oracle):
     assert Ah.last_stats["converged"] == 1 and relerr(Tn, Tr) < 1e-6, (relerr(Tn, Tr), Ah.last_stats)
 
 
+@pytest.mark.parametrize("model,seed", [("block", 20260104), ("mantle", 777)])
+def test_stopping_rule_513_vs_direct_solve(oracle, model, seed):
+    """Evidence for the Stokes stopping rule (true residual <= rtol AND estimated velocity error <= 3e-8, pl_solve_stats) on
+    the cases a regression of the estimate would hurt first: the 10^3 falling block of pylamp2.py:172-183 at 513^2 (the slow
+    case: a sharp viscosity jump, twice the iterations of the mantle model) and a second seed of the mantle model.  Fields from
+    16 markers per node as the step builds them; the direct solve is scipy's on the oracle's explicit matrix.  Asserted: the
+    TRUE velocity error is below the drop-in's 1e-6, and the estimate is not optimistic by more than 4x."""
+    from pylamp_amd import driver, pylamp_stokes as S
+    n = 513; nx = [n, n]; L = [660e3, 660e3]
+    grid = [np.linspace(0, L[0], n), np.linspace(0, L[1], n)]
+    gmp = oracle.gridmp_of(grid)
+    rng = np.random.default_rng(seed)
+    if model == "block":
+        tr_x, tr_f = driver.falling_block_tracers(nx, L, 16, rng)
+        oracle.property_update(tr_f, False, False)
+    else:
+        tr_x, tr_f = driver.mantle_tracers(nx, L, 16, rng, perturb=35.0)
+        oracle.property_update(tr_f, True, True)
+    rho, etas = oracle.trac2grid(tr_x, tr_f[:, [0, 1]], grid, nx, [5, 6])
+    etan, = oracle.trac2grid(tr_x, tr_f[:, [1]], gmp, nx, [6])
+    bc = [1, 1, 1, 1]
+    A, rhs = S.makeStokesMatrix(nx, grid, etas, etan, rho, bc)
+    x = S.solve(A, rhs)                                           # default rtol / maxit / error bound
+    st = A.last_stats
+    xr = oracle.stokes_solve(nx, grid, etas, etan, rho, bc)
+    (vz, vx), _ = S.x2vp(x, nx); (rz, rx), _ = oracle.x2vp(xr, nx)
+    err = np.sqrt((np.sum((vz - rz) ** 2) + np.sum((vx - rx) ** 2)) / (np.sum(rz ** 2) + np.sum(rx ** 2)))
+    assert st["converged"] == 1 and st["rel_residual"] <= S.DEFAULT_RTOL, st
+    assert err < 1e-6, (err, st)
+    assert st["error_estimate"] <= 4.5e-8 and st["error_estimate"] >= err / 4.0, (err, st)
+
+
 def test_config3_2049_67M_tracers(oracle):
     from pylamp_amd import driver, pylamp_trac as T
     n = 2049; nx = [n, n]; L = [660e3, 660e3]; dens = 16
