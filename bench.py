@@ -153,12 +153,13 @@ def cpu_baseline(n=257, tracdens=16, steps=1):
     tr_x, tr_f = driver.mantle_tracers(nx, L, tracdens, rng)
     st = dict(nx=nx, L=L, grid=[np.linspace(0, L[0], n), np.linspace(0, L[1], n)], tr_x=tr_x, tr_f=tr_f)
     cfg = O.StepConfig()
-    t0 = time.perf_counter()
+    t0 = time.perf_counter(); c0 = time.process_time()
     for it in range(1, steps + 1):
         O.step(st, cfg, it)
     dt = time.perf_counter() - t0
+    busy = (time.process_time() - c0) / dt           # cores the process actually kept busy (NumPy is single-threaded, SuperLU / BLAS may not be)
     cells = (n - 1) * (n - 1)
-    return {"value": round(cells * steps / dt, 1), "unit": "cell-updates/s", "cores": 1, "kind": "port",
+    return {"value": round(cells * steps / dt, 1), "unit": "cell-updates/s", "cores": max(1, int(round(busy))), "cores_busy": round(busy, 2), "kind": "port",
             "sample": "full step (scatter, scipy spsolve Stokes, heat, gather, RK4), mantle model, %dx%d nodes, "
                       "%d markers/node, %d step(s), %.1f s; the direct solve is infeasible at 2049^2" %
                       (n, n, tracdens, steps, dt),
@@ -187,14 +188,15 @@ def bench_3d(args):
     dt = 0.67 * (L[0] / (n - 1)) ** 2 / np.max(2 * 4.0 / (rho * 1250.0))
     Ah, _ = P3.makeDiffusionMatrix([n, n, n], grid, mid, Tn, [k, k, k], cp, rho, H, [0, 1, 1, 0, 1, 1], [273.0, 0, 0, 1623.0, 0, 0], dt, ctx=ctx)
     its, hits, res = [], [], []
-    x = None
+    # device-resident solves: coefficients are on the GPU, the solutions stay there (pl3_get_solution fetches them afterwards);
+    # every solve is a cold start from the hydrostatic state / from zero
     for s_ in range(args.warmup):
-        x = P3.solve(A); P3.solve_heat(Ah)
+        P3.solve(A, resident=True); P3.solve_heat(Ah, resident=True)
     t0 = time.perf_counter()
     for s_ in range(args.steps):
-        x = P3.solve(A); its.append(A.last_stats["iterations"]); res.append(A.last_stats["rel_residual"])
+        P3.solve(A, resident=True); its.append(A.last_stats["iterations"]); res.append(A.last_stats["rel_residual"])
         conv = A.last_stats["converged"]
-        P3.solve_heat(Ah); hits.append(Ah.last_stats["iterations"])
+        P3.solve_heat(Ah, resident=True); hits.append(Ah.last_stats["iterations"])
     el = time.perf_counter() - t0
     cells = (n - 1) ** 3
     ms_s = A.apply_bench(20, True); ms_p = A.apply_bench(20, False)
@@ -203,7 +205,7 @@ def bench_3d(args):
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "3D %d^3 nodes staggered Stokes (4 DOF/node, T-dependent viscosity 1e20..1e23) + implicit heat, one solve of each per step; "
-                                  "host arrays in and out through the module API (PCIe inside the timed region)" % n, "parallelism": "1 GPU",
+                                  "device-resident (coefficients uploaded before, solutions left on the GPU: no PCIe in the timed region)" % n, "parallelism": "1 GPU",
                       "parity": "unpinned (the reference is 2-D only)"},
            "stokes_iterations": its, "stokes_converged": conv, "stokes_rel_residual": [float("%.3g" % r) for r in res], "heat_iterations": hits,
            "roofline": {"kernel": "k3_apply<true> (3-D row-scaled Stokes stencil)", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
@@ -275,6 +277,8 @@ def main():
     ctx.check(ctx.lib.pl_sync(ctx.h))
     cc = (C.c_int64 * 4)()
     ctx.check(ctx.lib.pl_comm_stats(ctx.h, cc, 1))          # counts of the timed region only
+    ct = (C.c_double * 4)()
+    ctx.check(ctx.lib.pl_comm_times(ctx.h, ct, 1))
     barrier()
     t0 = time.perf_counter()
     timed = []
@@ -285,6 +289,8 @@ def main():
     elapsed = time.perf_counter() - t0
     ctx.check(ctx.lib.pl_comm_stats(ctx.h, cc, 0))
     comm_calls = [int(v) for v in cc]
+    ctx.check(ctx.lib.pl_comm_times(ctx.h, ct, 0))
+    comm_ms = [float(v) for v in ct]
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -341,6 +347,8 @@ def main():
             "time_steps_per_s": round(args.steps / elapsed, 4),
             "stage_ms": stages,
             "stokes_iterations": [r["stokes"]["iterations"] for r in timed],
+            "stokes_precond_applies": [r["stokes"]["precond_applies"] for r in timed],
+            "stokes_operator_applies": [r["stokes"]["operator_applies"] for r in timed],
             "stokes_rel_residual": [float("%.3g" % r["stokes"]["rel_residual"]) for r in timed],
             "stokes_converged": [r["stokes"]["converged"] for r in timed],
             "stokes_error_estimate": [float("%.3g" % r["stokes"]["error_estimate"]) for r in timed],
@@ -350,6 +358,12 @@ def main():
         }
         if world > 1:       # communication calls of rank 0 per timed step (halo exchanges, all-gathers, device / host all-reduces)
             out["comm_calls_per_step"] = [round(c / float(args.steps), 1) for c in comm_calls]
+            # rank 0's time inside them per step: [halo exchanges incl. pack / unpack, all-gathers, device all-reduces] between HIP
+            # events on the solver stream, [host all-reduces] host wall time
+            out["comm_ms_per_step"] = [round(v / float(args.steps), 3) for v in comm_ms]
+            out["transport"] = ("native RCCL (ncclSend/Recv groups, ncclAllReduce on the solver stream)" if (sim.ctx.comm is not None and sim.ctx.comm.native)
+                                else "torch.distributed callbacks (%s), host-synchronous" % (dist.get_backend() if dist is not None else "-"))
+            out["scaling_note"] = "no multi-GPU node was available to the build: N > 1 has only been rehearsed with virtual ranks / gloo on one GPU"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -115,6 +115,10 @@ int  pl_comm_info(pl_ctx* ctx, int* rank, int* nranks, int* native);
 /* Cumulative numbers of communication calls of this context: out[0] neighbour (halo) exchanges, [1] all-gathers,
  * [2] device all-reduces, [3] host all-reduces; reset != 0 clears the counters after reading. */
 int  pl_comm_stats(pl_ctx* ctx, int64_t out[4], int reset);
+/* Milliseconds spent in them since the last reset: out_ms[0..2] device time between HIP events recorded around every neighbour
+ * exchange (pack -> messages -> unpack), all-gather and device all-reduce on the context stream; out_ms[3] host wall time of
+ * the host all-reduces.  Synchronises the stream. */
+int  pl_comm_times(pl_ctx* ctx, double out_ms[4], int reset);
 /* raw copies between host and this context's device memory (used by the gloo fallback of the
  * communication layer, which stages through host buffers) */
 int  pl_memcpy_d2h(pl_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);

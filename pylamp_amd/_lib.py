@@ -79,6 +79,7 @@ SIGNATURES = {
     "pl_set_comm_local": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "pl_comm_info": (C.c_int, [C.c_void_p, c_int_p, c_int_p, c_int_p]),
     "pl_comm_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
+    "pl_comm_times": (C.c_int, [C.c_void_p, c_double_p, C.c_int]),
     "pl_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "pl_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "pl_dev_add": (C.c_int, [C.c_void_p, c_double_p, c_double_p, C.c_int64]),

@@ -177,9 +177,43 @@ int pl_comm_sendrecv(pl_ctx* ctx, const PlMsg* msgs, int nmsg) {
     return 0;
 }
 
+// ---- time spent in communication (pl_comm_times) -----------------------------------------------------------------------
+#define PL_COMM_EV_MAX 8192
+int pl_comm_time_begin(pl_ctx* ctx, int kind) {
+    if (ctx->comm_ev_used >= PL_COMM_EV_MAX) return -1;
+    const size_t slot = ctx->comm_ev_used;
+    if (ctx->comm_ev.size() < 2 * (slot + 1)) {
+        hipEvent_t a = nullptr, b = nullptr;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
+        ctx->comm_ev.push_back(a); ctx->comm_ev.push_back(b); ctx->comm_ev_kind.push_back(kind);
+    }
+    ctx->comm_ev_kind[slot] = kind;
+    (void)hipEventRecord(ctx->comm_ev[2 * slot], ctx->stream);
+    ctx->comm_ev_used++;
+    return (int)slot;
+}
+void pl_comm_time_end(pl_ctx* ctx, int slot) { if (slot >= 0) (void)hipEventRecord(ctx->comm_ev[2 * slot + 1], ctx->stream); }
+struct PlCommTimer {
+    pl_ctx* ctx; int slot;
+    PlCommTimer(pl_ctx* c, int kind) : ctx(c), slot(pl_comm_time_begin(c, kind)) {}
+    ~PlCommTimer() { pl_comm_time_end(ctx, slot); }
+};
+extern "C" int pl_comm_times(pl_ctx* ctx, double out_ms[4], int reset) {
+    PL_HIP(ctx, hipSetDevice(ctx->device));
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t k = 0; k < ctx->comm_ev_used; k++) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, ctx->comm_ev[2 * k], ctx->comm_ev[2 * k + 1]) == hipSuccess) ctx->comm_ms[ctx->comm_ev_kind[k]] += ms;
+    }
+    ctx->comm_ev_used = 0;
+    for (int k = 0; k < 4; k++) { if (out_ms) out_ms[k] = ctx->comm_ms[k]; if (reset) ctx->comm_ms[k] = 0.0; }
+    return 0;
+}
+
 int pl_comm_allgather(pl_ctx* ctx, const double* send, double* recv, long long count) {
     if (ctx->nranks <= 1) return 0;
     ctx->comm_calls[1]++;
+    PlCommTimer tm_(ctx, 1);
     PlNccl* N = nccl_of(ctx);
     if (N && N->ok) {
         if (N->AllGather(send, recv, (size_t)count, PL_NCCL_DOUBLE, N->comm, ctx->stream)) return pl_fail(ctx, "RCCL all-gather failed");
@@ -194,9 +228,12 @@ int pl_comm_allgather(pl_ctx* ctx, const double* send, double* recv, long long c
 int pl_allreduce_host(pl_ctx* ctx, double* buf, long long n, int op) {
     if (ctx->nranks <= 1) return 0;
     ctx->comm_calls[3]++;
-    if (ctx->local) return local_allreduce_host(ctx, buf, n, op);
-    if (ctx->comm.allreduce_host(ctx->comm.user, buf, n, op)) return pl_fail(ctx, "communication callback 'allreduce_host' failed");
-    return 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = 0;
+    if (ctx->local) rc = local_allreduce_host(ctx, buf, n, op);
+    else if (ctx->comm.allreduce_host(ctx->comm.user, buf, n, op)) rc = pl_fail(ctx, "communication callback 'allreduce_host' failed");
+    ctx->comm_ms[3] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
 }
 
 // in-place sum all-reduce of n (<= 16) doubles in DEVICE memory: stream-ordered on the native transport, through the
@@ -204,6 +241,7 @@ int pl_allreduce_host(pl_ctx* ctx, double* buf, long long n, int op) {
 int pl_comm_allreduce_dev(pl_ctx* ctx, double* dev, int n) {
     if (ctx->nranks <= 1) return 0;
     ctx->comm_calls[2]++;
+    PlCommTimer tm_(ctx, 2);
     PlNccl* N = nccl_of(ctx);
     if (N && N->ok) {
         if (N->AllReduce(dev, dev, (size_t)n, PL_NCCL_DOUBLE, PL_NCCL_SUM, N->comm, ctx->stream)) return pl_fail(ctx, "RCCL all-reduce failed");
@@ -281,6 +319,7 @@ static int halo_generic_t(pl_ctx* ctx, int lnz, int lnx, T* origin, long long pi
     if (ctx->nranks <= 1) return 0;
     if (depth < 1 || depth > PL_RING || depth > lnz || depth > lnx) return pl_fail(ctx, "pl_halo: bad depth");
     ctx->comm_calls[0]++;
+    PlCommTimer tm_(ctx, 0);               // pack -> messages -> unpack
     const int per_double = (int)(sizeof(double) / sizeof(T));
     HaloDesc S{}, R{};
     int peers[8];

@@ -228,6 +228,7 @@ extern "C" void pl_destroy(pl_ctx* ctx) {
     pl_mic_free(ctx);
     pl_solver_free(ctx);
     pl_direct_free(ctx);
+    for (hipEvent_t e : ctx->comm_ev) if (e) (void)hipEventDestroy(e);
     for (auto& kv : ctx->bufs) (void)hipFree(kv.second);
     if (ctx->stage) (void)hipFree(ctx->stage);
     pl_geom_free(ctx->geom);

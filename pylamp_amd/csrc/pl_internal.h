@@ -85,6 +85,12 @@ struct pl_ctx {
     // [gj0, gj0 + lnx) of geom.d (the last block of an axis also owns the last node row / column)
     int rank = 0, nranks = 1, Pz = 1, Px = 1, pz = 0, px = 0;
     long long comm_calls[4] = {0, 0, 0, 0};     // neighbour exchanges, all-gathers, device all-reduces, host all-reduces (pl_comm_stats)
+    // time spent in them (pl_comm_times): device time between HIP events recorded around every exchange / all-gather / device
+    // all-reduce on the context stream (a pool of event pairs, resolved when the figures are read), host wall time of the host all-reduces
+    double comm_ms[4] = {0, 0, 0, 0};
+    std::vector<hipEvent_t> comm_ev;            // pairs (start, stop)
+    std::vector<int> comm_ev_kind;
+    size_t comm_ev_used = 0;
     pl_comm_ops comm{};
     void* nccl = nullptr;     // pl_comm.hip: native RCCL transport (optional)
     void* local = nullptr;    // pl_comm.hip: in-process group of virtual ranks (pl_local_group_*)
@@ -195,6 +201,9 @@ void pl_local_detach(pl_ctx* ctx);
 void pl_comm_native_free(pl_ctx* ctx);
 int pl_comm_native_enabled(pl_ctx* ctx);
 int pl_comm_allreduce_dev(pl_ctx* ctx, double* dev, int n);
+// event pair around a communication call on the context stream (kind 0 exchange, 1 all-gather, 2 device all-reduce); -1 when the pool is full
+int pl_comm_time_begin(pl_ctx* ctx, int kind);
+void pl_comm_time_end(pl_ctx* ctx, int slot);
 void pl_geom_free(PlGeomHost& gh);
 // host (nz,nx) C-order  <->  device plane with ring/pitch
 int pl_plane_upload(pl_ctx* ctx, const PlGeom& g, const double* host, double* dplane);

@@ -77,6 +77,38 @@ struct PlGatherArgs {
     double* epi_Tsub; double* epi_dTs;
 };
 
+// Sort key of a tracer for the end-of-step counting sort (pl_step.hip): the cell of this rank's block it lies in, one of the 8
+// leaver buckets behind the cells (the neighbour block it has moved into) or the trash bucket (del_outside: at or beyond a wall).
+// Regular grids; k_rk4 can produce the keys and the per-key counts in its epilogue (the positions are in registers there),
+// which saves the separate pass over the positions.
+struct PlSortKey {
+    int on;                          // RK4: write keys and counts
+    double z0, rhz, x0, rhx;         // node grid origin and reciprocal spacings
+    int ncz, ncx, crow0, ccol0, gcz, gcx;
+    int del_outside; double Lz, Lx;
+    int* cell; int* count;
+};
+__device__ inline int mic_sort_key(const PlSortKey& k, double z, double x) {
+    const int nc = k.ncz * k.ncx;
+    if (k.del_outside && (z <= 0.0 || z >= k.Lz || x <= 0.0 || x >= k.Lx)) return nc + 8;
+    int ci = (int)floor((z - k.z0) * k.rhz), cj = (int)floor((x - k.x0) * k.rhx);     // the lookup of the scatter kernels
+    ci = min(max(ci, 0), k.gcz - 1) - k.crow0;                                          // global cell (clamped to the domain) -> block cell
+    cj = min(max(cj, 0), k.gcx - 1) - k.ccol0;
+    const int dz = ci < 0 ? -1 : (ci >= k.ncz ? 1 : 0), dx = cj < 0 ? -1 : (cj >= k.ncx ? 1 : 0);
+    if (dz == 0 && dx == 0) return ci * k.ncx + cj;
+    return nc + (dx == 0 ? (dz < 0 ? 0 : 1) : (dz == 0 ? (dx < 0 ? 2 : 3) : (dz < 0 ? (dx < 0 ? 4 : 5) : (dx < 0 ? 6 : 7))));
+}
+// runs of equal keys inside a wave (the tracers were sorted one step ago): first lane and length of my run
+__device__ inline void mic_wave_runs(int c, int lane, int& seg0, int& len) {
+    const int prev = __shfl_up(c, 1, 64);
+    const bool head = lane == 0 || prev != c;
+    const unsigned long long heads = __ballot(head);
+    seg0 = 63 - __clzll(heads & (~0ull >> (63 - lane)));
+    const unsigned long long above = (seg0 == 63) ? 0ull : (heads >> (seg0 + 1));
+    const int nact = __popcll(__ballot(1));                  // the active lanes are a prefix of the wave (the tail of the array)
+    len = above ? __ffsll((long long)above) : nact - seg0;
+}
+
 struct PlRk4Args {
     long long n;
     const double* tz; const double* tx;
@@ -86,6 +118,7 @@ struct PlRk4Args {
     double* tz_out; double* tx_out; double* vz_out; double* vx_out;
     int fence; double eps, Lz, Lx;                 // optional fence of pylamp2.py:563-570
     unsigned long long* n_outside_window;          // stage positions whose cell lies outside the local window (or NULL)
+    PlSortKey key;                                 // key.on: sort keys + counts of the advected positions (resident step)
 };
 
 // Fused scatter of a time step's four target sets over cell-sorted tracers (pl_mic_cells.hip)

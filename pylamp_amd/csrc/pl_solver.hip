@@ -1350,7 +1350,7 @@ static int dots5_dev(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, int nspl
     const bool reduce = ctx->nranks > 1 && pl_geom_is_dist(g);
     hipLaunchKernelGGL(k_sum_partials5, dim3(1), dim3(256), 0, ctx->stream, nb, S->scal + PL_SCAL_N, S->scal, reduce ? 0 : 1);
     if (reduce) {
-        PL_TRY(pl_comm_allreduce_dev(ctx, S->scal + 8, 11));        // scal[16..18]: the local ||x_vel||^2, y.s and y.t ride along
+        PL_TRY(pl_comm_allreduce_dev(ctx, S->scal + 8, 13));        // scal[16..20]: the local ||x_vel||^2, y.s, y.t, (unused) and ||z_vel||^2 ride along
         hipLaunchKernelGGL(k_bicg_derive, dim3(1), dim3(1), 0, ctx->stream, S->scal);
     }
     return 0;
@@ -1373,12 +1373,12 @@ __global__ __launch_bounds__(256) void k_norm2_sum(PlGeom g, int nplanes, const 
     if (threadIdx.x == 0) { part[2 * blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3]; part[2 * blockIdx.x + 1] = 0.0; }
 }
 // -> S->scal[16] (this rank's share when reduce = false: the fused reduction of the iteration all-reduces it)
-static int norm2_sum_dev(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const double* a, const double* b, bool reduce) {
+static int norm2_sum_dev(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const double* a, const double* b, bool reduce, int slot = 16) {
     long long rows = (long long)g.lnz * np;
     const int nb = (int)(rows < DOT_BLOCKS ? rows : DOT_BLOCKS);
     hipLaunchKernelGGL(k_norm2_sum, dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, S->scal + PL_SCAL_N);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, nb, S->scal + PL_SCAL_N, S->scal + 16, 0, 0.0);
-    if (reduce && ctx->nranks > 1 && pl_geom_is_dist(g)) PL_TRY(pl_comm_allreduce_dev(ctx, S->scal + 16, 2));
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, nb, S->scal + PL_SCAL_N, S->scal + slot, 0, 0.0);
+    if (reduce && ctx->nranks > 1 && pl_geom_is_dist(g)) PL_TRY(pl_comm_allreduce_dev(ctx, S->scal + slot, 2));
     return 0;
 }
 // sums of the two dot products into S->scal[0..1], no host synchronisation
@@ -2532,7 +2532,13 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
         if (hzmin > 0.0 && hxmin > 0.0) n_amp = std::max(n_amp, std::max((zc.back() - zc.front()) / hzmin, (xc.back() - xc.front()) / hxmin));
     }
     double est_rec = 0.0;                           // 0: unknown (far from convergence) -- only the residual test applies
-    double a_mom = 1.0;                             // ||A_vv^-1 r_mom|| / ||r_mom|| as measured at the last true check (below)
+    // ||A_vv^-1 r_mom|| / ||r_mom||: the amplification of the momentum residual.  Near the end it is measured in every iteration, for
+    // free, on the pair (s, z = M^-1 s) the iteration computes anyway -- ||z_vel|| / ||s_mom|| -- and then serves the estimate of the
+    // iterate's own residual r = s - omega t, which has the same character.  (Until round 3 it was measured by ONE MORE
+    // preconditioner application on the true residual at every check: 0.8-1.6 ms of a 25 ms solve at 2049^2.  PYLAMP_EST_EXACT=1
+    // brings that back.)
+    double a_mom = 1.0; bool a_mom_measured = false;
+    static const bool est_exact = getenv("PYLAMP_EST_EXACT") && atoi(getenv("PYLAMP_EST_EXACT")) != 0;
     // With the pressure-anchor deflation active the component of the residual along that mode needs its own term: its
     // amplification is ||w|| / ||u|| (1e4 and more), far beyond n -- r = gamma u + ..., gamma = y.r / y.u, and the error it stands
     // for is gamma w (A w = u).  Without the deflation BiCGStab has removed this component by the time it leaves its plateau;
@@ -2598,6 +2604,7 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
                 // it can ride along in the fused reduction -- the estimate needs it to ~10 %)
                 const bool want_xx = use_est && rnorm <= 1e3 * tol * bnorm;
                 if (want_xx) PL_TRY(norm2_sum_dev(ctx, S, g, np_vel, dx, dx != x ? (const double*)x : (const double*)nullptr, false));
+                if (want_xx && M) PL_TRY(norm2_sum_dev(ctx, S, g, np_vel, zv, nullptr, false, 20));      // ||z_vel||^2 of z = M^-1 s -> scal[20] (k_sum_partials also clears the slot behind its target: 19 belongs to y.t)
                 if (want_xx && anchor_term) {            // y.r of the updated residual = y.s - omega y.t: both ride in the reduction as well
                     ysum_dev(w.s + (long long)np_vel * g.plane, S->scal + 17);
                     ysum_dev(w.t + (long long)np_vel * g.plane, S->scal + 18);
@@ -2616,6 +2623,10 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
                 alpha = hs[2]; omega = hs[3];
                 rho_new = hs[5]; rnorm = std::sqrt(hs[6]);
                 if (!std::isfinite(alpha)) { broke = true; break; }
+                if (want_xx && M) {
+                    const double ss_mom = hs[12] - hs[15];
+                    if (ss_mom > 0.0 && hs[20] > 0.0) { a_mom = std::min(std::max(std::sqrt(hs[20] / ss_mom), 1.0), n_amp * n_amp); a_mom_measured = true; }
+                }
                 if (want_xx) est_rec = estimate(hs[15] - 2.0 * omega * hs[13] + omega * omega * hs[14], hs[6], hs[16], hs[17] - omega * hs[18]);
                 else est_rec = 0.0;
             } else {
@@ -2675,14 +2686,18 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
             // complement is only an approximation; measured 37 x below the true error on the 33 x 41 fixture)
             double dc[2], dz[2];
             PL_TRY(dots(ctx, S, g, np - np_vel, w.s + (long long)np_vel * g.plane, w.s + (long long)np_vel * g.plane, nullptr, nullptr, dc));
-            PL_TRY((*M)(w.s, w.z));
-            PL_TRY(dots(ctx, S, g, np_vel, w.z, w.z, nullptr, nullptr, dz));
+            const bool exact = est_exact || !a_mom_measured;
+            if (exact) {
+                PL_TRY((*M)(w.s, w.z));
+                PL_TRY(dots(ctx, S, g, np_vel, w.z, w.z, nullptr, nullptr, dz));
+            }
             PL_TRY(norm2_sum_dev(ctx, S, g, np_vel, dx, dx != x ? (const double*)x : (const double*)nullptr, true));
             PL_HIP(ctx, hipMemcpyAsync(S->hpart + 8 * DOT_BLOCKS, S->scal + 16, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
             PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
             est_checks++;
             const double xx = S->hpart[8 * DOT_BLOCKS];
             const double rc = dc[0] > 0.0 ? dc[0] : 0.0, rm = true_norm * true_norm - rc;
+            if (!exact) dz[0] = a_mom * a_mom * (rm > 0.0 ? rm : 0.0);            // the response the last iteration measured, scaled to this residual
             double est = xx > 0.0 ? (n_amp * std::sqrt(rc) + std::sqrt(dz[0] > 0.0 ? dz[0] : 0.0)) / std::sqrt(xx) : 0.0;
             double anchor_part = 0.0;
             if (anchor_term && xx > 0.0) {
@@ -2691,7 +2706,7 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
                 anchor_part = std::fabs(yr / S->defl_yAw) * std::sqrt(S->defl_wvel2 / xx);
                 est += anchor_part;
             }
-            if (rm > 0.0 && dz[0] > 0.0) a_mom = std::min(std::max(std::sqrt(dz[0] / rm), 1.0), n_amp * n_amp);
+            if (exact && rm > 0.0 && dz[0] > 0.0) { a_mom = std::min(std::max(std::sqrt(dz[0] / rm), 1.0), n_amp * n_amp); a_mom_measured = true; }
             st->error_estimate = est;
             if (trace) fprintf(stderr, "[pylamp bicgstab] it %3d  velocity-error estimate %.3e (etol %.1e): continuity %.3e momentum %.3e (amplification %.1f) anchor mode %.3e\n",
                                it, est, etol, xx > 0.0 ? n_amp * std::sqrt(rc / xx) : 0.0, xx > 0.0 ? std::sqrt(dz[0] / xx) : 0.0, a_mom, anchor_part);

@@ -95,14 +95,6 @@ __global__ __launch_bounds__(256) void k_col_to_aos(long long m, const double* _
 // The tracers were sorted one step ago and move less than a cell per step, so consecutive lanes mostly hold
 // the same cell: one atomic per RUN of equal cells in a wave instead of one per tracer (16x fewer at 16
 // markers per cell; the counters were atomic-bound: 2.7 + 3.7 ms for 67 M tracers).
-__device__ inline void wave_runs(int c, int lane, int& seg0, int& len) {
-    const int prev = __shfl_up(c, 1, 64);
-    const bool head = lane == 0 || prev != c;
-    const unsigned long long heads = __ballot(head);
-    seg0 = 63 - __clzll(heads & (~0ull >> (63 - lane)));
-    const unsigned long long above = (seg0 == 63) ? 0ull : (heads >> (seg0 + 1));
-    len = above ? __ffsll((long long)above) : 64 - seg0;            // lanes in my run
-}
 // Sort key of a tracer: the cell of this rank's block it lies in, [0, ncz*ncx); or, behind the cells, one of 8 LEAVER
 // buckets (the neighbour block it has moved into; order N S W E NW NE SW SE as in pl_comm.hip); or the trash bucket
 // behind those -- del_outside: a tracer at or beyond a wall (pylamp2.py:563-572 with the fence off: TR__ID = -1).
@@ -131,7 +123,7 @@ __global__ __launch_bounds__(256) void k_cell_count(long long n, const double* _
         cell[t] = c;
     }
     int seg0, len;
-    wave_runs(c, lane, seg0, len);
+    mic_wave_runs(c, lane, seg0, len);
     if (lane == seg0 && c >= 0) atomicAdd(&count[c], len);
 }
 // exclusive scan of m ints in three passes (1024 elements per block)
@@ -186,7 +178,7 @@ __global__ __launch_bounds__(256) void k_cell_place(long long n, const int* __re
     const int lane = threadIdx.x & 63;
     const int c = (t < n) ? cell[t] : -1;
     int seg0, len;
-    wave_runs(c, lane, seg0, len);
+    mic_wave_runs(c, lane, seg0, len);
     int base = 0;
     if (lane == seg0 && c >= 0) base = atomicAdd(&fill[c], len);
     base = __shfl(base, seg0, 64);
@@ -472,6 +464,7 @@ static void unpermute(pl_ctx* ctx, PlStepState* S, int na, const double* const* 
 struct SortOpts {
     int del_outside = 0; double Lz = 0.0, Lx = 0.0; long long* removed = nullptr;     // fence off: delete leavers of the domain
     const pl_step_config* inject = nullptr; int it = 0; int64_t* ninjected = nullptr;  // census + refill fused into the sort
+    bool keys_ready = false;          // S->cell and S->cell_count were filled by k_rk4's epilogue (prepare_sort_keys + stage_rk4)
 };
 static int sort_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, double x0, double hx, const SortOpts& o = SortOpts());
 // Host midpoint grids (pylamp2.py:92-95) and device copies of all coordinate arrays the marker kernels use:
@@ -684,6 +677,7 @@ static int sort_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, doubl
     long long n = S->n;
     if (n >= (1LL << 31)) return pl_fail(ctx, "sort_tracers: more than 2^31 tracers per GPU");
     if (!S->cell_count || S->ncz != ncz || S->ncx != ncx) {
+        if (o.keys_ready) return pl_fail(ctx, "sort_tracers: sort keys announced for another sort grid (internal error)");
         for (int** q : {&S->cell_count, &S->cell_start, &S->block_sums, &S->need, &S->need_off, &S->need_flag, &S->need_rank, &S->cell_res}) {
             if (*q) (void)hipFree(*q);
             *q = nullptr;
@@ -695,9 +689,11 @@ static int sort_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, doubl
         S->ncz = ncz; S->ncx = ncx;
     }
     S->sort_cells = nc;
-    PL_HIP(ctx, hipMemsetAsync(S->cell_count, 0, (size_t)m * sizeof(int), ctx->stream));
-    hipLaunchKernelGGL(k_cell_count, grid1d(n), dim3(256), 0, ctx->stream, n, S->tz, S->tx, z0, hz, x0, hx, coords_z(ctx, S, 0),
-                       coords_x(ctx, S, 0), ncz, ncx, S->crow0, S->ccol0, g.nz - 1, g.nx - 1, S->cell, S->cell_count, o.del_outside, o.Lz, o.Lx);
+    if (!o.keys_ready) {
+        PL_HIP(ctx, hipMemsetAsync(S->cell_count, 0, (size_t)m * sizeof(int), ctx->stream));
+        hipLaunchKernelGGL(k_cell_count, grid1d(n), dim3(256), 0, ctx->stream, n, S->tz, S->tx, z0, hz, x0, hx, coords_z(ctx, S, 0),
+                           coords_x(ctx, S, 0), ncz, ncx, S->crow0, S->ccol0, g.nz - 1, g.nx - 1, S->cell, S->cell_count, o.del_outside, o.Lz, o.Lx);
+    }
     // ---- census + deficits (the counts ARE the census)
     long long ninj = 0; int ndef = 0;
     double id0 = 0.0; bool strict = false;
@@ -1093,7 +1089,8 @@ static int stage_temp_to_tracers(pl_ctx* ctx, PlStepState* S, const pl_step_conf
 
 // stage 6b: RK4 through the advection velocities V = (Vz | Vx), the window [I0, I1] x [J0, J1] of the padded centre grid held
 // as dense (I1-I0+1) x (J1-J0+1) arrays; positions -> tz2/tx2 (swapped in), tracer velocities -> vtz/vtx (pylamp2.py:547-572)
-static int stage_rk4(pl_ctx* ctx, PlStepState* S, const double* V, int I0, int I1, int J0, int J1, double tstep, int fence, double Lz, double Lx) {
+static int stage_rk4(pl_ctx* ctx, PlStepState* S, const double* V, int I0, int I1, int J0, int J1, double tstep, int fence, double Lz, double Lx,
+                     bool* keys_ready = nullptr) {
     const int nz = ctx->nz, nx = ctx->nx;
     const StepGrid q = step_grid(ctx);
     const int nVr = I1 - I0 + 1, nVc = J1 - J0 + 1;
@@ -1112,6 +1109,22 @@ static int stage_rk4(pl_ctx* ctx, PlStepState* S, const double* V, int I0, int I
     ra.Vz = V; ra.Vx = V + VN; ra.dt = tstep;
     ra.tz_out = S->tz2; ra.tx_out = S->tx2; ra.vz_out = S->vtz; ra.vx_out = S->vtx;
     ra.fence = fence; ra.eps = PL_EPS; ra.Lz = Lz; ra.Lx = Lx;
+    if (keys_ready) {
+        // the end-of-step sort's keys and counts come out of this kernel (regular grid; the sort grid of this block is unchanged
+        // since the last sort): no separate pass over the new positions
+        *keys_ready = false;
+        const PlGeom& g = ctx->geom.d;
+        const int ncz = (g.gi0 + g.lnz >= g.nz) ? g.lnz - 1 : g.lnz, ncx = (g.gj0 + g.lnx >= g.nx) ? g.lnx - 1 : g.lnx;
+        static const bool fuse_keys = !(getenv("PYLAMP_RK4_KEYS") && atoi(getenv("PYLAMP_RK4_KEYS")) == 0);
+        if (fuse_keys && ctx->geom.uniform && S->cell_count && S->ncz == ncz && S->ncx == ncx && S->cell && S->n < (1LL << 31)) {
+            PlSortKey& k = ra.key;
+            k.on = 1; k.z0 = q.z0; k.rhz = 1.0 / q.hz; k.x0 = q.x0; k.rhx = 1.0 / q.hx;
+            k.ncz = ncz; k.ncx = ncx; k.crow0 = g.gi0; k.ccol0 = g.gj0; k.gcz = g.nz - 1; k.gcx = g.nx - 1;
+            k.del_outside = fence ? 0 : 1; k.Lz = Lz; k.Lx = Lx; k.cell = S->cell; k.count = S->cell_count;
+            PL_HIP(ctx, hipMemsetAsync(S->cell_count, 0, (size_t)(ncz * ncx + 10) * sizeof(int), ctx->stream));
+            *keys_ready = true;
+        }
+    }
     double* oowc = nullptr;
     if (ctx->nranks > 1) {
         PL_TRY(pl_buf(ctx, "rk4_counter", 64, &oowc, false));
@@ -1375,7 +1388,8 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
                            (cfg->bcstokes[0] & PL_BC_FREESLIP) ? 1 : 0, (cfg->bcstokes[1] & PL_BC_FREESLIP) ? 1 : 0,
                            (cfg->bcstokes[2] & PL_BC_FREESLIP) ? 1 : 0, (cfg->bcstokes[3] & PL_BC_FREESLIP) ? 1 : 0, I0, J0, nVr, nVc, V, V + VN);
     }
-    PL_TRY(stage_rk4(ctx, S, V, I0, I1, J0, J1, tstep, cfg->tracs_fence_disabled ? 0 : 1, Lz, Lx));
+    bool keys_ready = false;
+    PL_TRY(stage_rk4(ctx, S, V, I0, I1, J0, J1, tstep, cfg->tracs_fence_disabled ? 0 : 1, Lz, Lx, &keys_ready));
     rep->ms_advect = now_ms() - t0;
 
     // ---- 7. cell sort of the advected tracers, slab migration, census + injection --------------------
@@ -1384,6 +1398,7 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
     {
         long long removed = 0;
         SortOpts so; so.del_outside = cfg->tracs_fence_disabled ? 1 : 0; so.Lz = Lz; so.Lx = Lx; so.removed = &removed;
+        so.keys_ready = keys_ready;
         SortOpts si; si.inject = cfg; si.it = it; si.ninjected = &rep->ninjected;
         if (ctx->nranks == 1) { so.inject = si.inject; so.it = it; so.ninjected = si.ninjected; }     // one pass does it all
         PL_TRY(sort_tracers(ctx, S, z0, hz, x0, hx, so));

@@ -187,3 +187,45 @@ def test_config5_solve_129_cubed():
     assert np.abs(vy).max() > 1e-3 * vmax                                                                     # genuinely 3-D flow
     assert 0 < st["error_estimate"] <= 3e-8, st
     A._ctx.close()
+
+
+def test_config5_257_cubed_resident():
+    """BASELINE config 5 at its stated size, 257^3 nodes (68 M unknowns), as the bench runs it: device-resident Stokes and heat
+    solves (nothing but the coefficients crosses PCIe), warm-started second solve.  No reference exists in 3-D (parity unpinned):
+    the solution is checked through the host side of the C ABI -- true residual of the downloaded vector, discrete divergence,
+    error estimate -- and the resident temperature against the operator it solves."""
+    from pylamp_amd import pylamp3d as P3
+    n = 257; L = [660e3] * 3
+    grid = [np.linspace(0, L[d], n) for d in range(3)]
+    mid = [np.append(0.5 * (g[1:] + g[:-1]), g[-1] + 0.5 * (g[-1] - g[-2])) for g in grid]
+
+    def field(c):
+        Z, X, Y = np.meshgrid(*c, indexing="ij", sparse=True)
+        return 273 + 1350 * np.clip(Z / L[0], 0, 1) + 60 * np.sin(3 * np.pi * X / L[1]) * np.sin(np.pi * Z / L[0]) * np.cos(2 * np.pi * Y / L[2])
+    eta = lambda T: np.clip(1e20 * np.exp(120e3 / (8.31446 * T) - 120e3 / (8.31446 * 1623)), 1e17, 1e23)
+    Tn = field(grid)
+    rho = 3300 / (3.5e-5 * (Tn - 1623) + 1)
+    ctx = P3.Context3([n, n, n], grid)
+    A, rhs = P3.makeStokesMatrix([n, n, n], grid, eta(Tn), eta(field(mid)), rho, ctx=ctx)
+    assert P3.solve(A, resident=True) is None
+    st = dict(A.last_stats)
+    assert st["converged"] == 1 and st["rel_residual"] <= P3.DEFAULT_RTOL and st["iterations"] < 80 and 0 < st["error_estimate"] <= 3e-8, st
+    x = P3.solution(A)
+    r = rhs - A @ x
+    assert np.linalg.norm(r) / np.linalg.norm(rhs) < 1e-6
+    (vz, vx, vy), p = P3.x2vp(x, [n, n, n])
+    h = L[0] / (n - 1)
+    dv = ((vz[1:, :-1, :-1] - vz[:-1, :-1, :-1]) + (vx[:-1, 1:, :-1] - vx[:-1, :-1, :-1]) + (vy[:-1, :-1, 1:] - vy[:-1, :-1, :-1]))[1:-1, 1:-1, 1:-1]
+    assert np.sqrt(np.mean(dv ** 2)) < 1e-6 * np.sqrt(np.mean(vz ** 2 + vx ** 2 + vy ** 2))
+    del dv
+    # a warm-started second solve of the same system ends at once
+    P3.solve(A, resident=True, warm=True)
+    assert A.last_stats["converged"] == 1 and A.last_stats["iterations"] <= 2, A.last_stats
+    # heat on the same grid, resident
+    k = np.full((n, n, n), 4.0); cp = np.full((n, n, n), 1250.0); H = np.full((n, n, n), 0.02e-6 / 3300)
+    dt = 0.67 * h ** 2 / np.max(2 * 4.0 / (rho * 1250.0))
+    Ah, rh = P3.makeDiffusionMatrix([n, n, n], grid, mid, Tn, [k, k, k], cp, rho, H, [0, 1, 1, 0, 1, 1], [273.0, 0, 0, 1623.0, 0, 0], dt, ctx=ctx)
+    assert P3.solve_heat(Ah, resident=True) is None and Ah.last_stats["converged"] == 1, Ah.last_stats
+    T = P3.solution(Ah, heat=True)
+    assert np.linalg.norm(Ah @ T - rh) / np.linalg.norm(rh) < 1e-10
+    ctx.close()

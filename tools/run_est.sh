@@ -1,4 +1,6 @@
-export PYLAMP_SOLVER_TRACE=1
-python tools/traj_rtol.py 2>&1 | grep -E "x n =|traj_" | head -60
-for n in 129 513; do python tools/tune_nu.py mantle $n 1,1 3,3 2>&1 | grep -E "x n =|mantle" | tail -4; done
-python bench.py --steps 2 --warmup 1 --no-cpu-baseline --apply-reps 2 2>&1 | grep -E "x n =" | tail -3
+#!/bin/bash
+export PYLAMP_BENCH_NO_4097=1
+for e in 0 1; do
+  PYLAMP_EST_EXACT=$e python bench.py --steps 10 --warmup 4 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('exact=$e', d['ms_per_step'], d['stage_ms']['ms_stokes'], d['stokes_iterations'], d['stokes_precond_applies'], d['stokes_operator_applies'])"
+done
