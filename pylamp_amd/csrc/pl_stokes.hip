@@ -232,7 +232,8 @@ void pl_launch_stokes_apply(pl_ctx* ctx, const PlStokesOp& op, const double* x, 
     // (same loads and stores, no arithmetic) 58 us -> the arithmetic was exposed: no divisions in the plain
     // operator 76 us, factored coefficients 73 us, branch-free interior path 64 us.  Sharing the rows of a
     // 4- or 8-row tile through LDS (5 instead of 12 global row loads per wave) is SLOWER (68 us): the L1 re-reads
-    // were never the limit, the barrier is one.
+    // were never the limit, the barrier is one.  Round 3: two output rows per wave (17 instead of 24 row loads per pair of rows, 162 VGPRs):
+    // 69 vs 68 us at 2049^2, 298 vs 290 us at 4097^2 -- the re-reads are not what the kernel waits for.  Removed.
     // (The scalar one-column-per-lane kernel of round 1 is gone: the vectorised one is pinned directly against the reference's
     // explicit matrices on five grids, tests/test_hip_parity.py.)  double2 accesses need even plane strides and an even first
     // column: the pitch is a multiple of 16 and block columns start at even multiples (pl_set_comm_2d enforces even block widths).
