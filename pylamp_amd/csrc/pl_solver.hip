@@ -1164,6 +1164,7 @@ struct PlSolver {
     double defl_yAw = 0.0, defl_wvel2 = 0.0;     // host copies: y.(A w) and ||w_vel||^2 (the anchor-mode term of the error estimate)
     double schur_scale = 1.0;    // S^ = schur_scale * Kc^2 / eta_n (PYLAMP_SCHUR_SCALE)
     long long fused_max_nodes = 1100000;      // PYLAMP_MG_FUSED_MAX: largest level (nodes) that takes the tile kernels
+    long long tile32_min_nodes = 1000000;            // PYLAMP_MG_TS32: levels from this many nodes use 32 x 32 tiles (2049^2: level 1; 36.6 against 37.4 ms per step)
     bool fused = true;           // PYLAMP_MG_FUSED=0: every multigrid stage as a kernel of its own (the path the tile kernels are checked against)
     bool fuse_first = true;      // PYLAMP_FUSE_FIRST=0: the first sweep of level 0 as a pass of its own
     bool deep = true;            // PYLAMP_MG_DEEP=0: distributed levels exchange before every sweep instead of once per smoothing sequence
@@ -1210,6 +1211,7 @@ static PlSolver* solver_of(pl_ctx* ctx) {
         if (const char* e = getenv("PYLAMP_MG_FP32_NODES")) { long long v = atoll(e); if (v >= 1) S->f32_min_nodes = v; }
         if (const char* e = getenv("PYLAMP_FUSE_FIRST")) S->fuse_first = atoi(e) != 0;
         if (const char* e = getenv("PYLAMP_MG_FUSED")) S->fused = atoi(e) != 0;
+        if (const char* e = getenv("PYLAMP_MG_TS32")) { long long v = atoll(e); if (v > 0) S->tile32_min_nodes = v; }
         if (const char* e = getenv("PYLAMP_MG_FUSED_MAX")) { long long v = atoll(e); if (v > 0) S->fused_max_nodes = v; }
         if (const char* e = getenv("PYLAMP_SCHUR_SCALE")) { double v = atof(e); if (v > 0.0) S->schur_scale = v; }
         if (const char* e = getenv("PYLAMP_MG_TAIL_NU")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a + b > 0) { S->tail_nu_pre = a; S->tail_nu_post = b; } }
@@ -1798,6 +1800,8 @@ static bool level_deep_plan(const PlSolver* S, const MgLevel* L, size_t l, int& 
 template <typename T> static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const T* f, T** out, bool* wrote_final, double* final_out,
                                          double final_scale, int f_valid_depth, const int* first_done_anchor);
 static bool mg_fused_level_ok(pl_ctx* ctx, const PlSolver* S, size_t l);
+static bool mg_tail_lds_fits(const PlSolver* S, size_t l);
+__global__ void k_mg_tail_lds(TailArgs a);
 static void vcycle_fused_level(pl_ctx* ctx, PlSolver* S, size_t l, const double* f, double** out, double* final_out, double final_scale,
                                const PlStokesOp* sop, const double* rs, double* z);
 
@@ -1884,7 +1888,11 @@ static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const T* f, T** out, bool
                 ta.L[q].op = T_->op; ta.L[q].f = T_->f; ta.L[q].r = T_->r; ta.L[q].lmax = T_->lmax;
                 for (int b = 0; b < 3; b++) ta.L[q].v[b] = T_->v[b];
             }
-            hipLaunchKernelGGL(k_mg_tail, dim3(1), dim3(1024), 0, ctx->stream, ta);
+            // one rank: the LDS-resident twin (levels kept in LDS, the tile kernels' node functions) where its pool holds the levels
+            if (S->fused && ctx->nranks == 1 && !L->op.szz && ta.nu_pre >= 1 && ta.nu_post >= 1 && ta.coarse_sweeps >= 1 && mg_tail_lds_fits(S, l))
+                hipLaunchKernelGGL(k_mg_tail_lds, dim3(1), dim3(1024), 0, ctx->stream, ta);
+            else
+                hipLaunchKernelGGL(k_mg_tail, dim3(1), dim3(1024), 0, ctx->stream, ta);
             *out = L->v[0];
             return;
         }
@@ -1964,11 +1972,18 @@ static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const T* f, T** out, bool
 //     k_mg_pre :  [level 0: stage 1 of the block preconditioner -- S^-1 r_p, f = r_v - A_vp z_p --] first sweep from the zero
 //                 guess, NS - 1 Chebyshev sweeps, residual, full-weighting restriction  ->  iterate (this level), rhs (coarse level)
 //     k_mg_post:  prolongation + correction, NS Chebyshev sweeps                        ->  iterate (this level, or z on level 0)
-// LDS-resident data: three rotating iterates, the right-hand side, the two viscosity planes, the reciprocal-spacing tables of
-// the region (so rectilinear grids work), all in named __shared__ arrays (ds_read / ds_write; the earlier attempt that called the
-// generic node functions through flat pointers gained nothing).  Row classes (wall, slaved, interior) are
-// decided per node from the global index exactly as the one-kernel-per-stage path does, and a slaved node evaluates its
-// master's update -- so both paths compute the same numbers (tests/test_hip_solve.py::test_fused_levels_match_the_staged_path).
+// Every thread owns the same node(s) of the region in every stage and keeps in REGISTERS what its rows need through all of them:
+// the six coefficients, 1 / diagonal and right-hand side of the z- and the x-row it evaluates (its own, or its master's if the
+// node is slaved) and that row's previous iterate for the Chebyshev momentum term.  LDS holds two iterates (22-72 KB per
+// workgroup; the viscosity planes pass through one of them once, for the coefficients) and the spacing tables of the region, so
+// rectilinear grids work.  Measured on the way (2049^2, level 1 = 1025^2, pre kernel): with viscosities, tables, right-hand side
+// and three iterates in LDS and the coefficients recomputed in every stage 73 us; coefficients in registers 64; right-hand side
+// requested with the first loads instead of after the first barrier 52 (32 x 32 tiles) -- of which the loads are 22, coefficients
+// and first sweep 8, a sweep 6, residual + restriction 10.  Tile edge 32 from 10^6 nodes (halo recomputation 1.7x instead of
+// 2.6x at three sweeps), 16 below (more workgroups than CUs down to 257^2).
+// Row classes (wall, slaved, interior) are decided per node from the global index exactly as the one-kernel-per-stage path does,
+// and a slaved node evaluates its master's update -- so both paths compute the same numbers
+// (tests/test_hip_solve.py::test_fused_levels_match_the_staged_path).
 // Requirements (vcycle_fused_ok): one rank, FP64 level, no stabilisation terms, 1 <= sweeps <= 3; otherwise the staged path runs.
 // =========================================================================================
 #define MGT_TS 16
@@ -2009,8 +2024,8 @@ __device__ inline int mgt_cls_x(const PlVvOp& op, int i, int j, int& da, double&
 }
 // (A_vv v)_z, (A_vv v)_x and -diagonal at region node (a, b) = LDS index c (row pitch CR): vv_row_z / vv_row_x on LDS arrays.
 // The tables are stored shifted by one: rdz[a + 1] belongs to region row a.
-template <int CR, bool NEED_A>
-__device__ inline void mgt_row_z(const MgtTab& t, const double* vz, const double* vx, int c, int a, int b, double& Av, double& dg) {
+template <bool NEED_A>
+__device__ inline void mgt_row_z(const MgtTab& t, const int CR, const double* vz, const double* vx, int c, int a, int b, double& Av, double& dg) {
     const double rdz_i = t.rdz[a + 1], rdz_m = t.rdz[a], rDz_i = t.rDz[a + 1];
     const double rdx_j = t.rdx[b + 1], rDx_j = t.rDx[b + 1], rDx_p = t.rDx[b + 2];
     const double esC = t.es[c], esE = t.es[c + 1];
@@ -2024,8 +2039,8 @@ __device__ inline void mgt_row_z(const MgtTab& t, const double* vz, const double
              xE * (vx[c + 1] - vx[c - CR + 1]) - xW * (vx[c] - vx[c - CR]);
     }
 }
-template <int CR, bool NEED_A>
-__device__ inline void mgt_row_x(const MgtTab& t, const double* vz, const double* vx, int c, int a, int b, double& Av, double& dg) {
+template <bool NEED_A>
+__device__ inline void mgt_row_x(const MgtTab& t, const int CR, const double* vz, const double* vx, int c, int a, int b, double& Av, double& dg) {
     const double rdx_j = t.rdx[b + 1], rdx_m = t.rdx[b], rDx_j = t.rDx[b + 1];
     const double rdz_i = t.rdz[a + 1], rDz_i = t.rDz[a + 1], rDz_p = t.rDz[a + 2];
     const double esC = t.es[c], esN = t.es[c + CR];
@@ -2041,9 +2056,9 @@ __device__ inline void mgt_row_x(const MgtTab& t, const double* vz, const double
 }
 
 // everything the stages of one tile share
-template <int CR>
 struct MgtTile {
     int ci0, cj0;                      // global node of region element (0, 0)
+    int CR, NR;                        // row pitch (= columns) and rows of the region
     MgtTab t;
     // first sweep from the zero guess (cheb_first_node): v1 = -c2 f / diag, slaves copy s x their master's value
     __device__ inline void first(const PlVvOp& op, const double* fz, const double* fx, double* oz, double* ox, double c2, int a, int b) const {
@@ -2051,11 +2066,11 @@ struct MgtTile {
         int d; double s, Av, dg;
         double o = 0.0;
         int cls = mgt_cls_z(op, i, j, d, s);
-        if (cls != VV_ZERO && b + d >= 1 && b + d <= CR - 2) { mgt_row_z<CR, false>(t, nullptr, nullptr, c + d, a, b + d, Av, dg); o = (-s * c2 * fz[c + d]) * pl_rcp(dg); }
+        if (cls != VV_ZERO && b + d >= 1 && b + d <= CR - 2) { mgt_row_z<false>(t, CR, nullptr, nullptr, c + d, a, b + d, Av, dg); o = (-s * c2 * fz[c + d]) * pl_rcp(dg); }
         oz[c] = o;
         o = 0.0;
         cls = mgt_cls_x(op, i, j, d, s);
-        if (cls != VV_ZERO && a + d >= 1 && a + d <= CR - 2) { mgt_row_x<CR, false>(t, nullptr, nullptr, c + d * CR, a + d, b, Av, dg); o = (-s * c2 * fx[c + d * CR]) * pl_rcp(dg); }
+        if (cls != VV_ZERO && a + d >= 1 && a + d <= NR - 2) { mgt_row_x<false>(t, CR, nullptr, nullptr, c + d * CR, a + d, b, Av, dg); o = (-s * c2 * fx[c + d * CR]) * pl_rcp(dg); }
         ox[c] = o;
     }
     // one Chebyshev sweep (cheb_node); pz == nullptr: the previous iterate is zero
@@ -2067,14 +2082,14 @@ struct MgtTile {
         int cls = mgt_cls_z(op, i, j, d, s);
         if (cls != VV_ZERO && b + d >= 1 && b + d <= CR - 2) {
             const int cm = c + d;
-            mgt_row_z<CR, true>(t, vz, vx, cm, a, b + d, Av, dg);
+            mgt_row_z<true>(t, CR, vz, vx, cm, a, b + d, Av, dg);
             const double v0 = vz[cm], mom = (c1 != 0.0) ? c1 * (v0 - (pz ? pz[cm] : 0.0)) : 0.0;
             oz = s * (v0 + mom + (c2 * (Av - fz[cm])) * pl_rcp(dg));
         }
         cls = mgt_cls_x(op, i, j, d, s);
-        if (cls != VV_ZERO && a + d >= 1 && a + d <= CR - 2) {
+        if (cls != VV_ZERO && a + d >= 1 && a + d <= NR - 2) {
             const int cm = c + d * CR;
-            mgt_row_x<CR, true>(t, vz, vx, cm, a + d, b, Av, dg);
+            mgt_row_x<true>(t, CR, vz, vx, cm, a + d, b, Av, dg);
             const double v0 = vx[cm], mom = (c1 != 0.0) ? c1 * (v0 - (px ? px[cm] : 0.0)) : 0.0;
             ox = s * (v0 + mom + (c2 * (Av - fx[cm])) * pl_rcp(dg));
         }
@@ -2083,102 +2098,192 @@ struct MgtTile {
 
 // the tables of the region: value of table tab (indexed by global node + PL_TOFF, defined for -PL_TOFF .. n + PL_TOFF) at region rows / columns -1 .. CR + 1
 __device__ inline void mgt_load_table(double* dst, const double* tab, int first_global, int count, int n) {
-    for (int k = threadIdx.x; k < count; k += MGT_NT) {
+    for (int k = threadIdx.x; k < count; k += blockDim.x) {
         const int gk = first_global + k;
         dst[k] = (gk >= -PL_TOFF && gk < n + PL_TOFF) ? TB(tab, gk) : 0.0;
     }
 }
 
+// What a thread keeps in REGISTERS for one component of one node of its tile through all the stages: the coefficients of the row
+// it evaluates (its own, or its master's if it is a slaved node), 1 / diagonal and the right-hand side there.  The stages were
+// VALU-bound -- ~150 instructions per node and stage, two thirds of them recomputing these from the viscosity planes and spacing
+// tables in LDS (the level-1 visit took as long as the nine separate launches it replaces) -- now a sweep is 18 LDS reads and ~45 flops.
+// z: c0..c3 = cN cS cE cW, x0 x1 = xE xW;  x: c0..c3 = cE cW cN cS, x0 x1 = zN zS  (mgt_row_z / mgt_row_x: same expressions, same order).
+struct MgtC { double c0, c1, c2, c3, x0, x1, rdg, s, f; int cm, d; bool on, interior; };
+// first half (integers only, before anything is in LDS): which row the node evaluates -- so that the right-hand side there can be
+// requested together with the region's viscosities
+template <bool ZC>
+__device__ inline MgtC mgt_classify(const PlVvOp& op, int CR, int NR, int ci0, int cj0, int a, int b) {
+    MgtC k; k.c0 = k.c1 = k.c2 = k.c3 = k.x0 = k.x1 = k.rdg = k.f = 0.0; k.s = 1.0; k.cm = a * CR + b; k.d = 0; k.on = false; k.interior = false;
+    if (a < 1 || a > NR - 2 || b < 1 || b > CR - 2) return k;
+    int d; double s;
+    const int cls = ZC ? mgt_cls_z(op, ci0 + a, cj0 + b, d, s) : mgt_cls_x(op, ci0 + a, cj0 + b, d, s);
+    const int am = ZC ? a : a + d, bm = ZC ? b + d : b;
+    if (cls == VV_ZERO || am < 1 || am > NR - 2 || bm < 1 || bm > CR - 2) return k;
+    k.s = s; k.cm = am * CR + bm; k.d = d; k.on = true; k.interior = cls == VV_INT;
+    return k;
+}
+// second half: the coefficients of that row from the viscosity planes and spacing tables in LDS
+template <bool ZC>
+__device__ inline void mgt_coefficients(MgtC& k, const MgtTab& t, int CR) {
+    if (!k.on) return;
+    const int c = k.cm, am = c / CR, bm = c - am * CR;
+    if (ZC) {
+        const double rdz_i = t.rdz[am + 1], rdz_m = t.rdz[am], rDz_i = t.rDz[am + 1];
+        const double rdx_j = t.rdx[bm + 1], rDx_j = t.rDx[bm + 1], rDx_p = t.rDx[bm + 2];
+        const double esC = t.es[c], esE = t.es[c + 1];
+        k.c0 = 4.0 * t.en[c] * rdz_i * rDz_i; k.c1 = 4.0 * t.en[c - CR] * rdz_m * rDz_i;
+        k.c2 = 2.0 * esE * rDx_p * rdx_j; k.c3 = 2.0 * esC * rDx_j * rdx_j;
+        k.x0 = 2.0 * esE * rDz_i * rdx_j; k.x1 = 2.0 * esC * rDz_i * rdx_j;
+    } else {
+        const double rdx_j = t.rdx[bm + 1], rdx_m = t.rdx[bm], rDx_j = t.rDx[bm + 1];
+        const double rdz_i = t.rdz[am + 1], rDz_i = t.rDz[am + 1], rDz_p = t.rDz[am + 2];
+        const double esC = t.es[c], esN = t.es[c + CR];
+        k.c0 = 4.0 * t.en[c] * rdx_j * rDx_j; k.c1 = 4.0 * t.en[c - 1] * rdx_m * rDx_j;
+        k.c2 = 2.0 * esN * rDz_p * rdz_i; k.c3 = 2.0 * esC * rDz_i * rdz_i;
+        k.x0 = 2.0 * esN * rDx_j * rdz_i; k.x1 = 2.0 * esC * rDx_j * rdz_i;
+    }
+    k.rdg = pl_rcp(k.c0 + k.c1 + k.c2 + k.c3);
+}
+__device__ inline double mgt_dg(const MgtC& k) { return k.c0 + k.c1 + k.c2 + k.c3; }
+// (A_vv v) of the row, and v at its node
+__device__ inline double mgt_av_z(const MgtC& k, int CR, const double* vz, const double* vx, double& v0) {
+    const int c = k.cm; v0 = vz[c];
+    return k.c0 * (vz[c + CR] - v0) - k.c1 * (v0 - vz[c - CR]) + k.c2 * (vz[c + 1] - v0) - k.c3 * (v0 - vz[c - 1]) +
+           k.x0 * (vx[c + 1] - vx[c - CR + 1]) - k.x1 * (vx[c] - vx[c - CR]);
+}
+__device__ inline double mgt_av_x(const MgtC& k, int CR, const double* vz, const double* vx, double& v0) {
+    const int c = k.cm; v0 = vx[c];
+    return k.c0 * (vx[c + 1] - v0) - k.c1 * (v0 - vx[c - 1]) + k.c2 * (vx[c + CR] - v0) - k.c3 * (v0 - vx[c - CR]) +
+           k.x0 * (vz[c + CR] - vz[c + CR - 1]) - k.x1 * (vz[c] - vz[c - 1]);
+}
+// one Chebyshev sweep at a node (cheb_node).  pvz / pvx: the row's previous iterate, carried in registers from sweep to sweep (every
+// thread evaluates the same row in every stage, a slaved node its master's) -- so LDS holds two iterates, not three
+__device__ inline void mgt_cheb(const MgtC& kz, const MgtC& kx, int CR, const double* vz, const double* vx, double& pvz, double& pvx,
+                                double c1, double c2, double& oz, double& ox) {
+    oz = 0.0; ox = 0.0;
+    if (kz.on) {
+        double v0; const double Av = mgt_av_z(kz, CR, vz, vx, v0);
+        const double mom = (c1 != 0.0) ? c1 * (v0 - pvz) : 0.0;
+        oz = kz.s * (v0 + mom + (c2 * (Av - kz.f)) * kz.rdg);
+        pvz = v0;
+    }
+    if (kx.on) {
+        double v0; const double Av = mgt_av_x(kx, CR, vz, vx, v0);
+        const double mom = (c1 != 0.0) ? c1 * (v0 - pvx) : 0.0;
+        ox = kx.s * (v0 + mom + (c2 * (Av - kx.f)) * kx.rdg);
+        pvx = v0;
+    }
+}
+// threads of a tile kernel: one node of the region per thread where the region has at most 1024, else the fewest passes
+__host__ __device__ constexpr int mgt_npt(int nn) { return (nn + 1023) / 1024; }
+__host__ __device__ constexpr int mgt_nt(int nn) { return ((nn + mgt_npt(nn) - 1) / mgt_npt(nn) + 63) / 64 * 64; }
+__host__ __device__ constexpr int mgt_pre_nn(int NS, int TS) { return (TS + 2 * (NS + 2)) * (TS + 2 * (NS + 2)); }
+__host__ __device__ constexpr int mgt_post_nn(int NS, int TS) { return (TS + 2 * (NS + 1)) * (TS + 2 * (NS + 1)); }
+
 // NS: sweeps of the pre-smoothing sequence, the first from the zero guess included (1..3).  L0: level 0 of the Stokes
 // preconditioner -- the right-hand side is computed from the scaled residual rs (stage1_node) instead of read.
-template <int NS, bool L0>
-__global__ __launch_bounds__(MGT_NT) void k_mg_pre(MgTileArgs a) {
-    constexpr int TS = MGT_TS, H = NS + 1, HC = H + 1, CR = TS + 2 * HC, NN = CR * CR;
-    __shared__ double V[3][2][NN];
-    __shared__ double F[2][NN];
-    __shared__ double ES[NN], EN[NN];
+template <int NS, bool L0, int TS>
+__global__ __launch_bounds__(mgt_nt(mgt_pre_nn(NS, TS))) void k_mg_pre(MgTileArgs a) {
+    constexpr int H = NS + 1, HC = H + 1, CR = TS + 2 * HC, NN = CR * CR, NPT = mgt_npt(NN), NT = mgt_nt(NN);
+    __shared__ double V[2][2][NN];                  // two iterates; V[1] holds the viscosity planes until the rows are set up
     __shared__ double ZP[L0 ? NN : 1];
     __shared__ double TAB[4][CR + 4];
+    double* const ES = V[1][0]; double* const EN = V[1][1];
     const PlGeom& g = a.op.g;
     const int tid = threadIdx.x;
     const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x % a.tiles_x;
     const int ti0 = ty * TS, tj0 = tx * TS;
-    MgtTile<CR> T;
-    T.ci0 = ti0 - HC; T.cj0 = tj0 - HC;
-    T.t.es = ES; T.t.en = EN; T.t.rdz = TAB[0]; T.t.rDz = TAB[1]; T.t.rdx = TAB[2]; T.t.rDx = TAB[3];
-    mgt_load_table(TAB[0], a.op.rdz, T.ci0 - 1, CR + 3, g.nz); mgt_load_table(TAB[1], a.op.rDz, T.ci0 - 1, CR + 3, g.nz);
-    mgt_load_table(TAB[2], a.op.rdx, T.cj0 - 1, CR + 3, g.nx); mgt_load_table(TAB[3], a.op.rDx, T.cj0 - 1, CR + 3, g.nx);
+    const int ci0 = ti0 - HC, cj0 = tj0 - HC;
+    MgtTab t; t.es = ES; t.en = EN; t.rdz = TAB[0]; t.rDz = TAB[1]; t.rdx = TAB[2]; t.rDx = TAB[3];
+    mgt_load_table(TAB[0], a.op.rdz, ci0 - 1, CR + 3, g.nz); mgt_load_table(TAB[1], a.op.rDz, ci0 - 1, CR + 3, g.nz);
+    mgt_load_table(TAB[2], a.op.rdx, cj0 - 1, CR + 3, g.nx); mgt_load_table(TAB[3], a.op.rDx, cj0 - 1, CR + 3, g.nx);
     const long long P = g.plane;
-    // ---- load: viscosities (and the right-hand side, or the pressure residual) of the whole region; 0 beyond the planes' ring
-    for (int idx = tid; idx < NN; idx += MGT_NT) {
-        const int ra = idx / CR, rb = idx % CR, i = T.ci0 + ra, j = T.cj0 + rb;
+    // ---- load: viscosities (level 0: and S^-1 r_p) of the whole region, 0 beyond the planes' ring -- and in the same breath the
+    //      right-hand side (level 0: the scaled residual) of the row each node evaluates: its own, a slaved node its master's
+    MgtC kz[NPT], kx[NPT];
+    int depth[NPT];                                 // distance of the node from the border of the region; -1: no node
+#pragma unroll
+    for (int q = 0; q < NPT; q++) {
+        const int idx = tid + q * NT;
+        const bool have = idx < NN;
+        const int ra = have ? idx / CR : 0, rb = have ? idx % CR : 0, i = ci0 + ra, j = cj0 + rb;
+        depth[q] = have ? min(min(ra, CR - 1 - ra), min(rb, CR - 1 - rb)) : -1;
+        kz[q] = mgt_classify<true>(a.op, CR, CR, ci0, cj0, ra, rb);
+        kx[q] = mgt_classify<false>(a.op, CR, CR, ci0, cj0, ra, rb);
         const bool inmem = i >= -PL_RING && i < g.nz + PL_RING && j >= -PL_RING && j < g.nx + PL_RING;
         const long long c = pl_idx(g, i - g.gi0, j - g.gj0);
-        ES[idx] = inmem ? a.op.etas[c] : 0.0; EN[idx] = inmem ? a.op.etan[c] : 0.0;
-        if (L0) {
-            const bool indom = i >= 0 && i < g.nz && j >= 0 && j < g.nx;
-            ZP[idx] = indom ? prec_p_value(a.sop, a.rs + 2 * P, i, j, c) : 0.0;
-        } else {
-            F[0][idx] = inmem ? a.f[c] : 0.0; F[1][idx] = inmem ? a.f[c + P] : 0.0;
+        const double* const fsrc = L0 ? a.rs : a.f;
+        if (kz[q].on) kz[q].f = fsrc[c + kz[q].d];
+        if (kx[q].on) kx[q].f = fsrc[c + (long long)kx[q].d * g.pitch + P];
+        if (have) {
+            ES[idx] = inmem ? a.op.etas[c] : 0.0; EN[idx] = inmem ? a.op.etan[c] : 0.0;
+            if (L0) {
+                const bool indom = i >= 0 && i < g.nz && j >= 0 && j < g.nx;
+                ZP[idx] = indom ? prec_p_value(a.sop, a.rs + 2 * P, i, j, c) : 0.0;
+            }
         }
     }
     __syncthreads();
-    if (L0) {
-        // stage 1 (stage1_node): f = r_v - A_vp z_p on the interior momentum rows; un-scaling a row = multiplying by the sum of
-        // its four own-component coefficients (= the diagonal the sweeps use)
-        for (int idx = tid; idx < NN; idx += MGT_NT) {
-            const int ra = idx / CR, rb = idx % CR, i = T.ci0 + ra, j = T.cj0 + rb;
-            double fz = 0.0, fx = 0.0;
-            if (ra >= HC - H && ra < HC + TS + H && rb >= HC - H && rb < HC + TS + H) {
+    // ---- the coefficients of those rows.  Level 0 turns the scaled residual into the right-hand side (stage1_node):
+    //      f = r_v - A_vp z_p on the interior momentum rows; un-scaling a row = multiplying by the sum of its four own-component
+    //      coefficients (= the diagonal the sweeps use).
+#pragma unroll
+    for (int q = 0; q < NPT; q++) {
+        mgt_coefficients<true>(kz[q], t, CR); mgt_coefficients<false>(kx[q], t, CR);
+        if (L0) {
+            const int idx = tid + q * NT;
+            const int ra = depth[q] >= 0 ? idx / CR : 0, rb = depth[q] >= 0 ? idx % CR : 0, i = ci0 + ra, j = cj0 + rb;
+            if (kz[q].on) kz[q].f = kz[q].f * mgt_dg(kz[q]) + 2.0 * a.sop.Kc * TAB[1][ra + 1] * (ZP[kz[q].cm] - ZP[kz[q].cm - CR]);
+            if (kx[q].on) kx[q].f = kx[q].f * mgt_dg(kx[q]) + 2.0 * a.sop.Kc * TAB[3][rb + 1] * (ZP[kx[q].cm] - ZP[kx[q].cm - 1]);
+            if (depth[q] >= HC && i < g.nz && j < g.nx) {      // the tile itself: keep f and z_p
                 const long long c = pl_idx(g, i - g.gi0, j - g.gj0);
-                int d; double s, Av, dg;
-                if (mgt_cls_z(a.op, i, j, d, s) == VV_INT) {
-                    mgt_row_z<CR, false>(T.t, nullptr, nullptr, idx, ra, rb, Av, dg);
-                    fz = a.rs[c] * dg + 2.0 * a.sop.Kc * TAB[1][ra + 1] * (ZP[idx] - ZP[idx - CR]);
-                }
-                if (mgt_cls_x(a.op, i, j, d, s) == VV_INT) {
-                    mgt_row_x<CR, false>(T.t, nullptr, nullptr, idx, ra, rb, Av, dg);
-                    fx = a.rs[c + P] * dg + 2.0 * a.sop.Kc * TAB[3][rb + 1] * (ZP[idx] - ZP[idx - 1]);
-                }
-                if (ra >= HC && ra < HC + TS && rb >= HC && rb < HC + TS && i < g.nz && j < g.nx) {      // the tile itself: keep f and z_p
-                    a.fout[c] = fz; a.fout[c + P] = fx; a.z[c + 2 * P] = ZP[idx];
-                }
+                a.fout[c] = kz[q].interior ? kz[q].f : 0.0; a.fout[c + P] = kx[q].interior ? kx[q].f : 0.0; a.z[c + 2 * P] = ZP[idx];
             }
-            F[0][idx] = fz; F[1][idx] = fx;
         }
-        __syncthreads();
     }
-    // ---- first sweep from the zero guess on the region +-H
-    int cur = 0, prv = 1, nxt = 2;
-    for (int idx = tid; idx < NN; idx += MGT_NT) {
-        const int ra = idx / CR, rb = idx % CR;
-        if (ra >= HC - H && ra < HC + TS + H && rb >= HC - H && rb < HC + TS + H) T.first(a.op, F[0], F[1], V[cur][0], V[cur][1], a.c2[0], ra, rb);
+    // ---- first sweep from the zero guess on the region +-H (cheb_first_node): v1 = -c2 f / diag, slaves s x their master's value
+    int cur = 0;
+#pragma unroll
+    for (int q = 0; q < NPT; q++) {
+        const int idx = tid + q * NT;
+        if (depth[q] >= HC - H) {
+            V[0][0][idx] = kz[q].on ? (-kz[q].s * a.c2[0] * kz[q].f) * kz[q].rdg : 0.0;
+            V[0][1][idx] = kx[q].on ? (-kx[q].s * a.c2[0] * kx[q].f) * kx[q].rdg : 0.0;
+        }
     }
     __syncthreads();
     // ---- Chebyshev sweeps, each on a region one node smaller
+    double pvz[NPT], pvx[NPT];
+#pragma unroll
+    for (int q = 0; q < NPT; q++) { pvz[q] = 0.0; pvx[q] = 0.0; }
 #pragma unroll
     for (int k = 1; k < NS; k++) {
         const int h = H - k;
-        for (int idx = tid; idx < NN; idx += MGT_NT) {
-            const int ra = idx / CR, rb = idx % CR;
-            if (ra >= HC - h && ra < HC + TS + h && rb >= HC - h && rb < HC + TS + h) {
+#pragma unroll
+        for (int q = 0; q < NPT; q++) {
+            const int idx = tid + q * NT;
+            if (depth[q] >= HC - h) {
                 double oz, ox;
-                T.cheb(a.op, V[cur][0], V[cur][1], k == 1 ? nullptr : V[prv][0], k == 1 ? nullptr : V[prv][1], F[0], F[1], a.c1[k], a.c2[k], ra, rb, oz, ox);
-                V[nxt][0][idx] = oz; V[nxt][1][idx] = ox;
+                mgt_cheb(kz[q], kx[q], CR, V[cur][0], V[cur][1], pvz[q], pvx[q], a.c1[k], a.c2[k], oz, ox);
+                V[cur ^ 1][0][idx] = oz; V[cur ^ 1][1][idx] = ox;
             }
         }
         __syncthreads();
-        const int o = prv; prv = cur; cur = nxt; nxt = o;
+        cur ^= 1;
     }
     // ---- residual on the region +-1 (interior rows; 0 elsewhere) into the free buffer; the tile's iterate goes to memory
-    for (int idx = tid; idx < NN; idx += MGT_NT) {
-        const int ra = idx / CR, rb = idx % CR, i = T.ci0 + ra, j = T.cj0 + rb;
-        if (ra >= HC - 1 && ra < HC + TS + 1 && rb >= HC - 1 && rb < HC + TS + 1) {
-            int d; double s, Av, dg, rz = 0.0, rx = 0.0;
-            if (mgt_cls_z(a.op, i, j, d, s) == VV_INT) { mgt_row_z<CR, true>(T.t, V[cur][0], V[cur][1], idx, ra, rb, Av, dg); rz = F[0][idx] - Av; }
-            if (mgt_cls_x(a.op, i, j, d, s) == VV_INT) { mgt_row_x<CR, true>(T.t, V[cur][0], V[cur][1], idx, ra, rb, Av, dg); rx = F[1][idx] - Av; }
+    const int nxt = cur ^ 1;
+#pragma unroll
+    for (int q = 0; q < NPT; q++) {
+        const int idx = tid + q * NT;
+        if (depth[q] >= HC - 1) {
+            const int ra = idx / CR, rb = idx % CR, i = ci0 + ra, j = cj0 + rb;
+            double v0, rz = 0.0, rx = 0.0;
+            if (kz[q].interior) rz = kz[q].f - mgt_av_z(kz[q], CR, V[cur][0], V[cur][1], v0);
+            if (kx[q].interior) rx = kx[q].f - mgt_av_x(kx[q], CR, V[cur][0], V[cur][1], v0);
             V[nxt][0][idx] = rz; V[nxt][1][idx] = rx;
-            if (ra >= HC && ra < HC + TS && rb >= HC && rb < HC + TS && i < g.nz && j < g.nx) {
+            if (depth[q] >= HC && i < g.nz && j < g.nx) {
                 const long long c = pl_idx(g, i - g.gi0, j - g.gj0);
                 a.v[c] = V[cur][0][idx]; a.v[c + P] = V[cur][1][idx];
             }
@@ -2187,10 +2292,10 @@ __global__ __launch_bounds__(MGT_NT) void k_mg_pre(MgTileArgs a) {
     __syncthreads();
     // ---- full-weighting restriction (restrict_node) onto the coarse nodes of the tile
     const PlGeom& gc = a.opc.g;
-    for (int idx = tid; idx < (TS / 2) * (TS / 2); idx += MGT_NT) {
+    for (int idx = tid; idx < (TS / 2) * (TS / 2); idx += NT) {
         const int I = ty * (TS / 2) + idx / (TS / 2), J = tx * (TS / 2) + idx % (TS / 2);
         if (I >= gc.nz || J >= gc.nx) continue;
-        const int b0 = (2 * I - T.ci0) * CR + (2 * J - T.cj0);
+        const int b0 = (2 * I - ci0) * CR + (2 * J - cj0);
         int d; double s;
         double oz = 0.0, ox = 0.0;
         if (vv_cls_z(a.opc, I, J, d, s) == VV_INT) {
@@ -2213,47 +2318,60 @@ __global__ __launch_bounds__(MGT_NT) void k_mg_pre(MgTileArgs a) {
 }
 
 // NS: sweeps of the post-smoothing sequence (1..3); the last one writes the tile to `out` (times oscale)
-template <int NS>
-__global__ __launch_bounds__(MGT_NT) void k_mg_post(MgTileArgs a) {
-    constexpr int TS = MGT_TS, H = NS, HC = H + 1, CR = TS + 2 * HC, NN = CR * CR, ECR = TS / 2 + H + 6, ENN = ECR * ECR;
-    __shared__ double V[3][2][NN];
-    __shared__ double F[2][NN];
-    __shared__ double ES[NN], EN[NN];
+template <int NS, int TS>
+__global__ __launch_bounds__(mgt_nt(mgt_post_nn(NS, TS))) void k_mg_post(MgTileArgs a) {
+    constexpr int H = NS, HC = H + 1, CR = TS + 2 * HC, NN = CR * CR, ECR = TS / 2 + H + 6, ENN = ECR * ECR, NPT = mgt_npt(NN), NT = mgt_nt(NN);
+    __shared__ double V[2][2][NN];                  // V[1]: the pre-smoothed iterate; V[0]: the viscosity planes until the rows are set up
     __shared__ double EC[2][ENN];
     __shared__ double TAB[4][CR + 4];
+    double* const ES = V[0][0]; double* const EN = V[0][1];
     const PlGeom& g = a.op.g; const PlGeom& gc = a.opc.g;
     const int tid = threadIdx.x;
     const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x % a.tiles_x;
     const int ti0 = ty * TS, tj0 = tx * TS;
-    MgtTile<CR> T;
-    T.ci0 = ti0 - HC; T.cj0 = tj0 - HC;
-    T.t.es = ES; T.t.en = EN; T.t.rdz = TAB[0]; T.t.rDz = TAB[1]; T.t.rdx = TAB[2]; T.t.rDx = TAB[3];
-    mgt_load_table(TAB[0], a.op.rdz, T.ci0 - 1, CR + 3, g.nz); mgt_load_table(TAB[1], a.op.rDz, T.ci0 - 1, CR + 3, g.nz);
-    mgt_load_table(TAB[2], a.op.rdx, T.cj0 - 1, CR + 3, g.nx); mgt_load_table(TAB[3], a.op.rDx, T.cj0 - 1, CR + 3, g.nx);
+    const int ci0 = ti0 - HC, cj0 = tj0 - HC;
+    MgtTab t; t.es = ES; t.en = EN; t.rdz = TAB[0]; t.rDz = TAB[1]; t.rdx = TAB[2]; t.rDx = TAB[3];
+    mgt_load_table(TAB[0], a.op.rdz, ci0 - 1, CR + 3, g.nz); mgt_load_table(TAB[1], a.op.rDz, ci0 - 1, CR + 3, g.nz);
+    mgt_load_table(TAB[2], a.op.rdx, cj0 - 1, CR + 3, g.nx); mgt_load_table(TAB[3], a.op.rDx, cj0 - 1, CR + 3, g.nx);
     const long long P = g.plane;
     const int eI0 = ((ti0 - H) >> 1) - 2, eJ0 = ((tj0 - H) >> 1) - 2;      // coarse node of EC element (0, 0)
-    for (int idx = tid; idx < NN; idx += MGT_NT) {
-        const int ra = idx / CR, rb = idx % CR, i = T.ci0 + ra, j = T.cj0 + rb;
+    MgtC kz[NPT], kx[NPT];
+    int depth[NPT];
+#pragma unroll
+    for (int q = 0; q < NPT; q++) {
+        const int idx = tid + q * NT;
+        const bool have = idx < NN;
+        const int ra = have ? idx / CR : 0, rb = have ? idx % CR : 0, i = ci0 + ra, j = cj0 + rb;
+        depth[q] = have ? min(min(ra, CR - 1 - ra), min(rb, CR - 1 - rb)) : -1;
+        kz[q] = mgt_classify<true>(a.op, CR, CR, ci0, cj0, ra, rb);
+        kx[q] = mgt_classify<false>(a.op, CR, CR, ci0, cj0, ra, rb);
         const bool inmem = i >= -PL_RING && i < g.nz + PL_RING && j >= -PL_RING && j < g.nx + PL_RING;
         const long long c = pl_idx(g, i - g.gi0, j - g.gj0);
-        ES[idx] = inmem ? a.op.etas[c] : 0.0; EN[idx] = inmem ? a.op.etan[c] : 0.0;
-        F[0][idx] = inmem ? a.f[c] : 0.0; F[1][idx] = inmem ? a.f[c + P] : 0.0;
-        V[1][0][idx] = inmem ? a.v[c] : 0.0; V[1][1][idx] = inmem ? a.v[c + P] : 0.0;     // the pre-smoothed iterate
+        if (kz[q].on) kz[q].f = a.f[c + kz[q].d];
+        if (kx[q].on) kx[q].f = a.f[c + (long long)kx[q].d * g.pitch + P];
+        if (have) {
+            ES[idx] = inmem ? a.op.etas[c] : 0.0; EN[idx] = inmem ? a.op.etan[c] : 0.0;
+            V[1][0][idx] = inmem ? a.v[c] : 0.0; V[1][1][idx] = inmem ? a.v[c + P] : 0.0;     // the pre-smoothed iterate
+        }
     }
-    for (int idx = tid; idx < ENN; idx += MGT_NT) {
+    for (int idx = tid; idx < ENN; idx += NT) {
         const int I = eI0 + idx / ECR, J = eJ0 + idx % ECR;
         const bool inmem = I >= -PL_RING && I < gc.nz + PL_RING && J >= -PL_RING && J < gc.nx + PL_RING;
         const long long cc = pl_idx(gc, I - gc.gi0, J - gc.gj0);
         EC[0][idx] = inmem ? a.ec[cc] : 0.0; EC[1][idx] = inmem ? a.ec[cc + gc.plane] : 0.0;
     }
     __syncthreads();
-    // ---- prolongation + correction (prolong_node) on the region +-H: cur = s (v[master] + P e at the master)
+#pragma unroll
+    for (int q = 0; q < NPT; q++) { mgt_coefficients<true>(kz[q], t, CR); mgt_coefficients<false>(kx[q], t, CR); }
+    __syncthreads();                                // the viscosity planes have been read: V[0] is free
+    // ---- prolongation + correction (prolong_node) on the region +-H: V[0] = s (v[master] + P e at the master)
     auto ecz = [&](int I, int J) { return EC[0][(I - eI0) * ECR + (J - eJ0)]; };
     auto ecx = [&](int I, int J) { return EC[1][(I - eI0) * ECR + (J - eJ0)]; };
-    int cur = 0, prv = 1, nxt = 2;
-    for (int idx = tid; idx < NN; idx += MGT_NT) {
-        const int ra = idx / CR, rb = idx % CR, i = T.ci0 + ra, j = T.cj0 + rb;
-        if (ra >= HC - H && ra < HC + TS + H && rb >= HC - H && rb < HC + TS + H) {
+#pragma unroll
+    for (int q = 0; q < NPT; q++) {
+        const int idx = tid + q * NT;
+        if (depth[q] >= HC - H) {
+            const int ra = idx / CR, rb = idx % CR, i = ci0 + ra, j = cj0 + rb;
             int d; double s;
             double oz = 0.0, ox = 0.0;
             if (mgt_cls_z(a.op, i, j, d, s) != VV_ZERO) {
@@ -2277,22 +2395,215 @@ __global__ __launch_bounds__(MGT_NT) void k_mg_post(MgTileArgs a) {
     }
     __syncthreads();
     // ---- Chebyshev sweeps (the first with c1 = 0); the last one covers the tile only and goes to memory
+    int cur = 0;
+    double pvz[NPT], pvx[NPT];
+#pragma unroll
+    for (int q = 0; q < NPT; q++) { pvz[q] = 0.0; pvx[q] = 0.0; }
 #pragma unroll
     for (int k = 0; k < NS; k++) {
         const int h = H - 1 - k;
-        for (int idx = tid; idx < NN; idx += MGT_NT) {
-            const int ra = idx / CR, rb = idx % CR;
-            if (ra >= HC - h && ra < HC + TS + h && rb >= HC - h && rb < HC + TS + h) {
+#pragma unroll
+        for (int q = 0; q < NPT; q++) {
+            const int idx = tid + q * NT;
+            if (depth[q] >= HC - h) {
                 double oz, ox;
-                T.cheb(a.op, V[cur][0], V[cur][1], V[prv][0], V[prv][1], F[0], F[1], k == 0 ? 0.0 : a.c1[k], a.c2[k], ra, rb, oz, ox);
+                mgt_cheb(kz[q], kx[q], CR, V[cur][0], V[cur][1], pvz[q], pvx[q], k == 0 ? 0.0 : a.c1[k], a.c2[k], oz, ox);
                 if (k == NS - 1) {
-                    const int i = T.ci0 + ra, j = T.cj0 + rb;
+                    const int ra = idx / CR, rb = idx % CR, i = ci0 + ra, j = cj0 + rb;
                     if (i < g.nz && j < g.nx) { const long long c = pl_idx(g, i - g.gi0, j - g.gj0); a.out[c] = oz * a.oscale; a.out[c + a.out_plane] = ox * a.oscale; }
-                } else { V[nxt][0][idx] = oz; V[nxt][1][idx] = ox; }
+                } else { V[cur ^ 1][0][idx] = oz; V[cur ^ 1][1][idx] = ox; }
             }
         }
-        if (k < NS - 1) { __syncthreads(); const int o = prv; prv = cur; cur = nxt; nxt = o; }
+        if (k < NS - 1) { __syncthreads(); cur ^= 1; }
     }
+}
+
+// ---- LDS-resident coarse tail -----------------------------------------------------------------------------------------
+// The V-cycle of all levels <= 33^2 in ONE workgroup, like k_mg_tail -- but every level lives in LDS for the whole kernel (three
+// rotating iterates, right-hand side, viscosities, spacing tables; 147 KB for 33^2 + 17^2 + 9^2 + 5^2) and the stages are the tile
+// kernels' node functions on named __shared__ arrays.  k_mg_tail's 44 stages cost 2.3 us each whatever the level size (101 us per
+// preconditioner application, 17 % of it): generic node functions through flat pointers into global memory.  Same arithmetic, same
+// stage order: the result equals k_mg_tail's to rounding (test_fused_levels_match_the_staged_path runs both).
+#define MGT_TAIL_POOL 18600          // doubles
+// A level's arrays are addressed as pool + offset (never through stored pointers: those would be flat accesses, not ds_read).
+struct TailLvl { int base, NR, CR, N; };
+#define TL_V(D, buf, c) (pool + (D).base + (2 * (buf) + (c)) * (D).N)
+#define TL_F(D, c) (pool + (D).base + (6 + (c)) * (D).N)
+#define TL_ES(D) (pool + (D).base + 8 * (D).N)
+#define TL_EN(D) (pool + (D).base + 9 * (D).N)
+#define TL_TAB(D, k) (pool + (D).base + 10 * (D).N + ((k) < 2 ? (k) * ((D).NR + 3) : 2 * ((D).NR + 3) + ((k) - 2) * ((D).CR + 3)))
+// nodes that carry an equation or a slave value: i <= nz - 2 and j <= nx - 2 (the last row and column are zero rows of both
+// components and stay at the pool's zero) -- 32 x 32 = one pass of the 1024 threads on the 33^2 level
+#define TL_FOR_NODES(g)                                                                                                     \
+    for (int idx = threadIdx.x, nxm_ = (g).nx - 1, pw_ = (nxm_ & (nxm_ - 1)) == 0, sh_ = 31 - __clz(nxm_), i, j;            \
+         idx < ((g).nz - 1) * nxm_ && (i = pw_ ? idx >> sh_ : idx / nxm_, j = idx - i * nxm_, true); idx += MGT_NT)
+__device__ inline MgtTile mgt_tail_tile(double* pool, const TailLvl& D) {
+    MgtTile T; T.ci0 = -1; T.cj0 = -1; T.CR = D.CR; T.NR = D.NR;
+    T.t.es = TL_ES(D); T.t.en = TL_EN(D); T.t.rdz = TL_TAB(D, 0); T.t.rDz = TL_TAB(D, 1); T.t.rdx = TL_TAB(D, 2); T.t.rDx = TL_TAB(D, 3);
+    return T;
+}
+__device__ inline void mgt_tail_smooth(double* pool, const TailLevel& L, const TailLvl& D, int& cur, int& prv, int& nxt, int nsweep, double ratio, bool zero_guess) {
+    const double lmax = L.lmax, lmin = lmax / ratio;
+    const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
+    double rho_old = 1.0 / sigma;
+    const MgtTile T = mgt_tail_tile(pool, D);
+    for (int k = 0; k < nsweep; k++) {
+        double c1, c2;
+        if (k == 0) { c1 = 0.0; c2 = 1.0 / theta; }
+        else { const double rho = 1.0 / (2.0 * sigma - rho_old); c1 = rho * rho_old; c2 = 2.0 * rho / delta; rho_old = rho; }
+        double* const nz_ = TL_V(D, nxt, 0); double* const nx_ = TL_V(D, nxt, 1);
+        const double* const cz = TL_V(D, cur, 0); const double* const cx = TL_V(D, cur, 1);
+        const bool noprev = k == 1 && zero_guess;
+        const double* const pz = noprev ? nullptr : TL_V(D, prv, 0); const double* const px = noprev ? nullptr : TL_V(D, prv, 1);
+        TL_FOR_NODES(L.op.g) {
+            const int ra = i + 1, rb = j + 1;
+            if (k == 0 && zero_guess) T.first(L.op, TL_F(D, 0), TL_F(D, 1), nz_, nx_, c2, ra, rb);
+            else {
+                double oz, ox;
+                T.cheb(L.op, cz, cx, pz, px, TL_F(D, 0), TL_F(D, 1), c1, c2, ra, rb, oz, ox);
+                nz_[ra * D.CR + rb] = oz; nx_[ra * D.CR + rb] = ox;
+            }
+        }
+        __syncthreads();
+        const int o = prv; prv = cur; cur = nxt; nxt = o;
+    }
+}
+__global__ __launch_bounds__(MGT_NT) void k_mg_tail_lds(TailArgs a) {
+    __shared__ double pool[MGT_TAIL_POOL];
+    __shared__ TailLvl lv[PL_TAIL_MAX_LEVELS];
+    __shared__ int rot[PL_TAIL_MAX_LEVELS];          // which buffer holds a level's iterate after the way down
+    const int tid = threadIdx.x;
+    for (int k = tid; k < MGT_TAIL_POOL; k += MGT_NT) pool[k] = 0.0;          // rings, last row / column and unused corners read as zero
+    if (tid == 0) {
+        int q = 0;
+        for (int l = 0; l < a.nlev; l++) {
+            const PlGeom& g = a.L[l].op.g;
+            TailLvl D; D.base = q; D.NR = g.nz + 2; D.CR = g.nx + 2; D.N = D.NR * D.CR;
+            q += 10 * D.N + 2 * (D.NR + 3) + 2 * (D.CR + 3);
+            lv[l] = D;
+        }
+    }
+    __syncthreads();
+    // ---- load: viscosities and tables of every level, right-hand side of the first
+    for (int l = 0; l < a.nlev; l++) {
+        const TailLevel& L = a.L[l]; const PlGeom& g = L.op.g; const TailLvl D = lv[l];
+        for (int idx = tid; idx < g.nz * g.nx; idx += MGT_NT) {
+            const int i = idx / g.nx, j = idx - i * g.nx;
+            const long long c = pl_idx(g, i - g.gi0, j - g.gj0);
+            const int o = (i + 1) * D.CR + (j + 1);
+            TL_ES(D)[o] = L.op.etas[c]; TL_EN(D)[o] = L.op.etan[c];
+            if (l == 0) { TL_F(D, 0)[o] = L.f[c]; TL_F(D, 1)[o] = L.f[c + g.plane]; }
+        }
+        mgt_load_table(TL_TAB(D, 0), L.op.rdz, -2, D.NR + 3, g.nz); mgt_load_table(TL_TAB(D, 1), L.op.rDz, -2, D.NR + 3, g.nz);
+        mgt_load_table(TL_TAB(D, 2), L.op.rdx, -2, D.CR + 3, g.nx); mgt_load_table(TL_TAB(D, 3), L.op.rDx, -2, D.CR + 3, g.nx);
+    }
+    __syncthreads();
+    // ---- down
+    for (int l = 0; l < a.nlev; l++) {
+        const TailLevel& L = a.L[l]; const PlGeom& g = L.op.g; const TailLvl D = lv[l];
+        int cur = 0, prv = 1, nxt = 2;
+        if (l == a.nlev - 1) {
+            double ratio = 0.4 * g.nz * g.nx; if (ratio < 30.0) ratio = 30.0;
+            mgt_tail_smooth(pool, L, D, cur, prv, nxt, a.coarse_sweeps, ratio, true);
+            if (tid == 0) rot[l] = cur | (prv << 2) | (nxt << 4);
+            break;
+        }
+        mgt_tail_smooth(pool, L, D, cur, prv, nxt, a.nu_pre, a.ratio, true);
+        if (tid == 0) rot[l] = cur | (prv << 2) | (nxt << 4);
+        // residual on the interior rows (0 elsewhere) into the free buffer
+        const MgtTile T = mgt_tail_tile(pool, D);
+        double* const rz = TL_V(D, nxt, 0); double* const rx = TL_V(D, nxt, 1);
+        const double* const cz = TL_V(D, cur, 0); const double* const cx = TL_V(D, cur, 1);
+        TL_FOR_NODES(g) {
+            const int ra = i + 1, rb = j + 1, o = ra * D.CR + rb;
+            int d; double s, Av, dg, vz = 0.0, vx = 0.0;
+            if (mgt_cls_z(L.op, i, j, d, s) == VV_INT) { mgt_row_z<true>(T.t, D.CR, cz, cx, o, ra, rb, Av, dg); vz = TL_F(D, 0)[o] - Av; }
+            if (mgt_cls_x(L.op, i, j, d, s) == VV_INT) { mgt_row_x<true>(T.t, D.CR, cz, cx, o, ra, rb, Av, dg); vx = TL_F(D, 1)[o] - Av; }
+            rz[o] = vz; rx[o] = vx;
+        }
+        __syncthreads();
+        // restriction onto the next level's right-hand side (restrict_node)
+        const TailLevel& Cn = a.L[l + 1]; const TailLvl Dc = lv[l + 1];
+        double* const fz = TL_F(Dc, 0); double* const fx = TL_F(Dc, 1);
+        TL_FOR_NODES(Cn.op.g) {
+            const int b0 = (2 * i + 1) * D.CR + (2 * j + 1);
+            int d; double s, oz = 0.0, ox = 0.0;
+            if (vv_cls_z(Cn.op, i, j, d, s) == VV_INT) {
+                const double wz[3] = {0.25, 0.5, 0.25}, wx[4] = {0.125, 0.375, 0.375, 0.125};
+#pragma unroll
+                for (int u = 0; u < 3; u++)
+#pragma unroll
+                    for (int w = 0; w < 4; w++) oz += wz[u] * wx[w] * rz[b0 + (u - 1) * D.CR + (w - 1)];
+            }
+            if (vv_cls_x(Cn.op, i, j, d, s) == VV_INT) {
+                const double wz[4] = {0.125, 0.375, 0.375, 0.125}, wx[3] = {0.25, 0.5, 0.25};
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int w = 0; w < 3; w++) ox += wz[u] * wx[w] * rx[b0 + (u - 1) * D.CR + (w - 1)];
+            }
+            const int oc = (i + 1) * Dc.CR + (j + 1);
+            fz[oc] = oz; fx[oc] = ox;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    // ---- up
+    for (int l = a.nlev - 2; l >= 0; l--) {
+        const TailLevel& L = a.L[l]; const PlGeom& g = L.op.g; const TailLvl D = lv[l];
+        const PlGeom& gc = a.L[l + 1].op.g; const TailLvl Dc = lv[l + 1];
+        int cur = rot[l] & 3, prv = (rot[l] >> 2) & 3, nxt = (rot[l] >> 4) & 3;
+        const int curc = rot[l + 1] & 3;
+        const double* const ez = TL_V(Dc, curc, 0); const double* const ex = TL_V(Dc, curc, 1);
+        const double* const cz = TL_V(D, cur, 0); const double* const cx = TL_V(D, cur, 1);
+        double* const wz_ = TL_V(D, nxt, 0); double* const wx_ = TL_V(D, nxt, 1);
+        TL_FOR_NODES(g) {          // prolongation + correction (prolong_node) into the free buffer
+            const int o = (i + 1) * D.CR + (j + 1);
+            int d; double s, oz = 0.0, ox = 0.0;
+            if (mgt_cls_z(L.op, i, j, d, s) != VV_ZERO) {
+                const int jm = j + d, I0 = i >> 1, I1 = (i + 1) >> 1;
+                int Jn = jm >> 1, Jo = (jm & 1) ? Jn + 1 : Jn - 1;
+                Jn = min(max(Jn, 0), gc.nx - 2); Jo = min(max(Jo, 0), gc.nx - 2);
+                const double pa = 0.5 * (ez[(I0 + 1) * Dc.CR + Jn + 1] + ez[(I1 + 1) * Dc.CR + Jn + 1]);
+                const double pb = 0.5 * (ez[(I0 + 1) * Dc.CR + Jo + 1] + ez[(I1 + 1) * Dc.CR + Jo + 1]);
+                oz = s * (cz[o + d] + (0.75 * pa + 0.25 * pb));
+            }
+            if (mgt_cls_x(L.op, i, j, d, s) != VV_ZERO) {
+                const int im = i + d, J0 = j >> 1, J1 = (j + 1) >> 1;
+                int In = im >> 1, Io = (im & 1) ? In + 1 : In - 1;
+                In = min(max(In, 0), gc.nz - 2); Io = min(max(Io, 0), gc.nz - 2);
+                const double pa = 0.5 * (ex[(In + 1) * Dc.CR + J0 + 1] + ex[(In + 1) * Dc.CR + J1 + 1]);
+                const double pb = 0.5 * (ex[(Io + 1) * Dc.CR + J0 + 1] + ex[(Io + 1) * Dc.CR + J1 + 1]);
+                ox = s * (cx[o + d * D.CR] + (0.75 * pa + 0.25 * pb));
+            }
+            wz_[o] = oz; wx_[o] = ox;
+        }
+        __syncthreads();
+        { const int o = cur; cur = nxt; nxt = o; }
+        mgt_tail_smooth(pool, L, D, cur, prv, nxt, a.nu_post, a.ratio, false);
+        if (tid == 0) rot[l] = cur | (prv << 2) | (nxt << 4);
+        __syncthreads();
+    }
+    // ---- the first tail level's iterate goes back to memory
+    {
+        const TailLevel& L = a.L[0]; const PlGeom& g = L.op.g; const TailLvl D = lv[0];
+        const int cur = rot[0] & 3;
+        const double* const cz = TL_V(D, cur, 0); const double* const cx = TL_V(D, cur, 1);
+        for (int idx = tid; idx < g.nz * g.nx; idx += MGT_NT) {
+            const int i = idx / g.nx, j = idx - i * g.nx, o = (i + 1) * D.CR + (j + 1);
+            const long long c = pl_idx(g, i - g.gi0, j - g.gj0);
+            L.v[0][c] = cz[o]; L.v[0][c + g.plane] = cx[o];
+        }
+    }
+}
+// does the tail starting at level l fit into k_mg_tail_lds' pool?
+static bool mg_tail_lds_fits(const PlSolver* S, size_t l) {
+    long long need = 0;
+    for (size_t q = l; q < S->levels.size(); q++) {
+        const PlGeom& g = S->levels[q]->gh.d;
+        need += 10LL * (g.nz + 2) * (g.nx + 2) + 2LL * (g.nz + 5) + 2LL * (g.nx + 5);
+    }
+    return need <= MGT_TAIL_POOL;
 }
 
 // Chebyshev coefficients of a sequence of n sweeps on [lmax / ratio, lmax], as smooth() computes them
@@ -2328,11 +2639,14 @@ static void vcycle_fused_level(pl_ctx* ctx, PlSolver* S, size_t l, const double*
     MgTileArgs a{};
     a.op = L->op; a.opc = C->op;
     a.f = rs ? (const double*)L->f : f; a.fout = L->f; a.v = L->v[0]; a.fc = C->f;
-    a.tiles_x = (g.nx + MGT_TS - 1) / MGT_TS;
-    const dim3 grid((unsigned)(a.tiles_x * ((g.nz + MGT_TS - 1) / MGT_TS)));
+    // tile edge: 32 on the large levels (halo recomputation 1.7x instead of 2.6x at three sweeps; one workgroup per CU), 16 below
+    const int TS = (long long)g.nz * g.nx >= S->tile32_min_nodes ? 32 : MGT_TS;
+    a.tiles_x = (g.nx + TS - 1) / TS;
+    const dim3 grid((unsigned)(a.tiles_x * ((g.nz + TS - 1) / TS)));
     cheb_coeffs(L->lmax, S->cheb_ratio, npre, a.c1, a.c2);
     if (rs) { a.sop = *sop; a.rs = rs; a.z = z; }
-#define MGT_PRE(NS, L0) hipLaunchKernelGGL((k_mg_pre<NS, L0>), grid, dim3(MGT_NT), 0, ctx->stream, a)
+#define MGT_PRE(NS, L0) do { if (TS == 32) hipLaunchKernelGGL((k_mg_pre<NS, L0, 32>), grid, dim3(mgt_nt(mgt_pre_nn(NS, 32))), 0, ctx->stream, a); \
+                             else hipLaunchKernelGGL((k_mg_pre<NS, L0, MGT_TS>), grid, dim3(mgt_nt(mgt_pre_nn(NS, MGT_TS))), 0, ctx->stream, a); } while (0)
     if (rs) { if (npre == 1) MGT_PRE(1, true); else if (npre == 2) MGT_PRE(2, true); else MGT_PRE(3, true); }
     else { if (npre == 1) MGT_PRE(1, false); else if (npre == 2) MGT_PRE(2, false); else MGT_PRE(3, false); }
 #undef MGT_PRE
@@ -2341,9 +2655,10 @@ static void vcycle_fused_level(pl_ctx* ctx, PlSolver* S, size_t l, const double*
     vcycle<double>(ctx, S, l + 1, C->f, &ec, &wf, nullptr, 1.0, 0, nullptr);      // (takes the tile kernels itself where it can)
     a.ec = ec; a.out = final_out ? final_out : L->v[2]; a.oscale = final_out ? final_scale : 1.0; a.out_plane = g.plane;
     cheb_coeffs(L->lmax, S->cheb_ratio, npost, a.c1, a.c2);
-    if (npost == 1) hipLaunchKernelGGL((k_mg_post<1>), grid, dim3(MGT_NT), 0, ctx->stream, a);
-    else if (npost == 2) hipLaunchKernelGGL((k_mg_post<2>), grid, dim3(MGT_NT), 0, ctx->stream, a);
-    else hipLaunchKernelGGL((k_mg_post<3>), grid, dim3(MGT_NT), 0, ctx->stream, a);
+#define MGT_POST(NS) do { if (TS == 32) hipLaunchKernelGGL((k_mg_post<NS, 32>), grid, dim3(mgt_nt(mgt_post_nn(NS, 32))), 0, ctx->stream, a); \
+                          else hipLaunchKernelGGL((k_mg_post<NS, MGT_TS>), grid, dim3(mgt_nt(mgt_post_nn(NS, MGT_TS))), 0, ctx->stream, a); } while (0)
+    if (npost == 1) MGT_POST(1); else if (npost == 2) MGT_POST(2); else MGT_POST(3);
+#undef MGT_POST
     *out = final_out ? nullptr : L->v[2];
 }
 

@@ -262,8 +262,10 @@ def test_fused_levels_match_the_staged_path(nx, uniform, bc):
     rho = 3300 + 40 * np.sin(2 * np.pi * X / L[1]) * np.sin(np.pi * Z / L[0])
     r = rng.standard_normal(3 * nx[0] * nx[1])
     out = {}
-    for mode in ("1", "0"):
-        os.environ["PYLAMP_MG_FUSED"] = mode
+    envs = {"1": {"PYLAMP_MG_FUSED": "1"}, "0": {"PYLAMP_MG_FUSED": "0"},
+            "32": {"PYLAMP_MG_FUSED": "1", "PYLAMP_MG_TS32": "1", "PYLAMP_MG_FUSED_MAX": "100000000"}}      # 32 x 32 tiles, level 0 included
+    for mode, env in envs.items():
+        os.environ.update(env)
         try:
             _context.clear_contexts()
             A, rhs = S.makeStokesMatrix(nx, grid, f(Z, X), f(Zc, Xc), rho, bc)
@@ -272,11 +274,14 @@ def test_fused_levels_match_the_staged_path(nx, uniform, bc):
             out[mode] = (z.reshape(nx[0], nx[1], 3), x.reshape(nx[0], nx[1], 3), dict(A.last_stats))
             del A
         finally:
-            del os.environ["PYLAMP_MG_FUSED"]
+            for k in env:
+                del os.environ[k]
             _context.clear_contexts()
-    (zf, xf, sf), (zs, xs, ss) = out["1"], out["0"]
+    (zf, xf, sf), (zs, xs, ss), (z32, x32, s32) = out["1"], out["0"], out["32"]
     for q in range(3):
         assert np.max(np.abs(zf[:, :, q] - zs[:, :, q])) < 1e-10 * np.max(np.abs(zs[:, :, q])), q
+        assert np.max(np.abs(z32[:, :, q] - zs[:, :, q])) < 1e-10 * np.max(np.abs(zs[:, :, q])), q
     assert sf["converged"] == 1 and ss["converged"] == 1 and abs(sf["iterations"] - ss["iterations"]) <= 2, (sf, ss)
+    assert s32["converged"] == 1 and abs(s32["iterations"] - ss["iterations"]) <= 2, (s32, ss)
     v = lambda x: x[:, :, :2]
     assert np.linalg.norm(v(xf) - v(xs)) / np.linalg.norm(v(xs)) < 1e-6
