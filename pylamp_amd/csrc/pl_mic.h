@@ -75,6 +75,7 @@ struct PlGatherArgs {
     double* epi_T; const double* epi_hcp; const double* epi_rho; const double* epi_hcd;
     double epi_inv2, epi_dt;
     double* epi_Tsub; double* epi_dTs;
+    const int* epi_ix;                             // epoch layout (pl_step.hip): hcp / hcd of tracer t live at index epi_ix[t]; NULL: at t
 };
 
 // Sort key of a tracer for the end-of-step counting sort (pl_step.hip): the cell of this rank's block it lies in, one of the 8
@@ -126,6 +127,7 @@ struct PlScatterCellsArgs {
     const double* tz; const double* tx;
     const double* fn[6];            // node-set fields (all weighted; arithmetic, or geometric with the logarithm already taken)
     const double* fm;               // field of the two mid-face sets (heat conductivity)
+    const int* ix; unsigned ind;    // epoch layout (pl_step.hip): bit k of ind set -> fn[k] of tracer t is fn[k][ix[t]] (bit 31: fm); ix NULL: none
     double z0, hz, rhz, x0, hx, rhx;   // node grid: node k at z0 + k hz; the shifted sets start half a cell later
     int nz, nx;                     // nodes per target set (every set is nz x nx)
     int row0, nrows, col0, ncols;   // accumulator window (as PlScatterArgs)

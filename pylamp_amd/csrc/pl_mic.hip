@@ -390,7 +390,8 @@ __global__ __launch_bounds__(256) void k_gather(PlGatherArgs a) {
         if (EPI == 1) {
             const double Told = a.epi_T[t], Tnew = Told + v;
             if (!a.epi_subgrid) { a.epi_T[t] = Tnew; return; }
-            const double dt0 = a.epi_hcp[t] * a.epi_rho[t] / (a.epi_hcd[t] * a.epi_inv2);
+            const long long e = a.epi_ix ? (long long)a.epi_ix[t] : t;
+            const double dt0 = a.epi_hcp[e] * a.epi_rho[t] / (a.epi_hcd[e] * a.epi_inv2);
             const double ts = Told - (Told - Tnew) * exp(-0.5 * a.epi_dt / dt0);
             a.epi_Tsub[t] = ts; a.epi_dTs[t] = ts - Tnew;
         } else a.epi_T[t] = a.epi_Tsub[t] - v;

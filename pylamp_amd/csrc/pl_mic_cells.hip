@@ -76,9 +76,13 @@ __device__ inline void sc_slots3(double a, double w[3]) {
     else { w[0] = lo ? 0.5 - a : 0.0; w[1] = lo ? a + 0.5 : 1.5 - a; w[2] = lo ? 0.0 : a - 0.5; }
 }
 
-template <int NFN, int CEN, bool MID>
+// IND (heat step only): epoch layout of pl_step.hip -- node fields 2, 4, 5 (cp, H, mat) and the mid-face field (conductivity) of
+// tracer t are read at index a.ix[t]
+#define SC_IND_MASK ((1u << 2) | (1u << 4) | (1u << 5))
+template <int NFN, int CEN, bool MID, bool IND>
 __global__ __launch_bounds__(64) void k_scatter_cells(PlScatterCellsArgs a, int strips_x) {
     constexpr int NST = 2 + NFN + (MID ? 1 : 0);
+    constexpr unsigned IMASK = IND ? SC_IND_MASK : 0u;
     __shared__ double lds[NST][SC_CAPP];
     __shared__ int csl[SC_ROWS + 2][SC_NL + 1];                // cell_start of the rows / columns the strip visits
     const int lane = threadIdx.x, q = lane >> 4, L = lane & 15;
@@ -125,6 +129,12 @@ __global__ __launch_bounds__(64) void k_scatter_cells(PlScatterCellsArgs a, int 
     // memory time and its arithmetic time)
     constexpr int NU = SC_CAP / 64;
     double pf[NU][NST];
+    // epoch layout: the constant fields of a tracer sit at its epoch index.  The indices travel one row AHEAD of the fields and reach
+    // the loads that depend on them through LDS (ixs): prefetch(row) loads the fields of `row` with the indices staged a row ago, and
+    // the indices of row + 1 next to them -- no load of a prefetch waits for another one (a dependent load through a register costs a
+    // vmcnt wait that drains everything issued before it: 2.65 instead of 2.0 ms)
+    __shared__ int ixs[IND ? SC_CAP : 1];
+    int pix[NU];
     auto prefetch = [&](int row) {
         const int b0 = csl[row - i0][0], b1 = min(b0 + SC_CAP, csl[row - i0][SC_NL]);
 #pragma unroll
@@ -132,13 +142,27 @@ __global__ __launch_bounds__(64) void k_scatter_cells(PlScatterCellsArgs a, int 
             const int t = b0 + lane + 64 * u;
             if (t < b1) {
                 pf[u][0] = a.tz[t]; pf[u][1] = a.tx[t];
+                const int e = IND ? ixs[lane + 64 * u] : t;
 #pragma unroll
-                for (int k = 0; k < NFN; k++) pf[u][2 + k] = a.fn[k][t];
-                if (MID) pf[u][2 + NFN] = a.fm[t];
+                for (int k = 0; k < NFN; k++) pf[u][2 + k] = a.fn[k][(IMASK >> k) & 1u ? e : t];
+                if (MID) pf[u][2 + NFN] = a.fm[IND ? e : t];
             }
         }
+        if (IND && row + 1 < i1) {
+            const int c0n = csl[row + 1 - i0][0], c1n = min(c0n + SC_CAP, csl[row + 1 - i0][SC_NL]);
+#pragma unroll
+            for (int u = 0; u < NU; u++) { const int t = c0n + lane + 64 * u; if (t < c1n) pix[u] = a.ix[t]; }
+        }
     };
-    if (i0 < i1 && !(a.dbg & 8)) prefetch(i0);
+    if (i0 < i1 && !(a.dbg & 8)) {
+        if (IND) {
+            const int b0 = csl[0][0], b1 = min(b0 + SC_CAP, csl[0][SC_NL]);
+#pragma unroll
+            for (int u = 0; u < NU; u++) { const int t = b0 + lane + 64 * u; if (t < b1) ixs[lane + 64 * u] = a.ix[t]; }
+            __syncthreads();
+        }
+        prefetch(i0);
+    }
     for (int i = i0; i < i1; i++) {
         const int gi = a.crow0 + i;
         const double zc = a.z0 + gi * a.hz;                    // origin of this cell row
@@ -175,6 +199,11 @@ __global__ __launch_bounds__(64) void k_scatter_cells(PlScatterCellsArgs a, int 
                     for (int k = 0; k < NST; k++) lds[k][o] = pf[u][k];
                 }
             }
+            if (IND && i + 1 < i1) {                           // the indices of the next row (loaded with this row's fields)
+                const int c0n = csl[i + 1 - i0][0], c1n = min(c0n + SC_CAP, csl[i + 1 - i0][SC_NL]);
+#pragma unroll
+                for (int u = 0; u < NU; u++) if (c0n + lane + 64 * u < c1n) ixs[lane + 64 * u] = pix[u];
+            }
         }
         __syncthreads();
         if (i + 1 < i1 && !(a.dbg & 8)) prefetch(i + 1);
@@ -191,9 +220,10 @@ __global__ __launch_bounds__(64) void k_scatter_cells(PlScatterCellsArgs a, int 
                         const int t = wb + lane + 64 * (b * UB + u);
                         if (b * UB + u < NU && t < we) {
                             st[u][0] = a.tz[t]; st[u][1] = a.tx[t];
+                            const int e = IND ? a.ix[t] : t;
 #pragma unroll
-                            for (int k = 0; k < NFN; k++) st[u][2 + k] = a.fn[k][t];
-                            if (MID) st[u][2 + NFN] = a.fm[t];
+                            for (int k = 0; k < NFN; k++) st[u][2 + k] = a.fn[k][(IMASK >> k) & 1u ? e : t];
+                            if (MID) st[u][2 + NFN] = a.fm[IND ? e : t];
                         }
                     }
 #pragma unroll
@@ -338,11 +368,13 @@ __global__ __launch_bounds__(64) void k_scatter_cells(PlScatterCellsArgs a, int 
 }
 
 // the tracers the fused kernel set aside: one thread each, global atomics into all sets
-template <int NFN, int CEN, bool MID>
+template <int NFN, int CEN, bool MID, bool IND>
 __global__ __launch_bounds__(256) void k_scatter_cells_slow(PlScatterCellsArgs a) {
+    constexpr unsigned IMASK = IND ? SC_IND_MASK : 0u;
     const int n = min(*a.slow_count, a.slow_cap);
     for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
         const int t = a.slow_list[k];
+        const int e = IND ? a.ix[t] : t;
         const double z = a.tz[t], x = a.tx[t];
         auto add = [&](double* plane, int ni, int nj, double v) {
             if (ni < 0 || ni >= a.nz || nj < 0 || nj >= a.nx || ni < a.row0 || ni >= a.row0 + a.nrows || nj < a.col0 || nj >= a.col0 + a.ncols) return;
@@ -364,7 +396,8 @@ __global__ __launch_bounds__(256) void k_scatter_cells_slow(PlScatterCellsArgs a
                 if (flat) w = 1.0;
                 add(base, ie + di, je + dj, w);
                 for (int f = 0; f < nfs; f++) {
-                    const double v = set == 0 ? a.fn[f][t] : set == 1 ? a.fn[NFN > 1 ? 1 : 0][t] : a.fm[t];
+                    const int fk = set == 0 ? f : (NFN > 1 ? 1 : 0);
+                    const double v = set <= 1 ? a.fn[fk][(IMASK >> fk) & 1u ? e : t] : a.fm[IND ? e : t];
                     add(base + (long long)(1 + f) * a.N, ie + di, je + dj, v * w);
                 }
             }
@@ -392,11 +425,11 @@ void pl_launch_scatter_finalize_multi(pl_ctx* ctx, const PlScatterFinalArgs& a) 
     hipLaunchKernelGGL(k_scatter_finalize_multi, dim3((a.nx + 63) / 64, (a.nz + 3) / 4), dim3(64, 4), 0, ctx->stream, a);
 }
 
-template <int NFN, int CEN, bool MID>
+template <int NFN, int CEN, bool MID, bool IND = false>
 static void launch_cells(pl_ctx* ctx, const PlScatterCellsArgs& a) {
     const int strips_x = (a.ncx + SC_W - 1) / SC_W, strips_z = (a.ncz + SC_ROWS - 1) / SC_ROWS;
-    hipLaunchKernelGGL((k_scatter_cells<NFN, CEN, MID>), dim3((unsigned)(strips_x * strips_z)), dim3(64), 0, ctx->stream, a, strips_x);
-    hipLaunchKernelGGL((k_scatter_cells_slow<NFN, CEN, MID>), dim3(32), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL((k_scatter_cells<NFN, CEN, MID, IND>), dim3((unsigned)(strips_x * strips_z)), dim3(64), 0, ctx->stream, a, strips_x);
+    hipLaunchKernelGGL((k_scatter_cells_slow<NFN, CEN, MID, IND>), dim3(32), dim3(256), 0, ctx->stream, a);
 }
 
 // variant: 0 = heat step (6 node fields, weighted centres, both mid sets), 1 = heat off (2 node fields, unweighted centres),
@@ -405,7 +438,9 @@ int pl_scatter_cells_device(pl_ctx* ctx, PlScatterCellsArgs& a, int variant) {
     if (a.ncz <= 0 || a.ncx <= 0) return 0;
     a.rhz = 1.0 / a.hz; a.rhx = 1.0 / a.hx;
     PL_HIP(ctx, hipMemsetAsync(a.slow_count, 0, sizeof(int), ctx->stream));
-    if (variant == 0) launch_cells<6, 1, true>(ctx, a);
+    if (a.ix && (variant != 0 || a.ind != (SC_IND_MASK | (1u << 31)))) return pl_fail(ctx, "pl_scatter_cells_device: unsupported set of indexed fields");
+    if (variant == 0 && a.ix) launch_cells<6, 1, true, true>(ctx, a);
+    else if (variant == 0) launch_cells<6, 1, true>(ctx, a);
     else if (variant == 1) launch_cells<2, 2, false>(ctx, a);
     else if (variant == 2) launch_cells<1, 0, false>(ctx, a);
     else return pl_fail(ctx, "pl_scatter_cells_device: unknown variant");

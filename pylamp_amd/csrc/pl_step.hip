@@ -45,6 +45,13 @@ struct PlStepState {
     double max_id = -1.0;                            // current maximum of TR__ID over all ranks
     bool max_id_valid = false;                       // false after a deletion: recomputed on the device when needed
     int sort_cells = 0;                              // cells of the current sort grid (the trash bucket follows them)
+    // Epoch layout (one rank, regular grid; see sort_tracers): the ten columns no stage ever writes (tracer_const below) and `orig`
+    // stay in the order of the sort that opened the epoch; slot[t] is the epoch index of the tracer now at sorted position t.
+    int* slot = nullptr; int* slot2 = nullptr;
+    bool epoch_on = false; int epoch_age = 0;
+    // Lazy columns: RHO, ETA (rewritten by the next property update) and the tracer velocities (rewritten by the next advection) of
+    // the tracers [0, lazy_n) are still in PRE-sort order in f2[RHO], f2[ETA], tmp[0], tmp[1]; dest maps them (flush_lazy).
+    bool lazy_pending = false, lazy_inject = false; long long lazy_n = 0;
     std::vector<double> gmz, gmx;                    // midpoint grids (pylamp2.py:92-95)
 };
 
@@ -60,7 +67,7 @@ void pl_step_free(pl_ctx* ctx) {
         if (q) (void)hipFree(q);
     for (double* q : s->f) if (q) (void)hipFree(q);
     for (double* q : s->f2) if (q) (void)hipFree(q);
-    for (int* q : {s->cell, s->dest, s->orig, s->orig2, s->cell_count, s->cell_start, s->block_sums, s->need, s->need_off, s->need_flag, s->need_rank, s->cell_res}) if (q) (void)hipFree(q);
+    for (int* q : {s->slot, s->slot2, s->cell, s->dest, s->orig, s->orig2, s->cell_count, s->cell_start, s->block_sums, s->need, s->need_off, s->need_flag, s->need_rank, s->cell_res}) if (q) (void)hipFree(q);
     delete s;
     ctx->step = nullptr;
 }
@@ -263,14 +270,16 @@ __global__ __launch_bounds__(256) void k_property_update(long long n, const doub
                                                          const double* __restrict__ ace, const double* __restrict__ et0,
                                                          double* __restrict__ rho, double* __restrict__ eta, int tdep_rho,
                                                          int tdep_eta, double tref, double etamin, double etamax,
-                                                         double* __restrict__ logeta) {
+                                                         double* __restrict__ logeta, const int* __restrict__ ix) {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
+    const long long c = ix ? (long long)ix[t] : t;              // epoch layout: the constant columns sit at the tracer's epoch index
     const double Tt = T[t];
-    rho[t] = tdep_rho ? 1.0 / ((alp[t] * (Tt - tref) + 1.0) / rh0[t]) : rh0[t];
-    double e = et0[t];
+    rho[t] = tdep_rho ? 1.0 / ((alp[c] * (Tt - tref) + 1.0) / rh0[c]) : rh0[c];
+    double e = et0[c];
     if (tdep_eta) {
-        e = e * exp(ace[t] / (GASR * Tt) - ace[t] / (GASR * tref));
+        const double ac = ace[c];
+        e = e * exp(ac / (GASR * Tt) - ac / (GASR * tref));
         if (e < etamin) e = etamin;
         if (e > etamax) e = etamax;
     }
@@ -366,12 +375,14 @@ __global__ __launch_bounds__(256) void k_advection_velocity(PlGeom g, const doub
 __global__ __launch_bounds__(256) void k_subgrid_part1(long long n, double* __restrict__ T, const double* __restrict__ dTi,
                                                        const double* __restrict__ hcp, const double* __restrict__ rho,
                                                        const double* __restrict__ hcd, double inv2, double dt,
-                                                       int do_subgrid, double* __restrict__ Tsub, double* __restrict__ dTs) {
+                                                       int do_subgrid, double* __restrict__ Tsub, double* __restrict__ dTs,
+                                                       const int* __restrict__ ix) {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const double Told = T[t], Tnew = Told + dTi[t];
     if (!do_subgrid) { T[t] = Tnew; return; }
-    const double dt0 = hcp[t] * rho[t] / (hcd[t] * inv2);
+    const long long c = ix ? (long long)ix[t] : t;
+    const double dt0 = hcp[c] * rho[t] / (hcd[c] * inv2);
     const double ts = Told - (Told - Tnew) * exp(-0.5 * dt / dt0);
     Tsub[t] = ts; dTs[t] = ts - Tnew;
 }
@@ -426,11 +437,11 @@ static int grow_tracers(pl_ctx* ctx, PlStepState* S, long long n, long long keep
     for (int k = 0; k < NFTRAC; k++) { PL_TRY(regrow(&S->f[k], true)); PL_TRY(regrow(&S->f2[k], false)); }
     PL_TRY(regrow(&S->vtz, true)); PL_TRY(regrow(&S->vtx, true));
     for (double** q : {&S->tz2, &S->tx2, &S->tmp[0], &S->tmp[1], &S->tmp[2]}) PL_TRY(regrow(q, false));
-    for (int** q : {&S->dest, &S->orig2}) {
+    for (int** q : {&S->dest, &S->orig2, &S->slot2}) {
         if (*q) (void)hipFree(*q);
         PL_HIP(ctx, hipMalloc((void**)q, (size_t)cap * sizeof(int)));
     }
-    for (int** pq : {&S->orig, &S->cell}) {        // the sort keys of a sort in progress are kept as well
+    for (int** pq : {&S->orig, &S->cell, &S->slot}) {        // the sort keys of a sort in progress are kept as well
         int* q = nullptr; PL_HIP(ctx, hipMalloc((void**)&q, (size_t)cap * sizeof(int)));
         if (*pq && keep > 0) PL_HIP(ctx, hipMemcpy(q, *pq, (size_t)keep * sizeof(int), hipMemcpyDeviceToDevice));
         if (*pq) (void)hipFree(*pq);
@@ -452,7 +463,7 @@ static int ensure_tracers(pl_ctx* ctx, PlStepState* S, long long n) {
     };
     for (double** q : {&S->tz, &S->tx, &S->tz2, &S->tx2, &S->vtz, &S->vtx, &S->tmp[0], &S->tmp[1], &S->tmp[2]}) PL_TRY(re(q));
     for (int k = 0; k < NFTRAC; k++) { PL_TRY(re(&S->f[k])); PL_TRY(re(&S->f2[k])); }
-    for (int** q : {&S->cell, &S->dest, &S->orig, &S->orig2}) {
+    for (int** q : {&S->cell, &S->dest, &S->orig, &S->orig2, &S->slot, &S->slot2}) {
         if (*q) (void)hipFree(*q);
         PL_HIP(ctx, hipMalloc((void**)q, (size_t)cap * sizeof(int)));
     }
@@ -461,7 +472,10 @@ static int ensure_tracers(pl_ctx* ctx, PlStepState* S, long long n) {
 }
 
 static void unpermute(pl_ctx* ctx, PlStepState* S, int na, const double* const* in, double* const* out);
+static bool scatter_cells_on() { const char* e = getenv("PYLAMP_SCATTER"); return !(e && atoi(e) == 0); }    // read per call: tests switch it
+static int ensure_current(pl_ctx* ctx, PlStepState* S);
 struct SortOpts {
+    bool full = false;                // move every column (no epoch layout, no lazy columns): the first sort of uploaded tracers
     int del_outside = 0; double Lz = 0.0, Lx = 0.0; long long* removed = nullptr;     // fence off: delete leavers of the domain
     const pl_step_config* inject = nullptr; int it = 0; int64_t* ninjected = nullptr;  // census + refill fused into the sort
     bool keys_ready = false;          // S->cell and S->cell_count were filled by k_rk4's epilogue (prepare_sort_keys + stage_rk4)
@@ -505,6 +519,7 @@ extern "C" int pl_tracers_upload(pl_ctx* ctx, int64_t n, const double* tr_x, con
     PL_HIP(ctx, hipSetDevice(ctx->device));
     PlStepState* S = state_of(ctx);
     PL_TRY(ensure_tracers(ctx, S, n));
+    S->epoch_on = false; S->epoch_age = 0; S->lazy_pending = false;
     // stream the AoS rows through the staging buffer in chunks
     const long long chunk = 1 << 22;
     PL_TRY(pl_stage(ctx, (size_t)chunk * NFTRAC * sizeof(double)));
@@ -532,7 +547,7 @@ extern "C" int pl_tracers_upload(pl_ctx* ctx, int64_t n, const double* tr_x, con
     const int nz = ctx->nz, nx = ctx->nx;
     const double z0 = ctx->geom.zc[0], x0 = ctx->geom.xc[0];
     const double hz = (ctx->geom.zc[nz - 1] - z0) / (nz - 1), hx = (ctx->geom.xc[nx - 1] - x0) / (nx - 1);
-    PL_TRY(sort_tracers(ctx, S, z0, hz, x0, hx));
+    { SortOpts so; so.full = true; PL_TRY(sort_tracers(ctx, S, z0, hz, x0, hx, so)); }     // (an epoch opened on the caller's random order would scatter every read of the constant columns)
     PL_TRY(migrate_tracers(ctx, S, z0, hz, x0, hx));
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     S->sorted = true;
@@ -543,6 +558,7 @@ extern "C" int pl_tracers_download(pl_ctx* ctx, int64_t n, double* tr_x, double*
     PlStepState* S = state_of(ctx);
     if (n != S->n) return pl_fail(ctx, "pl_tracers_download: n does not match the resident tracer count");
     PL_HIP(ctx, hipSetDevice(ctx->device));
+    PL_TRY(ensure_current(ctx, S));
     const long long chunk = 1 << 22;
     PL_TRY(pl_stage(ctx, (size_t)chunk * NFTRAC * sizeof(double)));
     {   // caller's order
@@ -596,6 +612,7 @@ extern "C" int pl_get_tracer_velocity(pl_ctx* ctx, int64_t n, double* out) {
     PlStepState* S = state_of(ctx);
     if (n != S->n || !out) return pl_fail(ctx, "pl_get_tracer_velocity: bad argument");
     PL_HIP(ctx, hipSetDevice(ctx->device));
+    PL_TRY(ensure_current(ctx, S));
     const long long chunk = 1 << 22;
     PL_TRY(pl_stage(ctx, (size_t)chunk * 2 * sizeof(double)));
     {
@@ -620,7 +637,10 @@ struct InjectSorted {
     double* tz; double* tx; double* f[NFTRAC]; double* vtz; double* vtx; int* orig;
     double z0, hz, x0, hx; unsigned long long seed; unsigned step; double id0; int n_old;
     const double* zc; const double* xc;
+    int* slot;                   // epoch layout: epoch index of the tracer at a sorted position (NULL: every column in sorted order)
+    int lazy;                    // RHO / ETA of the residents are not in place yet: inject_fix_lazy writes the new tracers' when they are
 };
+__host__ __device__ inline bool tracer_const(int k) { return !(k == TR_RHO || k == TR_ETA || k == TR_TMP); }    // no stage writes these columns
 __global__ __launch_bounds__(64) void k_inject_sorted(InjectSorted a) {
     const int c = blockIdx.x * 64 + threadIdx.x;
     if (c >= a.nc) return;
@@ -631,21 +651,59 @@ __global__ __launch_bounds__(64) void k_inject_sorted(InjectSorted a) {
     double mean[NFTRAC];
     for (int k = 0; k < NFTRAC; k++) {
         double sum = 0.0;
-        for (int t = t0; t < t1; t++) sum += a.f[k][t];
+        if (a.lazy && (k == TR_RHO || k == TR_ETA)) { mean[k] = 0.0; continue; }
+        if (a.slot && tracer_const(k)) for (int t = t0; t < t1; t++) sum += a.f[k][a.slot[t]];
+        else for (int t = t0; t < t1; t++) sum += a.f[k][t];
         mean[k] = sum / (double)(t1 - t0);                          // 0/0 = NaN for an empty cell, like the reference
     }
     for (int q = 0; q < m; q++) {
         const int d = t1 + q;
+        const int e = a.slot ? a.n_old + a.off[c] + q : d;          // epoch layout: the constant columns of a new tracer go behind the epoch's
         const unsigned gc = (unsigned)(ci * 65536 + cj);            // the stream depends on the GLOBAL cell: same on any layout
         const double uz = inj_uniform(a.seed, gc, (unsigned)q, 2 * a.step), ux = inj_uniform(a.seed, gc, (unsigned)q, 2 * a.step + 1);
         a.tz[d] = a.zc ? a.zc[ci] + uz * (a.zc[ci + 1] - a.zc[ci]) : a.z0 + (ci + uz) * a.hz;
         a.tx[d] = a.xc ? a.xc[cj] + ux * (a.xc[cj + 1] - a.xc[cj]) : a.x0 + (cj + ux) * a.hx;
-        for (int k = 0; k < NFTRAC; k++) a.f[k][d] = mean[k];
+        for (int k = 0; k < NFTRAC; k++) {
+            if (a.lazy && (k == TR_RHO || k == TR_ETA)) continue;
+            a.f[k][tracer_const(k) ? e : d] = mean[k];
+        }
         // reference rule (pylamp2.py:621-622): the first new ID of every cell repeats the last ID handed out
-        a.f[TR__ID][d] = a.id0 + a.off[c] + q - (a.rank ? a.rank[c] : 0);
+        a.f[TR__ID][e] = a.id0 + a.off[c] + q - (a.rank ? a.rank[c] : 0);
         a.vtz[d] = 0.0; a.vtx[d] = 0.0;                             // injected tracers have not been advected yet
-        a.orig[d] = a.n_old + a.off[c] + q;                         // appended behind the residents in the caller's order
+        a.orig[e] = a.n_old + a.off[c] + q;                         // appended behind the residents in the caller's order
+        if (a.slot) a.slot[d] = e;
     }
+}
+// RHO and ETA of the tracers the last sort injected, once the residents' values have been moved into place (flush_lazy)
+__global__ __launch_bounds__(64) void k_inject_fix_lazy(int nc, const int* __restrict__ start, const int* __restrict__ count,
+                                                        const int* __restrict__ need, double* __restrict__ rho, double* __restrict__ eta) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= nc) return;
+    const int m = need[c];
+    if (m <= 0) return;
+    const int t0 = start[c], t1 = t0 + count[c];
+    double sr = 0.0, se = 0.0;
+    for (int t = t0; t < t1; t++) sr += rho[t];
+    for (int t = t0; t < t1; t++) se += eta[t];
+    sr /= (double)(t1 - t0); se /= (double)(t1 - t0);
+    for (int q = 0; q < m; q++) { rho[t1 + q] = sr; eta[t1 + q] = se; }
+}
+// slot2[dest[t]] = t: the sort that opens an epoch (its pre-sort order IS the epoch order)
+__global__ __launch_bounds__(256) void k_permute_iota(long long n, const int* __restrict__ dest, int* __restrict__ out) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[dest[t]] = (int)t;
+}
+// out_k[t] = in_k[idx[t]] for up to 5 arrays per launch (closing an epoch)
+struct GatherColsArgs { const double* in[5]; double* out[5]; int na; };
+__global__ __launch_bounds__(256) void k_gather_cols(long long n, const int* __restrict__ idx, GatherColsArgs a) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int s = idx[t];
+    for (int k = 0; k < a.na; k++) a.out[k][t] = a.in[k][s];
+}
+__global__ __launch_bounds__(256) void k_gather_int(long long n, const int* __restrict__ idx, const int* __restrict__ in, int* __restrict__ out) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = in[idx[t]];
 }
 // total[c] = count[c] + need[c] for the cells, count[c] for the buckets behind them
 __global__ __launch_bounds__(256) void k_add_need(int nc, int m, const int* __restrict__ count, const int* __restrict__ need, int* __restrict__ total) {
@@ -659,6 +717,59 @@ static int scan_ints(pl_ctx* ctx, PlStepState* S, int m, const int* in, int* out
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, ctx->stream, nb, S->block_sums);
     hipLaunchKernelGGL(k_scan_add, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, m, out, S->block_sums, 0);
     return 0;
+}
+
+// ---- epoch layout and lazy columns (one rank, regular grid, no deletion) ------------------------------------------------------------
+// The end-of-step sort used to move all 17 columns of every tracer (300 B per tracer and step, 4.4 ms for 68 M tracers: pure
+// overhead the reference does not have).  But no stage of the time step ever writes ten of the thirteen fields (tracer_const), and
+// four more columns are rewritten before anything reads them again:
+//   * EPOCH: the constant columns and `orig` stay where they were when the epoch was opened; a 4-byte `slot` per tracer -- the only
+//     thing the sort moves for them -- says where.  Tracers move less than a cell per step, so the tracers of a cell still find
+//     their constants in a few neighbouring cache lines; after PYLAMP_EPOCH (default 64) sorts relayout() brings the columns into
+//     the current order (one gather pass) and the next sort opens a new epoch.  The kernels of the step that read constants take
+//     the index array (k_property_update, k_scatter_cells, the gather epilogue, k_inject_sorted).
+//   * LAZY: RHO / ETA (next property update) and the tracer velocities (next advection) are not moved by the sort at all; whoever
+//     wants them before they are rewritten (downloads, the resident test entry points) calls ensure_current(), which moves them then.
+// Every path outside the resident step (downloads, migration, deletion, rectilinear grids, the one-set-per-pass scatter) works on
+// the classic layout: ensure_current() first.  PYLAMP_EPOCH=0 switches both off (all columns move in every sort, as before).
+static int epoch_length() { const char* e = getenv("PYLAMP_EPOCH"); return e ? atoi(e) : 64; }         // read per call: tests switch it
+static int flush_lazy(pl_ctx* ctx, PlStepState* S) {
+    if (!S->lazy_pending) return 0;
+    S->lazy_pending = false;
+    if (S->lazy_n > 0) {
+        PermArgs pa{}; pa.na = 4;
+        pa.in[0] = S->f2[TR_RHO]; pa.out[0] = S->f[TR_RHO]; pa.in[1] = S->f2[TR_ETA]; pa.out[1] = S->f[TR_ETA];
+        pa.in[2] = S->tmp[0]; pa.out[2] = S->vtz; pa.in[3] = S->tmp[1]; pa.out[3] = S->vtx;
+        hipLaunchKernelGGL(k_permute, grid1d(S->lazy_n), dim3(256), 0, ctx->stream, S->lazy_n, S->dest, pa);
+    }
+    if (S->lazy_inject)
+        hipLaunchKernelGGL(k_inject_fix_lazy, dim3((S->sort_cells + 63) / 64), dim3(64), 0, ctx->stream, S->sort_cells, S->cell_start, S->cell_res,
+                           S->need, S->f[TR_RHO], S->f[TR_ETA]);
+    PL_HIP(ctx, hipGetLastError());
+    return 0;
+}
+static int relayout(pl_ctx* ctx, PlStepState* S) {
+    if (!S->epoch_on) return 0;
+    S->epoch_on = false; S->epoch_age = 0;
+    const long long n = S->n;
+    if (n <= 0) return 0;
+    int cols[NFTRAC], nc = 0;
+    for (int k = 0; k < NFTRAC; k++) if (tracer_const(k)) cols[nc++] = k;
+    for (int k0 = 0; k0 < nc; k0 += 5) {
+        GatherColsArgs ga{}; ga.na = std::min(5, nc - k0);
+        for (int k = 0; k < ga.na; k++) { ga.in[k] = S->f[cols[k0 + k]]; ga.out[k] = S->f2[cols[k0 + k]]; }
+        hipLaunchKernelGGL(k_gather_cols, grid1d(n), dim3(256), 0, ctx->stream, n, S->slot, ga);
+    }
+    hipLaunchKernelGGL(k_gather_int, grid1d(n), dim3(256), 0, ctx->stream, n, S->slot, S->orig, S->orig2);
+    for (int k = 0; k < nc; k++) std::swap(S->f[cols[k]], S->f2[cols[k]]);
+    std::swap(S->orig, S->orig2);
+    PL_HIP(ctx, hipGetLastError());
+    return 0;
+}
+// every column in the current (sorted) order, as the code outside the resident step expects
+static int ensure_current(pl_ctx* ctx, PlStepState* S) {
+    PL_TRY(flush_lazy(ctx, S));
+    return relayout(ctx, S);
 }
 
 // Counting sort of all tracer arrays by the cells of this rank's block; leaves cell_start valid:
@@ -676,6 +787,13 @@ static int sort_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, doubl
     S->crow0 = g.gi0; S->ccol0 = g.gj0;
     long long n = S->n;
     if (n >= (1LL << 31)) return pl_fail(ctx, "sort_tracers: more than 2^31 tracers per GPU");
+    // epoch layout + lazy columns (see above) where the resident step is the only reader until the next sort
+    const bool epoch_ok = !o.full && epoch_length() > 0 && ctx->nranks == 1 && !o.del_outside && ctx->geom.uniform && scatter_cells_on();
+    if (!epoch_ok) PL_TRY(ensure_current(ctx, S));
+    else {
+        PL_TRY(flush_lazy(ctx, S));                     // (pl_step has dropped them already: rewritten before anything reads them)
+        if (S->epoch_on && S->epoch_age >= epoch_length()) PL_TRY(relayout(ctx, S));
+    }
     if (!S->cell_count || S->ncz != ncz || S->ncx != ncx) {
         if (o.keys_ready) return pl_fail(ctx, "sort_tracers: sort keys announced for another sort grid (internal error)");
         for (int** q : {&S->cell_count, &S->cell_start, &S->block_sums, &S->need, &S->need_off, &S->need_flag, &S->need_rank, &S->cell_res}) {
@@ -757,20 +875,34 @@ static int sort_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, doubl
     PL_HIP(ctx, hipMemsetAsync(S->cell_count, 0, (size_t)m * sizeof(int), ctx->stream));   // reused as fill counters
     if (n > 0) {
         hipLaunchKernelGGL(k_cell_place, grid1d(n), dim3(256), 0, ctx->stream, n, S->cell, S->cell_start, S->cell_count, S->dest);
-        // positions, the 13 fields and the velocities of the last advection travel together
-        const double* src[17]; double* dst[17];
-        src[0] = S->tz; dst[0] = S->tz2; src[1] = S->tx; dst[1] = S->tx2;
-        for (int k = 0; k < NFTRAC; k++) { src[2 + k] = S->f[k]; dst[2 + k] = S->f2[k]; }
-        src[15] = S->vtz; dst[15] = S->tmp[0]; src[16] = S->vtx; dst[16] = S->tmp[1];
-        for (int k0 = 0; k0 < 17; k0 += 5) {
-            PermArgs pa{}; pa.na = std::min(5, 17 - k0);
+        // classic: positions, the 13 fields and the velocities of the last advection travel together.
+        // epoch layout: positions and the temperature; the constants are represented by their slot; RHO, ETA and the velocities stay behind
+        const double* src[17]; double* dst[17]; int nmove = 0;
+        src[nmove] = S->tz; dst[nmove++] = S->tz2; src[nmove] = S->tx; dst[nmove++] = S->tx2;
+        for (int k = 0; k < NFTRAC; k++)
+            if (!epoch_ok || k == TR_TMP) { src[nmove] = S->f[k]; dst[nmove++] = S->f2[k]; }
+        if (!epoch_ok) { src[nmove] = S->vtz; dst[nmove++] = S->tmp[0]; src[nmove] = S->vtx; dst[nmove++] = S->tmp[1]; }
+        for (int k0 = 0; k0 < nmove; k0 += 5) {
+            PermArgs pa{}; pa.na = std::min(5, nmove - k0);
             for (int k = 0; k < pa.na; k++) { pa.in[k] = src[k0 + k]; pa.out[k] = dst[k0 + k]; }
             hipLaunchKernelGGL(k_permute, grid1d(n), dim3(256), 0, ctx->stream, n, S->dest, pa);
         }
-        hipLaunchKernelGGL(k_permute_int, grid1d(n), dim3(256), 0, ctx->stream, n, S->dest, S->orig, S->orig2);
-        std::swap(S->tz, S->tz2); std::swap(S->tx, S->tx2); std::swap(S->orig, S->orig2);
-        std::swap(S->vtz, S->tmp[0]); std::swap(S->vtx, S->tmp[1]);
-        for (int k = 0; k < NFTRAC; k++) std::swap(S->f[k], S->f2[k]);
+        std::swap(S->tz, S->tz2); std::swap(S->tx, S->tx2);
+        std::swap(S->vtz, S->tmp[0]); std::swap(S->vtx, S->tmp[1]);         // (lazy: the old values stay in tmp[0..1] / f2[RHO], f2[ETA])
+        if (!epoch_ok) {
+            hipLaunchKernelGGL(k_permute_int, grid1d(n), dim3(256), 0, ctx->stream, n, S->dest, S->orig, S->orig2);
+            std::swap(S->orig, S->orig2);
+            for (int k = 0; k < NFTRAC; k++) std::swap(S->f[k], S->f2[k]);
+        } else {
+            if (S->epoch_on) hipLaunchKernelGGL(k_permute_int, grid1d(n), dim3(256), 0, ctx->stream, n, S->dest, S->slot, S->slot2);
+            else hipLaunchKernelGGL(k_permute_iota, grid1d(n), dim3(256), 0, ctx->stream, n, S->dest, S->slot2);
+            std::swap(S->slot, S->slot2);
+            for (int k : {(int)TR_TMP, (int)TR_RHO, (int)TR_ETA}) std::swap(S->f[k], S->f2[k]);
+        }
+    }
+    if (epoch_ok) {
+        S->epoch_age = S->epoch_on ? S->epoch_age + 1 : 1; S->epoch_on = true;
+        S->lazy_pending = true; S->lazy_n = n; S->lazy_inject = ninj > 0;
     }
     if (ninj > 0) {
         InjectSorted a{};
@@ -778,6 +910,7 @@ static int sort_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, doubl
         a.need = S->need; a.off = S->need_off; a.rank = strict ? S->need_rank : nullptr;
         a.tz = S->tz; a.tx = S->tx; for (int k = 0; k < NFTRAC; k++) a.f[k] = S->f[k];
         a.vtz = S->vtz; a.vtx = S->vtx; a.orig = S->orig;
+        a.slot = epoch_ok ? S->slot : nullptr; a.lazy = epoch_ok ? 1 : 0;
         a.z0 = z0; a.hz = hz; a.x0 = x0; a.hx = hx; a.seed = o.inject->inject_seed; a.step = (unsigned)o.it; a.id0 = id0; a.n_old = (int)n;
         a.zc = coords_z(ctx, S, 0); a.xc = coords_x(ctx, S, 0);
         hipLaunchKernelGGL(k_inject_sorted, dim3((nc + 63) / 64), dim3(64), 0, ctx->stream, a);
@@ -897,9 +1030,8 @@ static int scatter_to_planes(pl_ctx* ctx, PlStepState* S, int nf, const int* fid
 //   variant 1 (heat off): nodes {rho AW, log eta GW} -> out[0..1], centres {log eta, UNWEIGHTED} -> out[2]   (pylamp2.py:316-319)
 //   variant 2:            nodes {fn[0] AW} -> out[0]                                          (subgrid diffusion, pylamp2.py:477)
 // PYLAMP_SCATTER=0 keeps the one-set-per-pass kernels (k_scatter_binned) -- the cross-check of the tests.
-static bool scatter_cells_on() { const char* e = getenv("PYLAMP_SCATTER"); return !(e && atoi(e) == 0); }    // read per call: tests switch it
 static int scatter_cells(pl_ctx* ctx, PlStepState* S, int variant, const double* const* fn, const double* fm, double z0, double hz,
-                         double x0, double hx, double* const* out) {
+                         double x0, double hx, double* const* out, const int* ix = nullptr, unsigned ind = 0u) {
     const PlGeom& g = ctx->geom.d;
     const int AW = PL_AVG_ARITHMETIC | PL_AVG_WEIGHTED, GW = PL_AVG_GEOMETRIC | PL_AVG_WEIGHTED, G0 = PL_AVG_GEOMETRIC;
     const int nfn = variant == 0 ? 6 : (variant == 1 ? 2 : 1);
@@ -908,7 +1040,7 @@ static int scatter_cells(pl_ctx* ctx, PlStepState* S, int variant, const double*
     PlScatterCellsArgs a{};
     a.tz = S->tz; a.tx = S->tx;
     for (int k = 0; k < nfn; k++) a.fn[k] = fn[k];
-    a.fm = fm;
+    a.fm = fm; a.ix = ind ? ix : nullptr; a.ind = ix ? ind : 0u;
     a.z0 = z0; a.hz = hz; a.x0 = x0; a.hx = hx; a.nz = g.nz; a.nx = g.nx;
     a.row0 = g.gi0 - 1; a.nrows = g.lnz + 2; a.col0 = g.gj0 - 1; a.ncols = g.lnx + 2;
     a.cell_start = S->cell_start; a.ncz = S->ncz; a.ncx = S->ncx; a.crow0 = S->crow0; a.ccol0 = S->ccol0;
@@ -973,7 +1105,7 @@ static int stage_props(pl_ctx* ctx, PlStepState* S, const pl_step_config* cfg) {
     const long long n = S->n;
     hipLaunchKernelGGL(k_property_update, grid1d(n), dim3(256), 0, ctx->stream, n, S->f[TR_TMP], S->f[TR_RH0], S->f[TR_ALP],
                        S->f[TR_ACE], S->f[TR_ET0], S->f[TR_RHO], S->f[TR_ETA], cfg->tdep_rho, cfg->tdep_eta, cfg->tref,
-                       cfg->etamin, cfg->etamax, S->tmp[2]);
+                       cfg->etamin, cfg->etamax, S->tmp[2], S->epoch_on ? (const int*)S->slot : (const int*)nullptr);
     PL_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -986,11 +1118,14 @@ static int stage_scatter(pl_ctx* ctx, PlStepState* S, const pl_step_config* cfg,
     const int AW = PL_AVG_ARITHMETIC | PL_AVG_WEIGHTED, GW = PL_AVG_GEOMETRIC | PL_AVG_WEIGHTED | PL_AVG_PRELOG;
     const int ETA_LOG = -3;                     // S->tmp[2]: log(eta) written by k_property_update
     const bool cells = scatter_cells_on() && ctx->geom.uniform;
+    if (!cells) PL_TRY(ensure_current(ctx, S));       // the one-set-per-pass kernels read every column at the tracer's own index
     if (cfg->do_heatdiff) {
         if (cells) {
             const double* fn[6] = {S->f[TR_RHO], S->tmp[2], S->f[TR_HCP], S->f[TR_TMP], S->f[TR_IHT], S->f[TR_MAT]};
             double* out[9] = {P.rho, P.etas, P.cp, P.T, P.H, P.mat, P.etan, P.kz, P.kx};
-            PL_TRY(scatter_cells(ctx, S, 0, fn, S->f[TR_HCD], z0, hz, x0, hx, out));
+            // epoch layout: cp, H, mat (fields 2, 4, 5) and the conductivity of the mid-face sets are constant columns
+            PL_TRY(scatter_cells(ctx, S, 0, fn, S->f[TR_HCD], z0, hz, x0, hx, out, S->epoch_on ? (const int*)S->slot : (const int*)nullptr,
+                                 (1u << 2) | (1u << 4) | (1u << 5) | (1u << 31)));
         } else {
             const int fi[6] = {TR_RHO, ETA_LOG, TR_HCP, TR_TMP, TR_IHT, TR_MAT};
             const int sc[6] = {AW, GW, AW, AW, AW, AW};
@@ -1030,6 +1165,7 @@ static int stage_temp_to_tracers(pl_ctx* ctx, PlStepState* S, const pl_step_conf
     const StepGrid q = step_grid(ctx);
     const double dz = cfg->length[0] / (nz - 1), dx = cfg->length[1] / (nx - 1);           // pylamp2.py:87
     const int AW = PL_AVG_ARITHMETIC | PL_AVG_WEIGHTED;
+    const int* ix = S->epoch_on ? S->slot : nullptr;
     double* cnt;
     PL_TRY(pl_buf(ctx, "mic_counter", 64, &cnt, false));
     PL_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
@@ -1057,12 +1193,12 @@ static int stage_temp_to_tracers(pl_ctx* ctx, PlStepState* S, const pl_step_conf
         if (fuse) {
             ga.epi = 1; ga.epi_subgrid = cfg->do_subgrid_heatdiff; ga.epi_T = S->f[TR_TMP]; ga.epi_hcp = S->f[TR_HCP];
             ga.epi_rho = S->f[TR_RHO]; ga.epi_hcd = S->f[TR_HCD]; ga.epi_inv2 = inv2; ga.epi_dt = tstep;
-            ga.epi_Tsub = S->tmp[1]; ga.epi_dTs = S->tmp[2];
+            ga.epi_Tsub = S->tmp[1]; ga.epi_dTs = S->tmp[2]; ga.epi_ix = ix;
         }
         pl_launch_gather(ctx, ga);
         if (!fuse)
             hipLaunchKernelGGL(k_subgrid_part1, grid1d(n), dim3(256), 0, ctx->stream, n, S->f[TR_TMP], S->tmp[0], S->f[TR_HCP],
-                               S->f[TR_RHO], S->f[TR_HCD], inv2, tstep, cfg->do_subgrid_heatdiff, S->tmp[1], S->tmp[2]);
+                               S->f[TR_RHO], S->f[TR_HCD], inv2, tstep, cfg->do_subgrid_heatdiff, S->tmp[1], S->tmp[2], ix);
         if (cfg->do_subgrid_heatdiff) {
             // T currently holds Told for the subgrid branch; dTs = tmp[2] -> nodes -> back to tracers
             if (scatter_cells_on() && ctx->geom.uniform) {
@@ -1174,6 +1310,10 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
 
     // tracers arrive cell-sorted (pl_tracers_upload / end of the previous step)
     if (!S->sorted) return pl_fail(ctx, "pl_step: tracers are not sorted (internal error)");
+    // the columns the last sort left behind (RHO, ETA, tracer velocities) are rewritten below before anything reads them -- unless
+    // this configuration does not run the stage that rewrites them
+    if (ctx->geom.uniform && scatter_cells_on()) S->lazy_pending = false;
+    else PL_TRY(ensure_current(ctx, S));
 
     // ---- 1. tracer properties --------------------------------------------------------------
     t0 = now_ms();
@@ -1425,6 +1565,7 @@ extern "C" int pl_resident_scatter(pl_ctx* ctx, const pl_step_config* cfg, int i
     PL_HIP(ctx, hipSetDevice(ctx->device));
     PlStepState* S = state_of(ctx);
     PL_TRY(resident_ready(ctx, S, "pl_resident_scatter"));
+    PL_TRY(flush_lazy(ctx, S));
     PL_TRY(ensure_coords(ctx, S));
     StepPlanes P;
     PL_TRY(step_planes(ctx, P));
@@ -1439,6 +1580,7 @@ extern "C" int pl_resident_temp_to_tracers(pl_ctx* ctx, const pl_step_config* cf
     PL_HIP(ctx, hipSetDevice(ctx->device));
     PlStepState* S = state_of(ctx);
     PL_TRY(resident_ready(ctx, S, "pl_resident_temp_to_tracers"));
+    PL_TRY(flush_lazy(ctx, S));
     PL_TRY(ensure_coords(ctx, S));
     StepPlanes P;
     PL_TRY(step_planes(ctx, P));
@@ -1453,6 +1595,7 @@ extern "C" int pl_resident_rk4(pl_ctx* ctx, const double* vz_pad, const double* 
     PL_HIP(ctx, hipSetDevice(ctx->device));
     PlStepState* S = state_of(ctx);
     PL_TRY(resident_ready(ctx, S, "pl_resident_rk4"));
+    PL_TRY(flush_lazy(ctx, S));
     PL_TRY(ensure_coords(ctx, S));
     const int nz = ctx->nz, nx = ctx->nx;
     const size_t VN = (size_t)(nz + 1) * (nx + 1);

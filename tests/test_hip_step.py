@@ -425,3 +425,50 @@ print("RESULT", json.dumps(dict(its=its, hits=hits, est=rep["stokes"]["error_est
     assert sum(sw["its"][3:]) < sum(sp["its"][3:]), (sw, sp)   # from the fourth step on the history is complete
     assert sum(sw["hits"][2:]) < sum(sp["hits"][2:]), (sw, sp)
     assert sw["est"] <= 3e-8 and sp["est"] <= 3e-8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("heat", [True, False])
+def test_epoch_layout_and_lazy_columns_change_nothing(heat, monkeypatch):
+    """The end-of-step sort of the resident step moves only positions, temperature and a 4-byte slot per tracer
+    (epoch layout: the ten columns no stage writes stay where they were, RHO / ETA / tracer velocities are moved only
+    when somebody asks for them; pl_step.hip).  Against PYLAMP_EPOCH=0 (every column moves in every sort): the constant
+    columns of the uploaded tracers come back IDENTICAL bit for bit, in the caller's order -- across epoch boundaries (epoch
+    length 3), with injection in every step and with downloads in the middle of an epoch; everything that went through a
+    Stokes solve agrees to the solver's own reproducibility (the order of the tracers inside a cell, hence the last bits
+    of the marker sums, depends on the order in which the sort's atomics land)."""
+    from pylamp_amd import driver
+    nx = [49, 65]; L = [660e3, 880e3]
+    runs = {}
+    const_cols = [2, 4, 5, 6, 7, 8, 9, 10, 11, 12]
+    for epoch in ("0", "3"):
+        monkeypatch.setenv("PYLAMP_EPOCH", epoch)
+        tr_x, tr_f = driver.mantle_tracers(nx, L, 9, np.random.default_rng(5))
+        rng = np.random.default_rng(6)                         # per-tracer constants: the indirection has something to get wrong
+        for col in (2, 4, 5, 6, 7, 9, 10, 11):
+            tr_f[:, col] *= rng.uniform(0.9, 1.1, tr_f.shape[0])
+        tr_f[:, 2] = rng.uniform(0, 1, tr_f.shape[0])
+        n0 = tr_x.shape[0]
+        opt = driver.Options(do_heatdiff=heat, do_subgrid_heatdiff=heat, tracdens=9, tracdens_min=8, inject_unique_ids=True)
+        sim = driver.Simulation(nx, L, tr_x, tr_f, opt)
+        out = []
+        for it in range(8):
+            rep = sim.step()
+            assert rep["stokes"]["converged"] == 1
+            if it in (1, 4, 7):                                # downloads at epoch age 2, 2 (after a relayout at 3) and 2
+                X, F = sim.tracers()
+                assert np.array_equal(F[:n0, const_cols], tr_f[:, const_cols]), (epoch, it)
+                out.append((it, rep["ninjected"], X, F, sim.tracer_velocity(), sim.field("rho"), sim.field("etas")))
+        assert sum(o[1] for o in out) > 0
+        runs[epoch] = out
+        sim.close()
+    for a, b in zip(runs["0"], runs["3"]):
+        assert a[0] == b[0] and a[1] == b[1]
+        Fa, Fb = a[3], b[3]
+        assert Fa.shape == Fb.shape
+        assert np.array_equal(Fa[:, 12], Fb[:, 12])                               # IDs incl. the injected ones
+        nan = np.isnan(Fa)
+        assert np.array_equal(nan, np.isnan(Fb))
+        assert np.allclose(Fa[~nan], Fb[~nan], rtol=1e-7, atol=0)                 # means of the injected tracers, T / rho / eta
+        assert relerr(b[2], a[2]) < 1e-9 and relerr(b[4], a[4]) < 1e-5
+        assert relerr(b[5], a[5]) < 1e-9 and relerr(b[6], a[6]) < 1e-7
