@@ -213,7 +213,8 @@ int pl_vec3_upload(pl_ctx* ctx, const PlGeom& g, const double* host, double* dve
 int pl_vec3_download(pl_ctx* ctx, const PlGeom& g, const double* dvec, double* host);
 
 // ---- kernels launched from several units -------------------------------------------------
-void pl_launch_stokes_apply(pl_ctx* ctx, const PlStokesOp& op, const double* x, double* y);
+void pl_launch_stokes_apply(pl_ctx* ctx, const PlStokesOp& op, const double* x, double* y, const double* add = nullptr,
+                            const double* coef = nullptr);
 void pl_launch_stokes_rhs(pl_ctx* ctx, const PlStokesOp& op, double* rhs);
 void pl_launch_heat_apply(pl_ctx* ctx, const PlHeatOp& op, const double* x, double* y, bool scaled = false);
 

@@ -1162,6 +1162,11 @@ struct PlSolver {
     bool defl_valid = false, defl_active = false;
     double *wdefl = nullptr, *udefl = nullptr;
     double defl_yAw = 0.0, defl_wvel2 = 0.0;     // host copies: y.(A w) and ||w_vel||^2 (the anchor-mode term of the error estimate)
+    // Lazy correction (one rank, device scalars): M leaves z = M^-1 r uncorrected and only computes the coefficient c of w (device
+    // slot 30 for the vector y, 31 for z); the operator application that follows adds c A w in its epilogue (Awdefl = A w under the
+    // current operator) and the iterate update adds (alpha c_y + omega c_z) w -- instead of one 72 B/node axpy per application
+    double* Awdefl = nullptr;
+    bool defl_lazy = false;
     double schur_scale = 1.0;    // S^ = schur_scale * Kc^2 / eta_n (PYLAMP_SCHUR_SCALE)
     long long fused_max_nodes = 1100000;      // PYLAMP_MG_FUSED_MAX: largest level (nodes) that takes the tile kernels
     long long tile32_min_nodes = 1000000;            // PYLAMP_MG_TS32: levels from this many nodes use 32 x 32 tiles (2049^2: level 1; 36.6 against 37.4 ms per step)
@@ -1240,7 +1245,7 @@ void pl_solver_free(pl_ctx* ctx) {
     PlSolver* S = (PlSolver*)ctx->krylov;
     if (!S) return;
     free_levels(S);
-    for (double* q : {S->r, S->rt, S->p, S->v, S->s, S->t, S->y, S->z, S->b, S->x, S->xb, S->dx, S->r0, S->xh, S->scal, S->wdefl, S->udefl})
+    for (double* q : {S->r, S->rt, S->p, S->v, S->s, S->t, S->y, S->z, S->b, S->x, S->xb, S->dx, S->r0, S->xh, S->scal, S->wdefl, S->udefl, S->Awdefl})
         if (q) (void)hipFree(q);
     for (double* q : S->h) if (q) (void)hipFree(q);
     for (double* q : S->hc) if (q) (void)hipFree(q);
@@ -1277,11 +1282,15 @@ __global__ void k_s_update_dev(long long n, double* __restrict__ y, const double
 // pass (beta from the fused reduction, sc[7]): r is not read back, 10 instead of 13 vector passes
 __global__ void k_xrp_update_dev(long long n, double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z,
                                  double* __restrict__ r, const double* __restrict__ s, const double* __restrict__ t,
-                                 double* __restrict__ p, const double* __restrict__ v, const double* __restrict__ sc) {
+                                 double* __restrict__ p, const double* __restrict__ v, const double* __restrict__ sc,
+                                 const double* __restrict__ wd) {
     const double alpha = sc[2], omega = sc[3], beta = sc[7];
+    const double cw = wd ? alpha * sc[30] + omega * sc[31] : 0.0;      // lazy deflation: y and z stand for y + c_y w and z + c_z w
     long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     for (; k < n; k += (long long)gridDim.x * blockDim.x) {
-        x[k] += alpha * y[k] + omega * z[k];
+        double xn = x[k] + alpha * y[k] + omega * z[k];
+        if (wd) xn += cw * wd[k];
+        x[k] = xn;
         const double rn = s[k] - omega * t[k];
         r[k] = rn;
         p[k] = rn + beta * (p[k] - omega * v[k]);
@@ -2927,7 +2936,8 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
                 PL_TRY(dots5_dev(ctx, S, g, np, use_est ? np_vel : np, w.t, w.s, w.rt));       // omega, rho' and |r|^2 from ONE reduction
                 // ... and the next direction in the same pass (the host's beta above is then only the breakdown test)
                 if (yv != w.p) {
-                    hipLaunchKernelGGL(k_xrp_update_dev, grid1d(n), dim3(256), 0, ctx->stream, n, dx, yv, zv, w.r, w.s, w.t, w.p, w.v, S->scal);
+                    hipLaunchKernelGGL(k_xrp_update_dev, grid1d(n), dim3(256), 0, ctx->stream, n, dx, yv, zv, w.r, w.s, w.t, w.p, w.v, S->scal,
+                                       (S->defl_lazy && S->defl_active && np == 3) ? (const double*)S->wdefl : (const double*)nullptr);
                     p_fused = true;
                 } else            // no preconditioner: y IS p
                     hipLaunchKernelGGL(k_xr_update_dev, grid1d(n), dim3(256), 0, ctx->stream, n, dx, yv, zv, w.r, w.s, w.t, S->scal);
@@ -3114,7 +3124,25 @@ __global__ __launch_bounds__(256) void k_defl_ysum(PlStokesOp op, const double* 
 }
 // y . (D_r A x) from the five cells without a continuity row.  mode 1: sc[24] = y.(A x) (the denominator, x = w);
 // mode 0: sc[25] = (sc[26] - y.(A x)) / sc[24]  (sc[26] = y . r, x = z); mode 2 + k_defl_divide: the same with an all-reduce in between
+__device__ inline double defl_five_cells(const PlStokesOp& op, const double* __restrict__ x);
+// lazy correction (one rank): sc[slot] = (sum of the nb k_defl_ysum partials - y.(A x)) / sc[24]; one wave
+__global__ __launch_bounds__(64) void k_defl_coef_lazy(PlStokesOp op, const double* __restrict__ x, double* __restrict__ sc, int slot, int nb,
+                                                       const double* __restrict__ part) {
+    double ysum = 0.0;
+    for (int k = threadIdx.x; k < nb; k += 64) ysum += part[2 * k];
+    for (int o = 32; o > 0; o >>= 1) ysum += __shfl_down(ysum, o, 64);
+    if (threadIdx.x != 0) return;
+    const double yAx = -defl_five_cells(op, x);
+    sc[26] = ysum;
+    sc[slot] = (sc[24] != 0.0 && isfinite(sc[24])) ? (ysum - yAx) / sc[24] : 0.0;
+}
 __global__ void k_defl_coef(PlStokesOp op, const double* __restrict__ x, double* __restrict__ sc, int mode) {
+    const double yAx = -defl_five_cells(op, x);
+    if (mode == 1) sc[24] = yAx;                                                                  // (this rank's share on several ranks)
+    else if (mode == 2) sc[27] = sc[26] - yAx;                                                    // this rank's share of the numerator
+    else sc[25] = (sc[24] != 0.0 && isfinite(sc[24])) ? (sc[26] - yAx) / sc[24] : 0.0;
+}
+__device__ inline double defl_five_cells(const PlStokesOp& op, const double* __restrict__ x) {
     const PlGeom& g = op.g;
     const int ci[5] = {op.anchor_i, 0, 0, g.nz - 2, g.nz - 2}, cj[5] = {op.anchor_j, 0, g.nx - 2, 0, g.nx - 2};
     const double* vz = x; const double* vx = x + g.plane;
@@ -3127,10 +3155,7 @@ __global__ void k_defl_coef(PlStokesOp op, const double* __restrict__ x, double*
         const long long c = pl_idx(g, i - g.gi0, j - g.gj0);
         five += (vz[c + g.pitch] - vz[c]) / TB(g.rdx, j) + (vx[c + 1] - vx[c]) / TB(g.rdz, i);      // area x div = hx dvz + hz dvx
     }
-    const double yAx = -five;
-    if (mode == 1) sc[24] = yAx;                                                                  // (this rank's share on several ranks)
-    else if (mode == 2) sc[27] = sc[26] - yAx;                                                    // this rank's share of the numerator
-    else sc[25] = (sc[24] != 0.0 && isfinite(sc[24])) ? (sc[26] - yAx) / sc[24] : 0.0;
+    return five;
 }
 __global__ void k_defl_divide(double* __restrict__ sc) { sc[25] = (sc[24] != 0.0 && isfinite(sc[24])) ? sc[27] / sc[24] : 0.0; }
 __global__ void k_axpy_dev_scalar(long long n, double* __restrict__ z, const double* __restrict__ w, const double* __restrict__ sc) {
@@ -3157,9 +3182,15 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
     PlStokesOp sop = ctx->sop;
     PlStokesOp sop_scaled = sop; sop_scaled.scaled = 1;
     S->napply = 0; S->nprec = 0;
+    // one rank with the scalars on the device: the deflation correction is applied lazily (PlSolver::Awdefl)
+    S->defl_lazy = ctx->nranks == 1 && dots_on_device(ctx, g) && !getenv("PYLAMP_HOST_SCALARS") &&
+                   !(getenv("PYLAMP_DEFL_LAZY") && atoi(getenv("PYLAMP_DEFL_LAZY")) == 0);
     VecOp A = [&](const double* in, double* out) -> int {
         PL_TRY(pl_halo(ctx, g, (double*)in, 3, g.plane));
-        pl_launch_stokes_apply(ctx, sop_scaled, in, out);      // y = D_r A x in one pass
+        // y = D_r A x in one pass; for a vector the preconditioner has just produced: + c A w (its lazy deflation correction)
+        if (S->defl_lazy && S->defl_active && (in == S->y || in == S->z))
+            pl_launch_stokes_apply(ctx, sop_scaled, in, out, S->Awdefl, S->scal + (in == S->y ? 30 : 31));
+        else pl_launch_stokes_apply(ctx, sop_scaled, in, out);
         S->napply++;
         return 0;
     };
@@ -3169,6 +3200,11 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
         if (S->defl_active) {                               // z += w y.(r - A z) / y.(A w), all scalars on the device
             const int nb = g.lnz < DOT_BLOCKS ? g.lnz : DOT_BLOCKS;
             hipLaunchKernelGGL(k_defl_ysum, dim3(nb), dim3(256), 0, ctx->stream, sop, in + 2 * g.plane, S->scal + PL_SCAL_N);
+            if (S->defl_lazy && (out == S->y || out == S->z)) {       // the coefficient only: A and the iterate update do the rest
+                hipLaunchKernelGGL(k_defl_coef_lazy, dim3(1), dim3(64), 0, ctx->stream, sop, (const double*)out, S->scal, out == S->y ? 30 : 31, nb,
+                                   (const double*)(S->scal + PL_SCAL_N));
+                return 0;
+            }
             hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, nb, S->scal + PL_SCAL_N, S->scal + 26, 0, 0.0);
             if (ctx->nranks > 1) {                          // one scalar per application: y.r and the five cells live on different ranks
                 hipLaunchKernelGGL(k_defl_coef, dim3(1), dim3(1), 0, ctx->stream, sop, (const double*)out, S->scal, 2);
@@ -3184,6 +3220,7 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
     S->defl_active = false;
     if (S->defl_enable && !sop.surfstab && S->levels.size() > 1) {
         if (!S->wdefl) { PL_TRY(dmalloc0(ctx, &S->wdefl, (size_t)n3v * sizeof(double))); PL_TRY(dmalloc0(ctx, &S->udefl, (size_t)n3v * sizeof(double))); S->defl_valid = false; }
+        if (!S->Awdefl) PL_TRY(dmalloc0(ctx, &S->Awdefl, (size_t)n3v * sizeof(double)));
         hipLaunchKernelGGL(k_defl_u, grid2d(g), dim3(64, 4), 0, ctx->stream, sop, S->udefl);
         // How good is the vector kept from the previous solve on this context for THIS operator?  ||u - A w|| / ||u||
         // (one operator application).  <= 0.1: use it as it is (measured at 2049^2: 2-3e-2 after one time step, and the
@@ -3192,20 +3229,21 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
         double q = 1.0;
         if (S->defl_valid) {
             double dq[2];
-            PL_TRY(A(S->wdefl, S->t));
-            hipLaunchKernelGGL(k_axpy_out, grid1d(n3v), dim3(256), 0, ctx->stream, n3v, S->s, (const double*)S->udefl, (const double*)S->t, -1.0);
+            PL_TRY(A(S->wdefl, S->Awdefl));                 // kept: A w under this solve's operator (lazy correction)
+            hipLaunchKernelGGL(k_axpy_out, grid1d(n3v), dim3(256), 0, ctx->stream, n3v, S->s, (const double*)S->udefl, (const double*)S->Awdefl, -1.0);
             PL_TRY(dots(ctx, S, g, 3, S->s, S->s, S->udefl, S->udefl, dq));
             q = (dq[1] > 0.0 && std::isfinite(dq[0])) ? std::sqrt(dq[0] / dq[1]) : 1.0;
         }
         static const bool trace_d = getenv("PYLAMP_SOLVER_TRACE") != nullptr;
         if (trace_d) fprintf(stderr, "[pylamp deflation] kept vector: ||u - A w|| / ||u|| = %.3e\n", q);
-        const bool reuse = S->defl_valid && q < 0.5;
+        static const double q_refresh = getenv("PYLAMP_DEFL_Q") ? atof(getenv("PYLAMP_DEFL_Q")) : 0.3;     // (0.1 until round 3: 0.45 costs no iteration at 2049^2 and halves the refreshes)
+        const bool reuse = S->defl_valid && q < std::max(0.5, q_refresh);
         if (reuse) {                                        // denominator y.(A w) of the old w under the new coefficients
             hipLaunchKernelGGL(k_defl_coef, dim3(1), dim3(1), 0, ctx->stream, sop, (const double*)S->wdefl, S->scal, 1);
             if (ctx->nranks > 1) PL_TRY(pl_comm_allreduce_dev(ctx, S->scal + 24, 1));
             S->defl_active = true;
         }
-        if (!reuse || q > 0.1) {
+        if (!reuse || q > q_refresh) {
             if (!reuse) PL_HIP(ctx, hipMemsetAsync(S->wdefl, 0, (size_t)n3v * sizeof(double), ctx->stream));
             pl_solve_stats st2{};
             PL_TRY(bicgstab(ctx, S, g, 3, A, &M, S->udefl, S->wdefl, reuse, 1e-3, 80, w, &st2));
@@ -3213,6 +3251,8 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
             if (S->defl_valid) {
                 hipLaunchKernelGGL(k_defl_coef, dim3(1), dim3(1), 0, ctx->stream, sop, (const double*)S->wdefl, S->scal, 1);
                 if (ctx->nranks > 1) PL_TRY(pl_comm_allreduce_dev(ctx, S->scal + 24, 1));
+                S->defl_active = false;                     // (A below must not take w for a preconditioned vector)
+                PL_TRY(A(S->wdefl, S->Awdefl));
             }
             S->defl_active = S->defl_valid;
         }

@@ -132,7 +132,8 @@ __device__ inline void stokes_interior_vals(const StokesRowK& k, const StokesVal
 struct StokesRows { Row2 vz_s, vz_i, vz_n, vx_s, vx_i, vx_n, p_s, p_i, en_s, en_i, es_i, es_n, t_rdx, t_rDx; };
 template <bool SCALED>
 __device__ inline void stokes_compute_store(const PlStokesOp& op, const StokesRows& R, int i, int jw, int lj0, int c,
-                                            const double* __restrict__ x, double* __restrict__ y) {
+                                            const double* __restrict__ x, double* __restrict__ y,
+                                            const double* __restrict__ add, const double* __restrict__ coef) {
     const PlGeom& g = op.g;
     const Row2 &vz_s = R.vz_s, &vz_i = R.vz_i, &vz_n = R.vz_n, &vx_s = R.vx_s, &vx_i = R.vx_i, &vx_n = R.vx_n;
     const Row2 &p_s = R.p_s, &p_i = R.p_i, &en_s = R.en_s, &en_i = R.en_i, &es_i = R.es_i, &es_n = R.es_n;
@@ -169,6 +170,15 @@ __device__ inline void stokes_compute_store(const PlStokesOp& op, const StokesRo
     q.rdx_j = rdx_b; q.rdx_m = rdx_a; q.rDx_j = rDx_b; q.rDx_p = rDx_pp;
     if (fast) stokes_interior_vals<SCALED>(rk, q, oz[1], ox[1], opv[1]);
     else if (colB) stokes_node_vals<SCALED>(op, i, j0 + 1, c + 1, q, x, oz[1], ox[1], opv[1]);
+    if (add) {                                              // wave-uniform: y = A x + coef[0] * add (pl_solver.hip, deflation)
+        const double cf = coef[0];
+        const long long P = g.plane;
+        if (colB) {
+            const double2 az = *reinterpret_cast<const double2*>(add + c), ax = *reinterpret_cast<const double2*>(add + c + P),
+                          ap = *reinterpret_cast<const double2*>(add + c + 2 * P);
+            oz[0] += cf * az.x; oz[1] += cf * az.y; ox[0] += cf * ax.x; ox[1] += cf * ax.y; opv[0] += cf * ap.x; opv[1] += cf * ap.y;
+        } else { oz[0] += cf * add[c]; ox[0] += cf * add[c + P]; opv[0] += cf * add[c + 2 * P]; }
+    }
     if (colB) {
         *reinterpret_cast<double2*>(y + c) = make_double2(oz[0], oz[1]);
         *reinterpret_cast<double2*>(y + c + g.plane) = make_double2(ox[0], ox[1]);
@@ -180,7 +190,8 @@ __device__ inline void stokes_compute_store(const PlStokesOp& op, const StokesRo
 
 template <int ROWS, bool SCALED>
 __global__ __launch_bounds__(64 * ROWS) void k_stokes_apply_v2(PlStokesOp op, const double* __restrict__ x,
-                                                               double* __restrict__ y) {
+                                                               double* __restrict__ y, const double* __restrict__ add,
+                                                               const double* __restrict__ coef) {
     const PlGeom& g = op.g;
     const int lane = threadIdx.x;
     const int lj0 = (blockIdx.x * 64 + lane) * 2;          // this lane's two columns: lj0, lj0+1
@@ -208,7 +219,7 @@ __global__ __launch_bounds__(64 * ROWS) void k_stokes_apply_v2(PlStokesOp op, co
     if (!active) return;
     const int i = g.gi0 + li;
     StokesRows R{vz_s, vz_i, vz_n, vx_s, vx_i, vx_n, p_s, p_i, en_s, en_i, es_i, es_n, t_rdx, t_rDx};
-    stokes_compute_store<SCALED>(op, R, i, g.gj0 + blockIdx.x * 128, lj0, c, x, y);
+    stokes_compute_store<SCALED>(op, R, i, g.gj0 + blockIdx.x * 128, lj0, c, x, y, add, coef);
 }
 
 __global__ __launch_bounds__(256) void k_stokes_rhs(PlStokesOp op, double* __restrict__ rhs) {
@@ -226,7 +237,8 @@ __global__ __launch_bounds__(256) void k_stokes_rhs(PlStokesOp op, double* __res
 
 static dim3 grid2d(const PlGeom& g) { return dim3((g.lnx + 63) / 64, (g.lnz + 3) / 4); }
 
-void pl_launch_stokes_apply(pl_ctx* ctx, const PlStokesOp& op, const double* x, double* y) {
+// add != NULL: y = A x + coef[0] * add  (coef on the device; add: 3 planes like y)
+void pl_launch_stokes_apply(pl_ctx* ctx, const PlStokesOp& op, const double* x, double* y, const double* add, const double* coef) {
     // Variants measured on MI355X at 2049^2: 8-byte loads 84 us; double2 81 us; + register row
     // marching (R = 8/16) 99/104 us; XCD-aware block remap, plane-stride padding: no effect; a memory-only twin
     // (same loads and stores, no arithmetic) 58 us -> the arithmetic was exposed: no divisions in the plain
@@ -241,8 +253,8 @@ void pl_launch_stokes_apply(pl_ctx* ctx, const PlStokesOp& op, const double* x, 
         const int gx = (op.g.lnx + 127) / 128;
 #define PL_APPLY_LAUNCH(KERNEL, ROWS)                                                                                   \
         do {                                                                                                            \
-            if (op.scaled) hipLaunchKernelGGL((KERNEL<ROWS, true>), dim3(gx, (op.g.lnz + ROWS - 1) / ROWS), dim3(64, ROWS), 0, ctx->stream, op, x, y);  \
-            else hipLaunchKernelGGL((KERNEL<ROWS, false>), dim3(gx, (op.g.lnz + ROWS - 1) / ROWS), dim3(64, ROWS), 0, ctx->stream, op, x, y);           \
+            if (op.scaled) hipLaunchKernelGGL((KERNEL<ROWS, true>), dim3(gx, (op.g.lnz + ROWS - 1) / ROWS), dim3(64, ROWS), 0, ctx->stream, op, x, y, add, coef);  \
+            else hipLaunchKernelGGL((KERNEL<ROWS, false>), dim3(gx, (op.g.lnz + ROWS - 1) / ROWS), dim3(64, ROWS), 0, ctx->stream, op, x, y, add, coef);           \
         } while (0)
         static const int rows_knob = [] { const char* e = getenv("PYLAMP_APPLY_ROWS"); return e ? atoi(e) : 0; }();
         const int rows = rows_knob ? rows_knob : ((long long)op.g.lnz * op.g.lnx >= 8000000LL ? 16 : 4);
