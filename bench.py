@@ -253,7 +253,9 @@ def main():
             if args.transport == "native":
                 os.environ["PYLAMP_RCCL"] = "1"
             torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            import datetime
+            # (a hung collective ends as an error after 3 minutes instead of the default 10: the driver's clock is running)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=180))
         else:
             dist.init_process_group(backend=backend)
     red_dev = "cuda" if (dist is not None and dist.get_backend() == "nccl") else "cpu"

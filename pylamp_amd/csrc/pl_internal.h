@@ -148,6 +148,15 @@ __device__ inline Row2T<T> load_row2(const T* __restrict__ row, int lj0, bool ac
     return r;
 }
 
+// the same for a row stored as TS, returned in the arithmetic type T (level 0 of the multigrid keeps three of its vectors in FP32)
+template <typename T, typename TS>
+__device__ inline Row2T<T> load_row2_as(const TS* __restrict__ row, int lj0, bool active, bool need_w, bool need_e,
+                                        int lane, bool has_right) {
+    const Row2T<TS> s = load_row2(row, lj0, active, need_w, need_e, lane, has_right);
+    Row2T<T> r;
+    r.v = PlVec2<T>::make((T)s.v.x, (T)s.v.y); r.w = (T)s.w; r.e = (T)s.e;
+    return r;
+}
 
 #define PL_ROW_LOOP(g, iters)                                                           \
     const int lj = blockIdx.x * 64 + threadIdx.x;                                       \

@@ -471,6 +471,9 @@ void pl_launch_rk4(pl_ctx* ctx, const PlRk4Args& a_in) {
     if (a_in.n <= 0) return;
     PlRk4Args a = a_in;
     a.g.sz = (a.g.nz - 1) / a.g.Lz; a.g.sx = (a.g.nx - 1) / a.g.Lx;
+    // (Round 3: a variant that stages the velocity window of a workgroup's 256 cell-sorted tracers -- ~4 x 21 nodes -- and the node
+    //  coordinates in LDS and gathers from there: 1.98 instead of 1.58 ms for the stage at 2049^2 / 68 M tracers.  The kernel is bound
+    //  by its arithmetic and the dependent chain of its four stages, not by the gather path; the window bookkeeping adds to both.  Removed.)
     if (!a.g.rect && a.g.fast_uniform) hipLaunchKernelGGL(k_rk4<true>, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, ctx->stream, a);
     else hipLaunchKernelGGL(k_rk4<false>, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, ctx->stream, a);
 }

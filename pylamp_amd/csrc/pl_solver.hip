@@ -75,8 +75,9 @@ __device__ inline T vv_stab_diag(T dg, T szz) { const T d = dg - szz; return d >
 
 // (A_vv v)_z and -diag at global node (i,j), plane offset c.  Zero-padded tables make the
 // mirror terms of the natural rows vanish (rDx[0] = rDx[nx-1] = 0, same in z).
-template <typename T>
-__device__ inline void vv_row_z(const PlVvOpT<T>& op, const T* __restrict__ vz, const T* __restrict__ vx,
+// (TV: storage type of the iterate; the arithmetic is T)
+template <typename T, typename TV>
+__device__ inline void vv_row_z(const PlVvOpT<T>& op, const TV* __restrict__ vz, const TV* __restrict__ vx,
                                 int c, int i, int j, T& Av, T& dg) {
     const int p = op.g.pitch;
     const T rdz_i = TB(op.rdz, i), rdz_m = TB(op.rdz, i - 1), rDz_i = TB(op.rDz, i);
@@ -85,19 +86,19 @@ __device__ inline void vv_row_z(const PlVvOpT<T>& op, const T* __restrict__ vz, 
     const T cN = T(4) * op.etan[c] * rdz_i * rDz_i, cS = T(4) * op.etan[c - p] * rdz_m * rDz_i;
     const T cE = T(2) * esE * rDx_p * rdx_j, cW = T(2) * esC * rDx_j * rdx_j;
     const T xE = T(2) * esE * rDz_i * rdx_j, xW = T(2) * esC * rDz_i * rdx_j;
-    const T v0 = vz[c];
-    Av = cN * (vz[c + p] - v0) - cS * (v0 - vz[c - p]) + cE * (vz[c + 1] - v0) - cW * (v0 - vz[c - 1]) +
-         xE * (vx[c + 1] - vx[c - p + 1]) - xW * (vx[c] - vx[c - p]);
+    const T v0 = (T)vz[c];
+    Av = cN * ((T)vz[c + p] - v0) - cS * (v0 - (T)vz[c - p]) + cE * ((T)vz[c + 1] - v0) - cW * (v0 - (T)vz[c - 1]) +
+         xE * ((T)vx[c + 1] - (T)vx[c - p + 1]) - xW * ((T)vx[c] - (T)vx[c - p]);
     dg = cN + cS + cE + cW;
     if (op.szz) {                                   // wave-uniform
         const T sd = op.szz[c];
-        Av += sd * v0 + op.szx[c] * vx[c];
+        Av += sd * v0 + op.szx[c] * (T)vx[c];
         dg = vv_stab_diag(dg, sd);
     }
 }
 
-template <typename T>
-__device__ inline void vv_row_x(const PlVvOpT<T>& op, const T* __restrict__ vz, const T* __restrict__ vx,
+template <typename T, typename TV>
+__device__ inline void vv_row_x(const PlVvOpT<T>& op, const TV* __restrict__ vz, const TV* __restrict__ vx,
                                 int c, int i, int j, T& Av, T& dg) {
     const int p = op.g.pitch;
     const T rdx_j = TB(op.rdx, j), rdx_m = TB(op.rdx, j - 1), rDx_j = TB(op.rDx, j);
@@ -106,9 +107,9 @@ __device__ inline void vv_row_x(const PlVvOpT<T>& op, const T* __restrict__ vz, 
     const T cE = T(4) * op.etan[c] * rdx_j * rDx_j, cW = T(4) * op.etan[c - 1] * rdx_m * rDx_j;
     const T cN = T(2) * esN * rDz_p * rdz_i, cS = T(2) * esC * rDz_i * rdz_i;
     const T zN = T(2) * esN * rDx_j * rdz_i, zS = T(2) * esC * rDx_j * rdz_i;
-    const T v0 = vx[c];
-    Av = cE * (vx[c + 1] - v0) - cW * (v0 - vx[c - 1]) + cN * (vx[c + p] - v0) - cS * (v0 - vx[c - p]) +
-         zN * (vz[c + p] - vz[c + p - 1]) - zS * (vz[c] - vz[c - 1]);
+    const T v0 = (T)vx[c];
+    Av = cE * ((T)vx[c + 1] - v0) - cW * (v0 - (T)vx[c - 1]) + cN * ((T)vx[c + p] - v0) - cS * (v0 - (T)vx[c - p]) +
+         zN * ((T)vz[c + p] - (T)vz[c + p - 1]) - zS * ((T)vz[c] - (T)vz[c - 1]);
     dg = cE + cW + cN + cS;
 }
 
@@ -124,21 +125,21 @@ __device__ inline void vv_row_x(const PlVvOpT<T>& op, const T* __restrict__ vz, 
 // update; all inputs are read-only so there is no ordering hazard).  80 B/node/sweep (FP64).
 // (32-bit element offsets from wave-uniform plane bases keep the address arithmetic in SGPR-base +
 // VGPR-offset form: fewer VGPRs, more waves per SIMD)
-template <typename T>
-__device__ inline T cheb_val_z(const PlVvOpT<T>& op, const T* __restrict__ vcur, const T* __restrict__ vprev,
-                               const T* __restrict__ f, T c1, T c2, int i, int j, int c) {
+template <typename T, typename TV, typename TF>
+__device__ inline T cheb_val_z(const PlVvOpT<T>& op, const TV* __restrict__ vcur, const TV* __restrict__ vprev,
+                               const TF* __restrict__ f, T c1, T c2, int i, int j, int c) {
     int moff = 0; T s = T(1);
     if (vv_cls_z(op, i, j, moff, s) == VV_ZERO) return T(0);
     const int cm = c + moff;
     T Av, dg;
     vv_row_z(op, vcur, vcur + op.g.plane, cm, i, j + moff, Av, dg);   // moff is +-1 for vz
-    const T v0 = vcur[cm];
-    const T mom = (c1 != T(0)) ? c1 * (v0 - (vprev ? vprev[cm] : T(0))) : T(0);   // nullptr: previous iterate is zero
-    return s * (v0 + mom + (c2 * (Av - f[cm])) * pl_rcp(dg));                     // D = -dg
+    const T v0 = (T)vcur[cm];
+    const T mom = (c1 != T(0)) ? c1 * (v0 - (vprev ? (T)vprev[cm] : T(0))) : T(0);   // nullptr: previous iterate is zero
+    return s * (v0 + mom + (c2 * (Av - (T)f[cm])) * pl_rcp(dg));                     // D = -dg
 }
-template <typename T>
-__device__ inline T cheb_val_x(const PlVvOpT<T>& op, const T* __restrict__ vcur, const T* __restrict__ vprev,
-                               const T* __restrict__ f, T c1, T c2, int i, int j, int c) {
+template <typename T, typename TV, typename TF>
+__device__ inline T cheb_val_x(const PlVvOpT<T>& op, const TV* __restrict__ vcur, const TV* __restrict__ vprev,
+                               const TF* __restrict__ f, T c1, T c2, int i, int j, int c) {
     const long long P = op.g.plane;
     int moff = 0; T s = T(1);
     if (vv_cls_x(op, i, j, moff, s) == VV_ZERO) return T(0);
@@ -146,14 +147,14 @@ __device__ inline T cheb_val_x(const PlVvOpT<T>& op, const T* __restrict__ vcur,
     const int im = i + (moff > 0 ? 1 : (moff < 0 ? -1 : 0));
     T Av, dg;
     vv_row_x(op, vcur, vcur + P, cm, im, j, Av, dg);
-    const T v0 = (vcur + P)[cm];
-    const T mom = (c1 != T(0)) ? c1 * (v0 - (vprev ? (vprev + P)[cm] : T(0))) : T(0);
-    return s * (v0 + mom + (c2 * (Av - (f + P)[cm])) * pl_rcp(dg));
+    const T v0 = (T)(vcur + P)[cm];
+    const T mom = (c1 != T(0)) ? c1 * (v0 - (vprev ? (T)(vprev + P)[cm] : T(0))) : T(0);
+    return s * (v0 + mom + (c2 * (Av - (T)(f + P)[cm])) * pl_rcp(dg));
 }
 // TO: type of the destination (the last sweep of an FP32 level 0 writes the FP64 Krylov vector, times oscale)
-template <typename T, typename TO>
-__device__ inline void cheb_node(const PlVvOpT<T>& op, const T* __restrict__ vcur, const T* __restrict__ vprev,
-                                 const T* __restrict__ f, TO* __restrict__ vnext, T c1, T c2, int i,
+template <typename T, typename TO, typename TV, typename TF>
+__device__ inline void cheb_node(const PlVvOpT<T>& op, const TV* __restrict__ vcur, const TV* __restrict__ vprev,
+                                 const TF* __restrict__ f, TO* __restrict__ vnext, T c1, T c2, int i,
                                  int j, long long c64, TO oscale = TO(1)) {
     const int c = (int)c64;
     vnext[c] = (TO)cheb_val_z(op, vcur, vprev, f, c1, c2, i, j, c) * oscale;
@@ -179,25 +180,25 @@ __device__ inline T vv_diag_x(const PlVvOpT<T>& op, int c, int i, int j) {
 
 // First sweep from a ZERO guess: A v = 0, so v1 = -c2 f / diag needs no stencil and no memset of the
 // iterate (48 instead of 80 + 16 B/node).  Slaves copy their master's value as usual.
-template <typename T>
-__device__ inline void cheb_first_node(const PlVvOpT<T>& op, const T* __restrict__ f, T* __restrict__ vnext,
+template <typename T, typename TF, typename TV>
+__device__ inline void cheb_first_node(const PlVvOpT<T>& op, const TF* __restrict__ f, TV* __restrict__ vnext,
                                        T c2, int i, int j, long long c64) {
     const long long P = op.g.plane;
     const int c = (int)c64;
-    const T* __restrict__ fz = f; const T* __restrict__ fx = f + P;
+    const TF* __restrict__ fz = f; const TF* __restrict__ fx = f + P;
     int moff = 0; T s = T(1);
     int cls = vv_cls_z(op, i, j, moff, s);
     T out = T(0);
-    if (cls != VV_ZERO) { const int cm = c + moff; out = (-s * c2 * fz[cm]) * pl_rcp(vv_diag_z(op, cm, i, j + moff)); }
-    vnext[c] = out;
+    if (cls != VV_ZERO) { const int cm = c + moff; out = (-s * c2 * (T)fz[cm]) * pl_rcp(vv_diag_z(op, cm, i, j + moff)); }
+    vnext[c] = (TV)out;
     cls = vv_cls_x(op, i, j, moff, s);
     out = T(0);
     if (cls != VV_ZERO) {
         const int cm = c + moff;
         const int im = i + (moff > 0 ? 1 : (moff < 0 ? -1 : 0));
-        out = (-s * c2 * fx[cm]) * pl_rcp(vv_diag_x(op, cm, im, j));
+        out = (-s * c2 * (T)fx[cm]) * pl_rcp(vv_diag_x(op, cm, im, j));
     }
-    (vnext + P)[c] = out;
+    (vnext + P)[c] = (TV)out;
 }
 
 template <typename T>
@@ -220,17 +221,17 @@ __global__ __launch_bounds__(256, PL_CHEB_WAVES) void k_vv_cheb(PlVvOpT<T> op, c
 
 // r = f - A v on interior rows, 0 elsewhere
 // (f and r may alias: every thread reads only its own f entries before writing r)
-template <typename T>
-__device__ inline void residual_node(const PlVvOpT<T>& op, const T* __restrict__ v, const T* f, T* r, int i,
+template <typename T, typename TV, typename TF, typename TR>
+__device__ inline void residual_node(const PlVvOpT<T>& op, const TV* __restrict__ v, const TF* f, TR* r, int i,
                                      int j, long long c64) {
     const long long P = op.g.plane;
     const int c = (int)c64;
-    const T* fx = f + P; T* rx_ = r + P;
+    const TF* fx = f + P; TR* rx_ = r + P;
     int moff; T s, Av, dg;
     T rz = T(0), rx = T(0);
-    if (vv_cls_z(op, i, j, moff, s) == VV_INT) { vv_row_z(op, v, v + P, c, i, j, Av, dg); rz = f[c] - Av; }
-    if (vv_cls_x(op, i, j, moff, s) == VV_INT) { vv_row_x(op, v, v + P, c, i, j, Av, dg); rx = fx[c] - Av; }
-    r[c] = rz; rx_[c] = rx;
+    if (vv_cls_z(op, i, j, moff, s) == VV_INT) { vv_row_z(op, v, v + P, c, i, j, Av, dg); rz = (T)f[c] - Av; }
+    if (vv_cls_x(op, i, j, moff, s) == VV_INT) { vv_row_x(op, v, v + P, c, i, j, Av, dg); rx = (T)fx[c] - Av; }
+    r[c] = (TR)rz; rx_[c] = (TR)rx;
 }
 
 template <typename T>
@@ -271,11 +272,15 @@ __device__ inline void vv_rows_vals(const VvVals<T>& q, const VvRowK<T>& k, T& A
     if (NEED_D) dx = dE + dW + dN + dS;
 }
 
-template <int MODE, typename T, typename TO>
-__global__ __launch_bounds__(256) void k_vv_sweep2(PlVvOpT<T> op, const T* __restrict__ vcur, const T* __restrict__ vprev,
-                                                   const T* f, TO* out, T c1, T c2, TO oscale) {
+// TV / TF: storage types of the iterate and of the right-hand side (the arithmetic is T; level 0 keeps f, its first iterate and its
+// residual in FP32 -- PlSolver::l0_mixed)
+template <int MODE, typename T, typename TO, typename TV = T, typename TF = T>
+__global__ __launch_bounds__(256) void k_vv_sweep2(PlVvOpT<T> op, const TV* __restrict__ vcur, const TV* __restrict__ vprev,
+                                                   const TF* f, TO* out, T c1, T c2, TO oscale) {
     typedef typename PlVec2<T>::type V2;
     typedef typename PlVec2<TO>::type VO2;
+    typedef typename PlVec2<TV>::type VV2;
+    typedef typename PlVec2<TF>::type VF2;
     const PlGeom& g = op.g;
     const int lane = threadIdx.x;
     const int lj0 = (blockIdx.x * 64 + lane) * 2;
@@ -295,9 +300,9 @@ __global__ __launch_bounds__(256) void k_vv_sweep2(PlVvOpT<T> op, const T* __res
         }
         return;
     }
-    const T* __restrict__ vz = vcur;
-    const T* __restrict__ vx = vcur + PLN;
-#define ROW(ptr, dr, w, e) load_row2((ptr) + (long long)c - lj0 + (long long)(dr) * p, lj0, active, w, e, lane, has_right)
+    const TV* __restrict__ vz = vcur;
+    const TV* __restrict__ vx = vcur + PLN;
+#define ROW(ptr, dr, w, e) load_row2_as<T>((ptr) + (long long)c - lj0 + (long long)(dr) * p, lj0, active, w, e, lane, has_right)
     const Row2T<T> vz_s = ROW(vz, -1, false, false), vz_i = ROW(vz, 0, true, true), vz_n = ROW(vz, 1, true, false);
     const Row2T<T> vx_s = ROW(vx, -1, false, true), vx_i = ROW(vx, 0, true, true), vx_n = ROW(vx, 1, false, false);
     const Row2T<T> en_s = ROW(op.etan, -1, false, false), en_i = ROW(op.etan, 0, true, false);
@@ -307,10 +312,12 @@ __global__ __launch_bounds__(256) void k_vv_sweep2(PlVvOpT<T> op, const T* __res
     const Row2T<T> t_rDx = load_row2(op.rDx + PL_TOFF + g.gj0, lj0, active, false, true, lane, has_right);
     if (!active) return;
     const bool colB = (lj0 + 1) < g.lnx;
-    const V2 fz = *reinterpret_cast<const V2*>(f + c), fx = *reinterpret_cast<const V2*>(f + PLN + c);
+    const VF2 fz_s = *reinterpret_cast<const VF2*>(f + c), fx_s = *reinterpret_cast<const VF2*>(f + PLN + c);
+    const V2 fz = PlVec2<T>::make((T)fz_s.x, (T)fz_s.y), fx = PlVec2<T>::make((T)fx_s.x, (T)fx_s.y);
     V2 pz = PlVec2<T>::make(T(0), T(0)), px = pz;
     if (MODE == 0 && c1 != T(0) && vprev) {
-        pz = *reinterpret_cast<const V2*>(vprev + c); px = *reinterpret_cast<const V2*>(vprev + PLN + c);
+        const VV2 a_ = *reinterpret_cast<const VV2*>(vprev + c), b_ = *reinterpret_cast<const VV2*>(vprev + PLN + c);
+        pz = PlVec2<T>::make((T)a_.x, (T)a_.y); px = PlVec2<T>::make((T)b_.x, (T)b_.y);
     }
     VvRowK<T> rk;
     {
@@ -386,10 +393,11 @@ __device__ inline bool stage1_fast_wave(const PlGeom& g, int i, int jw, int bx, 
 }
 // First sweep from the zero guess, two columns per lane (see cheb_first_node): v1 = -c2 f / diag.
 // only_slow != 0: stage 1 has already written the waves it treats as interior (stage1_fast_wave); do the others only
-template <typename T>
-__global__ __launch_bounds__(256) void k_vv_first2(PlVvOpT<T> op, const T* __restrict__ f, T* __restrict__ out, T c2,
+template <typename T, typename TF = T, typename TV = T>
+__global__ __launch_bounds__(256) void k_vv_first2(PlVvOpT<T> op, const TF* __restrict__ f, TV* __restrict__ out, T c2,
                                                    int only_slow, int anchor_i, int anchor_j) {
-    typedef typename PlVec2<T>::type V2;
+    typedef typename PlVec2<TV>::type V2;
+    typedef typename PlVec2<TF>::type VF2;
     const PlGeom& g = op.g;
     const int lane = threadIdx.x;
     // only_slow == 2: a 1-D launch over the FRAME of workgroups that can hold a slow wave (first / last two block rows,
@@ -426,7 +434,8 @@ __global__ __launch_bounds__(256) void k_vv_first2(PlVvOpT<T> op, const T* __res
 #undef ROW
     const Row2T<T> t_rdx = load_row2(op.rdx + PL_TOFF + g.gj0, lj0, true, true, false, lane, has_right);
     const Row2T<T> t_rDx = load_row2(op.rDx + PL_TOFF + g.gj0, lj0, true, false, true, lane, has_right);
-    const V2 fz = *reinterpret_cast<const V2*>(f + c), fx = *reinterpret_cast<const V2*>(f + PLN + c);
+    const VF2 fz_s = *reinterpret_cast<const VF2*>(f + c), fx_s = *reinterpret_cast<const VF2*>(f + PLN + c);
+    const typename PlVec2<T>::type fz = PlVec2<T>::make((T)fz_s.x, (T)fz_s.y), fx = PlVec2<T>::make((T)fx_s.x, (T)fx_s.y);
     const T rdz_i = TB(op.rdz, i), rdz_m = TB(op.rdz, i - 1), rDz_i = TB(op.rDz, i), rDz_p = TB(op.rDz, i + 1);
     const T Az = T(4) * rdz_i * rDz_i, Azm = T(4) * rdz_m * rDz_i, r2 = T(2) * rdz_i, nc2 = -c2;
     T oz[2], ox[2];
@@ -442,8 +451,8 @@ __global__ __launch_bounds__(256) void k_vv_first2(PlVvOpT<T> op, const T* __res
         const T dx = en_i.v.y * (B4 * rdx_j) + en_i.v.x * (B4 * rdx_m) + (es_n.v.y * r2) * rDz_p + (es_i.v.y * r2) * rDz_i;
         oz[1] = (nc2 * fz.y) * pl_rcp(dz); ox[1] = (nc2 * fx.y) * pl_rcp(dx);
     }
-    *reinterpret_cast<V2*>(out + c) = PlVec2<T>::make(oz[0], oz[1]);
-    *reinterpret_cast<V2*>(out + PLN + c) = PlVec2<T>::make(ox[0], ox[1]);
+    *reinterpret_cast<V2*>(out + c) = PlVec2<TV>::make((TV)oz[0], (TV)oz[1]);
+    *reinterpret_cast<V2*>(out + PLN + c) = PlVec2<TV>::make((TV)ox[0], (TV)ox[1]);
 }
 
 static inline dim3 pl_grid_rows2(const PlGeom& g) { return dim3((g.lnx + 127) / 128, (g.lnz + 3) / 4); }
@@ -528,27 +537,27 @@ __device__ inline TC prolong_x_at(const PlGeom& gc, const TC* __restrict__ ex, i
     return TC(0.75) * a + TC(0.25) * b;
 }
 
-template <typename TF, typename TC>
+template <typename TF, typename TC, typename TV>
 __device__ inline void prolong_node(const PlVvOpT<TF>& opf, const PlGeom& gc, const TC* __restrict__ ec,
-                                    const TF* __restrict__ vin, TF* __restrict__ vout, int i, int j, long long c) {
+                                    const TV* __restrict__ vin, TF* __restrict__ vout, int i, int j, long long c) {
     const long long P = opf.g.plane;
     int moff = 0; TF s = TF(1);
     int cls = vv_cls_z(opf, i, j, moff, s);
     TF o = TF(0);
-    if (cls != VV_ZERO) o = s * (vin[c + moff] + (TF)prolong_z_at(gc, ec, i, j + moff));
+    if (cls != VV_ZERO) o = s * ((TF)vin[c + moff] + (TF)prolong_z_at(gc, ec, i, j + moff));
     vout[c] = o;
     cls = vv_cls_x(opf, i, j, moff, s);
     o = TF(0);
     if (cls != VV_ZERO) {
         const int im = i + (moff > 0 ? 1 : (moff < 0 ? -1 : 0));
-        o = s * (vin[c + moff + P] + (TF)prolong_x_at(gc, ec + gc.plane, im, j));
+        o = s * ((TF)vin[c + moff + P] + (TF)prolong_x_at(gc, ec + gc.plane, im, j));
     }
     vout[c + P] = o;
 }
 
-template <typename TF, typename TC>
+template <typename TF, typename TC, typename TV = TF>
 __global__ __launch_bounds__(256) void k_vv_prolong_add(PlVvOpT<TF> opf, PlGeom gc, const TC* __restrict__ ec,
-                                                        const TF* __restrict__ vin, TF* __restrict__ vout) {
+                                                        const TV* __restrict__ vin, TF* __restrict__ vout) {
     PL_NODE_PROLOGUE(opf.g)
     prolong_node(opf, gc, ec, vin, vout, i, j, c);
 }
@@ -1172,6 +1181,8 @@ struct PlSolver {
     long long tile32_min_nodes = 1000000;            // PYLAMP_MG_TS32: levels from this many nodes use 32 x 32 tiles (2049^2: level 1; 36.6 against 37.4 ms per step)
     bool fused = true;           // PYLAMP_MG_FUSED=0: every multigrid stage as a kernel of its own (the path the tile kernels are checked against)
     bool fuse_first = true;      // PYLAMP_FUSE_FIRST=0: the first sweep of level 0 as a pass of its own
+    bool l0_mixed = true;        // PYLAMP_L0_MIXED=0: every vector of a staged level 0 in FP64 (stokes_precond_t)
+    bool l0_mixed_now = true;    // ... and only for warm-started solves to rtol >= 1e-8 (pl_stokes_solve_device)
     bool deep = true;            // PYLAMP_MG_DEEP=0: distributed levels exchange before every sweep instead of once per smoothing sequence
     int tail_nu_pre = -1, tail_nu_post = -1;        // smoothing sweeps on the replicated tail levels (-1: same as nu)
     double cheb_ratio = 6.0, lmax_safety = 1.1;     // smoothing window [lmax/ratio, lmax]; lmax = safety * power-iteration estimate
@@ -1215,6 +1226,7 @@ static PlSolver* solver_of(pl_ctx* ctx) {
         if (const char* e = getenv("PYLAMP_MG_FP32")) S->f32_enable = atoi(e) != 0;
         if (const char* e = getenv("PYLAMP_MG_FP32_NODES")) { long long v = atoll(e); if (v >= 1) S->f32_min_nodes = v; }
         if (const char* e = getenv("PYLAMP_FUSE_FIRST")) S->fuse_first = atoi(e) != 0;
+        if (const char* e = getenv("PYLAMP_L0_MIXED")) S->l0_mixed = atoi(e) != 0;
         if (const char* e = getenv("PYLAMP_MG_FUSED")) S->fused = atoi(e) != 0;
         if (const char* e = getenv("PYLAMP_MG_TS32")) { long long v = atoll(e); if (v > 0) S->tile32_min_nodes = v; }
         if (const char* e = getenv("PYLAMP_MG_FUSED_MAX")) { long long v = atoll(e); if (v > 0) S->fused_max_nodes = v; }
@@ -2739,6 +2751,54 @@ static int stokes_precond_t(pl_ctx* ctx, PlSolver* S, const double* rs, double* 
     // the first pre-smoothing sweep of level 0 (from the zero guess: v1 = -c2 f / diag) is written by stage 1 itself
     int npre0, npost0;
     level_nu(S, 0, npre0, npost0);
+    if constexpr (std::is_same<T, double>::value) {
+        // Staged level 0 (the two bandwidth-bound levels do not take the tile kernels) with V(1,1): the right-hand side f, the first
+        // iterate v1 = -c2 f / diag and the residual are STORED in FP32, everything is computed in FP64, and the iterate that carries
+        // the coarse correction (v = v1 + P e) as well as the result stay FP64.  Rounding f, v1 and r to 24 bits perturbs z by 1e-7 of
+        // |v1| << |z| -- unlike an FP32 iterate v, whose rough rounding error is amplified by (L/h)^2 in A v (why the all-FP32 level 0
+        // of round 2 cost iterations).  64 of the level's 280 B/node less.  Values outside a safe FP32 range (exotic units): all FP64.
+        // Measured (tools/l0_mixed_probe.py, 1025^2, cold start): 31 -> 33 iterations to 1e-7, 35 -> 40 to 1e-10; in the time loop at
+        // 2049^2 (warm starts, 1e-7): 10.0 -> 10.05 iterations, Stokes 20.4 -> 19.8 ms.  The perturbation of the recurrences adds up with
+        // the iteration count: hence only for solves to rtol >= 1e-8 that start from the caller's guess (the solves of a time loop).
+        const double hmean = 0.5 * ((ctx->geom.zc.back() - ctx->geom.zc.front()) / (ctx->nz - 1) + (ctx->geom.xc.back() - ctx->geom.xc.front()) / (ctx->nx - 1));
+        const double sig = ctx->sop.Kc / hmean, ik = 1.0 / S->kappa;            // ~ eta_min / h^2 and the typical entry of the scaled residual
+        const bool range_ok = std::isfinite(sig) && sig > 0.0 && ik * std::min(1.0, sig) > 1e-30 && ik * std::max(1.0, sig) < 1e22;
+        if (S->l0_mixed && S->l0_mixed_now && range_ok && !L0->dist && !L0->op.szz && g_vv_vec && (g.plane % 2) == 0 && S->levels.size() > 1 && npre0 == 1 && npost0 == 1 &&
+            S->fuse_first && S->early_K == 0 && ctx->nranks == 1 && !S->levels[1]->dist && !S->levels[1]->f32) {
+            MgLevel* C = S->levels[1];
+            // (planes of their own, zero-initialised: the ring around the block must read as zero, which a view of an FP64 buffer
+            //  that an all-FP64 solve has used before does not)
+            for (float** q : {&L0->ff, &L0->rf, &L0->vf[0]}) if (!*q) PL_TRY(fmalloc0(ctx, q, (size_t)2 * g.plane * sizeof(float)));
+            float* ff = L0->ff; float* rf = L0->rf; float* v1f = L0->vf[0];
+            double* vd = L0->v[0];
+            PlVvOpT<float> cls{};                                 // classification only (stage 1 reads the FP64 viscosities of `op`)
+            cls.g = L0->op.g; cls.slave_x = L0->op.slave_x; cls.slave_z0 = L0->op.slave_z0; cls.slave_zL = L0->op.slave_zL;
+            cls.s0 = (float)L0->op.s0; cls.sL = (float)L0->op.sL;
+            const double lmax = L0->lmax, lmin = lmax / S->cheb_ratio, c2 = 1.0 / (0.5 * (lmax + lmin));
+            const dim3 rows2 = pl_grid_rows2(g), bl(64, 4);
+            hipLaunchKernelGGL(k_prec_stage1_v2<float>, rows2, bl, 0, ctx->stream, op, cls, rs, z, ff, v1f, c2, 1.0, 1.0);
+            hipLaunchKernelGGL((k_vv_first2<double, float, float>), dim3(3 * rows2.x + 3 * rows2.y + 2), bl, 0, ctx->stream, L0->op, (const float*)ff, v1f, c2, 2,
+                               ctx->sop.anchor_i, ctx->sop.anchor_j);
+            static const bool r_double = getenv("PYLAMP_L0_MIXED") && atoi(getenv("PYLAMP_L0_MIXED")) == 2;      // experiment: residual kept in FP64
+            if (r_double) {
+                hipLaunchKernelGGL((k_vv_sweep2<1, double, double, float, float>), rows2, bl, 0, ctx->stream, L0->op, (const float*)v1f, (const float*)nullptr,
+                                   (const float*)ff, L0->r, 0.0, 0.0, 1.0);
+                hipLaunchKernelGGL((k_vv_restrict<double, double>), grid2d(C->gh.d), bl, 0, ctx->stream, g, C->op, (const double*)L0->r, C->f, 1.0);
+            } else {
+            hipLaunchKernelGGL((k_vv_sweep2<1, double, float, float, float>), rows2, bl, 0, ctx->stream, L0->op, (const float*)v1f, (const float*)nullptr,
+                               (const float*)ff, rf, 0.0, 0.0, 1.0f);
+            hipLaunchKernelGGL((k_vv_restrict<float, double>), grid2d(C->gh.d), bl, 0, ctx->stream, g, C->op, (const float*)rf, C->f, 1.0);
+            }
+            double* ec = nullptr; bool wf = false;
+            vcycle<double>(ctx, S, 1, C->f, &ec, &wf, nullptr, 1.0, 0, nullptr);
+            hipLaunchKernelGGL((k_vv_prolong_add<double, double, float>), grid2d(g), bl, 0, ctx->stream, L0->op, C->gh.d, (const double*)ec, (const float*)v1f, vd);
+            hipLaunchKernelGGL((k_vv_sweep2<0, double, double, double, float>), rows2, bl, 0, ctx->stream, L0->op, (const double*)vd, (const double*)nullptr,
+                               (const float*)ff, z, 0.0, c2, 1.0);
+            PL_HIP(ctx, hipGetLastError());
+            S->nprec++;
+            return 0;
+        }
+    }
     const bool fuse_first = S->fuse_first && g_vv_vec && (g.plane % 2) == 0 && S->levels.size() > 1 && npre0 >= 1 && !L0->op.szz;
     const int anchor[2] = {ctx->sop.anchor_i, ctx->sop.anchor_j};
     T* f0 = LevelT<T>::f(L0);
@@ -3182,6 +3242,7 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
     PlStokesOp sop = ctx->sop;
     PlStokesOp sop_scaled = sop; sop_scaled.scaled = 1;
     S->napply = 0; S->nprec = 0;
+    S->l0_mixed_now = rtol >= 1e-8 && use_x0;                // warm-started solves of a time loop (see stokes_precond_t)
     // one rank with the scalars on the device: the deflation correction is applied lazily (PlSolver::Awdefl)
     S->defl_lazy = ctx->nranks == 1 && dots_on_device(ctx, g) && !getenv("PYLAMP_HOST_SCALARS") &&
                    !(getenv("PYLAMP_DEFL_LAZY") && atoi(getenv("PYLAMP_DEFL_LAZY")) == 0);

@@ -226,6 +226,25 @@ __global__ __launch_bounds__(256) void k_permute(long long n, const int* __restr
     for (int k = 0; k < a.na; k++) a.out[k][d] = a.in[k][t];
 }
 
+// k_cell_place and the permutation of the few columns the epoch layout moves, in one pass: the destination goes straight from
+// the register into the stores (and into dest[] for the lazy columns); slot_in NULL: the sort opens an epoch (slot = old index)
+__global__ __launch_bounds__(256) void k_place_permute(long long n, const int* __restrict__ cell, const int* __restrict__ start, int* __restrict__ fill,
+                                                       int* __restrict__ dest, PermArgs a, const int* __restrict__ slot_in, int* __restrict__ slot_out) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int c = (t < n) ? cell[t] : -1;
+    int seg0, len;
+    mic_wave_runs(c, lane, seg0, len);
+    int base = 0;
+    if (lane == seg0 && c >= 0) base = atomicAdd(&fill[c], len);
+    base = __shfl(base, seg0, 64);
+    if (c < 0) return;
+    const int d = start[c] + base + (lane - seg0);
+    dest[t] = d;
+    for (int k = 0; k < a.na; k++) a.out[k][d] = a.in[k][t];
+    slot_out[d] = slot_in ? slot_in[t] : (int)t;
+}
+
 // ---- census + injection (pylamp2.py:588-633) ---------------------------------------------------
 __global__ __launch_bounds__(256) void k_deficit(int nc, int ncx, int row_lo, int row_hi, const int* __restrict__ start,
                                                  int dens, int dmin, int* __restrict__ need, int* __restrict__ flag) {
@@ -688,11 +707,6 @@ __global__ __launch_bounds__(64) void k_inject_fix_lazy(int nc, const int* __res
     sr /= (double)(t1 - t0); se /= (double)(t1 - t0);
     for (int q = 0; q < m; q++) { rho[t1 + q] = sr; eta[t1 + q] = se; }
 }
-// slot2[dest[t]] = t: the sort that opens an epoch (its pre-sort order IS the epoch order)
-__global__ __launch_bounds__(256) void k_permute_iota(long long n, const int* __restrict__ dest, int* __restrict__ out) {
-    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) out[dest[t]] = (int)t;
-}
 // out_k[t] = in_k[idx[t]] for up to 5 arrays per launch (closing an epoch)
 struct GatherColsArgs { const double* in[5]; double* out[5]; int na; };
 __global__ __launch_bounds__(256) void k_gather_cols(long long n, const int* __restrict__ idx, GatherColsArgs a) {
@@ -873,32 +887,31 @@ static int sort_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, doubl
         scan_ints(ctx, S, m, S->cell_count, S->cell_start);
     }
     PL_HIP(ctx, hipMemsetAsync(S->cell_count, 0, (size_t)m * sizeof(int), ctx->stream));   // reused as fill counters
-    if (n > 0) {
+    if (n > 0 && epoch_ok) {                                // positions, temperature and slot: placement and permutation in ONE pass
+        PermArgs pa{}; pa.na = 3;
+        pa.in[0] = S->tz; pa.out[0] = S->tz2; pa.in[1] = S->tx; pa.out[1] = S->tx2; pa.in[2] = S->f[TR_TMP]; pa.out[2] = S->f2[TR_TMP];
+        hipLaunchKernelGGL(k_place_permute, grid1d(n), dim3(256), 0, ctx->stream, n, S->cell, S->cell_start, S->cell_count, S->dest, pa,
+                           S->epoch_on ? (const int*)S->slot : (const int*)nullptr, S->slot2);
+        std::swap(S->tz, S->tz2); std::swap(S->tx, S->tx2);
+        std::swap(S->vtz, S->tmp[0]); std::swap(S->vtx, S->tmp[1]);         // (lazy: the old values stay in tmp[0..1] / f2[RHO], f2[ETA])
+        std::swap(S->slot, S->slot2);
+        for (int k : {(int)TR_TMP, (int)TR_RHO, (int)TR_ETA}) std::swap(S->f[k], S->f2[k]);
+    } else if (n > 0) {
         hipLaunchKernelGGL(k_cell_place, grid1d(n), dim3(256), 0, ctx->stream, n, S->cell, S->cell_start, S->cell_count, S->dest);
-        // classic: positions, the 13 fields and the velocities of the last advection travel together.
-        // epoch layout: positions and the temperature; the constants are represented by their slot; RHO, ETA and the velocities stay behind
-        const double* src[17]; double* dst[17]; int nmove = 0;
-        src[nmove] = S->tz; dst[nmove++] = S->tz2; src[nmove] = S->tx; dst[nmove++] = S->tx2;
-        for (int k = 0; k < NFTRAC; k++)
-            if (!epoch_ok || k == TR_TMP) { src[nmove] = S->f[k]; dst[nmove++] = S->f2[k]; }
-        if (!epoch_ok) { src[nmove] = S->vtz; dst[nmove++] = S->tmp[0]; src[nmove] = S->vtx; dst[nmove++] = S->tmp[1]; }
-        for (int k0 = 0; k0 < nmove; k0 += 5) {
-            PermArgs pa{}; pa.na = std::min(5, nmove - k0);
+        // classic: positions, the 13 fields and the velocities of the last advection travel together
+        const double* src[17]; double* dst[17];
+        src[0] = S->tz; dst[0] = S->tz2; src[1] = S->tx; dst[1] = S->tx2;
+        for (int k = 0; k < NFTRAC; k++) { src[2 + k] = S->f[k]; dst[2 + k] = S->f2[k]; }
+        src[15] = S->vtz; dst[15] = S->tmp[0]; src[16] = S->vtx; dst[16] = S->tmp[1];
+        for (int k0 = 0; k0 < 17; k0 += 5) {
+            PermArgs pa{}; pa.na = std::min(5, 17 - k0);
             for (int k = 0; k < pa.na; k++) { pa.in[k] = src[k0 + k]; pa.out[k] = dst[k0 + k]; }
             hipLaunchKernelGGL(k_permute, grid1d(n), dim3(256), 0, ctx->stream, n, S->dest, pa);
         }
-        std::swap(S->tz, S->tz2); std::swap(S->tx, S->tx2);
-        std::swap(S->vtz, S->tmp[0]); std::swap(S->vtx, S->tmp[1]);         // (lazy: the old values stay in tmp[0..1] / f2[RHO], f2[ETA])
-        if (!epoch_ok) {
-            hipLaunchKernelGGL(k_permute_int, grid1d(n), dim3(256), 0, ctx->stream, n, S->dest, S->orig, S->orig2);
-            std::swap(S->orig, S->orig2);
-            for (int k = 0; k < NFTRAC; k++) std::swap(S->f[k], S->f2[k]);
-        } else {
-            if (S->epoch_on) hipLaunchKernelGGL(k_permute_int, grid1d(n), dim3(256), 0, ctx->stream, n, S->dest, S->slot, S->slot2);
-            else hipLaunchKernelGGL(k_permute_iota, grid1d(n), dim3(256), 0, ctx->stream, n, S->dest, S->slot2);
-            std::swap(S->slot, S->slot2);
-            for (int k : {(int)TR_TMP, (int)TR_RHO, (int)TR_ETA}) std::swap(S->f[k], S->f2[k]);
-        }
+        hipLaunchKernelGGL(k_permute_int, grid1d(n), dim3(256), 0, ctx->stream, n, S->dest, S->orig, S->orig2);
+        std::swap(S->tz, S->tz2); std::swap(S->tx, S->tx2); std::swap(S->orig, S->orig2);
+        std::swap(S->vtz, S->tmp[0]); std::swap(S->vtx, S->tmp[1]);
+        for (int k = 0; k < NFTRAC; k++) std::swap(S->f[k], S->f2[k]);
     }
     if (epoch_ok) {
         S->epoch_age = S->epoch_on ? S->epoch_age + 1 : 1; S->epoch_on = true;

@@ -133,6 +133,30 @@ class Comm:
             except Exception as e:
                 self.errors.append("device path disabled: " + repr(e))
                 ok = 0
+            if ok:
+                # ... and the collectives the library will ask for, once, on small tensors: an all-reduce and the ring exchange of a
+                # grouped send / receive (the first multi-GPU run of this path is the driver's scaling run: a failure here costs the
+                # zero-copy transport, not the run -- everybody falls back to staging through the host)
+                try:
+                    dist, torch = self.dist, self.torch
+                    a = torch.full((8,), float(self.rank + 1), dtype=torch.float64, device="cuda")
+                    dist.all_reduce(a, group=self.group)
+                    want = 0.5 * self.size * (self.size + 1)
+                    sb = torch.full((8,), float(self.rank), dtype=torch.float64, device="cuda")
+                    rb = torch.full((8,), -1.0, dtype=torch.float64, device="cuda")
+                    if self.size > 1:
+                        nxt, prv = (self.rank + 1) % self.size, (self.rank - 1) % self.size
+                        ops = [dist.P2POp(dist.isend, sb, nxt, self.group), dist.P2POp(dist.irecv, rb, prv, self.group)]
+                        for w in dist.batch_isend_irecv(ops):
+                            w.wait()
+                    torch.cuda.synchronize()
+                    good = bool((a == want).all().item()) and (self.size == 1 or bool((rb == float((self.rank - 1) % self.size)).all().item()))
+                    if not good:
+                        self.errors.append("device path disabled: wrong result of the NCCL self-test")
+                        ok = 0
+                except Exception as e:
+                    self.errors.append("device path disabled (NCCL self-test): " + repr(e))
+                    ok = 0
         t = self.torch.tensor([ok], dtype=self.torch.int64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.host_group)
         if int(t.item()) == 0:

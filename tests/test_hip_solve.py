@@ -262,7 +262,7 @@ def test_fused_levels_match_the_staged_path(nx, uniform, bc):
     rho = 3300 + 40 * np.sin(2 * np.pi * X / L[1]) * np.sin(np.pi * Z / L[0])
     r = rng.standard_normal(3 * nx[0] * nx[1])
     out = {}
-    envs = {"1": {"PYLAMP_MG_FUSED": "1"}, "0": {"PYLAMP_MG_FUSED": "0"},
+    envs = {"1": {"PYLAMP_MG_FUSED": "1"}, "0": {"PYLAMP_MG_FUSED": "0", "PYLAMP_L0_MIXED": "0"},
             "32": {"PYLAMP_MG_FUSED": "1", "PYLAMP_MG_TS32": "1", "PYLAMP_MG_FUSED_MAX": "100000000"}}      # 32 x 32 tiles, level 0 included
     for mode, env in envs.items():
         os.environ.update(env)
@@ -285,3 +285,43 @@ def test_fused_levels_match_the_staged_path(nx, uniform, bc):
     assert s32["converged"] == 1 and abs(s32["iterations"] - ss["iterations"]) <= 2, (s32, ss)
     v = lambda x: x[:, :, :2]
     assert np.linalg.norm(v(xf) - v(xs)) / np.linalg.norm(v(xs)) < 1e-6
+
+
+def test_level0_fp32_storage_same_preconditioner():
+    """A staged level 0 (what the two bandwidth-bound levels of a large grid run) keeps its right-hand side, first iterate and
+    residual in FP32 while computing in FP64 (PlSolver::l0_mixed) -- in warm-started solves to rtol >= 1e-8, i.e. the solves of a
+    time loop.  Against the all-FP64 path: a cold solve does not take the FP32 path at all (identical iteration count), a
+    warm-started one converges to the same velocities in at most 2 iterations more."""
+    import os
+    from pylamp_amd import pylamp_stokes as S, _context
+    nx = [1025, 1025]; L = [660e3, 660e3]            # V(1,1) on the finest level from 10^6 nodes up: the configuration the FP32 storage serves
+    grid = [np.linspace(0, L[d], nx[d]) for d in range(2)]
+    Z, X = np.meshgrid(*grid, indexing='ij')
+    gm = [np.append(0.5 * (g[1:] + g[:-1]), g[-1] + 0.5 * (g[-1] - g[-2])) for g in grid]
+    Zc, Xc = np.meshgrid(*gm, indexing='ij')
+    f = lambda z, x: 1e20 * 10 ** (2.0 * np.sin(2 * np.pi * x / L[1]) * np.cos(np.pi * z / L[0]) + 0.3 * np.sin(17 * x / L[1]) * np.sin(23 * z / L[0]))
+    rho = 3300 + 40 * np.sin(2 * np.pi * X / L[1]) * np.sin(np.pi * Z / L[0])
+    rho2 = rho + 0.4 * np.sin(4 * np.pi * X / L[1]) * np.sin(2 * np.pi * Z / L[0])        # "the next time step": 1 % more load
+    out = {}
+    for mode in ("1", "0"):
+        env = {"PYLAMP_MG_FUSED": "0", "PYLAMP_L0_MIXED": mode}
+        os.environ.update(env)
+        try:
+            _context.clear_contexts()
+            A, rhs = S.makeStokesMatrix(nx, grid, f(Z, X), f(Zc, Xc), rho, [1, 1, 1, 1])
+            x = S.solve(A, rhs, rtol=1e-7)
+            cold = dict(A.last_stats)
+            A2, rhs2 = S.makeStokesMatrix(nx, grid, f(Z, X), f(Zc, Xc), rho2, [1, 1, 1, 1])
+            x2 = S.solve(A2, rhs2, x0=x, rtol=1e-7)
+            out[mode] = (x.reshape(nx[0], nx[1], 3), x2.reshape(nx[0], nx[1], 3), cold, dict(A2.last_stats))
+            del A, A2
+        finally:
+            for k in env:
+                del os.environ[k]
+            _context.clear_contexts()
+    (xm, xm2, cm, wm), (xd, xd2, cd, wd) = out["1"], out["0"]
+    assert cm["converged"] == 1 and cm["iterations"] == cd["iterations"] and np.array_equal(xm, xd), (cm, cd)
+    assert wm["converged"] == 1 and wd["converged"] == 1 and wm["iterations"] <= wd["iterations"] + 2, (wm, wd)
+    assert not np.array_equal(xm2, xd2)                                   # (the FP32 path did run)
+    v = lambda x: x[:, :, :2]
+    assert np.linalg.norm(v(xm2) - v(xd2)) / np.linalg.norm(v(xd2)) < 1e-6
