@@ -270,6 +270,13 @@ int  pl_tracers_count(pl_ctx* ctx, int64_t* n);
 /* Census of the resident tracers (pylamp2.py:588-598: np.bincount of the cell index): counts[c] for this rank's
  * owned cells, row-major (n_cell_rows x (nx-1)), ncells = their number.  counts == NULL only queries the rows. */
 int  pl_tracers_census(pl_ctx* ctx, int64_t ncells, int32_t* counts, int* first_cell_row, int* n_cell_rows);
+/* Layout of the resident tracer columns (tests; no counterpart in the reference, whose tracers are plain NumPy rows).  The
+ * end-of-step sort of the resident step moves only positions, temperature and a 4-byte slot per tracer:
+ *   *epoch_age > 0: the ten columns no stage writes (everything but TR_RHO, TR_ETA, TR_TMP) are still in the order of the sort
+ *                   that opened the epoch, *epoch_age sorts ago, and are read through the slot index;
+ *   *lazy != 0:     TR_RHO, TR_ETA and the tracer velocities have not been moved by the last sort yet.
+ * Downloads (pl_tracers_download, pl_get_tracer_velocity) bring every column into the current order first. */
+int  pl_tracers_layout(pl_ctx* ctx, int* epoch_age, int* lazy);
 /* One full time step on the device-resident state (pylamp2.py:284-583: properties, tracer -> grid, Stokes, time step, heat,
  * grid -> tracer with subgrid diffusion, RK4 advection, census + injection).  The iterative solves are warm-started from the
  * context's own history -- Stokes from the polynomial through its last three solutions evaluated at the new model time, heat

@@ -119,6 +119,7 @@ SIGNATURES = {
     "pl_tracers_download": (C.c_int, [C.c_void_p, C.c_int64, c_double_p, c_double_p]),
     "pl_tracers_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "pl_tracers_census": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32), c_int_p, c_int_p]),
+    "pl_tracers_layout": (C.c_int, [C.c_void_p, c_int_p, c_int_p]),
     "pl_step": (C.c_int, [C.c_void_p, C.POINTER(StepConfig), C.c_int, C.POINTER(StepReport)]),
     "pl_resident_scatter": (C.c_int, [C.c_void_p, C.POINTER(StepConfig), C.c_int]),
     "pl_resident_temp_to_tracers": (C.c_int, [C.c_void_p, C.POINTER(StepConfig), C.c_int, c_double_p, C.c_double]),

@@ -627,6 +627,13 @@ extern "C" int pl_tracers_census(pl_ctx* ctx, int64_t ncells, int32_t* counts, i
     return 0;
 }
 
+extern "C" int pl_tracers_layout(pl_ctx* ctx, int* epoch_age, int* lazy) {
+    PlStepState* S = state_of(ctx);
+    if (epoch_age) *epoch_age = S->epoch_on ? S->epoch_age : 0;
+    if (lazy) *lazy = S->lazy_pending ? 1 : 0;
+    return 0;
+}
+
 extern "C" int pl_get_tracer_velocity(pl_ctx* ctx, int64_t n, double* out) {
     PlStepState* S = state_of(ctx);
     if (n != S->n || !out) return pl_fail(ctx, "pl_get_tracer_velocity: bad argument");

@@ -246,15 +246,25 @@ class Simulation:
         self.ctx.check(self.ctx.lib.pl_resident_temp_to_tracers(self.ctx.handle(), C.byref(cfg), int(bool(first)), _lib.dptr(nt), float(tstep)))
         return self.tracers()[1][:, TR_TMP]
 
-    def advect(self, vz_pad, vx_pad, tstep, fence=None):
+    def layout(self):
+        """(epoch age, lazy columns pending) of the resident tracer columns -- see pl_tracers_layout."""
+        a = C.c_int(); b = C.c_int()
+        self.ctx.check(self.ctx.lib.pl_tracers_layout(self.ctx.handle(), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def advect(self, vz_pad, vx_pad, tstep, fence=None, download=True):
         """Stage 6b of the step: RK4 through velocities on the padded (nz+1, nx+1) centre grid (pylamp2.py:547-572),
-        then the end-of-step sort.  Returns (tracer velocities, new positions) in upload order, like pylamp_trac.RK."""
+        then the end-of-step sort.  Returns (tracer velocities, new positions) in upload order, like pylamp_trac.RK
+        (download=False: nothing -- a download brings every tracer column into the sorted order, which the step itself
+        does not do)."""
         vz = _lib.f64(vz_pad); vx = _lib.f64(vx_pad)
         if vz.shape != (self.nx[0] + 1, self.nx[1] + 1) or vx.shape != vz.shape:
             raise Exception("advect: velocities must be (nz+1, nx+1)")
         fence = self.opt.tracs_fence_enabled if fence is None else fence
         Lc = (C.c_double * 2)(*self.L)
         self.ctx.check(self.ctx.lib.pl_resident_rk4(self.ctx.handle(), _lib.dptr(vz), _lib.dptr(vx), float(tstep), int(bool(fence)), Lc))
+        if not download:
+            return None
         return self.tracer_velocity(), self.tracers()[0]
 
     # -- snapshot writer (pylamp2.py:637-650) ----------------------------------------------------------

@@ -2,7 +2,8 @@
 
 The module-level trac2grid / grid2trac / RK of pylamp_amd.pylamp_trac take host arrays and run the generic kernels
 (k_scatter_atomic, k_gather<false,0>, k_rk4<false>).  The resident step runs other kernels on its cell-sorted tracers:
-    k_scatter_cells<6,1,true> / <2,2,false> / <1,0,false>   (fused: all four staggered target sets in one pass)
+    k_scatter_cells<6,1,true,IND> / <2,2,false> / <1,0,false>   (fused: all four staggered target sets in one pass; IND: the constant
+                                                                 columns read through the slot index of the epoch layout)
     k_gather<true,0|1|2>                                     (regular-grid bilinear gather, subgrid-diffusion epilogues)
     k_rk4<true>
 Simulation.scatter_fields / temp_to_tracers / advect (C ABI pl_resident_*) run exactly those stage functions one at a
@@ -211,4 +212,30 @@ def test_resident_mic_kernels_2049_vs_oracle(oracle):
     # after the sort the census is that of the moved markers
     ci = np.minimum((x[:, 0] / h).astype(np.int64), n - 2); cj = np.minimum((x[:, 1] / h).astype(np.int64), n - 2)
     assert np.array_equal(sim.census(), np.bincount(ci * (n - 1) + cj, minlength=(n - 1) ** 2).reshape(n - 1, n - 1))
+    # ---- the same stages in the EPOCH layout, which is what the timed step runs from its second step on: after a sort that is not
+    # followed by a download the constant columns stay where they were and k_property_update, k_scatter_cells<6,1,true,true> and the
+    # gather epilogue read them through the slot index (pl_step.hip)
+    assert sim.layout() == (0, 0)                                     # the downloads above have closed the epoch
+    sim.advect(Vz, Vx, 0.5 * dt, fence=True, download=False)
+    assert sim.layout()[0] == 1 and sim.layout()[1] == 1
+    got = sim.scatter_fields()
+    assert sim.layout()[0] == 1                                       # (the scatter itself leaves the layout alone)
+    X1, F1 = sim.tracers()
+    ref = dict(zip(("rho", "etas", "cp", "f_T", "H", "mat"),
+                   oracle.trac2grid(X1, F1[:, [TR_RH0, TR_ET0, TR_HCP, TR_TMP, TR_IHT, TR_MAT]], tg["nodes"], nx, [5, 6, 5, 5, 5, 5])))
+    ref["etan"], = oracle.trac2grid(X1, F1[:, [TR_ET0]], tg["centres"], nx, [6])
+    ref["kz"], = oracle.trac2grid(X1, F1[:, [TR_HCD]], tg["zmid"], nx, [5])
+    ref["kx"], = oracle.trac2grid(X1, F1[:, [TR_HCD]], tg["xmid"], nx, [5])
+    for k, r in ref.items():
+        assert maxrel(got[k], r) < 1e-11, k
+    assert np.array_equal(F1[:, [TR_HCD, TR_HCP, TR_RH0, TR_ET0, TR_IHT, TR_MAT, TR__ID]], tr_f[:, [TR_HCD, TR_HCP, TR_RH0, TR_ET0, TR_IHT, TR_MAT, TR__ID]])
+    sim.advect(0 * Vz, 0 * Vx, dt, fence=True, download=False)       # a sort that moves nobody: a new epoch on the same positions
+    assert sim.layout()[0] == 1
+    got = sim.scatter_fields()
+    f_T1 = np.where(np.isnan(got["f_T"]), 0.0, got["f_T"])
+    newtemp1 = f_T1 + 10 * np.sin(60 * np.pi * Xg / L[1]) * np.sin(50 * np.pi * Z / L[0])
+    Tg = sim.temp_to_tracers(newtemp1, tstep, first=False)
+    F1[:, TR_RHO] = F1[:, TR_RH0]
+    exp = _subgrid_expected(oracle, X1, F1, grid, nx, L, f_T1, newtemp1, tstep, True)
+    assert maxrel(Tg, exp) < 1e-11
     sim.close()
