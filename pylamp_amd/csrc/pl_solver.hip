@@ -2791,6 +2791,9 @@ static int stokes_precond_t(pl_ctx* ctx, PlSolver* S, const double* rs, double* 
             }
             double* ec = nullptr; bool wf = false;
             vcycle<double>(ctx, S, 1, C->f, &ec, &wf, nullptr, 1.0, 0, nullptr);
+            // (Round 3: prolongation + correction + post-sweep in ONE kernel -- v never written, P e evaluated in registers from the coarse
+            //  rows m-1, m, m+1 with lane shuffles, 68 instead of 100 B/node; parity with this pair to 1e-11 -- took 115 us against
+            //  33 + 70: the sweep is co-limited by its FP64 instruction issue, and the interpolation arithmetic moves into it.  Removed.)
             hipLaunchKernelGGL((k_vv_prolong_add<double, double, float>), grid2d(g), bl, 0, ctx->stream, L0->op, C->gh.d, (const double*)ec, (const float*)v1f, vd);
             hipLaunchKernelGGL((k_vv_sweep2<0, double, double, double, float>), rows2, bl, 0, ctx->stream, L0->op, (const double*)vd, (const double*)nullptr,
                                (const float*)ff, z, 0.0, c2, 1.0);

@@ -291,7 +291,8 @@ def test_level0_fp32_storage_same_preconditioner():
     """A staged level 0 (what the two bandwidth-bound levels of a large grid run) keeps its right-hand side, first iterate and
     residual in FP32 while computing in FP64 (PlSolver::l0_mixed) -- in warm-started solves to rtol >= 1e-8, i.e. the solves of a
     time loop.  Against the all-FP64 path: a cold solve does not take the FP32 path at all (identical iteration count), a
-    warm-started one converges to the same velocities in at most 2 iterations more."""
+    warm-started one converges to the same velocities in at most 2 iterations more, with the same preconditioned vector to FP32
+    rounding.  (One fresh context per mode, the same call sequence in each: every solve refines the eigenvalue estimates.)"""
     import os
     from pylamp_amd import pylamp_stokes as S, _context
     nx = [1025, 1025]; L = [660e3, 660e3]            # V(1,1) on the finest level from 10^6 nodes up: the configuration the FP32 storage serves
@@ -302,9 +303,11 @@ def test_level0_fp32_storage_same_preconditioner():
     f = lambda z, x: 1e20 * 10 ** (2.0 * np.sin(2 * np.pi * x / L[1]) * np.cos(np.pi * z / L[0]) + 0.3 * np.sin(17 * x / L[1]) * np.sin(23 * z / L[0]))
     rho = 3300 + 40 * np.sin(2 * np.pi * X / L[1]) * np.sin(np.pi * Z / L[0])
     rho2 = rho + 0.4 * np.sin(4 * np.pi * X / L[1]) * np.sin(2 * np.pi * Z / L[0])        # "the next time step": 1 % more load
+    rr = np.random.default_rng(7).standard_normal(3 * nx[0] * nx[1])
     out = {}
-    for mode in ("1", "0"):
-        env = {"PYLAMP_MG_FUSED": "0", "PYLAMP_L0_MIXED": mode}
+    envs = {"mixed": {"PYLAMP_L0_MIXED": "1"}, "fp64": {"PYLAMP_L0_MIXED": "0"}}
+    for mode, env in envs.items():
+        env = dict(env, PYLAMP_MG_FUSED="0")
         os.environ.update(env)
         try:
             _context.clear_contexts()
@@ -313,15 +316,19 @@ def test_level0_fp32_storage_same_preconditioner():
             cold = dict(A.last_stats)
             A2, rhs2 = S.makeStokesMatrix(nx, grid, f(Z, X), f(Zc, Xc), rho2, [1, 1, 1, 1])
             x2 = S.solve(A2, rhs2, x0=x, rtol=1e-7)
-            out[mode] = (x.reshape(nx[0], nx[1], 3), x2.reshape(nx[0], nx[1], 3), cold, dict(A2.last_stats))
+            z = A2.precond(rr)                       # (the preconditioner as the warm-started solve ran it)
+            out[mode] = (x.reshape(nx[0], nx[1], 3), x2.reshape(nx[0], nx[1], 3), cold, dict(A2.last_stats), z.reshape(nx[0], nx[1], 3))
             del A, A2
         finally:
             for k in env:
                 del os.environ[k]
             _context.clear_contexts()
-    (xm, xm2, cm, wm), (xd, xd2, cd, wd) = out["1"], out["0"]
+    (xm, xm2, cm, wm, zm), (xd, xd2, cd, wd, zd) = out["mixed"], out["fp64"]
     assert cm["converged"] == 1 and cm["iterations"] == cd["iterations"] and np.array_equal(xm, xd), (cm, cd)
     assert wm["converged"] == 1 and wd["converged"] == 1 and wm["iterations"] <= wd["iterations"] + 2, (wm, wd)
     assert not np.array_equal(xm2, xd2)                                   # (the FP32 path did run)
     v = lambda x: x[:, :, :2]
     assert np.linalg.norm(v(xm2) - v(xd2)) / np.linalg.norm(v(xd2)) < 1e-6
+    for q in range(2):
+        assert np.max(np.abs(zm[:, :, q] - zd[:, :, q])) < 3e-6 * np.max(np.abs(zd[:, :, q])), q
+    assert np.array_equal(zm[:, :, 2], zd[:, :, 2])
