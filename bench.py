@@ -316,11 +316,15 @@ def main():
         stages = {k: round(float(np.mean([r[k] for r in timed])), 3) for k in stage_keys}
         # marker stages against the HBM roof: algorithmic bytes of one step (this rank's tracers and nodes) over the stage's
         # wall time (host-timed with a stream sync each side, so launch gaps are inside -- these stages are 1.7-6 ms long).
-        #   scatter  4 passes: positions 16 B + 8 B per field read per marker (6 + 1 + 1 + 1 fields = 136 B / marker), one
-        #            weight and nf value accumulators read-modify-written and nf planes written per node (208 B / node)
+        #   scatter  fused kernel (regular grid): positions 16 B + 7 fields 56 B (+ 4 B slot in the epoch layout) read ONCE per marker,
+        #            13 accumulator planes written and read by the finalisation + 9 result planes written per node (280 B / node);
+        #            the one-set-per-pass kernels (rectilinear grids, several target sets re-reading the positions): 136 B / marker
         #   rk4      positions read and written, velocities written: 48 B / marker (the 32 velocity gathers per marker hit
         #            a cache-resident window)
-        #   sort     key pass 16 B + placement 12 B + permutation of 17 columns + index 2 x 144 B = 316 B / marker
+        #   sort     epoch layout (one rank): key 4 B + destination 4 B + positions, temperature and slot read and written 56 B
+        #            = 64 B / marker, + the re-layout of the 10 constant columns and the index every PYLAMP_EPOCH sorts
+        #            (172 B / marker / epoch length); classic (several ranks): key pass 16 B + placement 12 B + 17 columns
+        #            and the index moved 2 x 144 B = 316 B / marker
         _, ni_, _, nj_, _, _ = sim.ctx.local_block()
         nt, nn = float(sim.ntrac), float(ni_ * nj_)
 
@@ -328,9 +332,21 @@ def main():
             gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                     "algorithmic_bytes_per_step": nbytes, "ms": ms, "bytes": what}
-        roof["scatter"] = stage_roof(stages["ms_scatter"], 136.0 * nt + 208.0 * nn, "136 B/marker + 208 B/node")
+        epoch_age, _lazy = sim.layout()
+        epoch_len = int(os.environ.get("PYLAMP_EPOCH", "64"))
+        fused_scatter = os.environ.get("PYLAMP_SCATTER", "1") != "0"
+        if fused_scatter:
+            per_marker = 72.0 + (4.0 if epoch_age > 0 else 0.0)
+            roof["scatter"] = stage_roof(stages["ms_scatter"], per_marker * nt + 280.0 * nn,
+                                         "%d B/marker + 280 B/node (fused kernel; the reference's four trac2grid calls read 136 B/marker)" % per_marker)
+        else:
+            roof["scatter"] = stage_roof(stages["ms_scatter"], 136.0 * nt + 208.0 * nn, "136 B/marker + 208 B/node")
         roof["rk4"] = stage_roof(stages["ms_advect"], 48.0 * nt, "48 B/marker")
-        roof["sort"] = stage_roof(stages["ms_sort"], 316.0 * nt, "316 B/marker")
+        if epoch_age > 0 and epoch_len > 0:
+            per_marker = 64.0 + 172.0 / epoch_len
+            roof["sort"] = stage_roof(stages["ms_sort"], per_marker * nt, "%.1f B/marker (epoch layout: 64 + 172 / %d)" % (per_marker, epoch_len))
+        else:
+            roof["sort"] = stage_roof(stages["ms_sort"], 316.0 * nt, "316 B/marker")
         out = {
             "metric": "stokes_heat_mic_cell_updates_per_s", "value": round(value, 1), "unit": "cell-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
