@@ -615,7 +615,7 @@ extern "C" void pl3_destroy(pl3_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     free_levels3(ctx);
     for (double* q : {ctx->es, ctx->en, ctx->rho, ctx->part, ctx->stage, ctx->hT, ctx->hH, ctx->hcdt, ctx->hrho, ctx->hcp, ctx->hbcv, ctx->htab}) if (q) (void)hipFree(q);
-    for (auto& v : ctx->vec) for (double* q : v) if (q) (void)hipFree(q);
+    for (auto& v : ctx->vec) if (v[0]) (void)hipFree(v[0]);
     for (double* q : ctx->hk) if (q) (void)hipFree(q);
     for (double* q : ctx->hvec) if (q) (void)hipFree(q);
     if (ctx->hpart) (void)hipHostFree(ctx->hpart);
@@ -650,7 +650,13 @@ static int download3(pl3_ctx* ctx, double* const* src, int ncomp, double* host) 
 }
 static int need_vecs(pl3_ctx* ctx, int nvec) {
     const long long vol = ctx->geom.d.vol;
-    for (int v = 0; v < nvec; v++) for (int q = 0; q < 4; q++) if (!ctx->vec[v][q]) P3_TRY(dmal(ctx, &ctx->vec[v][q], vol));
+    // the four arrays of a work vector are ONE allocation (vec[v][q] = vec[v][0] + q vol): the flat vector kernels and the reductions
+    // of BiCGStab then take a whole vector per launch (and per host synchronisation) instead of one array
+    for (int v = 0; v < nvec; v++)
+        if (!ctx->vec[v][0]) {
+            P3_TRY(dmal(ctx, &ctx->vec[v][0], 4 * vol));
+            for (int q = 1; q < 4; q++) ctx->vec[v][q] = ctx->vec[v][0] + (long long)q * vol;
+        }
     if (!ctx->part) {
         P3_TRY(dmal(ctx, &ctx->part, 5 * D3_BLOCKS));
         P3_HIP(ctx, hipHostMalloc((void**)&ctx->hpart, 5 * D3_BLOCKS * sizeof(double)));
@@ -748,8 +754,20 @@ static int dots3(pl3_ctx* ctx, long long n, int nd, const double* const* a, cons
     for (int q = 0; q < nd; q++) { double s = 0.0; for (int k = 0; k < D3_BLOCKS; k++) s += ctx->hpart[5 * k + q]; out[q] = s; }
     return 0;
 }
+// the na arrays of a vector follow each other in memory (need_vecs)
+static bool contig3(double* const* a, int na, long long vol) {
+    for (int c = 1; c < na; c++) if (a[c] != a[0] + (long long)c * vol) return false;
+    return true;
+}
 // dot products of multi-array vectors (na arrays each)
 static int vdots(pl3_ctx* ctx, long long vol, int na, int nd, double* const* const* a, double* const* const* b, double* out) {
+    bool flat = na > 1;
+    for (int q = 0; q < nd && flat; q++) flat = contig3(a[q], na, vol) && contig3(b[q], na, vol);
+    if (flat) {                                    // one pass, one copy, one synchronisation for the whole vector
+        const double* aa[5]; const double* bb[5];
+        for (int q = 0; q < nd; q++) { aa[q] = a[q][0]; bb[q] = b[q][0]; }
+        return dots3(ctx, (long long)na * vol, nd, aa, bb, out);
+    }
     for (int q = 0; q < nd; q++) out[q] = 0.0;
     for (int c = 0; c < na; c++) {
         const double* aa[5]; const double* bb[5]; double o[5];
@@ -908,10 +926,17 @@ static int bicgstab3(pl3_ctx* ctx, long long vol, int na, const Op3Fn& A, const 
                      double etol = 0.0) {
     double* const* r = w[0]; double* const* rt = w[1]; double* const* p = w[2]; double* const* v = w[3]; double* const* s = w[4];
     double* const* t = w[5]; double* const* y = w[6]; double* const* z = w[7]; double* const* dxb = w[8]; double* const* r0b = w[9];
+    auto flat3 = [&](double* const* a0, double* const* a1 = nullptr, double* const* a2 = nullptr) {
+        return na > 1 && contig3(a0, na, vol) && (!a1 || contig3(a1, na, vol)) && (!a2 || contig3(a2, na, vol));
+    };
     auto axpby = [&](double* const* yy, double a, double* const* xx, double bb, double* const* zz) {
+        if (flat3(yy, xx, zz)) { hipLaunchKernelGGL(k3_axpby, g1(na * vol), dim3(256), 0, ctx->stream, na * vol, yy[0], a, (const double*)xx[0], bb, (const double*)zz[0]); return; }
         for (int c = 0; c < na; c++) hipLaunchKernelGGL(k3_axpby, g1(vol), dim3(256), 0, ctx->stream, vol, yy[c], a, (const double*)xx[c], bb, (const double*)zz[c]);
     };
-    auto zero = [&](double* const* yy) { for (int c = 0; c < na; c++) (void)hipMemsetAsync(yy[c], 0, (size_t)vol * sizeof(double), ctx->stream); };
+    auto zero = [&](double* const* yy) {
+        if (flat3(yy)) { (void)hipMemsetAsync(yy[0], 0, (size_t)na * vol * sizeof(double), ctx->stream); return; }
+        for (int c = 0; c < na; c++) (void)hipMemsetAsync(yy[c], 0, (size_t)vol * sizeof(double), ctx->stream);
+    };
     double d[5];
     { double* const* aa[1] = {b}; P3_TRY(vdots(ctx, vol, na, 1, aa, aa, d)); }
     double bnorm = std::sqrt(d[0]);
@@ -965,7 +990,8 @@ static int bicgstab3(pl3_ctx* ctx, long long vol, int na, const Op3Fn& A, const 
             it++;
             if (!(std::fabs(rho_new) > 0.0) || !std::isfinite(rho_new)) { broke = true; break; }
             const double beta = (rho_new / rho) * (alpha / omega);
-            for (int c = 0; c < na; c++) hipLaunchKernelGGL(k3_p_update, g1(vol), dim3(256), 0, ctx->stream, vol, p[c], (const double*)r[c], (const double*)v[c], beta, omega);
+            if (flat3(p, r, v)) hipLaunchKernelGGL(k3_p_update, g1(na * vol), dim3(256), 0, ctx->stream, na * vol, p[0], (const double*)r[0], (const double*)v[0], beta, omega);
+            else for (int c = 0; c < na; c++) hipLaunchKernelGGL(k3_p_update, g1(vol), dim3(256), 0, ctx->stream, vol, p[c], (const double*)r[c], (const double*)v[c], beta, omega);
             double* const* yv = p;
             if (M) { P3_TRY((*M)(p, y)); yv = y; }
             P3_TRY(A(yv, v));
@@ -979,7 +1005,10 @@ static int bicgstab3(pl3_ctx* ctx, long long vol, int na, const Op3Fn& A, const 
             // one reduction: t.s, t.t, rt.s, rt.t, s.s  ->  omega, rho' = rt.s - omega rt.t, |r|^2 = s.s - 2 omega t.s + omega^2 t.t
             { double* const* aa[5] = {t, t, rt, rt, s}; double* const* bb[5] = {s, t, s, t, s}; P3_TRY(vdots(ctx, vol, na, 5, aa, bb, d)); }
             omega = (d[1] > 0.0) ? d[0] / d[1] : 0.0;
-            for (int c = 0; c < na; c++)
+            if (flat3(dx, yv, zv) && flat3(r, s, t))
+                hipLaunchKernelGGL(k3_xr_update, g1(na * vol), dim3(256), 0, ctx->stream, na * vol, dx[0], (const double*)yv[0], (const double*)zv[0], r[0],
+                                   (const double*)s[0], (const double*)t[0], alpha, omega);
+            else for (int c = 0; c < na; c++)
                 hipLaunchKernelGGL(k3_xr_update, g1(vol), dim3(256), 0, ctx->stream, vol, dx[c], (const double*)yv[c], (const double*)zv[c], r[c],
                                    (const double*)s[c], (const double*)t[c], alpha, omega);
             rho = rho_new; rho_new = d[2] - omega * d[3];

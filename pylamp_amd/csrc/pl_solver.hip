@@ -702,7 +702,7 @@ __global__ __launch_bounds__(256) void k_coarsen_visc(PlGeom gf, const double* _
 // no atomics; the host adds the (<= DOT_BLOCKS) partials in a fixed order, so the result is
 // deterministic.
 #define DOT_BLOCKS 1024
-#define PL_SCAL_N 32            // device scalars in front of the dot partials (PlSolver::scal)
+#define PL_SCAL_N 40            // device scalars in front of the dot partials (PlSolver::scal); 32..34: y.r, y.p, y.s of the lazy deflation
 template <bool HAS_A, bool HAS_C>
 __global__ __launch_bounds__(256) void k_dot2(PlGeom g, int nplanes, const double* __restrict__ a,
                                               const double* __restrict__ b, const double* __restrict__ cc,
@@ -794,6 +794,10 @@ __device__ inline void bicg_derive(double* __restrict__ out) {
     const double rr = ss - 2.0 * om * ts + om * om * tt;
     out[6] = rr > 0.0 ? rr : 0.0;
     out[7] = (out[5] / out[4]) * (out[2] / om);          // beta of the NEXT iteration: (rho' / rho) (alpha / omega)
+    // lazy deflation (k_defl_coef_lazy): y.v = y.p and y.t = y.s hold by construction of the corrected preconditioner, hence
+    // y.r' = y.s - omega y.t = (1 - omega) y.s  and  y.p' = y.r' + beta (y.p - omega y.v) = y.r' + beta (1 - omega) y.p
+    out[32] = (1.0 - om) * out[34];
+    out[33] = out[32] + out[7] * (1.0 - om) * out[33];
 }
 __global__ __launch_bounds__(256) void k_sum_partials5(int nb, const double* __restrict__ part, double* __restrict__ out, int derive) {
     __shared__ double sh[8][4];
@@ -2828,6 +2832,7 @@ static int stokes_precond(pl_ctx* ctx, PlSolver* S, const double* rs, double* z)
 }
 
 __global__ void k_defl_ysum(PlStokesOp op, const double* __restrict__ rp, double* __restrict__ part);      // defined with the deflation below
+__global__ void k_defl_init(double* __restrict__ sc);
 
 // =========================================================================================
 // Generic right-preconditioned BiCGStab (host-driven scalars)
@@ -2902,7 +2907,7 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
     double true_norm = -1.0, last_true = -1.0;          // ||r0 - A dx|| of the current dx (< 0: not evaluated)
     // BiCGStab is not monotone and, past the attainable accuracy, drifts and can blow up: keep the best
     // iterate, stop after 60 iterations without a new best or when the residual explodes, return the best.
-    double best = 0.0; int best_it = 0; bool have_best = false;
+    double best = 0.0, best_kept = 0.0; int best_it = 0; bool have_best = false;      // best_kept: residual of the iterate in w.xbest
     double tol = rtol;                              // lowered when the velocity-error estimate asks for it
     int est_checks = 0;
     // velocity-error estimate (see above): from the recurrence residual in every iteration near the end, from the true
@@ -2970,6 +2975,10 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
             if (restarts == 0) best = rnorm;
             set_kappa(rnorm);
             broke = false;
+            if (S->defl_lazy && S->defl_active && np == 3 && M) {       // y.r of the (re)start residual; p = r
+                ysum_dev(w.r + 2 * g.plane, S->scal + 32);
+                hipLaunchKernelGGL(k_defl_init, dim3(1), dim3(1), 0, ctx->stream, S->scal);
+            }
         }
         resume = false;
         while (it < maxit && (rnorm > tol * bnorm || (use_est && est_rec > 0.7 * etol))) {
@@ -3050,14 +3059,20 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
             if (!std::isfinite(rnorm) || !(std::fabs(omega) > 0.0)) { broke = true; break; }
             set_kappa(rnorm);
             if (trace) fprintf(stderr, "[pylamp bicgstab] it %3d  |r|/|b| %.3e  alpha %.3e omega %.3e\n", it, rnorm / bnorm, alpha, omega);
+            // the best iterate is kept as a copy (what a stagnating or diverging iteration falls back to).  While the residual still
+            // drops by a decade per iteration that copy -- 206 MB of traffic, 40 us at 2049^2, ten times per solve -- buys nothing: up to
+            // iteration 12 only every fourth improvement is copied (best / best_it follow every one: the stagnation test is unchanged)
             if (rnorm < 0.9 * best && w.xbest) {
-                best = rnorm; best_it = it; have_best = true;
-                PL_HIP(ctx, hipMemcpyAsync(w.xbest, dx, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+                best = rnorm; best_it = it;
+                if (it > 12 || (it & 3) == 0) {
+                    have_best = true; best_kept = rnorm;
+                    PL_HIP(ctx, hipMemcpyAsync(w.xbest, dx, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+                }
             }
             if (w.xbest && (it - best_it > 60 || rnorm > 1e6 * best)) { broke = true; break; }       // stagnation / divergence
         }
         bool restored = false;                      // dx was replaced by the best iterate: the Krylov recurrence no longer belongs to it
-        if (have_best && w.xbest && !(rnorm <= 1.5 * best)) {
+        if (have_best && w.xbest && !(rnorm <= 1.5 * best_kept)) {
             PL_HIP(ctx, hipMemcpyAsync(dx, w.xbest, bytes, hipMemcpyDeviceToDevice, ctx->stream));
             restored = true;
         }
@@ -3188,17 +3203,17 @@ __global__ __launch_bounds__(256) void k_defl_ysum(PlStokesOp op, const double* 
 // y . (D_r A x) from the five cells without a continuity row.  mode 1: sc[24] = y.(A x) (the denominator, x = w);
 // mode 0: sc[25] = (sc[26] - y.(A x)) / sc[24]  (sc[26] = y . r, x = z); mode 2 + k_defl_divide: the same with an all-reduce in between
 __device__ inline double defl_five_cells(const PlStokesOp& op, const double* __restrict__ x);
-// lazy correction (one rank): sc[slot] = (sum of the nb k_defl_ysum partials - y.(A x)) / sc[24]; one wave
-__global__ __launch_bounds__(64) void k_defl_coef_lazy(PlStokesOp op, const double* __restrict__ x, double* __restrict__ sc, int slot, int nb,
-                                                       const double* __restrict__ part) {
-    double ysum = 0.0;
-    for (int k = threadIdx.x; k < nb; k += 64) ysum += part[2 * k];
-    for (int o = 32; o > 0; o >>= 1) ysum += __shfl_down(ysum, o, 64);
-    if (threadIdx.x != 0) return;
+// lazy correction (one rank): sc[slot] = (y.in - y.(A x)) / sc[24] for x = M^-1 in.  y.in is NOT reduced: the corrected
+// preconditioner makes y.(A M~^-1 r) = y.r an identity, so y.p and y.s follow from scalar recurrences (sc[32] = y.r, sc[33] = y.p,
+// sc[34] = y.s; initialised by k_defl_init at every (re)start, advanced here and in bicg_derive) -- no pass over the vector
+__global__ void k_defl_coef_lazy(PlStokesOp op, const double* __restrict__ x, double* __restrict__ sc, int slot, int for_s) {
+    double yin = sc[33];                                        // in = p
+    if (for_s) { yin = sc[32] - sc[2] * sc[33]; sc[34] = yin; }  // in = s = r - alpha v,  y.v = y.p
     const double yAx = -defl_five_cells(op, x);
-    sc[26] = ysum;
-    sc[slot] = (sc[24] != 0.0 && isfinite(sc[24])) ? (ysum - yAx) / sc[24] : 0.0;
+    sc[26] = yin;
+    sc[slot] = (sc[24] != 0.0 && isfinite(sc[24])) ? (yin - yAx) / sc[24] : 0.0;
 }
+__global__ void k_defl_init(double* __restrict__ sc) { sc[33] = sc[32]; sc[34] = sc[32]; }     // p = r at a (re)start
 __global__ void k_defl_coef(PlStokesOp op, const double* __restrict__ x, double* __restrict__ sc, int mode) {
     const double yAx = -defl_five_cells(op, x);
     if (mode == 1) sc[24] = yAx;                                                                  // (this rank's share on several ranks)
@@ -3262,13 +3277,12 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
     VecOp M = [&](const double* in, double* out) -> int {
         PL_TRY(stokes_precond(ctx, S, in, out));
         if (S->defl_active) {                               // z += w y.(r - A z) / y.(A w), all scalars on the device
-            const int nb = g.lnz < DOT_BLOCKS ? g.lnz : DOT_BLOCKS;
-            hipLaunchKernelGGL(k_defl_ysum, dim3(nb), dim3(256), 0, ctx->stream, sop, in + 2 * g.plane, S->scal + PL_SCAL_N);
             if (S->defl_lazy && (out == S->y || out == S->z)) {       // the coefficient only: A and the iterate update do the rest
-                hipLaunchKernelGGL(k_defl_coef_lazy, dim3(1), dim3(64), 0, ctx->stream, sop, (const double*)out, S->scal, out == S->y ? 30 : 31, nb,
-                                   (const double*)(S->scal + PL_SCAL_N));
+                hipLaunchKernelGGL(k_defl_coef_lazy, dim3(1), dim3(1), 0, ctx->stream, sop, (const double*)out, S->scal, out == S->y ? 30 : 31, out == S->z ? 1 : 0);
                 return 0;
             }
+            const int nb = g.lnz < DOT_BLOCKS ? g.lnz : DOT_BLOCKS;
+            hipLaunchKernelGGL(k_defl_ysum, dim3(nb), dim3(256), 0, ctx->stream, sop, in + 2 * g.plane, S->scal + PL_SCAL_N);
             hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, nb, S->scal + PL_SCAL_N, S->scal + 26, 0, 0.0);
             if (ctx->nranks > 1) {                          // one scalar per application: y.r and the five cells live on different ranks
                 hipLaunchKernelGGL(k_defl_coef, dim3(1), dim3(1), 0, ctx->stream, sop, (const double*)out, S->scal, 2);

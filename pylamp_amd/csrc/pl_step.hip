@@ -333,6 +333,20 @@ __global__ __launch_bounds__(256) void k_minmax(PlGeom g, const double* __restri
     }
 }
 
+// second stage: the nb block partials -> out[0..2] (one workgroup; the host then reads 24 bytes instead of 400 KB of partials)
+__global__ __launch_bounds__(1024) void k_minmax_final(int nb, const double* __restrict__ part, double* __restrict__ out) {
+    double mn = INFINITY, mx = -INFINITY, nf = 0.0;
+    for (int k = threadIdx.x; k < nb; k += 1024) { mn = fmin(mn, part[3 * k]); mx = fmax(mx, part[3 * k + 1]); nf = fmax(nf, part[3 * k + 2]); }
+    __shared__ double sm[3][16];
+    for (int o = 32; o > 0; o >>= 1) { mn = fmin(mn, __shfl_down(mn, o, 64)); mx = fmax(mx, __shfl_down(mx, o, 64)); nf = fmax(nf, __shfl_down(nf, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = mn; sm[1][threadIdx.x >> 6] = mx; sm[2][threadIdx.x >> 6] = nf; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; w++) { mn = fmin(mn, sm[0][w]); mx = fmax(mx, sm[1][w]); nf = fmax(nf, sm[2][w]); }
+        out[0] = mn; out[1] = mx; out[2] = nf;
+    }
+}
+
 // f_T boundary rows/cols from the previous solution (pylamp2.py:333-337)
 __global__ __launch_bounds__(256) void k_copy_boundary(PlGeom g, const double* __restrict__ src, double* __restrict__ dst) {
     const int lj = blockIdx.x * 64 + threadIdx.x, li = blockIdx.y * 4 + threadIdx.y;
@@ -417,19 +431,16 @@ static int reduce_minmax(pl_ctx* ctx, PlStepState* S, const PlGeom& g, const dou
                          int mode, double* mn, double* mx, bool* has_nan) {
     dim3 gr = grid2d(g);
     size_t nb = (size_t)gr.x * gr.y;
-    if (!S->partial || S->hpartial.size() < 3 * nb) {
+    if (!S->partial || S->hpartial.size() < 3 * (nb + 1)) {
         if (S->partial) (void)hipFree(S->partial);
-        PL_HIP(ctx, hipMalloc((void**)&S->partial, 3 * nb * sizeof(double)));
-        S->hpartial.resize(3 * nb);
+        PL_HIP(ctx, hipMalloc((void**)&S->partial, 3 * (nb + 1) * sizeof(double)));
+        S->hpartial.resize(3 * (nb + 1));
     }
     hipLaunchKernelGGL(k_minmax, gr, dim3(64, 4), 0, ctx->stream, g, a, b, c, mode, S->partial);
-    PL_HIP(ctx, hipMemcpyAsync(S->hpartial.data(), S->partial, 3 * nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(1024), 0, ctx->stream, (int)nb, (const double*)S->partial, S->partial + 3 * nb);
+    PL_HIP(ctx, hipMemcpyAsync(S->hpartial.data(), S->partial + 3 * nb, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    double m0 = INFINITY, m1 = -INFINITY; bool nf = false;
-    for (size_t k = 0; k < nb; k++) {
-        m0 = std::fmin(m0, S->hpartial[3 * k]); m1 = std::fmax(m1, S->hpartial[3 * k + 1]);
-        if (S->hpartial[3 * k + 2] > 0) nf = true;
-    }
+    double m0 = S->hpartial[0], m1 = S->hpartial[1]; bool nf = S->hpartial[2] > 0;
     if (ctx->nranks > 1) {
         double v[3] = {-m0, m1, nf ? 1.0 : 0.0};                   // ONE max-reduction: min = -max(-x)
         PL_TRY(pl_allreduce_host(ctx, v, 3, 2));
