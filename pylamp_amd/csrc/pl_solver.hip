@@ -1104,6 +1104,7 @@ struct MgLevel {
     double* etas = nullptr; double* etan = nullptr; bool own_visc = false;
     double *rho = nullptr, *szz = nullptr, *szx = nullptr;     // free-surface stabilisation (allocated on first use)
     double* eig = nullptr; bool eig_valid = false;             // dominant eigenvector of D^-1 A from the last solve
+    int eig_confirm = 0, eig_skip = 0;                         // consecutive solves that confirmed lmax to 0.2 %; solves since the last refresh
     bool own_rho = false;
     double* v[3] = {nullptr, nullptr, nullptr};      // rotating Chebyshev buffers (2 planes each)
     double *f = nullptr, *r = nullptr;
@@ -1657,6 +1658,12 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
         // eigenvector of the previous solve with 3 instead of 12 iterations (each is a kernel + a host round trip;
         // 12 x 9 levels were ~4 ms of every solve).
         if (!L->eig) { PL_TRY(dmalloc0(ctx, &L->eig, (size_t)n2 * sizeof(double))); L->eig_valid = false; }
+        // In a time loop (the driver announces consecutive solves of one slowly changing model) an estimate that two solves in a row
+        // have confirmed to 0.2 % is refreshed only every fourth solve: each refresh is two 2-plane copies, a kernel, an axpy and a
+        // host round trip per level (0.5 ms per solve at 2049^2), and lmax carries a safety factor of 1.1
+        if (S->defl_persistent && L->eig_valid && L->eig_confirm >= 2 && L->eig_skip < 3 && L->lmax > 0.0) { L->eig_skip++; continue; }
+        L->eig_skip = 0;
+        const double lam_before = (L->eig_valid && S->lmax_safety > 0.0) ? L->lmax / S->lmax_safety : 0.0;
         if (L->eig_valid) PL_HIP(ctx, hipMemcpyAsync(L->v[0], L->eig, (size_t)n2 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
         else hipLaunchKernelGGL(k_random_interior, grid2d(g), dim3(64, 4), 0, ctx->stream, g, 2, L->v[0], 777u);
         const bool warm = L->eig_valid;
@@ -1678,6 +1685,7 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
         L->lmax = S->lmax_safety * lam;
         PL_HIP(ctx, hipMemcpyAsync(L->eig, L->v[0], (size_t)n2 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
         L->eig_valid = std::isfinite(lam) && lam > 0.0;
+        L->eig_confirm = (L->eig_valid && lam_before > 0.0 && std::fabs(lam - lam_before) < 0.002 * lam) ? L->eig_confirm + 1 : 0;
     }
     PL_TRY(setup_f32_levels(ctx, S));
     // early coarse branch: first level of at most early_max_nodes nodes, on one rank, when at least two levels lie above it
@@ -3452,6 +3460,7 @@ extern "C" int pl_stokes_solve(pl_ctx* ctx, const double* rhs, double* x, int us
     pl_solve_stats st{};
     if (rtol <= 0) rtol = 1e-10;
     if (maxit <= 0) maxit = 400;
+    S->defl_persistent = false;                  // a solve of its own, not a step of a time loop (pl_step announces those)
     PL_TRY(pl_stokes_solve_device(ctx, S->b, use_x0 != 0, rtol, maxit, &st));
     PL_TRY(pl_vec3_download(ctx, g, S->x, x));
     if (stats) *stats = st;
