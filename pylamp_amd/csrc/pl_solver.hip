@@ -2899,6 +2899,12 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
     }
     PL_HIP(ctx, hipMemsetAsync(dx, 0, bytes, ctx->stream));
     PL_HIP(ctx, hipMemcpyAsync(w.r, r0, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    double xx_guess = 0.0;                        // ||x0_vel||^2 of a warm start (0: unknown / cold start from a state without velocities)
+    if (use_x0 && etol > 0.0 && np_vel > 0 && np > np_vel) {
+        double dxx[2];
+        PL_TRY(dots(ctx, S, g, np_vel, x, x, nullptr, nullptr, dxx));
+        if (std::isfinite(dxx[0]) && dxx[0] > 0.0) xx_guess = dxx[0];
+    }
     // Shadow residual: the textbook choice r0 when a preconditioned solve starts from a guess (r0 = b - A x0 has components in all
     // rows), the seeded random vector otherwise -- with r0 = b the method breaks down (b lives on the vz rows only).  Against the
     // random vector in the time-step loop at 2049^2 the first iterations no longer stall on an arbitrary alpha (10.7 -> 9.7
@@ -3007,9 +3013,12 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
                 // near the end: ||x_vel||^2 for the error estimate (-> scal[16]; of the iterate BEFORE this update, so that
                 // it can ride along in the fused reduction -- the estimate needs it to ~10 %)
                 const bool want_xx = use_est && rnorm <= 1e3 * tol * bnorm;
-                if (want_xx) PL_TRY(norm2_sum_dev(ctx, S, g, np_vel, dx, dx != x ? (const double*)x : (const double*)nullptr, false));
+                // (warm start: ||x0_vel|| stands for ||x_vel|| in the per-iteration estimate -- they differ by the relative size of the
+                //  correction, and the estimate needs the norm to ~10 %; the check on the true residual below uses the exact one)
+                if (want_xx && !(xx_guess > 0.0)) PL_TRY(norm2_sum_dev(ctx, S, g, np_vel, dx, dx != x ? (const double*)x : (const double*)nullptr, false));
                 if (want_xx && M) PL_TRY(norm2_sum_dev(ctx, S, g, np_vel, zv, nullptr, false, 20));      // ||z_vel||^2 of z = M^-1 s -> scal[20] (k_sum_partials also clears the slot behind its target: 19 belongs to y.t)
-                if (want_xx && anchor_term) {            // y.r of the updated residual = y.s - omega y.t: both ride in the reduction as well
+                const bool y_recur = S->defl_lazy && S->defl_active && np == 3 && M;       // y.r of the updated residual comes out of bicg_derive (sc[32])
+                if (want_xx && anchor_term && !y_recur) {            // y.r of the updated residual = y.s - omega y.t: both ride in the reduction as well
                     ysum_dev(w.s + (long long)np_vel * g.plane, S->scal + 17);
                     ysum_dev(w.t + (long long)np_vel * g.plane, S->scal + 18);
                 }
@@ -3032,7 +3041,8 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
                     const double ss_mom = hs[12] - hs[15];
                     if (ss_mom > 0.0 && hs[20] > 0.0) { a_mom = std::min(std::max(std::sqrt(hs[20] / ss_mom), 1.0), n_amp * n_amp); a_mom_measured = true; }
                 }
-                if (want_xx) est_rec = estimate(hs[15] - 2.0 * omega * hs[13] + omega * omega * hs[14], hs[6], hs[16], hs[17] - omega * hs[18]);
+                if (want_xx) est_rec = estimate(hs[15] - 2.0 * omega * hs[13] + omega * omega * hs[14], hs[6], xx_guess > 0.0 ? xx_guess : hs[16],
+                                                y_recur ? hs[32] : hs[17] - omega * hs[18]);
                 else est_rec = 0.0;
             } else {
                 PL_TRY(dots(ctx, S, g, np, w.rt, w.v, nullptr, nullptr, d2));
@@ -3107,6 +3117,7 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
             PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
             est_checks++;
             const double xx = S->hpart[8 * DOT_BLOCKS];
+            if (xx_guess > 0.0 && xx > 0.0) xx_guess = xx;               // (the exact norm of this iterate from here on)
             const double rc = dc[0] > 0.0 ? dc[0] : 0.0, rm = true_norm * true_norm - rc;
             if (!exact) dz[0] = a_mom * a_mom * (rm > 0.0 ? rm : 0.0);            // the response the last iteration measured, scaled to this residual
             double est = xx > 0.0 ? (n_amp * std::sqrt(rc) + std::sqrt(dz[0] > 0.0 ? dz[0] : 0.0)) / std::sqrt(xx) : 0.0;
