@@ -1922,7 +1922,7 @@ static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const T* f, T** out, bool
                 for (int b = 0; b < 3; b++) ta.L[q].v[b] = T_->v[b];
             }
             // one rank: the LDS-resident twin (levels kept in LDS, the tile kernels' node functions) where its pool holds the levels
-            if (S->fused && ctx->nranks == 1 && !L->op.szz && ta.nu_pre >= 1 && ta.nu_post >= 1 && ta.coarse_sweeps >= 1 && mg_tail_lds_fits(S, l))
+            if (S->fused && !L->dist && !L->op.szz && ta.nu_pre >= 1 && ta.nu_post >= 1 && ta.coarse_sweeps >= 1 && mg_tail_lds_fits(S, l))
                 hipLaunchKernelGGL(k_mg_tail_lds, dim3(1), dim3(1024), 0, ctx->stream, ta);
             else
                 hipLaunchKernelGGL(k_mg_tail, dim3(1), dim3(1024), 0, ctx->stream, ta);
@@ -2649,9 +2649,11 @@ static void cheb_coeffs(double lmax, double ratio, int n, double* c1, double* c2
     }
 }
 static bool mg_fused_level_ok(pl_ctx* ctx, const PlSolver* S, size_t l) {
-    if (!S->fused || ctx->nranks != 1 || l + 1 >= S->levels.size() || S->early_K > 0) return false;
+    if (!S->fused || l + 1 >= S->levels.size() || S->early_K > 0) return false;
     const MgLevel* L = S->levels[l];
-    if (L->dist || L->f32 || L->op.szz) return false;
+    // several ranks: the REPLICATED levels (every rank holds and computes the whole level) run the tile kernels like one rank does --
+    // they are the latency-bound ones; a level whose own or whose coarse grid is distributed keeps the staged path with its exchanges
+    if (L->dist || S->levels[l + 1]->dist || L->f32 || L->op.szz) return false;
     const PlGeom& g = L->gh.d;
     if ((long long)g.nz * g.nx > S->fused_max_nodes) return false;
     if (S->use_tail && l > 0 && (long long)g.nz * g.nx <= S->tail_max_nodes && S->levels.size() - l <= PL_TAIL_MAX_LEVELS) return false;   // the tail kernel's levels
