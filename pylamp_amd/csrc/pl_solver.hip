@@ -3807,7 +3807,7 @@ static int heat_solve_cg(pl_ctx* ctx, PlSolver* S, const double* b_dev, double r
     // 1 / T_k(1 / rho) -- with NO reduction and ONE launch per sweep (CG: 4 launches and 2 reductions per iteration, which is what the
     // 2.2 ms of a 12-iteration solve at 2049^2 were made of).  The true residual is confirmed afterwards as before.
     const double rho_g = hs[7];
-    static const int cheb_env = getenv("PYLAMP_HEAT_CHEB") ? atoi(getenv("PYLAMP_HEAT_CHEB")) : 1;
+    const int cheb_env = getenv("PYLAMP_HEAT_CHEB") ? atoi(getenv("PYLAMP_HEAT_CHEB")) : 1;         // (read per solve: tests switch it)
     const bool cheb_ok = cheb_env != 0 && rho_g > 0.0 && rho_g < 0.97 && std::isfinite(rho_g);
     st->iterations = 0; st->converged = 0; st->rel_residual = 0.0; st->error_estimate = 0.0;
     S->napply = 0;

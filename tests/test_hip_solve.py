@@ -332,3 +332,56 @@ def test_level0_fp32_storage_same_preconditioner():
     for q in range(2):
         assert np.max(np.abs(zm[:, :, q] - zd[:, :, q])) < 3e-6 * np.max(np.abs(zd[:, :, q])), q
     assert np.array_equal(zm[:, :, 2], zd[:, :, 2])
+
+
+@pytest.mark.parametrize("tag,dtfac", [("b1", 1.0), ("c0", 1.0), ("b1", 300.0)])
+def test_heat_chebyshev_and_cg_agree(tag, dtfac, monkeypatch):
+    """The heat solve runs a Chebyshev iteration on the symmetrised system (Gershgorin bounds of D^-1 A; one launch per sweep, no
+    reduction) where its sweep count is small, and CG on the same system otherwise -- time steps far beyond the diffusive scale,
+    rho >= 0.97 -- or with PYLAMP_HEAT_CHEB=0.  Both against the reference's fixture (where the time step is the fixture's) and
+    against each other."""
+    from pylamp_amd import pylamp_diff as D
+    g = golden("heat_" + tag)
+    nx = [int(v) for v in g["nx"]]
+    sols = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PYLAMP_HEAT_CHEB", mode)
+        A, rhs = D.makeDiffusionMatrix(nx, [g["gz"], g["gx"]], [g["gmz"], g["gmx"]], g["T"], [g["kz"], g["kx"]],
+                                       g["Cp"], g["rho"], g["H"], list(g["bc"]), list(g["bcvalue"]), float(g["tstep"]) * dtfac)
+        x = D.solve(A, rhs)
+        assert A.last_stats["converged"] == 1, (mode, A.last_stats)
+        r = A @ x - rhs
+        assert np.linalg.norm(r) <= 1e-9 * np.linalg.norm(rhs), mode
+        sols[mode] = (D.x2t(x, nx), dict(A.last_stats))
+    assert relerr(sols["1"][0], sols["0"][0]) < 1e-9
+    if dtfac == 1.0:
+        assert relerr(sols["1"][0], g["sol"].reshape(nx)) < VEL_TOL
+
+
+def test_lazy_deflation_correction_same_solve(oracle, monkeypatch):
+    """The deflation of the pressure-anchor mode applied lazily (coefficient from scalar recurrences, c A w added in the operator's
+    epilogue, the w part of the iterate added in the update kernel) against the explicit correction z += c w: the same
+    preconditioner in exact arithmetic -- same velocities, iteration counts within one."""
+    from pylamp_amd import pylamp_stokes as S, _context
+    nx = [257, 193]; L = [660e3, 495e3]
+    grid = [np.linspace(0, L[d], nx[d]) for d in range(2)]
+    Z, X = np.meshgrid(*grid, indexing='ij')
+    gm = oracle.gridmp_of(grid)
+    Zc, Xc = np.meshgrid(*gm, indexing='ij')
+    f = lambda z, x: 1e20 * 10 ** (1.5 * np.sin(2 * np.pi * x / L[1]) * np.cos(np.pi * z / L[0]))
+    rho = 3300 + 40 * np.sin(2 * np.pi * X / L[1]) * np.sin(np.pi * Z / L[0])
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PYLAMP_DEFL_LAZY", mode)
+        _context.clear_contexts()
+        A, rhs = S.makeStokesMatrix(nx, grid, f(Z, X), f(Zc, Xc), rho, [1, 1, 1, 1])
+        x = S.solve(A, rhs)
+        x2 = S.solve(A, 1.02 * rhs, x0=x)             # a warm-started solve on the same context: the kept deflation vector is reused
+        out[mode] = (x.copy(), dict(A.last_stats), x2.copy())
+        del A
+    _context.clear_contexts()
+    (xl, sl, xl2), (xe, se, xe2) = out["1"], out["0"]
+    assert sl["converged"] == 1 and se["converged"] == 1 and abs(sl["iterations"] - se["iterations"]) <= 1, (sl, se)
+    v = lambda x: x.reshape(nx[0], nx[1], 3)[:, :, :2]
+    assert np.linalg.norm(v(xl) - v(xe)) / np.linalg.norm(v(xe)) < 1e-6
+    assert np.linalg.norm(v(xl2) - v(xe2)) / np.linalg.norm(v(xe2)) < 1e-6
