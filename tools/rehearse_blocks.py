@@ -1,7 +1,9 @@
 """Rehearsal of the Pz x Px block decomposition on ONE GPU with virtual ranks (driver.VirtualCluster): communication
 calls per time step / per BiCGStab iteration / per preconditioner application, and agreement with the one-rank run.
 
-    python tools/rehearse_blocks.py [n=2049] [Pz=2] [Px=4] [markers/node=4] [steps=2]
+    python tools/rehearse_blocks.py [n=2049] [Pz=2] [Px=4] [markers/node=8] [steps=2]
+
+(4 randomly placed markers per node leave a handful of the 4.2 M nodes of a 2049^2 grid without any marker in reach -- NaN fields.)
 
 Timings mean nothing here (8 contexts share one GPU and the in-process transport synchronises on the host); the
 COUNTS are those of the multi-GPU run."""
@@ -13,7 +15,7 @@ from pylamp_amd import driver
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2049
 Pz = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 Px = int(sys.argv[3]) if len(sys.argv) > 3 else 4
-dens = int(sys.argv[4]) if len(sys.argv) > 4 else 4
+dens = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 steps = int(sys.argv[5]) if len(sys.argv) > 5 else 2
 nx = [n, n]; L = [660e3, 660e3]
 rng = np.random.default_rng(20260103)
