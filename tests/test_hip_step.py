@@ -428,15 +428,16 @@ print("RESULT", json.dumps(dict(its=its, hits=hits, est=rep["stokes"]["error_est
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("heat", [True, False])
-def test_epoch_layout_and_lazy_columns_change_nothing(heat, monkeypatch):
+@pytest.mark.parametrize("heat,dens,dmin", [(True, 9, 8), (False, 9, 8), (True, 16, 15)])
+def test_epoch_layout_and_lazy_columns_change_nothing(heat, dens, dmin, monkeypatch):
     """The end-of-step sort of the resident step moves only positions, temperature and a 4-byte slot per tracer
     (epoch layout: the ten columns no stage writes stay where they were, RHO / ETA / tracer velocities are moved only
     when somebody asks for them; pl_step.hip).  Against PYLAMP_EPOCH=0 (every column moves in every sort): the constant
     columns of the uploaded tracers come back IDENTICAL bit for bit, in the caller's order -- across epoch boundaries (epoch
     length 3), with injection in every step and with downloads in the middle of an epoch; everything that went through a
     Stokes solve agrees to the solver's own reproducibility (the order of the tracers inside a cell, hence the last bits
-    of the marker sums, depends on the order in which the sort's atomics land)."""
+    of the marker sums, depends on the order in which the sort's atomics land).  The third case refills nearly every cell
+    from 9 to 16 markers in the first step: the tracer arrays are re-allocated in the middle of the sort that opens the epoch."""
     from pylamp_amd import driver
     nx = [49, 65]; L = [660e3, 880e3]
     runs = {}
@@ -449,7 +450,7 @@ def test_epoch_layout_and_lazy_columns_change_nothing(heat, monkeypatch):
             tr_f[:, col] *= rng.uniform(0.9, 1.1, tr_f.shape[0])
         tr_f[:, 2] = rng.uniform(0, 1, tr_f.shape[0])
         n0 = tr_x.shape[0]
-        opt = driver.Options(do_heatdiff=heat, do_subgrid_heatdiff=heat, tracdens=9, tracdens_min=8, inject_unique_ids=True)
+        opt = driver.Options(do_heatdiff=heat, do_subgrid_heatdiff=heat, tracdens=dens, tracdens_min=dmin, inject_unique_ids=True)
         sim = driver.Simulation(nx, L, tr_x, tr_f, opt)
         out = []
         for it in range(8):
