@@ -2945,7 +2945,7 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
     // iterate's own residual r = s - omega t, which has the same character.  (Until round 3 it was measured by ONE MORE
     // preconditioner application on the true residual at every check: 0.8-1.6 ms of a 25 ms solve at 2049^2.  PYLAMP_EST_EXACT=1
     // brings that back.)
-    double a_mom = 1.0; bool a_mom_measured = false;
+    double a_mom = 1.0; bool a_mom_measured = false; int amom_count = 0;
     static const bool est_exact = getenv("PYLAMP_EST_EXACT") && atoi(getenv("PYLAMP_EST_EXACT")) != 0;
     // With the pressure-anchor deflation active the component of the residual along that mode needs its own term: its
     // amplification is ||w|| / ||u|| (1e4 and more), far beyond n -- r = gamma u + ..., gamma = y.r / y.u, and the error it stands
@@ -3018,7 +3018,10 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
                 // (warm start: ||x0_vel|| stands for ||x_vel|| in the per-iteration estimate -- they differ by the relative size of the
                 //  correction, and the estimate needs the norm to ~10 %; the check on the true residual below uses the exact one)
                 if (want_xx && !(xx_guess > 0.0)) PL_TRY(norm2_sum_dev(ctx, S, g, np_vel, dx, dx != x ? (const double*)x : (const double*)nullptr, false));
-                if (want_xx && M) PL_TRY(norm2_sum_dev(ctx, S, g, np_vel, zv, nullptr, false, 20));      // ||z_vel||^2 of z = M^-1 s -> scal[20] (k_sum_partials also clears the slot behind its target: 19 belongs to y.t)
+                // (the amplification moves slowly: measured in the first two late iterations, then in every third)
+                const bool amom_now = want_xx && M && (amom_count < 2 || amom_count % 3 == 0);
+                if (want_xx && M) amom_count++;
+                if (amom_now) PL_TRY(norm2_sum_dev(ctx, S, g, np_vel, zv, nullptr, false, 20));      // ||z_vel||^2 of z = M^-1 s -> scal[20] (k_sum_partials also clears the slot behind its target: 19 belongs to y.t)
                 const bool y_recur = S->defl_lazy && S->defl_active && np == 3 && M;       // y.r of the updated residual comes out of bicg_derive (sc[32])
                 if (want_xx && anchor_term && !y_recur) {            // y.r of the updated residual = y.s - omega y.t: both ride in the reduction as well
                     ysum_dev(w.s + (long long)np_vel * g.plane, S->scal + 17);
@@ -3039,7 +3042,7 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
                 alpha = hs[2]; omega = hs[3];
                 rho_new = hs[5]; rnorm = std::sqrt(hs[6]);
                 if (!std::isfinite(alpha)) { broke = true; break; }
-                if (want_xx && M) {
+                if (amom_now) {
                     const double ss_mom = hs[12] - hs[15];
                     if (ss_mom > 0.0 && hs[20] > 0.0) { a_mom = std::min(std::max(std::sqrt(hs[20] / ss_mom), 1.0), n_amp * n_amp); a_mom_measured = true; }
                 }
