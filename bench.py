@@ -214,6 +214,49 @@ def bench_3d(args):
     print(json.dumps(out))
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): start the N ranks as child processes, one
+    per GPU, with the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT) and wait for them.
+    The parent never touches HIP (torch.cuda.device_count() does not initialise the GPU on this image); nothing is exec'ed from a
+    process that has.  Fewer visible GPUs than ranks: the ranks share the GPUs under the gloo backend (a rehearsal, said so on the
+    bench line).  A failed rank ends the job: the others are terminated (by pid) and the exit code is non-zero."""
+    import socket
+    import subprocess
+    try:
+        import torch
+        ndev = torch.cuda.device_count()
+    except Exception:
+        ndev = 0
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in env:
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); env["MASTER_PORT"] = str(s.getsockname()[1]); s.close()
+    env["WORLD_SIZE"] = str(n); env["LOCAL_WORLD_SIZE"] = str(n)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    if ndev < n and "PYLAMP_DIST_BACKEND" not in env:
+        env["PYLAMP_DIST_BACKEND"] = "gloo"
+    procs = []
+    for r in range(n):
+        e = dict(env); e["RANK"] = str(r); e["LOCAL_RANK"] = str(r)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e))
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            try:
+                code = p.wait(timeout=0.5)
+            except subprocess.TimeoutExpired:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:
+                    q.terminate()
+    if rc:
+        sys.exit(rc if 0 < rc < 256 else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="2d", choices=["2d", "3d257"], help="3d257: BASELINE config 5 on one GPU (3-D Stokes + heat)")
@@ -235,6 +278,8 @@ def main():
     args = ap.parse_args()
     if args.config == "3d257":
         return bench_3d(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -359,6 +404,10 @@ def main():
                                       (sim.ctx.local_block()[4], sim.ctx.local_block()[5], "direct RCCL on the solver stream" if (sim.ctx.comm is not None and sim.ctx.comm.native)
                                        else "torch.distributed (%s)" % (dist.get_backend() if dist is not None else "-")),
                        "stokes_rtol": sim.opt.stokes_rtol, "heat_rtol": sim.opt.heat_rtol,
+                       # what `dtype: f64` does not say: storage of the preconditioner's finest level and the tracer layout
+                       "precond_storage": ("level-0 f / v1 / r of the multigrid preconditioner stored in FP32 (FP64 arithmetic; operator, Krylov "
+                                           "vectors and every residual FP64)" if os.environ.get("PYLAMP_L0_MIXED", "1") != "0" else "FP64 throughout"),
+                       "tracer_layout": "epoch (PYLAMP_EPOCH=%s), age %d" % (os.environ.get("PYLAMP_EPOCH", "64"), epoch_age) if epoch_age > 0 else "classic",
                        "stokes_stop": "true relative residual <= stokes_rtol AND estimated relative velocity error <= %s "
                                       "(pl_solve_stats.error_estimate; the drop-in's promise against the reference's direct solve is 1e-6)"
                                       % os.environ.get("PYLAMP_STOKES_ETOL", "3e-8")},

@@ -285,10 +285,11 @@ def gen_grid2trac_rk():
 
 
 # ------------------------------------------------------------------------------------ F8
-def run_driver(tag, repl, nsteps, seed, capture_post=False):
+def run_driver(tag, repl, nsteps, seed, capture_post=False, compact=None):
     """exec the stock driver text with in-memory substitutions; collect its snapshots.
     capture_post: also store the tracer state at the END of every loop pass, i.e. after deletion and injection
-    (pylamp2.py:574-633) -- the stock snapshot holds the state BEFORE injection (prev_tr_x / prev_tr_f)."""
+    (pylamp2.py:574-633) -- the stock snapshot holds the state BEFORE injection (prev_tr_x / prev_tr_f).
+    compact: function that reduces the collected arrays before they are stored (the stock configuration has 370 845 tracers)."""
     src = open(os.path.join(REF, "pylamp2.py")).read()
     if capture_post:
         hook = "        if IPROC == 0 and output_numpy and ((output_stride > 0"
@@ -343,6 +344,8 @@ def run_driver(tag, repl, nsteps, seed, capture_post=False):
                 res["p%d_tr_x" % it] = po["tr_x"]; res["p%d_tr_f" % it] = po["tr_f"]
             if it == 1:
                 res["gz"] = gd["gridz"]; res["gx"] = gd["gridx"]
+    if compact:
+        res = compact(res)
     save("traj_" + tag, **res)
 
 
@@ -417,8 +420,67 @@ def gen_trajectory_surfstab():
         bcset], 3, 13)
 
 
+# ------------------------------------------------------------------------------------ F2 / F8: the reference's STOCK configuration
+def model5_tracers(nx, L, tracdens, seed):
+    """Tracers of the stock run exactly as pylamp2.py:116-125,225-242,255-262 makes them after np.random.seed(seed)."""
+    ntrac = int(np.prod(nx)) * tracdens
+    tr_x = np.random.RandomState(seed).rand(ntrac, 2) * np.array(L)
+    tr_f = np.zeros((ntrac, NFTRAC))
+    tr_f[:, TR__ID] = np.arange(0, ntrac)
+    tr_f[:, TR_RH0] = 1420; tr_f[:, TR_MAT] = 1; tr_f[:, TR_ET0] = 1e2
+    idx = (tr_x[:, 1] - 0.1) ** 2 + (tr_x[:, 0] - 0.2) ** 2 < 0.01 ** 2
+    tr_f[idx, TR_RH0] = 1470; tr_f[idx, TR_MAT] = 2; tr_f[idx, TR_ET0] = 1e12
+    return tr_x, tr_f
+
+
+def gen_model5():
+    """choose_model = 5 (pylamp2.py:225-242), the configuration the reference ships with: a dense sphere of viscosity 1e12 in a
+    fluid of viscosity 1e2 (contrast 1e10), 201 x 41 nodes on a 1 x 0.2 domain, 45 markers per node, heat off."""
+    nx = [201, 41]; L = [1.0, 0.2]; seed = 17
+    grid, mesh, gridmp, meshmp = ref_grids(nx, L)
+    tr_x, tr_f = model5_tracers(nx, L, 45, seed)
+    tr_f[:, TR_RHO] = tr_f[:, TR_RH0]; tr_f[:, TR_ETA] = tr_f[:, TR_ET0]
+    f_rho = np.zeros(nx); f_etas = np.zeros(nx); f_etan = np.zeros(nx)
+    # the advect-only branch of the driver (pylamp2.py:316-319): unweighted geometric mean for etan
+    RT.trac2grid(tr_x, tr_f[:, [TR_RHO, TR_ETA]], mesh, grid, [f_rho, f_etas], nx,
+                 avgscheme=[RT.INTERP_AVG_ARITHW, RT.INTERP_AVG_GEOMW])
+    RT.trac2grid(tr_x, tr_f[:, [TR_ETA]], meshmp, gridmp, [f_etan], nx, avgscheme=[RT.INTERP_AVG_GEOMETRIC])
+    bc = [1, 1, 1, 1]
+    A, rhs = RS.makeStokesMatrix(nx, grid, f_etas, f_etan, f_rho, bc)
+    x = spla.spsolve(sp.csc_matrix(A), rhs)
+    save("stokes_solve_sphere201x41", nx=np.array(nx), gz=grid[0], gx=grid[1], etas=f_etas, etan=f_etan, rho=f_rho,
+         bc=np.array(bc), rhs=rhs, x=x, seed=seed, tracdens=45)
+
+    # three steps of the UNMODIFIED driver (only max_it and the seed are set).  The stock run holds 370 845 tracers (44 MB per
+    # state): stored are the seed (the initial tracers follow from it, model5_tracers above -- checked here against the driver's
+    # own), the grid fields of every step, every 41st tracer (position, velocity), sums over all of them, and the rows the
+    # driver's census injected (pylamp2.py:588-633) so that a test can continue from the reference's post-injection state.
+    def compact(res):
+        ix, ifl = model5_tracers(nx, L, 45, seed)
+        assert np.array_equal(ix, res["init_tr_x"])
+        ref_f = res["init_tr_f"].copy()
+        mrk = ref_f[:, TR_MRK].copy(); ref_f[:, TR_MRK] = 0          # passive markers (pylamp2.py:255-262): stored separately
+        assert np.array_equal(ifl, ref_f)
+        out = dict(seed=seed, tracdens=45, tracdens_min=25, nsteps=res["nsteps"], gz=res["gz"], gx=res["gx"], stride=41,
+                   init_mrk_sum=mrk.sum(), init_mrk_sub=mrk[::41])
+        for it in range(1, int(res["nsteps"]) + 1):
+            p, q = "s%d_" % it, "p%d_" % it
+            for k in ("velz", "velx", "pres", "rho", "time"):
+                out[p + k] = res[p + k]
+            n_old = res[p + "tr_x"].shape[0]
+            out[p + "n"] = n_old
+            out[p + "tr_x_sub"] = res[p + "tr_x"][::41]; out[p + "tr_v_sub"] = res[p + "tr_v"][::41]
+            out[p + "tr_x_sum"] = res[p + "tr_x"].sum(axis=0); out[p + "tr_v_sum"] = np.abs(res[p + "tr_v"]).sum(axis=0)
+            out[q + "n"] = res[q + "tr_x"].shape[0]
+            out[q + "inj_x"] = res[q + "tr_x"][n_old:]; out[q + "inj_f"] = res[q + "tr_f"][n_old:]
+            out[q + "rho_col_sum"] = res[q + "tr_f"][:, TR_RHO].sum(); out[q + "mat_col_sum"] = res[q + "tr_f"][:, TR_MAT].sum()
+        return out
+    run_driver("model5", [], 3, seed, capture_post=True, compact=compact)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["op", "solve", "heat", "t2g", "g2t", "traj", "surfstab", "census"]
+    which = sys.argv[1:] or ["op", "solve", "heat", "t2g", "g2t", "traj", "surfstab", "census", "model5"]
+    if "model5" in which: gen_model5()
     if "op" in which: gen_stokes_operator()
     if "solve" in which: gen_stokes_solve()
     if "heat" in which: gen_heat()

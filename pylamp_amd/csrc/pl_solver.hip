@@ -3445,7 +3445,13 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
         const int it0 = st->iterations;
         PL_HIP(ctx, hipMemcpyAsync(S->x, S->xh, (size_t)3 * g.plane * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
         hipLaunchKernelGGL(k_close_constraints, grid2d(g), dim3(64, 4), 0, ctx->stream, sop, S->levels[0]->op, S->b, S->x);
-        PL_TRY(bicgstab(ctx, S, g, 3, A, &MD, S->b, S->x, true, rtol, 50, w, st, ref, S->etol, 2));
+        // MD never computes the lazy deflation coefficients (scal[30], scal[31]): with the deflation left active, A and the iterate
+        // update would keep adding stale -- after a breakdown possibly non-finite -- multiples of w.  The LU needs no deflation.
+        const bool defl_was = S->defl_active;
+        S->defl_active = false;
+        const int rc_direct = bicgstab(ctx, S, g, 3, A, &MD, S->b, S->x, true, rtol, 50, w, st, ref, S->etol, 2);
+        S->defl_active = defl_was;
+        PL_TRY(rc_direct);
         st->iterations += it0;
         st->used_direct = 1;
     }

@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _lib
 from ._context import Context
-from .pylamp_const import (DIM, IZ, IX, NFTRAC, SECINYR, TR_RHO, TR_ETA, TR_TMP, TR_HCD, TR_HCP, TR_RH0, TR_ALP,
+from .pylamp_const import (DIM, IZ, IX, NFTRAC, SECINYR, TR_RHO, TR_ETA, TR_MRK, TR_TMP, TR_HCD, TR_HCP, TR_RH0, TR_ALP,
                            TR_MAT, TR_ACE, TR_ET0, TR_IHT, TR__ID)
 from . import pylamp_stokes, pylamp_diff
 
@@ -59,6 +59,35 @@ def falling_block_tracers(nx, L, tracdens, rng):
     tr_f[:, TR_RH0] = 3300; tr_f[:, TR_MAT] = 1; tr_f[:, TR_ET0] = 1e19
     idxb = (tr_x[:, IZ] > 200e3) & (tr_x[:, IZ] < 300e3) & (tr_x[:, IX] > 280e3) & (tr_x[:, IX] < 380e3)
     tr_f[idxb, TR_RH0] = 3350; tr_f[idxb, TR_MAT] = 2; tr_f[idxb, TR_ET0] = 1e22
+    return tr_x, tr_f
+
+
+def passive_markers(tr_x, L):
+    """The chequerboard of passive markers every model of the reference starts with (pylamp2.py:254-262): column TR_MRK."""
+    zd = np.linspace(0, L[IZ], 10); xd = np.linspace(0, L[IX], 10)
+    m = np.zeros(tr_x.shape[0])
+    for i in range(0, 9, 2):
+        m[(tr_x[:, IZ] >= zd[i]) & (tr_x[:, IZ] < zd[i + 1])] += 1
+    for i in range(1, 9, 2):
+        m[(tr_x[:, IZ] >= zd[i]) & (tr_x[:, IZ] < zd[i + 1])] += 2
+    for i in range(0, 9, 2):
+        m[(tr_x[:, IX] >= xd[i]) & (tr_x[:, IX] < xd[i + 1])] *= -1
+    return m
+
+
+def sphere_tracers(nx, L, tracdens, seed):
+    """Model 5 of the reference -- the configuration it ships with (pylamp2.py:37-39,225-242): a dense sphere (1470 against
+    1420 kg/m3) of viscosity 1e12 in a fluid of viscosity 1e2, centre (z, x) = (0.2, 0.1), radius 0.01, on the 1 x 0.2 domain
+    with 201 x 41 nodes and 45 markers per node; heat off, constant properties.  The positions are the reference's own draw after
+    np.random.seed(seed) (pylamp2.py:119): np.random.rand(ntrac, DIM) * L."""
+    n = int(np.prod(nx)) * tracdens
+    tr_x = np.random.RandomState(seed).rand(n, DIM) * np.array(L)
+    tr_f = np.zeros((n, NFTRAC))
+    tr_f[:, TR__ID] = np.arange(n)
+    tr_f[:, TR_RH0] = 1420; tr_f[:, TR_MAT] = 1; tr_f[:, TR_ET0] = 1e2
+    idx = (tr_x[:, IX] - 0.1) ** 2 + (tr_x[:, IZ] - 0.2) ** 2 < 0.01 ** 2
+    tr_f[idx, TR_RH0] = 1470; tr_f[idx, TR_MAT] = 2; tr_f[idx, TR_ET0] = 1e12
+    tr_f[:, TR_MRK] = passive_markers(tr_x, L)
     return tr_x, tr_f
 
 

@@ -89,3 +89,21 @@ print("NATIVE", nat.value)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "NATIVE 1" in r.stdout, (r.stdout + r.stderr)[-2000:]
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher (the way the driver runs the N = 1 line): the script starts its two ranks
+    itself before anything touches the GPU (they share the test GPU under gloo) and rank 0 prints "n_gpus": 2."""
+    import json
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    env["PYLAMP_BENCH_NO_4097"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--grid", "257",
+                        "--tracdens", "8", "--apply-reps", "5"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and all(c == 1 for c in out["stokes_converged"]), out
+    assert out["comm_calls_per_step"][3] == 0, out["comm_calls_per_step"]      # no host all-reduce inside the timed loop
