@@ -28,7 +28,7 @@
 
 typedef struct { char internal[128]; } pl_ncclUniqueId;
 typedef void* pl_ncclComm_t;
-enum { PL_NCCL_DOUBLE = 8, PL_NCCL_SUM = 0 };
+enum { PL_NCCL_DOUBLE = 8, PL_NCCL_SUM = 0, PL_NCCL_MAX = 2, PL_NCCL_MIN = 3 };       // ncclDataType_t / ncclRedOp_t values
 
 struct PlNccl {
     void* lib = nullptr;
@@ -236,23 +236,26 @@ int pl_allreduce_host(pl_ctx* ctx, double* buf, long long n, int op) {
     return rc;
 }
 
-// in-place sum all-reduce of n (<= 16) doubles in DEVICE memory: stream-ordered on the native transport, through the
-// host otherwise
-int pl_comm_allreduce_dev(pl_ctx* ctx, double* dev, int n) {
-    if (ctx->nranks <= 1) return 0;
+// in-place all-reduce of n doubles in DEVICE memory (op: 0 sum, 1 min, 2 max): stream-ordered on the native transport (the host
+// does not wait), staged through the host otherwise.  Counted as ONE device all-reduce on every transport.
+int pl_comm_allreduce_dev(pl_ctx* ctx, double* dev, int n, int op) {
+    if (ctx->nranks <= 1 || n <= 0) return 0;
     ctx->comm_calls[2]++;
     PlCommTimer tm_(ctx, 2);
     PlNccl* N = nccl_of(ctx);
     if (N && N->ok) {
-        if (N->AllReduce(dev, dev, (size_t)n, PL_NCCL_DOUBLE, PL_NCCL_SUM, N->comm, ctx->stream)) return pl_fail(ctx, "RCCL all-reduce failed");
+        const int nop = op == 0 ? PL_NCCL_SUM : (op == 1 ? PL_NCCL_MIN : PL_NCCL_MAX);
+        if (N->AllReduce(dev, dev, (size_t)n, PL_NCCL_DOUBLE, nop, N->comm, ctx->stream)) return pl_fail(ctx, "RCCL all-reduce failed");
         return 0;
     }
-    double h[16];
-    if (n > 16) return pl_fail(ctx, "pl_comm_allreduce_dev: at most 16 values");
+    double small[16];
+    std::vector<double> big;
+    double* h = small;
+    if (n > 16) { big.resize((size_t)n); h = big.data(); }
     PL_HIP(ctx, hipMemcpyAsync(h, dev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->comm_calls[3]--;                                        // counted as ONE (device) all-reduce
-    PL_TRY(pl_allreduce_host(ctx, h, n, 0));
+    PL_TRY(pl_allreduce_host(ctx, h, n, op));
     PL_HIP(ctx, hipMemcpyAsync(dev, h, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return 0;

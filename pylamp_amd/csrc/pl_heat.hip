@@ -61,11 +61,13 @@ __global__ __launch_bounds__(256) void k_heat_rhs(PlHeatOp op, const double* __r
 }
 
 // c = dt / (rho * Cp)
+// (computed on the block AND its halo ring, clipped at the domain boundary: rho and cp arrive with their halo filled, and the
+//  Chebyshev heat solver of several ranks sweeps on the block extended into the ring)
 __global__ __launch_bounds__(256) void k_heat_coef(PlGeom g, const double* __restrict__ rho,
                                                    const double* __restrict__ cp, double dt,
-                                                   double* __restrict__ c_out) {
-    const int lj = blockIdx.x * 64 + threadIdx.x, li = blockIdx.y * 4 + threadIdx.y;
-    if (lj >= g.lnx || li >= g.lnz) return;
+                                                   double* __restrict__ c_out, int r0, int r1, int c0, int c1) {
+    const int lj = c0 + blockIdx.x * 64 + threadIdx.x, li = r0 + blockIdx.y * 4 + threadIdx.y;
+    if (lj >= c1 || li >= r1) return;
     const long long c = pl_idx(g, li, lj);
     c_out[c] = dt / (rho[c] * cp[c]);
 }
@@ -83,7 +85,9 @@ void pl_launch_heat_rhs(pl_ctx* ctx, const PlHeatOp& op, const double* Told, con
 }
 
 void pl_launch_heat_coef(pl_ctx* ctx, const PlGeom& g, const double* rho, const double* cp, double dt, double* c) {
-    hipLaunchKernelGGL(k_heat_coef, grid2d(g), dim3(64, 4), 0, ctx->stream, g, rho, cp, dt, c);
+    const int r0 = -std::min(PL_RING, g.gi0), r1 = g.lnz + std::min(PL_RING, g.nz - (g.gi0 + g.lnz));
+    const int c0 = -std::min(PL_RING, g.gj0), c1 = g.lnx + std::min(PL_RING, g.nx - (g.gj0 + g.lnx));
+    hipLaunchKernelGGL(k_heat_coef, dim3((c1 - c0 + 63) / 64, (r1 - r0 + 3) / 4), dim3(64, 4), 0, ctx->stream, g, rho, cp, dt, c, r0, r1, c0, c1);
 }
 
 // midpoint tables 1/(zm[i]-zm[i-1]) (pylamp_diff.py:167-170), indexed global + 1

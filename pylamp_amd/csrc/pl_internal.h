@@ -77,6 +77,8 @@ struct pl_ctx {
     std::map<std::string, size_t> buf_bytes;
     // Stokes
     PlStokesOp sop{}; bool sop_ready = false;
+    double visc_contrast = 1.0;  // max / min of the viscosity fields of the current operator (pl_stokes_solve_device: beyond 1e6 the
+                                 // row-scaled residual alone no longer vouches for the solution, see there)
     // Heat
     PlHeatOp hop{}; bool hop_ready = false; double heat_bcvalue[4] = {0, 0, 0, 0};
     int mic_search = 0;          // host-API gathers locate cells by per-axis search (pl_mic_set_search)
@@ -209,7 +211,7 @@ int pl_comm_native_init(pl_ctx* ctx);
 void pl_local_detach(pl_ctx* ctx);
 void pl_comm_native_free(pl_ctx* ctx);
 int pl_comm_native_enabled(pl_ctx* ctx);
-int pl_comm_allreduce_dev(pl_ctx* ctx, double* dev, int n);
+int pl_comm_allreduce_dev(pl_ctx* ctx, double* dev, int n, int op = 0);       // op: 0 sum, 1 min, 2 max
 // event pair around a communication call on the context stream (kind 0 exchange, 1 all-gather, 2 device all-reduce); -1 when the pool is full
 int pl_comm_time_begin(pl_ctx* ctx, int kind);
 void pl_comm_time_end(pl_ctx* ctx, int slot);

@@ -897,6 +897,18 @@ __global__ __launch_bounds__(256) void k_stokes_scale_rows(PlStokesOp op, double
     v[c] *= sz; v[c + op.g.plane] *= sx; v[c + 2 * op.g.plane] *= sp;
 }
 
+// out_r = D_r^-1 (b - t), out_b = D_r^-1 b for scaled vectors b, t (out_b may alias t)
+__global__ __launch_bounds__(256) void k_stokes_unscaled_pair(PlStokesOp op, const double* __restrict__ b, const double* __restrict__ t,
+                                                              double* __restrict__ out_r, double* __restrict__ out_b) {
+    PL_NODE_PROLOGUE(op.g)
+    double sz, sx, sp;
+    stokes_row_scales(op, i, j, c, sz, sx, sp);
+    const long long P = op.g.plane;
+    const double b0 = b[c], b1 = b[c + P], b2 = b[c + 2 * P], t0 = t[c], t1 = t[c + P], t2 = t[c + 2 * P];
+    out_r[c] = (b0 - t0) / sz; out_r[c + P] = (b1 - t1) / sx; out_r[c + 2 * P] = (b2 - t2) / sp;
+    out_b[c] = b0 / sz; out_b[c + P] = b1 / sx; out_b[c + 2 * P] = b2 / sp;
+}
+
 // S^ solve of one pressure node from the SCALED residual rs (continuity rows only)
 __device__ inline double prec_p_cont(const PlStokesOp& op, const double* __restrict__ rs_p, int i, int j, long long c) {
     // unscale = Kc (1/dx + 1/dz);  S^-1 = eta_n / Kc^2   ->   rs * (1/dx + 1/dz) * eta_n / Kc
@@ -1193,6 +1205,7 @@ struct PlSolver {
     double cheb_ratio = 6.0, lmax_safety = 1.1;     // smoothing window [lmax/ratio, lmax]; lmax = safety * power-iteration estimate
     // heat work vectors (1 plane each)
     double* h[11] = {nullptr};
+    double* hc3 = nullptr;                    // several ranks: the three Chebyshev iterates of the heat solve, contiguous (one halo exchange)
     double* hc[9] = {nullptr}; double* hc_part = nullptr; int hc_nb = 0, hc_last_its = 0;      // CG work planes (wall entries of d, r, z, p, q stay 0)
     int napply = 0, nprec = 0;
     // Early coarse branch (single rank): the levels >= early_K get R^K f -- the right-hand side itself, restricted K
@@ -1267,6 +1280,7 @@ void pl_solver_free(pl_ctx* ctx) {
     for (double* q : S->h) if (q) (void)hipFree(q);
     for (double* q : S->hc) if (q) (void)hipFree(q);
     if (S->hc_part) (void)hipFree(S->hc_part);
+    if (S->hc3) (void)hipFree(S->hc3);
     if (S->hpart) (void)hipHostFree(S->hpart);
     if (S->stream2) (void)hipStreamDestroy(S->stream2);
     if (S->ev_f) (void)hipEventDestroy(S->ev_f);
@@ -1347,8 +1361,8 @@ static int dots(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const double*
     if (a && c) hipLaunchKernelGGL((k_dot2<true, true>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + PL_SCAL_N);
     else if (a) hipLaunchKernelGGL((k_dot2<true, false>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + PL_SCAL_N);
     else hipLaunchKernelGGL((k_dot2<false, true>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + PL_SCAL_N);
-    if (ctx->nranks > 1 && pl_geom_is_dist(g) && pl_comm_native_enabled(ctx)) {
-        // slab + native RCCL: reduce on the device, all-reduce 2 doubles over xGMI, one 16-byte copy back
+    if (ctx->nranks > 1 && pl_geom_is_dist(g)) {
+        // several ranks: reduce on the device, all-reduce 2 doubles (stream-ordered over xGMI on the native transport), one 16-byte copy back
         hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, nb, S->scal + PL_SCAL_N, S->scal);
         PL_TRY(pl_comm_allreduce_dev(ctx, S->scal, 2));
         PL_HIP(ctx, hipMemcpyAsync(S->hpart, S->scal, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1361,7 +1375,6 @@ static int dots(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const double*
     double s0 = 0.0, s1 = 0.0;
     for (int k = 0; k < nb; k++) { s0 += S->hpart[2 * k]; s1 += S->hpart[2 * k + 1]; }
     out2[0] = s0; out2[1] = s1;
-    if (ctx->nranks > 1 && pl_geom_is_dist(g)) PL_TRY(pl_allreduce_host(ctx, out2, 2, 0));
     return 0;
 }
 
@@ -3386,17 +3399,27 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
             hipLaunchKernelGGL(k_hydro_chunk_scan, dim3((g.lnx + 63) / 64), dim3(64), 0, ctx->stream, g, nch, ctot, coltot);
             hipLaunchKernelGGL(k_hydro_add, grid2d(g), dim3(64, 4), 0, ctx->stream, g, S->y, ctot);
         }
-        // prefix over the blocks above (same block column) + anchor value, through the host
+        // prefix over the blocks above (same block column) + anchor value: one table [Pz x NX column totals | anchor value] summed
+        // over the ranks on the device, read back once
         const int Pz = ctx->Pz, NX = g.nx;
         std::vector<double> hb((size_t)Pz * NX + 1, 0.0);
-        PL_HIP(ctx, hipMemcpyAsync(hb.data() + (size_t)ctx->pz * NX + g.gj0, coltot, (size_t)g.lnx * sizeof(double),
-                                   hipMemcpyDeviceToHost, ctx->stream));
         const bool own_anchor = sop.anchor_i >= g.gi0 && sop.anchor_i < g.gi0 + g.lnz && sop.anchor_j >= g.gj0 && sop.anchor_j < g.gj0 + g.lnx;
-        if (own_anchor)
+        if (ctx->nranks > 1) {
+            double* tab;
+            PL_TRY(pl_buf(ctx, "hydro_table", hb.size() * sizeof(double), &tab, false));
+            PL_HIP(ctx, hipMemsetAsync(tab, 0, hb.size() * sizeof(double), ctx->stream));
+            PL_HIP(ctx, hipMemcpyAsync(tab + (size_t)ctx->pz * NX + g.gj0, coltot, (size_t)g.lnx * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+            if (own_anchor)
+                PL_HIP(ctx, hipMemcpyAsync(tab + (size_t)Pz * NX, S->y + 2 * g.plane + pl_idx(g, sop.anchor_i - g.gi0, sop.anchor_j - g.gj0),
+                                           sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+            PL_TRY(pl_comm_allreduce_dev(ctx, tab, (int)hb.size(), 0));
+            PL_HIP(ctx, hipMemcpyAsync(hb.data(), tab, hb.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        } else {
+            PL_HIP(ctx, hipMemcpyAsync(hb.data() + g.gj0, coltot, (size_t)g.lnx * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
             PL_HIP(ctx, hipMemcpyAsync(&hb[(size_t)Pz * NX], S->y + 2 * g.plane + pl_idx(g, sop.anchor_i - g.gi0, sop.anchor_j - g.gj0),
                                        sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        }
         PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        PL_TRY(pl_allreduce_host(ctx, hb.data(), (long long)hb.size(), 0));
         std::vector<double> pre((size_t)g.lnx, 0.0);
         for (int q = 0; q < ctx->pz; q++) for (int jj = 0; jj < g.lnx; jj++) pre[jj] += hb[(size_t)q * NX + g.gj0 + jj];
         double pa = hb[(size_t)Pz * NX];
@@ -3425,7 +3448,33 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
     }
     hipLaunchKernelGGL(k_close_constraints, grid2d(g), dim3(64, 4), 0, ctx->stream, sop, S->levels[0]->op, S->b, S->x);
     if (trace_t) tph[3] = now();
-    PL_TRY(bicgstab(ctx, S, g, 3, A, &M, S->b, S->x, use_x0, rtol, maxit, w, st, ref, S->etol, 2));
+    // Viscosity contrast beyond the validated envelope (smooth variations over 1e3..1e6, jumps of 1e3): the row scaling divides a
+    // momentum row by its viscosity, so a residual that is small in the scaled norm can still be a large FORCE inside a stiff
+    // inclusion -- and what that force does to the velocities is decided by the WEAK fluid around it.  Measured on the reference's
+    // stock model 5 (sphere 1e12 in 1e2, 201 x 41): scaled residual 7e-11, velocity error 4e-3, estimate 5e-9; the unscaled residual
+    // ||b - A x|| / ||b|| is 1.4e-5 there against 1e-8 for the reference's direct solve (tools/model5_probe.py).  Hence, beyond
+    // PYLAMP_CONTRAST_GATE (1e6): where the banded LU fits it solves UP FRONT (error 4e-7 against the refined direct solution);
+    // elsewhere the iteration runs and the solve counts as converged only if the UNSCALED residual meets the tolerance too.
+    static const double contrast_gate = getenv("PYLAMP_CONTRAST_GATE") ? atof(getenv("PYLAMP_CONTRAST_GATE")) : 1e6;
+    const bool beyond = contrast_gate > 0.0 && ctx->visc_contrast > contrast_gate;
+    // PYLAMP_FORCE_DIRECT=1 (experiments): skip the multigrid-preconditioned iteration where the banded LU fits
+    const bool force_direct = ((getenv("PYLAMP_FORCE_DIRECT") && atoi(getenv("PYLAMP_FORCE_DIRECT")) != 0) || beyond) && pl_direct_possible(ctx) &&
+                              !getenv("PYLAMP_NO_DIRECT");
+    if (force_direct) { st->iterations = 0; st->converged = 0; st->reserved_ = 0; st->rel_residual = 1.0; st->error_estimate = 0.0; }
+    else PL_TRY(bicgstab(ctx, S, g, 3, A, &M, S->b, S->x, use_x0, rtol, maxit, w, st, ref, S->etol, 2));
+    if (beyond && !force_direct && st->converged) {
+        // unscaled residual of the accepted iterate: D_r^-1 (b_s - A_s x) against D_r^-1 b_s
+        double du[2];
+        PL_TRY(A(S->x, S->t));
+        hipLaunchKernelGGL(k_stokes_unscaled_pair, grid2d(g), dim3(64, 4), 0, ctx->stream, sop, (const double*)S->b, (const double*)S->t, S->s, S->t);
+        PL_TRY(dots(ctx, S, g, 3, S->s, S->s, S->t, S->t, du));
+        const double rel_u = du[1] > 0.0 ? std::sqrt(du[0] / du[1]) : 0.0;
+        if (trace_t) fprintf(stderr, "[pylamp stokes] viscosity contrast %.1e beyond the gate: unscaled relative residual %.3e\n", ctx->visc_contrast, rel_u);
+        if (!(rel_u <= std::max(rtol, 1e-7))) {
+            st->converged = 0;
+            st->error_estimate = std::max(st->error_estimate, rel_u);      // (no bound is known: at least this)
+        }
+    }
     if (trace_t) {
         tph[4] = now();
         fprintf(stderr, "[pylamp stokes] phases: hierarchy + eigenvalues %.2f ms, deflation vector %.2f ms, hydrostatic state + reference norm %.2f ms, "
@@ -3621,20 +3670,29 @@ __global__ __launch_bounds__(256) void k_heat_close_walls(PlHeatOp op, double bz
     const PlGeom& g = op.g;
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int p = g.pitch;
+    // (every wall node is closed by the rank that owns it; its inner neighbour lies in the same block: blocks hold >= 2 rows / columns)
     if (pass == 0) {
         if (t >= 2 * (g.nz - 2)) return;
-        const int i = 1 + t % (g.nz - 2), right = t / (g.nz - 2);
-        const long long c = pl_idx(g, i, right ? g.nx - 1 : 0);
+        const int i = 1 + t % (g.nz - 2), right = t / (g.nz - 2), j = right ? g.nx - 1 : 0;
+        if (i < g.gi0 || i >= g.gi0 + g.lnz || j < g.gj0 || j >= g.gj0 + g.lnx) return;
+        const long long c = pl_idx(g, i - g.gi0, j - g.gj0);
         if (!right) x[c] = (op.bc[1] == PL_BC_FIXTEMP) ? bx0 : x[c + 1] - bx0 / (op.kx[c] * TB(g.rdx, 0));
         else x[c] = (op.bc[3] == PL_BC_FIXTEMP) ? bxL : x[c - 1] + bxL / (op.kx[c - 1] * TB(g.rdx, g.nx - 2));
     } else {
         if (t >= 2 * g.nx) return;
-        const int j = t % g.nx, bottom = t / g.nx;
-        const long long c = pl_idx(g, bottom ? g.nz - 1 : 0, j);
+        const int j = t % g.nx, bottom = t / g.nx, i = bottom ? g.nz - 1 : 0;
+        if (i < g.gi0 || i >= g.gi0 + g.lnz || j < g.gj0 || j >= g.gj0 + g.lnx) return;
+        const long long c = pl_idx(g, i - g.gi0, j - g.gj0);
         if (!bottom) x[c] = (op.bc[0] == PL_BC_FIXTEMP) ? bz0 : x[c + p] - bz0 / (op.kz[c] * TB(g.rdz, 0));
         else x[c] = (op.bc[2] == PL_BC_FIXTEMP) ? bzL : x[c - p] + bzL / (op.kz[c - p] * TB(g.rdz, g.nz - 2));
     }
 }
+// the (possibly extended) block a heat kernel runs on and the owned nodes whose contributions enter the sums
+struct HeatOwn { int i0, i1, j0, j1; };                 // global node range [i0, i1) x [j0, j1) this rank owns
+#define PL_HEAT_NODE(g)                                                                             \
+    const int lj = blockIdx.x * 64 + threadIdx.x, li = blockIdx.y * 4 + threadIdx.y;                \
+    const int i = (g).gi0 + li, j = (g).gj0 + lj;                                                    \
+    const bool in_blk = lj < (g).lnx && li < (g).lnz;
 __device__ inline void heat_block_sum3(double a0, double a1, double a2, double* __restrict__ part) {
     __shared__ double sh[3][4];
 #pragma unroll
@@ -3653,12 +3711,12 @@ __device__ inline void heat_block_sum3(double a0, double a1, double a2, double* 
 // mode 1 (check): r = S (b - A x) only; partials: (r dinv)^2 in slot 1
 __global__ __launch_bounds__(256) void k_heat_cg_residual(PlHeatOp op, const double* __restrict__ b, const double* __restrict__ x, double* __restrict__ r,
                                                           double* __restrict__ dinv, double* __restrict__ z, double* __restrict__ pdir, double* __restrict__ d,
-                                                          int mode, double* __restrict__ part) {
+                                                          int mode, double* __restrict__ part, HeatOwn own) {
     const PlGeom& g = op.g;
-    const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
+    PL_HEAT_NODE(g)
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    if (i >= 1 && i <= g.nz - 2 && j >= 1 && j <= g.nx - 2) {
-        const long long c = pl_idx(g, i, j);
+    if (in_blk && i >= 1 && i <= g.nz - 2 && j >= 1 && j <= g.nx - 2) {
+        const long long c = pl_idx(g, li, lj);
         const int p = g.pitch;
         const double dzb = 1.0 / TB(op.rdzb, i), dxb = 1.0 / TB(op.rdxb, j), t = x[c];
         const double wE = op.kx[c] * TB(g.rdx, j) * dzb, wW = op.kx[c - 1] * TB(g.rdx, j - 1) * dzb;
@@ -3670,8 +3728,9 @@ __global__ __launch_bounds__(256) void k_heat_cg_residual(PlHeatOp op, const dou
         const double di = 1.0 / (h.w[0] + h.w[1] + h.w[2] + h.w[3] + h.m);
         r[c] = res;
         const double zz = res * di;
-        if (mode == 0) { dinv[c] = di; z[c] = zz; pdir[c] = zz; d[c] = 0.0; s0 = res * zz; s1 = zz * zz; s2 = (Sb * di) * (Sb * di); }
-        else { s0 = res * zz; s1 = zz * zz; }
+        const bool mine = i >= own.i0 && i < own.i1 && j >= own.j0 && j < own.j1;
+        if (mode == 0) { dinv[c] = di; z[c] = zz; pdir[c] = zz; d[c] = 0.0; if (mine) { s0 = res * zz; s1 = zz * zz; s2 = (Sb * di) * (Sb * di); } }
+        else if (mine) { s0 = res * zz; s1 = zz * zz; }
     }
     heat_block_sum3(s0, s1, s2, part);
 }
@@ -3743,10 +3802,10 @@ __global__ __launch_bounds__(1024) void k_heat_cg_scalars(int nb, const double* 
 // operator -- the Gershgorin radius rho of D^-1 A_red, whose eigenvalues lie in [1 - rho, 1 + rho] (Chebyshev iteration below)
 __global__ __launch_bounds__(256) void k_heat_mass_norm(PlHeatOp op, const double* __restrict__ x, double* __restrict__ part) {
     const PlGeom& g = op.g;
-    const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
+    PL_HEAT_NODE(g)
     double s0 = 0.0, rad = 0.0;
-    if (i >= 1 && i <= g.nz - 2 && j >= 1 && j <= g.nx - 2) {
-        const long long c = pl_idx(g, i, j);
+    if (in_blk && i >= 1 && i <= g.nz - 2 && j >= 1 && j <= g.nx - 2) {
+        const long long c = pl_idx(g, li, lj);
         s0 = x[c] * x[c] / (TB(op.rdzb, i) * TB(op.rdxb, j) * op.rhocp_inv_dt[c]);
         const HeatRed h = heat_red(op, i, j, c);
         const double off = h.w[0] + h.w[1] + h.w[2] + h.w[3];
@@ -3761,12 +3820,14 @@ __global__ __launch_bounds__(256) void k_heat_mass_norm(PlHeatOp op, const doubl
 }
 // One Chebyshev sweep on the correction system  A_red d = r0  with the diagonal as preconditioner (three-term form, as the multigrid smoother):
 //     d_next = d + c1 (d - d_prev) + c2 dinv (r0 - A_red d)        -- no reduction, one launch per sweep
+// Several ranks: launched on the block EXTENDED into the halo (op.g is the extended view, every pointer shifted accordingly), one
+// node less per sweep, so that a round of sweeps needs ONE exchange (deep halo, as the multigrid smoother's)
 __global__ __launch_bounds__(256) void k_heat_cheb(PlHeatOp op, const double* __restrict__ dcur, const double* __restrict__ dprev, const double* __restrict__ r0,
                                                    const double* __restrict__ dinv, double* __restrict__ dnext, double c1, double c2) {
     const PlGeom& g = op.g;
-    const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
-    if (!(i >= 1 && i <= g.nz - 2 && j >= 1 && j <= g.nx - 2)) return;
-    const long long c = pl_idx(g, i, j);
+    PL_HEAT_NODE(g)
+    if (!(in_blk && i >= 1 && i <= g.nz - 2 && j >= 1 && j <= g.nx - 2)) return;
+    const long long c = pl_idx(g, li, lj);
     const int p = g.pitch;
     const HeatRed h = heat_red(op, i, j, c);
     const double dc = dcur[c];
@@ -3776,17 +3837,40 @@ __global__ __launch_bounds__(256) void k_heat_cheb(PlHeatOp op, const double* __
     dnext[c] = dc + (c1 != 0.0 ? c1 * (dc - dprev[c]) : 0.0) + c2 * di * (r0[c] - Ad);      // wall entries stay 0
 }
 
+// extended view of the heat operator: the block grown by e nodes into the halo (clipped at the domain walls); sh = element offset
+// of the view's local node (0,0) before the block's: every plane pointer handed to a kernel is shifted back by it
+struct HeatExt { PlHeatOp op; long long sh; };
+static HeatExt heat_ext(pl_ctx* ctx, const PlHeatOp& hop, int e) {
+    HeatExt v; v.op = hop; v.sh = 0;
+    if (e <= 0 || ctx->nranks <= 1) return v;
+    const PlGeom& g = hop.g;
+    const int a = std::min(e, g.gi0), b = std::min(e, g.nz - (g.gi0 + g.lnz)), c = std::min(e, g.gj0), d = std::min(e, g.nx - (g.gj0 + g.lnx));
+    v.op.g.gi0 -= a; v.op.g.lnz += a + b; v.op.g.gj0 -= c; v.op.g.lnx += c + d;
+    v.sh = (long long)a * g.pitch + c;
+    v.op.kz -= v.sh; v.op.kx -= v.sh; v.op.rhocp_inv_dt -= v.sh;
+    return v;
+}
+
+// CG / Chebyshev on the symmetrised heat system.  Several ranks (Chebyshev only): the sweeps need NO reduction; a round of up to
+// PL_RING - 1 sweeps runs on the block extended into the halo (one node less per sweep) after ONE exchange of the iterates, so a
+// solve costs ~5 halo exchanges and 4 small all-reduces (Gershgorin radius, mass norm, and the residual norms of its two passes)
+// where the BiCGStab path took 17 exchanges and 16 all-reduces.
 static int heat_solve_cg(pl_ctx* ctx, PlSolver* S, const double* b_dev, double rtol, int maxit, pl_solve_stats* st, double** x_out,
-                         const double* x0_dev) {
+                         const double* x0_dev, bool* unsuited) {
     const PlGeom& g = ctx->geom.d;
     const size_t pb = (size_t)g.plane * sizeof(double);
+    const bool multi = ctx->nranks > 1;
     for (int k = 0; k < 9; k++) if (!S->hc[k]) PL_TRY(dmalloc0(ctx, &S->hc[k], pb));
+    if (multi && !S->hc3) PL_TRY(dmalloc0(ctx, &S->hc3, 3 * pb));            // the three Chebyshev iterates as ONE allocation: one exchange for all
     if (!S->scal) {
         PL_TRY(dmalloc0(ctx, &S->scal, (PL_SCAL_N + 8 * DOT_BLOCKS) * sizeof(double)));
         PL_HIP(ctx, hipHostMalloc((void**)&S->hpart, (8 * DOT_BLOCKS + PL_SCAL_N) * sizeof(double)));
     }
-    const dim3 gr = grid2d(g), bl(64, 4);
-    const int nb = (int)(gr.x * gr.y);
+    // deepest extension a kernel of this solve runs on: it reads the coefficient planes one node further (ring PL_RING deep)
+    const int E = multi ? std::min(PL_RING - 1, std::min(g.lnz, g.lnx)) : 0;
+    const HeatExt X = heat_ext(ctx, ctx->hop, E > 0 ? E - 1 : 0);             // residual / first sweep: extended by E - 1
+    const dim3 grX = grid2d(X.op.g), gr = grid2d(g), bl(64, 4);
+    const int nb = (int)(grX.x * grX.y);
     if (!S->hc_part || S->hc_nb < nb) {
         if (S->hc_part) (void)hipFree(S->hc_part);
         PL_TRY(dmalloc0(ctx, &S->hc_part, (size_t)3 * nb * sizeof(double)));
@@ -3794,7 +3878,9 @@ static int heat_solve_cg(pl_ctx* ctx, PlSolver* S, const double* b_dev, double r
     }
     PL_TRY(pl_timer_start(ctx));
     const PlHeatOp hop = ctx->hop;
+    const HeatOwn own{g.gi0, g.gi0 + g.lnz, g.gj0, g.gj0 + g.lnx};
     double *x = S->hc[0], *d = S->hc[1], *r = S->hc[2], *z = S->hc[3], *q = S->hc[4], *dinv = S->hc[5], *pa = S->hc[6], *pbuf = S->hc[7];
+    if (multi) { d = S->hc3; pa = S->hc3 + g.plane; pbuf = S->hc3 + 2 * g.plane; }
     double* sc = S->scal; double* hs = S->hpart;
     if (x0_dev) PL_HIP(ctx, hipMemcpyAsync(x, x0_dev, pb, hipMemcpyDeviceToDevice, ctx->stream));
     else PL_HIP(ctx, hipMemsetAsync(x, 0, pb, ctx->stream));
@@ -3810,7 +3896,8 @@ static int heat_solve_cg(pl_ctx* ctx, PlSolver* S, const double* b_dev, double r
     };
     close_walls(x);
     hipLaunchKernelGGL(k_heat_mass_norm, gr, bl, 0, ctx->stream, hop, (const double*)x, S->hc_part);
-    hipLaunchKernelGGL(k_heat_cg_scalars, dim3(1), dim3(1024), 0, ctx->stream, nb, (const double*)S->hc_part, sc, 4);     // -> sc[4], sc[7]
+    hipLaunchKernelGGL(k_heat_cg_scalars, dim3(1), dim3(1024), 0, ctx->stream, (int)(gr.x * gr.y), (const double*)S->hc_part, sc, 4);     // -> sc[4], sc[7]
+    if (multi) { PL_TRY(pl_comm_allreduce_dev(ctx, sc + 4, 1, 0)); PL_TRY(pl_comm_allreduce_dev(ctx, sc + 7, 1, 2)); }
     PL_TRY(fetch());
     const double xmass = hs[4];
     // Chebyshev iteration instead of CG where its sweep count is known to be small: the eigenvalues of D^-1 A_red lie in
@@ -3820,13 +3907,27 @@ static int heat_solve_cg(pl_ctx* ctx, PlSolver* S, const double* b_dev, double r
     const double rho_g = hs[7];
     const int cheb_env = getenv("PYLAMP_HEAT_CHEB") ? atoi(getenv("PYLAMP_HEAT_CHEB")) : 1;         // (read per solve: tests switch it)
     const bool cheb_ok = cheb_env != 0 && rho_g > 0.0 && rho_g < 0.97 && std::isfinite(rho_g);
+    if (unsuited) *unsuited = false;
+    if (multi && !cheb_ok) {                              // (rho is the same on every rank: a collective decision) -- the caller runs BiCGStab
+        if (unsuited) *unsuited = true;
+        double ms0 = 0; PL_TRY(pl_timer_stop_ms(ctx, &ms0));
+        return 0;
+    }
     st->iterations = 0; st->converged = 0; st->rel_residual = 0.0; st->error_estimate = 0.0;
     S->napply = 0;
     double ref = 0.0, hist[4] = {0, 0, 0, 0};
     int it = 0;
+    if (multi && E > 0) PL_TRY(pl_halo(ctx, g, (double*)b_dev, 1, g.plane, E));            // the right-hand side, once
     for (int pass = 0; pass < 5; pass++) {               // (re)start from the true residual of the current x = x0 + d (the last pass only checks)
-        hipLaunchKernelGGL(k_heat_cg_residual, gr, bl, 0, ctx->stream, hop, b_dev, (const double*)x, r, dinv, z, pa, d, 0, S->hc_part);
+        if (multi && E > 0) {
+            PL_TRY(pl_halo(ctx, g, x, 1, g.plane, E));                                     // x with closed walls, E deep: residual on the block + (E - 1)
+            PL_HIP(ctx, hipMemsetAsync(d, 0, pb, ctx->stream));                            // the zero correction, also beyond the region the start kernel writes
+        }
+        hipLaunchKernelGGL(k_heat_cg_residual, grX, bl, 0, ctx->stream, X.op, b_dev - X.sh, (const double*)(x - X.sh), r - X.sh, dinv - X.sh, z - X.sh, pa - X.sh,
+                           d - X.sh, 0, S->hc_part, own);
         hipLaunchKernelGGL(k_heat_cg_scalars, dim3(1), dim3(1024), 0, ctx->stream, nb, (const double*)S->hc_part, sc, 0);
+        if (multi) { PL_HIP(ctx, hipMemcpyAsync(sc + 2, sc + 5, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream)); PL_TRY(pl_comm_allreduce_dev(ctx, sc, 3, 0));
+                     PL_HIP(ctx, hipMemcpyAsync(sc + 5, sc + 2, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream)); }
         S->napply++;
         PL_TRY(fetch());
         if (pass == 0) ref = std::sqrt(hs[5]);
@@ -3845,13 +3946,20 @@ static int heat_solve_cg(pl_ctx* ctx, PlSolver* S, const double* b_dev, double r
             const double theta = 1.0, delta = rho_g;
             double rho_old = 1.0 / sigma;
             double* bufs[3] = {d, pa, pbuf};                      // (cur, prev, free); d = 0 from the start kernel
+            int ext = E - 1;                                      // extension of the NEXT sweep (several ranks); r0 and d = 0 are valid that far
             for (int k = 0; k < ks; k++) {
                 double c1, c2;
                 if (k == 0) { c1 = 0.0; c2 = 1.0 / theta; }
                 else { const double rr = 1.0 / (2.0 * sigma - rho_old); c1 = rr * rho_old; c2 = 2.0 * rr / delta; rho_old = rr; }
-                hipLaunchKernelGGL(k_heat_cheb, gr, bl, 0, ctx->stream, hop, (const double*)bufs[0], (const double*)bufs[1], (const double*)r, (const double*)dinv,
-                                   bufs[2], c1, c2);
+                if (multi && ext < 0) {                           // the halo of the iterates is used up: ONE exchange of all three buffers
+                    PL_TRY(pl_halo(ctx, g, S->hc3, 3, g.plane, E));
+                    ext = E - 1;
+                }
+                const HeatExt V = heat_ext(ctx, hop, multi ? ext : 0);
+                hipLaunchKernelGGL(k_heat_cheb, grid2d(V.op.g), bl, 0, ctx->stream, V.op, (const double*)(bufs[0] - V.sh), (const double*)(bufs[1] - V.sh),
+                                   (const double*)(r - V.sh), (const double*)(dinv - V.sh), bufs[2] - V.sh, c1, c2);
                 double* nx = bufs[2]; bufs[2] = bufs[1]; bufs[1] = bufs[0]; bufs[0] = nx;
+                ext--;
                 S->napply++;
             }
             it += ks;
@@ -3899,7 +4007,11 @@ int pl_heat_solve_device(pl_ctx* ctx, const double* b_dev, double rtol, int maxi
     PlSolver* S = solver_of(ctx);
     // one rank: CG on the symmetrised system (PYLAMP_HEAT_CG=0: the Jacobi-scaled BiCGStab below, which several ranks still use)
     static const bool use_cg = !(getenv("PYLAMP_HEAT_CG") && atoi(getenv("PYLAMP_HEAT_CG")) == 0);
-    if (use_cg && ctx->nranks == 1 && ctx->nz >= 3 && ctx->nx >= 3) return heat_solve_cg(ctx, S, b_dev, rtol, maxit, st, x_out, x0_dev);
+    if (use_cg && ctx->nz >= 3 && ctx->nx >= 3 && (ctx->nranks == 1 || std::min(ctx->geom.d.lnz, ctx->geom.d.lnx) >= 2)) {
+        bool unsuited = false;
+        PL_TRY(heat_solve_cg(ctx, S, b_dev, rtol, maxit, st, x_out, x0_dev, &unsuited));
+        if (!unsuited) return 0;             // (several ranks and a Gershgorin radius >= 0.97: the Jacobi-scaled BiCGStab below)
+    }
     const PlGeom& g = ctx->geom.d;
     size_t pb = (size_t)g.plane * sizeof(double);
     for (int k = 0; k < 11; k++) if (!S->h[k]) PL_TRY(dmalloc0(ctx, &S->h[k], pb));

@@ -53,6 +53,9 @@ struct PlStepState {
     // the tracers [0, lazy_n) are still in PRE-sort order in f2[RHO], f2[ETA], tmp[0], tmp[1]; dest maps them (flush_lazy).
     bool lazy_pending = false, lazy_inject = false; long long lazy_n = 0;
     std::vector<double> gmz, gmx;                    // midpoint grids (pylamp2.py:92-95)
+    // several ranks: error counters of the marker stages of a step ([0] tracers outside the grid in grid2trac, [1] RK4 stages that
+    // left the rank's velocity window) and the count tables of the sort, reduced over the ranks ON THE DEVICE (pl_comm_allreduce_dev)
+    double* flags = nullptr; double* counts_dev = nullptr; int counts_cap = 0;
 };
 
 static PlStepState* state_of(pl_ctx* ctx) {
@@ -67,6 +70,7 @@ void pl_step_free(pl_ctx* ctx) {
         if (q) (void)hipFree(q);
     for (double* q : s->f) if (q) (void)hipFree(q);
     for (double* q : s->f2) if (q) (void)hipFree(q);
+    for (double* q : {s->flags, s->counts_dev}) if (q) (void)hipFree(q);
     for (int* q : {s->slot, s->slot2, s->cell, s->dest, s->orig, s->orig2, s->cell_count, s->cell_start, s->block_sums, s->need, s->need_off, s->need_flag, s->need_rank, s->cell_res}) if (q) (void)hipFree(q);
     delete s;
     ctx->step = nullptr;
@@ -426,27 +430,57 @@ __global__ __launch_bounds__(256) void k_subgrid_part2(long long n, double* __re
     T[t] = Tsub[t] - back[t];
 }
 
+__global__ void k_flag_from_u64(const unsigned long long* __restrict__ src, double* __restrict__ dst) { *dst = (double)*src; }
+// dst[first + k] = src[k + 1] - src[k] (sort buckets -> this rank's slots of a count table), or the ints themselves (diff = 0)
+__global__ void k_counts_from_ints(int n, const int* __restrict__ src, int diff, double* __restrict__ dst, int first) {
+    const int k = threadIdx.x;
+    if (k < n) dst[first + k] = diff ? (double)(src[k + 1] - src[k]) : (double)src[k];
+}
+static int step_flags(pl_ctx* ctx, PlStepState* S) {
+    if (!S->flags) { PL_HIP(ctx, hipMalloc((void**)&S->flags, 8 * sizeof(double))); PL_HIP(ctx, hipMemsetAsync(S->flags, 0, 8 * sizeof(double), ctx->stream)); }
+    return 0;
+}
+// zeroed table of n doubles on the device for a sum over the ranks
+static int step_counts(pl_ctx* ctx, PlStepState* S, int n) {
+    if (S->counts_cap < n) {
+        if (S->counts_dev) (void)hipFree(S->counts_dev);
+        PL_HIP(ctx, hipMalloc((void**)&S->counts_dev, (size_t)n * sizeof(double)));
+        S->counts_cap = n;
+    }
+    PL_HIP(ctx, hipMemsetAsync(S->counts_dev, 0, (size_t)n * sizeof(double), ctx->stream));
+    return 0;
+}
+
 // ---- helpers ---------------------------------------------------------------------------------
-static int reduce_minmax(pl_ctx* ctx, PlStepState* S, const PlGeom& g, const double* a, const double* b, const double* c,
-                         int mode, double* mn, double* mx, bool* has_nan) {
+// min / max / NaN flag of up to 4 planes in ONE host round trip and -- several ranks -- ONE device all-reduce (max) of 3 nq
+// values (min as -max(-x)): the reference's global np.min / np.max (pylamp_stokes.py:116-118, pylamp2.py:340-341,364).
+struct MinMaxSpec { const double* a; const double* b; const double* c; int mode; };
+struct MinMaxOut { double mn, mx; bool has_nan; };
+__global__ void k_minmax_negate(int nq, double* __restrict__ out) { if ((int)threadIdx.x < nq) out[3 * threadIdx.x] = -out[3 * threadIdx.x]; }
+static int reduce_minmax_multi(pl_ctx* ctx, PlStepState* S, const PlGeom& g, int nq, const MinMaxSpec* spec, MinMaxOut* res) {
     dim3 gr = grid2d(g);
-    size_t nb = (size_t)gr.x * gr.y;
-    if (!S->partial || S->hpartial.size() < 3 * (nb + 1)) {
+    const size_t nb = (size_t)gr.x * gr.y;
+    if (nq < 1 || nq > 4) return pl_fail(ctx, "reduce_minmax_multi: 1..4 planes");
+    if (!S->partial || S->hpartial.size() < 3 * (nb + 4)) {
         if (S->partial) (void)hipFree(S->partial);
-        PL_HIP(ctx, hipMalloc((void**)&S->partial, 3 * (nb + 1) * sizeof(double)));
-        S->hpartial.resize(3 * (nb + 1));
+        PL_HIP(ctx, hipMalloc((void**)&S->partial, 3 * (nb + 4) * sizeof(double)));
+        S->hpartial.resize(3 * (nb + 4));
     }
-    hipLaunchKernelGGL(k_minmax, gr, dim3(64, 4), 0, ctx->stream, g, a, b, c, mode, S->partial);
-    hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(1024), 0, ctx->stream, (int)nb, (const double*)S->partial, S->partial + 3 * nb);
-    PL_HIP(ctx, hipMemcpyAsync(S->hpartial.data(), S->partial + 3 * nb, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    double m0 = S->hpartial[0], m1 = S->hpartial[1]; bool nf = S->hpartial[2] > 0;
+    double* out = S->partial + 3 * nb;
+    for (int q = 0; q < nq; q++) {
+        hipLaunchKernelGGL(k_minmax, gr, dim3(64, 4), 0, ctx->stream, g, spec[q].a, spec[q].b, spec[q].c, spec[q].mode, S->partial);
+        hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(1024), 0, ctx->stream, (int)nb, (const double*)S->partial, out + 3 * q);
+    }
     if (ctx->nranks > 1) {
-        double v[3] = {-m0, m1, nf ? 1.0 : 0.0};                   // ONE max-reduction: min = -max(-x)
-        PL_TRY(pl_allreduce_host(ctx, v, 3, 2));
-        m0 = -v[0]; m1 = v[1]; nf = v[2] > 0.0;
+        hipLaunchKernelGGL(k_minmax_negate, dim3(1), dim3(64), 0, ctx->stream, nq, out);
+        PL_TRY(pl_comm_allreduce_dev(ctx, out, 3 * nq, 2));
     }
-    *mn = m0; *mx = m1; *has_nan = nf;
+    PL_HIP(ctx, hipMemcpyAsync(S->hpartial.data(), out, (size_t)3 * nq * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int q = 0; q < nq; q++) {
+        res[q].mn = ctx->nranks > 1 ? -S->hpartial[3 * q] : S->hpartial[3 * q];
+        res[q].mx = S->hpartial[3 * q + 1]; res[q].has_nan = S->hpartial[3 * q + 2] > 0.0;
+    }
     return 0;
 }
 
@@ -865,7 +899,14 @@ static int sort_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, doubl
         const int R = ctx->nranks;
         std::vector<double> cnt((size_t)2 * R, 0.0);
         cnt[2 * ctx->rank] = (double)ninj; cnt[2 * ctx->rank + 1] = ndef;
-        PL_TRY(pl_allreduce_host(ctx, cnt.data(), (long long)cnt.size(), 0));
+        if (R > 1) {                                              // every rank's (new tracers, refilled cells): summed on the device
+            PL_TRY(step_counts(ctx, S, 2 * R));
+            hipLaunchKernelGGL(k_counts_from_ints, dim3(1), dim3(64), 0, ctx->stream, 1, (const int*)(S->need_off + nc), 0, S->counts_dev, 2 * ctx->rank);
+            hipLaunchKernelGGL(k_counts_from_ints, dim3(1), dim3(64), 0, ctx->stream, 1, (const int*)(S->need_rank + nc), 0, S->counts_dev, 2 * ctx->rank + 1);
+            PL_TRY(pl_comm_allreduce_dev(ctx, S->counts_dev, 2 * R, 0));
+            PL_HIP(ctx, hipMemcpyAsync(cnt.data(), S->counts_dev, cnt.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
         double before = 0.0, total = 0.0, def_before = 0.0, def_total = 0.0;
         for (int q = 0; q < R; q++) {
             if (q < ctx->rank) { before += cnt[2 * q]; def_before += cnt[2 * q + 1]; }
@@ -996,8 +1037,11 @@ static int migrate_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, do
     const long long stay = h[0];
     // who sends how many to whom: slot [r*8 + k] = tracers rank r sends towards direction k
     std::vector<double> cnt((size_t)8 * R, 0.0);
-    for (int k = 0; k < 8; k++) cnt[(size_t)8 * ctx->rank + k] = (double)(h[k + 1] - h[k]);
-    PL_TRY(pl_allreduce_host(ctx, cnt.data(), (long long)cnt.size(), 0));
+    PL_TRY(step_counts(ctx, S, 8 * R));
+    hipLaunchKernelGGL(k_counts_from_ints, dim3(1), dim3(64), 0, ctx->stream, 8, (const int*)(S->cell_start + nc), 1, S->counts_dev, 8 * ctx->rank);
+    PL_TRY(pl_comm_allreduce_dev(ctx, S->counts_dev, 8 * R, 0));
+    PL_HIP(ctx, hipMemcpyAsync(cnt.data(), S->counts_dev, cnt.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     int peer[8]; long long nsend[8], nrecv[8], roff[8]; long long incoming = 0;
     for (int k = 0; k < 8; k++) {
         const int qz = ctx->pz + DZ[k], qx = ctx->px + DX[k];
@@ -1246,10 +1290,14 @@ static int stage_temp_to_tracers(pl_ctx* ctx, PlStepState* S, const pl_step_conf
         }
         ga.epi = 0;
     }
+    if (ctx->nranks > 1) {          // several ranks: the count joins the RK4 stage's in ONE reduction over the ranks (stage_rk4)
+        PL_TRY(step_flags(ctx, S));
+        hipLaunchKernelGGL(k_flag_from_u64, dim3(1), dim3(1), 0, ctx->stream, (const unsigned long long*)cnt, S->flags);
+        return 0;
+    }
     unsigned long long nout = 0;
     PL_HIP(ctx, hipMemcpyAsync(&nout, cnt, sizeof(nout), hipMemcpyDeviceToHost, ctx->stream));
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    { double v[1] = {(double)nout}; PL_TRY(pl_allreduce_host(ctx, v, 1, 0)); nout = (unsigned long long)v[0]; }
     if (nout > 0) return pl_fail(ctx, "stopOnError in grid2trac");        // pylamp2.py:445,453 stopOnError=True
     return 0;
 }
@@ -1303,11 +1351,15 @@ static int stage_rk4(pl_ctx* ctx, PlStepState* S, const double* V, int I0, int I
     std::swap(S->tz, S->tz2); std::swap(S->tx, S->tx2);
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->nranks > 1) {      // collective: a stage that left the local velocity window means the step was not CFL-limited
-        unsigned long long no = 0;
-        PL_HIP(ctx, hipMemcpy(&no, oowc, sizeof(no), hipMemcpyDeviceToHost));
-        double v[1] = {(double)no};
-        PL_TRY(pl_allreduce_host(ctx, v, 1, 0));
-        if (v[0] > 0) return pl_fail(ctx, "pl_step: a tracer moved by more than one cell in an RK4 stage (time step not CFL-limited); the "
+        PL_TRY(step_flags(ctx, S));
+        hipLaunchKernelGGL(k_flag_from_u64, dim3(1), dim3(1), 0, ctx->stream, (const unsigned long long*)oowc, S->flags + 1);
+        PL_TRY(pl_comm_allreduce_dev(ctx, S->flags, 2, 0));      // [0]: grid2trac's count of this step (stage_temp_to_tracers)
+        double v[2] = {0.0, 0.0};
+        PL_HIP(ctx, hipMemcpyAsync(v, S->flags, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        PL_HIP(ctx, hipMemsetAsync(S->flags, 0, 2 * sizeof(double), ctx->stream));
+        PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (v[0] > 0) return pl_fail(ctx, "stopOnError in grid2trac");        // pylamp2.py:445,453 stopOnError=True
+        if (v[1] > 0) return pl_fail(ctx, "pl_step: a tracer moved by more than one cell in an RK4 stage (time step not CFL-limited); the "
                                           "block decomposition holds the advection velocity one cell around each block only");
     }
     return 0;
@@ -1358,24 +1410,30 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     rep->ms_scatter = now_ms() - t0;
 
-    // ---- 3. heat time step (pylamp2.py:339-343) -------------------------------------------------
-    double tstep_temp = 0.0, mn, mx; bool hn;
-    if (cfg->do_heatdiff) {
-        PL_TRY(reduce_minmax(ctx, S, g, p_kz, p_rho, p_cp, 1, &mn, &mx, &hn));
-        if (hn) mx = std::numeric_limits<double>::quiet_NaN();
-        const double mindx = std::fmin(dz, dx);
-        tstep_temp = cfg->tstep_modifier * mindx * mindx / mx;
-        tstep_temp = (cfg->tstep_dif_max < tstep_temp) ? cfg->tstep_dif_max : tstep_temp;   // python min/max order
-        tstep_temp = (cfg->tstep_dif_min > tstep_temp) ? cfg->tstep_dif_min : tstep_temp;
+    // ---- 3. heat time step (pylamp2.py:339-343) and the viscosity minima of the Stokes scaling (pylamp_stokes.py:116-118): ONE reduction
+    double tstep_temp = 0.0, mx;
+    double mes, men;
+    {
+        MinMaxSpec sp[3] = {{p_etas, nullptr, nullptr, 0}, {p_etan, nullptr, nullptr, 0}, {p_kz, p_rho, p_cp, 1}};
+        MinMaxOut mm[3];
+        PL_TRY(reduce_minmax_multi(ctx, S, g, cfg->do_heatdiff ? 3 : 2, sp, mm));
+        mes = mm[0].has_nan ? std::numeric_limits<double>::quiet_NaN() : mm[0].mn;
+        men = mm[1].has_nan ? std::numeric_limits<double>::quiet_NaN() : mm[1].mn;
+        {
+            const double lo = std::fmin(mm[0].mn, mm[1].mn), hi = std::fmax(mm[0].mx, mm[1].mx);
+            ctx->visc_contrast = (lo > 0.0 && hi > 0.0 && std::isfinite(hi / lo)) ? hi / lo : 1.0;
+        }
+        if (cfg->do_heatdiff) {
+            mx = mm[2].has_nan ? std::numeric_limits<double>::quiet_NaN() : mm[2].mx;
+            const double mindx = std::fmin(dz, dx);
+            tstep_temp = cfg->tstep_modifier * mindx * mindx / mx;
+            tstep_temp = (cfg->tstep_dif_max < tstep_temp) ? cfg->tstep_dif_max : tstep_temp;   // python min/max order
+            tstep_temp = (cfg->tstep_dif_min > tstep_temp) ? cfg->tstep_dif_min : tstep_temp;
+        }
     }
 
     // ---- 4. Stokes (pylamp2.py:349-366) -----------------------------------------------------------
     t0 = now_ms();
-    double mes, men; bool nes, nen;
-    PL_TRY(reduce_minmax(ctx, S, g, p_etas, nullptr, nullptr, 0, &mes, &mx, &nes));
-    PL_TRY(reduce_minmax(ctx, S, g, p_etan, nullptr, nullptr, 0, &men, &mx, &nen));
-    if (nes) mes = std::numeric_limits<double>::quiet_NaN();
-    if (nen) men = std::numeric_limits<double>::quiet_NaN();
     double Kc, Kb;
     pl_stokes_scaling_host(ctx->geom, mes, men, &Kc, &Kb);
     const bool ss = cfg->surface_stabilization != 0;
@@ -1459,8 +1517,14 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
     double* xsol = pl_stokes_solution_device(ctx);
     double* p_vz = xsol; double* p_vx = xsol + g.plane;
     double vmax_z, vmax_x;
-    PL_TRY(reduce_minmax(ctx, S, g, p_vz, nullptr, nullptr, 0, &mn, &vmax_z, &hn));
-    PL_TRY(reduce_minmax(ctx, S, g, p_vx, nullptr, nullptr, 0, &mn, &vmax_x, &hn));
+    auto velocity_max = [&]() -> int {
+        MinMaxSpec sp[2] = {{p_vz, nullptr, nullptr, 0}, {p_vx, nullptr, nullptr, 0}};
+        MinMaxOut mm[2];
+        PL_TRY(reduce_minmax_multi(ctx, S, g, 2, sp, mm));
+        vmax_z = mm[0].mx; vmax_x = mm[1].mx;
+        return 0;
+    };
+    PL_TRY(velocity_max());
     const double vmax = std::fmax(vmax_z, vmax_x);                  // signed np.max over both arrays (pylamp2.py:364)
     double tstep_stokes = cfg->tstep_modifier * std::fmin(dz, dx) / vmax;
     tstep_stokes = (cfg->tstep_adv_max < tstep_stokes) ? cfg->tstep_adv_max : tstep_stokes;
@@ -1484,8 +1548,7 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
             rep->stokes.rel_residual = st2.rel_residual; rep->stokes.error_estimate = st2.error_estimate; rep->stokes.solve_ms += st2.solve_ms;
             rep->stokes.operator_applies += st2.operator_applies; rep->stokes.precond_applies += st2.precond_applies;
             rep->stokes.used_direct |= st2.used_direct;
-            PL_TRY(reduce_minmax(ctx, S, g, p_vz, nullptr, nullptr, 0, &mn, &vmax_z, &hn));
-            PL_TRY(reduce_minmax(ctx, S, g, p_vx, nullptr, nullptr, 0, &mn, &vmax_x, &hn));
+            PL_TRY(velocity_max());
             const double check = cfg->tstep_modifier * std::fmin(dz, dx) / std::fmax(vmax_z, vmax_x);
             if (check < tstep) { tstep = check; limiter = 's'; }
             else break;

@@ -331,6 +331,16 @@ extern "C" int pl_stokes_set_coeffs(pl_ctx* ctx, const double* etas, const doubl
     double Kc, Kb;
     pl_stokes_scaling_host(ctx->geom, np_min(etas, n), np_min(etan, n), &Kc, &Kb);
     pl_stokes_fill_op(ctx, d_es, d_en, d_rho, bc, surfstab, tstep, theta, Kc, Kb);
+    {   // viscosity contrast over the values the operator reads (etan: the physical cells)
+        double lo = std::numeric_limits<double>::infinity(), hi = 0.0;
+        for (int i = 0; i < ctx->nz; i++)
+            for (int j = 0; j < ctx->nx; j++) {
+                const double a = etas[(size_t)i * ctx->nx + j];
+                if (a > 0.0) { lo = std::min(lo, a); hi = std::max(hi, a); }
+                if (i < ctx->nz - 1 && j < ctx->nx - 1) { const double b = etan[(size_t)i * ctx->nx + j]; if (b > 0.0) { lo = std::min(lo, b); hi = std::max(hi, b); } }
+            }
+        ctx->visc_contrast = (hi > 0.0 && lo > 0.0 && std::isfinite(hi / lo)) ? hi / lo : 1.0;
+    }
     return 0;
 }
 
