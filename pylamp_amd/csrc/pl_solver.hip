@@ -702,7 +702,10 @@ __global__ __launch_bounds__(256) void k_coarsen_visc(PlGeom gf, const double* _
 // no atomics; the host adds the (<= DOT_BLOCKS) partials in a fixed order, so the result is
 // deterministic.
 #define DOT_BLOCKS 1024
-#define PL_SCAL_N 40            // device scalars in front of the dot partials (PlSolver::scal); 32..34: y.r, y.p, y.s of the lazy deflation
+#define PL_SCAL_N 64            // device scalars in front of the dot partials (PlSolver::scal); 32..34: y.r, y.p, y.s of the lazy deflation;
+                                // several ranks (lazy deflation riding in the two reductions): 35 r~.Aw, 36 this rank's share of the five-cell sum,
+                                // 37 Aw.Aw, 38 the same over the continuity plane, 40..43 Aw.s, Aw.t and their continuity parts, 44..63 all-reduce staging
+#define PL_PART_N 16            // doubles per block of the partial-sum area behind the scalars
 template <bool HAS_A, bool HAS_C>
 __global__ __launch_bounds__(256) void k_dot2(PlGeom g, int nplanes, const double* __restrict__ a,
                                               const double* __restrict__ b, const double* __restrict__ cc,
@@ -817,6 +820,91 @@ __global__ __launch_bounds__(256) void k_sum_partials5(int nb, const double* __r
     }
 }
 __global__ void k_bicg_derive(double* __restrict__ out) { bicg_derive(out); }
+
+// ---- lazy deflation on SEVERAL ranks: the coefficients ride in the two reductions of the iteration --------------------------------
+// One rank computes c = (y.in - y.(A x)) / y.(A w) right after the preconditioner (k_defl_coef_lazy) and lets the operator add c A w.
+// On several ranks y.(A x) -- minus the area-weighted divergence of x in the anchor cell and the four corner cells -- lives on up to
+// four ranks, and an all-reduce of its own per application (two per iteration) is what that would cost.  Instead the operator is
+// applied to the UNCORRECTED vector and everything that follows is corrected algebraically, with the five-cell share added to the
+// all-reduce that follows anyway:
+//   first reduction:   r~.v_u and five(y_u)      ->  c_y = (y.p + five) / y.Aw,   r~.v = r~.v_u + c_y r~.Aw,   alpha = rho / r~.v
+//                      s = r - alpha (v_u + c_y Aw);   v = v_u + c_y Aw is written in the same pass (k_s_update_defl)
+//   second reduction:  the eight sums on t_u, four more with Aw, five(z_u)  ->  c_z = (y.s + five) / y.Aw and
+//                      t.s = t_u.s + c_z Aw.s,  t.t = t_u.t_u + 2 c_z Aw.t_u + c_z^2 Aw.Aw,  r~.t = r~.t_u + c_z r~.Aw   (k_bicg_unpack_defl)
+//                      r = s - omega (t_u + c_z Aw),  x += alpha y_u + omega z_u + (alpha c_y + omega c_z) w   (k_xrp_update_dev)
+// r~.Aw, Aw.Aw (constant during a solve) are computed once per solve.  Two all-reduces per iteration, as without the deflation.
+__global__ void k_defl_five_local(PlStokesOp op, const double* __restrict__ x, double* __restrict__ dst);
+__global__ void k_set3(double* __restrict__ a, double va, double* __restrict__ b, double vb, double* __restrict__ c, double vc) { *a = va; *b = vb; *c = vc; }
+__global__ void k_defl_alpha_ride(double* __restrict__ sc, double rho_new) {
+    const double five = sc[1];                                   // summed over the ranks next to r~.v_u
+    const double cy = (sc[24] != 0.0 && isfinite(sc[24])) ? (sc[33] + five) / sc[24] : 0.0;
+    sc[30] = cy; sc[26] = sc[33];
+    const double rtv = sc[0] + cy * sc[35];
+    sc[0] = rtv; sc[2] = rho_new / rtv; sc[4] = rho_new;
+}
+__global__ void k_defl_pack_first(double* __restrict__ sc) { sc[1] = sc[36]; }
+// s = r - alpha (v + c_y Aw), v += c_y Aw
+__global__ void k_s_update_defl(long long n, double* __restrict__ s, const double* __restrict__ r, double* __restrict__ v, const double* __restrict__ aw,
+                                const double* __restrict__ sc) {
+    const double alpha = sc[2], cy = sc[30];
+    long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; k < n; k += (long long)gridDim.x * blockDim.x) { const double vv = v[k] + cy * aw[k]; v[k] = vv; s[k] = r[k] - alpha * vv; }
+}
+// block partials of Aw.s, Aw.t over all planes and over the planes >= nsplit
+__global__ __launch_bounds__(256) void k_dot4w(PlGeom g, int nplanes, int nsplit, const double* __restrict__ aw, const double* __restrict__ sv,
+                                               const double* __restrict__ t, double* __restrict__ part) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    const long long rows = (long long)g.lnz * nplanes;
+    for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
+        const int q = (int)(r / g.lnz), li = (int)(r % g.lnz);
+        const long long base = pl_idx(g, li, 0) + q * g.plane;
+        double b0 = 0.0, b1 = 0.0;
+        for (int k = threadIdx.x; k < g.lnx; k += 256) { const double w = aw[base + k]; b0 += w * sv[base + k]; b1 += w * t[base + k]; }
+        a0 += b0; a1 += b1;
+        if (q >= nsplit) { a2 += b0; a3 += b1; }
+    }
+    __shared__ double sh[4][4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a0 += __shfl_down(a0, o, 64); a1 += __shfl_down(a1, o, 64); a2 += __shfl_down(a2, o, 64); a3 += __shfl_down(a3, o, 64); }
+    if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; sh[0][w] = a0; sh[1][w] = a1; sh[2][w] = a2; sh[3][w] = a3; }
+    __syncthreads();
+    if (threadIdx.x < 4) part[4 * blockIdx.x + threadIdx.x] = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
+}
+__global__ __launch_bounds__(256) void k_sum_partials4(int nb, const double* __restrict__ part, double* __restrict__ out) {
+    __shared__ double sh[4][4];
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int k = threadIdx.x; k < nb; k += 256)
+#pragma unroll
+        for (int q = 0; q < 4; q++) a[q] += part[4 * k + q];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        for (int o = 32; o > 0; o >>= 1) a[q] += __shfl_down(a[q], o, 64);
+        if ((threadIdx.x & 63) == 0) sh[q][threadIdx.x >> 6] = a[q];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) for (int q = 0; q < 4; q++) out[q] = sh[q][0] + sh[q][1] + sh[q][2] + sh[q][3];
+}
+// staging block of the second reduction: [0..7] the k_dot5 sums, [8..12] slots 16..20, [13] five(z_u) share, [14..17] the Aw sums
+__global__ void k_bicg_pack_defl(double* __restrict__ sc) {
+    const int k = threadIdx.x;
+    if (k < 13) sc[44 + k] = sc[8 + k];
+    else if (k == 13) sc[44 + 13] = sc[36];
+    else if (k < 18) sc[44 + k] = sc[40 + (k - 14)];
+}
+__global__ void k_bicg_unpack_defl(double* __restrict__ sc) {
+    for (int k = 0; k < 13; k++) sc[8 + k] = sc[44 + k];
+    const double five = sc[44 + 13], aws = sc[44 + 14], awt = sc[44 + 15], aws_c = sc[44 + 16], awt_c = sc[44 + 17];
+    const double ys = sc[32] - sc[2] * sc[33];                   // y.s = y.r - alpha y.v, y.v = y.p
+    sc[34] = ys; sc[26] = ys;
+    const double cz = (sc[24] != 0.0 && isfinite(sc[24])) ? (ys + five) / sc[24] : 0.0;
+    sc[31] = cz;
+    sc[8] += cz * aws;                                           // t.s
+    sc[9] += 2.0 * cz * awt + cz * cz * sc[37];                  // t.t
+    sc[11] += cz * sc[35];                                       // r~.t
+    sc[13] += cz * aws_c;                                        // continuity parts
+    sc[14] += 2.0 * cz * awt_c + cz * cz * sc[38];
+    bicg_derive(sc);
+}
 
 // p = r + beta (p - omega v)
 __global__ void k_p_update(long long n, double* __restrict__ p, const double* __restrict__ r,
@@ -1314,15 +1402,16 @@ __global__ void k_s_update_dev(long long n, double* __restrict__ y, const double
 __global__ void k_xrp_update_dev(long long n, double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z,
                                  double* __restrict__ r, const double* __restrict__ s, const double* __restrict__ t,
                                  double* __restrict__ p, const double* __restrict__ v, const double* __restrict__ sc,
-                                 const double* __restrict__ wd) {
+                                 const double* __restrict__ wd, const double* __restrict__ awd) {
     const double alpha = sc[2], omega = sc[3], beta = sc[7];
     const double cw = wd ? alpha * sc[30] + omega * sc[31] : 0.0;      // lazy deflation: y and z stand for y + c_y w and z + c_z w
+    const double cz = awd ? sc[31] : 0.0;                              // ... and (several ranks) t for t + c_z A w
     long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     for (; k < n; k += (long long)gridDim.x * blockDim.x) {
         double xn = x[k] + alpha * y[k] + omega * z[k];
         if (wd) xn += cw * wd[k];
         x[k] = xn;
-        const double rn = s[k] - omega * t[k];
+        const double rn = s[k] - omega * (awd ? t[k] + cz * awd[k] : t[k]);
         r[k] = rn;
         p[k] = rn + beta * (p[k] - omega * v[k]);
     }
@@ -1384,12 +1473,22 @@ static bool dots_on_device(pl_ctx* ctx, const PlGeom& g) {
     return true;       // pl_comm_allreduce_dev stages through the host on the non-native transports
 }
 // second reduction point of BiCGStab: omega -> scal[3], rho' -> scal[5], |r|^2 -> scal[6] (ONE all-reduce of 5 doubles)
-static int dots5_dev(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, int nsplit, const double* t, const double* sv, const double* rt) {
+static int dots5_dev(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, int nsplit, const double* t, const double* sv, const double* rt,
+                     const double* aw_ride = nullptr) {
     long long rows = (long long)g.lnz * np;
     const int nb = (int)(rows < DOT_BLOCKS ? rows : DOT_BLOCKS);
     hipLaunchKernelGGL(k_dot5, dim3(nb), dim3(256), 0, ctx->stream, g, np, nsplit, t, sv, rt, S->scal + PL_SCAL_N);
     const bool reduce = ctx->nranks > 1 && pl_geom_is_dist(g);
     hipLaunchKernelGGL(k_sum_partials5, dim3(1), dim3(256), 0, ctx->stream, nb, S->scal + PL_SCAL_N, S->scal, reduce ? 0 : 1);
+    if (reduce && aw_ride) {          // lazy deflation on several ranks: its sums and the five-cell share ride in this ONE all-reduce (18 values)
+        double* part2 = S->scal + PL_SCAL_N + 8 * DOT_BLOCKS;
+        hipLaunchKernelGGL(k_dot4w, dim3(nb), dim3(256), 0, ctx->stream, g, np, nsplit, aw_ride, sv, t, part2);
+        hipLaunchKernelGGL(k_sum_partials4, dim3(1), dim3(256), 0, ctx->stream, nb, (const double*)part2, S->scal + 40);
+        hipLaunchKernelGGL(k_bicg_pack_defl, dim3(1), dim3(64), 0, ctx->stream, S->scal);
+        PL_TRY(pl_comm_allreduce_dev(ctx, S->scal + 44, 18));
+        hipLaunchKernelGGL(k_bicg_unpack_defl, dim3(1), dim3(1), 0, ctx->stream, S->scal);
+        return 0;
+    }
     if (reduce) {
         PL_TRY(pl_comm_allreduce_dev(ctx, S->scal + 8, 13));        // scal[16..20]: the local ||x_vel||^2, y.s, y.t, (unused) and ||z_vel||^2 ride along
         hipLaunchKernelGGL(k_bicg_derive, dim3(1), dim3(1), 0, ctx->stream, S->scal);
@@ -1426,7 +1525,7 @@ static int norm2_sum_dev(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, cons
 // mode 1 / 2: alpha resp. omega are derived in the same pass (see k_sum_partials); with several ranks the sums
 // are all-reduced first and a one-thread kernel derives the scalar
 static int dots_dev(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const double* a, const double* b, const double* c,
-                    const double* d, int mode, double rho_new) {
+                    const double* d, int mode, double rho_new, bool ride = false) {
     long long rows = (long long)g.lnz * np;
     const int nb = (int)(rows < DOT_BLOCKS ? rows : DOT_BLOCKS);
     if (a && c) hipLaunchKernelGGL((k_dot2<true, true>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + PL_SCAL_N);
@@ -1434,6 +1533,12 @@ static int dots_dev(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const dou
     else hipLaunchKernelGGL((k_dot2<false, true>), dim3(nb), dim3(256), 0, ctx->stream, g, np, a, b, c, d, S->scal + PL_SCAL_N);
     const bool reduce = ctx->nranks > 1 && pl_geom_is_dist(g);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, nb, S->scal + PL_SCAL_N, S->scal, reduce ? 0 : mode, rho_new);
+    if (reduce && ride && mode == 1) {                  // lazy deflation on several ranks: the five-cell share of y_u travels with r~.v_u
+        hipLaunchKernelGGL(k_defl_pack_first, dim3(1), dim3(1), 0, ctx->stream, S->scal);
+        PL_TRY(pl_comm_allreduce_dev(ctx, S->scal, 2));
+        hipLaunchKernelGGL(k_defl_alpha_ride, dim3(1), dim3(1), 0, ctx->stream, S->scal, rho_new);
+        return 0;
+    }
     if (reduce) {
         PL_TRY(pl_comm_allreduce_dev(ctx, S->scal, 2));
         if (mode == 1) hipLaunchKernelGGL(k_scalar_alpha, dim3(1), dim3(1), 0, ctx->stream, S->scal, rho_new);
@@ -2931,6 +3036,14 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
         hipLaunchKernelGGL(k_random_interior, grid2d(g), dim3(64, 4), 0, ctx->stream, g, np, w.rt, 1234u);
     }
     const bool on_device = dots_on_device(ctx, g) && !getenv("PYLAMP_HOST_SCALARS");
+    // lazy deflation on several ranks: its coefficients ride in the two reductions of an iteration (k_defl_alpha_ride ...)
+    const bool ride = S->defl_lazy && S->defl_active && np == 3 && M && on_device && ctx->nranks > 1 && pl_geom_is_dist(g);
+    if (ride) {                                          // r~.Aw, Aw.Aw and its continuity part: constant during this solve
+        double c1[2], c2[2];
+        PL_TRY(dots(ctx, S, g, 3, w.rt, S->Awdefl, S->Awdefl, S->Awdefl, c1));
+        PL_TRY(dots(ctx, S, g, 1, S->Awdefl + 2 * g.plane, S->Awdefl + 2 * g.plane, nullptr, nullptr, c2));
+        hipLaunchKernelGGL(k_set3, dim3(1), dim3(1), 0, ctx->stream, S->scal + 35, c1[0], S->scal + 37, c1[1], S->scal + 38, c2[0]);
+    }
     static const bool trace = getenv("PYLAMP_SOLVER_TRACE") != nullptr;        // residual history on stderr
     int it = 0, restarts = 0;
     double true_norm = -1.0, last_true = -1.0;          // ||r0 - A dx|| of the current dx (< 0: not evaluated)
@@ -2980,9 +3093,9 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
     auto ysum_host = [&](const double* rp, double& yr) -> int {     // the same, reduced over the ranks, on the host
         ysum_dev(rp, S->scal + 28);
         if (ctx->nranks > 1 && pl_geom_is_dist(g)) PL_TRY(pl_comm_allreduce_dev(ctx, S->scal + 28, 1));
-        PL_HIP(ctx, hipMemcpyAsync(S->hpart + 8 * DOT_BLOCKS, S->scal + 28, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        PL_HIP(ctx, hipMemcpyAsync(S->hpart + PL_PART_N * DOT_BLOCKS, S->scal + 28, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        yr = S->hpart[8 * DOT_BLOCKS];
+        yr = S->hpart[PL_PART_N * DOT_BLOCKS];
         return 0;
     };
     bool resume = false;                            // continue the running iteration instead of restarting it
@@ -3006,6 +3119,7 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
             broke = false;
             if (S->defl_lazy && S->defl_active && np == 3 && M) {       // y.r of the (re)start residual; p = r
                 ysum_dev(w.r + 2 * g.plane, S->scal + 32);
+                if (ride) PL_TRY(pl_comm_allreduce_dev(ctx, S->scal + 32, 1));
                 hipLaunchKernelGGL(k_defl_init, dim3(1), dim3(1), 0, ctx->stream, S->scal);
             }
         }
@@ -3021,8 +3135,9 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
             const double* zv = w.s;
             if (on_device) {
                 // alpha, omega stay on the device; a breakdown (rt.v = 0) shows up as a non-finite alpha / ||r|| below
-                PL_TRY(dots_dev(ctx, S, g, np, w.rt, w.v, nullptr, nullptr, 1, rho_new));
-                hipLaunchKernelGGL(k_s_update_dev, grid1d(n), dim3(256), 0, ctx->stream, n, w.s, w.r, w.v, S->scal);
+                PL_TRY(dots_dev(ctx, S, g, np, w.rt, w.v, nullptr, nullptr, 1, rho_new, ride));
+                if (ride) hipLaunchKernelGGL(k_s_update_defl, grid1d(n), dim3(256), 0, ctx->stream, n, w.s, (const double*)w.r, w.v, (const double*)S->Awdefl, (const double*)S->scal);
+                else hipLaunchKernelGGL(k_s_update_dev, grid1d(n), dim3(256), 0, ctx->stream, n, w.s, w.r, w.v, S->scal);
                 if (M) { PL_TRY((*M)(w.s, w.z)); zv = w.z; }
                 PL_TRY(A(zv, w.t));
                 // near the end: ||x_vel||^2 for the error estimate (-> scal[16]; of the iterate BEFORE this update, so that
@@ -3040,15 +3155,16 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
                     ysum_dev(w.s + (long long)np_vel * g.plane, S->scal + 17);
                     ysum_dev(w.t + (long long)np_vel * g.plane, S->scal + 18);
                 }
-                PL_TRY(dots5_dev(ctx, S, g, np, use_est ? np_vel : np, w.t, w.s, w.rt));       // omega, rho' and |r|^2 from ONE reduction
+                PL_TRY(dots5_dev(ctx, S, g, np, use_est ? np_vel : np, w.t, w.s, w.rt, ride ? (const double*)S->Awdefl : (const double*)nullptr));       // omega, rho' and |r|^2 from ONE reduction
                 // ... and the next direction in the same pass (the host's beta above is then only the breakdown test)
                 if (yv != w.p) {
                     hipLaunchKernelGGL(k_xrp_update_dev, grid1d(n), dim3(256), 0, ctx->stream, n, dx, yv, zv, w.r, w.s, w.t, w.p, w.v, S->scal,
-                                       (S->defl_lazy && S->defl_active && np == 3) ? (const double*)S->wdefl : (const double*)nullptr);
+                                       (S->defl_lazy && S->defl_active && np == 3) ? (const double*)S->wdefl : (const double*)nullptr,
+                                       ride ? (const double*)S->Awdefl : (const double*)nullptr);
                     p_fused = true;
                 } else            // no preconditioner: y IS p
                     hipLaunchKernelGGL(k_xr_update_dev, grid1d(n), dim3(256), 0, ctx->stream, n, dx, yv, zv, w.r, w.s, w.t, S->scal);
-                double* hs = S->hpart + 8 * DOT_BLOCKS;
+                double* hs = S->hpart + PL_PART_N * DOT_BLOCKS;
                 PL_HIP(ctx, hipMemcpyAsync(hs, S->scal, PL_SCAL_N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
                 PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 rho = rho_new;
@@ -3084,9 +3200,9 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
                     double dc[2];
                     PL_TRY(dots(ctx, S, g, np - np_vel, w.r + (long long)np_vel * g.plane, w.r + (long long)np_vel * g.plane, nullptr, nullptr, dc));
                     PL_TRY(norm2_sum_dev(ctx, S, g, np_vel, dx, dx != x ? (const double*)x : (const double*)nullptr, true));
-                    PL_HIP(ctx, hipMemcpyAsync(S->hpart + 8 * DOT_BLOCKS, S->scal + 16, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+                    PL_HIP(ctx, hipMemcpyAsync(S->hpart + PL_PART_N * DOT_BLOCKS, S->scal + 16, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
                     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                    const double xxh = S->hpart[8 * DOT_BLOCKS];
+                    const double xxh = S->hpart[PL_PART_N * DOT_BLOCKS];
                     double yr = 0.0;
                     if (anchor_term) PL_TRY(ysum_host(w.r + (long long)np_vel * g.plane, yr));
                     est_rec = estimate(dc[0], d2[1], xxh, yr);
@@ -3131,10 +3247,10 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
                 PL_TRY(dots(ctx, S, g, np_vel, w.z, w.z, nullptr, nullptr, dz));
             }
             PL_TRY(norm2_sum_dev(ctx, S, g, np_vel, dx, dx != x ? (const double*)x : (const double*)nullptr, true));
-            PL_HIP(ctx, hipMemcpyAsync(S->hpart + 8 * DOT_BLOCKS, S->scal + 16, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            PL_HIP(ctx, hipMemcpyAsync(S->hpart + PL_PART_N * DOT_BLOCKS, S->scal + 16, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
             PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
             est_checks++;
-            const double xx = S->hpart[8 * DOT_BLOCKS];
+            const double xx = S->hpart[PL_PART_N * DOT_BLOCKS];
             if (xx_guess > 0.0 && xx > 0.0) xx_guess = xx;               // (the exact norm of this iterate from here on)
             const double rc = dc[0] > 0.0 ? dc[0] : 0.0, rm = true_norm * true_norm - rc;
             if (!exact) dz[0] = a_mom * a_mom * (rm > 0.0 ? rm : 0.0);            // the response the last iteration measured, scaled to this residual
@@ -3186,8 +3302,8 @@ static int stokes_alloc(pl_ctx* ctx, PlSolver* S) {
     for (double** q : {&S->r, &S->rt, &S->p, &S->v, &S->s, &S->t, &S->y, &S->z, &S->b, &S->x, &S->xb, &S->dx, &S->r0})
         PL_TRY(dmalloc0(ctx, q, vb));
     if (!S->scal) {
-        PL_TRY(dmalloc0(ctx, &S->scal, (PL_SCAL_N + 8 * DOT_BLOCKS) * sizeof(double)));
-        PL_HIP(ctx, hipHostMalloc((void**)&S->hpart, (8 * DOT_BLOCKS + PL_SCAL_N) * sizeof(double)));
+        PL_TRY(dmalloc0(ctx, &S->scal, (PL_SCAL_N + PL_PART_N * DOT_BLOCKS) * sizeof(double)));
+        PL_HIP(ctx, hipHostMalloc((void**)&S->hpart, (PL_PART_N * DOT_BLOCKS + PL_SCAL_N) * sizeof(double)));
     }
     return 0;
 }
@@ -3272,6 +3388,7 @@ __device__ inline double defl_five_cells(const PlStokesOp& op, const double* __r
     }
     return five;
 }
+__global__ void k_defl_five_local(PlStokesOp op, const double* __restrict__ x, double* __restrict__ dst) { *dst = defl_five_cells(op, x); }
 __global__ void k_defl_divide(double* __restrict__ sc) { sc[25] = (sc[24] != 0.0 && isfinite(sc[24])) ? sc[27] / sc[24] : 0.0; }
 __global__ void k_axpy_dev_scalar(long long n, double* __restrict__ z, const double* __restrict__ w, const double* __restrict__ sc) {
     const double a = sc[0];
@@ -3299,12 +3416,12 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
     S->napply = 0; S->nprec = 0;
     S->l0_mixed_now = rtol >= 1e-8 && use_x0;                // warm-started solves of a time loop (see stokes_precond_t)
     // one rank with the scalars on the device: the deflation correction is applied lazily (PlSolver::Awdefl)
-    S->defl_lazy = ctx->nranks == 1 && dots_on_device(ctx, g) && !getenv("PYLAMP_HOST_SCALARS") &&
+    S->defl_lazy = dots_on_device(ctx, g) && !getenv("PYLAMP_HOST_SCALARS") &&
                    !(getenv("PYLAMP_DEFL_LAZY") && atoi(getenv("PYLAMP_DEFL_LAZY")) == 0);
     VecOp A = [&](const double* in, double* out) -> int {
         PL_TRY(pl_halo(ctx, g, (double*)in, 3, g.plane));
         // y = D_r A x in one pass; for a vector the preconditioner has just produced: + c A w (its lazy deflation correction)
-        if (S->defl_lazy && S->defl_active && (in == S->y || in == S->z))
+        if (S->defl_lazy && S->defl_active && ctx->nranks == 1 && (in == S->y || in == S->z))
             pl_launch_stokes_apply(ctx, sop_scaled, in, out, S->Awdefl, S->scal + (in == S->y ? 30 : 31));
         else pl_launch_stokes_apply(ctx, sop_scaled, in, out);
         S->napply++;
@@ -3314,6 +3431,10 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
     VecOp M = [&](const double* in, double* out) -> int {
         PL_TRY(stokes_precond(ctx, S, in, out));
         if (S->defl_active) {                               // z += w y.(r - A z) / y.(A w), all scalars on the device
+            if (S->defl_lazy && ctx->nranks > 1 && (out == S->y || out == S->z)) {   // several ranks: this rank's share of the five-cell sum; it rides in
+                hipLaunchKernelGGL(k_defl_five_local, dim3(1), dim3(1), 0, ctx->stream, sop, (const double*)out, S->scal + 36);      // the reduction that follows
+                return 0;
+            }
             if (S->defl_lazy && (out == S->y || out == S->z)) {       // the coefficient only: A and the iterate update do the rest
                 hipLaunchKernelGGL(k_defl_coef_lazy, dim3(1), dim3(1), 0, ctx->stream, sop, (const double*)out, S->scal, out == S->y ? 30 : 31, out == S->z ? 1 : 0);
                 return 0;
@@ -3376,9 +3497,9 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
         double dw[2];
         PL_TRY(dots(ctx, S, g, 2, S->wdefl, S->wdefl, nullptr, nullptr, dw));
         S->defl_wvel2 = dw[0];
-        PL_HIP(ctx, hipMemcpyAsync(S->hpart + 8 * DOT_BLOCKS, S->scal + 24, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        PL_HIP(ctx, hipMemcpyAsync(S->hpart + PL_PART_N * DOT_BLOCKS, S->scal + 24, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        S->defl_yAw = S->hpart[8 * DOT_BLOCKS];
+        S->defl_yAw = S->hpart[PL_PART_N * DOT_BLOCKS];
     }
     if (trace_t) tph[2] = now();
     if (b_dev != S->b)
@@ -3863,8 +3984,8 @@ static int heat_solve_cg(pl_ctx* ctx, PlSolver* S, const double* b_dev, double r
     for (int k = 0; k < 9; k++) if (!S->hc[k]) PL_TRY(dmalloc0(ctx, &S->hc[k], pb));
     if (multi && !S->hc3) PL_TRY(dmalloc0(ctx, &S->hc3, 3 * pb));            // the three Chebyshev iterates as ONE allocation: one exchange for all
     if (!S->scal) {
-        PL_TRY(dmalloc0(ctx, &S->scal, (PL_SCAL_N + 8 * DOT_BLOCKS) * sizeof(double)));
-        PL_HIP(ctx, hipHostMalloc((void**)&S->hpart, (8 * DOT_BLOCKS + PL_SCAL_N) * sizeof(double)));
+        PL_TRY(dmalloc0(ctx, &S->scal, (PL_SCAL_N + PL_PART_N * DOT_BLOCKS) * sizeof(double)));
+        PL_HIP(ctx, hipHostMalloc((void**)&S->hpart, (PL_PART_N * DOT_BLOCKS + PL_SCAL_N) * sizeof(double)));
     }
     // deepest extension a kernel of this solve runs on: it reads the coefficient planes one node further (ring PL_RING deep)
     const int E = multi ? std::min(PL_RING - 1, std::min(g.lnz, g.lnx)) : 0;
@@ -4016,8 +4137,8 @@ int pl_heat_solve_device(pl_ctx* ctx, const double* b_dev, double rtol, int maxi
     size_t pb = (size_t)g.plane * sizeof(double);
     for (int k = 0; k < 11; k++) if (!S->h[k]) PL_TRY(dmalloc0(ctx, &S->h[k], pb));
     if (!S->scal) {
-        PL_TRY(dmalloc0(ctx, &S->scal, (PL_SCAL_N + 8 * DOT_BLOCKS) * sizeof(double)));
-        PL_HIP(ctx, hipHostMalloc((void**)&S->hpart, (8 * DOT_BLOCKS + PL_SCAL_N) * sizeof(double)));
+        PL_TRY(dmalloc0(ctx, &S->scal, (PL_SCAL_N + PL_PART_N * DOT_BLOCKS) * sizeof(double)));
+        PL_HIP(ctx, hipHostMalloc((void**)&S->hpart, (PL_PART_N * DOT_BLOCKS + PL_SCAL_N) * sizeof(double)));
     }
     PL_TRY(pl_timer_start(ctx));
     PlHeatOp hop = ctx->hop;

@@ -100,7 +100,7 @@ def test_bench_starts_its_own_ranks():
         env.pop(k, None)
     env["PYLAMP_BENCH_NO_4097"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--grid", "257",
-                        "--tracdens", "8", "--apply-reps", "5"], capture_output=True, text=True, timeout=900, env=env)
+                        "--tracdens", "16", "--apply-reps", "5"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
