@@ -314,6 +314,18 @@ typedef struct pl3_ctx pl3_ctx;
 int  pl3_create(pl3_ctx** out, int device, int nz, int nx, int ny, const double* zc, const double* xc, const double* yc);
 void pl3_destroy(pl3_ctx* ctx);
 const char* pl3_last_error(const pl3_ctx* ctx);
+/* Several ranks (BASELINE config 5: "1 -> 8 MI355X"; the reference has no 3-D code at all, pylamp_const.py:6, pylamp_stokes.py:24-35):
+ * right after pl3_create -- with the GLOBAL grid on every rank -- this context becomes one block of a Pz x Px x Py decomposition of
+ * the node grid, rank = (pz Px + px) Py + py, (n - 1) divisible by the block count along every axis, >= 4 cells per block.  `comm`
+ * is a 2-D context (pl_create on any small grid) that carries the transport: its pl_set_comm / pl_set_comm_2d / pl_set_comm_local must
+ * have been called with Pz * Px * Py ranks, and it must outlive this context (whose stream it shares from then on).  Host arrays stay
+ * GLOBAL on every rank (the block and the one ring of halo nodes the stencils reach are cut out of them; results are assembled).
+ * Every pl3_* call that follows is collective.  Halo: one node deep, exchanged axis by axis (z, x, y planes: 6 messages carry faces,
+ * edges and corners); every multigrid level is distributed (blocks halved with the grid), dot products are all-reduced on the host. */
+int  pl3_set_comm(pl3_ctx* ctx, pl_ctx* comm, int Pz, int Px, int Py);
+int  pl3_local_block(pl3_ctx* ctx, int first[3], int count[3]);
+/* out[0] halo exchanges, out[1] host all-reduces of this context so far; reset != 0 clears the counters */
+int  pl3_comm_stats(pl3_ctx* ctx, int64_t out[2], int reset);
 /* grav = G[3] (NULL: (9.81, 0, 0), pylamp_const.py:21); Kcont = 3 min(eta) / sum(avgd), Kbond = 9 min(eta) / sum(avgd)^2 */
 int  pl3_stokes_set_coeffs(pl3_ctx* ctx, const double* etas, const double* etan, const double* rho, const double grav[3]);
 /* slaved != 0 (default): the reference's wall rows extended to 3-D (outermost in-domain tangential velocities slaved to their

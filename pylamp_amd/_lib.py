@@ -54,6 +54,9 @@ SIGNATURES = {
     "pl_abi_layout": (C.c_int, [C.POINTER(C.c_size_t)]),
     "pl3_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p]),
     "pl3_destroy": (None, [C.c_void_p]),
+    "pl3_set_comm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "pl3_local_block": (C.c_int, [C.c_void_p, c_int_p, c_int_p]),
+    "pl3_comm_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
     "pl3_last_error": (C.c_char_p, [C.c_void_p]),
     "pl3_stokes_set_coeffs": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p]),
     "pl3_stokes_set_wall_rows": (C.c_int, [C.c_void_p, C.c_int]),

@@ -26,10 +26,12 @@ typedef const double __attribute__((address_space(4))) * pl_ctab;
 #define TB(tab, k) (((pl_ctab)(tab))[(k) + PL_TOFF])
 
 struct G3 {
-    int n[3];                        // nz, nx, ny
+    int n[3];                        // nodes of THIS RANK's block along z, x, y (the whole grid on one rank)
+    int gn[3];                       // global node counts nz, nx, ny
+    int o[3];                        // global index of local node (0, 0, 0)
     long long s[3];                  // element strides of z, x, y
     long long vol;                   // elements per scalar array (incl. one ring of nodes in z and x, padding in y)
-    const double* rd[3];             // 1/(c[i+1]-c[i])      per axis, zero padded, index + PL_TOFF
+    const double* rd[3];             // 1/(c[i+1]-c[i])      per axis, zero padded, GLOBAL index + PL_TOFF
     const double* rD[3];             // 1/(c[i+1]-c[i-1])
 };
 __host__ __device__ inline long long i3(const G3& g, int i, int j, int k) {
@@ -50,7 +52,7 @@ enum { C3_ZERO = 0, C3_INT = 1, C3_SLAVE = 2 };
 // class of the row of velocity component D at node idx; slaves get the offset to their (interior) master
 template <int D> __device__ inline int cls3(const Op3& op, const int* idx, long long& moff) {
     constexpr int E = (D + 1) % 3, F = (D + 2) % 3;
-    const int* n = op.g.n;
+    const int* n = op.g.gn;
     moff = 0;
     if (idx[D] <= 0 || idx[D] >= n[D] - 1 || idx[E] >= n[E] - 1 || idx[F] >= n[F] - 1) return C3_ZERO;
     if (op.slave) {
@@ -109,10 +111,12 @@ template <int D> __device__ inline double diag3(const Op3& op, long long c, cons
     return d;
 }
 
+// li, lj, lk: node of this rank's block; i, j, k (= idx): its GLOBAL index -- row classes and spacing tables are global
 #define K3_PROLOGUE(g)                                                                          \
-    const int k = blockIdx.x * 64 + threadIdx.x, j = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y), i = blockIdx.z; \
-    if (k >= (g).n[2] || j >= (g).n[1]) return;                                                 \
-    const long long c = i3((g), i, j, k);                                                       \
+    const int lk = blockIdx.x * 64 + threadIdx.x, lj = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y), li = blockIdx.z; \
+    if (lk >= (g).n[2] || lj >= (g).n[1]) return;                                               \
+    const long long c = i3((g), li, lj, lk);                                                    \
+    const int k = lk + (g).o[2], j = __builtin_amdgcn_readfirstlane(lj + (g).o[1]), i = li + (g).o[0]; \
     const int idx[3] = {i, j, k};                                                               \
     (void)idx;
 static dim3 grid3(const G3& g) { return dim3((g.n[2] + 63) / 64, (g.n[1] + 3) / 4, g.n[0]); }
@@ -129,7 +133,7 @@ struct W3 { double* p[3]; };
 
 // pressure row class: 0 ghost/anchor (Kc P), 1 continuity, 2 symmetry with the neighbour at offset moff (Kb (P_nb - P))
 __device__ inline int cls3_p(const Op3& op, const int* idx, long long& moff) {
-    const int* n = op.g.n;
+    const int* n = op.g.gn;
     moff = 0;
     if (idx[0] >= n[0] - 1 || idx[1] >= n[1] - 1 || idx[2] >= n[2] - 1) return 0;
     if (idx[0] == op.anchor[0] && idx[1] == op.anchor[1] && idx[2] == op.anchor[2]) return 0;
@@ -150,7 +154,7 @@ template <int D> __device__ inline double apply_vel3(const Op3& op, const double
     if (cl == C3_SLAVE) {
         // the matrix row couples to the neighbour along the FIRST boundary axis (E before F), pylamp_stokes.py:170-175
         constexpr int E = (D + 1) % 3, F = (D + 2) % 3;
-        const int* n = op.g.n;
+        const int* n = op.g.gn;
         long long nb;
         if (idx[E] == 0) nb = op.g.s[E]; else if (idx[E] == n[E] - 2) nb = -op.g.s[E];
         else nb = (idx[F] == 0) ? op.g.s[F] : -op.g.s[F];
@@ -266,8 +270,8 @@ template <int D> __device__ inline double cheb3(const Op3& op, const double* con
     const long long cm = c + moff;
     int im[3] = {idx[0], idx[1], idx[2]};
     if (cl == C3_SLAVE) {
-        if (idx[E] == 0) im[E] = 1; else if (idx[E] == op.g.n[E] - 2) im[E] = op.g.n[E] - 3;
-        if (idx[F] == 0) im[F] = 1; else if (idx[F] == op.g.n[F] - 2) im[F] = op.g.n[F] - 3;
+        if (idx[E] == 0) im[E] = 1; else if (idx[E] == op.g.gn[E] - 2) im[E] = op.g.gn[E] - 3;
+        if (idx[F] == 0) im[F] = 1; else if (idx[F] == op.g.gn[F] - 2) im[F] = op.g.gn[F] - 3;
     }
     if (zero) return (-c2 * f[cm]) * pl_rcp(diag3<D>(op, cm, im));
     double Av, dg;
@@ -293,8 +297,8 @@ template <int D> __device__ inline double resid3(const Op3& op, const double* co
     const long long cm = c + moff;
     int im[3] = {idx[0], idx[1], idx[2]};
     if (cl == C3_SLAVE) {
-        if (idx[E] == 0) im[E] = 1; else if (idx[E] == op.g.n[E] - 2) im[E] = op.g.n[E] - 3;
-        if (idx[F] == 0) im[F] = 1; else if (idx[F] == op.g.n[F] - 2) im[F] = op.g.n[F] - 3;
+        if (idx[E] == 0) im[E] = 1; else if (idx[E] == op.g.gn[E] - 2) im[E] = op.g.gn[E] - 3;
+        if (idx[F] == 0) im[F] = 1; else if (idx[F] == op.g.gn[F] - 2) im[F] = op.g.gn[F] - 3;
     }
     double Av, dg;
     row3<D>(op, v, cm, im, Av, dg);
@@ -314,7 +318,7 @@ template <int D> __device__ inline double restrict3(const G3& gf, const Op3& opc
     constexpr int E = (D + 1) % 3, F = (D + 2) % 3;
     long long moff;
     if (cls3<D>(opc, idx, moff) != C3_INT) return 0.0;
-    const long long b = i3(gf, 2 * idx[0], 2 * idx[1], 2 * idx[2]);
+    const long long b = i3(gf, 2 * idx[0] - gf.o[0], 2 * idx[1] - gf.o[1], 2 * idx[2] - gf.o[2]);
     const double wv[3] = {0.25, 0.5, 0.25}, wc[4] = {0.125, 0.375, 0.375, 0.125};
     double acc = 0.0;
 #pragma unroll
@@ -343,11 +347,11 @@ template <int D> __device__ inline double prolong3_at(const G3& gc, const double
     const int d0 = idx[D] >> 1, d1 = (idx[D] + 1) >> 1;
     int en_ = idx[E] >> 1, eo = (idx[E] & 1) ? en_ + 1 : en_ - 1;
     int fn = idx[F] >> 1, fo = (idx[F] & 1) ? fn + 1 : fn - 1;
-    const int emax = gc.n[E] - 2, fmax = gc.n[F] - 2;
+    const int emax = gc.gn[E] - 2, fmax = gc.gn[F] - 2;
     en_ = min(max(en_, 0), emax); eo = min(max(eo, 0), emax); fn = min(max(fn, 0), fmax); fo = min(max(fo, 0), fmax);
     auto at = [&](int a, int b_, int c_) {
         int id[3]; id[D] = a; id[E] = b_; id[F] = c_;
-        return e[i3(gc, id[0], id[1], id[2])];
+        return e[i3(gc, id[0] - gc.o[0], id[1] - gc.o[1], id[2] - gc.o[2])];
     };
     auto lin = [&](int b_, int c_) { return 0.5 * (at(d0, b_, c_) + at(d1, b_, c_)); };
     return 0.75 * (0.75 * lin(en_, fn) + 0.25 * lin(en_, fo)) + 0.25 * (0.75 * lin(eo, fn) + 0.25 * lin(eo, fo));
@@ -360,8 +364,8 @@ template <int D> __device__ inline double prolong3(const Op3& opf, const G3& gc,
     if (cl == C3_ZERO) return 0.0;
     int im[3] = {idx[0], idx[1], idx[2]};
     if (cl == C3_SLAVE) {
-        if (idx[E] == 0) im[E] = 1; else if (idx[E] == opf.g.n[E] - 2) im[E] = opf.g.n[E] - 3;
-        if (idx[F] == 0) im[F] = 1; else if (idx[F] == opf.g.n[F] - 2) im[F] = opf.g.n[F] - 3;
+        if (idx[E] == 0) im[E] = 1; else if (idx[E] == opf.g.gn[E] - 2) im[E] = opf.g.gn[E] - 3;
+        if (idx[F] == 0) im[F] = 1; else if (idx[F] == opf.g.gn[F] - 2) im[F] = opf.g.gn[F] - 3;
     }
     return vin[c + moff] + prolong3_at<D>(gc, e, im);
 }
@@ -379,12 +383,12 @@ __global__ __launch_bounds__(256) void k3_coarsen(G3 gf, const double* __restric
     for (int a = -1; a <= 1; a++)
         for (int q = -1; q <= 1; q++)
             for (int p = -1; p <= 1; p++) {
-                const int fi = min(max(2 * i + a, 0), gf.n[0] - 1), fj = min(max(2 * j + q, 0), gf.n[1] - 1), fk = min(max(2 * k + p, 0), gf.n[2] - 1);
-                acc += (a == 0 ? 2.0 : 1.0) * (q == 0 ? 2.0 : 1.0) * (p == 0 ? 2.0 : 1.0) * esf[i3(gf, fi, fj, fk)];
+                const int fi = min(max(2 * i + a, 0), gf.gn[0] - 1), fj = min(max(2 * j + q, 0), gf.gn[1] - 1), fk = min(max(2 * k + p, 0), gf.gn[2] - 1);
+                acc += (a == 0 ? 2.0 : 1.0) * (q == 0 ? 2.0 : 1.0) * (p == 0 ? 2.0 : 1.0) * esf[i3(gf, fi - gf.o[0], fj - gf.o[1], fk - gf.o[2])];
             }
     esc[c] = acc * (1.0 / 64.0);
-    const int ci = min(i, gc.n[0] - 2), cj = min(j, gc.n[1] - 2), ck = min(k, gc.n[2] - 2);      // ghost entries copy their neighbour
-    const long long b = i3(gf, 2 * ci, 2 * cj, 2 * ck);
+    const int ci = min(i, gc.gn[0] - 2), cj = min(j, gc.gn[1] - 2), ck = min(k, gc.gn[2] - 2);      // ghost entries copy their neighbour
+    const long long b = i3(gf, 2 * ci - gf.o[0], 2 * cj - gf.o[1], 2 * ck - gf.o[2]);
     double s = 0.0;
     for (int a = 0; a < 2; a++) for (int q = 0; q < 2; q++) for (int p = 0; p < 2; p++) s += enf[b + a * gf.s[0] + q * gf.s[1] + p * gf.s[2]];
     enc[c] = 0.125 * s;
@@ -436,7 +440,7 @@ __global__ __launch_bounds__(256) void k3_random(G3 g, double* __restrict__ v, u
     K3_PROLOGUE(g)
     unsigned h = (unsigned)(((unsigned)i * 73856093u) ^ ((unsigned)j * 19349663u) ^ ((unsigned)k * 83492791u)) ^ seed;
     h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
-    v[c] = (i < g.n[0] - 1 && j < g.n[1] - 1 && k < g.n[2] - 1) ? (double)h * (2.0 / 4294967296.0) - 1.0 : 0.0;
+    v[c] = (i < g.gn[0] - 1 && j < g.gn[1] - 1 && k < g.gn[2] - 1) ? (double)h * (2.0 / 4294967296.0) - 1.0 : 0.0;
 }
 
 // ---- heat ------------------------------------------------------------------------------------------------------------
@@ -456,12 +460,12 @@ template <bool SCALED> __global__ __launch_bounds__(256) void k3_heat_apply(Heat
     int wall = -1, ax = 0, hi = 0;
     for (int a = 0; a < 3 && wall < 0; a++) {
         if (idx[a] == 0) { wall = a; ax = a; hi = 0; }
-        else if (idx[a] == g.n[a] - 1) { wall = a + 3; ax = a; hi = 1; }
+        else if (idx[a] == g.gn[a] - 1) { wall = a + 3; ax = a; hi = 1; }
     }
     if (wall >= 0) {
         if (op.bc[wall] == PL_BC_FIXTEMP) r = t;
         else if (!hi) { const double kq = op.kk[ax][c] * TB(g.rd[ax], 0); r = kq * (T[c + g.s[ax]] - t); dg = -kq; }
-        else { const double kq = op.kk[ax][c - g.s[ax]] * TB(g.rd[ax], g.n[ax] - 2); r = kq * (t - T[c - g.s[ax]]); dg = kq; }
+        else { const double kq = op.kk[ax][c - g.s[ax]] * TB(g.rd[ax], g.gn[ax] - 2); r = kq * (t - T[c - g.s[ax]]); dg = kq; }
     } else {
         double fl = 0.0, dsum = 0.0;
         for (int a = 0; a < 3; a++) {
@@ -483,12 +487,12 @@ __global__ __launch_bounds__(256) void k3_heat_rhs(Heat3 op, const double* __res
     int wall = -1, ax = 0, hi = 0;
     for (int a = 0; a < 3 && wall < 0; a++) {
         if (idx[a] == 0) { wall = a; ax = a; hi = 0; }
-        else if (idx[a] == g.n[a] - 1) { wall = a + 3; ax = a; hi = 1; }
+        else if (idx[a] == g.gn[a] - 1) { wall = a + 3; ax = a; hi = 1; }
     }
     double r, dg = 1.0;
     if (wall >= 0) {
         r = bcv[wall];
-        if (op.bc[wall] != PL_BC_FIXTEMP) dg = hi ? op.kk[ax][c - g.s[ax]] * TB(g.rd[ax], g.n[ax] - 2) : -op.kk[ax][c] * TB(g.rd[ax], 0);
+        if (op.bc[wall] != PL_BC_FIXTEMP) dg = hi ? op.kk[ax][c - g.s[ax]] * TB(g.rd[ax], g.gn[ax] - 2) : -op.kk[ax][c] * TB(g.rd[ax], 0);
     } else {
         r = -Told[c] - op.cdt[c] * H[c];
         if (scaled) {
@@ -507,13 +511,50 @@ __global__ __launch_bounds__(256) void k3_heat_coef(G3 g, const double* __restri
 
 // ---- host <-> device layout ------------------------------------------------------------------------------------------
 // host arrays are C-order (nz, nx, ny) [optionally with ncomp interleaved components last]
+// (src / dst: the GLOBAL array; from_host also fills the ring of nodes around the block from it -- coefficient arrays need no exchange)
 __global__ __launch_bounds__(256) void k3_from_host(G3 g, const double* __restrict__ src, int ncomp, int comp, double* __restrict__ dst) {
-    K3_PROLOGUE(g)
-    dst[c] = src[(((long long)i * g.n[1] + j) * g.n[2] + k) * ncomp + comp];
+    const int lk = (int)(blockIdx.x * 64 + threadIdx.x) - 1, lj = (int)(blockIdx.y * 4 + threadIdx.y) - 1, li = (int)blockIdx.z - 1;
+    if (lk > g.n[2] || lj > g.n[1]) return;
+    const int i = li + g.o[0], j = lj + g.o[1], k = lk + g.o[2];
+    if (i < 0 || i >= g.gn[0] || j < 0 || j >= g.gn[1] || k < 0 || k >= g.gn[2]) return;
+    dst[i3(g, li, lj, lk)] = src[(((long long)i * g.gn[1] + j) * g.gn[2] + k) * ncomp + comp];
 }
 __global__ __launch_bounds__(256) void k3_to_host(G3 g, const double* __restrict__ src, int ncomp, int comp, double* __restrict__ dst) {
     K3_PROLOGUE(g)
-    dst[(((long long)i * g.n[1] + j) * g.n[2] + k) * ncomp + comp] = src[c];
+    dst[(((long long)i * g.gn[1] + j) * g.gn[2] + k) * ncomp + comp] = src[c];
+}
+// one plane of nodes normal to `axis` (local index `plane`, -1 .. n: the rings included) of na arrays <-> a dense buffer; the other
+// two axes run over -1 .. n, so that exchanging z, then x, then y carries the edge and corner nodes along (halo3)
+struct Slab3 { double* a[4]; int na; };
+__global__ __launch_bounds__(256) void k3_slab(G3 g, int axis, int plane, Slab3 sl, double* __restrict__ buf, int to_buf) {
+    const int A1 = axis == 0 ? 1 : 0, A2 = axis == 2 ? 1 : 2;       // the two in-plane axes, the faster one second
+    const int n1 = g.n[A1] + 2, n2 = g.n[A2] + 2;
+    const long long per = (long long)n1 * n2, total = per * sl.na;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        const int q = (int)(t / per); const long long e = t % per;
+        int id[3]; id[axis] = plane; id[A1] = (int)(e / n2) - 1; id[A2] = (int)(e % n2) - 1;
+        double* p = sl.a[q] + i3(g, id[0], id[1], id[2]);
+        if (to_buf) buf[t] = *p; else *p = buf[t];
+    }
+}
+// up to five dot products over the OWNED nodes of na consecutive arrays per vector (several ranks: the rings hold the neighbours' values)
+__global__ __launch_bounds__(256) void k3_dots_own(G3 g, int na, Dot5 d, double* __restrict__ part) {
+    double acc[5] = {0, 0, 0, 0, 0};
+    const long long rows = (long long)na * g.n[0] * g.n[1];
+    for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
+        const int q = (int)(r / ((long long)g.n[0] * g.n[1])); const int ij = (int)(r % ((long long)g.n[0] * g.n[1]));
+        const long long base = (long long)q * g.vol + i3(g, ij / g.n[1], ij % g.n[1], 0);
+        for (int kk = threadIdx.x; kk < g.n[2]; kk += 256)
+            for (int u = 0; u < d.n; u++) acc[u] += d.a[u][base + kk] * d.b[u][base + kk];
+    }
+    __shared__ double sh[5][4];
+    for (int u = 0; u < 5; u++) {
+        double a = acc[u];
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+        if ((threadIdx.x & 63) == 0) sh[u][threadIdx.x >> 6] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) part[5 * blockIdx.x + threadIdx.x] = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
 }
 
 // =====================================================================================================================
@@ -530,6 +571,14 @@ struct Lev3 {
 struct pl3_ctx {
     bool have_x = false, have_T = false;      // a device-resident Stokes / heat solution exists (pl3_get_solution)
     int device = 0; hipStream_t stream = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // several ranks (pl3_set_comm): Pz x Px x Py blocks of the node grid, rank = (pz Px + px) Py + py; the messages and host reductions
+    // go through a 2-D context that carries the transport (native RCCL / callback table / in-process group, pl_comm.hip) and whose stream
+    // this context then shares
+    pl_ctx* comm = nullptr; bool own_stream = true;
+    int P[3] = {1, 1, 1}, pc[3] = {0, 0, 0}, nranks = 1, rank = 0;
+    int gn[3] = {0, 0, 0}; std::vector<double> gcoord[3];     // the global grid
+    double* hbuf = nullptr; size_t hbuf_n = 0;                // halo exchange: send lo | send hi | recv lo | recv hi
+    long long halo_calls = 0, reduce_calls = 0;
     std::string err;
     G3Host geom;
     double *es = nullptr, *en = nullptr, *rho = nullptr; Op3 op{}; bool op_ready = false;
@@ -551,12 +600,21 @@ static int p3_fail(pl3_ctx* ctx, const std::string& m) { if (ctx) ctx->err = m; 
 #define P3_HIP(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return p3_fail(ctx, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
 #define P3_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 
-static int g3_build(pl3_ctx* ctx, G3Host& gh, const int n[3], const double* const c[3]) {
+// gn / c: the GLOBAL grid of the level; the block of this rank follows from ctx->P / ctx->pc: C = (gn - 1) / P cells per block, first
+// node pc C, the last block of an axis also owns the last node
+static int g3_build(pl3_ctx* ctx, G3Host& gh, const int gn[3], const double* const c[3]) {
     G3& g = gh.d;
-    for (int a = 0; a < 3; a++) { g.n[a] = n[a]; gh.c[a].assign(c[a], c[a] + n[a]); }
+    int n[3];
+    for (int a = 0; a < 3; a++) {
+        if ((gn[a] - 1) % ctx->P[a]) return p3_fail(ctx, "3-D grid: (nodes - 1) must be divisible by the number of blocks along every axis");
+        const int C = (gn[a] - 1) / ctx->P[a];
+        g.gn[a] = gn[a]; g.o[a] = ctx->pc[a] * C; g.n[a] = n[a] = C + (ctx->pc[a] == ctx->P[a] - 1 ? 1 : 0);
+        gh.c[a].assign(c[a], c[a] + gn[a]);
+    }
     const long long py = ((P3_PAD + n[2] + 1 + 15) / 16) * 16;
     g.s[2] = 1; g.s[1] = py; g.s[0] = (long long)(n[1] + 2) * py;
     g.vol = (long long)(n[0] + 2) * g.s[0];
+    for (int a = 0; a < 3; a++) n[a] = gn[a];                 // the tables are global
     size_t len[3], tot = 0;
     for (int a = 0; a < 3; a++) { len[a] = ((size_t)n[a] + 2 * PL_TOFF + 3) & ~(size_t)1; tot += 2 * len[a]; }
     std::vector<double> t(tot, 0.0);
@@ -593,6 +651,7 @@ extern "C" int pl3_create(pl3_ctx** out, int device, int nz, int nx, int ny, con
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { delete ctx; return p3_fail(nullptr, "pl3_create: stream creation failed"); }
     const int n[3] = {nz, nx, ny}; const double* c[3] = {zc, xc, yc};
+    for (int a = 0; a < 3; a++) { ctx->gn[a] = n[a]; ctx->gcoord[a].assign(c[a], c[a] + n[a]); }
     if (g3_build(ctx, ctx->geom, n, c)) { std::string m = ctx->err; delete ctx; return p3_fail(nullptr, m); }
     if (const char* e = getenv("PYLAMP_MG_NU3")) { int a = atoi(e); if (a >= 1 && a <= 6) { ctx->nu = a; ctx->nu_set = true; } }
     if (const char* e = getenv("PYLAMP_MG_NU3_FINE")) { int a = atoi(e); if (a >= 1 && a <= 6) ctx->nu_fine = a; }
@@ -614,13 +673,14 @@ extern "C" void pl3_destroy(pl3_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     free_levels3(ctx);
-    for (double* q : {ctx->es, ctx->en, ctx->rho, ctx->part, ctx->stage, ctx->hT, ctx->hH, ctx->hcdt, ctx->hrho, ctx->hcp, ctx->hbcv, ctx->htab}) if (q) (void)hipFree(q);
+    for (double* q : {ctx->es, ctx->en, ctx->rho, ctx->part, ctx->stage, ctx->hT, ctx->hH, ctx->hcdt, ctx->hrho, ctx->hcp, ctx->hbcv, ctx->htab, ctx->hbuf}) if (q) (void)hipFree(q);
     for (auto& v : ctx->vec) if (v[0]) (void)hipFree(v[0]);
     for (double* q : ctx->hk) if (q) (void)hipFree(q);
     for (double* q : ctx->hvec) if (q) (void)hipFree(q);
     if (ctx->hpart) (void)hipHostFree(ctx->hpart);
     if (ctx->geom.tables) (void)hipFree(ctx->geom.tables);
-    (void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1); (void)hipStreamDestroy(ctx->stream);
+    (void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 static int stage3(pl3_ctx* ctx, size_t bytes) {
@@ -630,22 +690,67 @@ static int stage3(pl3_ctx* ctx, size_t bytes) {
     ctx->stage_bytes = bytes;
     return 0;
 }
+// host arrays are GLOBAL on every rank: the block and the ring of nodes around it are taken from them; a download assembles the global
+// array from the blocks (own block + zeros, summed over the ranks)
 static int upload3(pl3_ctx* ctx, const double* host, int ncomp, double* const* dst) {
     const G3& g = ctx->geom.d;
-    const size_t bytes = (size_t)g.n[0] * g.n[1] * g.n[2] * ncomp * sizeof(double);
+    const size_t bytes = (size_t)g.gn[0] * g.gn[1] * g.gn[2] * ncomp * sizeof(double);
     P3_TRY(stage3(ctx, bytes));
     P3_HIP(ctx, hipMemcpyAsync(ctx->stage, host, bytes, hipMemcpyHostToDevice, ctx->stream));
-    for (int q = 0; q < ncomp; q++) hipLaunchKernelGGL(k3_from_host, grid3(g), dim3(64, 4), 0, ctx->stream, g, (const double*)ctx->stage, ncomp, q, dst[q]);
+    const dim3 gr((g.n[2] + 2 + 63) / 64, (g.n[1] + 2 + 3) / 4, g.n[0] + 2);
+    for (int q = 0; q < ncomp; q++) hipLaunchKernelGGL(k3_from_host, gr, dim3(64, 4), 0, ctx->stream, g, (const double*)ctx->stage, ncomp, q, dst[q]);
     P3_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
 static int download3(pl3_ctx* ctx, double* const* src, int ncomp, double* host) {
     const G3& g = ctx->geom.d;
-    const size_t bytes = (size_t)g.n[0] * g.n[1] * g.n[2] * ncomp * sizeof(double);
+    const size_t count = (size_t)g.gn[0] * g.gn[1] * g.gn[2] * ncomp, bytes = count * sizeof(double);
     P3_TRY(stage3(ctx, bytes));
+    if (ctx->nranks > 1) P3_HIP(ctx, hipMemsetAsync(ctx->stage, 0, bytes, ctx->stream));
     for (int q = 0; q < ncomp; q++) hipLaunchKernelGGL(k3_to_host, grid3(g), dim3(64, 4), 0, ctx->stream, g, (const double*)src[q], ncomp, q, ctx->stage);
     P3_HIP(ctx, hipMemcpyAsync(host, ctx->stage, bytes, hipMemcpyDeviceToHost, ctx->stream));
     P3_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->nranks > 1 && pl_allreduce_host(ctx->comm, host, (long long)count, 0)) return p3_fail(ctx, std::string("3-D download: ") + pl_last_error(ctx->comm));
+    return 0;
+}
+
+// ---- several ranks: halo exchange and reductions ------------------------------------------------------------------------------
+// One ring of nodes around the block is all the stencils reach (faces, the edge neighbours (i-1, j+1) ... of the momentum rows, and the
+// corner nodes of the full-weighting restriction): exchanged axis by axis -- z planes, then x planes including the z ring just
+// received, then y planes including both -- so that 6 messages carry all 26 neighbours' nodes.
+static int halo3(pl3_ctx* ctx, const G3& g, double* const* arr, int na) {
+    if (ctx->nranks <= 1) return 0;
+    ctx->halo_calls++;
+    for (int a = 0; a < 3; a++) {
+        if (ctx->P[a] == 1) continue;
+        const int A1 = a == 0 ? 1 : 0, A2 = a == 2 ? 1 : 2;
+        const long long cnt = (long long)na * (g.n[A1] + 2) * (g.n[A2] + 2);
+        if (ctx->hbuf_n < (size_t)(4 * cnt)) {
+            if (ctx->hbuf) { P3_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->hbuf); ctx->hbuf = nullptr; }
+            P3_HIP(ctx, hipMalloc((void**)&ctx->hbuf, (size_t)(4 * cnt) * sizeof(double)));
+            ctx->hbuf_n = (size_t)(4 * cnt);
+        }
+        Slab3 sl{}; sl.na = na; for (int q = 0; q < na; q++) sl.a[q] = arr[q];
+        const bool lo = ctx->pc[a] > 0, hi = ctx->pc[a] < ctx->P[a] - 1;
+        int step = 1; for (int b = a + 1; b < 3; b++) step *= ctx->P[b];          // rank distance of the neighbour along axis a
+        const unsigned nb = (unsigned)std::min<long long>((cnt + 255) / 256, 2048);
+        PlMsg m[2]; int nm = 0;
+        if (lo) { hipLaunchKernelGGL(k3_slab, dim3(nb), dim3(256), 0, ctx->stream, g, a, 0, sl, ctx->hbuf, 1);
+                  m[nm++] = PlMsg{ctx->rank - step, ctx->hbuf, cnt, ctx->hbuf + 2 * cnt, cnt}; }
+        if (hi) { hipLaunchKernelGGL(k3_slab, dim3(nb), dim3(256), 0, ctx->stream, g, a, g.n[a] - 1, sl, ctx->hbuf + cnt, 1);
+                  m[nm++] = PlMsg{ctx->rank + step, ctx->hbuf + cnt, cnt, ctx->hbuf + 3 * cnt, cnt}; }
+        if (pl_comm_sendrecv(ctx->comm, m, nm)) return p3_fail(ctx, std::string("3-D halo exchange: ") + pl_last_error(ctx->comm));
+        if (lo) hipLaunchKernelGGL(k3_slab, dim3(nb), dim3(256), 0, ctx->stream, g, a, -1, sl, ctx->hbuf + 2 * cnt, 0);
+        if (hi) hipLaunchKernelGGL(k3_slab, dim3(nb), dim3(256), 0, ctx->stream, g, a, g.n[a], sl, ctx->hbuf + 3 * cnt, 0);
+    }
+    P3_HIP(ctx, hipGetLastError());
+    return 0;
+}
+static int halo3_1(pl3_ctx* ctx, const G3& g, double* arr) { double* a[1] = {arr}; return halo3(ctx, g, a, 1); }
+static int allreduce3(pl3_ctx* ctx, double* v, int n, int op) {
+    if (ctx->nranks <= 1) return 0;
+    ctx->reduce_calls++;
+    if (pl_allreduce_host(ctx->comm, v, n, op)) return p3_fail(ctx, std::string("3-D all-reduce: ") + pl_last_error(ctx->comm));
     return 0;
 }
 static int need_vecs(pl3_ctx* ctx, int nvec) {
@@ -664,6 +769,37 @@ static int need_vecs(pl3_ctx* ctx, int nvec) {
     return 0;
 }
 
+// Several ranks (right after pl3_create, before any coefficients): this context becomes rank `comm`'s rank of a Pz x Px x Py block
+// layout, rank = (pz Px + px) Py + py.  comm: a 2-D context (pl_create on any small grid) whose communicator has been set
+// (pl_set_comm / pl_set_comm_2d / pl_set_comm_local with Pz * Px = the number of ranks); it must outlive this context.
+extern "C" int pl3_set_comm(pl3_ctx* ctx, pl_ctx* comm, int Pz, int Px, int Py) {
+    if (!ctx || !comm) return p3_fail(ctx, "pl3_set_comm: NULL argument");
+    if (Pz < 1 || Px < 1 || Py < 1 || Pz * Px * Py != comm->nranks) return p3_fail(ctx, "pl3_set_comm: Pz * Px * Py must equal the number of ranks of the communicator");
+    if (ctx->op_ready || ctx->hop_ready || !ctx->levels.empty()) return p3_fail(ctx, "pl3_set_comm: call it right after pl3_create");
+    if (comm->device != ctx->device) return p3_fail(ctx, "pl3_set_comm: the communicator context lives on another device");
+    P3_HIP(ctx, hipSetDevice(ctx->device));
+    P3_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream) { (void)hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
+    ctx->stream = comm->stream;                      // messages are ordered with this context's kernels
+    ctx->comm = comm; ctx->nranks = comm->nranks; ctx->rank = comm->rank;
+    ctx->P[0] = Pz; ctx->P[1] = Px; ctx->P[2] = Py;
+    ctx->pc[2] = ctx->rank % Py; ctx->pc[1] = (ctx->rank / Py) % Px; ctx->pc[0] = ctx->rank / (Py * Px);
+    for (int a = 0; a < 3; a++)
+        if (ctx->P[a] > 1 && (ctx->gn[a] - 1) / ctx->P[a] < 4) return p3_fail(ctx, "pl3_set_comm: at least 4 cells per block and axis");
+    const double* c[3] = {ctx->gcoord[0].data(), ctx->gcoord[1].data(), ctx->gcoord[2].data()};
+    return g3_build(ctx, ctx->geom, ctx->gn, c);
+}
+extern "C" int pl3_local_block(pl3_ctx* ctx, int first[3], int count[3]) {
+    for (int a = 0; a < 3; a++) { if (first) first[a] = ctx->geom.d.o[a]; if (count) count[a] = ctx->geom.d.n[a]; }
+    return 0;
+}
+// halo exchanges (3 phases each) and host all-reduces of this context so far; reset != 0 clears the counters
+extern "C" int pl3_comm_stats(pl3_ctx* ctx, int64_t out[2], int reset) {
+    if (out) { out[0] = ctx->halo_calls; out[1] = ctx->reduce_calls; }
+    if (reset) { ctx->halo_calls = 0; ctx->reduce_calls = 0; }
+    return 0;
+}
+
 // pylamp_stokes.py:116-122 extended dimension-wise: Kcont = DIM mineta / sum(avgd), Kbond = DIM^2 mineta / sum(avgd)^2
 extern "C" int pl3_stokes_set_coeffs(pl3_ctx* ctx, const double* etas, const double* etan, const double* rho, const double grav[3]) {
     if (!etas || !etan || !rho) return p3_fail(ctx, "pl3_stokes_set_coeffs: NULL argument");
@@ -674,13 +810,13 @@ extern "C" int pl3_stokes_set_coeffs(pl3_ctx* ctx, const double* etas, const dou
     d1[0] = ctx->es; P3_TRY(upload3(ctx, etas, 1, d1));
     d1[0] = ctx->en; P3_TRY(upload3(ctx, etan, 1, d1));
     d1[0] = ctx->rho; P3_TRY(upload3(ctx, rho, 1, d1));
-    const size_t N = (size_t)g.n[0] * g.n[1] * g.n[2];
+    const size_t N = (size_t)g.gn[0] * g.gn[1] * g.gn[2];
     double mes = INFINITY, men = INFINITY; bool nes = false, nen = false;
     for (size_t t = 0; t < N; t++) { if (etas[t] != etas[t]) nes = true; else mes = std::min(mes, etas[t]); if (etan[t] != etan[t]) nen = true; else men = std::min(men, etan[t]); }
     if (nes) mes = NAN; if (nen) men = NAN;
     const double mineta = (men < mes) ? men : mes;                  // python's min(a, b), pylamp_stokes.py:116-118
     double sum = 0.0;
-    for (int a = 0; a < 3; a++) sum += (ctx->geom.c[a].back() - ctx->geom.c[a].front()) / g.n[a];     // avgd = L / n (sic, :119-120)
+    for (int a = 0; a < 3; a++) sum += (ctx->geom.c[a].back() - ctx->geom.c[a].front()) / g.gn[a];     // avgd = L / n (sic, :119-120)
     Op3& op = ctx->op;
     op.g = g; op.es = ctx->es; op.en = ctx->en; op.rho = ctx->rho;
     op.Kc = 3.0 * mineta / sum; op.Kb = 9.0 * mineta / (sum * sum); op.iKc = 1.0 / op.Kc;
@@ -712,7 +848,7 @@ extern "C" int pl3_stokes_apply(pl3_ctx* ctx, const double* x, double* y) {
     if (!ctx->op_ready) return p3_fail(ctx, "stokes operator not set");
     P3_HIP(ctx, hipSetDevice(ctx->device));
     P3_TRY(need_vecs(ctx, 2));
-    P3_TRY(upload3(ctx, x, 4, ctx->vec[0]));
+    P3_TRY(upload3(ctx, x, 4, ctx->vec[0]));                 // (the upload fills the ring of nodes around the block as well)
     hipLaunchKernelGGL(k3_apply<false>, grid3(ctx->op.g), dim3(64, 4), 0, ctx->stream, ctx->op, cv4(ctx->vec[0]), wv4(ctx->vec[1]));
     P3_HIP(ctx, hipGetLastError());
     return download3(ctx, ctx->vec[1], 4, y);
@@ -748,6 +884,19 @@ extern "C" int pl3_stokes_apply_bench(pl3_ctx* ctx, int scaled, int reps, double
 static int dots3(pl3_ctx* ctx, long long n, int nd, const double* const* a, const double* const* b, double* out) {
     Dot5 d{}; d.n = nd;
     for (int q = 0; q < nd; q++) { d.a[q] = a[q]; d.b[q] = b[q]; }
+    if (ctx->nranks > 1) {
+        // several ranks: only the OWNED nodes count (the rings hold copies of the neighbours' values); n = m x (elements of one array
+        // of the finest grid or of a multigrid level), m <= 4 consecutive arrays per vector
+        const G3* g = nullptr;
+        if (n % ctx->geom.d.vol == 0 && n / ctx->geom.d.vol <= 4) g = &ctx->geom.d;
+        for (size_t l = 0; !g && l < ctx->levels.size(); l++) if (n % ctx->levels[l]->gh.d.vol == 0 && n / ctx->levels[l]->gh.d.vol <= 4) g = &ctx->levels[l]->gh.d;
+        if (!g) return p3_fail(ctx, "dots3: vector length matches no grid level (internal error)");
+        hipLaunchKernelGGL(k3_dots_own, dim3(D3_BLOCKS), dim3(256), 0, ctx->stream, *g, (int)(n / g->vol), d, ctx->part);
+        P3_HIP(ctx, hipMemcpyAsync(ctx->hpart, ctx->part, 5 * D3_BLOCKS * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        P3_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int q = 0; q < nd; q++) { double sum = 0.0; for (int k = 0; k < D3_BLOCKS; k++) sum += ctx->hpart[5 * k + q]; out[q] = sum; }
+        return allreduce3(ctx, out, nd, 0);
+    }
     hipLaunchKernelGGL(k3_dots, dim3(D3_BLOCKS), dim3(256), 0, ctx->stream, n, d, ctx->part);
     P3_HIP(ctx, hipMemcpyAsync(ctx->hpart, ctx->part, 5 * D3_BLOCKS * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     P3_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -781,8 +930,8 @@ static int vdots(pl3_ctx* ctx, long long vol, int na, int nd, double* const* con
 // ---- multigrid -----------------------------------------------------------------------------------------------------------
 static int build_levels3(pl3_ctx* ctx) {
     if (ctx->levels.empty()) {
-        int n[3] = {ctx->geom.d.n[0], ctx->geom.d.n[1], ctx->geom.d.n[2]};
-        std::vector<double> c[3] = {ctx->geom.c[0], ctx->geom.c[1], ctx->geom.c[2]};
+        int n[3] = {ctx->gn[0], ctx->gn[1], ctx->gn[2]};                     // GLOBAL node counts of the level
+        std::vector<double> c[3] = {ctx->gcoord[0], ctx->gcoord[1], ctx->gcoord[2]};
         for (int l = 0;; l++) {
             Lev3* L = new Lev3();
             const double* cc[3] = {c[0].data(), c[1].data(), c[2].data()};
@@ -794,6 +943,9 @@ static int build_levels3(pl3_ctx* ctx) {
             ctx->levels.push_back(L);
             bool stop = false;
             for (int a = 0; a < 3; a++) if ((n[a] - 1) % 2 || (n[a] - 1) / 2 < 4) stop = true;
+            // several ranks: every block is halved with the grid -- a block with an odd number of cells (or one that would shrink below
+            // two) ends the hierarchy here, and this level is smoothed as the coarsest one (more sweeps: coarse_sweeps by its size)
+            for (int a = 0; a < 3; a++) if (ctx->P[a] > 1 && (((n[a] - 1) / ctx->P[a]) % 2 || (n[a] - 1) / ctx->P[a] / 2 < 2)) stop = true;
             if (stop) break;
             for (int a = 0; a < 3; a++) {
                 std::vector<double> c2;
@@ -808,6 +960,7 @@ static int build_levels3(pl3_ctx* ctx) {
         if (l > 0) {
             Lev3* F = ctx->levels[l - 1];
             hipLaunchKernelGGL(k3_coarsen, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, F->gh.d, (const double*)F->es, (const double*)F->en, L->gh.d, L->es, L->en);
+            P3_TRY(halo3_1(ctx, L->gh.d, L->es)); P3_TRY(halo3_1(ctx, L->gh.d, L->en));      // the rows of this level and the next coarsening read the ring
         }
         L->op = ctx->op; L->op.g = L->gh.d; L->op.es = L->es; L->op.en = L->en; L->op.slave = (l == 0) ? ctx->op.slave : 0;
         // lambda_max of D^-1 A_vv by power iteration
@@ -820,12 +973,14 @@ static int build_levels3(pl3_ctx* ctx) {
         else for (int q = 0; q < 3; q++) hipLaunchKernelGGL(k3_random, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, L->gh.d, L->v[0][q], 777u + q);
         {   // the start vector must satisfy the constraints of THIS operator: close it
             for (int q = 0; q < 3; q++) P3_HIP(ctx, hipMemsetAsync(L->r[q], 0, (size_t)vol * sizeof(double), ctx->stream));
+            P3_TRY(halo3(ctx, L->gh.d, L->v[0], 3));
             hipLaunchKernelGGL(k3_close, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, wv3(L->v[0]), cv3(L->r));
         }
         double lam = warm ? L->lmax / 1.1 : 2.5, lam_prev = 0.0;
         for (int it = 0; it < 12; it++) {
             if (warm && it >= 1 && std::fabs(lam - lam_prev) < 0.01 * lam) break;
             lam_prev = lam;
+            P3_TRY(halo3(ctx, L->gh.d, L->v[0], 3));
             hipLaunchKernelGGL(k3_resid, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, cv3(L->v[0]), cv3(L->f), wv3(L->v[1]), 1);
             double* const* aa[2] = {L->v[1], L->v[0]}; double* const* bb[2] = {L->v[1], L->v[0]};
             double nn[2];
@@ -856,6 +1011,9 @@ static void smooth3(pl3_ctx* ctx, Lev3* L, double* const* f, int nsweep, double 
         if (k == 1 && zero_guess) for (int q = 0; q < 3; q++) vp.p[q] = nullptr;
         // the last sweep may write straight into the caller's arrays (the preconditioner's output) instead of a level buffer
         const W3 dst = (final_out && k == nsweep - 1) ? *final_out : wv3(L->v[nxt]);
+        // several ranks: the sweep reads the iterate one node into the ring (the first sweep from the zero guess: only the right-hand
+        // side, at a slave's master)
+        if (k == 0 && zero_guess) (void)halo3(ctx, L->gh.d, (double* const*)f, 3); else (void)halo3(ctx, L->gh.d, L->v[cur], 3);
         hipLaunchKernelGGL(k3_cheb, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, cv3(L->v[cur]), vp, cv3(f), dst, c1, c2,
                            (k == 0 && zero_guess) ? 1 : 0);
         prev = cur; cur = nxt;
@@ -866,7 +1024,7 @@ static void vcycle3(pl3_ctx* ctx, size_t l, double* const* f, int& out_buf, cons
     int cur = 0;
     if (l + 1 == ctx->levels.size()) {
         const G3& g = L->gh.d;
-        double ratio = 0.4 * std::pow((double)g.n[0] * g.n[1] * g.n[2], 2.0 / 3.0); if (ratio < 30.0) ratio = 30.0;
+        double ratio = 0.4 * std::pow((double)g.gn[0] * g.gn[1] * g.gn[2], 2.0 / 3.0); if (ratio < 30.0) ratio = 30.0;
         int n = std::max((int)std::sqrt(ratio), ctx->coarse_sweeps); if (n > 150) n = 150;
         smooth3(ctx, L, f, n, ratio, true, cur);
         out_buf = cur;
@@ -875,17 +1033,20 @@ static void vcycle3(pl3_ctx* ctx, size_t l, double* const* f, int& out_buf, cons
     // From 10^6 nodes up: V(1,1) on the finest level, V(3,3) below (the 2-D solver's choice, pl_solver.hip) -- 257^3: 494 ms per solve
     // pair with 24 iterations against 539 ms with 23 for V(2,2) throughout (1/4: 492, 2/3: 499, 1/2: 504; tools/run_nu3.sh).
     // PYLAMP_MG_NU3 / PYLAMP_MG_NU3_FINE override the two counts.
-    const bool big = (long long)ctx->levels[0]->gh.d.n[0] * ctx->levels[0]->gh.d.n[1] * ctx->levels[0]->gh.d.n[2] >= 1000000;
+    const bool big = (long long)ctx->gn[0] * ctx->gn[1] * ctx->gn[2] >= 1000000;
     const int nu_fine = ctx->nu_fine > 0 ? ctx->nu_fine : (big && !ctx->nu_set ? 1 : ctx->nu);
     const int nu_rest = (big && !ctx->nu_set) ? 3 : ctx->nu;
     const int nu = l == 0 ? nu_fine : nu_rest;
     smooth3(ctx, L, f, nu, ctx->cheb_ratio, true, cur);
+    (void)halo3(ctx, L->gh.d, L->v[cur], 3);
     hipLaunchKernelGGL(k3_resid, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, cv3(L->v[cur]), cv3(f), wv3(L->r), 0);
     Lev3* C = ctx->levels[l + 1];
+    (void)halo3(ctx, L->gh.d, L->r, 3);
     hipLaunchKernelGGL(k3_restrict, grid3(C->gh.d), dim3(64, 4), 0, ctx->stream, L->gh.d, C->op, cv3(L->r), wv3(C->f));
     int cb = 0;
     vcycle3(ctx, l + 1, C->f, cb);
     const int nxt = (cur + 1) % 3;
+    (void)halo3(ctx, C->gh.d, C->v[cb], 3);              // (the ring of L->v[cur] is still the one exchanged for the residual)
     hipLaunchKernelGGL(k3_prolong_add, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, C->gh.d, cv3(C->v[cb]), cv3(L->v[cur]), wv3(L->v[nxt]));
     cur = nxt;
     smooth3(ctx, L, f, nu, ctx->cheb_ratio, false, cur, final_out);
@@ -952,7 +1113,7 @@ static int bicgstab3(pl3_ctx* ctx, long long vol, int na, const Op3Fn& A, const 
     static const bool trace3 = getenv("PYLAMP_SOLVER_TRACE") != nullptr;
     // velocity-error estimate (n |r_cont| + |(M^-1 r)_vel|) / |x_vel| as in pl_solver.hip (na = 4: three velocity arrays + pressure)
     const bool use_est = etol > 0.0 && na == 4 && M;
-    const double n_amp = (double)std::max(g.n[0], std::max(g.n[1], g.n[2]));
+    const double n_amp = (double)std::max(g.gn[0], std::max(g.gn[1], g.gn[2]));
     double tol = rtol, est_rec = 0.0, a_mom = 1.0;
     int est_checks = 0;
     bool resume = false, broke = false;
@@ -1066,23 +1227,32 @@ static int bicgstab3(pl3_ctx* ctx, long long vol, int na, const Op3Fn& A, const 
 
 // hydrostatic pressure guess: with v = 0 the interior z-momentum rows reduce to -2 Kc rDz_i (P[i] - P[i-1]) = b_z; integrate down
 // every column, anchor cell to zero (same construction as pl_solver.hip)
-__global__ __launch_bounds__(256) void k3_hydro(Op3 op, double* __restrict__ P) {
-    const int k = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+// (several ranks: every block integrates from zero at its own top; coltot receives the block's column totals, and k3_hydro_add the sum
+//  of the totals of the blocks above -- pl3_stokes_solve)
+__global__ __launch_bounds__(256) void k3_hydro(Op3 op, double* __restrict__ P, double* __restrict__ coltot) {
+    const int lk = blockIdx.x * 64 + threadIdx.x, lj = blockIdx.y * 4 + threadIdx.y;
     const G3& g = op.g;
-    if (k >= g.n[2] || j >= g.n[1]) return;
+    if (lk >= g.n[2] || lj >= g.n[1]) return;
+    const int j = lj + g.o[1], k = lk + g.o[2];
     const double* r = op.rho;
-    const int jn = (j + 1 < g.n[1]) ? 1 : 0, kn = (k + 1 < g.n[2]) ? 1 : 0;
+    const int jn = (j + 1 < g.gn[1]) ? 1 : 0, kn = (k + 1 < g.gn[2]) ? 1 : 0;
     double acc = 0.0;
-    for (int i = 0; i < g.n[0]; i++) {
-        const long long c = i3(g, i, j, k);
-        if (i >= 1 && i <= g.n[0] - 2)
+    for (int li = 0; li < g.n[0]; li++) {
+        const int i = li + g.o[0];
+        const long long c = i3(g, li, lj, lk);
+        if (i >= 1 && i <= g.gn[0] - 2)
             acc += 0.25 * ((r[c] + r[c + jn * g.s[1]]) + (r[c + kn * g.s[2]] + r[c + jn * g.s[1] + kn * g.s[2]])) * op.grav[0] / (2.0 * op.Kc * TB(g.rD[0], i));
-        P[c] = (i >= g.n[0] - 1 || j >= g.n[1] - 1 || k >= g.n[2] - 1) ? 0.0 : acc;
+        P[c] = (i >= g.gn[0] - 1 || j >= g.gn[1] - 1 || k >= g.gn[2] - 1) ? 0.0 : acc;
     }
+    if (coltot) coltot[(long long)lj * g.n[2] + lk] = acc;
+}
+__global__ __launch_bounds__(256) void k3_hydro_add(G3 g, double* __restrict__ P, const double* __restrict__ above) {
+    K3_PROLOGUE(g)
+    if (i < g.gn[0] - 1 && j < g.gn[1] - 1 && k < g.gn[2] - 1) P[c] += above[(long long)lj * g.n[2] + lk];
 }
 __global__ __launch_bounds__(256) void k3_shift(G3 g, double* __restrict__ P, const double* __restrict__ anchor_val) {
     K3_PROLOGUE(g)
-    if (i < g.n[0] - 1 && j < g.n[1] - 1 && k < g.n[2] - 1) P[c] -= *anchor_val;
+    if (i < g.gn[0] - 1 && j < g.gn[1] - 1 && k < g.gn[2] - 1) P[c] -= *anchor_val;
 }
 
 extern "C" int pl3_stokes_solve(pl3_ctx* ctx, const double* rhs, double* x, int use_x0, double rtol, int maxit, pl_solve_stats* stats) {
@@ -1105,11 +1275,13 @@ extern "C" int pl3_stokes_solve(pl3_ctx* ctx, const double* rhs, double* x, int 
     bool defl_active = false; double yAw = 1.0;
     double* const* W = ctx->vec[13];
     Op3Fn A = [&](double* const* in, double* const* out) -> int {
+        P3_TRY(halo3(ctx, g, in, 4));
         hipLaunchKernelGGL(k3_apply<true>, grid3(g), dim3(64, 4), 0, ctx->stream, ctx->op, cv4(in), wv4(out));
         napply++; return 0;
     };
     Op3Fn M = [&](double* const* in, double* const* out) -> int {
         Lev3* L0 = ctx->levels[0];
+        P3_TRY(halo3_1(ctx, g, in[3]));             // S^-1 r_p of the neighbour cell (A_vp z_p) reads the pressure residual one node beyond the block
         hipLaunchKernelGGL(k3_stage1, grid3(g), dim3(64, 4), 0, ctx->stream, ctx->op, cv4(in), out[3], wv3(L0->f));
         int ob = 0;
         if (ctx->levels.size() > 1) {           // the post-smoothing sweep of the finest level writes the velocities into out[0..2] itself
@@ -1122,6 +1294,7 @@ extern "C" int pl3_stokes_solve(pl3_ctx* ctx, const double* rhs, double* x, int 
         nprec++;
         if (defl_active) {                  // z += w yw.(r - A z) / yw.(A w); the continuity rows of A z come from z's velocities alone
             const double* a1[2] = {ctx->dfl_y, ctx->dfl_y}; const double* b1[2] = {in[3], ctx->dfl_t}; double o[2];
+            P3_TRY(halo3(ctx, g, out, 3));
             hipLaunchKernelGGL(k3_cont_rows, grid3(g), dim3(64, 4), 0, ctx->stream, ctx->op, cv3(out), ctx->dfl_t);
             P3_TRY(dots3(ctx, vol, 2, a1, b1, o));
             const double coef = (o[0] - o[1]) / yAw;
@@ -1133,8 +1306,38 @@ extern "C" int pl3_stokes_solve(pl3_ctx* ctx, const double* rhs, double* x, int 
     double ref = 0.0;
     {
         for (int q = 0; q < 3; q++) P3_HIP(ctx, hipMemsetAsync(XH[q], 0, (size_t)vol * sizeof(double), ctx->stream));
-        hipLaunchKernelGGL(k3_hydro, dim3((g.n[2] + 63) / 64, (g.n[1] + 3) / 4), dim3(64, 4), 0, ctx->stream, ctx->op, XH[3]);
-        P3_HIP(ctx, hipMemcpyAsync(ctx->part, XH[3] + i3(g, 3, 2, 2), sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));   // anchor value
+        if (ctx->nranks == 1) {
+            hipLaunchKernelGGL(k3_hydro, dim3((g.n[2] + 63) / 64, (g.n[1] + 3) / 4), dim3(64, 4), 0, ctx->stream, ctx->op, XH[3], (double*)nullptr);
+            P3_HIP(ctx, hipMemcpyAsync(ctx->part, XH[3] + i3(g, 3, 2, 2), sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));   // anchor value
+        } else {
+            // every block integrated from zero at its top: add the column totals of the blocks above (same block column), then the anchor
+            // value -- one table [Pz][nx][ny] and one scalar summed over the ranks on the host (once per solve)
+            const long long cols = (long long)g.n[1] * g.n[2], gcols = (long long)g.gn[1] * g.gn[2];
+            double* coltot = ctx->vec[5][0];                    // scratch (a work vector of the iteration, free before it starts)
+            hipLaunchKernelGGL(k3_hydro, dim3((g.n[2] + 63) / 64, (g.n[1] + 3) / 4), dim3(64, 4), 0, ctx->stream, ctx->op, XH[3], coltot);
+            std::vector<double> mine((size_t)cols), tab((size_t)ctx->P[0] * gcols, 0.0);
+            P3_HIP(ctx, hipMemcpyAsync(mine.data(), coltot, (size_t)cols * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            P3_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            for (int jj = 0; jj < g.n[1]; jj++) for (int kk = 0; kk < g.n[2]; kk++)
+                tab[(size_t)ctx->pc[0] * gcols + (size_t)(g.o[1] + jj) * g.gn[2] + (g.o[2] + kk)] = mine[(size_t)jj * g.n[2] + kk];
+            P3_TRY(allreduce3(ctx, tab.data(), (int)tab.size(), 0));
+            for (int jj = 0; jj < g.n[1]; jj++) for (int kk = 0; kk < g.n[2]; kk++) {
+                double a = 0.0;
+                for (int q = 0; q < ctx->pc[0]; q++) a += tab[(size_t)q * gcols + (size_t)(g.o[1] + jj) * g.gn[2] + (g.o[2] + kk)];
+                mine[(size_t)jj * g.n[2] + kk] = a;
+            }
+            P3_HIP(ctx, hipMemcpyAsync(coltot, mine.data(), (size_t)cols * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(k3_hydro_add, grid3(g), dim3(64, 4), 0, ctx->stream, g, XH[3], (const double*)coltot);
+            double av[1] = {0.0};
+            const int ai = ctx->op.anchor[0] - g.o[0], aj = ctx->op.anchor[1] - g.o[1], ak = ctx->op.anchor[2] - g.o[2];
+            if (ai >= 0 && ai < g.n[0] && aj >= 0 && aj < g.n[1] && ak >= 0 && ak < g.n[2])
+                P3_HIP(ctx, hipMemcpyAsync(av, XH[3] + i3(g, ai, aj, ak), sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            P3_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            P3_TRY(allreduce3(ctx, av, 1, 0));
+            P3_HIP(ctx, hipMemcpyAsync(ctx->part, av, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            P3_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            P3_HIP(ctx, hipMemsetAsync(coltot, 0, (size_t)cols * sizeof(double), ctx->stream));
+        }
         hipLaunchKernelGGL(k3_shift, grid3(g), dim3(64, 4), 0, ctx->stream, g, XH[3], (const double*)ctx->part);
         P3_TRY(A(XH, ctx->vec[5]));
         for (int c = 0; c < 4; c++) hipLaunchKernelGGL(k3_axpby, g1(vol), dim3(256), 0, ctx->stream, vol, ctx->vec[4][c], 1.0, (const double*)B[c], -1.0, (const double*)ctx->vec[5][c]);
@@ -1145,6 +1348,7 @@ extern "C" int pl3_stokes_solve(pl3_ctx* ctx, const double* rhs, double* x, int 
     }
     if (use_x0) { if (x) P3_TRY(upload3(ctx, x, 4, X)); }
     else for (int c = 0; c < 4; c++) P3_HIP(ctx, hipMemcpyAsync(X[c], XH[c], (size_t)vol * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    P3_TRY(halo3(ctx, g, X, 3));
     hipLaunchKernelGGL(k3_close, grid3(g), dim3(64, 4), 0, ctx->stream, ctx->op, wv3(X), cv3(B));
     double* const* w[10] = {ctx->vec[0], ctx->vec[1], ctx->vec[2], ctx->vec[3], ctx->vec[4], ctx->vec[5], ctx->vec[6], ctx->vec[7], ctx->vec[8], ctx->vec[9]};
     static const bool defl_on = !(getenv("PYLAMP_DEFLATE") && atoi(getenv("PYLAMP_DEFLATE")) == 0);
@@ -1156,6 +1360,7 @@ extern "C" int pl3_stokes_solve(pl3_ctx* ctx, const double* rhs, double* x, int 
         hipLaunchKernelGGL(k3_defl_setup, grid3(g), dim3(64, 4), 0, ctx->stream, ctx->op, wv4(U), ctx->dfl_y);
         auto denominator = [&]() -> int {
             const double* a1[1] = {ctx->dfl_y}; const double* b1[1] = {ctx->dfl_t}; double o[1];
+            P3_TRY(halo3(ctx, g, W, 3));
             hipLaunchKernelGGL(k3_cont_rows, grid3(g), dim3(64, 4), 0, ctx->stream, ctx->op, cv3(W), ctx->dfl_t);
             P3_TRY(dots3(ctx, vol, 1, a1, b1, o));
             yAw = o[0];
@@ -1213,10 +1418,10 @@ extern "C" int pl3_heat_set_coeffs(pl3_ctx* ctx, const double* zmp, const double
     for (int q = 0; q < 7; q++) { double* d1[1] = {dst[q]}; P3_TRY(upload3(ctx, src[q], 1, d1)); }
     const double* mp[3] = {zmp, xmp, ymp};
     size_t len[3], tot = 0;
-    for (int a = 0; a < 3; a++) { len[a] = (size_t)g.n[a] + 2 * PL_TOFF + 2; tot += len[a]; }
+    for (int a = 0; a < 3; a++) { len[a] = (size_t)g.gn[a] + 2 * PL_TOFF + 2; tot += len[a]; }
     std::vector<double> t(tot, 0.0);
     size_t off = 0, offs[3];
-    for (int a = 0; a < 3; a++) { offs[a] = off; for (int i = 1; i < g.n[a]; i++) t[off + i + PL_TOFF] = 1.0 / (mp[a][i] - mp[a][i - 1]); off += len[a]; }
+    for (int a = 0; a < 3; a++) { offs[a] = off; for (int i = 1; i < g.gn[a]; i++) t[off + i + PL_TOFF] = 1.0 / (mp[a][i] - mp[a][i - 1]); off += len[a]; }
     if (!ctx->htab) P3_HIP(ctx, hipMalloc((void**)&ctx->htab, tot * sizeof(double)));
     P3_HIP(ctx, hipMemcpy(ctx->htab, t.data(), tot * sizeof(double), hipMemcpyHostToDevice));
     if (!ctx->hbcv) P3_HIP(ctx, hipMalloc((void**)&ctx->hbcv, 6 * sizeof(double)));
@@ -1266,6 +1471,7 @@ extern "C" int pl3_heat_solve(pl3_ctx* ctx, const double* rhs, double* x, double
     hipLaunchKernelGGL(k3_heat_rhs, grid3(g), dim3(64, 4), 0, ctx->stream, ctx->hop, (const double*)ctx->hT, (const double*)ctx->hH, (const double*)ctx->hbcv, B[0], 1);
     int napply = 0;
     Op3Fn A = [&](double* const* in, double* const* out) -> int {
+        P3_TRY(halo3(ctx, g, in, 1));
         hipLaunchKernelGGL(k3_heat_apply<true>, grid3(g), dim3(64, 4), 0, ctx->stream, ctx->hop, (const double*)in[0], out[0]);
         napply++; return 0;
     };

@@ -1236,8 +1236,9 @@ struct PlSolver {
     int bc_key[4] = {-1, -1, -1, -1};
     int repl_start = -1;        // multi-rank: first REPLICATED level (all-gathered, solved redundantly by every rank);
                                 // the finer levels are distributed row slabs with halo exchanges
-    long long repl_max_nodes = 150000;   // PYLAMP_MG_REPL_NODES: a level this small costs less to compute redundantly
-                                         // (~9 launch-bound kernels) than its 8 halo exchanges per cycle
+    long long repl_max_nodes = 300000;   // PYLAMP_MG_REPL_NODES: a level this small costs less to compute redundantly (two tile kernels
+                                         // since round 3) than its halo exchanges per cycle (150 000 until round 4: the 513^2 level of the
+                                         // 2049^2 grid was distributed: 4 more exchanges per BiCGStab iteration than one all-gather costs)
     // BiCGStab work vectors (3 planes each)
     double *r = nullptr, *rt = nullptr, *p = nullptr, *v = nullptr, *s = nullptr, *t = nullptr, *y = nullptr,
            *z = nullptr, *b = nullptr, *x = nullptr, *xb = nullptr, *dx = nullptr, *r0 = nullptr, *xh = nullptr;
@@ -3583,19 +3584,24 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
                               !getenv("PYLAMP_NO_DIRECT");
     if (force_direct) { st->iterations = 0; st->converged = 0; st->reserved_ = 0; st->rel_residual = 1.0; st->error_estimate = 0.0; }
     else PL_TRY(bicgstab(ctx, S, g, 3, A, &M, S->b, S->x, use_x0, rtol, maxit, w, st, ref, S->etol, 2));
-    if (beyond && !force_direct && st->converged) {
-        // unscaled residual of the accepted iterate: D_r^-1 (b_s - A_s x) against D_r^-1 b_s
+    // Beyond the gate the solve is judged by the UNSCALED residual ||b - A x|| / ||b|| of the iterate it returns: measured on the stock
+    // model, velocity error / unscaled residual = 140 (LU path: 4.4e-7 / 3.2e-9) and 290 (iterative path: 4.1e-3 / 1.4e-5), i.e. the
+    // domain's n = max(nz, nx) = 201 within a factor 1.5 -- the same amplification the continuity term of the estimate uses.  Hence
+    // error_estimate = max(estimate, n x unscaled residual), and -- FP64 cannot do better than ~4e-7 on such a system (the refined
+    // direct solve of the oracle needs an extended-precision residual) -- the bound it has to meet is the drop-in's own 1e-6.
+    auto judge_unscaled = [&]() -> int {
         double du[2];
         PL_TRY(A(S->x, S->t));
         hipLaunchKernelGGL(k_stokes_unscaled_pair, grid2d(g), dim3(64, 4), 0, ctx->stream, sop, (const double*)S->b, (const double*)S->t, S->s, S->t);
         PL_TRY(dots(ctx, S, g, 3, S->s, S->s, S->t, S->t, du));
         const double rel_u = du[1] > 0.0 ? std::sqrt(du[0] / du[1]) : 0.0;
-        if (trace_t) fprintf(stderr, "[pylamp stokes] viscosity contrast %.1e beyond the gate: unscaled relative residual %.3e\n", ctx->visc_contrast, rel_u);
-        if (!(rel_u <= std::max(rtol, 1e-7))) {
-            st->converged = 0;
-            st->error_estimate = std::max(st->error_estimate, rel_u);      // (no bound is known: at least this)
-        }
-    }
+        const double est_u = (double)std::max(ctx->nz, ctx->nx) * rel_u;
+        if (trace_t) fprintf(stderr, "[pylamp stokes] viscosity contrast %.1e beyond the gate: unscaled relative residual %.3e, estimate %.3e\n", ctx->visc_contrast, rel_u, est_u);
+        st->error_estimate = std::max(st->error_estimate, est_u);
+        st->converged = (st->rel_residual <= rtol && std::isfinite(est_u) && est_u <= 1e-6) ? 1 : 0;
+        return 0;
+    };
+    if (beyond && !force_direct && st->converged) PL_TRY(judge_unscaled());
     if (trace_t) {
         tph[4] = now();
         fprintf(stderr, "[pylamp stokes] phases: hierarchy + eigenvalues %.2f ms, deflation vector %.2f ms, hydrostatic state + reference norm %.2f ms, "
@@ -3624,6 +3630,7 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
         PL_TRY(rc_direct);
         st->iterations += it0;
         st->used_direct = 1;
+        if (beyond) PL_TRY(judge_unscaled());
     }
     double ms = 0;
     PL_TRY(pl_timer_stop_ms(ctx, &ms));

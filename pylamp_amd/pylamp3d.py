@@ -56,6 +56,19 @@ class Context3:
         self.h = h
         self._fin = weakref.finalize(self, lib.pl3_destroy, h)
 
+    def attach_comm(self, comm_ctx, Pz, Px, Py):
+        """Make this context one block of a Pz x Px x Py decomposition (right after construction).  comm_ctx: a 2-D
+        pylamp_amd Context whose communicator is set (torch.distributed under torchrun, or Context.attach_local for virtual
+        ranks) with Pz * Px * Py ranks; it is kept alive with this context."""
+        self.check(self.lib.pl3_set_comm(self.handle(), comm_ctx.handle(), int(Pz), int(Px), int(Py)))
+        self._comm_ctx = comm_ctx
+        self.layout = (int(Pz), int(Px), int(Py))
+
+    def comm_stats(self, reset=False):
+        v = (C.c_int64 * 2)()
+        self.check(self.lib.pl3_comm_stats(self.handle(), v, 1 if reset else 0))
+        return int(v[0]), int(v[1])
+
     def handle(self):
         """Native handle for a library call; a closed context raises instead of handing NULL to C."""
         if self.h is None:
@@ -215,3 +228,49 @@ def solve_heat(A, rtol=1e-12, maxit=2000, resident=False):
     ctx.check(ctx.lib.pl3_heat_solve(ctx.handle(), None, _lib.dptr(x), float(rtol), int(maxit), C.byref(st)))
     A.last_stats = st.as_dict()
     return x
+
+
+class VirtualCluster3:
+    """Pz x Px x Py virtual ranks in ONE process on one GPU, each a Context3 block with its own host thread, joined by the
+    library's in-process transport (as driver.VirtualCluster for the 2-D step): the rehearsal of BASELINE config 5 on several
+    GPUs -- the same halo pack / unpack kernels, block-wise multigrid levels and all-reduced dot products, only the wire is a
+    device-to-device copy."""
+
+    def __init__(self, nx, grid, Pz, Px, Py, device=0):
+        import concurrent.futures
+        from ._context import Context
+        lib = _lib.load()
+        self.lib = lib
+        self.size = int(Pz) * int(Px) * int(Py)
+        g = C.c_void_p()
+        if lib.pl_local_group_create(C.byref(g), self.size) != 0:
+            raise Exception("pl_local_group_create failed")
+        self.group = g
+        self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=self.size)
+        ncol = 16 * self.size + 1                      # the carrier context only carries the transport: any grid its 1 x size layout divides
+        tiny = [np.linspace(0, 1, 17), np.linspace(0, 1, ncol)]
+        self.comms, self.ctxs = [], []
+        for r in range(self.size):
+            c2 = Context([17, ncol], tiny, device=device, attach_dist=False)
+            c2.attach_local(g, r, 1, self.size)
+            c3 = Context3(nx, grid, device)
+            c3.attach_comm(c2, Pz, Px, Py)
+            self.comms.append(c2); self.ctxs.append(c3)
+
+    def all(self, fn, timeout=1800):
+        """fn(ctx3, rank) on every rank at once (the calls are collective); results in rank order."""
+        import concurrent.futures as cf
+        futs = [self.pool.submit(fn, c, r) for r, c in enumerate(self.ctxs)]
+        done, pending = cf.wait(futs, timeout=timeout, return_when=cf.FIRST_EXCEPTION)
+        if pending:
+            self.lib.pl_local_group_abort(self.group)
+            cf.wait(futs, timeout=60)
+        return [f.result(timeout=1) for f in futs]
+
+    def close(self):
+        for c in self.ctxs:
+            c.close()
+        for c in self.comms:
+            c.close()
+        self.pool.shutdown(wait=False)
+        self.lib.pl_local_group_destroy(self.group)

@@ -229,3 +229,67 @@ def test_config5_257_cubed_resident():
     T = P3.solution(Ah, heat=True)
     assert np.linalg.norm(Ah @ T - rh) / np.linalg.norm(rh) < 1e-10
     ctx.close()
+
+
+def _mantle3(n, L):
+    grid = [np.linspace(0, L[d], n[d]) for d in range(3)]
+    mid = [np.append(0.5 * (g[1:] + g[:-1]), g[-1] + 0.5 * (g[-1] - g[-2])) for g in grid]
+
+    def field(c):
+        Z, X, Y = np.meshgrid(*c, indexing="ij", sparse=True)
+        return 273 + 1350 * np.clip(Z / L[0], 0, 1) + 60 * np.sin(3 * np.pi * X / L[1]) * np.sin(np.pi * Z / L[0]) * np.cos(2 * np.pi * Y / L[2])
+    eta = lambda T: np.clip(1e20 * np.exp(120e3 / (8.31446 * T) - 120e3 / (8.31446 * 1623)), 1e17, 1e23)
+    Tn = field(grid)
+    return grid, mid, Tn, eta(Tn), eta(field(mid)), 3300 / (3.5e-5 * (Tn - 1623) + 1)
+
+
+@pytest.mark.parametrize("n,layout", [([33, 49, 65], (2, 2, 2)), ([65, 65, 65], (2, 2, 2)), ([33, 33, 65], (1, 1, 4)), ([49, 33, 33], (3, 2, 1)),
+                                      ([33, 41, 49], (2, 2, 2))])
+def test_blocks_3d_equal_one_rank(n, layout):
+    """BASELINE config 5 on several ranks, rehearsed with Pz x Px x Py virtual ranks on one GPU (pylamp3d.VirtualCluster3: the
+    multi-GPU code path except for the wire): operator, right-hand side, Stokes solve and heat solve of the block-decomposed
+    contexts against the one-rank context -- operator to rounding, the same multigrid hierarchy and iteration counts, solutions
+    to 1e-8.  Parity stays UNPINNED (no 3-D reference exists); this pins the decomposition against the one-rank code."""
+    from pylamp_amd import pylamp3d as P3
+    L = [660e3, 660e3 * (n[1] - 1) / (n[0] - 1), 660e3 * (n[2] - 1) / (n[0] - 1)]
+    grid, mid, Tn, es, en, rho = _mantle3(n, L)
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal(4 * int(np.prod(n)))
+    k = np.full(n, 4.0); cp = np.full(n, 1250.0); H = np.full(n, 0.02e-6 / 3300)
+    dt = 0.67 * (L[0] / (n[0] - 1)) ** 2 / np.max(2 * 4.0 / (rho * 1250.0)) * 5
+    hbc, hbv = [0, 1, 1, 0, 1, 1], [273.0, 0, 0, 1623.0, 0, 0]
+    # one rank
+    c1 = P3.Context3(n, grid)
+    A1, rhs1 = P3.makeStokesMatrix(n, grid, es, en, rho, ctx=c1)
+    y1 = A1 @ x
+    x1 = P3.solve(A1)
+    st1 = A1.last_stats
+    H1, _ = P3.makeDiffusionMatrix(n, grid, mid, Tn, [k, k, k], cp, rho, H, hbc, hbv, dt, ctx=c1)
+    T1 = P3.solve_heat(H1); ht1 = H1.last_stats
+    lev1 = A1.mg_info()[0]
+    c1.close()
+    assert st1["converged"] == 1 and ht1["converged"] == 1
+    # blocks
+    vc = P3.VirtualCluster3(n, grid, *layout)
+
+    def run(ctx, rank):
+        A, rhs = P3.makeStokesMatrix(n, grid, es, en, rho, ctx=ctx)
+        y = A @ x
+        xs = P3.solve(A)
+        Hm, _ = P3.makeDiffusionMatrix(n, grid, mid, Tn, [k, k, k], cp, rho, H, hbc, hbv, dt, ctx=ctx)
+        T = P3.solve_heat(Hm)
+        return rhs, y, xs, A.last_stats, T, Hm.last_stats, A.mg_info()[0], ctx.comm_stats()
+    res = vc.all(run)
+    vc.close()
+    for rhs, y, xs, st, T, ht, lev, cs in res:
+        assert np.array_equal(rhs, rhs1)
+        assert np.abs(y - y1).max() <= 1e-13 * np.abs(y1).max()
+        # blocks are halved with the grid: the hierarchy is the one-rank one as long as every block keeps an even number of cells
+        # (all cases but the last, whose 5-cell blocks end it one level early: more sweeps on the coarsest level, a few more iterations)
+        assert lev <= lev1 and (lev == lev1 or n == [33, 41, 49]) and st["converged"] == 1 and ht["converged"] == 1
+        assert abs(st["iterations"] - st1["iterations"]) <= (3 if lev == lev1 else 8), (st, st1)       # (BiCGStab counts move by one or two with the summation order of the dot products)
+        (v, p), (v1, p1) = P3.x2vp(xs, n), P3.x2vp(x1, n)
+        ev = np.sqrt(sum(np.sum((a - b) ** 2) for a, b in zip(v, v1)) / sum(np.sum(b ** 2) for b in v1))
+        assert ev < 1e-8 and relerr(p, p1) < 1e-7, (ev, relerr(p, p1))
+        assert relerr(T, T1) < 1e-10 and abs(ht["iterations"] - ht1["iterations"]) <= 1
+        assert cs[0] > 0 and cs[1] > 0                    # halo exchanges and all-reduces happened
