@@ -166,52 +166,90 @@ def cpu_baseline(n=257, tracdens=16, steps=1):
             "steps_per_s": round(steps / dt, 5)}
 
 
+def layout3(world):
+    """Pz x Px x Py of BASELINE config 5 on N GPUs: 2 -> 1x1x2, 4 -> 1x2x2, 8 -> 2x2x2 (PYLAMP_DECOMP3="PzxPxxPy" overrides)."""
+    e = os.environ.get("PYLAMP_DECOMP3")
+    if e:
+        p = [int(v) for v in e.lower().split("x")]
+        if len(p) == 3 and p[0] * p[1] * p[2] == world:
+            return tuple(p)
+    return {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 2, 2), 8: (2, 2, 2)}.get(world, (1, 1, world))
+
+
 def bench_3d(args):
-    """--config 3d257 (BASELINE config 5, one GPU): 3-D staggered Stokes + heat at n^3 nodes -- a "step" is one Stokes solve
-    (multigrid-preconditioned BiCGStab, default tolerance) plus one implicit heat solve on the same grid.  No reference
-    implementation exists in 3-D (parity unpinned; validation by extrusion / manufactured solutions in tests/test_hip_3d.py)."""
+    """--config 3d257 (BASELINE config 5: "3D 257^3 staggered Stokes + heat, 1 -> 8 MI355X weak scaling"): 3-D staggered Stokes + heat
+    -- a "step" is one Stokes solve (multigrid-preconditioned BiCGStab, default tolerance) plus one implicit heat solve on the same
+    grid.  N > 1: every GPU holds one (n-1)^3-cell block of a Pz x Px x Py decomposition (weak scaling: the global grid is
+    ((n-1) Pz + 1) x ((n-1) Px + 1) x ((n-1) Py + 1) nodes over a correspondingly larger domain).  No reference implementation exists in 3-D
+    (parity unpinned; validation by extrusion / manufactured solutions / blocks against one rank in tests/test_hip_3d.py)."""
     from pylamp_amd import pylamp3d as P3
-    n = args.n3
-    L = [660e3, 660e3, 660e3]
-    grid = [np.linspace(0, L[d], n) for d in range(3)]
+    rank, world, local_rank, dist, red_dev, barrier, device = init_dist(args)
+    P = layout3(world)
+    nb = args.n3
+    n = [(nb - 1) * P[d] + 1 for d in range(3)]
+    L = [660e3 * P[d] for d in range(3)]
+    grid = [np.linspace(0, L[d], n[d]) for d in range(3)]
     mid = [np.append(0.5 * (g[1:] + g[:-1]), g[-1] + 0.5 * (g[-1] - g[-2])) for g in grid]
-    rng = np.random.default_rng(20260105)
     def field(c):                         # T-dependent mantle: conductive profile + a 3-D perturbation
         Z, X, Y = np.meshgrid(*c, indexing="ij", sparse=True)
         return 273 + 1350 * np.clip(Z / L[0], 0, 1) + 60 * np.sin(3 * np.pi * X / L[1]) * np.sin(np.pi * Z / L[0]) * np.cos(2 * np.pi * Y / L[2])
     eta = lambda T: np.clip(1e20 * np.exp(120e3 / (8.31446 * T) - 120e3 / (8.31446 * 1623)), 1e17, 1e23)
     Tn = field(grid)
     es = eta(Tn); en = eta(field(mid)); rho = 3300 / (3.5e-5 * (Tn - 1623) + 1)
-    ctx = P3.Context3([n, n, n], grid)
-    A, _ = P3.makeStokesMatrix([n, n, n], grid, es, en, rho, ctx=ctx)
-    k = np.full((n, n, n), 4.0); cp = np.full((n, n, n), 1250.0); H = np.full((n, n, n), 0.02e-6 / 3300)
-    dt = 0.67 * (L[0] / (n - 1)) ** 2 / np.max(2 * 4.0 / (rho * 1250.0))
-    Ah, _ = P3.makeDiffusionMatrix([n, n, n], grid, mid, Tn, [k, k, k], cp, rho, H, [0, 1, 1, 0, 1, 1], [273.0, 0, 0, 1623.0, 0, 0], dt, ctx=ctx)
+    ctx = P3.Context3(n, grid, device)
+    carrier = None
+    if world > 1:                         # the 2-D carrier context brings the transport (pylamp_amd/parallel.py), see pl3_set_comm
+        from pylamp_amd._context import Context
+        ncol = 16 * world + 1
+        carrier = Context([17, ncol], [np.linspace(0, 1, 17), np.linspace(0, 1, ncol)], device=device)
+        ctx.attach_comm(carrier, *P)
+    A, _ = P3.makeStokesMatrix(n, grid, es, en, rho, ctx=ctx)
+    k = np.full(n, 4.0); cp = np.full(n, 1250.0); H = np.full(n, 0.02e-6 / 3300)
+    dt = 0.67 * (L[0] / (n[0] - 1)) ** 2 / np.max(2 * 4.0 / (rho * 1250.0))
+    Ah, _ = P3.makeDiffusionMatrix(n, grid, mid, Tn, [k, k, k], cp, rho, H, [0, 1, 1, 0, 1, 1], [273.0, 0, 0, 1623.0, 0, 0], dt, ctx=ctx)
+    del es, en, rho, Tn, k, cp, H
     its, hits, res = [], [], []
     # device-resident solves: coefficients are on the GPU, the solutions stay there (pl3_get_solution fetches them afterwards);
     # every solve is a cold start from the hydrostatic state / from zero
     for s_ in range(args.warmup):
         P3.solve(A, resident=True); P3.solve_heat(Ah, resident=True)
+    ctx.comm_stats(reset=True)
+    barrier()
     t0 = time.perf_counter()
     for s_ in range(args.steps):
         P3.solve(A, resident=True); its.append(A.last_stats["iterations"]); res.append(A.last_stats["rel_residual"])
         conv = A.last_stats["converged"]
         P3.solve_heat(Ah, resident=True); hits.append(Ah.last_stats["iterations"])
+    barrier()
     el = time.perf_counter() - t0
-    cells = (n - 1) ** 3
-    ms_s = A.apply_bench(20, True); ms_p = A.apply_bench(20, False)
-    ach = 80.0 * n ** 3 / (ms_s * 1e-3) / 1e9
-    out = {"metric": "stokes_heat_3d_cell_updates_per_s", "value": round(cells * args.steps / el, 1), "unit": "cell-updates/s", "n_gpus": 1,
-           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3), "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": "3D %d^3 nodes staggered Stokes (4 DOF/node, T-dependent viscosity 1e20..1e23) + implicit heat, one solve of each per step; "
-                                  "device-resident (coefficients uploaded before, solutions left on the GPU: no PCIe in the timed region)" % n, "parallelism": "1 GPU",
-                      "parity": "unpinned (the reference is 2-D only)"},
-           "stokes_iterations": its, "stokes_converged": conv, "stokes_rel_residual": [float("%.3g" % r) for r in res], "heat_iterations": hits,
-           "roofline": {"kernel": "k3_apply<true> (3-D row-scaled Stokes stencil)", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": 80.0 * n ** 3,
-                        "avg_launch_ms": round(ms_s, 5), "plain_operator_ms": round(ms_p, 5)}}
-    print(json.dumps(out))
+    if dist is not None:
+        import torch
+        t = torch.tensor([el], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    cells = (n[0] - 1) * (n[1] - 1) * (n[2] - 1)
+    if rank == 0:
+        ms_s = A.apply_bench(20, True); ms_p = A.apply_bench(20, False)
+        ach = 80.0 * nb ** 3 / (ms_s * 1e-3) / 1e9          # this rank's block
+        out = {"metric": "stokes_heat_3d_cell_updates_per_s", "value": round(cells * args.steps / el, 1), "unit": "cell-updates/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "3D %dx%dx%d nodes staggered Stokes (4 DOF/node, T-dependent viscosity 1e20..1e23) + implicit heat, one solve of each per step; "
+                                      "device-resident (coefficients uploaded before, solutions left on the GPU: no PCIe in the timed region)" % tuple(n),
+                          "parallelism": "1 GPU" if world == 1 else "%d x %d x %d blocks of %d^3 nodes, one-node halos exchanged axis by axis, host all-reduced dot products" % (P + (nb,)),
+                          "parity": "unpinned (the reference is 2-D only)"},
+               "stokes_iterations": its, "stokes_converged": conv, "stokes_rel_residual": [float("%.3g" % r) for r in res], "heat_iterations": hits,
+               "roofline": {"kernel": "k3_apply<true> (3-D row-scaled Stokes stencil)", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": 80.0 * nb ** 3,
+                            "avg_launch_ms": round(ms_s, 5), "plain_operator_ms": round(ms_p, 5)}}
+        if world > 1:
+            hc, rc = ctx.comm_stats()
+            out["comm_calls_per_step"] = {"halo_exchanges": round(hc / float(args.steps), 1), "host_allreduces": round(rc / float(args.steps), 1)}
+            out["scaling_note"] = "no multi-GPU node was available to the build: N > 1 has only been rehearsed with virtual ranks / gloo on one GPU"
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def spawn_ranks(n):
@@ -257,30 +295,9 @@ def spawn_ranks(n):
         sys.exit(rc if 0 < rc < 256 else 1)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--config", default="2d", choices=["2d", "3d257"], help="3d257: BASELINE config 5 on one GPU (3-D Stokes + heat)")
-    ap.add_argument("--grid3", dest="n3", type=int, default=257, help="nodes per side of the 3-D configuration")
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--grid", dest="n", type=int, default=2049, help="nodes per side (default 2049: BASELINE config 3)")
-    ap.add_argument("--tracdens", type=int, default=16)
-    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
-                    help="N > 1: strong = the same grid split over N GPUs (BASELINE's metric); weak = one --grid slab per GPU")
-    ap.add_argument("--model", choices=["mantle", "block"], default="mantle",
-                    help="mantle (default, the headline): T-dependent convection with heat; block: the 10^3 falling block of config 1 "
-                         "(heat off) at the same size -- the slower-converging Stokes problem, a secondary figure")
-    ap.add_argument("--transport", choices=["torch", "native"], default="torch",
-                    help="N > 1: torch.distributed callbacks (default) or direct RCCL calls on the solver stream (opt-in)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--apply-reps", type=int, default=50)
-    args = ap.parse_args()
-    if args.config == "3d257":
-        return bench_3d(args)
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        return spawn_ranks(args.gpus)
-
+def init_dist(args):
+    """torch.distributed set-up of one rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment: torchrun, or spawn_ranks).
+    Returns rank, world, local_rank, the dist module (None on one rank), the device of the timing reductions, a barrier and the GPU."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -316,6 +333,34 @@ def main():
     if world > 1 and not os.environ.get("PYLAMP_DEVICE") and os.environ.get("PYLAMP_DIST_BACKEND", "nccl") != "nccl":
         import torch                                                # rehearsal: several gloo ranks may share the GPUs of the box
         device = local_rank % max(torch.cuda.device_count(), 1)
+    return rank, world, local_rank, dist, red_dev, barrier, device
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="2d", choices=["2d", "3d257"], help="3d257: BASELINE config 5 on one GPU (3-D Stokes + heat)")
+    ap.add_argument("--grid3", dest="n3", type=int, default=257, help="nodes per side of the 3-D configuration")
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--grid", dest="n", type=int, default=2049, help="nodes per side (default 2049: BASELINE config 3)")
+    ap.add_argument("--tracdens", type=int, default=16)
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: strong = the same grid split over N GPUs (BASELINE's metric); weak = one --grid slab per GPU")
+    ap.add_argument("--model", choices=["mantle", "block"], default="mantle",
+                    help="mantle (default, the headline): T-dependent convection with heat; block: the 10^3 falling block of config 1 "
+                         "(heat off) at the same size -- the slower-converging Stokes problem, a secondary figure")
+    ap.add_argument("--transport", choices=["torch", "native"], default="torch",
+                    help="N > 1: torch.distributed callbacks (default) or direct RCCL calls on the solver stream (opt-in)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--apply-reps", type=int, default=50)
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)
+    if args.config == "3d257":
+        return bench_3d(args)
+
+    rank, world, local_rank, dist, red_dev, barrier, device = init_dist(args)
     sim = build_sim(args.n, args.tracdens, 20260103, device, rank, world, args.scaling, args.model)
     ctx = sim.ctx
     reports = []
