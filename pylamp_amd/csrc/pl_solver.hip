@@ -2335,9 +2335,12 @@ __host__ __device__ constexpr int mgt_post_nn(int NS, int TS) { return (TS + 2 *
 
 // NS: sweeps of the pre-smoothing sequence, the first from the zero guess included (1..3).  L0: level 0 of the Stokes
 // preconditioner -- the right-hand side is computed from the scaled residual rs (stage1_node) instead of read.
-template <int NS, bool L0, int TS>
-__global__ __launch_bounds__(mgt_nt(mgt_pre_nn(NS, TS))) void k_mg_pre(MgTileArgs a) {
-    constexpr int H = NS + 1, HC = H + 1, CR = TS + 2 * HC, NN = CR * CR, NPT = mgt_npt(NN), NT = mgt_nt(NN);
+// EXT = 1 (a level DISTRIBUTED over several ranks): the region is one node wider, so that the pre-smoothed iterate comes out valid NS
+// nodes around the tile -- the tiles at the rim of the rank's block write it into the halo ring as well (the same numbers the
+// neighbour computes for its own nodes), and k_mg_post finds there what it needs without an exchange of the iterate.
+template <int NS, bool L0, int TS, int EXT = 0>
+__global__ __launch_bounds__(mgt_nt(mgt_pre_nn(NS + EXT, TS))) void k_mg_pre(MgTileArgs a) {
+    constexpr int H = NS + 1 + EXT, HC = H + 1, CR = TS + 2 * HC, NN = CR * CR, NPT = mgt_npt(NN), NT = mgt_nt(NN);
     __shared__ double V[2][2][NN];                  // two iterates; V[1] holds the viscosity planes until the rows are set up
     __shared__ double ZP[L0 ? NN : 1];
     __shared__ double TAB[4][CR + 4];
@@ -2345,7 +2348,7 @@ __global__ __launch_bounds__(mgt_nt(mgt_pre_nn(NS, TS))) void k_mg_pre(MgTileArg
     const PlGeom& g = a.op.g;
     const int tid = threadIdx.x;
     const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x % a.tiles_x;
-    const int ti0 = ty * TS, tj0 = tx * TS;
+    const int ti0 = g.gi0 + ty * TS, tj0 = g.gj0 + tx * TS;          // tiles cover this rank's block (global node indices)
     const int ci0 = ti0 - HC, cj0 = tj0 - HC;
     MgtTab t; t.es = ES; t.en = EN; t.rdz = TAB[0]; t.rDz = TAB[1]; t.rdx = TAB[2]; t.rDx = TAB[3];
     mgt_load_table(TAB[0], a.op.rdz, ci0 - 1, CR + 3, g.nz); mgt_load_table(TAB[1], a.op.rDz, ci0 - 1, CR + 3, g.nz);
@@ -2363,7 +2366,7 @@ __global__ __launch_bounds__(mgt_nt(mgt_pre_nn(NS, TS))) void k_mg_pre(MgTileArg
         depth[q] = have ? min(min(ra, CR - 1 - ra), min(rb, CR - 1 - rb)) : -1;
         kz[q] = mgt_classify<true>(a.op, CR, CR, ci0, cj0, ra, rb);
         kx[q] = mgt_classify<false>(a.op, CR, CR, ci0, cj0, ra, rb);
-        const bool inmem = i >= -PL_RING && i < g.nz + PL_RING && j >= -PL_RING && j < g.nx + PL_RING;
+        const bool inmem = i - g.gi0 >= -PL_RING && i - g.gi0 < g.lnz + PL_RING && j - g.gj0 >= -PL_RING && j - g.gj0 < g.lnx + PL_RING;
         const long long c = pl_idx(g, i - g.gi0, j - g.gj0);
         const double* const fsrc = L0 ? a.rs : a.f;
         if (kz[q].on) kz[q].f = fsrc[c + kz[q].d];
@@ -2388,7 +2391,7 @@ __global__ __launch_bounds__(mgt_nt(mgt_pre_nn(NS, TS))) void k_mg_pre(MgTileArg
             const int ra = depth[q] >= 0 ? idx / CR : 0, rb = depth[q] >= 0 ? idx % CR : 0, i = ci0 + ra, j = cj0 + rb;
             if (kz[q].on) kz[q].f = kz[q].f * mgt_dg(kz[q]) + 2.0 * a.sop.Kc * TAB[1][ra + 1] * (ZP[kz[q].cm] - ZP[kz[q].cm - CR]);
             if (kx[q].on) kx[q].f = kx[q].f * mgt_dg(kx[q]) + 2.0 * a.sop.Kc * TAB[3][rb + 1] * (ZP[kx[q].cm] - ZP[kx[q].cm - 1]);
-            if (depth[q] >= HC && i < g.nz && j < g.nx) {      // the tile itself: keep f and z_p
+            if (depth[q] >= HC && i < g.nz && j < g.nx && i - g.gi0 < g.lnz && j - g.gj0 < g.lnx) {      // the tile itself: keep f and z_p
                 const long long c = pl_idx(g, i - g.gi0, j - g.gj0);
                 a.fout[c] = kz[q].interior ? kz[q].f : 0.0; a.fout[c + P] = kx[q].interior ? kx[q].f : 0.0; a.z[c + 2 * P] = ZP[idx];
             }
@@ -2430,13 +2433,18 @@ __global__ __launch_bounds__(mgt_nt(mgt_pre_nn(NS, TS))) void k_mg_pre(MgTileArg
     for (int q = 0; q < NPT; q++) {
         const int idx = tid + q * NT;
         if (depth[q] >= HC - 1) {
-            const int ra = idx / CR, rb = idx % CR, i = ci0 + ra, j = cj0 + rb;
             double v0, rz = 0.0, rx = 0.0;
             if (kz[q].interior) rz = kz[q].f - mgt_av_z(kz[q], CR, V[cur][0], V[cur][1], v0);
             if (kx[q].interior) rx = kx[q].f - mgt_av_x(kx[q], CR, V[cur][0], V[cur][1], v0);
             V[nxt][0][idx] = rz; V[nxt][1][idx] = rx;
-            if (depth[q] >= HC && i < g.nz && j < g.nx) {
-                const long long c = pl_idx(g, i - g.gi0, j - g.gj0);
+        }
+        // the iterate goes to memory: the tile's own nodes, and (EXT) the nodes of the halo ring NS deep around the rank's block
+        if (depth[q] >= HC - (EXT ? NS : 0)) {
+            const int ra = idx / CR, rb = idx % CR, i = ci0 + ra, j = cj0 + rb, li = i - g.gi0, lj = j - g.gj0;
+            const bool owned = li >= 0 && li < g.lnz && lj >= 0 && lj < g.lnx;
+            const bool ring = EXT && !owned && li >= -NS && li < g.lnz + NS && lj >= -NS && lj < g.lnx + NS;
+            if (i >= 0 && i < g.nz && j >= 0 && j < g.nx && ((owned && depth[q] >= HC) || ring)) {
+                const long long c = pl_idx(g, li, lj);
                 a.v[c] = V[cur][0][idx]; a.v[c + P] = V[cur][1][idx];
             }
         }
@@ -2445,8 +2453,8 @@ __global__ __launch_bounds__(mgt_nt(mgt_pre_nn(NS, TS))) void k_mg_pre(MgTileArg
     // ---- full-weighting restriction (restrict_node) onto the coarse nodes of the tile
     const PlGeom& gc = a.opc.g;
     for (int idx = tid; idx < (TS / 2) * (TS / 2); idx += NT) {
-        const int I = ty * (TS / 2) + idx / (TS / 2), J = tx * (TS / 2) + idx % (TS / 2);
-        if (I >= gc.nz || J >= gc.nx) continue;
+        const int I = (ti0 >> 1) + idx / (TS / 2), J = (tj0 >> 1) + idx % (TS / 2);
+        if (I >= gc.nz || J >= gc.nx || 2 * I - g.gi0 >= g.lnz || 2 * J - g.gj0 >= g.lnx) continue;      // (only the coarse nodes of this rank's block)
         const int b0 = (2 * I - ci0) * CR + (2 * J - cj0);
         int d; double s;
         double oz = 0.0, ox = 0.0;
@@ -2480,7 +2488,7 @@ __global__ __launch_bounds__(mgt_nt(mgt_post_nn(NS, TS))) void k_mg_post(MgTileA
     const PlGeom& g = a.op.g; const PlGeom& gc = a.opc.g;
     const int tid = threadIdx.x;
     const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x % a.tiles_x;
-    const int ti0 = ty * TS, tj0 = tx * TS;
+    const int ti0 = g.gi0 + ty * TS, tj0 = g.gj0 + tx * TS;
     const int ci0 = ti0 - HC, cj0 = tj0 - HC;
     MgtTab t; t.es = ES; t.en = EN; t.rdz = TAB[0]; t.rDz = TAB[1]; t.rdx = TAB[2]; t.rDx = TAB[3];
     mgt_load_table(TAB[0], a.op.rdz, ci0 - 1, CR + 3, g.nz); mgt_load_table(TAB[1], a.op.rDz, ci0 - 1, CR + 3, g.nz);
@@ -2497,7 +2505,7 @@ __global__ __launch_bounds__(mgt_nt(mgt_post_nn(NS, TS))) void k_mg_post(MgTileA
         depth[q] = have ? min(min(ra, CR - 1 - ra), min(rb, CR - 1 - rb)) : -1;
         kz[q] = mgt_classify<true>(a.op, CR, CR, ci0, cj0, ra, rb);
         kx[q] = mgt_classify<false>(a.op, CR, CR, ci0, cj0, ra, rb);
-        const bool inmem = i >= -PL_RING && i < g.nz + PL_RING && j >= -PL_RING && j < g.nx + PL_RING;
+        const bool inmem = i - g.gi0 >= -PL_RING && i - g.gi0 < g.lnz + PL_RING && j - g.gj0 >= -PL_RING && j - g.gj0 < g.lnx + PL_RING;
         const long long c = pl_idx(g, i - g.gi0, j - g.gj0);
         if (kz[q].on) kz[q].f = a.f[c + kz[q].d];
         if (kx[q].on) kx[q].f = a.f[c + (long long)kx[q].d * g.pitch + P];
@@ -2508,7 +2516,7 @@ __global__ __launch_bounds__(mgt_nt(mgt_post_nn(NS, TS))) void k_mg_post(MgTileA
     }
     for (int idx = tid; idx < ENN; idx += NT) {
         const int I = eI0 + idx / ECR, J = eJ0 + idx % ECR;
-        const bool inmem = I >= -PL_RING && I < gc.nz + PL_RING && J >= -PL_RING && J < gc.nx + PL_RING;
+        const bool inmem = I - gc.gi0 >= -PL_RING && I - gc.gi0 < gc.lnz + PL_RING && J - gc.gj0 >= -PL_RING && J - gc.gj0 < gc.lnx + PL_RING;
         const long long cc = pl_idx(gc, I - gc.gi0, J - gc.gj0);
         EC[0][idx] = inmem ? a.ec[cc] : 0.0; EC[1][idx] = inmem ? a.ec[cc + gc.plane] : 0.0;
     }
@@ -2562,7 +2570,9 @@ __global__ __launch_bounds__(mgt_nt(mgt_post_nn(NS, TS))) void k_mg_post(MgTileA
                 mgt_cheb(kz[q], kx[q], CR, V[cur][0], V[cur][1], pvz[q], pvx[q], k == 0 ? 0.0 : a.c1[k], a.c2[k], oz, ox);
                 if (k == NS - 1) {
                     const int ra = idx / CR, rb = idx % CR, i = ci0 + ra, j = cj0 + rb;
-                    if (i < g.nz && j < g.nx) { const long long c = pl_idx(g, i - g.gi0, j - g.gj0); a.out[c] = oz * a.oscale; a.out[c + a.out_plane] = ox * a.oscale; }
+                    if (i < g.nz && j < g.nx && i - g.gi0 < g.lnz && j - g.gj0 < g.lnx) {
+                        const long long c = pl_idx(g, i - g.gi0, j - g.gj0); a.out[c] = oz * a.oscale; a.out[c + a.out_plane] = ox * a.oscale;
+                    }
                 } else { V[cur ^ 1][0][idx] = oz; V[cur ^ 1][1][idx] = ox; }
             }
         }
@@ -2772,9 +2782,21 @@ static bool mg_fused_level_ok(pl_ctx* ctx, const PlSolver* S, size_t l) {
     const MgLevel* L = S->levels[l];
     // several ranks: the REPLICATED levels (every rank holds and computes the whole level) run the tile kernels like one rank does --
     // they are the latency-bound ones; a level whose own or whose coarse grid is distributed keeps the staged path with its exchanges
-    if (L->dist || S->levels[l + 1]->dist || L->f32 || L->op.szz) return false;
+    if (L->f32 || L->op.szz) return false;
     const PlGeom& g = L->gh.d;
-    if ((long long)g.nz * g.nx > S->fused_max_nodes) return false;
+    int npre_, npost_;
+    level_nu(S, l, npre_, npost_);
+    if (L->dist) {
+        // a DISTRIBUTED level (round 4): tiles over the rank's block, right-hand side exchanged npre + 2 deep, the iterate written into
+        // the ring by the rim tiles (k_mg_pre<.., EXT = 1>), the coarse correction exchanged 4 deep unless its level is replicated.
+        // Level 0 (stage 1 of the block preconditioner inside the tile kernel) stays with the staged path on several ranks.
+        const bool dist_fused = !(getenv("PYLAMP_MG_FUSED_DIST") && atoi(getenv("PYLAMP_MG_FUSED_DIST")) == 0);      // (read per call: tests switch it)
+        const MgLevel* C = S->levels[l + 1];
+        if (!dist_fused || l == 0 || npre_ + 2 > std::min(g.lnz, g.lnx) || npre_ + 3 > PL_RING) return false;
+        if (C->dist && std::min(C->gh.d.lnz, C->gh.d.lnx) < 4) return false;
+        if ((g.gi0 & 1) || (g.gj0 & 1)) return false;
+    } else if (S->levels[l + 1]->dist) return false;
+    if ((long long)g.lnz * g.lnx > S->fused_max_nodes) return false;
     if (S->use_tail && l > 0 && (long long)g.nz * g.nx <= S->tail_max_nodes && S->levels.size() - l <= PL_TAIL_MAX_LEVELS) return false;   // the tail kernel's levels
     int npre, npost;
     level_nu(S, l, npre, npost);
@@ -2794,19 +2816,28 @@ static void vcycle_fused_level(pl_ctx* ctx, PlSolver* S, size_t l, const double*
     a.op = L->op; a.opc = C->op;
     a.f = rs ? (const double*)L->f : f; a.fout = L->f; a.v = L->v[0]; a.fc = C->f;
     // tile edge: 32 on the large levels (halo recomputation 1.7x instead of 2.6x at three sweeps; one workgroup per CU), 16 below
-    const int TS = (long long)g.nz * g.nx >= S->tile32_min_nodes ? 32 : MGT_TS;
-    a.tiles_x = (g.nx + TS - 1) / TS;
-    const dim3 grid((unsigned)(a.tiles_x * ((g.nz + TS - 1) / TS)));
+    const int TS = (long long)g.lnz * g.lnx >= S->tile32_min_nodes ? 32 : MGT_TS;
+    a.tiles_x = (g.lnx + TS - 1) / TS;
+    const dim3 grid((unsigned)(a.tiles_x * ((g.lnz + TS - 1) / TS)));
     cheb_coeffs(L->lmax, S->cheb_ratio, npre, a.c1, a.c2);
     if (rs) { a.sop = *sop; a.rs = rs; a.z = z; }
 #define MGT_PRE(NS, L0) do { if (TS == 32) hipLaunchKernelGGL((k_mg_pre<NS, L0, 32>), grid, dim3(mgt_nt(mgt_pre_nn(NS, 32))), 0, ctx->stream, a); \
                              else hipLaunchKernelGGL((k_mg_pre<NS, L0, MGT_TS>), grid, dim3(mgt_nt(mgt_pre_nn(NS, MGT_TS))), 0, ctx->stream, a); } while (0)
-    if (rs) { if (npre == 1) MGT_PRE(1, true); else if (npre == 2) MGT_PRE(2, true); else MGT_PRE(3, true); }
+#define MGT_PRE_X(NS) do { if (TS == 32) hipLaunchKernelGGL((k_mg_pre<NS, false, 32, 1>), grid, dim3(mgt_nt(mgt_pre_nn(NS + 1, 32))), 0, ctx->stream, a); \
+                           else hipLaunchKernelGGL((k_mg_pre<NS, false, MGT_TS, 1>), grid, dim3(mgt_nt(mgt_pre_nn(NS + 1, MGT_TS))), 0, ctx->stream, a); } while (0)
+    if (L->dist) {
+        (void)pl_halo(ctx, g, (double*)a.f, 2, g.plane, npre + 2);          // ONE exchange on the way down: the right-hand side
+        if (npre == 1) MGT_PRE_X(1); else if (npre == 2) MGT_PRE_X(2); else MGT_PRE_X(3);
+        if (!C->dist) (void)pl_gather_blocks(ctx, C->gh.d, C->f, 2, C->gh.d.plane);      // replicated coarse level: everybody's restricted residual
+    }
+    else if (rs) { if (npre == 1) MGT_PRE(1, true); else if (npre == 2) MGT_PRE(2, true); else MGT_PRE(3, true); }
     else { if (npre == 1) MGT_PRE(1, false); else if (npre == 2) MGT_PRE(2, false); else MGT_PRE(3, false); }
 #undef MGT_PRE
+#undef MGT_PRE_X
     double* ec = nullptr;
     bool wf = false;
     vcycle<double>(ctx, S, l + 1, C->f, &ec, &wf, nullptr, 1.0, 0, nullptr);      // (takes the tile kernels itself where it can)
+    if (L->dist && C->dist) (void)pl_halo(ctx, C->gh.d, ec, 2, C->gh.d.plane, 4);  // ONE exchange on the way up: the coarse correction
     a.ec = ec; a.out = final_out ? final_out : L->v[2]; a.oscale = final_out ? final_scale : 1.0; a.out_plane = g.plane;
     cheb_coeffs(L->lmax, S->cheb_ratio, npost, a.c1, a.c2);
 #define MGT_POST(NS) do { if (TS == 32) hipLaunchKernelGGL((k_mg_post<NS, 32>), grid, dim3(mgt_nt(mgt_post_nn(NS, 32))), 0, ctx->stream, a); \

@@ -49,6 +49,8 @@ struct PlStepState {
     // stay in the order of the sort that opened the epoch; slot[t] is the epoch index of the tracer now at sorted position t.
     int* slot = nullptr; int* slot2 = nullptr;
     bool epoch_on = false; int epoch_age = 0;
+    long long epoch_len = 0;                         // entries of the epoch-ordered arrays in use (= n on one rank; several ranks: tracers that have
+                                                     // left keep their entry until the next re-layout, arrivals and injected tracers append theirs)
     // Lazy columns: RHO, ETA (rewritten by the next property update) and the tracer velocities (rewritten by the next advection) of
     // the tracers [0, lazy_n) are still in PRE-sort order in f2[RHO], f2[ETA], tmp[0], tmp[1]; dest maps them (flush_lazy).
     bool lazy_pending = false, lazy_inject = false; long long lazy_n = 0;
@@ -543,6 +545,8 @@ struct SortOpts {
     int del_outside = 0; double Lz = 0.0, Lx = 0.0; long long* removed = nullptr;     // fence off: delete leavers of the domain
     const pl_step_config* inject = nullptr; int it = 0; int64_t* ninjected = nullptr;  // census + refill fused into the sort
     bool keys_ready = false;          // S->cell and S->cell_count were filled by k_rk4's epilogue (prepare_sort_keys + stage_rk4)
+    bool premigrated = false;         // several ranks: leavers have been sent and re-keyed as trash, arrivals appended with their keys (migrate_presort)
+    bool drop_trash = false;          // the trash bucket behind the sorted tracers is dropped (S->n = everything before it)
 };
 static int sort_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, double x0, double hx, const SortOpts& o = SortOpts());
 // Host midpoint grids (pylamp2.py:92-95) and device copies of all coordinate arrays the marker kernels use:
@@ -829,6 +833,9 @@ static int relayout(pl_ctx* ctx, PlStepState* S) {
     hipLaunchKernelGGL(k_gather_int, grid1d(n), dim3(256), 0, ctx->stream, n, S->slot, S->orig, S->orig2);
     for (int k = 0; k < nc; k++) std::swap(S->f[cols[k]], S->f2[cols[k]]);
     std::swap(S->orig, S->orig2);
+    S->epoch_len = n;
+    // several ranks: tracers come and go, a caller's order does not exist (downloads are matched by TR__ID): the identity
+    if (ctx->nranks > 1) hipLaunchKernelGGL(k_iota, grid1d(n), dim3(256), 0, ctx->stream, n, S->orig, 0);
     PL_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -854,7 +861,7 @@ static int sort_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, doubl
     long long n = S->n;
     if (n >= (1LL << 31)) return pl_fail(ctx, "sort_tracers: more than 2^31 tracers per GPU");
     // epoch layout + lazy columns (see above) where the resident step is the only reader until the next sort
-    const bool epoch_ok = !o.full && epoch_length() > 0 && ctx->nranks == 1 && !o.del_outside && ctx->geom.uniform && scatter_cells_on();
+    const bool epoch_ok = !o.full && epoch_length() > 0 && (ctx->nranks == 1 || o.premigrated) && !o.del_outside && ctx->geom.uniform && scatter_cells_on();
     if (!epoch_ok) PL_TRY(ensure_current(ctx, S));
     else {
         PL_TRY(flush_lazy(ctx, S));                     // (pl_step has dropped them already: rewritten before anything reads them)
@@ -935,7 +942,10 @@ static int sort_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, doubl
             id0 = strict ? S->max_id + before - def_before : S->max_id + 1.0 + before;
             S->max_id += strict ? total - def_total : total;
         }
-        if (ninj > 0) PL_TRY(grow_tracers(ctx, S, n + ninj, n));
+        if (ninj > 0) {
+            const long long used = std::max(n, (epoch_ok && S->epoch_on) ? S->epoch_len : n);
+            PL_TRY(grow_tracers(ctx, S, used + ninj, used));
+        }
     }
     // ---- offsets of the sorted arrays: residents (+ room for the new tracers of a cell right behind them)
     if (ninj > 0) {
@@ -973,6 +983,7 @@ static int sort_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, doubl
         for (int k = 0; k < NFTRAC; k++) std::swap(S->f[k], S->f2[k]);
     }
     if (epoch_ok) {
+        if (!S->epoch_on) S->epoch_len = n;                 // the sort has just opened the epoch: slot = the index before it
         S->epoch_age = S->epoch_on ? S->epoch_age + 1 : 1; S->epoch_on = true;
         S->lazy_pending = true; S->lazy_n = n; S->lazy_inject = ninj > 0;
     }
@@ -983,7 +994,9 @@ static int sort_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, doubl
         a.tz = S->tz; a.tx = S->tx; for (int k = 0; k < NFTRAC; k++) a.f[k] = S->f[k];
         a.vtz = S->vtz; a.vtx = S->vtx; a.orig = S->orig;
         a.slot = epoch_ok ? S->slot : nullptr; a.lazy = epoch_ok ? 1 : 0;
-        a.z0 = z0; a.hz = hz; a.x0 = x0; a.hx = hx; a.seed = o.inject->inject_seed; a.step = (unsigned)o.it; a.id0 = id0; a.n_old = (int)n;
+        a.z0 = z0; a.hz = hz; a.x0 = x0; a.hx = hx; a.seed = o.inject->inject_seed; a.step = (unsigned)o.it; a.id0 = id0;
+        a.n_old = (int)(epoch_ok ? S->epoch_len : n);        // epoch layout: the constants of new tracers go behind everything the epoch holds
+        if (epoch_ok) S->epoch_len += ninj;
         a.zc = coords_z(ctx, S, 0); a.xc = coords_x(ctx, S, 0);
         hipLaunchKernelGGL(k_inject_sorted, dim3((nc + 63) / 64), dim3(64), 0, ctx->stream, a);
         S->n = n + ninj;
@@ -991,6 +1004,12 @@ static int sort_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, doubl
     if (o.ninjected) *o.ninjected = ninj;
     PL_HIP(ctx, hipGetLastError());
     if (o.removed) *o.removed = 0;
+    if (o.drop_trash) {                                   // (several ranks: the tracers that have left for a neighbour block)
+        int keep = 0;
+        PL_HIP(ctx, hipMemcpyAsync(&keep, S->cell_start + nc + 8, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        S->n = keep;
+    }
     if (o.del_outside && n > 0) {
         int h[2] = {0, 0};
         PL_HIP(ctx, hipMemcpyAsync(h, S->cell_start + nc + 8, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -1070,6 +1089,120 @@ static int migrate_tracers(pl_ctx* ctx, PlStepState* S, double z0, double hz, do
     S->n = stay + incoming;
     hipLaunchKernelGGL(k_iota, grid1d(S->n), dim3(256), 0, ctx->stream, S->n, S->orig, 0);
     return sort_tracers(ctx, S, z0, hz, x0, hx, o);
+}
+
+// ---- several ranks, regular grid: migration BEFORE the sort ---------------------------------------------------------------------------
+// k_rk4's epilogue has keyed every tracer (cell of this block, or one of the 8 leaver buckets) and counted the keys.  Instead of
+// sort -> send the leaver buckets -> append -> sort again (two full sorts of 17 columns per step), the leavers are collected straight
+// from the unsorted arrays into per-direction send buffers (a few thousand tracers: the rim of the block), re-keyed as trash, the
+// arrivals are appended with their keys, and ONE sort -- the epoch-layout sort of one rank: positions, temperature and a 4-byte slot
+// per tracer -- places everything and drops the trash.  Constants of arrivals are appended to the epoch-ordered arrays like those of
+// injected tracers; the entries of tracers that have left stay behind unreferenced until the next re-layout.
+struct LeaverArgs {
+    long long n; int nc;
+    int* cell; int* count; const int* slot;             // slot NULL: every column at the tracer's own index
+    const double* col[17];                              // tz, tx, f[0..12], vtz, vtx
+    int* fill;                                          // 8 counters
+    long long off[8], cnt[8];                           // element offset (in tracers) and capacity of each direction's segment
+    double* buf;
+};
+__global__ __launch_bounds__(256) void k_pack_leavers(LeaverArgs a) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.n) return;
+    const int c = a.cell[t];
+    if (c < a.nc || c >= a.nc + 8) return;
+    const int k = c - a.nc;
+    const int q = atomicAdd(&a.fill[k], 1);
+    if (q >= a.cnt[k]) return;                          // (cannot happen: the counts come from the same keys)
+    const long long e = a.slot ? (long long)a.slot[t] : t;
+    double* seg = a.buf + 17 * a.off[k];
+    for (int m = 0; m < 17; m++) {
+        const bool at_epoch = m >= 2 && m < 15 && tracer_const(m - 2);
+        seg[(long long)m * a.cnt[k] + q] = a.col[m][at_epoch ? e : t];
+    }
+    a.cell[t] = a.nc + 8;                               // trash: the sort drops it
+    atomicAdd(&a.count[a.nc + 8], 1); atomicSub(&a.count[c], 1);
+}
+struct ArrivalArgs {
+    long long first, e0; long long off[8], cnt[8]; int ndir;      // sorted-order index / epoch index of the first arrival
+    double* col[17]; int* slot; int* orig; const double* buf;
+};
+__global__ __launch_bounds__(256) void k_unpack_arrivals(ArrivalArgs a, long long total) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= total) return;
+    int k = 0;
+    for (int d = 0; d < 8; d++) if (r >= a.off[d] && r < a.off[d] + a.cnt[d]) k = d;
+    const long long q = r - a.off[k];
+    const double* seg = a.buf + 17 * a.off[k];
+    const long long t = a.first + r, e = a.e0 + r;
+    for (int m = 0; m < 17; m++) {
+        const bool at_epoch = a.slot && m >= 2 && m < 15 && tracer_const(m - 2);
+        a.col[m][at_epoch ? e : t] = seg[(long long)m * a.cnt[k] + q];
+    }
+    if (a.slot) a.slot[t] = (int)e;
+    a.orig[a.slot ? e : t] = (int)(a.slot ? e : t);
+}
+static int migrate_presort(pl_ctx* ctx, PlStepState* S, double z0, double hz, double x0, double hx) {
+    static const int DZ[8] = {-1, 1, 0, 0, -1, -1, 1, 1}, DX[8] = {0, 0, -1, 1, -1, 1, -1, 1}, OPP[8] = {1, 0, 3, 2, 7, 6, 5, 4};
+    const PlGeom& g = ctx->geom.d;
+    const int nc = S->sort_cells, R = ctx->nranks;
+    const long long n_all = S->n;
+    // who sends how many to whom (slot [r*8 + k] = tracers rank r sends towards direction k): summed over the ranks on the device
+    std::vector<double> cnt((size_t)8 * R, 0.0);
+    PL_TRY(step_counts(ctx, S, 8 * R));
+    hipLaunchKernelGGL(k_counts_from_ints, dim3(1), dim3(64), 0, ctx->stream, 8, (const int*)(S->cell_count + nc), 0, S->counts_dev, 8 * ctx->rank);
+    PL_TRY(pl_comm_allreduce_dev(ctx, S->counts_dev, 8 * R, 0));
+    PL_HIP(ctx, hipMemcpyAsync(cnt.data(), S->counts_dev, cnt.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int peer[8]; long long nsend[8], nrecv[8], soff[8], roff[8], outgoing = 0, incoming = 0;
+    for (int k = 0; k < 8; k++) {
+        const int qz = ctx->pz + DZ[k], qx = ctx->px + DX[k];
+        peer[k] = (qz < 0 || qz >= ctx->Pz || qx < 0 || qx >= ctx->Px) ? -1 : qz * ctx->Px + qx;
+        nsend[k] = (long long)cnt[(size_t)8 * ctx->rank + k];
+        nrecv[k] = peer[k] < 0 ? 0 : (long long)cnt[(size_t)8 * peer[k] + OPP[k]];
+        if (peer[k] < 0 && nsend[k] > 0) return pl_fail(ctx, "migrate_presort: a tracer left through a domain wall (internal error)");
+        soff[k] = outgoing; outgoing += nsend[k]; roff[k] = incoming; incoming += nrecv[k];
+    }
+    double *sb = nullptr, *rb = nullptr;
+    PL_TRY(pl_buf(ctx, "mig_send", (size_t)std::max<long long>(17 * outgoing, 1) * sizeof(double), &sb, false));
+    PL_TRY(pl_buf(ctx, "mig_recv", (size_t)std::max<long long>(17 * incoming, 1) * sizeof(double), &rb, false));
+    const long long used = std::max(n_all, S->epoch_on ? S->epoch_len : n_all);
+    PL_TRY(grow_tracers(ctx, S, used + incoming, used));         // (collective in effect: every rank knows its own need)
+    double* cols[17];
+    cols[0] = S->tz; cols[1] = S->tx; for (int k = 0; k < NFTRAC; k++) cols[2 + k] = S->f[k]; cols[15] = S->vtz; cols[16] = S->vtx;
+    if (outgoing > 0) {
+        double* fc;
+        PL_TRY(pl_buf(ctx, "mig_fill", 64, &fc, false));
+        PL_HIP(ctx, hipMemsetAsync(fc, 0, 64, ctx->stream));
+        LeaverArgs a{};
+        a.n = n_all; a.nc = nc; a.cell = S->cell; a.count = S->cell_count; a.slot = S->epoch_on ? S->slot : nullptr;
+        for (int m = 0; m < 17; m++) a.col[m] = cols[m];
+        a.fill = (int*)fc; a.buf = sb;
+        for (int k = 0; k < 8; k++) { a.off[k] = soff[k]; a.cnt[k] = nsend[k]; }
+        hipLaunchKernelGGL(k_pack_leavers, grid1d(n_all), dim3(256), 0, ctx->stream, a);
+    }
+    std::vector<PlMsg> msgs;
+    for (int k = 0; k < 8; k++) {
+        if (peer[k] < 0 || (nsend[k] == 0 && nrecv[k] == 0)) continue;
+        msgs.push_back(PlMsg{peer[k], sb + 17 * soff[k], 17 * nsend[k], rb + 17 * roff[k], 17 * nrecv[k]});
+    }
+    PL_TRY(pl_comm_sendrecv(ctx, msgs.data(), (int)msgs.size()));
+    if (incoming > 0) {
+        ArrivalArgs a{};
+        a.first = n_all; a.e0 = S->epoch_on ? S->epoch_len : n_all;
+        for (int m = 0; m < 17; m++) a.col[m] = cols[m];
+        a.slot = S->epoch_on ? S->slot : nullptr; a.orig = S->orig; a.buf = rb;
+        for (int k = 0; k < 8; k++) { a.off[k] = roff[k]; a.cnt[k] = nrecv[k]; }
+        hipLaunchKernelGGL(k_unpack_arrivals, grid1d(incoming), dim3(256), 0, ctx->stream, a, incoming);
+        // their sort keys, counted into the same table (the arrivals may lie one block further already: forwarded at the next step)
+        hipLaunchKernelGGL(k_cell_count, grid1d(incoming), dim3(256), 0, ctx->stream, incoming, (const double*)(S->tz + n_all), (const double*)(S->tx + n_all),
+                           z0, hz, x0, hx, (const double*)nullptr, (const double*)nullptr, S->ncz, S->ncx, S->crow0, S->ccol0, g.nz - 1, g.nx - 1,
+                           S->cell + n_all, S->cell_count, 0, 0.0, 0.0);
+        if (S->epoch_on) S->epoch_len += incoming;
+    }
+    S->n = n_all + incoming;
+    PL_HIP(ctx, hipGetLastError());
+    return 0;
 }
 
 // un-permute resident arrays into the spare buffers so that downloads come out in the caller's order
@@ -1634,10 +1767,16 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
         SortOpts so; so.del_outside = cfg->tracs_fence_disabled ? 1 : 0; so.Lz = Lz; so.Lx = Lx; so.removed = &removed;
         so.keys_ready = keys_ready;
         SortOpts si; si.inject = cfg; si.it = it; si.ninjected = &rep->ninjected;
-        if (ctx->nranks == 1) { so.inject = si.inject; so.it = it; so.ninjected = si.ninjected; }     // one pass does it all
+        static const bool presort_env = !(getenv("PYLAMP_MIGRATE_PRESORT") && atoi(getenv("PYLAMP_MIGRATE_PRESORT")) == 0);
+        const bool presort = ctx->nranks > 1 && presort_env && keys_ready && !so.del_outside && ctx->geom.uniform && scatter_cells_on() && epoch_length() > 0;
+        if (ctx->nranks == 1 || presort) { so.inject = si.inject; so.it = it; so.ninjected = si.ninjected; }     // one pass does it all
+        if (presort) {                // several ranks: leavers out / arrivals in BEFORE the one sort (epoch layout, as on one rank)
+            PL_TRY(migrate_presort(ctx, S, z0, hz, x0, hx));
+            so.premigrated = true; so.drop_trash = true;
+        }
         PL_TRY(sort_tracers(ctx, S, z0, hz, x0, hx, so));
         rep->nremoved = removed;
-        PL_TRY(migrate_tracers(ctx, S, z0, hz, x0, hx, si));          // several ranks: the refill follows the migration
+        if (!presort) PL_TRY(migrate_tracers(ctx, S, z0, hz, x0, hx, si));          // classic: sort, send the leaver buckets, append, sort again
     }
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     S->sorted = true;
