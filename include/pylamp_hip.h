@@ -108,6 +108,11 @@ int  pl_local_group_create(pl_local_group** out, int nranks);
 void pl_local_group_destroy(pl_local_group* g);
 void pl_local_group_abort(pl_local_group* g);    /* a rank's driver thread failed: every collective call of the group returns an error */
 int  pl_set_comm_local(pl_ctx* ctx, pl_local_group* g, int rank, int Pz, int Px);
+/* Bracket a rank thread's stretch of library calls.  No-ops unless PYLAMP_LOCAL_SERIAL=1 was set when the group was created: then the
+ * group has ONE GPU token, held by the thread that runs and handed over (stream drained) while it waits inside a collective call, so
+ * that the kernels of virtual ranks sharing a GPU never overlap -- a kernel trace then shows their true durations. */
+void pl_local_group_enter(pl_local_group* g);
+void pl_local_group_leave(pl_local_group* g, pl_ctx* ctx);
 /* *native = 1 when the exchanges run as direct RCCL calls on the context stream (dlopen'ed librccl, self-tested at
  * pl_set_comm), 2 for the in-process group, 0 when they go through the callback table.
  * The native path is opt-in: PYLAMP_RCCL=1 (bench.py sets it under the nccl backend). */

@@ -79,6 +79,8 @@ SIGNATURES = {
     "pl_local_group_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "pl_local_group_destroy": (None, [C.c_void_p]),
     "pl_local_group_abort": (None, [C.c_void_p]),
+    "pl_local_group_enter": (None, [C.c_void_p]),
+    "pl_local_group_leave": (None, [C.c_void_p, C.c_void_p]),
     "pl_set_comm_local": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "pl_comm_info": (C.c_int, [C.c_void_p, c_int_p, c_int_p, c_int_p]),
     "pl_comm_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int]),

@@ -60,14 +60,26 @@ struct pl_local_group {
     std::vector<const PlMsg*> msgs; std::vector<int> nmsg;
     std::vector<const void*> ptr;
     bool failed = false;         // a rank gave up (error on its side, or a barrier timed out): every later barrier fails at once
+    // PYLAMP_LOCAL_SERIAL=1 (profiling rehearsals): one GPU token for the group -- a rank's host thread holds it while it runs and
+    // hands it over (with its stream drained) while it waits in a collective call, so that the kernels of the virtual ranks never
+    // overlap on the shared GPU and a kernel trace reports their true durations (tools/rehearse_trace.sh)
+    bool serialize = false, token_busy = false;
+    std::condition_variable token_cv;
+    void token_acquire(std::unique_lock<std::mutex>& lk) { token_cv.wait(lk, [&] { return !token_busy || failed; }); token_busy = true; }
+    void token_release() { token_busy = false; token_cv.notify_one(); }
     // false: the group has failed -- some rank did not arrive (it raised an error before the collective call)
-    bool barrier() {
+    bool barrier(pl_ctx* who = nullptr) {
+        if (serialize && who) (void)hipStreamSynchronize(who->stream);
         std::unique_lock<std::mutex> lk(m);
         if (failed) return false;
+        if (serialize) token_release();
         const long long g = gen;
-        if (++arrived == n) { arrived = 0; gen++; cv.notify_all(); return true; }
-        if (!cv.wait_for(lk, std::chrono::seconds(300), [&] { return gen != g || failed; })) { failed = true; cv.notify_all(); }
-        return !failed;
+        bool ok = true;
+        if (++arrived == n) { arrived = 0; gen++; cv.notify_all(); }
+        else if (!cv.wait_for(lk, std::chrono::seconds(300), [&] { return gen != g || failed; })) { failed = true; cv.notify_all(); token_cv.notify_all(); }
+        ok = !failed;
+        if (serialize && ok) token_acquire(lk);
+        return ok && !failed;
     }
 };
 
@@ -75,8 +87,22 @@ extern "C" int pl_local_group_create(pl_local_group** out, int nranks) {
     if (!out || nranks < 1) return 1;
     pl_local_group* g = new pl_local_group();
     g->n = nranks; g->ctx.assign(nranks, nullptr); g->msgs.assign(nranks, nullptr); g->nmsg.assign(nranks, 0); g->ptr.assign(nranks, nullptr);
+    g->serialize = getenv("PYLAMP_LOCAL_SERIAL") && atoi(getenv("PYLAMP_LOCAL_SERIAL")) != 0;
     *out = g;
     return 0;
+}
+// a rank's host thread starts / ends a stretch of library calls (the driver wraps every collective call sequence in them): with
+// PYLAMP_LOCAL_SERIAL it takes / returns the group's GPU token; otherwise nothing
+extern "C" void pl_local_group_enter(pl_local_group* g) {
+    if (!g || !g->serialize) return;
+    std::unique_lock<std::mutex> lk(g->m);
+    g->token_acquire(lk);
+}
+extern "C" void pl_local_group_leave(pl_local_group* g, pl_ctx* ctx) {
+    if (!g || !g->serialize) return;
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    std::unique_lock<std::mutex> lk(g->m);
+    g->token_release();
 }
 extern "C" void pl_local_group_destroy(pl_local_group* g) { delete g; }
 // wake every rank waiting in a collective call with an error (a rank's driver thread has failed)
@@ -84,7 +110,7 @@ extern "C" void pl_local_group_abort(pl_local_group* g) {
     if (!g) return;
     std::unique_lock<std::mutex> lk(g->m);
     g->failed = true;
-    g->cv.notify_all();
+    g->cv.notify_all(); g->token_cv.notify_all();
 }
 
 int pl_local_attach(pl_ctx* ctx, pl_local_group* g, int rank) {
@@ -100,7 +126,7 @@ static int local_sendrecv(pl_ctx* ctx, const PlMsg* msgs, int nmsg) {
     pl_local_group* G = local_of(ctx);
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));              // my send buffers are complete
     G->msgs[ctx->rank] = msgs; G->nmsg[ctx->rank] = nmsg;
-    if (!G->barrier()) return pl_fail(ctx, "in-process transport: another rank failed or did not arrive");
+    if (!G->barrier(ctx)) return pl_fail(ctx, "in-process transport: another rank failed or did not arrive");
     int rc = 0;
     for (int k = 0; k < nmsg && !rc; k++) {
         if (msgs[k].nrecv <= 0) continue;
@@ -116,14 +142,14 @@ static int local_sendrecv(pl_ctx* ctx, const PlMsg* msgs, int nmsg) {
     }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = pl_fail(ctx, "in-process transport: synchronisation failed");
     if (rc) pl_local_group_abort(G);
-    if (!G->barrier() && !rc) rc = pl_fail(ctx, "in-process transport: another rank failed or did not arrive");   // everybody has read: send buffers may be reused
+    if (!G->barrier(ctx) && !rc) rc = pl_fail(ctx, "in-process transport: another rank failed or did not arrive");   // everybody has read: send buffers may be reused
     return rc;
 }
 
 static int local_allreduce_host(pl_ctx* ctx, double* buf, long long n, int op) {
     pl_local_group* G = local_of(ctx);
     G->ptr[ctx->rank] = buf;
-    if (!G->barrier()) return pl_fail(ctx, "in-process transport: another rank failed or did not arrive");
+    if (!G->barrier(ctx)) return pl_fail(ctx, "in-process transport: another rank failed or did not arrive");
     std::vector<double> tmp((size_t)n);
     for (long long k = 0; k < n; k++) {
         double a = ((const double*)G->ptr[0])[k];
@@ -133,7 +159,7 @@ static int local_allreduce_host(pl_ctx* ctx, double* buf, long long n, int op) {
         }
         tmp[(size_t)k] = a;
     }
-    if (!G->barrier()) return pl_fail(ctx, "in-process transport: another rank failed or did not arrive");
+    if (!G->barrier(ctx)) return pl_fail(ctx, "in-process transport: another rank failed or did not arrive");
     memcpy(buf, tmp.data(), (size_t)n * sizeof(double));
     return 0;
 }
@@ -142,14 +168,14 @@ static int local_allgather(pl_ctx* ctx, const double* send, double* recv, long l
     pl_local_group* G = local_of(ctx);
     PL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     G->ptr[ctx->rank] = send;
-    if (!G->barrier()) return pl_fail(ctx, "in-process transport: another rank failed or did not arrive");
+    if (!G->barrier(ctx)) return pl_fail(ctx, "in-process transport: another rank failed or did not arrive");
     int rc = 0;
     for (int r = 0; r < G->n && !rc; r++)
         if (hipMemcpyAsync(recv + (long long)r * count, G->ptr[r], (size_t)count * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
             rc = pl_fail(ctx, "in-process transport: device copy failed");
     if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = pl_fail(ctx, "in-process transport: synchronisation failed");
     if (rc) pl_local_group_abort(G);
-    if (!G->barrier() && !rc) rc = pl_fail(ctx, "in-process transport: another rank failed or did not arrive");
+    if (!G->barrier(ctx) && !rc) rc = pl_fail(ctx, "in-process transport: another rank failed or did not arrive");
     return rc;
 }
 

@@ -1660,7 +1660,9 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
                 S->nu_pre = S->nu_post = nu; S->nu0_pre = S->nu0_post = -1;
             }
         }
-        S->tail_max_nodes = S->tail_knob ? S->tail_knob : (R > 1 ? (long long)PL_TAIL_MAX_NODES : 33LL * 33);
+        // (several ranks used to start the one-workgroup tail at 65^2 -- the levels above it cost halo exchanges then; since the
+        //  replicated levels run the tile kernels it is the one-rank choice: 33^2, which is what the LDS-resident tail holds)
+        S->tail_max_nodes = S->tail_knob ? S->tail_knob : 33LL * 33;
         S->repl_start = -1;
         for (int l = 0;; l++) {
             MgLevel* L = new MgLevel();

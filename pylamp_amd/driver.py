@@ -342,7 +342,14 @@ class VirtualCluster:
     def all(self, fn, timeout=900):
         """fn(sim) on every rank at once (the calls are collective); returns the list of results in rank order."""
         import concurrent.futures as cf
-        futs = [self.pool.submit(fn, s) for s in self.sims]
+
+        def run(s):                      # (PYLAMP_LOCAL_SERIAL=1: one rank at a time on the shared GPU, see pl_local_group_enter)
+            self.lib.pl_local_group_enter(self.group)
+            try:
+                return fn(s)
+            finally:
+                self.lib.pl_local_group_leave(self.group, s.ctx.h)
+        futs = [self.pool.submit(run, s) for s in self.sims]
         done, pending = cf.wait(futs, timeout=timeout, return_when=cf.FIRST_EXCEPTION)
         if pending:                      # a rank raised (or the time is up): release the others from their collective calls
             self.lib.pl_local_group_abort(self.group)
