@@ -290,6 +290,6 @@ def test_blocks_3d_equal_one_rank(n, layout):
         assert abs(st["iterations"] - st1["iterations"]) <= (3 if lev == lev1 else 8), (st, st1)       # (BiCGStab counts move by one or two with the summation order of the dot products)
         (v, p), (v1, p1) = P3.x2vp(xs, n), P3.x2vp(x1, n)
         ev = np.sqrt(sum(np.sum((a - b) ** 2) for a, b in zip(v, v1)) / sum(np.sum(b ** 2) for b in v1))
-        assert ev < 1e-8 and relerr(p, p1) < 1e-7, (ev, relerr(p, p1))
+        assert ev < 5e-8 and relerr(p, p1) < 1e-7, (ev, relerr(p, p1))     # (both solves stop at an estimated error of 3e-8)
         assert relerr(T, T1) < 1e-10 and abs(ht["iterations"] - ht1["iterations"]) <= 1
         assert cs[0] > 0 and cs[1] > 0                    # halo exchanges and all-reduces happened
