@@ -167,8 +167,14 @@ template <int D> __device__ inline double apply_vel3(const Op3& op, const double
     return scaled ? Av * pl_rcp(dg) : Av;
 }
 
-template <bool SCALED> __global__ __launch_bounds__(256) void k3_apply(Op3 op, V4 x, W4 y) {
+// rim_only != 0: only the nodes with a wall / slaved / symmetry row are evaluated (all four rows of such a node); the interior rows are
+// k3_apply_m's
+template <bool SCALED> __global__ __launch_bounds__(256) void k3_apply(Op3 op, V4 x, W4 y, int rim_only) {
     K3_PROLOGUE(op.g)
+    if (rim_only) {
+        long long m_;
+        if (cls3<0>(op, idx, m_) == C3_INT && cls3<1>(op, idx, m_) == C3_INT && cls3<2>(op, idx, m_) == C3_INT && cls3_p(op, idx, m_) == 1) return;
+    }
     const double* v[3] = {x.p[0], x.p[1], x.p[2]};
     const double* __restrict__ P = x.p[3];
     y.p[0][c] = apply_vel3<0>(op, v, P, c, idx, SCALED);
@@ -280,12 +286,38 @@ template <int D> __device__ inline double cheb3(const Op3& op, const double* con
     const double mom = (c1 != 0.0) ? c1 * (v0 - (vprev ? vprev[cm] : 0.0)) : 0.0;
     return v0 + mom + (c2 * (Av - f[cm])) * pl_rcp(dg);                                  // D = -dg
 }
-__global__ __launch_bounds__(256) void k3_cheb(Op3 op, V3 vcur, V3 vprev, V3 f, W3 vnext, double c1, double c2, int zero) {
+// rim_only != 0: only the nodes with a wall or slaved row (all three rows of such a node); the interior rows are k3_sweep_m's
+__device__ inline bool k3_all_interior(const Op3& op, const int* idx) {
+    long long m_;
+    return cls3<0>(op, idx, m_) == C3_INT && cls3<1>(op, idx, m_) == C3_INT && cls3<2>(op, idx, m_) == C3_INT;
+}
+__global__ __launch_bounds__(256) void k3_cheb(Op3 op, V3 vcur, V3 vprev, V3 f, W3 vnext, double c1, double c2, int zero, int rim_only) {
     K3_PROLOGUE(op.g)
+    if (rim_only && k3_all_interior(op, idx)) return;
     const double* v[3] = {vcur.p[0], vcur.p[1], vcur.p[2]};
     vnext.p[0][c] = cheb3<0>(op, v, vprev.p[0], f.p[0], c1, c2, c, idx, zero);
     vnext.p[1][c] = cheb3<1>(op, v, vprev.p[1], f.p[1], c1, c2, c, idx, zero);
     vnext.p[2][c] = cheb3<2>(op, v, vprev.p[2], f.p[2], c1, c2, c, idx, zero);
+}
+// 1 / diag of the three velocity rows (interior rows; 0 elsewhere), once per set of coefficients: the first sweep of every smoothing
+// sequence starts from the zero guess, v1 = -c2 f / diag, and used to rebuild the diagonal from ~30 viscosity loads per node
+__global__ __launch_bounds__(256) void k3_dinv(Op3 op, W3 dinv) {
+    K3_PROLOGUE(op.g)
+    long long moff;
+    dinv.p[0][c] = cls3<0>(op, idx, moff) == C3_INT ? pl_rcp(diag3<0>(op, c, idx)) : 0.0;
+    dinv.p[1][c] = cls3<1>(op, idx, moff) == C3_INT ? pl_rcp(diag3<1>(op, c, idx)) : 0.0;
+    dinv.p[2][c] = cls3<2>(op, idx, moff) == C3_INT ? pl_rcp(diag3<2>(op, c, idx)) : 0.0;
+}
+// v1 = -c2 f / diag at the row's master (a slave evaluates its master's update: the same numbers as k3_cheb with zero != 0)
+__global__ __launch_bounds__(256) void k3_cheb0(Op3 op, V3 f, V3 dinv, W3 vnext, double c2) {
+    K3_PROLOGUE(op.g)
+    long long moff;
+    int cl = cls3<0>(op, idx, moff);
+    vnext.p[0][c] = cl == C3_ZERO ? 0.0 : (-c2 * f.p[0][c + moff]) * dinv.p[0][c + moff];
+    cl = cls3<1>(op, idx, moff);
+    vnext.p[1][c] = cl == C3_ZERO ? 0.0 : (-c2 * f.p[1][c + moff]) * dinv.p[1][c + moff];
+    cl = cls3<2>(op, idx, moff);
+    vnext.p[2][c] = cl == C3_ZERO ? 0.0 : (-c2 * f.p[2][c + moff]) * dinv.p[2][c + moff];
 }
 // mode 0: r = f - A v on interior rows (0 elsewhere); mode 1: y = D^-1 A v with closure (power iteration)
 template <int D> __device__ inline double resid3(const Op3& op, const double* const* v, const double* __restrict__ f, long long c,
@@ -304,12 +336,340 @@ template <int D> __device__ inline double resid3(const Op3& op, const double* co
     row3<D>(op, v, cm, im, Av, dg);
     return mode == 0 ? f[c] - Av : Av * pl_rcp(dg);
 }
-__global__ __launch_bounds__(256) void k3_resid(Op3 op, V3 vv, V3 f, W3 r, int mode) {
+__global__ __launch_bounds__(256) void k3_resid(Op3 op, V3 vv, V3 f, W3 r, int mode, int rim_only) {
     K3_PROLOGUE(op.g)
+    if (rim_only && k3_all_interior(op, idx)) return;
     const double* v[3] = {vv.p[0], vv.p[1], vv.p[2]};
     r.p[0][c] = resid3<0>(op, v, f.p[0], c, idx, mode);
     r.p[1][c] = resid3<1>(op, v, f.p[1], c, idx, mode);
     r.p[2][c] = resid3<2>(op, v, f.p[2], c, idx, mode);
+}
+
+// ---- LDS-tiled variants of the three heavy stencil kernels (round 4) ------------------------------------------------------------------------
+// Counters (tools/pmc_passes.sh, profiles/r04_3d257_pmc.csv) say what binds the per-node kernels above: not HBM (the XCD-banded
+// workgroup order cut k3_apply's traffic from 2.46x to 1.07x of the algorithmic bytes and made it 9 % SLOWER), not the branches (a
+// branch-free rewrite with 114 registers: 29 % slower), but the NUMBER of 8-byte gather instructions -- 68 ... 129 per node, ~22 cycles
+// of the CU's texture path each, whether they hit or not (time = 100 us + 11 us x loads per node over k3_cont_rows / k3_heat_apply /
+// k3_apply).  Here a workgroup loads its 4 x 64 tile of the planes i-1, i, i+1 with a one-node rim ONCE, coalesced (23 ... 28 loads per
+// thread instead of 88 ... 129), and evaluates the rows from LDS (ds_read: a quarter of the cycles of a gather).  Same thread <-> node
+// mapping, same row functions (row3 / diag3 on an Op3 whose strides and viscosity pointers are the window's); the rare slaved rows (their
+// master's stencil can leave the window) and symmetry rows take the global-memory path.  PYLAMP_3D_LDS=0 keeps the per-node kernels.
+#define K3T_SR 68                        // row pitch of the window: 66 columns (k-1 .. k+64) padded
+#define K3T_SP (6 * K3T_SR)              // plane pitch: 6 rows (j-1 .. j+4)
+#define K3T_N (3 * K3T_SP)               // one array: 3 planes
+// ---- z-marching variant: the workgroup keeps its tile and walks K3M_ZC planes --------------------------------------------------------------
+// The window's three planes live in a ring of LDS slots; per step ONE new plane of every array is fetched (2 elements per thread and
+// array, requested BEFORE the step's arithmetic and written behind it: the latency is hidden even at two workgroups per CU), i.e.
+// ~12 loads per node instead of 28 (tile-at-a-time) or 88 (per-node kernel).  The rows are row3's expressions on (plane slot, in-plane
+// index) pairs.
+#define K3M_ZC 32
+struct K3Ring { int o[3]; };                         // LDS offsets of the planes i-1, i, i+1
+template <int D, int dD, int dE, int dF> __device__ inline double k3r_at(const double* __restrict__ A, const K3Ring& r, int q) {
+    constexpr int E = (D + 1) % 3, F = (D + 2) % 3;
+    constexpr int dz = (D == 0 ? dD : 0) + (E == 0 ? dE : 0) + (F == 0 ? dF : 0);
+    constexpr int dx = (D == 1 ? dD : 0) + (E == 1 ? dE : 0) + (F == 1 ? dF : 0);
+    constexpr int dy = (D == 2 ? dD : 0) + (E == 2 ? dE : 0) + (F == 2 ? dF : 0);
+    return A[r.o[1 + dz] + q + dx * K3T_SR + dy];
+}
+// row3 on the ring (same expressions, same order)
+// the spacing-table entries a node's rows use, per axis a: 1/(c[i+1]-c[i]), the same one node lower, 1/(c[i+1]-c[i-1]), the same one node
+// higher.  The marching kernel loads the x and y entries ONCE per thread and the z entries once per plane (scalar loads share the LDS
+// counter: one inside the row evaluation drains the LDS pipeline each time)
+struct K3Tab { double rd[3], rdm[3], rD[3], rDp[3]; };
+template <int D> __device__ inline void row3r(const K3Tab& tb, const double* const* __restrict__ V, const double* __restrict__ ES, const double* __restrict__ EN,
+                                               const K3Ring& r, const K3Ring& rs, const K3Ring& rn, int q, double& Av, double& dg) {
+    constexpr int E = (D + 1) % 3, F = (D + 2) % 3;
+    const double* __restrict__ u = V[D];
+    const double rd_d = tb.rd[D], rd_dm = tb.rdm[D], rD_d = tb.rD[D];
+    const double u0 = k3r_at<D, 0, 0, 0>(u, r, q);
+    const double cN = 4.0 * k3r_at<D, 0, 0, 0>(EN, rn, q) * rd_d * rD_d, cS = 4.0 * k3r_at<D, -1, 0, 0>(EN, rn, q) * rd_dm * rD_d;
+    double a = cN * (k3r_at<D, 1, 0, 0>(u, r, q) - u0) - cS * (u0 - k3r_at<D, -1, 0, 0>(u, r, q));
+    double d = cN + cS;
+    {
+        const double rd_e = tb.rd[E], rD_e = tb.rD[E], rD_ep = tb.rDp[E];
+        const double ep = 0.5 * (k3r_at<D, 0, 1, 0>(ES, rs, q) + k3r_at<D, 0, 1, 1>(ES, rs, q)), em = 0.5 * (k3r_at<D, 0, 0, 0>(ES, rs, q) + k3r_at<D, 0, 0, 1>(ES, rs, q));
+        const double cE = 2.0 * ep * rD_ep * rd_e, cW = 2.0 * em * rD_e * rd_e;
+        const double* __restrict__ w = V[E];
+        a += cE * (k3r_at<D, 0, 1, 0>(u, r, q) - u0) - cW * (u0 - k3r_at<D, 0, -1, 0>(u, r, q)) +
+             (2.0 * ep * rD_d * rd_e) * (k3r_at<D, 0, 1, 0>(w, r, q) - k3r_at<D, -1, 1, 0>(w, r, q)) -
+             (2.0 * em * rD_d * rd_e) * (k3r_at<D, 0, 0, 0>(w, r, q) - k3r_at<D, -1, 0, 0>(w, r, q));
+        d += cE + cW;
+    }
+    {
+        const double rd_f = tb.rd[F], rD_f = tb.rD[F], rD_fp = tb.rDp[F];
+        const double ep = 0.5 * (k3r_at<D, 0, 0, 1>(ES, rs, q) + k3r_at<D, 0, 1, 1>(ES, rs, q)), em = 0.5 * (k3r_at<D, 0, 0, 0>(ES, rs, q) + k3r_at<D, 0, 1, 0>(ES, rs, q));
+        const double cE = 2.0 * ep * rD_fp * rd_f, cW = 2.0 * em * rD_f * rd_f;
+        const double* __restrict__ w = V[F];
+        a += cE * (k3r_at<D, 0, 0, 1>(u, r, q) - u0) - cW * (u0 - k3r_at<D, 0, 0, -1>(u, r, q)) +
+             (2.0 * ep * rD_d * rd_f) * (k3r_at<D, 0, 0, 1>(w, r, q) - k3r_at<D, -1, 0, 1>(w, r, q)) -
+             (2.0 * em * rD_d * rd_f) * (k3r_at<D, 0, 0, 0>(w, r, q) - k3r_at<D, -1, 0, 0>(w, r, q));
+        d += cE + cW;
+    }
+    Av = a; dg = d;
+}
+// this thread's (up to 2) elements of one plane slab (6 rows x 66 columns): global offset within the plane li = 0, LDS offset, validity
+struct K3PSlots { long long go[2]; int lo[2]; bool ok[2], in[2]; };
+__device__ inline K3PSlots k3m_slots(const G3& g, int lj0, int lk0) {
+    K3PSlots q;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int e = tid + 256 * u, r = e / 66, c = e % 66;
+        const int lj = lj0 + r - 1, lk = lk0 + c - 1;
+        q.in[u] = e < 396;
+        q.ok[u] = q.in[u] && lj <= g.n[1] && lk <= g.n[2];
+        q.go[u] = q.ok[u] ? i3(g, 0, lj, lk) : 0;
+        q.lo[u] = r * K3T_SR + c;
+    }
+    return q;
+}
+template <bool SCALED>
+__global__ __launch_bounds__(256) void k3_apply_m(Op3 op, V4 x, W4 y) {
+    // rings: the velocities need the planes i-1, i, i+1 (3 slots), the shear viscosity i, i+1, the normal viscosity and the pressure
+    // i-1, i (2 slots each): 48 KB -> three workgroups per CU
+    __shared__ double WV[3][3 * K3T_SP];
+    __shared__ double WS[2 * K3T_SP], WN[2 * K3T_SP], WP[2 * K3T_SP];
+    const G3& g = op.g;
+    const int lj0 = blockIdx.y * 4, lk0 = blockIdx.x * 64;
+    const int z0 = blockIdx.z * K3M_ZC, z1 = min(z0 + K3M_ZC, g.n[0]);
+    const K3PSlots ps = k3m_slots(g, lj0, lk0);
+    const double* vg[3] = {x.p[0], x.p[1], x.p[2]};
+    auto fetch = [&](const double* __restrict__ src, int plane, double* tmp) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) tmp[u] = ps.ok[u] ? src[ps.go[u] + (long long)plane * g.s[0]] : 0.0;
+    };
+    auto put = [&](double* __restrict__ dst, int slot, const double* tmp) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) if (ps.in[u]) dst[slot * K3T_SP + ps.lo[u]] = tmp[u];
+    };
+    // prologue: plane p of the velocities in slot (p + 3) % 3 ... of the 2-slot rings in slot (p + 2) % 2
+    {
+        double t0[9][2], t1[6][2];
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int m = 0; m < 3; m++) fetch(vg[m], z0 + a - 1, t0[3 * a + m]);
+        fetch(op.es, z0, t1[0]); fetch(op.es, z0 + 1, t1[1]); fetch(op.en, z0 - 1, t1[2]); fetch(op.en, z0, t1[3]);
+        fetch(x.p[3], z0 - 1, t1[4]); fetch(x.p[3], z0, t1[5]);
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int m = 0; m < 3; m++) put(WV[m], (z0 + a - 1 + 3) % 3, t0[3 * a + m]);
+        put(WS, z0 & 1, t1[0]); put(WS, (z0 + 1) & 1, t1[1]); put(WN, (z0 + 1) & 1, t1[2]); put(WN, z0 & 1, t1[3]);
+        put(WP, (z0 + 1) & 1, t1[4]); put(WP, z0 & 1, t1[5]);
+    }
+    __syncthreads();
+    const int lk = lk0 + threadIdx.x, lj = lj0 + threadIdx.y;
+    const bool mine = lk < g.n[2] && lj < g.n[1];
+    const int q = (threadIdx.y + 1) * K3T_SR + (threadIdx.x + 1);
+    const double* V[3] = {WV[0], WV[1], WV[2]};
+    K3Tab tb;
+    {
+        const int j = min(lj, g.n[1] - 1) + g.o[1], k = min(lk, g.n[2] - 1) + g.o[2];
+        tb.rd[1] = TB(g.rd[1], j); tb.rdm[1] = TB(g.rd[1], j - 1); tb.rD[1] = TB(g.rD[1], j); tb.rDp[1] = TB(g.rD[1], j + 1);
+        tb.rd[2] = TB(g.rd[2], k); tb.rdm[2] = TB(g.rd[2], k - 1); tb.rD[2] = TB(g.rD[2], k); tb.rDp[2] = TB(g.rD[2], k + 1);
+    }
+    for (int li = z0; li < z1; li++) {
+        {
+            const int i = li + g.o[0];
+            tb.rd[0] = TB(g.rd[0], i); tb.rdm[0] = TB(g.rd[0], i - 1); tb.rD[0] = TB(g.rD[0], i); tb.rDp[0] = TB(g.rD[0], i + 1);
+        }
+        // requested now, written behind the arithmetic: the planes li + 2 (velocities, shear viscosity) and li + 1 (normal viscosity, pressure)
+        const bool more = li + 1 < z1;
+        double tv[3][2], ts[2], tn[2], tp[2];
+        if (more) {
+#pragma unroll
+            for (int m = 0; m < 3; m++) fetch(vg[m], li + 2, tv[m]);
+            fetch(op.es, li + 2, ts); fetch(op.en, li + 1, tn); fetch(x.p[3], li + 1, tp);
+        }
+        K3Ring rv, rs, rn;
+        rv.o[0] = ((li + 2) % 3) * K3T_SP; rv.o[1] = (li % 3) * K3T_SP; rv.o[2] = ((li + 1) % 3) * K3T_SP;        // (li - 1 + 3) % 3 = (li + 2) % 3
+        rs.o[0] = 0; rs.o[1] = (li & 1) * K3T_SP; rs.o[2] = ((li + 1) & 1) * K3T_SP;
+        rn.o[0] = ((li + 1) & 1) * K3T_SP; rn.o[1] = (li & 1) * K3T_SP; rn.o[2] = 0;
+        if (mine) {
+            const long long c = i3(g, li, lj, lk);
+            const int i = li + g.o[0], j = lj + g.o[1], k = lk + g.o[2];
+            const int idx[3] = {i, j, k};
+            // (interior rows only: the walls, slaved and symmetry rows -- a rim two nodes thick -- are k3_apply<.., rim only>'s, launched behind)
+#define K3M_COMP(D)                                                                                                   \
+            {                                                                                                         \
+                long long moff;                                                                                       \
+                const int cls = cls3<D>(op, idx, moff);                                                               \
+                if (cls == C3_INT) {                                                                                  \
+                    double Av, dg;                                                                                    \
+                    row3r<D>(tb, V, WS, WN, rv, rs, rn, q, Av, dg);                                                   \
+                    Av -= 2.0 * op.Kc * tb.rD[D] * (k3r_at<D, 0, 0, 0>(WP, rn, q) - k3r_at<D, -1, 0, 0>(WP, rn, q));    \
+                    y.p[D][c] = SCALED ? Av * pl_rcp(dg) : Av;                                                        \
+                }                                                                                                     \
+            }
+            K3M_COMP(0) K3M_COMP(1) K3M_COMP(2)
+#undef K3M_COMP
+            long long moff;
+            if (cls3_p(op, idx, moff) == 1) {
+                const double rz = tb.rd[0], rx = tb.rd[1], ry = tb.rd[2];
+                const double div = (WV[0][rv.o[2] + q] - WV[0][rv.o[1] + q]) * rz + (WV[1][rv.o[1] + q + K3T_SR] - WV[1][rv.o[1] + q]) * rx +
+                                   (WV[2][rv.o[1] + q + 1] - WV[2][rv.o[1] + q]) * ry;
+                y.p[3][c] = SCALED ? div * pl_rcp(rz + rx + ry) : op.Kc * div;
+            }
+        }
+        __syncthreads();                              // everybody has read the oldest planes
+        if (more) {
+#pragma unroll
+            for (int m = 0; m < 3; m++) put(WV[m], (li + 2) % 3, tv[m]);
+            put(WS, li & 1, ts); put(WN, (li + 1) & 1, tn); put(WP, (li + 1) & 1, tp);
+        }
+        __syncthreads();
+    }
+}
+// the smoother / residual on the same rings (no pressure): MODE 0 one Chebyshev sweep from a non-zero iterate, 1 residual f - A v
+template <int MODE>
+__global__ __launch_bounds__(256) void k3_sweep_m(Op3 op, V3 vcur, V3 vprev, V3 f, W3 out, double c1, double c2) {
+    __shared__ double WV[3][3 * K3T_SP];
+    __shared__ double WS[2 * K3T_SP], WN[2 * K3T_SP];
+    const G3& g = op.g;
+    const int lj0 = blockIdx.y * 4, lk0 = blockIdx.x * 64;
+    const int z0 = blockIdx.z * K3M_ZC, z1 = min(z0 + K3M_ZC, g.n[0]);
+    const K3PSlots ps = k3m_slots(g, lj0, lk0);
+    const double* vg[3] = {vcur.p[0], vcur.p[1], vcur.p[2]};
+    auto fetch = [&](const double* __restrict__ src, int plane, double* tmp) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) tmp[u] = ps.ok[u] ? src[ps.go[u] + (long long)plane * g.s[0]] : 0.0;
+    };
+    auto put = [&](double* __restrict__ dst, int slot, const double* tmp) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) if (ps.in[u]) dst[slot * K3T_SP + ps.lo[u]] = tmp[u];
+    };
+    {
+        double t0[9][2], t1[4][2];
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int m = 0; m < 3; m++) fetch(vg[m], z0 + a - 1, t0[3 * a + m]);
+        fetch(op.es, z0, t1[0]); fetch(op.es, z0 + 1, t1[1]); fetch(op.en, z0 - 1, t1[2]); fetch(op.en, z0, t1[3]);
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int m = 0; m < 3; m++) put(WV[m], (z0 + a - 1 + 3) % 3, t0[3 * a + m]);
+        put(WS, z0 & 1, t1[0]); put(WS, (z0 + 1) & 1, t1[1]); put(WN, (z0 + 1) & 1, t1[2]); put(WN, z0 & 1, t1[3]);
+    }
+    __syncthreads();
+    const int lk = lk0 + threadIdx.x, lj = lj0 + threadIdx.y;
+    const bool mine = lk < g.n[2] && lj < g.n[1];
+    const int q = (threadIdx.y + 1) * K3T_SR + (threadIdx.x + 1);
+    const double* V[3] = {WV[0], WV[1], WV[2]};
+    K3Tab tb;
+    {
+        const int j = min(lj, g.n[1] - 1) + g.o[1], k = min(lk, g.n[2] - 1) + g.o[2];
+        tb.rd[1] = TB(g.rd[1], j); tb.rdm[1] = TB(g.rd[1], j - 1); tb.rD[1] = TB(g.rD[1], j); tb.rDp[1] = TB(g.rD[1], j + 1);
+        tb.rd[2] = TB(g.rd[2], k); tb.rdm[2] = TB(g.rd[2], k - 1); tb.rD[2] = TB(g.rD[2], k); tb.rDp[2] = TB(g.rD[2], k + 1);
+    }
+    for (int li = z0; li < z1; li++) {
+        {
+            const int i = li + g.o[0];
+            tb.rd[0] = TB(g.rd[0], i); tb.rdm[0] = TB(g.rd[0], i - 1); tb.rD[0] = TB(g.rD[0], i); tb.rDp[0] = TB(g.rD[0], i + 1);
+        }
+        const bool more = li + 1 < z1;
+        double tv[3][2], ts[2], tn[2];
+        if (more) {
+#pragma unroll
+            for (int m = 0; m < 3; m++) fetch(vg[m], li + 2, tv[m]);
+            fetch(op.es, li + 2, ts); fetch(op.en, li + 1, tn);
+        }
+        K3Ring rv, rs, rn;
+        rv.o[0] = ((li + 2) % 3) * K3T_SP; rv.o[1] = (li % 3) * K3T_SP; rv.o[2] = ((li + 1) % 3) * K3T_SP;
+        rs.o[0] = 0; rs.o[1] = (li & 1) * K3T_SP; rs.o[2] = ((li + 1) & 1) * K3T_SP;
+        rn.o[0] = ((li + 1) & 1) * K3T_SP; rn.o[1] = (li & 1) * K3T_SP; rn.o[2] = 0;
+        if (mine) {
+            const long long c = i3(g, li, lj, lk);
+            const int idx[3] = {li + g.o[0], lj + g.o[1], lk + g.o[2]};
+#define K3M_COMP(D)                                                                                                   \
+            {                                                                                                         \
+                long long moff;                                                                                       \
+                if (cls3<D>(op, idx, moff) == C3_INT) {                                                               \
+                    double Av, dg;                                                                                    \
+                    row3r<D>(tb, V, WS, WN, rv, rs, rn, q, Av, dg);                                                   \
+                    if (MODE == 0) {                                                                                  \
+                        const double v0 = WV[D][rv.o[1] + q];                                                         \
+                        const double mom = (c1 != 0.0) ? c1 * (v0 - (vprev.p[D] ? vprev.p[D][c] : 0.0)) : 0.0;        \
+                        out.p[D][c] = v0 + mom + (c2 * (Av - f.p[D][c])) * pl_rcp(dg);                                \
+                    } else out.p[D][c] = f.p[D][c] - Av;                                                              \
+                }                                                                                                     \
+            }
+            K3M_COMP(0) K3M_COMP(1) K3M_COMP(2)
+#undef K3M_COMP
+        }
+        __syncthreads();
+        if (more) {
+#pragma unroll
+            for (int m = 0; m < 3; m++) put(WV[m], (li + 2) % 3, tv[m]);
+            put(WS, li & 1, ts); put(WN, (li + 1) & 1, tn);
+        }
+        __syncthreads();
+    }
+}
+// ---- the rim of the marching kernels: every node with a wall, slaved, ghost or symmetry row lies on one of the nine planes
+// index in {0, n - 2, n - 1} of an axis (global indices), plus the pressure anchor.  One thread per rim node (~600 000 of 17 M at 257^3;
+// a full-grid pass that only classifies took 169 us per launch): ALL rows of the node by the per-node row functions.
+struct RimArgs { Op3 op; V4 x; W4 y; V3 vprev; V3 f; double c1, c2; int what, scaled; };       // what: 0 apply, 1 Chebyshev sweep, 2 residual
+__global__ __launch_bounds__(256) void k3_rim(RimArgs a) {
+    const G3& g = a.op.g;
+    const long long N[3] = {3LL * g.n[1] * g.n[2], 3LL * g.n[0] * g.n[2], 3LL * g.n[0] * g.n[1]};
+    long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    int l[3];
+    auto rimpos = [&](int ax, int which) { const int gi = which == 0 ? 0 : g.gn[ax] - 3 + which; return gi - g.o[ax]; };      // 0, n-2, n-1 -> local
+    auto on_rim = [&](int ax, int li) { const int gi = li + g.o[ax]; return gi == 0 || gi >= g.gn[ax] - 2; };
+    if (t < N[0]) {                                         // z slabs: (which, j, k)
+        const int w = (int)(t / ((long long)g.n[1] * g.n[2])); const long long r = t % ((long long)g.n[1] * g.n[2]);
+        l[0] = rimpos(0, w); l[1] = (int)(r / g.n[2]); l[2] = (int)(r % g.n[2]);
+    } else if ((t -= N[0]) < N[1]) {                        // x slabs: (which, i, k), without the z slabs' nodes
+        const int w = (int)(t / ((long long)g.n[0] * g.n[2])); const long long r = t % ((long long)g.n[0] * g.n[2]);
+        l[1] = rimpos(1, w); l[0] = (int)(r / g.n[2]); l[2] = (int)(r % g.n[2]);
+        if (on_rim(0, l[0])) return;
+    } else if ((t -= N[1]) < N[2]) {                        // y slabs: (which, i, j), without the others'
+        const int w = (int)(t / ((long long)g.n[0] * g.n[1])); const long long r = t % ((long long)g.n[0] * g.n[1]);
+        l[2] = rimpos(2, w); l[0] = (int)(r / g.n[1]); l[1] = (int)(r % g.n[1]);
+        if (on_rim(0, l[0]) || on_rim(1, l[1])) return;
+    } else if (t == N[2] && a.what == 0) {                  // the pressure anchor
+        for (int q = 0; q < 3; q++) l[q] = a.op.anchor[q] - g.o[q];
+        if (on_rim(0, l[0]) || on_rim(1, l[1]) || on_rim(2, l[2])) return;
+    } else return;
+    for (int q = 0; q < 3; q++) if (l[q] < 0 || l[q] >= g.n[q]) return;
+    const long long c = i3(g, l[0], l[1], l[2]);
+    const int idx[3] = {l[0] + g.o[0], l[1] + g.o[1], l[2] + g.o[2]};
+    const int i = idx[0], j = idx[1], k = idx[2];
+    const double* v[3] = {a.x.p[0], a.x.p[1], a.x.p[2]};
+    if (a.what == 0) {
+        const double* __restrict__ P = a.x.p[3];
+        const bool SC = a.scaled != 0;
+        a.y.p[0][c] = apply_vel3<0>(a.op, v, P, c, idx, SC); a.y.p[1][c] = apply_vel3<1>(a.op, v, P, c, idx, SC); a.y.p[2][c] = apply_vel3<2>(a.op, v, P, c, idx, SC);
+        long long moff;
+        const int cl = cls3_p(a.op, idx, moff);
+        double yp;
+        if (cl == 0) yp = SC ? P[c] : a.op.Kc * P[c];
+        else if (cl == 2) yp = SC ? (P[c + moff] - P[c]) : a.op.Kb * (P[c + moff] - P[c]);
+        else {
+            const double rz = TB(g.rd[0], i), rx = TB(g.rd[1], j), ry = TB(g.rd[2], k);
+            const double div = (v[0][c + g.s[0]] - v[0][c]) * rz + (v[1][c + g.s[1]] - v[1][c]) * rx + (v[2][c + g.s[2]] - v[2][c]) * ry;
+            yp = SC ? div * pl_rcp(rz + rx + ry) : a.op.Kc * div;
+        }
+        a.y.p[3][c] = yp;
+    } else if (a.what == 1) {
+        a.y.p[0][c] = cheb3<0>(a.op, v, a.vprev.p[0], a.f.p[0], a.c1, a.c2, c, idx, 0);
+        a.y.p[1][c] = cheb3<1>(a.op, v, a.vprev.p[1], a.f.p[1], a.c1, a.c2, c, idx, 0);
+        a.y.p[2][c] = cheb3<2>(a.op, v, a.vprev.p[2], a.f.p[2], a.c1, a.c2, c, idx, 0);
+    } else {
+        a.y.p[0][c] = resid3<0>(a.op, v, a.f.p[0], c, idx, 0); a.y.p[1][c] = resid3<1>(a.op, v, a.f.p[1], c, idx, 0); a.y.p[2][c] = resid3<2>(a.op, v, a.f.p[2], c, idx, 0);
+    }
+}
+static void launch_rim3(hipStream_t stream, const RimArgs& a) {
+    const G3& g = a.op.g;
+    const long long n = 3LL * g.n[1] * g.n[2] + 3LL * g.n[0] * g.n[2] + 3LL * g.n[0] * g.n[1] + 1;
+    hipLaunchKernelGGL(k3_rim, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
+}
+static dim3 grid3m(const G3& g) { return dim3((g.n[2] + 63) / 64, (g.n[1] + 3) / 4, (g.n[0] + K3M_ZC - 1) / K3M_ZC); }
+static bool k3_use_lds(const G3& g) {
+    static const bool on = !(getenv("PYLAMP_3D_LDS") && atoi(getenv("PYLAMP_3D_LDS")) == 0);
+    return on && (long long)g.n[0] * g.n[1] * g.n[2] >= 200000;        // the small (latency-bound) levels keep the per-node kernels
 }
 
 // full-weighting restriction: vertex-centred [1/4 1/2 1/4] along the component's own axis, cell-centred [1/8 3/8 3/8 1/8]
@@ -435,6 +795,42 @@ __global__ __launch_bounds__(256) void k3_dots(long long n, Dot5 d, double* __re
     }
     __syncthreads();
     if (threadIdx.x < 5) part[5 * blockIdx.x + threadIdx.x] = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
+}
+// The second reduction point of BiCGStab with everything the velocity-error estimate needs, in ONE pass (one rank; vectors of 4 consecutive
+// arrays of `vol` elements, the pressure array last): part[11 b + ..] = t.s, t.t, r~.s, r~.t, s.s | the same three of the pressure array
+// (t.s, t.t, s.s: the continuity part of |s - omega t|^2 follows) | |(x + dx)_vel|^2 | yw.s_p, yw.t_p (the anchor-mode term).
+// Until round 4 the estimate cost three more passes and three more host synchronisations per late iteration.
+struct Fuse11 { const double* t; const double* s; const double* rt; const double* x; const double* dx; const double* yw; long long vol; };
+__global__ __launch_bounds__(256) void k3_dots11(Fuse11 a, double* __restrict__ part) {
+    double acc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const long long n = 4 * a.vol, np = 3 * a.vol;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        const double T = a.t[e], S = a.s[e], R = a.rt[e];
+        acc[0] += T * S; acc[1] += T * T; acc[2] += R * S; acc[3] += R * T; acc[4] += S * S;
+        if (e >= np) {
+            acc[5] += T * S; acc[6] += T * T; acc[7] += S * S;
+            if (a.yw) { const double Y = a.yw[e - np]; acc[9] += Y * S; acc[10] += Y * T; }
+        } else if (a.x) { const double X = a.x[e] + (a.dx ? a.dx[e] : 0.0); acc[8] += X * X; }
+    }
+    __shared__ double sh[11][4];
+    for (int q = 0; q < 11; q++) {
+        double v = acc[q];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if ((threadIdx.x & 63) == 0) sh[q][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 11) part[11 * blockIdx.x + threadIdx.x] = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
+}
+// x += alpha y + omega z, r = s - omega t, and the NEXT direction p = r + beta (p - omega v) in the same pass
+__global__ void k3_xrp_update(long long n, double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z, double* __restrict__ r,
+                              const double* __restrict__ s, const double* __restrict__ t_, double* __restrict__ p, const double* __restrict__ v,
+                              double alpha, double omega, double beta) {
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        x[t] += alpha * y[t] + omega * z[t];
+        const double rn = s[t] - omega * t_[t];
+        r[t] = rn;
+        p[t] = rn + beta * (p[t] - omega * v[t]);
+    }
 }
 __global__ __launch_bounds__(256) void k3_random(G3 g, double* __restrict__ v, unsigned seed) {
     K3_PROLOGUE(g)
@@ -565,6 +961,7 @@ struct Lev3 {
     G3Host gh; Op3 op{};
     double *es = nullptr, *en = nullptr; bool own = false;
     double* v[3][3] = {{nullptr}}; double* f[3] = {nullptr}; double* r[3] = {nullptr};
+    double* dinv[3] = {nullptr, nullptr, nullptr};      // 1 / diag of the velocity rows (k3_dinv)
     double lmax = 3.0;
     double* eig[3] = {nullptr, nullptr, nullptr}; bool eig_valid = false;      // eigenvector of the last power iteration (warm restart)
 };
@@ -662,7 +1059,7 @@ static void free_levels3(pl3_ctx* ctx) {
     for (Lev3* L : ctx->levels) {
         if (L->own) { (void)hipFree(L->es); (void)hipFree(L->en); }
         for (int b = 0; b < 3; b++) for (int q = 0; q < 3; q++) if (L->v[b][q]) (void)hipFree(L->v[b][q]);
-        for (int q = 0; q < 3; q++) { if (L->f[q]) (void)hipFree(L->f[q]); if (L->r[q]) (void)hipFree(L->r[q]); if (L->eig[q]) (void)hipFree(L->eig[q]); }
+        for (int q = 0; q < 3; q++) { if (L->f[q]) (void)hipFree(L->f[q]); if (L->r[q]) (void)hipFree(L->r[q]); if (L->eig[q]) (void)hipFree(L->eig[q]); if (L->dinv[q]) (void)hipFree(L->dinv[q]); }
         if (L->gh.tables) (void)hipFree(L->gh.tables);
         delete L;
     }
@@ -763,8 +1160,8 @@ static int need_vecs(pl3_ctx* ctx, int nvec) {
             for (int q = 1; q < 4; q++) ctx->vec[v][q] = ctx->vec[v][0] + (long long)q * vol;
         }
     if (!ctx->part) {
-        P3_TRY(dmal(ctx, &ctx->part, 5 * D3_BLOCKS));
-        P3_HIP(ctx, hipHostMalloc((void**)&ctx->hpart, 5 * D3_BLOCKS * sizeof(double)));
+        P3_TRY(dmal(ctx, &ctx->part, 11 * D3_BLOCKS));
+        P3_HIP(ctx, hipHostMalloc((void**)&ctx->hpart, 11 * D3_BLOCKS * sizeof(double)));
     }
     return 0;
 }
@@ -844,12 +1241,20 @@ static W4 wv4(double* const* p) { W4 v; for (int q = 0; q < 4; q++) v.p[q] = p[q
 static V3 cv3(double* const* p) { V3 v; for (int q = 0; q < 3; q++) v.p[q] = p[q]; return v; }
 static W3 wv3(double* const* p) { W3 v; for (int q = 0; q < 3; q++) v.p[q] = p[q]; return v; }
 
+// y = A x (scaled: D_r A x): the marching LDS kernel for the interior rows + the per-node kernel on the rim, or the per-node kernel alone
+template <bool SCALED> static void launch_apply3(pl3_ctx* ctx, const Op3& op, double* const* in, double* const* out) {
+    if (k3_use_lds(op.g)) {
+        hipLaunchKernelGGL(k3_apply_m<SCALED>, grid3m(op.g), dim3(64, 4), 0, ctx->stream, op, cv4(in), wv4(out));
+        RimArgs ra{}; ra.op = op; ra.x = cv4(in); ra.y = wv4(out); ra.what = 0; ra.scaled = SCALED ? 1 : 0;
+        launch_rim3(ctx->stream, ra);
+    } else hipLaunchKernelGGL(k3_apply<SCALED>, grid3(op.g), dim3(64, 4), 0, ctx->stream, op, cv4(in), wv4(out), 0);
+}
 extern "C" int pl3_stokes_apply(pl3_ctx* ctx, const double* x, double* y) {
     if (!ctx->op_ready) return p3_fail(ctx, "stokes operator not set");
     P3_HIP(ctx, hipSetDevice(ctx->device));
     P3_TRY(need_vecs(ctx, 2));
     P3_TRY(upload3(ctx, x, 4, ctx->vec[0]));                 // (the upload fills the ring of nodes around the block as well)
-    hipLaunchKernelGGL(k3_apply<false>, grid3(ctx->op.g), dim3(64, 4), 0, ctx->stream, ctx->op, cv4(ctx->vec[0]), wv4(ctx->vec[1]));
+    launch_apply3<false>(ctx, ctx->op, ctx->vec[0], ctx->vec[1]);
     P3_HIP(ctx, hipGetLastError());
     return download3(ctx, ctx->vec[1], 4, y);
 }
@@ -867,8 +1272,8 @@ extern "C" int pl3_stokes_apply_bench(pl3_ctx* ctx, int scaled, int reps, double
     P3_TRY(need_vecs(ctx, 2));
     for (int q = 0; q < 4; q++) hipLaunchKernelGGL(k3_random, grid3(ctx->op.g), dim3(64, 4), 0, ctx->stream, ctx->op.g, ctx->vec[0][q], 99u + q);
     auto launch = [&]() {
-        if (scaled) hipLaunchKernelGGL(k3_apply<true>, grid3(ctx->op.g), dim3(64, 4), 0, ctx->stream, ctx->op, cv4(ctx->vec[0]), wv4(ctx->vec[1]));
-        else hipLaunchKernelGGL(k3_apply<false>, grid3(ctx->op.g), dim3(64, 4), 0, ctx->stream, ctx->op, cv4(ctx->vec[0]), wv4(ctx->vec[1]));
+        if (scaled) launch_apply3<true>(ctx, ctx->op, ctx->vec[0], ctx->vec[1]);
+        else launch_apply3<false>(ctx, ctx->op, ctx->vec[0], ctx->vec[1]);
     };
     launch();
     P3_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
@@ -939,7 +1344,7 @@ static int build_levels3(pl3_ctx* ctx) {
             const long long vol = L->gh.d.vol;
             if (l > 0) { L->own = true; P3_TRY(dmal(ctx, &L->es, vol)); P3_TRY(dmal(ctx, &L->en, vol)); }
             for (int b = 0; b < 3; b++) for (int q = 0; q < 3; q++) P3_TRY(dmal(ctx, &L->v[b][q], vol));
-            for (int q = 0; q < 3; q++) { P3_TRY(dmal(ctx, &L->f[q], vol)); P3_TRY(dmal(ctx, &L->r[q], vol)); }
+            for (int q = 0; q < 3; q++) { P3_TRY(dmal(ctx, &L->f[q], vol)); P3_TRY(dmal(ctx, &L->r[q], vol)); P3_TRY(dmal(ctx, &L->dinv[q], vol)); }
             ctx->levels.push_back(L);
             bool stop = false;
             for (int a = 0; a < 3; a++) if ((n[a] - 1) % 2 || (n[a] - 1) / 2 < 4) stop = true;
@@ -963,6 +1368,8 @@ static int build_levels3(pl3_ctx* ctx) {
             P3_TRY(halo3_1(ctx, L->gh.d, L->es)); P3_TRY(halo3_1(ctx, L->gh.d, L->en));      // the rows of this level and the next coarsening read the ring
         }
         L->op = ctx->op; L->op.g = L->gh.d; L->op.es = L->es; L->op.en = L->en; L->op.slave = (l == 0) ? ctx->op.slave : 0;
+        hipLaunchKernelGGL(k3_dinv, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, wv3(L->dinv));
+        P3_TRY(halo3(ctx, L->gh.d, L->dinv, 3));            // (a slaved row reads its master's entry, possibly in the neighbour block)
         // lambda_max of D^-1 A_vv by power iteration
         const long long vol = L->gh.d.vol;
         // Warm restart as in the 2-D solver (pl_solver.hip): consecutive solves on one context (a time loop, or the same operator
@@ -981,7 +1388,7 @@ static int build_levels3(pl3_ctx* ctx) {
             if (warm && it >= 1 && std::fabs(lam - lam_prev) < 0.01 * lam) break;
             lam_prev = lam;
             P3_TRY(halo3(ctx, L->gh.d, L->v[0], 3));
-            hipLaunchKernelGGL(k3_resid, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, cv3(L->v[0]), cv3(L->f), wv3(L->v[1]), 1);
+            hipLaunchKernelGGL(k3_resid, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, cv3(L->v[0]), cv3(L->f), wv3(L->v[1]), 1, 0);
             double* const* aa[2] = {L->v[1], L->v[0]}; double* const* bb[2] = {L->v[1], L->v[0]};
             double nn[2];
             P3_TRY(vdots(ctx, vol, 3, 2, aa, bb, nn));
@@ -1014,8 +1421,15 @@ static void smooth3(pl3_ctx* ctx, Lev3* L, double* const* f, int nsweep, double 
         // several ranks: the sweep reads the iterate one node into the ring (the first sweep from the zero guess: only the right-hand
         // side, at a slave's master)
         if (k == 0 && zero_guess) (void)halo3(ctx, L->gh.d, (double* const*)f, 3); else (void)halo3(ctx, L->gh.d, L->v[cur], 3);
-        hipLaunchKernelGGL(k3_cheb, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, cv3(L->v[cur]), vp, cv3(f), dst, c1, c2,
-                           (k == 0 && zero_guess) ? 1 : 0);
+        if (!(k == 0 && zero_guess) && k3_use_lds(L->gh.d)) {        // interior rows: the marching LDS kernel; the rim: the per-node kernel
+            hipLaunchKernelGGL(k3_sweep_m<0>, grid3m(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, cv3(L->v[cur]), vp, cv3(f), dst, c1, c2);
+            RimArgs ra{}; ra.op = L->op; ra.what = 1; ra.c1 = c1; ra.c2 = c2; ra.vprev = vp; ra.f = cv3(f);
+            for (int q = 0; q < 3; q++) { ra.x.p[q] = L->v[cur][q]; ra.y.p[q] = dst.p[q]; }
+            launch_rim3(ctx->stream, ra);
+        } else if (k == 0 && zero_guess)
+            hipLaunchKernelGGL(k3_cheb0, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, cv3(f), cv3(L->dinv), dst, c2);
+        else
+        hipLaunchKernelGGL(k3_cheb, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, cv3(L->v[cur]), vp, cv3(f), dst, c1, c2, 0, 0);
         prev = cur; cur = nxt;
     }
 }
@@ -1039,7 +1453,13 @@ static void vcycle3(pl3_ctx* ctx, size_t l, double* const* f, int& out_buf, cons
     const int nu = l == 0 ? nu_fine : nu_rest;
     smooth3(ctx, L, f, nu, ctx->cheb_ratio, true, cur);
     (void)halo3(ctx, L->gh.d, L->v[cur], 3);
-    hipLaunchKernelGGL(k3_resid, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, cv3(L->v[cur]), cv3(f), wv3(L->r), 0);
+    if (k3_use_lds(L->gh.d)) {
+        V3 none{};
+        hipLaunchKernelGGL(k3_sweep_m<1>, grid3m(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, cv3(L->v[cur]), none, cv3(f), wv3(L->r), 0.0, 0.0);
+        RimArgs ra{}; ra.op = L->op; ra.what = 2; ra.f = cv3(f);
+        for (int q = 0; q < 3; q++) { ra.x.p[q] = L->v[cur][q]; ra.y.p[q] = L->r[q]; }
+        launch_rim3(ctx->stream, ra);
+    } else hipLaunchKernelGGL(k3_resid, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, cv3(L->v[cur]), cv3(f), wv3(L->r), 0, 0);
     Lev3* C = ctx->levels[l + 1];
     (void)halo3(ctx, L->gh.d, L->r, 3);
     hipLaunchKernelGGL(k3_restrict, grid3(C->gh.d), dim3(64, 4), 0, ctx->stream, L->gh.d, C->op, cv3(L->r), wv3(C->f));
@@ -1116,7 +1536,10 @@ static int bicgstab3(pl3_ctx* ctx, long long vol, int na, const Op3Fn& A, const 
     const double n_amp = (double)std::max(g.gn[0], std::max(g.gn[1], g.gn[2]));
     double tol = rtol, est_rec = 0.0, a_mom = 1.0;
     int est_checks = 0;
-    bool resume = false, broke = false;
+    bool resume = false, broke = false, p_fused = false;
+    // one rank, Stokes vectors (4 consecutive arrays each): the fused reduction / update kernels
+    const bool fused = ctx->nranks == 1 && na == 4 && M && flat3(t, s, rt) && flat3(dxb, x, p) && flat3(r, v, y) && flat3(z) &&
+                       !(getenv("PYLAMP_3D_FUSED") && atoi(getenv("PYLAMP_3D_FUSED")) == 0);
     double rho = 1.0, alpha = 1.0, omega = 1.0, rho_new = 0.0, rnorm = 0.0, best = 0.0; int best_it = 0;
     st->error_estimate = 0.0;
     // the component of the residual along the deflated anchor mode has its own amplification |w| / |u| (see pl_solver.hip)
@@ -1140,7 +1563,7 @@ static int bicgstab3(pl3_ctx* ctx, long long vol, int na, const Op3Fn& A, const 
     for (;;) {
         if (!resume) {
             zero(p); zero(v);
-            rho = alpha = omega = 1.0;
+            rho = alpha = omega = 1.0; p_fused = false;
             { double* const* aa[2] = {rt, r}; double* const* bb[2] = {r, r}; P3_TRY(vdots(ctx, vol, na, 2, aa, bb, d)); }
             rho_new = d[0]; rnorm = std::sqrt(d[1]);
             broke = false;
@@ -1151,7 +1574,8 @@ static int bicgstab3(pl3_ctx* ctx, long long vol, int na, const Op3Fn& A, const 
             it++;
             if (!(std::fabs(rho_new) > 0.0) || !std::isfinite(rho_new)) { broke = true; break; }
             const double beta = (rho_new / rho) * (alpha / omega);
-            if (flat3(p, r, v)) hipLaunchKernelGGL(k3_p_update, g1(na * vol), dim3(256), 0, ctx->stream, na * vol, p[0], (const double*)r[0], (const double*)v[0], beta, omega);
+            if (p_fused) p_fused = false;                   // (written by k3_xrp_update of the previous iteration)
+            else if (flat3(p, r, v)) hipLaunchKernelGGL(k3_p_update, g1(na * vol), dim3(256), 0, ctx->stream, na * vol, p[0], (const double*)r[0], (const double*)v[0], beta, omega);
             else for (int c = 0; c < na; c++) hipLaunchKernelGGL(k3_p_update, g1(vol), dim3(256), 0, ctx->stream, vol, p[c], (const double*)r[c], (const double*)v[c], beta, omega);
             double* const* yv = p;
             if (M) { P3_TRY((*M)(p, y)); yv = y; }
@@ -1164,9 +1588,27 @@ static int bicgstab3(pl3_ctx* ctx, long long vol, int na, const Op3Fn& A, const 
             if (M) { P3_TRY((*M)(s, z)); zv = z; }
             P3_TRY(A(zv, t));
             // one reduction: t.s, t.t, rt.s, rt.t, s.s  ->  omega, rho' = rt.s - omega rt.t, |r|^2 = s.s - 2 omega t.s + omega^2 t.t
+            double f11[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            const bool late = use_est && rnorm <= 1e3 * tol * bnorm;
+            if (fused) {       // ... and, near the end, everything the error estimate of the updated iterate needs, in the same pass
+                Fuse11 fa{}; fa.t = t[0]; fa.s = s[0]; fa.rt = rt[0]; fa.vol = vol;
+                if (late) { fa.x = x[0]; fa.dx = (dx != x) ? dx[0] : nullptr; fa.yw = anchor_term ? ctx->dfl_y : nullptr; }
+                hipLaunchKernelGGL(k3_dots11, dim3(D3_BLOCKS), dim3(256), 0, ctx->stream, fa, ctx->part);
+                P3_HIP(ctx, hipMemcpyAsync(ctx->hpart, ctx->part, 11 * D3_BLOCKS * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+                P3_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                for (int q = 0; q < 11; q++) { double sm = 0.0; for (int kk = 0; kk < D3_BLOCKS; kk++) sm += ctx->hpart[11 * kk + q]; f11[q] = sm; }
+                for (int q = 0; q < 5; q++) d[q] = f11[q];
+            } else
             { double* const* aa[5] = {t, t, rt, rt, s}; double* const* bb[5] = {s, t, s, t, s}; P3_TRY(vdots(ctx, vol, na, 5, aa, bb, d)); }
             omega = (d[1] > 0.0) ? d[0] / d[1] : 0.0;
-            if (flat3(dx, yv, zv) && flat3(r, s, t))
+            if (fused) {
+                const double rho_next = d[2] - omega * d[3];
+                const double beta_next = (rho_next / rho_new) * (alpha / omega);
+                hipLaunchKernelGGL(k3_xrp_update, g1(na * vol), dim3(256), 0, ctx->stream, na * vol, dx[0], (const double*)yv[0], (const double*)zv[0], r[0],
+                                   (const double*)s[0], (const double*)t[0], p[0], (const double*)v[0], alpha, omega, beta_next);
+                p_fused = std::isfinite(beta_next);
+            }
+            else if (flat3(dx, yv, zv) && flat3(r, s, t))
                 hipLaunchKernelGGL(k3_xr_update, g1(na * vol), dim3(256), 0, ctx->stream, na * vol, dx[0], (const double*)yv[0], (const double*)zv[0], r[0],
                                    (const double*)s[0], (const double*)t[0], alpha, omega);
             else for (int c = 0; c < na; c++)
@@ -1179,6 +1621,12 @@ static int bicgstab3(pl3_ctx* ctx, long long vol, int na, const Op3Fn& A, const 
             if (rnorm < best) { best = rnorm; best_it = it; }
             if (trace3) fprintf(stderr, "[pylamp3 bicgstab] it %3d  |r|/|b| %.3e\n", it, rnorm / bnorm);
             est_rec = 0.0;
+            if (fused && late) {                                  // (sums of the fused reduction; |x_vel| of the iterate BEFORE this update: needed to ~10 %)
+                const double rc0 = f11[7] - 2.0 * omega * f11[5] + omega * omega * f11[6], xx = f11[8];
+                const double rcc = rc0 > 0.0 ? rc0 : 0.0, rm = rr - rcc > 0.0 ? rr - rcc : 0.0;
+                const double ap = (anchor_term && xx > 0.0) ? std::fabs((f11[9] - omega * f11[10]) / ctx->dfl_yAw) * std::sqrt(ctx->dfl_wvel2 / xx) : 0.0;
+                if (xx > 0.0) est_rec = (n_amp * std::sqrt(rcc) + a_mom * std::sqrt(rm)) / std::sqrt(xx) + ap;
+            } else
             if (use_est && rnorm <= 1e3 * tol * bnorm) {          // near the end: the estimate from the recurrence residual
                 double rc[1], xx = 0.0;
                 { double* const* aa[1] = {r + 3}; P3_TRY(vdots(ctx, vol, 1, 1, aa, aa, rc)); }
@@ -1276,7 +1724,7 @@ extern "C" int pl3_stokes_solve(pl3_ctx* ctx, const double* rhs, double* x, int 
     double* const* W = ctx->vec[13];
     Op3Fn A = [&](double* const* in, double* const* out) -> int {
         P3_TRY(halo3(ctx, g, in, 4));
-        hipLaunchKernelGGL(k3_apply<true>, grid3(g), dim3(64, 4), 0, ctx->stream, ctx->op, cv4(in), wv4(out));
+        launch_apply3<true>(ctx, ctx->op, in, out);
         napply++; return 0;
     };
     Op3Fn M = [&](double* const* in, double* const* out) -> int {
@@ -1436,7 +1884,7 @@ extern "C" int pl3_heat_set_coeffs(pl3_ctx* ctx, const double* zmp, const double
 }
 static int need_hvecs(pl3_ctx* ctx) {
     for (int v = 0; v < 12; v++) if (!ctx->hvec[v]) P3_TRY(dmal(ctx, &ctx->hvec[v], ctx->geom.d.vol));
-    if (!ctx->part) { P3_TRY(dmal(ctx, &ctx->part, 5 * D3_BLOCKS)); P3_HIP(ctx, hipHostMalloc((void**)&ctx->hpart, 5 * D3_BLOCKS * sizeof(double))); }
+    if (!ctx->part) { P3_TRY(dmal(ctx, &ctx->part, 11 * D3_BLOCKS)); P3_HIP(ctx, hipHostMalloc((void**)&ctx->hpart, 11 * D3_BLOCKS * sizeof(double))); }
     return 0;
 }
 extern "C" int pl3_heat_apply(pl3_ctx* ctx, const double* x, double* y) {
