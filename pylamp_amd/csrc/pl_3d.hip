@@ -408,59 +408,77 @@ template <int D> __device__ inline void row3r(const K3Tab& tb, const double* con
     Av = a; dg = d;
 }
 // this thread's (up to 2) elements of one plane slab (6 rows x 66 columns): global offset within the plane li = 0, LDS offset, validity
-struct K3PSlots { long long go[2]; int lo[2]; bool ok[2], in[2]; };
+// (addresses beyond the block's ring are clamped into it: every thread loads unconditionally -- a predicated load per array and element
+//  was a basic block of its own with a branch, 24 per plane -- and what lands in those window entries is never read: the rows the
+//  marching kernels evaluate are strictly inside the domain.  has2: this thread also carries one of the elements 256..395.)
+struct K3PSlots { long long go[2]; int lo[2]; bool has2; };
 __device__ inline K3PSlots k3m_slots(const G3& g, int lj0, int lk0) {
     K3PSlots q;
     const int tid = threadIdx.y * 64 + threadIdx.x;
+    q.has2 = tid + 256 < 396;
 #pragma unroll
     for (int u = 0; u < 2; u++) {
-        const int e = tid + 256 * u, r = e / 66, c = e % 66;
-        const int lj = lj0 + r - 1, lk = lk0 + c - 1;
-        q.in[u] = e < 396;
-        q.ok[u] = q.in[u] && lj <= g.n[1] && lk <= g.n[2];
-        q.go[u] = q.ok[u] ? i3(g, 0, lj, lk) : 0;
+        const int e = min(tid + 256 * u, 395), r = e / 66, c = e % 66;
+        const int lj = min(lj0 + r - 1, g.n[1]), lk = min(lk0 + c - 1, g.n[2]);
+        q.go[u] = i3(g, 0, lj, lk);
         q.lo[u] = r * K3T_SR + c;
     }
     return q;
 }
+// strictly inside the domain in the two in-plane axes / in z: all four rows of such a node are interior rows (cls3 == C3_INT, cls3_p == 1
+// but for the anchor cell, which k3_rim rewrites behind the marching kernel)
+__device__ inline bool k3m_inside(const G3& g, int ax, int l) { const int gi = l + g.o[ax]; return l < g.n[ax] && gi >= 1 && gi <= g.gn[ax] - 3; }
+// Tile of a workgroup.  The hardware deals consecutive workgroup ids round-robin to the 8 XCDs, each with an L2 of its own; with the
+// plain (k, j, z-chunk) order the neighbours that share a tile's halo rows and the cache lines of its halo columns sit on 8 different
+// L2s and the halo is fetched from the fabric every time (measured: 2.6x the algorithmic bytes).  band != 0: XCD x gets the x-th eighth
+// of the tile list, so neighbours meet in one L2.
+struct K3Tile { int bx, by, bz; };
+__device__ inline K3Tile k3m_tile(const G3& g, int band, int zc) {
+    const unsigned nx = (g.n[2] + 63) / 64, ny = (g.n[1] + 3) / 4, nz = (g.n[0] + zc - 1) / zc;
+    const unsigned total = nx * ny * nz, id = blockIdx.x;
+    unsigned lid = id;
+    if (band) { const unsigned fl = total / 8, rem = total % 8, xcd = id % 8; lid = xcd * fl + min(xcd, rem) + id / 8; }
+    K3Tile t; t.bx = lid % nx; t.by = (lid / nx) % ny; t.bz = lid / (nx * ny);
+    return t;
+}
 template <bool SCALED>
-__global__ __launch_bounds__(256) void k3_apply_m(Op3 op, V4 x, W4 y) {
+__global__ __launch_bounds__(256, 3) void k3_apply_m(Op3 op, V4 x, W4 y, int band, int zc) {
     // rings: the velocities need the planes i-1, i, i+1 (3 slots), the shear viscosity i, i+1, the normal viscosity and the pressure
     // i-1, i (2 slots each): 48 KB -> three workgroups per CU
     __shared__ double WV[3][3 * K3T_SP];
     __shared__ double WS[2 * K3T_SP], WN[2 * K3T_SP], WP[2 * K3T_SP];
     const G3& g = op.g;
-    const int lj0 = blockIdx.y * 4, lk0 = blockIdx.x * 64;
-    const int z0 = blockIdx.z * K3M_ZC, z1 = min(z0 + K3M_ZC, g.n[0]);
+    const K3Tile tl = k3m_tile(g, band, zc);
+    const int lj0 = tl.by * 4, lk0 = tl.bx * 64;
+    const int z0 = tl.bz * zc, z1 = min(z0 + zc, g.n[0]);
     const K3PSlots ps = k3m_slots(g, lj0, lk0);
     const double* vg[3] = {x.p[0], x.p[1], x.p[2]};
-    auto fetch = [&](const double* __restrict__ src, int plane, double* tmp) {
-#pragma unroll
-        for (int u = 0; u < 2; u++) tmp[u] = ps.ok[u] ? src[ps.go[u] + (long long)plane * g.s[0]] : 0.0;
-    };
-    auto put = [&](double* __restrict__ dst, int slot, const double* tmp) {
-#pragma unroll
-        for (int u = 0; u < 2; u++) if (ps.in[u]) dst[slot * K3T_SP + ps.lo[u]] = tmp[u];
-    };
+    // element u of plane `plane` of the six arrays (velocities, shear / normal viscosity, pressure)
+    const double* src6[6] = {vg[0], vg[1], vg[2], op.es, op.en, x.p[3]};
+    auto fetch = [&](int m, int plane, int u) { return src6[m][ps.go[u] + (long long)plane * g.s[0]]; };
     // prologue: plane p of the velocities in slot (p + 3) % 3 ... of the 2-slot rings in slot (p + 2) % 2
-    {
-        double t0[9][2], t1[6][2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        if (u == 1 && !ps.has2) break;
+        double t0[9], t1[6];
 #pragma unroll
         for (int a = 0; a < 3; a++)
 #pragma unroll
-            for (int m = 0; m < 3; m++) fetch(vg[m], z0 + a - 1, t0[3 * a + m]);
-        fetch(op.es, z0, t1[0]); fetch(op.es, z0 + 1, t1[1]); fetch(op.en, z0 - 1, t1[2]); fetch(op.en, z0, t1[3]);
-        fetch(x.p[3], z0 - 1, t1[4]); fetch(x.p[3], z0, t1[5]);
+            for (int m = 0; m < 3; m++) t0[3 * a + m] = fetch(m, z0 + a - 1, u);
+        t1[0] = fetch(3, z0, u); t1[1] = fetch(3, z0 + 1, u); t1[2] = fetch(4, z0 - 1, u); t1[3] = fetch(4, z0, u);
+        t1[4] = fetch(5, z0 - 1, u); t1[5] = fetch(5, z0, u);
+        const int lo = ps.lo[u];
 #pragma unroll
         for (int a = 0; a < 3; a++)
 #pragma unroll
-            for (int m = 0; m < 3; m++) put(WV[m], (z0 + a - 1 + 3) % 3, t0[3 * a + m]);
-        put(WS, z0 & 1, t1[0]); put(WS, (z0 + 1) & 1, t1[1]); put(WN, (z0 + 1) & 1, t1[2]); put(WN, z0 & 1, t1[3]);
-        put(WP, (z0 + 1) & 1, t1[4]); put(WP, z0 & 1, t1[5]);
+            for (int m = 0; m < 3; m++) WV[m][((z0 + a - 1 + 3) % 3) * K3T_SP + lo] = t0[3 * a + m];
+        WS[(z0 & 1) * K3T_SP + lo] = t1[0]; WS[((z0 + 1) & 1) * K3T_SP + lo] = t1[1];
+        WN[((z0 + 1) & 1) * K3T_SP + lo] = t1[2]; WN[(z0 & 1) * K3T_SP + lo] = t1[3];
+        WP[((z0 + 1) & 1) * K3T_SP + lo] = t1[4]; WP[(z0 & 1) * K3T_SP + lo] = t1[5];
     }
     __syncthreads();
     const int lk = lk0 + threadIdx.x, lj = lj0 + threadIdx.y;
-    const bool mine = lk < g.n[2] && lj < g.n[1];
+    const bool mine_jk = k3m_inside(g, 1, lj) && k3m_inside(g, 2, lk);
     const int q = (threadIdx.y + 1) * K3T_SR + (threadIdx.x + 1);
     const double* V[3] = {WV[0], WV[1], WV[2]};
     K3Tab tb;
@@ -476,85 +494,84 @@ __global__ __launch_bounds__(256) void k3_apply_m(Op3 op, V4 x, W4 y) {
         }
         // requested now, written behind the arithmetic: the planes li + 2 (velocities, shear viscosity) and li + 1 (normal viscosity, pressure)
         const bool more = li + 1 < z1;
-        double tv[3][2], ts[2], tn[2], tp[2];
+        double tq[6], tq2[6];
         if (more) {
 #pragma unroll
-            for (int m = 0; m < 3; m++) fetch(vg[m], li + 2, tv[m]);
-            fetch(op.es, li + 2, ts); fetch(op.en, li + 1, tn); fetch(x.p[3], li + 1, tp);
+            for (int m = 0; m < 6; m++) tq[m] = fetch(m, m < 4 ? li + 2 : li + 1, 0);
+            if (ps.has2) {
+#pragma unroll
+                for (int m = 0; m < 6; m++) tq2[m] = fetch(m, m < 4 ? li + 2 : li + 1, 1);
+            }
         }
         K3Ring rv, rs, rn;
         rv.o[0] = ((li + 2) % 3) * K3T_SP; rv.o[1] = (li % 3) * K3T_SP; rv.o[2] = ((li + 1) % 3) * K3T_SP;        // (li - 1 + 3) % 3 = (li + 2) % 3
         rs.o[0] = 0; rs.o[1] = (li & 1) * K3T_SP; rs.o[2] = ((li + 1) & 1) * K3T_SP;
         rn.o[0] = ((li + 1) & 1) * K3T_SP; rn.o[1] = (li & 1) * K3T_SP; rn.o[2] = 0;
-        if (mine) {
+        if (mine_jk && k3m_inside(g, 0, li)) {
+            // (nodes strictly inside the domain only: the walls, slaved, ghost and symmetry rows -- a rim two nodes thick -- and the
+            //  anchor cell are k3_rim's, launched behind)
             const long long c = i3(g, li, lj, lk);
-            const int i = li + g.o[0], j = lj + g.o[1], k = lk + g.o[2];
-            const int idx[3] = {i, j, k};
-            // (interior rows only: the walls, slaved and symmetry rows -- a rim two nodes thick -- are k3_apply<.., rim only>'s, launched behind)
 #define K3M_COMP(D)                                                                                                   \
             {                                                                                                         \
-                long long moff;                                                                                       \
-                const int cls = cls3<D>(op, idx, moff);                                                               \
-                if (cls == C3_INT) {                                                                                  \
-                    double Av, dg;                                                                                    \
-                    row3r<D>(tb, V, WS, WN, rv, rs, rn, q, Av, dg);                                                   \
-                    Av -= 2.0 * op.Kc * tb.rD[D] * (k3r_at<D, 0, 0, 0>(WP, rn, q) - k3r_at<D, -1, 0, 0>(WP, rn, q));    \
-                    y.p[D][c] = SCALED ? Av * pl_rcp(dg) : Av;                                                        \
-                }                                                                                                     \
+                double Av, dg;                                                                                        \
+                row3r<D>(tb, V, WS, WN, rv, rs, rn, q, Av, dg);                                                       \
+                Av -= 2.0 * op.Kc * tb.rD[D] * (k3r_at<D, 0, 0, 0>(WP, rn, q) - k3r_at<D, -1, 0, 0>(WP, rn, q));        \
+                y.p[D][c] = SCALED ? Av * pl_rcp(dg) : Av;                                                            \
             }
             K3M_COMP(0) K3M_COMP(1) K3M_COMP(2)
 #undef K3M_COMP
-            long long moff;
-            if (cls3_p(op, idx, moff) == 1) {
-                const double rz = tb.rd[0], rx = tb.rd[1], ry = tb.rd[2];
-                const double div = (WV[0][rv.o[2] + q] - WV[0][rv.o[1] + q]) * rz + (WV[1][rv.o[1] + q + K3T_SR] - WV[1][rv.o[1] + q]) * rx +
-                                   (WV[2][rv.o[1] + q + 1] - WV[2][rv.o[1] + q]) * ry;
-                y.p[3][c] = SCALED ? div * pl_rcp(rz + rx + ry) : op.Kc * div;
-            }
+            const double rz = tb.rd[0], rx = tb.rd[1], ry = tb.rd[2];
+            const double div = (WV[0][rv.o[2] + q] - WV[0][rv.o[1] + q]) * rz + (WV[1][rv.o[1] + q + K3T_SR] - WV[1][rv.o[1] + q]) * rx +
+                               (WV[2][rv.o[1] + q + 1] - WV[2][rv.o[1] + q]) * ry;
+            y.p[3][c] = SCALED ? div * pl_rcp(rz + rx + ry) : op.Kc * div;
         }
         __syncthreads();                              // everybody has read the oldest planes
         if (more) {
+            const int sl[6] = {((li + 2) % 3) * K3T_SP, ((li + 2) % 3) * K3T_SP, ((li + 2) % 3) * K3T_SP, (li & 1) * K3T_SP, ((li + 1) & 1) * K3T_SP, ((li + 1) & 1) * K3T_SP};
+            double* const dst6[6] = {WV[0], WV[1], WV[2], WS, WN, WP};
 #pragma unroll
-            for (int m = 0; m < 3; m++) put(WV[m], (li + 2) % 3, tv[m]);
-            put(WS, li & 1, ts); put(WN, (li + 1) & 1, tn); put(WP, (li + 1) & 1, tp);
+            for (int m = 0; m < 6; m++) dst6[m][sl[m] + ps.lo[0]] = tq[m];
+            if (ps.has2) {
+#pragma unroll
+                for (int m = 0; m < 6; m++) dst6[m][sl[m] + ps.lo[1]] = tq2[m];
+            }
         }
         __syncthreads();
     }
 }
 // the smoother / residual on the same rings (no pressure): MODE 0 one Chebyshev sweep from a non-zero iterate, 1 residual f - A v
 template <int MODE>
-__global__ __launch_bounds__(256) void k3_sweep_m(Op3 op, V3 vcur, V3 vprev, V3 f, W3 out, double c1, double c2) {
+__global__ __launch_bounds__(256, 3) void k3_sweep_m(Op3 op, V3 vcur, V3 vprev, V3 f, W3 out, double c1, double c2, int band, int zc) {
     __shared__ double WV[3][3 * K3T_SP];
     __shared__ double WS[2 * K3T_SP], WN[2 * K3T_SP];
     const G3& g = op.g;
-    const int lj0 = blockIdx.y * 4, lk0 = blockIdx.x * 64;
-    const int z0 = blockIdx.z * K3M_ZC, z1 = min(z0 + K3M_ZC, g.n[0]);
+    const K3Tile tl = k3m_tile(g, band, zc);
+    const int lj0 = tl.by * 4, lk0 = tl.bx * 64;
+    const int z0 = tl.bz * zc, z1 = min(z0 + zc, g.n[0]);
     const K3PSlots ps = k3m_slots(g, lj0, lk0);
     const double* vg[3] = {vcur.p[0], vcur.p[1], vcur.p[2]};
-    auto fetch = [&](const double* __restrict__ src, int plane, double* tmp) {
+    const double* src5[5] = {vg[0], vg[1], vg[2], op.es, op.en};
+    auto fetch = [&](int m, int plane, int u) { return src5[m][ps.go[u] + (long long)plane * g.s[0]]; };
 #pragma unroll
-        for (int u = 0; u < 2; u++) tmp[u] = ps.ok[u] ? src[ps.go[u] + (long long)plane * g.s[0]] : 0.0;
-    };
-    auto put = [&](double* __restrict__ dst, int slot, const double* tmp) {
-#pragma unroll
-        for (int u = 0; u < 2; u++) if (ps.in[u]) dst[slot * K3T_SP + ps.lo[u]] = tmp[u];
-    };
-    {
-        double t0[9][2], t1[4][2];
+    for (int u = 0; u < 2; u++) {
+        if (u == 1 && !ps.has2) break;
+        double t0[9], t1[4];
 #pragma unroll
         for (int a = 0; a < 3; a++)
 #pragma unroll
-            for (int m = 0; m < 3; m++) fetch(vg[m], z0 + a - 1, t0[3 * a + m]);
-        fetch(op.es, z0, t1[0]); fetch(op.es, z0 + 1, t1[1]); fetch(op.en, z0 - 1, t1[2]); fetch(op.en, z0, t1[3]);
+            for (int m = 0; m < 3; m++) t0[3 * a + m] = fetch(m, z0 + a - 1, u);
+        t1[0] = fetch(3, z0, u); t1[1] = fetch(3, z0 + 1, u); t1[2] = fetch(4, z0 - 1, u); t1[3] = fetch(4, z0, u);
+        const int lo = ps.lo[u];
 #pragma unroll
         for (int a = 0; a < 3; a++)
 #pragma unroll
-            for (int m = 0; m < 3; m++) put(WV[m], (z0 + a - 1 + 3) % 3, t0[3 * a + m]);
-        put(WS, z0 & 1, t1[0]); put(WS, (z0 + 1) & 1, t1[1]); put(WN, (z0 + 1) & 1, t1[2]); put(WN, z0 & 1, t1[3]);
+            for (int m = 0; m < 3; m++) WV[m][((z0 + a - 1 + 3) % 3) * K3T_SP + lo] = t0[3 * a + m];
+        WS[(z0 & 1) * K3T_SP + lo] = t1[0]; WS[((z0 + 1) & 1) * K3T_SP + lo] = t1[1];
+        WN[((z0 + 1) & 1) * K3T_SP + lo] = t1[2]; WN[(z0 & 1) * K3T_SP + lo] = t1[3];
     }
     __syncthreads();
     const int lk = lk0 + threadIdx.x, lj = lj0 + threadIdx.y;
-    const bool mine = lk < g.n[2] && lj < g.n[1];
+    const bool mine_jk = k3m_inside(g, 1, lj) && k3m_inside(g, 2, lk);
     const int q = (threadIdx.y + 1) * K3T_SR + (threadIdx.x + 1);
     const double* V[3] = {WV[0], WV[1], WV[2]};
     K3Tab tb;
@@ -569,40 +586,44 @@ __global__ __launch_bounds__(256) void k3_sweep_m(Op3 op, V3 vcur, V3 vprev, V3 
             tb.rd[0] = TB(g.rd[0], i); tb.rdm[0] = TB(g.rd[0], i - 1); tb.rD[0] = TB(g.rD[0], i); tb.rDp[0] = TB(g.rD[0], i + 1);
         }
         const bool more = li + 1 < z1;
-        double tv[3][2], ts[2], tn[2];
+        double tq[5], tq2[5];
         if (more) {
 #pragma unroll
-            for (int m = 0; m < 3; m++) fetch(vg[m], li + 2, tv[m]);
-            fetch(op.es, li + 2, ts); fetch(op.en, li + 1, tn);
+            for (int m = 0; m < 5; m++) tq[m] = fetch(m, m < 4 ? li + 2 : li + 1, 0);
+            if (ps.has2) {
+#pragma unroll
+                for (int m = 0; m < 5; m++) tq2[m] = fetch(m, m < 4 ? li + 2 : li + 1, 1);
+            }
         }
         K3Ring rv, rs, rn;
         rv.o[0] = ((li + 2) % 3) * K3T_SP; rv.o[1] = (li % 3) * K3T_SP; rv.o[2] = ((li + 1) % 3) * K3T_SP;
         rs.o[0] = 0; rs.o[1] = (li & 1) * K3T_SP; rs.o[2] = ((li + 1) & 1) * K3T_SP;
         rn.o[0] = ((li + 1) & 1) * K3T_SP; rn.o[1] = (li & 1) * K3T_SP; rn.o[2] = 0;
-        if (mine) {
+        if (mine_jk && k3m_inside(g, 0, li)) {
             const long long c = i3(g, li, lj, lk);
-            const int idx[3] = {li + g.o[0], lj + g.o[1], lk + g.o[2]};
 #define K3M_COMP(D)                                                                                                   \
             {                                                                                                         \
-                long long moff;                                                                                       \
-                if (cls3<D>(op, idx, moff) == C3_INT) {                                                               \
-                    double Av, dg;                                                                                    \
-                    row3r<D>(tb, V, WS, WN, rv, rs, rn, q, Av, dg);                                                   \
-                    if (MODE == 0) {                                                                                  \
-                        const double v0 = WV[D][rv.o[1] + q];                                                         \
-                        const double mom = (c1 != 0.0) ? c1 * (v0 - (vprev.p[D] ? vprev.p[D][c] : 0.0)) : 0.0;        \
-                        out.p[D][c] = v0 + mom + (c2 * (Av - f.p[D][c])) * pl_rcp(dg);                                \
-                    } else out.p[D][c] = f.p[D][c] - Av;                                                              \
-                }                                                                                                     \
+                double Av, dg;                                                                                        \
+                row3r<D>(tb, V, WS, WN, rv, rs, rn, q, Av, dg);                                                       \
+                if (MODE == 0) {                                                                                      \
+                    const double v0 = WV[D][rv.o[1] + q];                                                             \
+                    const double mom = (c1 != 0.0) ? c1 * (v0 - (vprev.p[D] ? vprev.p[D][c] : 0.0)) : 0.0;            \
+                    out.p[D][c] = v0 + mom + (c2 * (Av - f.p[D][c])) * pl_rcp(dg);                                    \
+                } else out.p[D][c] = f.p[D][c] - Av;                                                                  \
             }
             K3M_COMP(0) K3M_COMP(1) K3M_COMP(2)
 #undef K3M_COMP
         }
         __syncthreads();
         if (more) {
+            const int sl[5] = {((li + 2) % 3) * K3T_SP, ((li + 2) % 3) * K3T_SP, ((li + 2) % 3) * K3T_SP, (li & 1) * K3T_SP, ((li + 1) & 1) * K3T_SP};
+            double* const dst5[5] = {WV[0], WV[1], WV[2], WS, WN};
 #pragma unroll
-            for (int m = 0; m < 3; m++) put(WV[m], (li + 2) % 3, tv[m]);
-            put(WS, li & 1, ts); put(WN, (li + 1) & 1, tn);
+            for (int m = 0; m < 5; m++) dst5[m][sl[m] + ps.lo[0]] = tq[m];
+            if (ps.has2) {
+#pragma unroll
+                for (int m = 0; m < 5; m++) dst5[m][sl[m] + ps.lo[1]] = tq2[m];
+            }
         }
         __syncthreads();
     }
@@ -666,7 +687,19 @@ static void launch_rim3(hipStream_t stream, const RimArgs& a) {
     const long long n = 3LL * g.n[1] * g.n[2] + 3LL * g.n[0] * g.n[2] + 3LL * g.n[0] * g.n[1] + 1;
     hipLaunchKernelGGL(k3_rim, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
 }
-static dim3 grid3m(const G3& g) { return dim3((g.n[2] + 63) / 64, (g.n[1] + 3) / 4, (g.n[0] + K3M_ZC - 1) / K3M_ZC); }
+// planes a workgroup walks: K3M_ZC, shorter on the smaller levels until the launch has ~2 workgroups per slot of the chip (3 per CU)
+static int k3m_zc(const G3& g) {
+    static const int forced = getenv("PYLAMP_3D_ZC") ? atoi(getenv("PYLAMP_3D_ZC")) : 0;
+    if (forced > 0) return forced;
+    const long long tiles = (long long)((g.n[2] + 63) / 64) * ((g.n[1] + 3) / 4);
+    int zc = K3M_ZC;
+    while (zc > 8 && tiles * ((g.n[0] + zc - 1) / zc) < 1536) zc >>= 1;
+    return zc;
+}
+static dim3 grid3m(const G3& g) { const int zc = k3m_zc(g); return dim3(((g.n[2] + 63) / 64) * ((g.n[1] + 3) / 4) * ((g.n[0] + zc - 1) / zc)); }
+// (measured at 257^3, profiles/r04_3d257_banded_pmc.csv: banding cuts k3_apply_m's fetch from 2091 to 1218 MB per launch and its time
+//  goes UP from 455 to 517 us -- the kernel is not bound by fabric traffic; off unless PYLAMP_3D_BAND=1)
+static int k3_band() { static const int on = getenv("PYLAMP_3D_BAND") && atoi(getenv("PYLAMP_3D_BAND")) != 0; return on; }
 static bool k3_use_lds(const G3& g) {
     static const bool on = !(getenv("PYLAMP_3D_LDS") && atoi(getenv("PYLAMP_3D_LDS")) == 0);
     return on && (long long)g.n[0] * g.n[1] * g.n[2] >= 200000;        // the small (latency-bound) levels keep the per-node kernels
@@ -1244,7 +1277,7 @@ static W3 wv3(double* const* p) { W3 v; for (int q = 0; q < 3; q++) v.p[q] = p[q
 // y = A x (scaled: D_r A x): the marching LDS kernel for the interior rows + the per-node kernel on the rim, or the per-node kernel alone
 template <bool SCALED> static void launch_apply3(pl3_ctx* ctx, const Op3& op, double* const* in, double* const* out) {
     if (k3_use_lds(op.g)) {
-        hipLaunchKernelGGL(k3_apply_m<SCALED>, grid3m(op.g), dim3(64, 4), 0, ctx->stream, op, cv4(in), wv4(out));
+        hipLaunchKernelGGL(k3_apply_m<SCALED>, grid3m(op.g), dim3(64, 4), 0, ctx->stream, op, cv4(in), wv4(out), k3_band(), k3m_zc(op.g));
         RimArgs ra{}; ra.op = op; ra.x = cv4(in); ra.y = wv4(out); ra.what = 0; ra.scaled = SCALED ? 1 : 0;
         launch_rim3(ctx->stream, ra);
     } else hipLaunchKernelGGL(k3_apply<SCALED>, grid3(op.g), dim3(64, 4), 0, ctx->stream, op, cv4(in), wv4(out), 0);
@@ -1422,7 +1455,7 @@ static void smooth3(pl3_ctx* ctx, Lev3* L, double* const* f, int nsweep, double 
         // side, at a slave's master)
         if (k == 0 && zero_guess) (void)halo3(ctx, L->gh.d, (double* const*)f, 3); else (void)halo3(ctx, L->gh.d, L->v[cur], 3);
         if (!(k == 0 && zero_guess) && k3_use_lds(L->gh.d)) {        // interior rows: the marching LDS kernel; the rim: the per-node kernel
-            hipLaunchKernelGGL(k3_sweep_m<0>, grid3m(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, cv3(L->v[cur]), vp, cv3(f), dst, c1, c2);
+            hipLaunchKernelGGL(k3_sweep_m<0>, grid3m(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, cv3(L->v[cur]), vp, cv3(f), dst, c1, c2, k3_band(), k3m_zc(L->gh.d));
             RimArgs ra{}; ra.op = L->op; ra.what = 1; ra.c1 = c1; ra.c2 = c2; ra.vprev = vp; ra.f = cv3(f);
             for (int q = 0; q < 3; q++) { ra.x.p[q] = L->v[cur][q]; ra.y.p[q] = dst.p[q]; }
             launch_rim3(ctx->stream, ra);
@@ -1455,7 +1488,7 @@ static void vcycle3(pl3_ctx* ctx, size_t l, double* const* f, int& out_buf, cons
     (void)halo3(ctx, L->gh.d, L->v[cur], 3);
     if (k3_use_lds(L->gh.d)) {
         V3 none{};
-        hipLaunchKernelGGL(k3_sweep_m<1>, grid3m(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, cv3(L->v[cur]), none, cv3(f), wv3(L->r), 0.0, 0.0);
+        hipLaunchKernelGGL(k3_sweep_m<1>, grid3m(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, cv3(L->v[cur]), none, cv3(f), wv3(L->r), 0.0, 0.0, k3_band(), k3m_zc(L->gh.d));
         RimArgs ra{}; ra.op = L->op; ra.what = 2; ra.f = cv3(f);
         for (int q = 0; q < 3; q++) { ra.x.p[q] = L->v[cur][q]; ra.y.p[q] = L->r[q]; }
         launch_rim3(ctx->stream, ra);

@@ -136,7 +136,12 @@ static int local_sendrecv(pl_ctx* ctx, const PlMsg* msgs, int nmsg) {
         const PlMsg* pm = G->msgs[p]; const PlMsg* hit = nullptr;
         for (int q = 0, seen = 0; q < G->nmsg[p]; q++)
             if (pm[q].peer == ctx->rank) { if (seen == ord) { hit = &pm[q]; break; } seen++; }
-        if (!hit || hit->nsend != msgs[k].nrecv) { rc = pl_fail(ctx, "in-process transport: unmatched message"); break; }
+        if (!hit || hit->nsend != msgs[k].nrecv) {
+            char why[200];
+            snprintf(why, sizeof why, "in-process transport: unmatched message (rank %d, message %d of %d: %lld doubles expected from rank %d, which sends %lld in %d messages)",
+                     ctx->rank, k, nmsg, (long long)msgs[k].nrecv, p, hit ? (long long)hit->nsend : -1LL, G->nmsg[p]);
+            rc = pl_fail(ctx, why); break;
+        }
         if (hipMemcpyAsync(msgs[k].recv, hit->send, (size_t)msgs[k].nrecv * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
             rc = pl_fail(ctx, "in-process transport: device copy failed");
     }
