@@ -428,17 +428,77 @@ __device__ inline K3PSlots k3m_slots(const G3& g, int lj0, int lk0) {
 // strictly inside the domain in the two in-plane axes / in z: all four rows of such a node are interior rows (cls3 == C3_INT, cls3_p == 1
 // but for the anchor cell, which k3_rim rewrites behind the marching kernel)
 __device__ inline bool k3m_inside(const G3& g, int ax, int l) { const int gi = l + g.o[ax]; return l < g.n[ax] && gi >= 1 && gi <= g.gn[ax] - 3; }
+// ---- the rim of the marching kernels: every node with a wall, slaved, ghost or symmetry row lies on one of the nine planes
+// index in {0, n - 2, n - 1} of an axis (global indices), plus the pressure anchor.  One thread per rim node (~600 000 of 17 M at 257^3;
+// a full-grid pass that only classifies took 169 us per launch): ALL rows of the node by the per-node row functions.
+struct RimArgs { Op3 op; V4 x; W4 y; V3 vprev; V3 f; double c1, c2; int what, scaled; };       // what: 0 apply, 1 Chebyshev sweep, 2 residual
+__device__ inline long long k3_rim_count(const G3& g) { return 3LL * g.n[1] * g.n[2] + 3LL * g.n[0] * g.n[2] + 3LL * g.n[0] * g.n[1] + 1; }
+// (the marching kernels run this in workgroups of their own BEHIND the tiles -- the rim fills the tail of the launch instead of
+//  a 35 us launch of its own; the anchor cell, strictly inside the domain, is a pressure row only: the tiles leave it alone)
+__device__ __forceinline__ void k3_rim_body(const RimArgs& a, long long t) {
+    const G3& g = a.op.g;
+    const long long N[3] = {3LL * g.n[1] * g.n[2], 3LL * g.n[0] * g.n[2], 3LL * g.n[0] * g.n[1]};
+    bool anchor_only = false;
+    int l[3];
+    auto rimpos = [&](int ax, int which) { const int gi = which == 0 ? 0 : g.gn[ax] - 3 + which; return gi - g.o[ax]; };      // 0, n-2, n-1 -> local
+    auto on_rim = [&](int ax, int li) { const int gi = li + g.o[ax]; return gi == 0 || gi >= g.gn[ax] - 2; };
+    if (t < N[0]) {                                         // z slabs: (which, j, k)
+        const int w = (int)(t / ((long long)g.n[1] * g.n[2])); const long long r = t % ((long long)g.n[1] * g.n[2]);
+        l[0] = rimpos(0, w); l[1] = (int)(r / g.n[2]); l[2] = (int)(r % g.n[2]);
+    } else if ((t -= N[0]) < N[1]) {                        // x slabs: (which, i, k), without the z slabs' nodes
+        const int w = (int)(t / ((long long)g.n[0] * g.n[2])); const long long r = t % ((long long)g.n[0] * g.n[2]);
+        l[1] = rimpos(1, w); l[0] = (int)(r / g.n[2]); l[2] = (int)(r % g.n[2]);
+        if (on_rim(0, l[0])) return;
+    } else if ((t -= N[1]) < N[2]) {                        // y slabs: (which, i, j), without the others'
+        const int w = (int)(t / ((long long)g.n[0] * g.n[1])); const long long r = t % ((long long)g.n[0] * g.n[1]);
+        l[2] = rimpos(2, w); l[0] = (int)(r / g.n[1]); l[1] = (int)(r % g.n[1]);
+        if (on_rim(0, l[0]) || on_rim(1, l[1])) return;
+    } else if (t == N[2] && a.what == 0) {                  // the pressure anchor
+        for (int q = 0; q < 3; q++) l[q] = a.op.anchor[q] - g.o[q];
+        if (on_rim(0, l[0]) || on_rim(1, l[1]) || on_rim(2, l[2])) return;
+        anchor_only = true;
+    } else return;
+    for (int q = 0; q < 3; q++) if (l[q] < 0 || l[q] >= g.n[q]) return;
+    const long long c = i3(g, l[0], l[1], l[2]);
+    const int idx[3] = {l[0] + g.o[0], l[1] + g.o[1], l[2] + g.o[2]};
+    const int i = idx[0], j = idx[1], k = idx[2];
+    const double* v[3] = {a.x.p[0], a.x.p[1], a.x.p[2]};
+    if (a.what == 0) {
+        const double* __restrict__ P = a.x.p[3];
+        const bool SC = a.scaled != 0;
+        if (!anchor_only) { a.y.p[0][c] = apply_vel3<0>(a.op, v, P, c, idx, SC); a.y.p[1][c] = apply_vel3<1>(a.op, v, P, c, idx, SC); a.y.p[2][c] = apply_vel3<2>(a.op, v, P, c, idx, SC); }
+        long long moff;
+        const int cl = cls3_p(a.op, idx, moff);
+        double yp;
+        if (cl == 0) yp = SC ? P[c] : a.op.Kc * P[c];
+        else if (cl == 2) yp = SC ? (P[c + moff] - P[c]) : a.op.Kb * (P[c + moff] - P[c]);
+        else {
+            const double rz = TB(g.rd[0], i), rx = TB(g.rd[1], j), ry = TB(g.rd[2], k);
+            const double div = (v[0][c + g.s[0]] - v[0][c]) * rz + (v[1][c + g.s[1]] - v[1][c]) * rx + (v[2][c + g.s[2]] - v[2][c]) * ry;
+            yp = SC ? div * pl_rcp(rz + rx + ry) : a.op.Kc * div;
+        }
+        a.y.p[3][c] = yp;
+    } else if (a.what == 1) {
+        a.y.p[0][c] = cheb3<0>(a.op, v, a.vprev.p[0], a.f.p[0], a.c1, a.c2, c, idx, 0);
+        a.y.p[1][c] = cheb3<1>(a.op, v, a.vprev.p[1], a.f.p[1], a.c1, a.c2, c, idx, 0);
+        a.y.p[2][c] = cheb3<2>(a.op, v, a.vprev.p[2], a.f.p[2], a.c1, a.c2, c, idx, 0);
+    } else {
+        a.y.p[0][c] = resid3<0>(a.op, v, a.f.p[0], c, idx, 0); a.y.p[1][c] = resid3<1>(a.op, v, a.f.p[1], c, idx, 0); a.y.p[2][c] = resid3<2>(a.op, v, a.f.p[2], c, idx, 0);
+    }
+}
+__global__ __launch_bounds__(256) void k3_rim(RimArgs a) { k3_rim_body(a, (long long)blockIdx.x * 256 + threadIdx.x); }
 // Tile of a workgroup.  The hardware deals consecutive workgroup ids round-robin to the 8 XCDs, each with an L2 of its own; with the
 // plain (k, j, z-chunk) order the neighbours that share a tile's halo rows and the cache lines of its halo columns sit on 8 different
 // L2s and the halo is fetched from the fabric every time (measured: 2.6x the algorithmic bytes).  band != 0: XCD x gets the x-th eighth
 // of the tile list, so neighbours meet in one L2.
-struct K3Tile { int bx, by, bz; };
+struct K3Tile { int bx, by, bz; long long rim; };          // rim >= 0: not a tile -- the rim.th workgroup of the rim
 __device__ inline K3Tile k3m_tile(const G3& g, int band, int zc) {
     const unsigned nx = (g.n[2] + 63) / 64, ny = (g.n[1] + 3) / 4, nz = (g.n[0] + zc - 1) / zc;
     const unsigned total = nx * ny * nz, id = blockIdx.x;
+    if (id >= total) { K3Tile t; t.bx = t.by = t.bz = 0; t.rim = id - total; return t; }
     unsigned lid = id;
     if (band) { const unsigned fl = total / 8, rem = total % 8, xcd = id % 8; lid = xcd * fl + min(xcd, rem) + id / 8; }
-    K3Tile t; t.bx = lid % nx; t.by = (lid / nx) % ny; t.bz = lid / (nx * ny);
+    K3Tile t; t.bx = lid % nx; t.by = (lid / nx) % ny; t.bz = lid / (nx * ny); t.rim = -1;
     return t;
 }
 template <bool SCALED>
@@ -449,6 +509,12 @@ __global__ __launch_bounds__(256, 3) void k3_apply_m(Op3 op, V4 x, W4 y, int ban
     __shared__ double WS[2 * K3T_SP], WN[2 * K3T_SP], WP[2 * K3T_SP];
     const G3& g = op.g;
     const K3Tile tl = k3m_tile(g, band, zc);
+    if (tl.rim >= 0) {
+        RimArgs ra; ra.op = op; ra.x = x; ra.y = y; ra.what = 0; ra.scaled = SCALED ? 1 : 0; ra.c1 = ra.c2 = 0.0;
+        for (int q = 0; q < 3; q++) ra.vprev.p[q] = ra.f.p[q] = nullptr;
+        k3_rim_body(ra, tl.rim * 256 + threadIdx.y * 64 + threadIdx.x);
+        return;
+    }
     const int lj0 = tl.by * 4, lk0 = tl.bx * 64;
     const int z0 = tl.bz * zc, z1 = min(z0 + zc, g.n[0]);
     const K3PSlots ps = k3m_slots(g, lj0, lk0);
@@ -479,6 +545,7 @@ __global__ __launch_bounds__(256, 3) void k3_apply_m(Op3 op, V4 x, W4 y, int ban
     __syncthreads();
     const int lk = lk0 + threadIdx.x, lj = lj0 + threadIdx.y;
     const bool mine_jk = k3m_inside(g, 1, lj) && k3m_inside(g, 2, lk);
+    const bool anchor_jk = lj + g.o[1] == op.anchor[1] && lk + g.o[2] == op.anchor[2];
     const int q = (threadIdx.y + 1) * K3T_SR + (threadIdx.x + 1);
     const double* V[3] = {WV[0], WV[1], WV[2]};
     K3Tab tb;
@@ -523,7 +590,7 @@ __global__ __launch_bounds__(256, 3) void k3_apply_m(Op3 op, V4 x, W4 y, int ban
             const double rz = tb.rd[0], rx = tb.rd[1], ry = tb.rd[2];
             const double div = (WV[0][rv.o[2] + q] - WV[0][rv.o[1] + q]) * rz + (WV[1][rv.o[1] + q + K3T_SR] - WV[1][rv.o[1] + q]) * rx +
                                (WV[2][rv.o[1] + q + 1] - WV[2][rv.o[1] + q]) * ry;
-            y.p[3][c] = SCALED ? div * pl_rcp(rz + rx + ry) : op.Kc * div;
+            if (!(anchor_jk && li + g.o[0] == op.anchor[0])) y.p[3][c] = SCALED ? div * pl_rcp(rz + rx + ry) : op.Kc * div;
         }
         __syncthreads();                              // everybody has read the oldest planes
         if (more) {
@@ -546,6 +613,13 @@ __global__ __launch_bounds__(256, 3) void k3_sweep_m(Op3 op, V3 vcur, V3 vprev, 
     __shared__ double WS[2 * K3T_SP], WN[2 * K3T_SP];
     const G3& g = op.g;
     const K3Tile tl = k3m_tile(g, band, zc);
+    if (tl.rim >= 0) {
+        RimArgs ra; ra.op = op; ra.what = MODE == 0 ? 1 : 2; ra.scaled = 0; ra.c1 = c1; ra.c2 = c2; ra.vprev = vprev; ra.f = f;
+        for (int q = 0; q < 3; q++) { ra.x.p[q] = vcur.p[q]; ra.y.p[q] = out.p[q]; }
+        ra.x.p[3] = nullptr; ra.y.p[3] = nullptr;
+        k3_rim_body(ra, tl.rim * 256 + threadIdx.y * 64 + threadIdx.x);
+        return;
+    }
     const int lj0 = tl.by * 4, lk0 = tl.bx * 64;
     const int z0 = tl.bz * zc, z1 = min(z0 + zc, g.n[0]);
     const K3PSlots ps = k3m_slots(g, lj0, lk0);
@@ -628,65 +702,6 @@ __global__ __launch_bounds__(256, 3) void k3_sweep_m(Op3 op, V3 vcur, V3 vprev, 
         __syncthreads();
     }
 }
-// ---- the rim of the marching kernels: every node with a wall, slaved, ghost or symmetry row lies on one of the nine planes
-// index in {0, n - 2, n - 1} of an axis (global indices), plus the pressure anchor.  One thread per rim node (~600 000 of 17 M at 257^3;
-// a full-grid pass that only classifies took 169 us per launch): ALL rows of the node by the per-node row functions.
-struct RimArgs { Op3 op; V4 x; W4 y; V3 vprev; V3 f; double c1, c2; int what, scaled; };       // what: 0 apply, 1 Chebyshev sweep, 2 residual
-__global__ __launch_bounds__(256) void k3_rim(RimArgs a) {
-    const G3& g = a.op.g;
-    const long long N[3] = {3LL * g.n[1] * g.n[2], 3LL * g.n[0] * g.n[2], 3LL * g.n[0] * g.n[1]};
-    long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    int l[3];
-    auto rimpos = [&](int ax, int which) { const int gi = which == 0 ? 0 : g.gn[ax] - 3 + which; return gi - g.o[ax]; };      // 0, n-2, n-1 -> local
-    auto on_rim = [&](int ax, int li) { const int gi = li + g.o[ax]; return gi == 0 || gi >= g.gn[ax] - 2; };
-    if (t < N[0]) {                                         // z slabs: (which, j, k)
-        const int w = (int)(t / ((long long)g.n[1] * g.n[2])); const long long r = t % ((long long)g.n[1] * g.n[2]);
-        l[0] = rimpos(0, w); l[1] = (int)(r / g.n[2]); l[2] = (int)(r % g.n[2]);
-    } else if ((t -= N[0]) < N[1]) {                        // x slabs: (which, i, k), without the z slabs' nodes
-        const int w = (int)(t / ((long long)g.n[0] * g.n[2])); const long long r = t % ((long long)g.n[0] * g.n[2]);
-        l[1] = rimpos(1, w); l[0] = (int)(r / g.n[2]); l[2] = (int)(r % g.n[2]);
-        if (on_rim(0, l[0])) return;
-    } else if ((t -= N[1]) < N[2]) {                        // y slabs: (which, i, j), without the others'
-        const int w = (int)(t / ((long long)g.n[0] * g.n[1])); const long long r = t % ((long long)g.n[0] * g.n[1]);
-        l[2] = rimpos(2, w); l[0] = (int)(r / g.n[1]); l[1] = (int)(r % g.n[1]);
-        if (on_rim(0, l[0]) || on_rim(1, l[1])) return;
-    } else if (t == N[2] && a.what == 0) {                  // the pressure anchor
-        for (int q = 0; q < 3; q++) l[q] = a.op.anchor[q] - g.o[q];
-        if (on_rim(0, l[0]) || on_rim(1, l[1]) || on_rim(2, l[2])) return;
-    } else return;
-    for (int q = 0; q < 3; q++) if (l[q] < 0 || l[q] >= g.n[q]) return;
-    const long long c = i3(g, l[0], l[1], l[2]);
-    const int idx[3] = {l[0] + g.o[0], l[1] + g.o[1], l[2] + g.o[2]};
-    const int i = idx[0], j = idx[1], k = idx[2];
-    const double* v[3] = {a.x.p[0], a.x.p[1], a.x.p[2]};
-    if (a.what == 0) {
-        const double* __restrict__ P = a.x.p[3];
-        const bool SC = a.scaled != 0;
-        a.y.p[0][c] = apply_vel3<0>(a.op, v, P, c, idx, SC); a.y.p[1][c] = apply_vel3<1>(a.op, v, P, c, idx, SC); a.y.p[2][c] = apply_vel3<2>(a.op, v, P, c, idx, SC);
-        long long moff;
-        const int cl = cls3_p(a.op, idx, moff);
-        double yp;
-        if (cl == 0) yp = SC ? P[c] : a.op.Kc * P[c];
-        else if (cl == 2) yp = SC ? (P[c + moff] - P[c]) : a.op.Kb * (P[c + moff] - P[c]);
-        else {
-            const double rz = TB(g.rd[0], i), rx = TB(g.rd[1], j), ry = TB(g.rd[2], k);
-            const double div = (v[0][c + g.s[0]] - v[0][c]) * rz + (v[1][c + g.s[1]] - v[1][c]) * rx + (v[2][c + g.s[2]] - v[2][c]) * ry;
-            yp = SC ? div * pl_rcp(rz + rx + ry) : a.op.Kc * div;
-        }
-        a.y.p[3][c] = yp;
-    } else if (a.what == 1) {
-        a.y.p[0][c] = cheb3<0>(a.op, v, a.vprev.p[0], a.f.p[0], a.c1, a.c2, c, idx, 0);
-        a.y.p[1][c] = cheb3<1>(a.op, v, a.vprev.p[1], a.f.p[1], a.c1, a.c2, c, idx, 0);
-        a.y.p[2][c] = cheb3<2>(a.op, v, a.vprev.p[2], a.f.p[2], a.c1, a.c2, c, idx, 0);
-    } else {
-        a.y.p[0][c] = resid3<0>(a.op, v, a.f.p[0], c, idx, 0); a.y.p[1][c] = resid3<1>(a.op, v, a.f.p[1], c, idx, 0); a.y.p[2][c] = resid3<2>(a.op, v, a.f.p[2], c, idx, 0);
-    }
-}
-static void launch_rim3(hipStream_t stream, const RimArgs& a) {
-    const G3& g = a.op.g;
-    const long long n = 3LL * g.n[1] * g.n[2] + 3LL * g.n[0] * g.n[2] + 3LL * g.n[0] * g.n[1] + 1;
-    hipLaunchKernelGGL(k3_rim, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
-}
 // planes a workgroup walks: K3M_ZC, shorter on the smaller levels until the launch has ~2 workgroups per slot of the chip (3 per CU)
 static int k3m_zc(const G3& g) {
     static const int forced = getenv("PYLAMP_3D_ZC") ? atoi(getenv("PYLAMP_3D_ZC")) : 0;
@@ -696,7 +711,11 @@ static int k3m_zc(const G3& g) {
     while (zc > 8 && tiles * ((g.n[0] + zc - 1) / zc) < 1536) zc >>= 1;
     return zc;
 }
-static dim3 grid3m(const G3& g) { const int zc = k3m_zc(g); return dim3(((g.n[2] + 63) / 64) * ((g.n[1] + 3) / 4) * ((g.n[0] + zc - 1) / zc)); }
+static dim3 grid3m(const G3& g) {          // the tiles, then the rim (one thread per rim node)
+    const int zc = k3m_zc(g);
+    const long long rim = 3LL * g.n[1] * g.n[2] + 3LL * g.n[0] * g.n[2] + 3LL * g.n[0] * g.n[1] + 1;
+    return dim3((unsigned)(((g.n[2] + 63) / 64) * ((g.n[1] + 3) / 4) * ((g.n[0] + zc - 1) / zc) + (rim + 255) / 256));
+}
 // (measured at 257^3, profiles/r04_3d257_banded_pmc.csv: banding cuts k3_apply_m's fetch from 2091 to 1218 MB per launch and its time
 //  goes UP from 455 to 517 us -- the kernel is not bound by fabric traffic; off unless PYLAMP_3D_BAND=1)
 static int k3_band() { static const int on = getenv("PYLAMP_3D_BAND") && atoi(getenv("PYLAMP_3D_BAND")) != 0; return on; }
@@ -1278,8 +1297,6 @@ static W3 wv3(double* const* p) { W3 v; for (int q = 0; q < 3; q++) v.p[q] = p[q
 template <bool SCALED> static void launch_apply3(pl3_ctx* ctx, const Op3& op, double* const* in, double* const* out) {
     if (k3_use_lds(op.g)) {
         hipLaunchKernelGGL(k3_apply_m<SCALED>, grid3m(op.g), dim3(64, 4), 0, ctx->stream, op, cv4(in), wv4(out), k3_band(), k3m_zc(op.g));
-        RimArgs ra{}; ra.op = op; ra.x = cv4(in); ra.y = wv4(out); ra.what = 0; ra.scaled = SCALED ? 1 : 0;
-        launch_rim3(ctx->stream, ra);
     } else hipLaunchKernelGGL(k3_apply<SCALED>, grid3(op.g), dim3(64, 4), 0, ctx->stream, op, cv4(in), wv4(out), 0);
 }
 extern "C" int pl3_stokes_apply(pl3_ctx* ctx, const double* x, double* y) {
@@ -1456,9 +1473,6 @@ static void smooth3(pl3_ctx* ctx, Lev3* L, double* const* f, int nsweep, double 
         if (k == 0 && zero_guess) (void)halo3(ctx, L->gh.d, (double* const*)f, 3); else (void)halo3(ctx, L->gh.d, L->v[cur], 3);
         if (!(k == 0 && zero_guess) && k3_use_lds(L->gh.d)) {        // interior rows: the marching LDS kernel; the rim: the per-node kernel
             hipLaunchKernelGGL(k3_sweep_m<0>, grid3m(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, cv3(L->v[cur]), vp, cv3(f), dst, c1, c2, k3_band(), k3m_zc(L->gh.d));
-            RimArgs ra{}; ra.op = L->op; ra.what = 1; ra.c1 = c1; ra.c2 = c2; ra.vprev = vp; ra.f = cv3(f);
-            for (int q = 0; q < 3; q++) { ra.x.p[q] = L->v[cur][q]; ra.y.p[q] = dst.p[q]; }
-            launch_rim3(ctx->stream, ra);
         } else if (k == 0 && zero_guess)
             hipLaunchKernelGGL(k3_cheb0, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, cv3(f), cv3(L->dinv), dst, c2);
         else
@@ -1489,9 +1503,6 @@ static void vcycle3(pl3_ctx* ctx, size_t l, double* const* f, int& out_buf, cons
     if (k3_use_lds(L->gh.d)) {
         V3 none{};
         hipLaunchKernelGGL(k3_sweep_m<1>, grid3m(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, cv3(L->v[cur]), none, cv3(f), wv3(L->r), 0.0, 0.0, k3_band(), k3m_zc(L->gh.d));
-        RimArgs ra{}; ra.op = L->op; ra.what = 2; ra.f = cv3(f);
-        for (int q = 0; q < 3; q++) { ra.x.p[q] = L->v[cur][q]; ra.y.p[q] = L->r[q]; }
-        launch_rim3(ctx->stream, ra);
     } else hipLaunchKernelGGL(k3_resid, grid3(L->gh.d), dim3(64, 4), 0, ctx->stream, L->op, cv3(L->v[cur]), cv3(f), wv3(L->r), 0, 0);
     Lev3* C = ctx->levels[l + 1];
     (void)halo3(ctx, L->gh.d, L->r, 3);
