@@ -494,10 +494,15 @@ __global__ __launch_bounds__(256) void k3_rim(RimArgs a) { k3_rim_body(a, (long 
 struct K3Tile { int bx, by, bz; long long rim; };          // rim >= 0: not a tile -- the rim.th workgroup of the rim
 __device__ inline K3Tile k3m_tile(const G3& g, int band, int zc) {
     const unsigned nx = (g.n[2] + 63) / 64, ny = (g.n[1] + 3) / 4, nz = (g.n[0] + zc - 1) / zc;
-    const unsigned total = nx * ny * nz, id = blockIdx.x;
+    const unsigned total = band == 2 ? nx * 8 * ((ny * nz + 7) / 8) : nx * ny * nz, id = blockIdx.x;
     if (id >= total) { K3Tile t; t.bx = t.by = t.bz = 0; t.rim = id - total; return t; }
     unsigned lid = id;
-    if (band) { const unsigned fl = total / 8, rem = total % 8, xcd = id % 8; lid = xcd * fl + min(xcd, rem) + id / 8; }
+    if (band == 2) {       // the nx tiles of a k-row on ONE XCD (they share the cache lines of their halo columns); rows round-robin as before
+        const unsigned xcd = id % 8, m = id / 8, R = (m / nx) * 8 + xcd;
+        K3Tile t; t.bx = m % nx; t.by = R % ny; t.bz = R / ny; t.rim = R < ny * nz ? -1 : (1LL << 40);      // (padding: a rim index beyond the rim)
+        return t;
+    }
+    if (band == 1) { const unsigned fl = total / 8, rem = total % 8, xcd = id % 8; lid = xcd * fl + min(xcd, rem) + id / 8; }
     K3Tile t; t.bx = lid % nx; t.by = (lid / nx) % ny; t.bz = lid / (nx * ny); t.rim = -1;
     return t;
 }
@@ -702,6 +707,11 @@ __global__ __launch_bounds__(256, 3) void k3_sweep_m(Op3 op, V3 vcur, V3 vprev, 
         __syncthreads();
     }
 }
+// (measured at 257^3, profiles/r04_3d257_banded_pmc.csv: banding cuts k3_apply_m's fetch from 2091 to 1218 MB per launch and its time
+//  goes UP from 455 to 517 us -- the kernel is not bound by fabric traffic; off unless PYLAMP_3D_BAND=1)
+// PYLAMP_3D_BAND = 2 (the default): only the tiles of one k-row share an XCD -- they share the cache lines of their halo COLUMNS, the rows
+// stay dealt round-robin: k3_apply_m 0.425 -> 0.410 ms (0.41 of the HBM roof on the algorithmic bytes); 0: plain order
+static int k3_band() { static const int on = getenv("PYLAMP_3D_BAND") ? atoi(getenv("PYLAMP_3D_BAND")) : 2; return on; }
 // planes a workgroup walks: K3M_ZC, shorter on the smaller levels until the launch has ~2 workgroups per slot of the chip (3 per CU)
 static int k3m_zc(const G3& g) {
     static const int forced = getenv("PYLAMP_3D_ZC") ? atoi(getenv("PYLAMP_3D_ZC")) : 0;
@@ -714,11 +724,9 @@ static int k3m_zc(const G3& g) {
 static dim3 grid3m(const G3& g) {          // the tiles, then the rim (one thread per rim node)
     const int zc = k3m_zc(g);
     const long long rim = 3LL * g.n[1] * g.n[2] + 3LL * g.n[0] * g.n[2] + 3LL * g.n[0] * g.n[1] + 1;
-    return dim3((unsigned)(((g.n[2] + 63) / 64) * ((g.n[1] + 3) / 4) * ((g.n[0] + zc - 1) / zc) + (rim + 255) / 256));
+    const long long nx = (g.n[2] + 63) / 64, rows = (long long)((g.n[1] + 3) / 4) * ((g.n[0] + zc - 1) / zc);
+    return dim3((unsigned)((k3_band() == 2 ? nx * 8 * ((rows + 7) / 8) : nx * rows) + (rim + 255) / 256));
 }
-// (measured at 257^3, profiles/r04_3d257_banded_pmc.csv: banding cuts k3_apply_m's fetch from 2091 to 1218 MB per launch and its time
-//  goes UP from 455 to 517 us -- the kernel is not bound by fabric traffic; off unless PYLAMP_3D_BAND=1)
-static int k3_band() { static const int on = getenv("PYLAMP_3D_BAND") && atoi(getenv("PYLAMP_3D_BAND")) != 0; return on; }
 static bool k3_use_lds(const G3& g) {
     static const bool on = !(getenv("PYLAMP_3D_LDS") && atoi(getenv("PYLAMP_3D_LDS")) == 0);
     return on && (long long)g.n[0] * g.n[1] * g.n[2] >= 200000;        // the small (latency-bound) levels keep the per-node kernels
