@@ -244,7 +244,7 @@ def _mantle3(n, L):
 
 
 @pytest.mark.parametrize("n,layout", [([33, 49, 65], (2, 2, 2)), ([65, 65, 65], (2, 2, 2)), ([33, 33, 65], (1, 1, 4)), ([49, 33, 33], (3, 2, 1)),
-                                      ([33, 41, 49], (2, 2, 2))])
+                                      ([33, 41, 49], (2, 2, 2)), ([129, 65, 65], (2, 1, 1))])     # (the last: blocks large enough for the marching LDS kernels)
 def test_blocks_3d_equal_one_rank(n, layout):
     """BASELINE config 5 on several ranks, rehearsed with Pz x Px x Py virtual ranks on one GPU (pylamp3d.VirtualCluster3: the
     multi-GPU code path except for the wire): operator, right-hand side, Stokes solve and heat solve of the block-decomposed
