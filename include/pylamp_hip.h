@@ -52,12 +52,21 @@ typedef struct pl_solve_stats {
                              * small single-GPU systems finished the solve (indefinite systems: the reference's
                              * free-surface stabilisation sign at the Courant step, pylamp2.py:387-405) */
     int    reserved_;       /* 0 */
-    double error_estimate;  /* Stokes: estimate of the relative velocity error of the returned iterate from its true residual
-                             * (the residual norm alone does not bound it: error / residual
-                             * is ~10 on large smooth problems and ~1e4 on coarse ones): (n |r_cont| + |(M^-1 r)_v|) / |x_v|,
-                             * n = max(nz, nx), M^-1 = one preconditioner application.  A solve whose residual meets rtol
-                             * keeps iterating until this estimate is <= 3e-8 (PYLAMP_STOKES_ETOL; 0 switches the test off);
-                             * 0 when not evaluated (heat, or the solve ended otherwise) */
+    double error_estimate;  /* Stokes: estimate of the relative velocity error of the returned iterate from its true residual r
+                             * (the residual norm alone does not bound it: error / residual is ~10 on large smooth problems and
+                             * ~1e4 on coarse ones):
+                             *     (n |r_cont| + |(M^-1 r)_vel|) / |x_vel|  +  |y.r_p / y.A w| |w_vel| / |x_vel|
+                             * n = max(nz, nx, L_z / min dz, L_x / min dx) (graded grids count by their finest cell), M^-1 = one
+                             * preconditioner application, the last term = the component of r along the deflated pressure-anchor
+                             * mode w (it is amplified by |w| / |x|, not by n).  Between the exact evaluations (each costs a
+                             * preconditioner application) the iteration uses (n |r_cont| + a |r_mom|) / |x_vel| on the
+                             * recurrence residual, a = |(M^-1 s)_vel| / |s_mom| measured on the way.  A solve whose residual meets
+                             * rtol keeps iterating until the estimate is <= 3e-8 (PYLAMP_STOKES_ETOL; 0 switches the test off).
+                             * Viscosity contrast above 1e6 (PYLAMP_CONTRAST_GATE): the ROW-SCALED residual no longer bounds
+                             * anything (reference model 5, contrast 1e10: scaled residual 7e-11 at a velocity error of 4e-3), so
+                             * systems the banded LU can hold go there up front and every result is judged by its UNSCALED
+                             * residual: error_estimate = max(nz, nx) |b - A x|_2 / |b - A x_hydrostatic|_2, converged iff that is
+                             * <= 1e-6 as well.  0 when not evaluated (heat, or the solve ended otherwise) */
 } pl_solve_stats;
 
 /* ---- context --------------------------------------------------------------------- */
@@ -115,7 +124,7 @@ void pl_local_group_enter(pl_local_group* g);
 void pl_local_group_leave(pl_local_group* g, pl_ctx* ctx);
 /* *native = 1 when the exchanges run as direct RCCL calls on the context stream (dlopen'ed librccl, self-tested at
  * pl_set_comm), 2 for the in-process group, 0 when they go through the callback table.
- * The native path is opt-in: PYLAMP_RCCL=1 (bench.py sets it under the nccl backend). */
+ * The native path is opt-in: PYLAMP_RCCL=1 (bench.py sets it for --transport native only; it has not run on a multi-GPU node yet). */
 int  pl_comm_info(pl_ctx* ctx, int* rank, int* nranks, int* native);
 /* Cumulative numbers of communication calls of this context: out[0] neighbour (halo) exchanges, [1] all-gathers,
  * [2] device all-reduces, [3] host all-reduces; reset != 0 clears the counters after reading. */

@@ -714,8 +714,6 @@ __global__ __launch_bounds__(256, 3) void k3_sweep_m(Op3 op, V3 vcur, V3 vprev, 
 static int k3_band() { static const int on = getenv("PYLAMP_3D_BAND") ? atoi(getenv("PYLAMP_3D_BAND")) : 2; return on; }
 // planes a workgroup walks: K3M_ZC, shorter on the smaller levels until the launch has ~2 workgroups per slot of the chip (3 per CU)
 static int k3m_zc(const G3& g) {
-    static const int forced = getenv("PYLAMP_3D_ZC") ? atoi(getenv("PYLAMP_3D_ZC")) : 0;
-    if (forced > 0) return forced;
     const long long tiles = (long long)((g.n[2] + 63) / 64) * ((g.n[1] + 3) / 4);
     int zc = K3M_ZC;
     while (zc > 8 && tiles * ((g.n[0] + zc - 1) / zc) < 1536) zc >>= 1;

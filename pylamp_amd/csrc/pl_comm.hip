@@ -470,7 +470,7 @@ __global__ void k_comm_fill(long long n, double* __restrict__ d, double v) {
 // Called from pl_set_comm on every rank (collective).  Never fails hard: on any problem the native
 // path is simply left disabled - but the decision is taken collectively so that all ranks agree.
 int pl_comm_native_init(pl_ctx* ctx) {
-    // Opt-in (PYLAMP_RCCL=1; bench.py sets it for the nccl backend): the native path is self-tested at start-up and
+    // Opt-in (PYLAMP_RCCL=1; bench.py sets it for --transport native only): the native path is self-tested at start-up and
     // falls back to the callback table, but it has not yet been exercised on a multi-GPU node.
     const char* e = getenv("PYLAMP_RCCL");
     const bool want = (e && atoi(e) != 0) || getenv("PYLAMP_RCCL_SELFTEST");

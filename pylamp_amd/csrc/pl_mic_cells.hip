@@ -12,9 +12,10 @@
 // No atomics and no cross-lane traffic per tracer (the previous kernel spent ~15 VALU instructions per value and corner
 // on segmented DPP sums and one LDS atomic per run).  At the end of a row the Q partial sums of a cell are added (two
 // butterfly steps), neighbouring columns are combined by lane shuffles, neighbouring rows through register carries, and a
-// node that has received ALL its contributions inside the strip is written with one plain store.  Only the nodes on the
-// rim of a strip (first / last rows and columns: their other contributors belong to another wave) are added with global
-// atomics -- ~0.2 per tracer instead of ~1 before; the accumulator planes are zeroed beforehand for them.
+// node that has received ALL its contributions inside the strip is written with one plain store.  A strip VISITS one more cell
+// column each side and one more cell row above and below the cells it owns (lanes 0 and 15 are those virtual columns), so every
+// node it owns receives all its contributions inside the strip: no global atomics, no zeroed accumulator planes, and the same
+// bits from run to run (the rim cells are read by two strips; the round-2 kernel added the rim nodes with global atomics).
 // A tracer that does not lie in the cell the sort put it in (1-ulp disagreement on a cell boundary) is appended to a
 // list and scattered by the generic atomic kernel afterwards: the result never depends on the sort being exact.
 #include "pl_internal.h"

@@ -1253,7 +1253,7 @@ struct PlSolver {
     bool use_tail = true;
     long long tail_knob = 0;                            // PYLAMP_MG_TAIL_NODES (0: automatic)
     long long tail_max_nodes = 33 * 33;                 // levels up to this size run in the fused tail kernel
-    int min_cells = 4;                                  // coarsest grid has >= min_cells cells per side (PYLAMP_MG_MINCELLS)
+    int min_cells = 4;                                  // coarsest grid has >= min_cells cells per side 
     // halo policy inside the V-cycle on distributed levels: 2 = exchange before every sweep / residual /
     // transfer (identical numerics to one rank); 1 = once per level and direction; 0 = none (slab-local
     // smoothing with frozen zero halos; only the replicated coarse tail couples the slabs)
@@ -1287,7 +1287,7 @@ struct PlSolver {
     long long fused_max_nodes = 1100000;      // PYLAMP_MG_FUSED_MAX: largest level (nodes) that takes the tile kernels
     long long tile32_min_nodes = 1000000;            // PYLAMP_MG_TS32: levels from this many nodes use 32 x 32 tiles (2049^2: level 1; 36.6 against 37.4 ms per step)
     bool fused = true;           // PYLAMP_MG_FUSED=0: every multigrid stage as a kernel of its own (the path the tile kernels are checked against)
-    bool fuse_first = true;      // PYLAMP_FUSE_FIRST=0: the first sweep of level 0 as a pass of its own
+    bool fuse_first = true;      // false: the first sweep of level 0 as a pass of its own
     bool l0_mixed = true;        // PYLAMP_L0_MIXED=0: every vector of a staged level 0 in FP64 (stokes_precond_t)
     bool l0_mixed_now = true;    // ... and only for warm-started solves to rtol >= 1e-8 (pl_stokes_solve_device)
     bool deep = true;            // PYLAMP_MG_DEEP=0: distributed levels exchange before every sweep instead of once per smoothing sequence
@@ -1323,7 +1323,6 @@ static PlSolver* solver_of(pl_ctx* ctx) {
         if (const char* e = getenv("PYLAMP_MG_POWER")) { int a = atoi(e); if (a >= 1) S->power_its_warm = a; }
         if (const char* e = getenv("PYLAMP_MG_COARSE")) { int a = atoi(e); if (a > 0) S->coarse_sweeps = a; }
         if (const char* e = getenv("PYLAMP_MG_TAIL")) S->use_tail = atoi(e) != 0;
-        if (const char* e = getenv("PYLAMP_MG_MINCELLS")) { int v = atoi(e); if (v >= 2) S->min_cells = v; }
         if (const char* e = getenv("PYLAMP_MG_REPL_NODES")) { long long v = atoll(e); if (v >= 25) S->repl_max_nodes = v; }
         if (const char* e = getenv("PYLAMP_MG_TAIL_NODES")) { long long v = atoll(e); if (v >= 25 && v <= PL_TAIL_MAX_NODES) S->tail_knob = v; }
         if (const char* e = getenv("PYLAMP_MG_HALO")) S->mg_halo = atoi(e);
@@ -1333,7 +1332,6 @@ static PlSolver* solver_of(pl_ctx* ctx) {
         if (const char* e = getenv("PYLAMP_STOKES_ETOL")) { const double v = atof(e); if (v >= 0.0) S->etol = v; }
         if (const char* e = getenv("PYLAMP_MG_FP32")) S->f32_enable = atoi(e) != 0;
         if (const char* e = getenv("PYLAMP_MG_FP32_NODES")) { long long v = atoll(e); if (v >= 1) S->f32_min_nodes = v; }
-        if (const char* e = getenv("PYLAMP_FUSE_FIRST")) S->fuse_first = atoi(e) != 0;
         if (const char* e = getenv("PYLAMP_L0_MIXED")) S->l0_mixed = atoi(e) != 0;
         if (const char* e = getenv("PYLAMP_MG_FUSED")) S->fused = atoi(e) != 0;
         if (const char* e = getenv("PYLAMP_MG_TS32")) { long long v = atoll(e); if (v > 0) S->tile32_min_nodes = v; }
@@ -1738,7 +1736,7 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
             PL_TRY(pl_halo(ctx, L->gh.d, L->etan, 1, L->gh.d.plane, dep));
         }
     }
-    const bool stab_in_mg = !getenv("PYLAMP_STAB_PRECOND") || atoi(getenv("PYLAMP_STAB_PRECOND")) != 0;
+    const bool stab_in_mg = true;
     if (sop.surfstab && sop.ss != 0.0 && sop.gz != 0.0 && stab_in_mg) {
         // stabilisation-aware velocity block: density coarsened like the nodal viscosity, terms rediscretised per level
         const double coef = sop.ss * sop.gz;
@@ -3507,7 +3505,7 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
         }
         static const bool trace_d = getenv("PYLAMP_SOLVER_TRACE") != nullptr;
         if (trace_d) fprintf(stderr, "[pylamp deflation] kept vector: ||u - A w|| / ||u|| = %.3e\n", q);
-        static const double q_refresh = getenv("PYLAMP_DEFL_Q") ? atof(getenv("PYLAMP_DEFL_Q")) : 0.3;     // (0.1 until round 3: 0.45 costs no iteration at 2049^2 and halves the refreshes)
+        static const double q_refresh = 0.3;     // (0.1 until round 3: 0.45 costs no iteration at 2049^2 and halves the refreshes)
         const bool reuse = S->defl_valid && q < std::max(0.5, q_refresh);
         if (reuse) {                                        // denominator y.(A w) of the old w under the new coefficients
             hipLaunchKernelGGL(k_defl_coef, dim3(1), dim3(1), 0, ctx->stream, sop, (const double*)S->wdefl, S->scal, 1);

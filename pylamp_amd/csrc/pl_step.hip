@@ -54,6 +54,7 @@ struct PlStepState {
     // Lazy columns: RHO, ETA (rewritten by the next property update) and the tracer velocities (rewritten by the next advection) of
     // the tracers [0, lazy_n) are still in PRE-sort order in f2[RHO], f2[ETA], tmp[0], tmp[1]; dest maps them (flush_lazy).
     bool lazy_pending = false, lazy_inject = false; long long lazy_n = 0;
+    bool cols_undefined = false;      // a step dropped the lazy columns (RHO, ETA, tracer velocities) and failed before rewriting them
     std::vector<double> gmz, gmx;                    // midpoint grids (pylamp2.py:92-95)
     // several ranks: error counters of the marker stages of a step ([0] tracers outside the grid in grid2trac, [1] RK4 stages that
     // left the rank's velocity window) and the count tables of the sort, reduced over the ranks ON THE DEVICE (pl_comm_allreduce_dev)
@@ -587,7 +588,7 @@ extern "C" int pl_tracers_upload(pl_ctx* ctx, int64_t n, const double* tr_x, con
     PL_HIP(ctx, hipSetDevice(ctx->device));
     PlStepState* S = state_of(ctx);
     PL_TRY(ensure_tracers(ctx, S, n));
-    S->epoch_on = false; S->epoch_age = 0; S->lazy_pending = false;
+    S->epoch_on = false; S->epoch_age = 0; S->lazy_pending = false; S->cols_undefined = false;
     // stream the AoS rows through the staging buffer in chunks
     const long long chunk = 1 << 22;
     PL_TRY(pl_stage(ctx, (size_t)chunk * NFTRAC * sizeof(double)));
@@ -841,6 +842,8 @@ static int relayout(pl_ctx* ctx, PlStepState* S) {
 }
 // every column in the current (sorted) order, as the code outside the resident step expects
 static int ensure_current(pl_ctx* ctx, PlStepState* S) {
+    if (S->cols_undefined)
+        return pl_fail(ctx, "tracer RHO / ETA / velocities are undefined: the last pl_step failed before it had rewritten them (upload the tracers again)");
     PL_TRY(flush_lazy(ctx, S));
     return relayout(ctx, S);
 }
@@ -1263,7 +1266,10 @@ static int scatter_cells(pl_ctx* ctx, PlStepState* S, int variant, const double*
     double* sc;
     PL_TRY(pl_buf(ctx, "scatter_slow_count", 64, &sc, false));
     a.slow_count = (int*)sc; a.slow_list = S->dest; a.slow_cap = (int)std::min<long long>(S->cap, 0x7fffffff);   // `dest` is free outside the sort
+    a.dbg = 0;
+#ifdef PL_SC_ABLATE          // (ablation builds only: the bits switch parts of the kernel OFF -- never in the shipped library)
     a.dbg = getenv("PYLAMP_SC_DBG") ? atoi(getenv("PYLAMP_SC_DBG")) : 0;
+#endif
     PL_TRY(pl_scatter_cells_device(ctx, a, variant));
     if (ctx->nranks > 1)       // what I accumulated for nodes of the neighbour blocks is added to their accumulators
         PL_TRY(pl_halo_generic(ctx, g.lnz, g.lnx, accbuf + a.ncols + 1, a.ncols, nplanes, (long long)N, 1, true));
@@ -1463,7 +1469,7 @@ static int stage_rk4(pl_ctx* ctx, PlStepState* S, const double* V, int I0, int I
         *keys_ready = false;
         const PlGeom& g = ctx->geom.d;
         const int ncz = (g.gi0 + g.lnz >= g.nz) ? g.lnz - 1 : g.lnz, ncx = (g.gj0 + g.lnx >= g.nx) ? g.lnx - 1 : g.lnx;
-        static const bool fuse_keys = !(getenv("PYLAMP_RK4_KEYS") && atoi(getenv("PYLAMP_RK4_KEYS")) == 0);
+        const bool fuse_keys = true;           // (the sort keys as a pass of their own cost 0.35 ms at 2049^2 / 68 M tracers)
         if (fuse_keys && ctx->geom.uniform && S->cell_count && S->ncz == ncz && S->ncx == ncx && S->cell && S->n < (1LL << 31)) {
             PlSortKey& k = ra.key;
             k.on = 1; k.z0 = q.z0; k.rhz = 1.0 / q.hz; k.x0 = q.x0; k.rhx = 1.0 / q.hx;
@@ -1528,7 +1534,8 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
     if (!S->sorted) return pl_fail(ctx, "pl_step: tracers are not sorted (internal error)");
     // the columns the last sort left behind (RHO, ETA, tracer velocities) are rewritten below before anything reads them -- unless
     // this configuration does not run the stage that rewrites them
-    if (ctx->geom.uniform && scatter_cells_on()) S->lazy_pending = false;
+    if (S->cols_undefined) return pl_fail(ctx, "pl_step: the previous step failed half-way; upload the tracers again");
+    if (ctx->geom.uniform && scatter_cells_on()) { S->cols_undefined = S->lazy_pending; S->lazy_pending = false; }     // (defined again behind stage_rk4)
     else PL_TRY(ensure_current(ctx, S));
 
     // ---- 1. tracer properties --------------------------------------------------------------
@@ -1757,6 +1764,7 @@ extern "C" int pl_step(pl_ctx* ctx, const pl_step_config* cfg, int it, pl_step_r
     }
     bool keys_ready = false;
     PL_TRY(stage_rk4(ctx, S, V, I0, I1, J0, J1, tstep, cfg->tracs_fence_disabled ? 0 : 1, Lz, Lx, &keys_ready));
+    S->cols_undefined = false;        // RHO / ETA (stage 1) and the tracer velocities (here) have been rewritten
     rep->ms_advect = now_ms() - t0;
 
     // ---- 7. cell sort of the advected tracers, slab migration, census + injection --------------------

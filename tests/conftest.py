@@ -37,6 +37,18 @@ def maxrel(a, b):
     return np.max(np.abs(a[m] - b[m])) / (s if s > 0 else 1.0)
 
 
+def pointrel(a, b):
+    """max over the points of |a-b| / |b| (NaN patterns identical): for fields that span decades (GEOM-mean viscosities), where
+    a tolerance relative to the global maximum says little at the low-viscosity nodes."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert np.array_equal(np.isnan(a), np.isnan(b)), "NaN masks differ"
+    m = ~np.isnan(b) & (b != 0)
+    if not m.any():
+        return 0.0
+    return float(np.max(np.abs(a[m] - b[m]) / np.abs(b[m])))
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import pylamp_oracle

@@ -15,11 +15,18 @@ import os
 import numpy as np
 import pytest
 
-from conftest import golden, maxrel, relerr
+from conftest import golden, maxrel, pointrel, relerr
 
 pytestmark = pytest.mark.gpu
 
 TR_RHO, TR_ETA, TR_MRK, TR_TMP, TR_HCD, TR_HCP, TR_RH0, TR_ALP, TR_MAT, TR_ACE, TR_ET0, TR_IHT, TR__ID = range(13)
+# GEOM-mean viscosities: exp(sum w ln eta / sum w) at EVERY node to this relative error (|ln eta| ~ 50, so a few 1e-14 are
+# inherent); the other fields keep conftest.maxrel (relative to the field's maximum)
+ETA_TOL = 1e-11
+
+
+def _close(name, a, b, tol):
+    return (pointrel(a, b) < max(tol, ETA_TOL)) if name in ("etas", "etan") else (maxrel(a, b) < tol)
 
 
 def _tracers(tr_x, cols):
@@ -58,8 +65,8 @@ def test_fused_scatter_vs_reference_fixture(oracle, case):
     tg = _targets(oracle, nx, L)
     # against the reference's own output
     assert maxrel(got["rho"], g[case + "_nodes"][2]) < 1e-12
-    assert maxrel(got["etas"], g[case + "_nodes"][3]) < 1e-12
-    assert maxrel(got["etan"], g[case + "_centres"][3]) < 1e-12
+    assert pointrel(got["etas"], g[case + "_nodes"][3]) < ETA_TOL           # (pointwise: the viscosities span decades)
+    assert pointrel(got["etan"], g[case + "_centres"][3]) < ETA_TOL
     assert maxrel(got["kz"], g[case + "_zmid"][2]) < 1e-12
     assert maxrel(got["kx"], g[case + "_xmid"][2]) < 1e-12
     # the other node fields against the (pinned) oracle
@@ -73,7 +80,7 @@ def test_fused_scatter_vs_reference_fixture(oracle, case):
     finally:
         del os.environ["PYLAMP_SCATTER"]
     for k in got:
-        assert maxrel(got[k], old[k]) < 1e-12, k
+        assert _close(k, got[k], old[k], 1e-12), k
     sim.close()
 
 
@@ -87,9 +94,9 @@ def test_fused_scatter_heat_off_vs_reference_fixture(oracle, case):
     sim = _sim(nx, L, X, _tracers(X, {TR_RH0: F[:, 2], TR_ET0: F[:, 1]}), do_heatdiff=False)
     got = sim.scatter_fields()
     assert maxrel(got["rho"], g[case + "_nodes"][2]) < 1e-12
-    assert maxrel(got["etan"], g[case + "_centres"][1]) < 1e-12                   # unweighted GEOM, the reference's output
+    assert pointrel(got["etan"], g[case + "_centres"][1]) < ETA_TOL               # unweighted GEOM, the reference's output
     etas, = oracle.trac2grid(X, F[:, [1]], _targets(oracle, nx, L)["nodes"], nx, [6])
-    assert maxrel(got["etas"], etas) < 1e-12
+    assert pointrel(got["etas"], etas) < ETA_TOL
     sim.close()
 
 
@@ -187,7 +194,7 @@ def test_resident_mic_kernels_2049_vs_oracle(oracle):
     ref["kz"], = oracle.trac2grid(X, tr_f[:, [TR_HCD]], tg["zmid"], nx, [5])
     ref["kx"], = oracle.trac2grid(X, tr_f[:, [TR_HCD]], tg["xmid"], nx, [5])
     for k, r in ref.items():
-        assert maxrel(got[k], r) < 1e-11, k
+        assert _close(k, got[k], r, 1e-11), k
     # temperature to tracers with subgrid diffusion (the NaN nodes outside the window are never read: every marker sits inside)
     tr_f[:, TR_RHO] = tr_f[:, TR_RH0]
     grid = tg["nodes"]
@@ -227,7 +234,7 @@ def test_resident_mic_kernels_2049_vs_oracle(oracle):
     ref["kz"], = oracle.trac2grid(X1, F1[:, [TR_HCD]], tg["zmid"], nx, [5])
     ref["kx"], = oracle.trac2grid(X1, F1[:, [TR_HCD]], tg["xmid"], nx, [5])
     for k, r in ref.items():
-        assert maxrel(got[k], r) < 1e-11, k
+        assert _close(k, got[k], r, 1e-11), k
     assert np.array_equal(F1[:, [TR_HCD, TR_HCP, TR_RH0, TR_ET0, TR_IHT, TR_MAT, TR__ID]], tr_f[:, [TR_HCD, TR_HCP, TR_RH0, TR_ET0, TR_IHT, TR_MAT, TR__ID]])
     sim.advect(0 * Vz, 0 * Vx, dt, fence=True, download=False)       # a sort that moves nobody: a new epoch on the same positions
     assert sim.layout()[0] == 1
