@@ -208,6 +208,130 @@ __global__ __launch_bounds__(256) void k_vv_cheb_first(PlVvOpT<T> op, const T* _
         cheb_first_node(op, f, vnext, c2, op.g.gi0 + li, op.g.gj0 + lj, pl_idx(op.g, li, lj));
 }
 
+// =========================================================================================
+// z-LINE relaxation (stretched and graded grids).  Where the cells are much wider than high (dx >> dz) the
+// z-couplings of a velocity row are ~ (dx/dz)^2 times its x-couplings: point Jacobi leaves the modes that are smooth along z untouched
+// and full coarsening cannot carry them (513 x 129 nodes on a square: 41 iterations; a grid graded 30 x in z: 209).  Here the block
+// of the Jacobi splitting is the TRIDIAGONAL matrix T of each component's own z-couplings, column by column:
+//     v_next = v + c1 (v - v_prev) + c2 T^-1 (A v - f),        T v = dg v - cN v[i+1] - cS v[i-1]   on the interior rows
+// (wall rows: identity; slaved rows take s x their master's value afterwards, as in the point sweeps), Chebyshev-accelerated on the
+// spectrum of T^-1 A exactly like the point version (the power iteration runs through this kernel: mode 1).
+// One workgroup solves LZ columns of ONE component by parallel cyclic reduction in LDS: ceil(log2 nz) steps, each thread keeps its
+// rows' (a, b, c, d) in registers and reads the rows i -+ stride of the previous step from LDS.  32 nz LZ bytes of LDS: nz <= 4097.
+// =========================================================================================
+#define LZ_NT 1024
+#define LZ_EPT 5            // rows per thread at most: nz <= 4097 + (LZ_EPT * LZ_NT >= nz * cols)
+struct LineArgs {
+    PlVvOp op; const double* v; const double* vprev; const double* f; double* out;
+    double c1, c2, oscale; int mode /* 0 sweep, 1 out = T^-1 A v */; int cols;
+};
+__global__ __launch_bounds__(LZ_NT) void k_vv_line_z(LineArgs a) {
+    extern __shared__ double lz_sh[];
+    const PlGeom& g = a.op.g;
+    const int n = g.nz, cols = a.cols, comp = blockIdx.y, j0 = blockIdx.x * cols, tot = n * cols;
+    double* const SA = lz_sh; double* const SB = SA + tot; double* const SC = SB + tot; double* const SD = SC + tot;
+    const long long P = g.plane;
+    const double* vz = a.v; const double* vx = a.v ? a.v + P : nullptr;
+    double A_[LZ_EPT], B_[LZ_EPT], C_[LZ_EPT], D_[LZ_EPT], base[LZ_EPT], sfac[LZ_EPT];
+    int cout_[LZ_EPT];      // element offset of the node this entry is written to (-1: none)
+    // interior (equation-carrying) rows of column je of this component
+    auto is_int = [&](int i, int je) {
+        if (comp == 0) return i >= 1 && i <= n - 2 && je >= 0 && je < g.nx - 1 && !(a.op.slave_x && (je == 0 || je == g.nx - 2));
+        return je >= 1 && je <= g.nx - 2 && i >= (a.op.slave_z0 ? 1 : 0) && i <= (a.op.slave_zL ? n - 3 : n - 2);
+    };
+#pragma unroll
+    for (int q = 0; q < LZ_EPT; q++) {
+        const int e = threadIdx.x + q * LZ_NT;
+        A_[q] = 0.0; B_[q] = 1.0; C_[q] = 0.0; D_[q] = 0.0; base[q] = 0.0; sfac[q] = 0.0; cout_[q] = -1;
+        if (e >= tot) continue;
+        const int i = e / cols, j = j0 + e % cols;
+        if (j >= g.nx) continue;
+        const int c = (int)pl_idx(g, i - g.gi0, j - g.gj0);
+        cout_[q] = c;
+        int je = j;                                  // the column whose rows this entry evaluates: a slaved vz column its master's
+        if (comp == 0 && a.op.slave_x && (j == 0 || j == g.nx - 2)) je = j == 0 ? 1 : g.nx - 3;
+        if (!is_int(i, je)) continue;                // wall row (0), or a slaved vx row (filled in behind the solve)
+        const int cm = c + (je - j);
+        double Av = 0.0, dg, cN, cS;
+        const int p = g.pitch;
+        if (comp == 0) {
+            const double rdz_i = TB(a.op.rdz, i), rdz_m = TB(a.op.rdz, i - 1), rDz_i = TB(a.op.rDz, i);
+            cN = 4.0 * a.op.etan[cm] * rdz_i * rDz_i; cS = 4.0 * a.op.etan[cm - p] * rdz_m * rDz_i;
+            if (a.v) vv_row_z(a.op, vz, vx, cm, i, je, Av, dg); else dg = vv_diag_z(a.op, cm, i, je);
+            if (a.v) base[q] = vz[cm] + ((a.c1 != 0.0 && a.mode == 0) ? a.c1 * (vz[cm] - (a.vprev ? a.vprev[cm] : 0.0)) : 0.0);
+        } else {
+            const double rdz_i = TB(a.op.rdz, i), rDz_i = TB(a.op.rDz, i), rDz_p = TB(a.op.rDz, i + 1);
+            cN = 2.0 * a.op.etas[cm + p] * rDz_p * rdz_i; cS = 2.0 * a.op.etas[cm] * rDz_i * rdz_i;
+            if (a.v) vv_row_x(a.op, vz, vx, cm, i, je, Av, dg); else dg = vv_diag_x(a.op, cm, i, je);
+            if (a.v) base[q] = vx[cm] + ((a.c1 != 0.0 && a.mode == 0) ? a.c1 * (vx[cm] - (a.vprev ? (a.vprev + P)[cm] : 0.0)) : 0.0);
+        }
+        sfac[q] = 1.0;
+        B_[q] = dg;
+        A_[q] = is_int(i - 1, je) ? -cS : 0.0;
+        C_[q] = is_int(i + 1, je) ? -cN : 0.0;
+        D_[q] = Av - ((a.mode == 0 && a.f) ? (a.f + comp * P)[cm] : 0.0);
+    }
+    if (a.mode == 1) {
+#pragma unroll
+        for (int q = 0; q < LZ_EPT; q++) base[q] = 0.0;
+    }
+    // ---- parallel cyclic reduction: after the step of stride s every row couples to the rows i -+ 2 s only
+    for (int st = 1; st < n; st <<= 1) {
+#pragma unroll
+        for (int q = 0; q < LZ_EPT; q++) {
+            const int e = threadIdx.x + q * LZ_NT;
+            if (e < tot) { SA[e] = A_[q]; SB[e] = B_[q]; SC[e] = C_[q]; SD[e] = D_[q]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < LZ_EPT; q++) {
+            const int e = threadIdx.x + q * LZ_NT;
+            if (e >= tot) continue;
+            const int i = e / cols;
+            double al = 0.0, ga = 0.0, am = 0.0, cm_ = 0.0, dm = 0.0, ap = 0.0, cp = 0.0, dp = 0.0;
+            if (i - st >= 0 && A_[q] != 0.0) { const int m = e - st * cols; al = -A_[q] / SB[m]; am = SA[m]; cm_ = SC[m]; dm = SD[m]; }
+            if (i + st < n && C_[q] != 0.0) { const int m = e + st * cols; ga = -C_[q] / SB[m]; ap = SA[m]; cp = SC[m]; dp = SD[m]; }
+            B_[q] = B_[q] + al * cm_ + ga * ap;
+            D_[q] = D_[q] + al * dm + ga * dp;
+            A_[q] = al * am; C_[q] = ga * cp;
+        }
+        __syncthreads();
+    }
+    // ---- the update; slaved vx rows copy s x their master's (the row next to them, same column)
+#pragma unroll
+    for (int q = 0; q < LZ_EPT; q++) {
+        const int e = threadIdx.x + q * LZ_NT;
+        if (e < tot) SD[e] = sfac[q] != 0.0 ? base[q] + (a.mode == 0 ? a.c2 : 1.0) * (D_[q] / B_[q]) : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < LZ_EPT; q++) {
+        const int e = threadIdx.x + q * LZ_NT;
+        if (e >= tot || cout_[q] < 0) continue;
+        const int i = e / cols, j = j0 + e % cols;
+        double val = SD[e];
+        if (comp == 1 && j >= 1 && j <= g.nx - 2) {
+            if (i == 0 && a.op.slave_z0) val = a.op.s0 * SD[e + cols];
+            else if (i == n - 2 && a.op.slave_zL && n >= 3) val = a.op.sL * SD[e - cols];
+        }
+        (a.out + comp * P)[cout_[q]] = val * a.oscale;
+    }
+}
+static bool line_z_possible(const pl_ctx* ctx, int nz) { return ctx->nranks == 1 && nz <= 4097 && nz >= 3; }
+static int line_z_launch(pl_ctx* ctx, const PlVvOp& op, const double* v, const double* vprev, const double* f, double* out, double c1, double c2,
+                         double oscale, int mode) {
+    LineArgs a{}; a.op = op; a.v = v; a.vprev = vprev; a.f = f; a.out = out; a.c1 = c1; a.c2 = c2; a.oscale = oscale; a.mode = mode;
+    const int n = op.g.nz;
+    int cols = (LZ_EPT * LZ_NT) / n; if (cols > 16) cols = 16; if (cols > op.g.nx) cols = op.g.nx; if (cols < 1) cols = 1;
+    while (cols > 1 && (size_t)32 * n * cols > 150000) cols--;
+    a.cols = cols;
+    const size_t lds = (size_t)32 * n * cols;
+    static size_t lds_set = 0;
+    if (lds > lds_set) { PL_HIP(ctx, hipFuncSetAttribute((const void*)k_vv_line_z, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); lds_set = 160 * 1024; }
+    hipLaunchKernelGGL(k_vv_line_z, dim3((op.g.nx + cols - 1) / cols, 2), dim3(LZ_NT), lds, ctx->stream, a);
+    return 0;
+}
+
 #ifndef PL_CHEB_WAVES
 #define PL_CHEB_WAVES 4
 #endif
@@ -1214,6 +1338,7 @@ struct MgLevel {
     double *f = nullptr, *r = nullptr;
     double* fe = nullptr;        // early coarse branch: R^l f of the finest level (levels 1 .. early_K-1)
     double lmax = 3.0;
+    bool line_z = false;         // z-line relaxation instead of point Jacobi (k_vv_line_z): cells of this level at least 6 x wider than high somewhere
     // FP32 twin (large levels only, see build_hierarchy): viscosity planes times 1/sigma, the 1-D tables, work planes
     bool f32 = false;
     PlVvOpF opf{};
@@ -1255,6 +1380,7 @@ struct PlSolver {
                                                         // 1 % rule may stop them (so at least 2; 3 measured 0.8 ms slower per solve at 2049^2, same iterations)
     bool nu_auto = true;                                // no PYLAMP_MG_NU / PYLAMP_MG_NU0 given: chosen from the grid size
     bool use_tail = true;
+    bool any_line = false;       // some level smooths with z-lines: no tile kernels / one-workgroup tail / FP32 storage / fused first sweep there
     long long tail_knob = 0;                            // PYLAMP_MG_TAIL_NODES (0: automatic)
     long long tail_max_nodes = 33 * 33;                 // levels up to this size run in the fused tail kernel
     int min_cells = 4;                                  // coarsest grid has >= min_cells cells per side 
@@ -1591,8 +1717,8 @@ static int setup_f32_levels(pl_ctx* ctx, PlSolver* S) {
     for (size_t l = 0; l < S->levels.size(); l++) {
         MgLevel* L = S->levels[l];
         const PlGeom& g = L->gh.d;
-        const bool tail = S->use_tail && l > 0 && (long long)g.nz * g.nx <= S->tail_max_nodes && S->levels.size() - l <= PL_TAIL_MAX_LEVELS;
-        const bool want = S->f32_enable && prefix && !tail && l + 1 < S->levels.size() && (long long)g.lnz * g.lnx >= S->f32_min_nodes &&
+        const bool tail = S->use_tail && !S->any_line && l > 0 && (long long)g.nz * g.nx <= S->tail_max_nodes && S->levels.size() - l <= PL_TAIL_MAX_LEVELS;
+        const bool want = S->f32_enable && !S->any_line && prefix && !tail && l + 1 < S->levels.size() && (long long)g.lnz * g.lnx >= S->f32_min_nodes &&
                           !L->op.szz && (ctx->nranks == 1 || L->dist) && (g.plane % 2) == 0;
         L->f32 = want;
         prefix = prefix && want;
@@ -1656,8 +1782,10 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
             const double hz = (ctx->geom.zc.back() - ctx->geom.zc.front()) / (ctx->nz - 1);
             const double hx = (ctx->geom.xc.back() - ctx->geom.xc.front()) / (ctx->nx - 1);
             const double a = hz > hx ? hz / hx : hx / hz;
+            const char* le = getenv("PYLAMP_MG_LINE");
+            const bool lines = hx >= 6.0 * hz && line_z_possible(ctx, ctx->nz) && !(le && atoi(le) == 0);      // (wide cells: the z-line smoother's case)
             S->cheb_ratio = 6.0;
-            if (a > 1.5) {
+            if (a > 1.5 && !lines) {
                 S->cheb_ratio = 6.0 * a * a;
                 int nu = (int)std::ceil(2.0 * a); if (nu > 10) nu = 10;
                 S->nu_pre = S->nu_post = nu; S->nu0_pre = S->nu0_post = -1;
@@ -1666,7 +1794,7 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
         // (several ranks used to start the one-workgroup tail at 65^2 -- the levels above it cost halo exchanges then; since the
         //  replicated levels run the tile kernels it is the one-rank choice: 33^2, which is what the LDS-resident tail holds)
         S->tail_max_nodes = S->tail_knob ? S->tail_knob : 33LL * 33;
-        S->repl_start = -1;
+        S->repl_start = -1; S->any_line = false;
         for (int l = 0;; l++) {
             MgLevel* L = new MgLevel();
             if (pl_geom_build(ctx, L->gh, nz, nx, zc.data(), xc.data())) { delete L; return 1; }
@@ -1694,6 +1822,19 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
             }
             for (int q = 0; q < 3; q++) PL_TRY(dmalloc0(ctx, &L->v[q], vb));
             PL_TRY(dmalloc0(ctx, &L->f, vb)); PL_TRY(dmalloc0(ctx, &L->r, vb));
+            {   // z-lines where some cell of the level is at least 6 x wider than high (PYLAMP_MG_LINE=0: never; =1: on every level).
+                // Measured (tools/stretch_probe.py, viscosity contrast 1e3): cells 4:1 (513 x 129 nodes on a square) point sweeps with the
+                // anisotropy rule 41 iterations / 72 ms, lines 45 / 93 -- the count is set by the pressure block there, not by the
+                // smoother; z graded 30 x (cells up to 8.5:1): 209 / 101 ms against 91 / 217 ms; cells 16:1 (1025 x 65): the point
+                // sweeps do NOT converge (residual 2e-4 after 109 iterations), lines reach 1e-8 in 164.
+                double dzmin = 1e300, dxmax = 0.0;
+                for (int i = 0; i + 1 < nz; i++) dzmin = std::min(dzmin, zc[i + 1] - zc[i]);
+                for (int j = 0; j + 1 < nx; j++) dxmax = std::max(dxmax, xc[j + 1] - xc[j]);
+                const char* e = getenv("PYLAMP_MG_LINE");
+                const int knob = e ? atoi(e) : -1;
+                L->line_z = line_z_possible(ctx, nz) && knob != 0 && (knob == 1 || dxmax >= 6.0 * dzmin);
+                if (L->line_z) S->any_line = true;
+            }
             S->levels.push_back(L);
             if ((nz - 1) % 2 || (nx - 1) % 2 || (nz - 1) / 2 < S->min_cells || (nx - 1) / 2 < S->min_cells) break;
             // blocks with an odd number of rows / columns cannot be halved rank by rank: this level stays the coarsest
@@ -1799,7 +1940,8 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
             if (warm && it >= S->power_its_warm && std::fabs(lam - lam_prev) < 0.01 * lam) break;
             lam_prev = lam;
             if (L->dist) PL_TRY(pl_halo(ctx, g, L->v[0], 2, g.plane));
-            hipLaunchKernelGGL(k_vv_dinv_apply, grid2d(g), dim3(64, 4), 0, ctx->stream, L->op, L->v[0], L->v[1]);
+            if (L->line_z) PL_TRY(line_z_launch(ctx, L->op, L->v[0], nullptr, nullptr, L->v[1], 0.0, 1.0, 1.0, 1));
+            else hipLaunchKernelGGL(k_vv_dinv_apply, grid2d(g), dim3(64, 4), 0, ctx->stream, L->op, L->v[0], L->v[1]);
             PL_TRY(dots(ctx, S, g, 2, L->v[1], L->v[1], L->v[0], L->v[0], nn));
             if (!(nn[1] > 0.0) || !(nn[0] > 0.0)) break;
             lam = std::sqrt(nn[0] / nn[1]);
@@ -1886,6 +2028,16 @@ static bool smooth(pl_ctx* ctx, MgLevel* L, T* buf[3], const T* f, int nsweep, d
         const long long sh = V.sh;
         const bool to_final = final_out && k == nsweep - 1;
         T* dst = buf[2];
+        if constexpr (std::is_same<T, double>::value) {
+            if (L->line_z) {               // z-line relaxation: same three-term recurrence, T^-1 in place of D^-1 (one rank, FP64, no views)
+                const double* cur = (k == 0 && zero_guess) ? nullptr : buf[0];
+                const double* prv = (k == 0 || (k == 1 && zero_guess)) ? nullptr : buf[1];
+                (void)line_z_launch(ctx, L->op, cur, prv, f, to_final ? final_out : dst, c1, c2, to_final ? final_scale : 1.0, 0);
+                if (to_final) { wrote_final = true; break; }
+                { T* nxt = buf[2]; buf[2] = buf[1]; buf[1] = buf[0]; buf[0] = nxt; }
+                continue;
+            }
+        }
         if (k == 0 && zero_guess) {        // buf[0] is NOT read (and need not be zeroed); never the final sweep of level 0 (a
                                            // V-cycle with a coarse level has a prolongation before its last sweep)
             if (g_vv_vec && first_done_anchor) {      // stage 1 wrote the interior waves of this sweep already (into dst = buf[2])
@@ -2034,7 +2186,7 @@ static void vcycle(pl_ctx* ctx, PlSolver* S, size_t l, const T* f, T** out, bool
     const PlGeom& g = L->gh.d;
     *wrote_final = false;
     if constexpr (std::is_same<T, double>::value) {
-        if (S->use_tail && l > 0 && (long long)g.nz * g.nx <= S->tail_max_nodes &&
+        if (S->use_tail && !S->any_line && l > 0 && (long long)g.nz * g.nx <= S->tail_max_nodes &&
             S->levels.size() - l <= PL_TAIL_MAX_LEVELS && f == L->f) {
             TailArgs ta{};
             ta.nlev = (int)(S->levels.size() - l);
@@ -2332,6 +2484,13 @@ __device__ inline void mgt_cheb(const MgtC& kz, const MgtC& kx, int CR, const do
         pvx = v0;
     }
 }
+// Node (ra, rb) of a region (global node i, j) belongs to the tile: its TS x TS nodes -- and the grid's LAST row / column where the tile
+// ends right in front of it.  Those nodes are zero rows of both components on every level; a tile row and column of their own
+// (33 x 33 tiles for 1025^2 nodes: 1089 workgroups, a fifth round of the 256 one-per-CU slots for 65 of them) cost level 1 a
+// fifth of its time.
+__device__ inline bool mgt_owns(int ra, int rb, int HC, int TS, int i, int j, const PlGeom& g) {
+    return ra >= HC && (ra < HC + TS || (ra == HC + TS && i == g.nz - 1)) && rb >= HC && (rb < HC + TS || (rb == HC + TS && j == g.nx - 1));
+}
 // threads of a tile kernel: one node of the region per thread where the region has at most 1024, else the fewest passes
 __host__ __device__ constexpr int mgt_npt(int nn) { return (nn + 1023) / 1024; }
 __host__ __device__ constexpr int mgt_nt(int nn) { return ((nn + mgt_npt(nn) - 1) / mgt_npt(nn) + 63) / 64 * 64; }
@@ -2396,7 +2555,7 @@ __global__ __launch_bounds__(mgt_nt(mgt_pre_nn(NS + EXT, TS))) void k_mg_pre(MgT
             const int ra = depth[q] >= 0 ? idx / CR : 0, rb = depth[q] >= 0 ? idx % CR : 0, i = ci0 + ra, j = cj0 + rb;
             if (kz[q].on) kz[q].f = kz[q].f * mgt_dg(kz[q]) + 2.0 * a.sop.Kc * TAB[1][ra + 1] * (ZP[kz[q].cm] - ZP[kz[q].cm - CR]);
             if (kx[q].on) kx[q].f = kx[q].f * mgt_dg(kx[q]) + 2.0 * a.sop.Kc * TAB[3][rb + 1] * (ZP[kx[q].cm] - ZP[kx[q].cm - 1]);
-            if (depth[q] >= HC && i < g.nz && j < g.nx && i - g.gi0 < g.lnz && j - g.gj0 < g.lnx) {      // the tile itself: keep f and z_p
+            if (depth[q] >= 0 && mgt_owns(ra, rb, HC, TS, i, j, g) && i < g.nz && j < g.nx && i - g.gi0 < g.lnz && j - g.gj0 < g.lnx) {      // the tile itself: keep f and z_p
                 const long long c = pl_idx(g, i - g.gi0, j - g.gj0);
                 a.fout[c] = kz[q].interior ? kz[q].f : 0.0; a.fout[c + P] = kx[q].interior ? kx[q].f : 0.0; a.z[c + 2 * P] = ZP[idx];
             }
@@ -2444,11 +2603,11 @@ __global__ __launch_bounds__(mgt_nt(mgt_pre_nn(NS + EXT, TS))) void k_mg_pre(MgT
             V[nxt][0][idx] = rz; V[nxt][1][idx] = rx;
         }
         // the iterate goes to memory: the tile's own nodes, and (EXT) the nodes of the halo ring NS deep around the rank's block
-        if (depth[q] >= HC - (EXT ? NS : 0)) {
+        if (depth[q] >= HC - (EXT ? NS : 1)) {
             const int ra = idx / CR, rb = idx % CR, i = ci0 + ra, j = cj0 + rb, li = i - g.gi0, lj = j - g.gj0;
             const bool owned = li >= 0 && li < g.lnz && lj >= 0 && lj < g.lnx;
             const bool ring = EXT && !owned && li >= -NS && li < g.lnz + NS && lj >= -NS && lj < g.lnx + NS;
-            if (i >= 0 && i < g.nz && j >= 0 && j < g.nx && ((owned && depth[q] >= HC) || ring)) {
+            if (i >= 0 && i < g.nz && j >= 0 && j < g.nx && ((owned && mgt_owns(ra, rb, HC, TS, i, j, g)) || ring)) {
                 const long long c = pl_idx(g, li, lj);
                 a.v[c] = V[cur][0][idx]; a.v[c + P] = V[cur][1][idx];
             }
@@ -2457,8 +2616,10 @@ __global__ __launch_bounds__(mgt_nt(mgt_pre_nn(NS + EXT, TS))) void k_mg_pre(MgT
     __syncthreads();
     // ---- full-weighting restriction (restrict_node) onto the coarse nodes of the tile
     const PlGeom& gc = a.opc.g;
-    for (int idx = tid; idx < (TS / 2) * (TS / 2); idx += NT) {
-        const int I = (ti0 >> 1) + idx / (TS / 2), J = (tj0 >> 1) + idx % (TS / 2);
+    for (int idx = tid; idx < (TS / 2 + 1) * (TS / 2 + 1); idx += NT) {          // (+ 1: the coarse grid's last row / column, as mgt_owns)
+        const int u_ = idx / (TS / 2 + 1), w_ = idx % (TS / 2 + 1);
+        const int I = (ti0 >> 1) + u_, J = (tj0 >> 1) + w_;
+        if ((u_ == TS / 2 && I != gc.nz - 1) || (w_ == TS / 2 && J != gc.nx - 1)) continue;
         if (I >= gc.nz || J >= gc.nx || 2 * I - g.gi0 >= g.lnz || 2 * J - g.gj0 >= g.lnx) continue;      // (only the coarse nodes of this rank's block)
         const int b0 = (2 * I - ci0) * CR + (2 * J - cj0);
         int d; double s;
@@ -2582,6 +2743,17 @@ __global__ __launch_bounds__(mgt_nt(mgt_post_nn(NS, TS))) void k_mg_post(MgTileA
             }
         }
         if (k < NS - 1) { __syncthreads(); cur ^= 1; }
+    }
+    // the grid's last row / column next to the tile (mgt_owns): zero rows
+#pragma unroll
+    for (int q = 0; q < NPT; q++) {
+        const int idx = tid + q * NT;
+        if (depth[q] == HC - 1) {
+            const int ra = idx / CR, rb = idx % CR, i = ci0 + ra, j = cj0 + rb;
+            if (mgt_owns(ra, rb, HC, TS, i, j, g) && i - g.gi0 < g.lnz && j - g.gj0 < g.lnx) {
+                const long long c = pl_idx(g, i - g.gi0, j - g.gj0); a.out[c] = 0.0; a.out[c + a.out_plane] = 0.0;
+            }
+        }
     }
 }
 
@@ -2783,7 +2955,7 @@ static void cheb_coeffs(double lmax, double ratio, int n, double* c1, double* c2
     }
 }
 static bool mg_fused_level_ok(pl_ctx* ctx, const PlSolver* S, size_t l) {
-    if (!S->fused || l + 1 >= S->levels.size() || S->early_K > 0) return false;
+    if (!S->fused || l + 1 >= S->levels.size() || S->early_K > 0 || S->any_line) return false;
     const MgLevel* L = S->levels[l];
     // several ranks: the REPLICATED levels (every rank holds and computes the whole level) run the tile kernels like one rank does --
     // they are the latency-bound ones; a level whose own or whose coarse grid is distributed keeps the staged path with its exchanges
@@ -2822,8 +2994,10 @@ static void vcycle_fused_level(pl_ctx* ctx, PlSolver* S, size_t l, const double*
     a.f = rs ? (const double*)L->f : f; a.fout = L->f; a.v = L->v[0]; a.fc = C->f;
     // tile edge: 32 on the large levels (halo recomputation 1.7x instead of 2.6x at three sweeps; one workgroup per CU), 16 below
     const int TS = (long long)g.lnz * g.lnx >= S->tile32_min_nodes ? 32 : MGT_TS;
-    a.tiles_x = (g.lnx + TS - 1) / TS;
-    const dim3 grid((unsigned)(a.tiles_x * ((g.lnz + TS - 1) / TS)));
+    // (the grid's last row / column belong to the tiles in front of them: mgt_owns)
+    const int own_z = g.lnz - (g.gi0 + g.lnz == g.nz ? 1 : 0), own_x = g.lnx - (g.gj0 + g.lnx == g.nx ? 1 : 0);
+    a.tiles_x = (own_x + TS - 1) / TS;
+    const dim3 grid((unsigned)(a.tiles_x * ((own_z + TS - 1) / TS)));
     cheb_coeffs(L->lmax, S->cheb_ratio, npre, a.c1, a.c2);
     if (rs) { a.sop = *sop; a.rs = rs; a.z = z; }
 #define MGT_PRE(NS, L0) do { if (TS == 32) hipLaunchKernelGGL((k_mg_pre<NS, L0, 32>), grid, dim3(mgt_nt(mgt_pre_nn(NS, 32))), 0, ctx->stream, a); \
@@ -2932,7 +3106,7 @@ static int stokes_precond_t(pl_ctx* ctx, PlSolver* S, const double* rs, double* 
         const double hmean = 0.5 * ((ctx->geom.zc.back() - ctx->geom.zc.front()) / (ctx->nz - 1) + (ctx->geom.xc.back() - ctx->geom.xc.front()) / (ctx->nx - 1));
         const double sig = ctx->sop.Kc / hmean, ik = 1.0 / S->kappa;            // ~ eta_min / h^2 and the typical entry of the scaled residual
         const bool range_ok = std::isfinite(sig) && sig > 0.0 && ik * std::min(1.0, sig) > 1e-30 && ik * std::max(1.0, sig) < 1e22;
-        if (S->l0_mixed && S->l0_mixed_now && range_ok && !L0->dist && !L0->op.szz && g_vv_vec && (g.plane % 2) == 0 && S->levels.size() > 1 && npre0 == 1 && npost0 == 1 &&
+        if (S->l0_mixed && S->l0_mixed_now && !S->any_line && range_ok && !L0->dist && !L0->op.szz && g_vv_vec && (g.plane % 2) == 0 && S->levels.size() > 1 && npre0 == 1 && npost0 == 1 &&
             S->fuse_first && S->early_K == 0 && ctx->nranks == 1 && !S->levels[1]->dist && !S->levels[1]->f32) {
             MgLevel* C = S->levels[1];
             // (planes of their own, zero-initialised: the ring around the block must read as zero, which a view of an FP64 buffer
@@ -2971,7 +3145,7 @@ static int stokes_precond_t(pl_ctx* ctx, PlSolver* S, const double* rs, double* 
             return 0;
         }
     }
-    const bool fuse_first = S->fuse_first && g_vv_vec && (g.plane % 2) == 0 && S->levels.size() > 1 && npre0 >= 1 && !L0->op.szz;
+    const bool fuse_first = S->fuse_first && !S->any_line && g_vv_vec && (g.plane % 2) == 0 && S->levels.size() > 1 && npre0 >= 1 && !L0->op.szz;
     const int anchor[2] = {ctx->sop.anchor_i, ctx->sop.anchor_j};
     T* f0 = LevelT<T>::f(L0);
     if (g_vv_vec && (g.plane % 2) == 0) {

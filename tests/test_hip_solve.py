@@ -2,6 +2,7 @@
 
 Tolerance (BASELINE north_star): velocity and temperature within 1e-6 relative-L2 of the
 scipy direct solve.  Pressure is compared in the reference's Kcont-scaled units."""
+import os
 import numpy as np
 import pytest
 
@@ -412,3 +413,30 @@ def test_stock_model5_sphere_contrast_1e10(oracle):
     assert ev_true < VEL_TOL, (ev_true, st)
     assert ev_fix < 1e-4, (ev_fix, st)
     assert st["error_estimate"] == 0.0 or st["error_estimate"] >= ev_true / 4, (ev_true, st)
+
+
+@pytest.mark.parametrize("nx,forced", [([513, 33], False), ([129, 129], True)])
+def test_z_line_relaxation_vs_direct_solve(oracle, nx, forced):
+    """Stretched grids (pl_solver.hip, k_vv_line_z): 513 x 33 nodes on a square domain -- cells 16 times wider than high, where the
+    point-Jacobi multigrid stalls -- take the z-line smoother by themselves; the isotropic 129^2 case forces it on every level
+    (PYLAMP_MG_LINE=1) so that the kernel is checked where the point smoother's answer is known to be good.  Both against the
+    oracle's direct solve at the north-star tolerance."""
+    from pylamp_amd import pylamp_stokes as S
+    grid = [np.linspace(0, 1, nx[0]), np.linspace(0, 1, nx[1])]
+    Z, X = np.meshgrid(grid[0], grid[1], indexing="ij")
+    eta = 10 ** (1.0 * np.sin(3 * np.pi * X) * np.cos(2 * np.pi * Z))
+    rho = 1.0 + 0.1 * np.exp(-((Z - 0.4) ** 2 + (X - 0.55) ** 2) / 0.02)
+    bc = [1, 1, 1, 1]
+    if forced:
+        os.environ["PYLAMP_MG_LINE"] = "1"
+    try:
+        A, rhs = S.makeStokesMatrix(nx, grid, eta, eta, rho, bc)
+        x = S.solve(A, rhs)
+    finally:
+        os.environ.pop("PYLAMP_MG_LINE", None)
+    st = A.last_stats
+    xo = oracle.stokes_solve(nx, grid, eta, eta, rho, bc)
+    ev, _ = _vel_err(S, x, xo, nx)
+    print("z-lines %s: %s, velocity error %.2e" % (nx, st, ev))
+    assert st["converged"] == 1 and st["used_direct"] == 0, st
+    assert ev < VEL_TOL, (ev, st)
