@@ -62,7 +62,7 @@ typedef struct pl_solve_stats {
                              * preconditioner application) the iteration uses (n |r_cont| + a |r_mom|) / |x_vel| on the
                              * recurrence residual, a = |(M^-1 s)_vel| / |s_mom| measured on the way.  A solve whose residual meets
                              * rtol keeps iterating until the estimate is <= 3e-8 (PYLAMP_STOKES_ETOL; 0 switches the test off).
-                             * Viscosity contrast above 1e6 (PYLAMP_CONTRAST_GATE): the ROW-SCALED residual no longer bounds
+                             * Viscosity contrast above 3e5 (PYLAMP_CONTRAST_GATE): the ROW-SCALED residual no longer bounds
                              * anything (reference model 5, contrast 1e10: scaled residual 7e-11 at a velocity error of 4e-3), so
                              * systems the banded LU can hold go there up front and every result is judged by its UNSCALED
                              * residual: error_estimate = max(nz, nx) |b - A x|_2 / |b - A x_hydrostatic|_2, converged iff that is
