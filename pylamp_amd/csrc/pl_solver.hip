@@ -3283,7 +3283,7 @@ static int bicgstab(pl_ctx* ctx, PlSolver* S, const PlGeom& g, int np, const Vec
     // preconditioner application on the true residual at every check: 0.8-1.6 ms of a 25 ms solve at 2049^2.  PYLAMP_EST_EXACT=1
     // brings that back.)
     double a_mom = 1.0; bool a_mom_measured = false; int amom_count = 0;
-    static const bool est_exact = getenv("PYLAMP_EST_EXACT") && atoi(getenv("PYLAMP_EST_EXACT")) != 0;
+    const bool est_exact = getenv("PYLAMP_EST_EXACT") && atoi(getenv("PYLAMP_EST_EXACT")) != 0;      // (read per solve: tests compare both)
     // With the pressure-anchor deflation active the component of the residual along that mode needs its own term: its
     // amplification is ||w|| / ||u|| (1e4 and more), far beyond n -- r = gamma u + ..., gamma = y.r / y.u, and the error it stands
     // for is gamma w (A w = u).  Without the deflation BiCGStab has removed this component by the time it leaves its plateau;

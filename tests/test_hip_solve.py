@@ -58,6 +58,19 @@ def test_stokes_solve_vs_oracle_midsize(oracle, n, bc):
     ev, ep = _vel_err(S, x, xref, nx)
     assert st["converged"] == 1 and ev < VEL_TOL and ep < 1e-5, (ev, ep, st)
     assert st["iterations"] < 120, st
+    # the estimate that decided `converged` (momentum amplification measured on the way): honest on this cold start, and
+    # the same verdict as with one exact preconditioner application per check
+    assert st["error_estimate"] >= ev / 16 or ev < 1e-8, (ev, st)
+    os.environ["PYLAMP_EST_EXACT"] = "1"
+    try:
+        A2, rhs2 = S.makeStokesMatrix(nx, grid, fes, fen, frho, bc)
+        x2 = S.solve(A2, rhs2)
+    finally:
+        del os.environ["PYLAMP_EST_EXACT"]
+    st2 = A2.last_stats
+    ev2, _ = _vel_err(S, x2, xref, nx)
+    print("estimate measured / exact: %.2e (error %.2e, %d its) / %.2e (error %.2e, %d its)" % (st["error_estimate"], ev, st["iterations"], st2["error_estimate"], ev2, st2["iterations"]))
+    assert st2["converged"] == 1 and ev2 < VEL_TOL and (st2["error_estimate"] >= ev2 / 16 or ev2 < 1e-8), (ev2, st2)
 
 
 def test_stokes_solve_zero_rhs_and_x0():
