@@ -1034,6 +1034,7 @@ struct pl3_ctx {
     int gn[3] = {0, 0, 0}; std::vector<double> gcoord[3];     // the global grid
     double* hbuf = nullptr; size_t hbuf_n = 0;                // halo exchange: send lo | send hi | recv lo | recv hi
     long long halo_calls = 0, reduce_calls = 0;
+    bool halo_failed = false;       // an exchange inside the V-cycle failed (its callers are void): the preconditioner reports it
     std::string err;
     G3Host geom;
     double *es = nullptr, *en = nullptr, *rho = nullptr; Op3 op{}; bool op_ready = false;
@@ -1173,7 +1174,13 @@ static int download3(pl3_ctx* ctx, double* const* src, int ncomp, double* host) 
 // One ring of nodes around the block is all the stencils reach (faces, the edge neighbours (i-1, j+1) ... of the momentum rows, and the
 // corner nodes of the full-weighting restriction): exchanged axis by axis -- z planes, then x planes including the z ring just
 // received, then y planes including both -- so that 6 messages carry all 26 neighbours' nodes.
+static int halo3_impl(pl3_ctx* ctx, const G3& g, double* const* arr, int na);
 static int halo3(pl3_ctx* ctx, const G3& g, double* const* arr, int na) {
+    const int rc = halo3_impl(ctx, g, arr, na);
+    if (rc) ctx->halo_failed = true;
+    return rc;
+}
+static int halo3_impl(pl3_ctx* ctx, const G3& g, double* const* arr, int na) {
     if (ctx->nranks <= 1) return 0;
     ctx->halo_calls++;
     for (int a = 0; a < 3; a++) {
@@ -1760,6 +1767,7 @@ extern "C" int pl3_stokes_solve(pl3_ctx* ctx, const double* rhs, double* x, int 
     if (!x && use_x0 && !ctx->have_x) return p3_fail(ctx, "pl3_stokes_solve: no resident solution to start from");
     P3_HIP(ctx, hipSetDevice(ctx->device));
     P3_TRY(need_vecs(ctx, 14));
+    ctx->halo_failed = false;
     if (rtol <= 0) rtol = 1e-7;
     if (maxit <= 0) maxit = 600;
     const G3& g = ctx->geom.d;
@@ -1790,6 +1798,7 @@ extern "C" int pl3_stokes_solve(pl3_ctx* ctx, const double* rhs, double* x, int 
             for (int q = 0; q < 3; q++) P3_HIP(ctx, hipMemcpyAsync(out[q], L0->v[ob][q], (size_t)vol * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
         }
         nprec++;
+        if (ctx->halo_failed) return 1;      // (an exchange inside the V-cycle; ctx->err says which)
         if (defl_active) {                  // z += w yw.(r - A z) / yw.(A w); the continuity rows of A z come from z's velocities alone
             const double* a1[2] = {ctx->dfl_y, ctx->dfl_y}; const double* b1[2] = {in[3], ctx->dfl_t}; double o[2];
             P3_TRY(halo3(ctx, g, out, 3));

@@ -265,6 +265,9 @@ class VirtualCluster3:
         if pending:
             self.lib.pl_local_group_abort(self.group)
             cf.wait(futs, timeout=60)
+        errs = [(r, f.exception()) for r, f in enumerate(futs) if f.done() and f.exception() is not None]
+        if errs:       # every rank's message: the first one in rank order is often only the consequence of another rank's failure
+            raise Exception("virtual ranks failed: " + " | ".join("rank %d: %s" % (r, e) for r, e in errs)) from errs[0][1]
         return [f.result(timeout=1) for f in futs]
 
     def close(self):
