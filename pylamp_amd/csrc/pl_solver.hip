@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void k_vv_cheb_first(PlVvOpT<T> op, const T* _
 }
 
 // =========================================================================================
-// z-LINE relaxation (stretched and graded grids).  Where the cells are much wider than high (dx >> dz) the
+// LINE relaxation (stretched and graded grids); described for z-lines, k_vv_line<1> is the transposed twin.  Where the cells are much wider than high (dx >> dz) the
 // z-couplings of a velocity row are ~ (dx/dz)^2 times its x-couplings: point Jacobi leaves the modes that are smooth along z untouched
 // and full coarsening cannot carry them (513 x 129 nodes on a square: 41 iterations; a grid graded 30 x in z: 209).  Here the block
 // of the Jacobi splitting is the TRIDIAGONAL matrix T of each component's own z-couplings, column by column:
@@ -225,57 +225,81 @@ struct LineArgs {
     PlVvOp op; const double* v; const double* vprev; const double* f; double* out;
     double c1, c2, oscale; int mode /* 0 sweep, 1 out = T^-1 A v */; int cols;
 };
-__global__ __launch_bounds__(LZ_NT) void k_vv_line_z(LineArgs a) {
+// AX = 0: lines along z (cells wider than high); AX = 1: lines along x (cells higher than wide) -- the same kernel with the roles of the
+// axes swapped: the couplings of T are the component's own couplings ALONG the line, a slaved line evaluates its master line, slaved
+// points inside a line copy their neighbour behind the solve.
+template <int AX>
+__global__ __launch_bounds__(LZ_NT) void k_vv_line(LineArgs a) {
     extern __shared__ double lz_sh[];
     const PlGeom& g = a.op.g;
-    const int n = g.nz, cols = a.cols, comp = blockIdx.y, j0 = blockIdx.x * cols, tot = n * cols;
+    const int n = AX == 0 ? g.nz : g.nx, nlines = AX == 0 ? g.nx : g.nz;     // points per line, lines of the level
+    const int cols = a.cols, comp = blockIdx.y, l0 = blockIdx.x * cols, tot = n * cols;
+    const int stride = AX == 0 ? cols : 1;                                    // LDS distance of neighbours along the line
     double* const SA = lz_sh; double* const SB = SA + tot; double* const SC = SB + tot; double* const SD = SC + tot;
     const long long P = g.plane;
     const double* vz = a.v; const double* vx = a.v ? a.v + P : nullptr;
     double A_[LZ_EPT], B_[LZ_EPT], C_[LZ_EPT], D_[LZ_EPT], base[LZ_EPT], sfac[LZ_EPT];
     int cout_[LZ_EPT];      // element offset of the node this entry is written to (-1: none)
-    // interior (equation-carrying) rows of column je of this component
-    auto is_int = [&](int i, int je) {
-        if (comp == 0) return i >= 1 && i <= n - 2 && je >= 0 && je < g.nx - 1 && !(a.op.slave_x && (je == 0 || je == g.nx - 2));
-        return je >= 1 && je <= g.nx - 2 && i >= (a.op.slave_z0 ? 1 : 0) && i <= (a.op.slave_zL ? n - 3 : n - 2);
+    // interior (equation-carrying) rows of this component
+    auto is_int = [&](int i, int j) {
+        if (comp == 0) return i >= 1 && i <= g.nz - 2 && j >= 0 && j < g.nx - 1 && !(a.op.slave_x && (j == 0 || j == g.nx - 2));
+        return j >= 1 && j <= g.nx - 2 && i >= (a.op.slave_z0 ? 1 : 0) && i <= (a.op.slave_zL ? g.nz - 3 : g.nz - 2);
     };
+    // position along the line and line of entry e (AX = 0: the lines of a workgroup are adjacent columns, line index fastest;
+    // AX = 1: adjacent rows, position fastest -- either way neighbouring threads read neighbouring columns)
+    auto pos_of = [&](int e) { return AX == 0 ? e / cols : e % n; };
+    auto line_of = [&](int e) { return AX == 0 ? e % cols : e / n; };
 #pragma unroll
     for (int q = 0; q < LZ_EPT; q++) {
         const int e = threadIdx.x + q * LZ_NT;
         A_[q] = 0.0; B_[q] = 1.0; C_[q] = 0.0; D_[q] = 0.0; base[q] = 0.0; sfac[q] = 0.0; cout_[q] = -1;
         if (e >= tot) continue;
-        const int i = e / cols, j = j0 + e % cols;
-        if (j >= g.nx) continue;
+        const int ln = l0 + line_of(e);
+        if (ln >= nlines) continue;
+        const int i = AX == 0 ? pos_of(e) : ln, j = AX == 0 ? ln : pos_of(e);
         const int c = (int)pl_idx(g, i - g.gi0, j - g.gj0);
         cout_[q] = c;
-        int je = j;                                  // the column whose rows this entry evaluates: a slaved vz column its master's
-        if (comp == 0 && a.op.slave_x && (j == 0 || j == g.nx - 2)) je = j == 0 ? 1 : g.nx - 3;
-        if (!is_int(i, je)) continue;                // wall row (0), or a slaved vx row (filled in behind the solve)
-        const int cm = c + (je - j);
-        double Av = 0.0, dg, cN, cS;
+        // the node whose row this entry evaluates: a point of a slaved LINE its master's
+        int ie = i, je = j;
+        if (AX == 0 && comp == 0 && a.op.slave_x && (j == 0 || j == g.nx - 2)) je = j == 0 ? 1 : g.nx - 3;
+        if (AX == 1 && comp == 1 && ((i == 0 && a.op.slave_z0) || (i == g.nz - 2 && a.op.slave_zL)) && g.nz >= 4) ie = i == 0 ? 1 : g.nz - 3;
+        if (!is_int(ie, je)) continue;               // wall row (0), or a slaved point inside the line (filled in behind the solve)
         const int p = g.pitch;
+        const int cm = c + (je - j) + (ie - i) * p;
+        double Av = 0.0, dg, cNext, cPrev;
         if (comp == 0) {
-            const double rdz_i = TB(a.op.rdz, i), rdz_m = TB(a.op.rdz, i - 1), rDz_i = TB(a.op.rDz, i);
-            cN = 4.0 * a.op.etan[cm] * rdz_i * rDz_i; cS = 4.0 * a.op.etan[cm - p] * rdz_m * rDz_i;
-            if (a.v) vv_row_z(a.op, vz, vx, cm, i, je, Av, dg); else dg = vv_diag_z(a.op, cm, i, je);
+            if (AX == 0) {
+                const double rdz_i = TB(a.op.rdz, ie), rdz_m = TB(a.op.rdz, ie - 1), rDz_i = TB(a.op.rDz, ie);
+                cNext = 4.0 * a.op.etan[cm] * rdz_i * rDz_i; cPrev = 4.0 * a.op.etan[cm - p] * rdz_m * rDz_i;
+            } else {
+                const double rdx_j = TB(a.op.rdx, je), rDx_j = TB(a.op.rDx, je), rDx_p = TB(a.op.rDx, je + 1);
+                cNext = 2.0 * a.op.etas[cm + 1] * rDx_p * rdx_j; cPrev = 2.0 * a.op.etas[cm] * rDx_j * rdx_j;
+            }
+            if (a.v) vv_row_z(a.op, vz, vx, cm, ie, je, Av, dg); else dg = vv_diag_z(a.op, cm, ie, je);
             if (a.v) base[q] = vz[cm] + ((a.c1 != 0.0 && a.mode == 0) ? a.c1 * (vz[cm] - (a.vprev ? a.vprev[cm] : 0.0)) : 0.0);
         } else {
-            const double rdz_i = TB(a.op.rdz, i), rDz_i = TB(a.op.rDz, i), rDz_p = TB(a.op.rDz, i + 1);
-            cN = 2.0 * a.op.etas[cm + p] * rDz_p * rdz_i; cS = 2.0 * a.op.etas[cm] * rDz_i * rdz_i;
-            if (a.v) vv_row_x(a.op, vz, vx, cm, i, je, Av, dg); else dg = vv_diag_x(a.op, cm, i, je);
+            if (AX == 0) {
+                const double rdz_i = TB(a.op.rdz, ie), rDz_i = TB(a.op.rDz, ie), rDz_p = TB(a.op.rDz, ie + 1);
+                cNext = 2.0 * a.op.etas[cm + p] * rDz_p * rdz_i; cPrev = 2.0 * a.op.etas[cm] * rDz_i * rdz_i;
+            } else {
+                const double rdx_j = TB(a.op.rdx, je), rdx_m = TB(a.op.rdx, je - 1), rDx_j = TB(a.op.rDx, je);
+                cNext = 4.0 * a.op.etan[cm] * rdx_j * rDx_j; cPrev = 4.0 * a.op.etan[cm - 1] * rdx_m * rDx_j;
+            }
+            if (a.v) vv_row_x(a.op, vz, vx, cm, ie, je, Av, dg); else dg = vv_diag_x(a.op, cm, ie, je);
             if (a.v) base[q] = vx[cm] + ((a.c1 != 0.0 && a.mode == 0) ? a.c1 * (vx[cm] - (a.vprev ? (a.vprev + P)[cm] : 0.0)) : 0.0);
         }
-        sfac[q] = 1.0;
+        // a slaved line takes s x its master line (vz columns: s = 1; vx rows: s0 / sL)
+        sfac[q] = (AX == 1 && comp == 1 && ie != i) ? (i == 0 ? a.op.s0 : a.op.sL) : 1.0;
         B_[q] = dg;
-        A_[q] = is_int(i - 1, je) ? -cS : 0.0;
-        C_[q] = is_int(i + 1, je) ? -cN : 0.0;
+        A_[q] = is_int(AX == 0 ? ie - 1 : ie, AX == 0 ? je : je - 1) ? -cPrev : 0.0;
+        C_[q] = is_int(AX == 0 ? ie + 1 : ie, AX == 0 ? je : je + 1) ? -cNext : 0.0;
         D_[q] = Av - ((a.mode == 0 && a.f) ? (a.f + comp * P)[cm] : 0.0);
     }
     if (a.mode == 1) {
 #pragma unroll
         for (int q = 0; q < LZ_EPT; q++) base[q] = 0.0;
     }
-    // ---- parallel cyclic reduction: after the step of stride s every row couples to the rows i -+ 2 s only
+    // ---- parallel cyclic reduction: after the step of stride st every row couples to the rows pos -+ 2 st only
     for (int st = 1; st < n; st <<= 1) {
 #pragma unroll
         for (int q = 0; q < LZ_EPT; q++) {
@@ -287,48 +311,59 @@ __global__ __launch_bounds__(LZ_NT) void k_vv_line_z(LineArgs a) {
         for (int q = 0; q < LZ_EPT; q++) {
             const int e = threadIdx.x + q * LZ_NT;
             if (e >= tot) continue;
-            const int i = e / cols;
+            const int ps = pos_of(e);
             double al = 0.0, ga = 0.0, am = 0.0, cm_ = 0.0, dm = 0.0, ap = 0.0, cp = 0.0, dp = 0.0;
-            if (i - st >= 0 && A_[q] != 0.0) { const int m = e - st * cols; al = -A_[q] / SB[m]; am = SA[m]; cm_ = SC[m]; dm = SD[m]; }
-            if (i + st < n && C_[q] != 0.0) { const int m = e + st * cols; ga = -C_[q] / SB[m]; ap = SA[m]; cp = SC[m]; dp = SD[m]; }
+            if (ps - st >= 0 && A_[q] != 0.0) { const int m = e - st * stride; al = -A_[q] / SB[m]; am = SA[m]; cm_ = SC[m]; dm = SD[m]; }
+            if (ps + st < n && C_[q] != 0.0) { const int m = e + st * stride; ga = -C_[q] / SB[m]; ap = SA[m]; cp = SC[m]; dp = SD[m]; }
             B_[q] = B_[q] + al * cm_ + ga * ap;
             D_[q] = D_[q] + al * dm + ga * dp;
             A_[q] = al * am; C_[q] = ga * cp;
         }
         __syncthreads();
     }
-    // ---- the update; slaved vx rows copy s x their master's (the row next to them, same column)
+    // ---- the update; slaved points inside a line copy s x their master's (the point next to them on the line)
 #pragma unroll
     for (int q = 0; q < LZ_EPT; q++) {
         const int e = threadIdx.x + q * LZ_NT;
-        if (e < tot) SD[e] = sfac[q] != 0.0 ? base[q] + (a.mode == 0 ? a.c2 : 1.0) * (D_[q] / B_[q]) : 0.0;
+        if (e < tot) SD[e] = sfac[q] != 0.0 ? sfac[q] * (base[q] + (a.mode == 0 ? a.c2 : 1.0) * (D_[q] / B_[q])) : 0.0;
     }
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < LZ_EPT; q++) {
         const int e = threadIdx.x + q * LZ_NT;
         if (e >= tot || cout_[q] < 0) continue;
-        const int i = e / cols, j = j0 + e % cols;
+        const int ln = l0 + line_of(e);
+        const int i = AX == 0 ? pos_of(e) : ln, j = AX == 0 ? ln : pos_of(e);
         double val = SD[e];
-        if (comp == 1 && j >= 1 && j <= g.nx - 2) {
-            if (i == 0 && a.op.slave_z0) val = a.op.s0 * SD[e + cols];
-            else if (i == n - 2 && a.op.slave_zL && n >= 3) val = a.op.sL * SD[e - cols];
+        if (AX == 0 && comp == 1 && j >= 1 && j <= g.nx - 2 && n >= 4) {
+            if (i == 0 && a.op.slave_z0) val = a.op.s0 * SD[e + stride];
+            else if (i == n - 2 && a.op.slave_zL) val = a.op.sL * SD[e - stride];
+        }
+        if (AX == 1 && comp == 0 && a.op.slave_x && i >= 1 && i <= g.nz - 2 && n >= 4) {
+            if (j == 0) val = SD[e + 1];
+            else if (j == n - 2) val = SD[e - 1];
         }
         (a.out + comp * P)[cout_[q]] = val * a.oscale;
     }
 }
-static bool line_z_possible(const pl_ctx* ctx, int nz) { return ctx->nranks == 1 && nz <= 4097 && nz >= 3; }
+static bool line_z_possible(const pl_ctx* ctx, int npts) { return ctx->nranks == 1 && npts <= 4097 && npts >= 4; }
+// ax = 0: z-lines, 1: x-lines
 static int line_z_launch(pl_ctx* ctx, const PlVvOp& op, const double* v, const double* vprev, const double* f, double* out, double c1, double c2,
-                         double oscale, int mode) {
+                         double oscale, int mode, int ax) {
     LineArgs a{}; a.op = op; a.v = v; a.vprev = vprev; a.f = f; a.out = out; a.c1 = c1; a.c2 = c2; a.oscale = oscale; a.mode = mode;
-    const int n = op.g.nz;
-    int cols = (LZ_EPT * LZ_NT) / n; if (cols > 16) cols = 16; if (cols > op.g.nx) cols = op.g.nx; if (cols < 1) cols = 1;
+    const int n = ax == 0 ? op.g.nz : op.g.nx, nlines = ax == 0 ? op.g.nx : op.g.nz;
+    int cols = (LZ_EPT * LZ_NT) / n; if (cols > 16) cols = 16; if (cols > nlines) cols = nlines; if (cols < 1) cols = 1;
     while (cols > 1 && (size_t)32 * n * cols > 150000) cols--;
     a.cols = cols;
     const size_t lds = (size_t)32 * n * cols;
-    static size_t lds_set = 0;
-    if (lds > lds_set) { PL_HIP(ctx, hipFuncSetAttribute((const void*)k_vv_line_z, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); lds_set = 160 * 1024; }
-    hipLaunchKernelGGL(k_vv_line_z, dim3((op.g.nx + cols - 1) / cols, 2), dim3(LZ_NT), lds, ctx->stream, a);
+    static bool lds_set = false;
+    if (!lds_set) {
+        PL_HIP(ctx, hipFuncSetAttribute((const void*)k_vv_line<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PL_HIP(ctx, hipFuncSetAttribute((const void*)k_vv_line<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        lds_set = true;
+    }
+    if (ax == 0) hipLaunchKernelGGL(k_vv_line<0>, dim3((nlines + cols - 1) / cols, 2), dim3(LZ_NT), lds, ctx->stream, a);
+    else hipLaunchKernelGGL(k_vv_line<1>, dim3((nlines + cols - 1) / cols, 2), dim3(LZ_NT), lds, ctx->stream, a);
     return 0;
 }
 
@@ -1338,7 +1373,8 @@ struct MgLevel {
     double *f = nullptr, *r = nullptr;
     double* fe = nullptr;        // early coarse branch: R^l f of the finest level (levels 1 .. early_K-1)
     double lmax = 3.0;
-    bool line_z = false;         // z-line relaxation instead of point Jacobi (k_vv_line_z): cells of this level at least 6 x wider than high somewhere
+    bool line_z = false;         // line relaxation instead of point Jacobi (k_vv_line): cells of this level at least 6 x wider than high (or
+    int line_ax = 0;             // higher than wide) somewhere; line_ax 0: z-lines, 1: x-lines
     // FP32 twin (large levels only, see build_hierarchy): viscosity planes times 1/sigma, the 1-D tables, work planes
     bool f32 = false;
     PlVvOpF opf{};
@@ -1783,7 +1819,8 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
             const double hx = (ctx->geom.xc.back() - ctx->geom.xc.front()) / (ctx->nx - 1);
             const double a = hz > hx ? hz / hx : hx / hz;
             const char* le = getenv("PYLAMP_MG_LINE");
-            const bool lines = hx >= 6.0 * hz && line_z_possible(ctx, ctx->nz) && !(le && atoi(le) == 0);      // (wide cells: the z-line smoother's case)
+            const bool lines = ((hx >= 6.0 * hz && line_z_possible(ctx, ctx->nz)) || (hz >= 6.0 * hx && line_z_possible(ctx, ctx->nx))) &&
+                               !(le && atoi(le) == 0);                                    // (the line smoothers' cases)
             S->cheb_ratio = 6.0;
             if (a > 1.5 && !lines) {
                 S->cheb_ratio = 6.0 * a * a;
@@ -1827,12 +1864,15 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
                 // anisotropy rule 41 iterations / 72 ms, lines 45 / 93 -- the count is set by the pressure block there, not by the
                 // smoother; z graded 30 x (cells up to 8.5:1): 209 / 101 ms against 91 / 217 ms; cells 16:1 (1025 x 65): the point
                 // sweeps do NOT converge (residual 2e-4 after 109 iterations), lines reach 1e-8 in 164.
-                double dzmin = 1e300, dxmax = 0.0;
-                for (int i = 0; i + 1 < nz; i++) dzmin = std::min(dzmin, zc[i + 1] - zc[i]);
-                for (int j = 0; j + 1 < nx; j++) dxmax = std::max(dxmax, xc[j + 1] - xc[j]);
+                double dzmin = 1e300, dxmax = 0.0, dxmin = 1e300, dzmax = 0.0;
+                for (int i = 0; i + 1 < nz; i++) { dzmin = std::min(dzmin, zc[i + 1] - zc[i]); dzmax = std::max(dzmax, zc[i + 1] - zc[i]); }
+                for (int j = 0; j + 1 < nx; j++) { dxmax = std::max(dxmax, xc[j + 1] - xc[j]); dxmin = std::min(dxmin, xc[j + 1] - xc[j]); }
                 const char* e = getenv("PYLAMP_MG_LINE");
-                const int knob = e ? atoi(e) : -1;
-                L->line_z = line_z_possible(ctx, nz) && knob != 0 && (knob == 1 || dxmax >= 6.0 * dzmin);
+                const int knob = e ? atoi(e) : -1;                  // 0 never, 1 z-lines on every level, 2 x-lines on every level
+                const double wide = dxmax / dzmin, high = dzmax / dxmin;
+                L->line_z = false; L->line_ax = 0;
+                if (knob == 1 || (knob < 0 && wide >= 6.0 && wide >= high)) { L->line_z = line_z_possible(ctx, nz); L->line_ax = 0; }
+                else if (knob == 2 || (knob < 0 && high >= 6.0)) { L->line_z = line_z_possible(ctx, nx); L->line_ax = 1; }
                 if (L->line_z) S->any_line = true;
             }
             S->levels.push_back(L);
@@ -1940,7 +1980,7 @@ static int build_hierarchy(pl_ctx* ctx, PlSolver* S) {
             if (warm && it >= S->power_its_warm && std::fabs(lam - lam_prev) < 0.01 * lam) break;
             lam_prev = lam;
             if (L->dist) PL_TRY(pl_halo(ctx, g, L->v[0], 2, g.plane));
-            if (L->line_z) PL_TRY(line_z_launch(ctx, L->op, L->v[0], nullptr, nullptr, L->v[1], 0.0, 1.0, 1.0, 1));
+            if (L->line_z) PL_TRY(line_z_launch(ctx, L->op, L->v[0], nullptr, nullptr, L->v[1], 0.0, 1.0, 1.0, 1, L->line_ax));
             else hipLaunchKernelGGL(k_vv_dinv_apply, grid2d(g), dim3(64, 4), 0, ctx->stream, L->op, L->v[0], L->v[1]);
             PL_TRY(dots(ctx, S, g, 2, L->v[1], L->v[1], L->v[0], L->v[0], nn));
             if (!(nn[1] > 0.0) || !(nn[0] > 0.0)) break;
@@ -2032,7 +2072,7 @@ static bool smooth(pl_ctx* ctx, MgLevel* L, T* buf[3], const T* f, int nsweep, d
             if (L->line_z) {               // z-line relaxation: same three-term recurrence, T^-1 in place of D^-1 (one rank, FP64, no views)
                 const double* cur = (k == 0 && zero_guess) ? nullptr : buf[0];
                 const double* prv = (k == 0 || (k == 1 && zero_guess)) ? nullptr : buf[1];
-                (void)line_z_launch(ctx, L->op, cur, prv, f, to_final ? final_out : dst, c1, c2, to_final ? final_scale : 1.0, 0);
+                (void)line_z_launch(ctx, L->op, cur, prv, f, to_final ? final_out : dst, c1, c2, to_final ? final_scale : 1.0, 0, L->line_ax);
                 if (to_final) { wrote_final = true; break; }
                 { T* nxt = buf[2]; buf[2] = buf[1]; buf[1] = buf[0]; buf[0] = nxt; }
                 continue;

@@ -428,7 +428,7 @@ def test_stock_model5_sphere_contrast_1e10(oracle):
     assert st["error_estimate"] == 0.0 or st["error_estimate"] >= ev_true / 4, (ev_true, st)
 
 
-@pytest.mark.parametrize("nx,forced", [([513, 33], False), ([129, 129], True)])
+@pytest.mark.parametrize("nx,forced", [([513, 33], 0), ([129, 129], 1), ([33, 513], 0), ([129, 129], 2)])
 def test_z_line_relaxation_vs_direct_solve(oracle, nx, forced):
     """Stretched grids (pl_solver.hip, k_vv_line_z): 513 x 33 nodes on a square domain -- cells 16 times wider than high, where the
     point-Jacobi multigrid stalls -- take the z-line smoother by themselves; the isotropic 129^2 case forces it on every level
@@ -440,8 +440,8 @@ def test_z_line_relaxation_vs_direct_solve(oracle, nx, forced):
     eta = 10 ** (1.0 * np.sin(3 * np.pi * X) * np.cos(2 * np.pi * Z))
     rho = 1.0 + 0.1 * np.exp(-((Z - 0.4) ** 2 + (X - 0.55) ** 2) / 0.02)
     bc = [1, 1, 1, 1]
-    if forced:
-        os.environ["PYLAMP_MG_LINE"] = "1"
+    if forced:             # 1: z-lines, 2: x-lines on every level (the 33 x 513 case -- cells 16 times higher than wide -- takes x-lines by itself)
+        os.environ["PYLAMP_MG_LINE"] = str(forced)
     try:
         A, rhs = S.makeStokesMatrix(nx, grid, eta, eta, rho, bc)
         x = S.solve(A, rhs)

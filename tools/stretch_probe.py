@@ -1,5 +1,5 @@
 """Stretched / graded grids: the multigrid-preconditioned Stokes solve against the oracle's direct solve.
-    python tools/stretch_probe.py [case ...]      cases: flat (513 x 129 nodes on a 1 x 1 domain), flat16 (1025 x 65), tall (129 x 513), graded (513^2, z spacing
+    python tools/stretch_probe.py [case ...]      cases: flat (513 x 129 nodes on a 1 x 1 domain), flat16 (1025 x 65), tall16 (65 x 1025), tall (129 x 513), graded (513^2, z spacing
                                                   growing 30x towards the bottom), graded2 (both axes graded)"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
@@ -16,6 +16,7 @@ def graded(n, ratio):
 def case(name):
     if name == "flat": nx = [513, 129]; grid = [np.linspace(0, 1, 513), np.linspace(0, 1, 129)]
     elif name == "flat16": nx = [1025, 65]; grid = [np.linspace(0, 1, 1025), np.linspace(0, 1, 65)]
+    elif name == "tall16": nx = [65, 1025]; grid = [np.linspace(0, 1, 65), np.linspace(0, 1, 1025)]
     elif name == "tall": nx = [129, 513]; grid = [np.linspace(0, 1, 129), np.linspace(0, 1, 513)]
     elif name == "graded": nx = [513, 513]; grid = [graded(513, 30.0), np.linspace(0, 1, 513)]
     elif name == "graded2": nx = [513, 513]; grid = [graded(513, 30.0), graded(513, 10.0)]
