@@ -16,6 +16,9 @@ def graded(n, ratio):
 def case(name):
     if name == "flat": nx = [513, 129]; grid = [np.linspace(0, 1, 513), np.linspace(0, 1, 129)]
     elif name == "flat16": nx = [1025, 65]; grid = [np.linspace(0, 1, 1025), np.linspace(0, 1, 65)]
+    elif name == "iso": nx = [257, 257]; grid = [np.linspace(0, 1, 257), np.linspace(0, 1, 257)]
+    elif name == "flat_isovisc": nx = [513, 129]; grid = [np.linspace(0, 1, 513), np.linspace(0, 1, 129)]
+    elif name == "flat16_isovisc": nx = [1025, 65]; grid = [np.linspace(0, 1, 1025), np.linspace(0, 1, 65)]
     elif name == "tall16": nx = [65, 1025]; grid = [np.linspace(0, 1, 65), np.linspace(0, 1, 1025)]
     elif name == "tall": nx = [129, 513]; grid = [np.linspace(0, 1, 129), np.linspace(0, 1, 513)]
     elif name == "graded": nx = [513, 513]; grid = [graded(513, 30.0), np.linspace(0, 1, 513)]
@@ -24,6 +27,7 @@ def case(name):
     else: raise SystemExit("unknown case " + name)
     Z, X = np.meshgrid(grid[0], grid[1], indexing="ij")
     eta = 10 ** (1.5 * np.sin(3 * np.pi * X) * np.cos(2 * np.pi * Z))
+    if name.endswith("_isovisc"): eta = np.ones_like(eta)
     etan = eta
     rho = 1.0 + 0.1 * np.exp(-((Z - 0.4) ** 2 + (X - 0.55) ** 2) / 0.02)
     return nx, grid, eta, etan, rho
