@@ -45,6 +45,7 @@ struct PlStokesOp {
     int anchor_i, anchor_j;  // pressure anchor cell (3,2) (pylamp_stokes.py:536-551)
     double gz, gx;           // gravity components G[IZ], G[IX] (pylamp_const.py:21)
     int scaled;              // 1: y = D_r A x (Jacobi-like row scaling used by the Krylov solver)
+    int wall_ps;             // 1: the pressure block of the preconditioner uses the wall stencils where cells are stretched (prec_p_value)
 };
 
 struct PlHeatOp {

@@ -546,15 +546,18 @@ __global__ __launch_bounds__(256) void k_vv_sweep2(PlVvOpT<T> op, const TV* __re
 }
 
 // wave-uniform: every node of the 128-column wave at row i is of the interior class in stage 1 (and in the first sweep)
-__device__ inline bool stage1_fast_wave(const PlGeom& g, int i, int jw, int bx, int anchor_i, int anchor_j) {
+// wall != 0 (PlStokesOp::wall_ps): the two cell rows / columns next to every wall take the per-node path as well -- the pressure
+// block there is a stencil over its neighbours (prec_p_value), and the straight-line path evaluates S^-1 r_p of rows i, i - 1
+__device__ inline bool stage1_fast_wave(const PlGeom& g, int i, int jw, int bx, int anchor_i, int anchor_j, int wall) {
     const bool anchor_near = (anchor_i == i || anchor_i == i - 1) && anchor_j >= jw - 1 && anchor_j <= jw + 127;
-    return !(i < 1 || i > g.nz - 3 || jw < 1 || jw + 127 > g.nx - 3 || anchor_near || bx * 128 + 127 >= g.lnx);
+    const int m = wall ? 1 : 0;
+    return !(i < 1 + 2 * m || i > g.nz - 3 - m || jw < 1 || jw + 127 > g.nx - 3 - m || anchor_near || bx * 128 + 127 >= g.lnx);
 }
 // First sweep from the zero guess, two columns per lane (see cheb_first_node): v1 = -c2 f / diag.
 // only_slow != 0: stage 1 has already written the waves it treats as interior (stage1_fast_wave); do the others only
 template <typename T, typename TF = T, typename TV = T>
 __global__ __launch_bounds__(256) void k_vv_first2(PlVvOpT<T> op, const TF* __restrict__ f, TV* __restrict__ out, T c2,
-                                                   int only_slow, int anchor_i, int anchor_j) {
+                                                   int only_slow, int anchor_i, int anchor_j, int wall) {
     typedef typename PlVec2<TV>::type V2;
     typedef typename PlVec2<TF>::type VF2;
     const PlGeom& g = op.g;
@@ -580,7 +583,7 @@ __global__ __launch_bounds__(256) void k_vv_first2(PlVvOpT<T> op, const TF* __re
     const int c = (int)pl_idx(g, li, lj0);
     const int i = g.gi0 + li, j0 = g.gj0 + lj0;
     const int jw = g.gj0 + bx * 128;
-    if (only_slow && stage1_fast_wave(g, i, jw, bx, anchor_i, anchor_j)) return;
+    if (only_slow && stage1_fast_wave(g, i, jw, bx, anchor_i, anchor_j, wall)) return;
     // walls, slaves, stabilised rows, or a wave that sticks out of the block (wave-uniform)
     if (only_slow || i <= 0 || i >= nz - 2 || jw < 1 || jw + 127 > nx - 3 || op.szz || bx * 128 + 127 >= g.lnx) {
         if (!active) return;
@@ -1168,11 +1171,65 @@ __device__ inline double prec_p_cont(const PlStokesOp& op, const double* __restr
 
 // z_p = S^-1 r_p at one pressure node, from the SCALED residual (ghost/anchor rows: r/Kc = rs;
 // corners: P_c = P_nb - r/Kb; continuity rows: r eta_n / Kc^2)
+// Wall rows of the pressure Schur complement (round 4).  Isoviscous, S = A_pp - A_pv A_vv^-1 A_vp is EXACTLY
+// Kc^2 / (2 eta) I in the bulk whatever the cell shape, but in the two cell columns next to an x-wall -- where the reference slaves the
+// tangential velocity to its inner neighbour -- its rows are nonlocal along the wall and its eigenvalues go down to (dz/dx)^2 / 2 of
+// that: on cells a = dx/dz times wider than high the diagonal S^ leaves O(wall length) eigenvalues of S^-1 S near 1/a^2 (isoviscous
+// 65 x 17 nodes: 25 iterations instead of 11).  The INVERSE of the wall block, however, is local -- measured on dense Schur complements
+// (tools/schur_spectrum.py ...), in units of eta / Kc^2 with r the unscaled continuity residual, wall column 0 and its neighbour 1:
+//     z_0(i) = 1.45 r_0 - 0.225 r_1 - (a^2 / 4) [d(i-1) - 2 d(i) + d(i+1)],   d = r_0 - r_1;        z_1(i) = 0.25 r_0 + 0.775 r_1
+// (the bulk value being 1 in these units: the library's S^-1 is half the exact inverse throughout).  The same with rows and columns
+// swapped next to the z-walls on cells higher than wide.  Used where the local aspect ratio is at least 2 (op.wall_ps, one rank).
+__device__ inline double prec_p_rhat(const PlStokesOp& op, const double* __restrict__ rs_p, int i, int j, long long c) {
+    return rs_p[c] * (TB(op.g.rdx, j) + TB(op.g.rdz, i)) * op.iKc;              // prec_p_cont without the viscosity
+}
+__device__ inline bool prec_p_is_cont(const PlStokesOp& op, int i, int j) {         // a plain continuity row
+    const int nz = op.g.nz, nx = op.g.nx;
+    return i >= 0 && j >= 0 && i <= nz - 2 && j <= nx - 2 && !(i == op.anchor_i && j == op.anchor_j) && !((i == 0 || i == nz - 2) && (j == 0 || j == nx - 2));
+}
 __device__ inline double prec_p_value(const PlStokesOp& op, const double* __restrict__ rs_p, int i, int j, long long c) {
     const int nz = op.g.nz, nx = op.g.nx;
     if (i >= nz - 1 || j >= nx - 1 || (i == op.anchor_i && j == op.anchor_j)) return rs_p[c];
     if ((i == 0 || i == nz - 2) && j == 0) return prec_p_cont(op, rs_p, i, 1, c + 1) - rs_p[c];
     if ((i == 0 || i == nz - 2) && j == nx - 2) return prec_p_cont(op, rs_p, i, nx - 3, c - 1) - rs_p[c];
+    if (op.wall_ps && nz >= 9 && nx >= 9) {
+        const double a = TB(op.g.rdz, i) / TB(op.g.rdx, j);                  // dx / dz of this cell
+        const int p = op.g.pitch;
+        // x-walls: columns 0, 1 and nx-2, nx-3 (dj: towards the interior)
+        if (a >= 2.0 && (j <= 1 || j >= nx - 3)) {
+            const int dj = j <= 1 ? 1 : -1, jw = (j == 0 || j == nx - 2) ? j : j - dj, ji = jw + dj;
+            const long long cw = c + (jw - j), ci = c + (ji - j);
+            if (prec_p_is_cont(op, i, jw) && prec_p_is_cont(op, i, ji)) {
+                const double r0 = prec_p_rhat(op, rs_p, i, jw, cw), r1 = prec_p_rhat(op, rs_p, i, ji, ci);
+                if (j != jw) return op.etan[c] * (0.25 * r0 + 0.775 * r1);
+                const double d0 = r0 - r1;
+                double d2 = 0.0;
+                if (prec_p_is_cont(op, i - 1, jw) && prec_p_is_cont(op, i - 1, ji))
+                    d2 += prec_p_rhat(op, rs_p, i - 1, jw, cw - p) - prec_p_rhat(op, rs_p, i - 1, ji, ci - p) - d0;
+                if (prec_p_is_cont(op, i + 1, jw) && prec_p_is_cont(op, i + 1, ji))
+                    d2 += prec_p_rhat(op, rs_p, i + 1, jw, cw + p) - prec_p_rhat(op, rs_p, i + 1, ji, ci + p) - d0;
+                return op.etan[c] * (1.45 * r0 - 0.225 * r1 - 0.25 * a * a * d2);
+            }
+        }
+        // z-walls: rows 0, 1 and nz-2, nz-3.  Only up to 6:1: measured at 16:1 (65 x 1025 nodes, x-line smoothing) the iteration with
+        // V(2,2) does not profit (isoviscous 30 -> 30, variable viscosity 62 -> 84; with V(3,3) 14 / 43, slower in time than without) --
+        // unlike the x-wall case (1025 x 65: 84 -> 13 and 140 -> 34) -- for reasons that were not found
+        if (a <= 0.5 && a > 1.0 / 6.0 && (i <= 1 || i >= nz - 3)) {
+            const int di = i <= 1 ? 1 : -1, iw = (i == 0 || i == nz - 2) ? i : i - di, ii = iw + di;
+            const long long cw = c + (long long)(iw - i) * p, ci = c + (long long)(ii - i) * p;
+            if (prec_p_is_cont(op, iw, j) && prec_p_is_cont(op, ii, j)) {
+                const double r0 = prec_p_rhat(op, rs_p, iw, j, cw), r1 = prec_p_rhat(op, rs_p, ii, j, ci);
+                if (i != iw) return op.etan[c] * (0.25 * r0 + 0.775 * r1);
+                const double d0 = r0 - r1;
+                double d2 = 0.0;
+                if (prec_p_is_cont(op, iw, j - 1) && prec_p_is_cont(op, ii, j - 1))
+                    d2 += prec_p_rhat(op, rs_p, iw, j - 1, cw - 1) - prec_p_rhat(op, rs_p, ii, j - 1, ci - 1) - d0;
+                if (prec_p_is_cont(op, iw, j + 1) && prec_p_is_cont(op, ii, j + 1))
+                    d2 += prec_p_rhat(op, rs_p, iw, j + 1, cw + 1) - prec_p_rhat(op, rs_p, ii, j + 1, ci + 1) - d0;
+                return op.etan[c] * (1.45 * r0 - 0.225 * r1 - 0.25 / (a * a) * d2);
+            }
+        }
+    }
     return prec_p_cont(op, rs_p, i, j, c);
 }
 
@@ -1241,7 +1298,7 @@ __global__ __launch_bounds__(256) void k_prec_stage1_v2(PlStokesOp op, PlVvOpT<T
     const int i = g.gi0 + li;
     const int jw = g.gj0 + blockIdx.x * 128;
     (void)nz; (void)nx;
-    if (!stage1_fast_wave(g, i, jw, blockIdx.x, op.anchor_i, op.anchor_j)) {     // walls, slaves, anchor, or the wave sticks out of the block
+    if (!stage1_fast_wave(g, i, jw, blockIdx.x, op.anchor_i, op.anchor_j, op.wall_ps)) {     // walls, slaves, anchor, or the wave sticks out of the block
         for (int q = 0; q < 2 && lj0 + q < g.lnx; q++) stage1_node(op, vop, rs, z, f, li, lj0 + q, fscale);
         return;
     }
@@ -2083,9 +2140,9 @@ static bool smooth(pl_ctx* ctx, MgLevel* L, T* buf[3], const T* f, int nsweep, d
             if (g_vv_vec && first_done_anchor) {      // stage 1 wrote the interior waves of this sweep already (into dst = buf[2])
                 const dim3 full = pl_grid_rows2(V.op.g);
                 hipLaunchKernelGGL(k_vv_first2<T>, dim3(3 * full.x + 3 * full.y + 2), dim3(64, 4), 0, ctx->stream, V.op, f - sh, dst - sh, (T)c2, 2,
-                                   first_done_anchor[0], first_done_anchor[1]);
+                                   first_done_anchor[0], first_done_anchor[1], ctx->sop.wall_ps);
             }
-            else if (g_vv_vec) hipLaunchKernelGGL(k_vv_first2<T>, pl_grid_rows2(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, f - sh, dst - sh, (T)c2, 0, -9, -9);
+            else if (g_vv_vec) hipLaunchKernelGGL(k_vv_first2<T>, pl_grid_rows2(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, f - sh, dst - sh, (T)c2, 0, -9, -9, 0);
             else hipLaunchKernelGGL(k_vv_cheb_first<T>, pl_grid_rows(V.op.g), dim3(64, 4), 0, ctx->stream, V.op, f - sh, dst - sh, (T)c2,
                                     pl_row_iters(V.op.g));
         } else {
@@ -3161,7 +3218,7 @@ static int stokes_precond_t(pl_ctx* ctx, PlSolver* S, const double* rs, double* 
             const dim3 rows2 = pl_grid_rows2(g), bl(64, 4);
             hipLaunchKernelGGL(k_prec_stage1_v2<float>, rows2, bl, 0, ctx->stream, op, cls, rs, z, ff, v1f, c2, 1.0, 1.0);
             hipLaunchKernelGGL((k_vv_first2<double, float, float>), dim3(3 * rows2.x + 3 * rows2.y + 2), bl, 0, ctx->stream, L0->op, (const float*)ff, v1f, c2, 2,
-                               ctx->sop.anchor_i, ctx->sop.anchor_j);
+                               ctx->sop.anchor_i, ctx->sop.anchor_j, ctx->sop.wall_ps);
             static const bool r_double = getenv("PYLAMP_L0_MIXED") && atoi(getenv("PYLAMP_L0_MIXED")) == 2;      // experiment: residual kept in FP64
             if (r_double) {
                 hipLaunchKernelGGL((k_vv_sweep2<1, double, double, float, float>), rows2, bl, 0, ctx->stream, L0->op, (const float*)v1f, (const float*)nullptr,
@@ -3662,6 +3719,20 @@ int pl_stokes_solve_device(pl_ctx* ctx, const double* b_dev, bool use_x0, double
     PL_TRY(build_hierarchy(ctx, S));
     if (trace_t) tph[1] = now();
     const PlGeom& g = ctx->geom.d;
+    {   // wall stencils of the pressure block (prec_p_value): one rank, some cell at a wall at least 2 x longer along the wall than
+        // across (PYLAMP_SCHUR_WALL=0: never, =1: wherever the local aspect ratio reaches 2, whatever the walls look like)
+        const std::vector<double>& zc = ctx->geom.zc; const std::vector<double>& xc = ctx->geom.xc;
+        const int nz = ctx->nz, nx = ctx->nx;
+        double dzmin = 1e300, dzmax = 0.0, dxmin = 1e300, dxmax = 0.0;
+        for (int i = 0; i + 1 < nz; i++) { dzmin = std::min(dzmin, zc[i + 1] - zc[i]); dzmax = std::max(dzmax, zc[i + 1] - zc[i]); }
+        for (int j = 0; j + 1 < nx; j++) { dxmin = std::min(dxmin, xc[j + 1] - xc[j]); dxmax = std::max(dxmax, xc[j + 1] - xc[j]); }
+        const double wx = std::max(xc[1] - xc[0], xc[nx - 1] - xc[nx - 2]) / dzmin;        // widest aspect of a cell in the x-wall columns
+        const double wz = std::max(zc[1] - zc[0], zc[nz - 1] - zc[nz - 2]) / dxmin;        // ... of a cell in the z-wall rows
+        const char* e = getenv("PYLAMP_SCHUR_WALL");
+        const int knob = e ? atoi(e) : -1;
+        ctx->sop.wall_ps = (ctx->nranks == 1 && nz >= 9 && nx >= 9 && knob != 0 && (knob == 1 || wx >= 2.0 || wz >= 2.0)) ? 1 : 0;
+        (void)dzmax; (void)dxmax;
+    }
     PlStokesOp sop = ctx->sop;
     PlStokesOp sop_scaled = sop; sop_scaled.scaled = 1;
     S->napply = 0; S->nprec = 0;

@@ -18,6 +18,8 @@ def case(name):
     elif name == "flat16": nx = [1025, 65]; grid = [np.linspace(0, 1, 1025), np.linspace(0, 1, 65)]
     elif name == "iso": nx = [257, 257]; grid = [np.linspace(0, 1, 257), np.linspace(0, 1, 257)]
     elif name == "iso_isovisc": nx = [257, 257]; grid = [np.linspace(0, 1, 257), np.linspace(0, 1, 257)]
+    elif name == "tall_isovisc": nx = [129, 513]; grid = [np.linspace(0, 1, 129), np.linspace(0, 1, 513)]
+    elif name == "tall16_isovisc": nx = [65, 1025]; grid = [np.linspace(0, 1, 65), np.linspace(0, 1, 1025)]
     elif name == "flat_isovisc": nx = [513, 129]; grid = [np.linspace(0, 1, 513), np.linspace(0, 1, 129)]
     elif name == "flat16_isovisc": nx = [1025, 65]; grid = [np.linspace(0, 1, 1025), np.linspace(0, 1, 65)]
     elif name == "tall16": nx = [65, 1025]; grid = [np.linspace(0, 1, 65), np.linspace(0, 1, 1025)]
