@@ -483,3 +483,33 @@ def test_wall_stencil_of_the_pressure_block(oracle, nx):
         its[knob] = st["iterations"]
     print("wall stencil %s: %d iterations, diagonal block alone %d" % (nx, its["-1"], its["0"]))
     assert its["-1"] <= 0.75 * its["0"], its
+
+
+def test_graded_grid_takes_lines_and_wall_stencils_locally(oracle):
+    """A grid graded 20 x in z (129^2 nodes on a square: cells from 6 times wider than high at the top to 3 times higher than wide at
+    the bottom): the line relaxation and the wall stencils of the pressure block are chosen from the LOCAL cell shapes; the answer is
+    the oracle's direct solve either way, and the default needs fewer iterations than both switched off."""
+    from pylamp_amd import pylamp_stokes as S
+    n = 129
+    w = np.geomspace(1.0, 20.0, n - 1)
+    grid = [np.concatenate([[0.0], np.cumsum(w)]) / w.sum(), np.linspace(0, 1, n)]
+    Z, X = np.meshgrid(grid[0], grid[1], indexing="ij")
+    eta = 10 ** (1.0 * np.sin(3 * np.pi * X) * np.cos(2 * np.pi * Z))
+    rho = 1.0 + 0.1 * np.exp(-((Z - 0.4) ** 2 + (X - 0.55) ** 2) / 0.02)
+    nx = [n, n]; bc = [1, 1, 1, 1]
+    xo = oracle.stokes_solve(nx, grid, eta, eta, rho, bc)
+    its = {}
+    for name, env in (("default", {}), ("off", {"PYLAMP_MG_LINE": "0", "PYLAMP_SCHUR_WALL": "0"})):
+        os.environ.update(env)
+        try:
+            A, rhs = S.makeStokesMatrix(nx, grid, eta, eta, rho, bc)
+            x = S.solve(A, rhs)
+        finally:
+            for k in env:
+                del os.environ[k]
+        st = A.last_stats
+        ev, _ = _vel_err(S, x, xo, nx)
+        print("graded 129^2, %s: %s, velocity error %.2e" % (name, st, ev))
+        assert st["converged"] == 1 and ev < VEL_TOL, (name, ev, st)
+        its[name] = st["iterations"]
+    assert its["default"] < its["off"], its
